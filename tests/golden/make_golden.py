@@ -1,0 +1,354 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Runs only in the dev container (needs /root/reference, cython, gcc).  It
+cythonizes ultranest/mlfriends.pyx + stepfuncs.pyx into a throw-away directory
+OUTSIDE the repository (nothing of the reference -- source, generated C, .so or
+bytecode -- is written into the repo or travels to the GPU box), imports the
+package from there and records input/output vectors as small .npz fixtures.
+
+    python tests/golden/make_golden.py            # regenerate everything
+    python tests/golden/make_golden.py g1 g3      # only some groups
+
+Inputs are regenerated from seeds by tests/golden/inputs.py (RandomState, no
+LAPACK) so mostly OUTPUTS are stored.  Where a reference stage depends on
+BLAS/LAPACK (np.dot, eigh, inv, cov) the stage's OUTPUT matrices are stored and
+fed to the later stages, as SURVEY.md 8(c) prescribes.
+"""
+import glob
+import json
+import os
+import subprocess
+import sys
+import sysconfig
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import inputs  # noqa: E402
+
+REF = os.environ.get("ULTRANEST_REFERENCE", "/root/reference")
+
+
+def build_reference():
+    """Cythonize + compile the reference's two extension modules in a scratch dir."""
+    scratch = os.environ.get("ULTRANEST_REFBUILD") or os.path.join(tempfile.gettempdir(), "ultranest_refbuild")
+    pkg = os.path.join(scratch, "ultranest")
+    suffix = sysconfig.get_config_var("EXT_SUFFIX")
+    if not os.path.exists(os.path.join(pkg, "mlfriends" + suffix)):
+        os.makedirs(pkg, exist_ok=True)
+        for f in glob.glob(os.path.join(REF, "ultranest", "*.py")):
+            dst = os.path.join(pkg, os.path.basename(f))
+            if not os.path.lexists(dst):
+                os.symlink(f, dst)
+        inc = [np.get_include(), sysconfig.get_paths()["include"]]
+        for mod in ("mlfriends", "stepfuncs"):
+            c = os.path.join(pkg, mod + ".c")
+            subprocess.check_call(["cython", "-3", os.path.join(REF, "ultranest", mod + ".pyx"), "-o", c])
+            subprocess.check_call(["gcc", "-O3", "-shared", "-fPIC", "-w"] + ["-I" + i for i in inc]
+                                  + [c, "-o", os.path.join(pkg, mod + suffix)])
+    sys.path.insert(0, scratch)
+    import ultranest.mlfriends as ref
+    return ref
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("  wrote %-28s %7.1f KiB" % (os.path.basename(path), os.path.getsize(path) / 1024.))
+
+
+# ------------------------------------------------------------------ G1 ------
+
+def g1(ref):
+    """find_nearby / count_nearby (via sample_from_points is indirect, so the
+    count golden comes from find_nearby-consistent full scans below)."""
+    out = {}
+    for i, (name, n, d, p) in enumerate(inputs.FIND_NEARBY_CASES):
+        apts, bpts = inputs.find_nearby_inputs(100 + i, n, d, p)
+        r2 = inputs.median_nn_radius(apts, bpts)
+        for tag, rr in (("mid", r2), ("none", 1e-300), ("all", 1e300), ("big", 4 * r2)):
+            idx = np.empty(p, dtype=np.int64)
+            ref.find_nearby(apts, bpts, rr, idx)
+            out["%s_%s_idx" % (name, tag)] = idx
+            out["%s_%s_r2" % (name, tag)] = np.float64(rr)
+        hit = out[name + "_mid_idx"] >= 0
+        print("  G1 %-5s N=%d d=%d P=%d  r2=%.6g hit fraction %.3f" % (name, n, d, p, r2, hit.mean()))
+        assert out[name + "_none_idx"][p // 3] >= 0, "coincident point must hit at r2=1e-300"
+    save("g1_find_nearby", **out)
+
+
+# ------------------------------------------------------------------ G2 ------
+
+def g2(ref):
+    out = {}
+    for tag, n, d in (("a", 300, 4), ("b", 1000, 7)):
+        u = inputs.two_blobs(200, n, d)
+        # radius: a bit more than the typical nearest-neighbour distance
+        nn = []
+        for j in range(n):
+            d2 = ((u - u[j]) ** 2).sum(axis=1)
+            d2[j] = np.inf
+            nn.append(d2.min())
+        r2 = float(np.max(nn)) * 2.0
+        out[tag + "_r2"] = np.float64(r2)
+        out[tag + "_subtract"] = ref.subtract_nearby(u, r2)
+        nclusters, ids, overlapped = ref.update_clusters(u, u, r2)
+        out[tag + "_nclusters"] = np.int64(nclusters)
+        out[tag + "_ids"] = ids
+        out[tag + "_overlapped"] = overlapped
+        # re-clustering with previous ids as seeds and a smaller radius
+        nclusters2, ids2, overlapped2 = ref.update_clusters(u, u, r2 / 6, ids)
+        out[tag + "_r2b"] = np.float64(r2 / 6)
+        out[tag + "_nclusters2"] = np.int64(nclusters2)
+        out[tag + "_ids2"] = ids2
+        out[tag + "_mpd"] = np.float64(ref.compute_mean_pair_distance(u, ids))
+        ids_z = ids.copy()
+        ids_z[::5] = 0
+        out[tag + "_mpd_z"] = np.float64(ref.compute_mean_pair_distance(u, ids_z))
+        print("  G2 %s N=%d d=%d r2=%.4g nclusters=%d/%d mpd=%.6g" % (tag, n, d, r2, nclusters, nclusters2, out[tag + "_mpd"]))
+    # the reference's own fixture (tests/test_clustering.py:38-48)
+    pts = np.loadtxt(os.path.join(REF, "tests", "clusters2.txt"))
+    rad = float(np.loadtxt(os.path.join(REF, "tests", "clusters2_radius.txt")))
+    nclusters, ids, overlapped = ref.update_clusters(pts, pts, rad)
+    out["ref_clusters2_pts"] = pts
+    out["ref_clusters2_r2"] = np.float64(rad)
+    out["ref_clusters2_nclusters"] = np.int64(nclusters)
+    out["ref_clusters2_ids"] = ids
+    save("g2_clusters", **out)
+
+
+# ------------------------------------------------------------------ G3 ------
+
+def g3(ref):
+    """Bootstrapped radius/enlargement.  ScalingLayer() (mean 0, std 1) makes
+    unormed == u bit-exactly, so K4's inputs carry no LAPACK dependence."""
+    out = {}
+    for i, (name, n, d, B) in enumerate(inputs.BOOTSTRAP_CASES):
+        u = inputs.live_points(300 + i, n, d)
+        region = ref.MLFriends(u, ref.ScalingLayer())
+        assert np.array_equal(region.unormed, u)
+        rs = np.random.RandomState(900 + i)
+        rr, ff = [], []
+        t0 = time.time()
+        for b in range(B):
+            r, f = region.compute_enlargement(nbootstraps=1, minvol=0., rng=rs)
+            rr.append(r)
+            ff.append(f)
+        rr, ff = np.array(rr), np.array(ff)
+        assert np.array_equal(rr, rr.astype(np.float32).astype(np.float64)), "r2 must be float32-representable"
+        # aggregate call on a fresh stream with the same seed
+        r30, f30 = region.compute_enlargement(nbootstraps=B, minvol=0., rng=np.random.RandomState(900 + i))
+        assert r30 == rr.max() and f30 == ff.max()
+        out[name + "_r"] = rr
+        out[name + "_f"] = ff
+        # ellipsoid-only regions on the same stream
+        rob = ref.RobustEllipsoidRegion(u, ref.ScalingLayer())
+        r_rob, f_rob = rob.compute_enlargement(nbootstraps=B, rng=np.random.RandomState(900 + i))
+        out[name + "_rob"] = np.array([r_rob, f_rob])
+        sim = ref.SimpleRegion(u, ref.ScalingLayer())
+        r_sim, f_sim = sim.compute_enlargement(nbootstraps=B, rng=np.random.RandomState(900 + i))
+        out[name + "_sim"] = np.array([r_sim, f_sim])
+        wrap = ref.WrappingEllipsoid(u)
+        out[name + "_wrap"] = np.float64(wrap.compute_enlargement(nbootstraps=B, rng=np.random.RandomState(900 + i)))
+        print("  G3 %-5s N=%d d=%d B=%d  r2=%.9g f=%.9g  (%.1fs)" % (name, n, d, B, r30, f30, time.time() - t0))
+    # the reference's own fixture and recipe: tests/test_clustering.py:81-99
+    # (ScalingLayer.optimize, global-RNG compute_maxradiussq(30) for seeds 0-9,
+    #  then update_clusters(points, points, maxr); pinned 1e-10 < maxr < 6e-10, 14 < nclusters < 20)
+    pts = np.loadtxt(os.path.join(REF, "tests", "eggboxregion.txt"))
+    layer = ref.ScalingLayer()
+    layer.optimize(pts, pts)
+    maxrs, ncl = [], []
+    for seed in range(10):
+        np.random.seed(seed)
+        region = ref.MLFriends(pts, layer)
+        maxr = region.compute_maxradiussq(nbootstraps=30)
+        assert 1e-10 < maxr < 6e-10
+        nclusters, clusteridxs, _ = ref.update_clusters(pts, pts, maxr)
+        assert 14 < nclusters < 20
+        maxrs.append(maxr)
+        ncl.append(nclusters)
+    out["eggbox_pts"] = pts
+    out["eggbox_mean"] = layer.mean
+    out["eggbox_std"] = layer.std
+    out["eggbox_unormed"] = region.unormed
+    out["eggbox_maxr"] = np.array(maxrs)
+    out["eggbox_nclusters"] = np.array(ncl)
+    out["eggbox_ids_seed9"] = clusteridxs
+    print("  G3 eggboxregion: maxr", maxrs[:3], "nclusters", ncl)
+    save("g3_bootstrap", **out)
+
+
+# ------------------------------------------------------------- G4/G5/G6 ------
+
+def _region_with_layer(ref, u, layer_cls, seed, B=30):
+    layer = layer_cls()
+    layer.optimize(u, u)
+    region = ref.MLFriends(u, layer)
+    r, f = region.compute_enlargement(nbootstraps=B, rng=np.random.RandomState(seed))
+    region.maxradiussq, region.enlarge = r, f
+    region.create_ellipsoid(minvol=0.0)
+    return layer, region
+
+
+def g456(ref):
+    out = {}
+    for i, (name, n, d, p) in enumerate((("c1", 400, 5, 3000), ("c2", 2000, 20, 3000), ("c5", 4000, 50, 1536))):
+        u = inputs.live_points(400 + i, n, d)
+        layer, region = _region_with_layer(ref, u, ref.AffineLayer, 950 + i)
+        pts = inputs.proposal_mix(500 + i, u, p, shell_q=region.enlarge)
+        mask = region.inside(pts)
+        emask = region.inside_ellipsoid(pts)
+        # margins to both thresholds (numpy, float64): min relative distance
+        delta = pts - region.ellipsoid_center
+        q = np.einsum('ij,jk,ik->i', delta, region.ellipsoid_invcov, delta)
+        m_ell = np.abs(q - region.enlarge) / region.enlarge
+        t = layer.transform(pts[emask])
+        m_scan = np.full(emask.sum(), np.inf)
+        for lo in range(0, n, 256):
+            d2 = ((t[:, None, :] - region.unormed[None, lo:lo + 256, :]) ** 2).sum(axis=2)
+            m_scan = np.minimum(m_scan, (np.abs(d2 - region.maxradiussq) / region.maxradiussq).min(axis=1))
+        margin = min(m_ell.min(), m_scan.min())
+        assert margin > 1e-9, margin
+        # same region with an artificially tighter radius: many scan rejections
+        r2_full = region.maxradiussq
+        for frac in (0.7, 0.55, 0.4):
+            region.maxradiussq = r2_full * frac
+            mask_t = region.inside(pts)
+            m_t = np.full(emask.sum(), np.inf)
+            for lo in range(0, n, 256):
+                d2 = ((t[:, None, :] - region.unormed[None, lo:lo + 256, :]) ** 2).sum(axis=2)
+                m_t = np.minimum(m_t, (np.abs(d2 - region.maxradiussq) / region.maxradiussq).min(axis=1))
+            if 0.15 < mask_t[emask].mean() < 0.85:
+                break
+        assert m_t.min() > 1e-9, m_t.min()
+        margin = min(margin, m_t.min())
+        out[name + "_r2_tight"] = np.float64(region.maxradiussq)
+        out[name + "_mask_tight"] = np.packbits(mask_t)
+        print("     tight radius frac %.2f: scan accepts %.3f of ellipsoid-passing points" % (frac, mask_t[emask].mean()))
+        region.maxradiussq = r2_full
+        out[name + "_layer_ctr"] = layer.ctr
+        out[name + "_layer_T"] = layer.T
+        out[name + "_layer_invT"] = layer.invT
+        out[name + "_layer_logvolscale"] = np.float64(layer.logvolscale)
+        out[name + "_r2"] = np.float64(region.maxradiussq)
+        out[name + "_enlarge"] = np.float64(region.enlarge)
+        out[name + "_ell_center"] = region.ellipsoid_center
+        out[name + "_ell_cov"] = region.ellipsoid_cov
+        out[name + "_ell_invcov"] = region.ellipsoid_invcov
+        out[name + "_ell_axes"] = region.ellipsoid_axes
+        out[name + "_ell_axlens"] = region.ellipsoid_axlens
+        out[name + "_ell_inv_axes"] = region.ellipsoid_inv_axes
+        out[name + "_volume"] = np.float64(region.estimate_volume())
+        out[name + "_mask"] = np.packbits(mask)
+        out[name + "_emask"] = np.packbits(emask)
+        out[name + "_margin"] = np.float64(margin)
+        out[name + "_inside_live"] = np.bool_(region.inside(u).all())
+        print("  G4 %-3s N=%d d=%d P=%d  r2=%.6g enlarge=%.6g  ellipsoid pass %.3f  inside %.3f  margin %.2e" % (
+            name, n, d, p, region.maxradiussq, region.enlarge, emask.mean(), mask.mean(), margin))
+    # G5: metric-learning layers on clustered data = the reference's own
+    # eggboxregion.txt fixture (tests/test_clustering.py:81-99), two generations
+    # as the integrator iterates them (integrator.py:2068-2091)
+    u = np.loadtxt(os.path.join(REF, "tests", "eggboxregion.txt"))
+    out["g5_u"] = u
+    for lname, cls in (("affine", ref.AffineLayer), ("local", ref.LocalAffineLayer),
+                       ("gap", ref.MaxPrincipleGapAffineLayer), ("scaling", ref.ScalingLayer)):
+        layer = cls()
+        layer.optimize(u, u)
+        for gen in (1, 2):
+            region = ref.MLFriends(u, layer)
+            r, f = region.compute_enlargement(nbootstraps=30, rng=np.random.RandomState(77 + gen))
+            nxt = layer.create_new(u, r)
+            key = "g5_%s%d_" % (lname, gen)
+            out[key + "r_f"] = np.array([r, f])
+            out[key + "nclusters"] = np.int64(nxt.nclusters)
+            out[key + "ids"] = nxt.clusterids
+            out[key + "logvolscale"] = np.float64(nxt.logvolscale)
+            if lname == "scaling":
+                out[key + "mean"] = nxt.mean
+                out[key + "std"] = nxt.std
+            else:
+                out[key + "ctr"] = nxt.ctr
+                out[key + "cov"] = nxt.cov
+                out[key + "T"] = nxt.T
+            print("  G5 %-7s gen %d r2=%.6g nclusters=%d logvolscale=%.6f" % (lname, gen, r, nxt.nclusters, nxt.logvolscale))
+            layer = nxt
+    # wrapped dims round trip (tests/test_transforms.py:89-124 style)
+    rs = np.random.RandomState(8)
+    uw = np.column_stack([np.fmod(0.9 + 0.15 * rs.uniform(size=400), 1.0), 0.3 + 0.2 * rs.uniform(size=400)])
+    layer = ref.AffineLayer(wrapped_dims=[0])
+    layer.optimize(uw, uw)
+    out["g5_wrap_u"] = uw
+    out["g5_wrap_cuts"] = np.array(layer.wrap_cuts)
+    out["g5_wrap_t"] = layer.transform(uw)
+    out["g5_wrap_ctr"] = layer.ctr
+    out["g5_wrap_T"] = layer.T
+    save("g456_region", **out)
+
+
+# ------------------------------------------------------------------ G7 ------
+
+def g7(ref):
+    out = {}
+    n = 1024
+    centers5 = np.ones(5) * 0.5
+    x = inputs.likelihood_inputs(700, n, 5, 0.45, 0.55)
+    out["gauss5"] = -0.5 * (((x - centers5) / 0.01) ** 2).sum(axis=1) - 0.5 * np.log(2 * np.pi * 0.01 ** 2) * 5
+    ndim = 20
+    sigma = 0.1
+    width = max(0, 1 - 5 * sigma)
+    centers = (np.sin(np.arange(ndim) / 2.) * width + 1.) / 2.
+    x = inputs.likelihood_inputs(701, n, ndim, 0, 1)
+    out["gauss20_centers"] = centers
+    out["gauss20"] = -0.5 * (((x - centers) / sigma) ** 2).sum(axis=1) - 0.5 * np.log(2 * np.pi * sigma ** 2) * ndim
+    for d in (2, 10):
+        z = inputs.likelihood_inputs(702 + d, n, d, 0, 1) * 10 * np.pi
+        out["eggbox%d" % d] = (2. + (np.cos(z / 2.)).prod(axis=1)) ** 5
+        out["eggboxsq%d" % d] = np.cos(z).prod(axis=1) ** 2
+    for d in (2, 50):
+        theta = inputs.likelihood_inputs(720 + d, n, d, 0, 1) * 20 - 10
+        a, b = theta[:, :-1], theta[:, 1:]
+        out["rosenbrock%d" % d] = -2 * (100 * (b - a ** 2) ** 2 + (1 - a) ** 2).sum(axis=1)
+    save("g7_likelihoods", **out)
+
+
+# ------------------------------------------------------------------ G8 ------
+
+def g8(ref):
+    """End-to-end C1 plumbing run on the stock reference (5-d Gaussian, sigma
+    0.01, 400 live points, vectorized=True)."""
+    import ultranest
+    ndim = 5
+    centers = np.ones(ndim) * 0.5
+    sigma = 0.01
+
+    def loglike(theta):
+        return -0.5 * (((theta - centers) / sigma) ** 2).sum(axis=1) - 0.5 * np.log(2 * np.pi * sigma ** 2) * ndim
+
+    np.random.seed(1)
+    t0 = time.time()
+    sampler = ultranest.ReactiveNestedSampler(["p%d" % i for i in range(ndim)], loglike,
+                                              transform=lambda x: x, vectorized=True, log_dir=None)
+    res = sampler.run(min_num_live_points=400, viz_callback=None, show_status=False)
+    meta = dict(logz=res["logz"], logzerr=res["logzerr"], ncall=int(res["ncall"]), niter=int(res["niter"]),
+                seconds=time.time() - t0, ultranest=ultranest.__version__, numpy=np.__version__)
+    print("  G8", meta)
+    with open(os.path.join(HERE, "g8_c1_run.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+GROUPS = dict(g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8)
+
+if __name__ == "__main__":
+    want = sys.argv[1:] or list(GROUPS)
+    ref = build_reference()
+    meta = dict(numpy=np.__version__, reference="UltraNest 4.5.0 (/root/reference)",
+                generated=time.strftime("%Y-%m-%d"))
+    for g in want:
+        print(g)
+        GROUPS[g](ref)
+    with open(os.path.join(HERE, "META.json"), "w") as f:
+        json.dump(meta, f, indent=1)
