@@ -1,0 +1,160 @@
+/*
+ * mlfriends_hip.h -- C ABI of libmlfriends_hip.so: the MI355X (gfx950) implementation of the
+ * UltraNest MLFriends hot path.  This is the drop-in boundary: plain pointers and sizes, no
+ * torch / numpy types.  The Python host layer (ultranest_amd/_lib.py) binds exactly these
+ * symbols with ctypes, in the convention of the reference's own compiled-callback examples
+ * (reference languages/c/mylib.c:33 + languages/c/runc.py:8-28: C-contiguous float64 (n, d)
+ * arrays, sizes as size_t, caller-allocated outputs).
+ *
+ * Every entry point names the reference routine it replaces (paths relative to the UltraNest
+ * 4.5.0 tree).  All arrays are row-major float64 unless stated; index outputs are int64
+ * (reference mlfriends.pyx:25-26), masks are one byte per element (numpy bool).
+ *
+ * Return value: 0 = ok; < 0 = -(hipError_t) (message via mlf_last_error()); > 0 = domain
+ * condition (MLF_E_*).  Host-pointer entry points are synchronous: inputs are copied to the
+ * device, outputs are complete on return, no host pointer is retained.  *_dev entry points
+ * take DEVICE pointers plus a hipStream_t (passed as void*) and only enqueue work.
+ */
+#ifndef MLFRIENDS_HIP_H
+#define MLFRIENDS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLF_ABI_VERSION 1
+
+#define MLF_E_BADARG 1      /* null pointer, zero dimension, inconsistent sizes            */
+#define MLF_E_DIM 2         /* dimensionality above MLF_MAX_DIM                            */
+#define MLF_E_NODEVICE 3    /* no usable gfx950 device                                      */
+#define MLF_E_STATE 4       /* region handle used before mlf_region_set                     */
+
+#define MLF_MAX_DIM 128
+
+/* ---- library / device ---------------------------------------------------------------- */
+int mlf_abi_version(void);
+const char *mlf_last_error(void);
+int mlf_device_count(int *count);
+int mlf_set_device(int device);            /* device used by this process (default 0)      */
+int mlf_device_name(char *buf, size_t buflen);
+int mlf_synchronize(void);
+
+/* ---- K1: find_nearby -- ultranest/mlfriends.pyx:143-183 -----------------------------------
+ * out[j] = lowest i with sum_k (apts[i,k]-bpts[j,k])^2 <= radiussq (k ascending, no FMA),
+ * else -1. */
+int mlf_find_nearby(const double *apts, size_t na, const double *bpts, size_t nb, size_t d,
+                    double radiussq, int64_t *out);
+
+/* ---- K2: count_nearby -- ultranest/mlfriends.pyx:31-68 (cdef; used by sample_from_points :1088) */
+int mlf_count_nearby(const double *apts, size_t na, const double *bpts, size_t nb, size_t d,
+                     double radiussq, int64_t *out);
+
+/* ---- K3: subtract_nearby -- ultranest/mlfriends.pyx:73-138 ----------------------------------
+ * out[j,:] = pts[j,:] - mean of all pts[i,:] with dist2(i,j) <= radiussq (i ascending sum). */
+int mlf_subtract_nearby(const double *pts, size_t n, size_t d, double radiussq, double *out);
+
+/* ---- K4: compute_maxradiussq over bootstrap rounds -- mlfriends.pyx:188-224 called from
+ * MLFriends.compute_enlargement :1044-1054 and MLFriends.compute_maxradiussq :1004-1012.
+ * selected is (B, n) bytes (non-zero = selected).  maxd_out[b] = max over unselected j of the
+ * min over selected i of dist2(i,j), narrowed to binary32 and widened back exactly as the
+ * reference's `cdef float` return does.  skipped_out[b] = 1 when bootstrap b selects all or
+ * no points (reference :1048 `continue`); maxd_out[b] = 0 then.  skipped_out may be NULL. */
+int mlf_maxradiussq_bootstrap(const double *pts, size_t n, size_t d, const uint8_t *selected,
+                              size_t B, double *maxd_out, uint8_t *skipped_out);
+
+/* ---- K5: pair distances for compute_mean_pair_distance -- mlfriends.pyx:229-270 -------------
+ * dist2_out is the packed strict lower triangle: entry j*(j-1)/2 + i for i < j.  The host
+ * layer applies sqrt, the cluster mask and the reference's (j outer, i inner) running sum. */
+int mlf_pair_dist2_lower(const double *pts, size_t n, size_t d, double *dist2_out);
+
+/* ---- H3: _inside_ellipsoid -- mlfriends.pyx:882-912 -----------------------------------------
+ * mask[p] = einsum('ij,jk,ik->i', pts-ctr, invcov, pts-ctr)[p] <= sqradius, evaluated in
+ * numpy's c_einsum order (one accumulator, j outer / k inner, (d_j*A_jk)*d_k, no FMA).
+ * q_out (may be NULL) receives the quadratic form. */
+int mlf_inside_ellipsoid(const double *pts, size_t np, size_t d, const double *ctr,
+                         const double *invcov, double sqradius, uint8_t *mask, double *q_out);
+
+/* ---- T1: AffineLayer.transform -- mlfriends.pyx:737-743 (+ wrap :529-536) -------------------
+ * out = (wrap(pts) - ctr) . T, k-ascending FMA chain.  wrap_shift is NULL or d doubles:
+ * for a wrapped dimension the value (1 - cut), NaN for an unwrapped one. */
+int mlf_affine_transform(const double *pts, size_t np, size_t d, const double *ctr,
+                         const double *T, const double *wrap_shift, double *out);
+
+/* ---- bootstrap ellipsoid statistics -- mlfriends.pyx:1056-1066, :1426-1436, :1586-1594 ------
+ * For each bootstrap b: mean (d) and sample covariance (d,d; ddof=1, NOT yet scaled by d+2) of
+ * the selected rows of u.  Two-pass (centred) accumulation. */
+int mlf_bootstrap_moments(const double *u, size_t n, size_t d, const uint8_t *selected, size_t B,
+                          double *mean_out /* B*d */, double *cov_out /* B*d*d */);
+/* f_out[b] = max over UNselected rows of (u-ctr_b)^T invcov_b (u-ctr_b). */
+int mlf_bootstrap_quadform_max(const double *u, size_t n, size_t d, const uint8_t *selected,
+                               size_t B, const double *ctr /* B*d */,
+                               const double *invcov /* B*d*d */, double *f_out);
+
+/* ---- device-resident region: MLFriends.inside -- mlfriends.pyx:1186-1211 --------------------
+ * Holds the whitened live points (both layouts), the layer (ctr, T, wraps), the wrapping
+ * ellipsoid and the two thresholds.  mlf_region_inside = H3 -> T1 -> K1 on the device with the
+ * neighbour scan gated on the ellipsoid result (reference :1202-1209). */
+typedef struct mlf_region mlf_region;
+int mlf_region_create(mlf_region **out);
+int mlf_region_destroy(mlf_region *r);
+/* layer_kind: 0 = AffineLayer family (ctr[d], T[d,d]); 1 = ScalingLayer (ctr = mean[d],
+ * T = std[d]).  use_scan = 0 gives RobustEllipsoidRegion.inside (:1374-1390, H3 only). */
+int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int layer_kind,
+                   const double *layer_ctr, const double *layer_T, const double *wrap_shift,
+                   const double *ell_center, const double *ell_invcov, double enlarge,
+                   double radiussq, int use_scan);
+/* in-place live point replacement, integrator.py:2753-2754 */
+int mlf_region_update_point(mlf_region *r, size_t row, const double *unormed_row);
+int mlf_region_set_thresholds(mlf_region *r, double enlarge, double radiussq);
+int mlf_region_set_ellipsoid_center(mlf_region *r, const double *ell_center);
+int mlf_region_inside(mlf_region *r, const double *pts, size_t np, uint8_t *mask);
+/* device pointers; enqueues on `stream`; d_mask is np bytes */
+int mlf_region_inside_dev(mlf_region *r, const double *d_pts, size_t np, uint8_t *d_mask,
+                          void *stream);
+/* scan only (K1 against the resident live points), device pointers */
+int mlf_region_find_nearby_dev(mlf_region *r, const double *d_tpts, size_t np, int64_t *d_idx,
+                               void *stream);
+
+/* ---- vectorized likelihood batch (V1; signature of languages/c/mylib.c:33) -------------------
+ * params is (n, d) row-major; like receives n values. */
+int mlf_loglike_gauss(const double *params, size_t d, size_t n, const double *centers,
+                      double sigma, double *like);          /* docs/gauss.py:25-27          */
+int mlf_loglike_eggbox(const double *params, size_t d, size_t n, double *like);
+                                                            /* examples/testeggbox.py:9-11  */
+int mlf_loglike_eggbox2(const double *params, size_t d, size_t n, double *like);
+                                                            /* test_PopSliceSampler.py:69-71 */
+int mlf_loglike_rosenbrock(const double *params, size_t d, size_t n, double *like);
+                                                            /* examples/testrosenbrock.py:10-13 */
+/* kind: 0 gauss (aux = centers[d] then sigma), 1 eggbox, 2 eggbox2, 3 rosenbrock; device ptrs */
+int mlf_loglike_dev(int kind, const double *d_params, size_t d, size_t n, const double *d_aux,
+                    double sigma, double *d_like, void *stream);
+
+/* H3 -> T1 -> K1 with the index kept: d_idx[p] = first live point within radiussq (>= 0),
+ * -1 = inside the ellipsoid but no neighbour, -2 = outside the wrapping ellipsoid. */
+int mlf_region_first_index_dev(mlf_region *r, const double *d_pts, size_t np, int64_t *d_idx,
+                               void *stream);
+
+/* ---- bench / profiling helpers ---------------------------------------------------------- */
+/* Runs the neighbour-scan kernel `reps` times on device data and returns the mean kernel time
+ * in milliseconds measured with hipEvents on `stream`. */
+int mlf_region_time_inside_dev(mlf_region *r, const double *d_pts, size_t np, uint8_t *d_mask,
+                               void *stream, int reps, float *ms_total, float *ms_scan);
+
+/* mlf_region_inside_dev with hipEvents recorded around the per-proposal stage and the
+ * neighbour scan, on `stream`, without synchronising.  mlf_region_timing_collect waits for the
+ * recorded events and returns the number of timed calls and the summed milliseconds of each
+ * stage since the last collect. */
+int mlf_region_inside_dev_timed(mlf_region *r, const double *d_pts, size_t np, uint8_t *d_mask,
+                                void *stream);
+int mlf_region_timing_collect(mlf_region *r, int *ncalls, double *ms_prep, double *ms_scan);
+/* Measured issue rate of independent v_add_f64/v_mul_f64 (the non-fused FP64 vector rate that
+ * bounds the distance kernels), in Tera-instructions*lanes per second (= TFLOP/s, 1 flop each). */
+int mlf_bench_fp64_valu(double *tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLFRIENDS_HIP_H */

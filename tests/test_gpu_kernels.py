@@ -1,0 +1,253 @@
+"""GPU parity tests: the HIP kernels, called through the C ABI (ctypes), against
+  (a) the golden vectors produced by the real reference (tests/golden/*.npz), and
+  (b) the CPU oracle on seeded inputs at sizes it finishes in seconds.
+Bit-exact for indices, counts, masks, radii; stated tolerances elsewhere.  Run with `-m gpu`."""
+import numpy as np
+import pytest
+
+import inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from ultranest_amd import _lib, kernels
+    assert _lib.device_count() >= 1, "no MI355X visible"
+    print("device:", _lib.device_name())
+    return kernels
+
+
+def _find(K, apts, bpts, r2):
+    out = np.empty(len(bpts), dtype=np.int64)
+    K.find_nearby(apts, bpts, r2, out)
+    return out
+
+
+# ------------------------------------------------------------------ K1 / K2 ------------------
+@pytest.mark.parametrize("case", range(len(inputs.FIND_NEARBY_CASES)))
+def test_find_nearby_golden(case, golden, K):
+    g = golden("g1_find_nearby")
+    name, n, d, p = inputs.FIND_NEARBY_CASES[case]
+    apts, bpts = inputs.find_nearby_inputs(100 + case, n, d, p)
+    for tag in ("mid", "none", "all", "big"):
+        r2 = float(g["%s_%s_r2" % (name, tag)])
+        assert np.array_equal(_find(K, apts, bpts, r2), g["%s_%s_idx" % (name, tag)]), (name, tag)
+
+
+@pytest.mark.parametrize("n,d,p", [(1, 1, 1), (63, 2, 65), (64, 7, 64), (65, 9, 1), (1000, 13, 777),
+                                   (130, 64, 50), (200, 70, 33), (90, 128, 40)])
+def test_find_and_count_vs_oracle(n, d, p, K, oracle):
+    rs = np.random.RandomState(n * 1000 + d)
+    apts = rs.normal(size=(n, d))
+    bpts = rs.normal(size=(p, d)) * 0.7
+    bpts[0] = apts[n - 1]
+    r2 = float(np.median(((bpts[:, None, :] - apts[None, :50, :]) ** 2).sum(axis=2).min(axis=1)))
+    for rr in (r2, 0.0, 1e300):
+        assert np.array_equal(_find(K, apts, bpts, rr), oracle.find_nearby(apts, bpts, rr)), rr
+        cnt = np.empty(p, dtype=np.int64)
+        K.count_nearby(apts, bpts, rr, cnt)
+        assert np.array_equal(cnt, oracle.count_nearby(apts, bpts, rr)), rr
+
+
+def test_find_nearby_edge_cases(K):
+    out = np.empty(0, dtype=np.int64)
+    K.find_nearby(np.zeros((5, 3)), np.zeros((0, 3)), 1.0, out)          # no queries
+    out = np.empty(4, dtype=np.int64)
+    K.find_nearby(np.zeros((0, 3)), np.zeros((4, 3)), 1.0, out)          # no live points
+    assert (out == -1).all()
+    with pytest.raises(ValueError):
+        K.find_nearby(np.zeros((5, 200)), np.zeros((4, 200)), 1.0, out)  # d > MLF_MAX_DIM, loud
+    # non-contiguous inputs are accepted like the reference's strided buffers
+    rs = np.random.RandomState(5)
+    a = rs.normal(size=(40, 6))[:, ::2]
+    b = rs.normal(size=(10, 6))[:, ::2]
+    K.find_nearby(a, b, 2.0, out := np.empty(10, dtype=np.int64))
+    ref = np.array([next((i for i in range(40) if ((a[i] - b[j]) ** 2).sum() <= 2.0), -1) for j in range(10)])
+    assert np.array_equal(out, ref)
+
+
+# ------------------------------------------------------------------ K3 / K5 / H1 --------------
+@pytest.mark.parametrize("tag,n,d", [("a", 300, 4), ("b", 1000, 7)])
+def test_subtract_nearby_and_pairdist_golden(tag, n, d, golden, K):
+    g = golden("g2_clusters")
+    u = inputs.two_blobs(200, n, d)
+    assert np.array_equal(K.subtract_nearby(u, float(g[tag + "_r2"])), g[tag + "_subtract"])
+    assert K.compute_mean_pair_distance(u, g[tag + "_ids"]) == float(g[tag + "_mpd"])
+    ids_z = g[tag + "_ids"].copy()
+    ids_z[::5] = 0
+    assert K.compute_mean_pair_distance(u, ids_z) == float(g[tag + "_mpd_z"])
+
+
+def test_subtract_nearby_vs_oracle_dense(K, oracle):
+    rs = np.random.RandomState(3)
+    u = rs.uniform(size=(333, 11))
+    for r2 in (0.0, 0.9, 1e300):     # self only / some / everybody is a neighbour
+        assert np.array_equal(K.subtract_nearby(u, r2), oracle.subtract_nearby(u, r2)), r2
+
+
+# ------------------------------------------------------------------ K4 ------------------------
+@pytest.mark.parametrize("case", range(len(inputs.BOOTSTRAP_CASES)))
+def test_bootstrap_radius_golden(case, golden, K, oracle):
+    g = golden("g3_bootstrap")
+    name, n, d, B = inputs.BOOTSTRAP_CASES[case]
+    u = inputs.live_points(300 + case, n, d)
+    masks = oracle.draw_bootstrap_masks(np.random.RandomState(900 + case), n, B)
+    r, skipped = K.maxradiussq_bootstrap(u, masks)
+    assert not skipped.any()
+    assert np.array_equal(r, g[name + "_r"])
+
+
+def test_bootstrap_radius_degenerate_masks(K, oracle):
+    u = inputs.live_points(1, 100, 3)
+    masks = np.zeros((3, 100), dtype=bool)
+    masks[0] = True                  # all selected -> skipped (reference :1048)
+    masks[2, ::2] = True             # row 1: none selected -> skipped
+    r, skipped = K.maxradiussq_bootstrap(u, masks)
+    ro, so = oracle.maxradiussq_bootstrap(u, masks)
+    assert list(skipped) == [True, True, False] == list(so)
+    assert np.array_equal(r, ro)
+
+
+def test_bootstrap_eggboxregion_reference_recipe(golden, K, oracle):
+    g = golden("g3_bootstrap")
+    pts = g["eggbox_pts"]
+    unormed = g["eggbox_unormed"]
+    for seed in range(10):
+        masks = oracle.draw_bootstrap_masks(np.random.RandomState(seed), len(pts), 30)
+        r, _ = K.maxradiussq_bootstrap(unormed, masks)
+        assert r.max() == g["eggbox_maxr"][seed]
+        assert 1e-10 < r.max() < 6e-10      # the reference test's own pin
+
+
+# ------------------------------------------------------------------ H3 / T1 / R3 --------------
+@pytest.mark.parametrize("name,n,d,p,case", [("c1", 400, 5, 3000, 0), ("c2", 2000, 20, 3000, 1), ("c5", 4000, 50, 1536, 2)])
+def test_region_inside_golden(name, n, d, p, case, golden, K, oracle):
+    g = golden("g456_region")
+    u = inputs.live_points(400 + case, n, d)
+    pts = inputs.proposal_mix(500 + case, u, p, shell_q=float(g[name + "_enlarge"]))
+    ctr, T = g[name + "_layer_ctr"], g[name + "_layer_T"]
+    ell_c, ell_a, enlarge = g[name + "_ell_center"], g[name + "_ell_invcov"], float(g[name + "_enlarge"])
+    # H3: bit-exact with the oracle (= numpy's einsum order), mask equal to the reference's
+    emask, q = K.inside_ellipsoid(pts, ell_c, ell_a, enlarge, return_q=True)
+    emask_o, q_o = oracle.inside_ellipsoid(pts, ell_c, ell_a, enlarge, return_q=True)
+    assert np.array_equal(q, q_o)
+    assert np.array_equal(emask, np.unpackbits(g[name + "_emask"])[:p].astype(bool))
+    # T1: FMA chain == oracle restatement bit for bit; within 1e-13 of numpy's BLAS
+    t = K.affine_transform(pts, ctr, T)
+    assert np.array_equal(t, oracle.affine_transform(pts, ctr, T))
+    np.testing.assert_allclose(t, np.dot(pts - ctr, T), rtol=0, atol=1e-12)
+    # R3: device-resident region, whole pipeline
+    unormed = np.dot(u - ctr, T)
+    reg = K.DeviceRegion()
+    for r2key, mkey in (("_r2", "_mask"), ("_r2_tight", "_mask_tight")):
+        reg.set(unormed, 0, ctr, T, None, ell_c, ell_a, enlarge, float(g[name + r2key]))
+        mask = reg.inside(pts)
+        assert np.array_equal(mask, np.unpackbits(g[name + mkey])[:p].astype(bool)), (name, mkey)
+    # live points are inside their own region (reference integrator.py:2102)
+    reg.set(unormed, 0, ctr, T, None, ell_c, ell_a, enlarge, float(g[name + "_r2"]))
+    assert reg.inside(u).all() == bool(g[name + "_inside_live"])
+    # in-place live point replacement keeps device state in sync (integrator.py:2753)
+    t_new = K.affine_transform(pts[:1], ctr, T)[0]
+    reg.update_point(3, t_new)
+    un2 = unormed.copy()
+    un2[3] = t_new
+    ref = oracle.region_inside(pts, un2, ctr, T, ell_c, ell_a, enlarge, float(g[name + "_r2_tight"]))
+    reg.set_thresholds(enlarge, float(g[name + "_r2_tight"]))
+    got = reg.inside(pts)
+    assert np.array_equal(got, ref)
+    reg.close()
+
+
+def test_region_ellipsoid_only_and_scaling_layer(K, oracle):
+    rs = np.random.RandomState(11)
+    n, d, p = 500, 6, 2000
+    u = inputs.live_points(77, n, d)
+    mean, std = u.mean(axis=0), u.std(axis=0)
+    unormed = (u - mean) / std
+    ctr, cov = oracle.bounding_ellipsoid(u)
+    inv = np.linalg.inv(cov)
+    pts = inputs.proposal_mix(78, u, p, shell_q=1.5)
+    reg = K.DeviceRegion()
+    reg.set(None, 0, None, None, None, ctr, inv, 1.5, 1e300, use_scan=False)   # RobustEllipsoidRegion
+    assert np.array_equal(reg.inside(pts), oracle.inside_ellipsoid(pts, ctr, inv, 1.5))
+    reg.set(unormed, 1, mean, std, None, ctr, inv, 1.5, 0.8)                    # ScalingLayer
+    emask = oracle.inside_ellipsoid(pts, ctr, inv, 1.5)
+    idx = oracle.find_nearby(unormed, (pts - mean) / std, 0.8)
+    assert np.array_equal(reg.inside(pts), emask & (idx >= 0))
+    reg.close()
+
+
+def test_affine_transform_wrapped_dims(golden, K):
+    g = golden("g456_region")
+    uw = g["g5_wrap_u"]
+    shift = np.array([1 - g["g5_wrap_cuts"][0], np.nan])
+    t = K.affine_transform(uw, g["g5_wrap_ctr"], g["g5_wrap_T"], wrap_shift=shift)
+    np.testing.assert_allclose(t, g["g5_wrap_t"], rtol=0, atol=1e-12)
+
+
+def test_bootstrap_enlargement_f(golden, K, oracle):
+    g = golden("g3_bootstrap")
+    name, n, d, B = inputs.BOOTSTRAP_CASES[1]
+    u = inputs.live_points(301, n, d)
+    masks = oracle.draw_bootstrap_masks(np.random.RandomState(901), n, B)
+    mean, cov = K.bootstrap_moments(u, masks)
+    ctrs, invs = [], []
+    for b in range(B):
+        c_np, cov_np = oracle.bounding_ellipsoid(u[masks[b]])
+        np.testing.assert_allclose(mean[b], c_np, rtol=1e-13)
+        np.testing.assert_allclose(cov[b] * (d + 2), cov_np, rtol=1e-9, atol=1e-18)
+        ctrs.append(c_np)
+        invs.append(np.linalg.inv(cov_np))
+    f = K.bootstrap_quadform_max(u, masks, np.array(ctrs), np.array(invs))
+    np.testing.assert_allclose(f, g[name + "_f"], rtol=1e-10)
+
+
+# ------------------------------------------------------------------ likelihoods ---------------
+def test_likelihoods_golden(golden):
+    from ultranest_amd import likelihoods as L
+    g = golden("g7_likelihoods")
+    n = 1024
+    x = inputs.likelihood_inputs(700, n, 5, 0.45, 0.55)
+    np.testing.assert_allclose(L.GaussLikelihood(0.5, 0.01, 5)(x), g["gauss5"], rtol=1e-12)
+    x = inputs.likelihood_inputs(701, n, 20, 0, 1)
+    np.testing.assert_allclose(L.GaussLikelihood(g["gauss20_centers"], 0.1, 20)(x), g["gauss20"], rtol=1e-12)
+    for d in (2, 10):
+        z = inputs.likelihood_inputs(702 + d, n, d, 0, 1) * 10 * np.pi
+        np.testing.assert_allclose(L.eggbox_loglike(z), g["eggbox%d" % d], rtol=1e-12)
+        np.testing.assert_allclose(L.eggbox2_loglike(z), g["eggboxsq%d" % d], rtol=1e-12, atol=1e-300)
+    for d in (2, 50):
+        theta = inputs.likelihood_inputs(720 + d, n, d, 0, 1) * 20 - 10
+        np.testing.assert_allclose(L.rosenbrock_loglike(theta), g["rosenbrock%d" % d], rtol=1e-12)
+
+
+# ------------------------------------------------------------------ full-size properties ------
+def test_full_size_properties_c5(K):
+    """BASELINE full size (N=4000, d=50, P=1e5 here x10 in bench): size-independent checks --
+    live points find themselves at index i with r2=0, permuting queries permutes results,
+    a superset radius never loses hits, count>0 <=> find>=0."""
+    rs = np.random.RandomState(2024)
+    n, d, p = 4000, 50, 100000
+    a = rs.normal(size=(n, d))
+    out = _find(K, a, a, 0.0)
+    assert np.array_equal(out, np.arange(n))
+    b = a[rs.randint(n, size=p)] + 0.55 * rs.normal(size=(p, d))
+    r2 = 16.0
+    idx = _find(K, a, b, r2)
+    frac = (idx >= 0).mean()
+    assert 0.02 < frac < 0.98, frac
+    perm = rs.permutation(p)
+    assert np.array_equal(_find(K, a, b[perm], r2), idx[perm])
+    idx_big = _find(K, a, b, r2 * 1.5)
+    assert ((idx_big >= 0) >= (idx >= 0)).all() and (idx_big[idx >= 0] <= idx[idx >= 0]).all()
+    cnt = np.empty(p, dtype=np.int64)
+    K.count_nearby(a, b, r2, cnt)
+    assert np.array_equal(cnt > 0, idx >= 0)
+    # spot-check 64 hits and 64 misses exactly
+    hit = np.flatnonzero(idx >= 0)[:64]
+    for j in hit:
+        acc = np.zeros(n)
+        for k in range(d):
+            diff = a[:, k] - b[j, k]
+            acc = acc + diff * diff
+        assert np.flatnonzero(acc <= r2)[0] == idx[j]

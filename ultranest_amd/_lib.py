@@ -1,0 +1,121 @@
+"""ctypes binding of libmlfriends_hip.so (C ABI: include/mlfriends_hip.h).
+
+The library is the ONLY compute backend of this package.  If it is missing, or if no MI355X is
+visible when a kernel is called, an exception is raised -- there is no CPU fallback.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmlfriends_hip.so")
+
+ABI_VERSION = 1
+
+_c_double_p = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_dbl = ctypes.c_double
+_int = ctypes.c_int
+_vp = ctypes.c_void_p
+
+# symbol -> argtypes; this table is what tests/test_abi.py checks against include/mlfriends_hip.h
+SIGNATURES = {
+    "mlf_abi_version": [],
+    "mlf_last_error": [],
+    "mlf_device_count": [_vp],
+    "mlf_set_device": [_int],
+    "mlf_device_name": [_vp, _sz],
+    "mlf_synchronize": [],
+    "mlf_find_nearby": [_vp, _sz, _vp, _sz, _sz, _dbl, _vp],
+    "mlf_count_nearby": [_vp, _sz, _vp, _sz, _sz, _dbl, _vp],
+    "mlf_subtract_nearby": [_vp, _sz, _sz, _dbl, _vp],
+    "mlf_maxradiussq_bootstrap": [_vp, _sz, _sz, _vp, _sz, _vp, _vp],
+    "mlf_pair_dist2_lower": [_vp, _sz, _sz, _vp],
+    "mlf_inside_ellipsoid": [_vp, _sz, _sz, _vp, _vp, _dbl, _vp, _vp],
+    "mlf_affine_transform": [_vp, _sz, _sz, _vp, _vp, _vp, _vp],
+    "mlf_bootstrap_moments": [_vp, _sz, _sz, _vp, _sz, _vp, _vp],
+    "mlf_bootstrap_quadform_max": [_vp, _sz, _sz, _vp, _sz, _vp, _vp, _vp],
+    "mlf_region_create": [_vp],
+    "mlf_region_destroy": [_vp],
+    "mlf_region_set": [_vp, _vp, _sz, _sz, _int, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int],
+    "mlf_region_update_point": [_vp, _sz, _vp],
+    "mlf_region_set_thresholds": [_vp, _dbl, _dbl],
+    "mlf_region_set_ellipsoid_center": [_vp, _vp],
+    "mlf_region_inside": [_vp, _vp, _sz, _vp],
+    "mlf_region_inside_dev": [_vp, _vp, _sz, _vp, _vp],
+    "mlf_region_find_nearby_dev": [_vp, _vp, _sz, _vp, _vp],
+    "mlf_loglike_gauss": [_vp, _sz, _sz, _vp, _dbl, _vp],
+    "mlf_loglike_eggbox": [_vp, _sz, _sz, _vp],
+    "mlf_loglike_eggbox2": [_vp, _sz, _sz, _vp],
+    "mlf_loglike_rosenbrock": [_vp, _sz, _sz, _vp],
+    "mlf_loglike_dev": [_int, _vp, _sz, _sz, _vp, _dbl, _vp, _vp],
+    "mlf_region_time_inside_dev": [_vp, _vp, _sz, _vp, _vp, _int, _vp, _vp],
+    "mlf_region_first_index_dev": [_vp, _vp, _sz, _vp, _vp],
+    "mlf_region_inside_dev_timed": [_vp, _vp, _sz, _vp, _vp],
+    "mlf_region_timing_collect": [_vp, _vp, _vp, _vp],
+    "mlf_bench_fp64_valu": [_vp],
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    """The HIP library is missing or a HIP call failed (never silently replaced by CPU code)."""
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Loading needs no GPU; calling kernels does."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                "%s not found: build it with `python ultranest_amd/csrc/build.py` "
+                "(ultranest_amd has no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if a symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_char_p if name == "mlf_last_error" else ctypes.c_int
+        if L.mlf_abi_version() != ABI_VERSION:
+            raise HipLibraryError("libmlfriends_hip.so ABI %d != expected %d" % (L.mlf_abi_version(), ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    """Map a status code to an exception (0 = ok)."""
+    if rc == 0:
+        return
+    msg = lib().mlf_last_error()
+    msg = msg.decode() if msg else ""
+    if rc < 0:
+        raise HipLibraryError("HIP failure (%d): %s" % (rc, msg))
+    if rc == 3:
+        raise HipLibraryError(msg or "no HIP device")
+    raise ValueError("mlfriends_hip: %s (code %d)" % (msg, rc))
+
+
+def f64(a):
+    """C-contiguous float64 view/copy (the reference accepts arbitrary strides; the ABI does not)."""
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(lib().mlf_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def device_name():
+    buf = ctypes.create_string_buffer(256)
+    check(lib().mlf_device_name(buf, 256))
+    return buf.value.decode()
+
+
+def set_device(i):
+    check(lib().mlf_set_device(int(i)))

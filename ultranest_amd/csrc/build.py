@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Build ultranest_amd/libmlfriends_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python ultranest_amd/csrc/build.py [--force]
+
+-ffp-contract=off is part of the arithmetic contract (no FMA may be formed in the distance
+accumulation; the reference's x86-64 build has none).  The library is built IN-TREE so that it
+travels to the GPU box with the repository snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, "libmlfriends_hip.so")
+OBJ = os.path.join(HERE, "build")
+SOURCES = ["mlf_scan.hip", "mlf_boot.hip", "mlf_prep.hip", "mlf_misc.hip", "mlf_api.hip"]
+HEADERS = ["mlf_common.hpp", "mlf_misc.hpp", os.path.join("..", "..", "include", "mlfriends_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(HERE, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(OUT, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

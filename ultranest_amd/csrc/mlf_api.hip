@@ -1,0 +1,823 @@
+// mlf_api.hip -- the C ABI of libmlfriends_hip.so (include/mlfriends_hip.h): argument checks,
+// device buffers, host<->device staging and kernel sequencing.  No numerics live here.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mlfriends_hip.h"
+#include "mlf_misc.hpp"
+
+namespace {
+
+using namespace mlf;
+
+thread_local std::string g_err;
+
+int fail_hip(hipError_t e, const char *what, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "HIP error %d (%s) at mlf_api.hip:%d: %s", (int)e, hipGetErrorString(e),
+           line, what);
+  g_err = buf;
+  return -(int)e;
+}
+
+int fail_arg(int code, const char *msg) {
+  g_err = msg;
+  return code;
+}
+
+#define CK(x)                                                   \
+  do {                                                          \
+    hipError_t e_ = (x);                                        \
+    if (e_ != hipSuccess) return fail_hip(e_, #x, __LINE__);    \
+  } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) {
+      hipError_t e = hipFree(p);
+      p = nullptr;
+      cap = 0;
+      if (e != hipSuccess) return e;
+    }
+    const size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) return e;
+    cap = want;
+    return hipSuccess;
+  }
+  template <class T>
+  T *as() const { return static_cast<T *>(p); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct Ctx {
+  bool ready = false;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // scratch used by the stateless host-pointer entry points
+  DevBuf src, refT, refR, q, out, flags, sel, selbytes, M, small0, small1, small2, small3, mask, tq;
+};
+
+Ctx g_ctx;
+
+int ensure_ctx() {
+  if (g_ctx.ready) return 0;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_err = "libmlfriends_hip: no HIP device visible (this library has no CPU fallback)";
+    return MLF_E_NODEVICE;
+  }
+  CK(hipSetDevice(g_ctx.device));
+  CK(hipStreamCreate(&g_ctx.stream));
+  g_ctx.ready = true;
+  return 0;
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// d x d row-major -> d rows of dp doubles, zero padded; optional transpose
+std::vector<double> pad_matrix(const double *m, int d, int dp, bool transpose) {
+  std::vector<double> o((size_t)d * dp, 0.0);
+  for (int r = 0; r < d; ++r)
+    for (int c = 0; c < d; ++c) o[(size_t)r * dp + c] = transpose ? m[(size_t)c * d + r] : m[(size_t)r * d + c];
+  return o;
+}
+
+std::vector<double> pad_vector(const double *v, int d, int dp, double fill = 0.0) {
+  std::vector<double> o((size_t)dp, fill);
+  for (int k = 0; k < d; ++k) o[k] = v[k];
+  return o;
+}
+
+int upload(DevBuf &b, const void *host, size_t bytes, hipStream_t s) {
+  CK(b.reserve(bytes ? bytes : 1));
+  if (bytes) CK(hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, s));
+  return 0;
+}
+
+int check_dims(size_t d) {
+  if (d == 0) return fail_arg(MLF_E_BADARG, "dimensionality must be positive");
+  if (d > MLF_MAX_DIM) return fail_arg(MLF_E_DIM, "dimensionality above MLF_MAX_DIM (128) is not supported");
+  return 0;
+}
+
+// Live points (row-major, host) -> device layouts in the context scratch.
+int stage_live_points(const double *pts, size_t n, size_t d, int dp, int npad, bool want_rows) {
+  Ctx &c = g_ctx;
+  int rc = upload(c.src, pts, n * d * sizeof(double), c.stream);
+  if (rc) return rc;
+  CK(c.refT.reserve((size_t)npad * dp * sizeof(double)));
+  CK(c.refR.reserve((size_t)npad * dp * sizeof(double)));
+  (void)want_rows;
+  launch_build_layouts(c.src.as<double>(), (int)n, (int)d, dp, npad, c.refT.as<double>(),
+                       c.refR.as<double>(), c.stream);
+  CK(hipGetLastError());
+  return 0;
+}
+
+int scan_host(const double *apts, size_t na, const double *bpts, size_t nb, size_t d, double r2,
+              int mode, int64_t *out) {
+  if (int rc = check_dims(d)) return rc;
+  if (nb == 0) return 0;
+  if (!bpts || !out || (na && !apts)) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (na == 0) {  // the reference loops over zero live points
+    for (size_t j = 0; j < nb; ++j) out[j] = mode == SCAN_FIRST ? -1 : 0;
+    return 0;
+  }
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  const int dp = pick_dp((int)d);
+  const int npad = round_up((int)na, kWave);
+  if (int rc = stage_live_points(apts, na, d, dp, npad, false)) return rc;
+  if (int rc = upload(c.q, bpts, nb * d * sizeof(double), c.stream)) return rc;
+  CK(c.out.reserve(nb * sizeof(long long)));
+  ScanArgs a{};
+  a.refT = c.refT.as<double>();
+  a.n = (int)na;
+  a.npad = npad;
+  a.ntiles = npad / kWave;
+  a.q = c.q.as<double>();
+  a.ldq = (long long)d;
+  a.nq = (long long)nb;
+  a.d = (int)d;
+  a.r2 = r2;
+  a.mode = mode;
+  a.out_idx = c.out.as<long long>();
+  CK(launch_scan(dp, a, c.stream));
+  CK(hipMemcpyAsync(out, c.out.p, nb * sizeof(long long), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+int prep_consts(DevBuf &ctr_b, DevBuf &mat_b, const double *ctr, const double *mat, int d, int dp,
+                bool transpose, hipStream_t s) {
+  std::vector<double> pc = pad_vector(ctr, d, dp);
+  std::vector<double> pm = pad_matrix(mat, d, dp, transpose);
+  if (int rc = upload(ctr_b, pc.data(), pc.size() * sizeof(double), s)) return rc;
+  if (int rc = upload(mat_b, pm.data(), pm.size() * sizeof(double), s)) return rc;
+  CK(hipStreamSynchronize(s));  // host vectors go out of scope
+  return 0;
+}
+
+}  // namespace
+
+// ============================================================================================
+struct mlf_region {
+  bool ready = false;
+  int n = 0, d = 0, dp = 0, npad = 0;
+  int layer_kind = 0, use_scan = 1;
+  bool has_wrap = false;
+  double enlarge = 0.0, r2 = 0.0;
+  DevBuf refT, refR, lay_ctr, lay_mat, wrap, ell_ctr, ell_A;
+  DevBuf tq, gate, pts, mask, row;
+  std::vector<hipEvent_t> events;  // 3 per timed call
+  size_t events_used = 0;
+};
+
+namespace {
+
+int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t *d_mask,
+                          hipStream_t s, hipEvent_t *ev /* 3 events or null */,
+                          long long *d_idx = nullptr) {
+  if (np == 0) return 0;
+  if (d_idx && !r->use_scan) return fail_arg(MLF_E_STATE, "region has no live points set");
+  CK(r->gate.reserve(np));
+  uint8_t *gate = r->use_scan ? r->gate.as<uint8_t>() : d_mask;
+  PrepArgs pa{};
+  pa.pts = d_pts;
+  pa.np = (long long)np;
+  pa.d = r->d;
+  pa.do_ell = 1;
+  pa.ell_ctr = r->ell_ctr.as<double>();
+  pa.ell_A = r->ell_A.as<double>();
+  pa.enlarge = r->enlarge;
+  pa.mask = gate;
+  pa.q_out = nullptr;
+  if (r->use_scan) {
+    CK(r->tq.reserve(np * (size_t)r->d * sizeof(double)));
+    pa.t_out = r->tq.as<double>();
+    pa.ldt = r->d;
+    if (r->layer_kind == 0) {
+      pa.do_tr = 1;
+      pa.lay_ctr = r->lay_ctr.as<double>();
+      pa.lay_Tt = r->lay_mat.as<double>();
+      pa.wrap_shift = r->has_wrap ? r->wrap.as<double>() : nullptr;
+    }
+  }
+  if (ev) CK(hipEventRecord(ev[0], s));
+  CK(launch_prep(r->dp, pa, s));
+  if (r->use_scan && r->layer_kind == 1) {
+    launch_scaling_transform(d_pts, (long long)np, r->d, r->lay_ctr.as<double>(), r->lay_mat.as<double>(),
+                             r->has_wrap ? r->wrap.as<double>() : nullptr, gate, r->tq.as<double>(),
+                             r->d, s);
+    CK(hipGetLastError());
+  }
+  if (ev) CK(hipEventRecord(ev[1], s));
+  if (r->use_scan) {
+    ScanArgs a{};
+    a.refT = r->refT.as<double>();
+    a.n = r->n;
+    a.npad = r->npad;
+    a.ntiles = r->npad / kWave;
+    a.q = r->tq.as<double>();
+    a.ldq = r->d;
+    a.nq = (long long)np;
+    a.d = r->d;
+    a.r2 = r->r2;
+    a.mode = d_idx ? SCAN_FIRST : SCAN_MASK;
+    a.gate = gate;
+    a.out_mask = d_mask;
+    a.out_idx = d_idx;
+    CK(launch_scan(r->dp, a, s));
+    if (d_idx) {
+      launch_mark_gated(gate, (long long)np, d_idx, s);
+      CK(hipGetLastError());
+    }
+  }
+  if (ev) CK(hipEventRecord(ev[2], s));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mlf_abi_version(void) { return MLF_ABI_VERSION; }
+
+const char *mlf_last_error(void) { return g_err.c_str(); }
+
+int mlf_device_count(int *count) {
+  if (!count) return fail_arg(MLF_E_BADARG, "null pointer");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  *count = (e == hipSuccess) ? c : 0;
+  return 0;
+}
+
+int mlf_set_device(int device) {
+  if (g_ctx.ready && device != g_ctx.device)
+    return fail_arg(MLF_E_STATE, "mlf_set_device must be called before the first compute call");
+  g_ctx.device = device;
+  return 0;
+}
+
+int mlf_device_name(char *buf, size_t buflen) {
+  if (!buf || !buflen) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (int rc = ensure_ctx()) return rc;
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, g_ctx.device));
+  snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return 0;
+}
+
+int mlf_synchronize(void) {
+  if (int rc = ensure_ctx()) return rc;
+  CK(hipDeviceSynchronize());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ K1 / K2 ----
+int mlf_find_nearby(const double *apts, size_t na, const double *bpts, size_t nb, size_t d,
+                    double radiussq, int64_t *out) {
+  return scan_host(apts, na, bpts, nb, d, radiussq, SCAN_FIRST, out);
+}
+
+int mlf_count_nearby(const double *apts, size_t na, const double *bpts, size_t nb, size_t d,
+                     double radiussq, int64_t *out) {
+  return scan_host(apts, na, bpts, nb, d, radiussq, SCAN_COUNT, out);
+}
+
+// ------------------------------------------------------------------------------ K3 ---------
+int mlf_subtract_nearby(const double *pts, size_t n, size_t d, double radiussq, double *out) {
+  if (int rc = check_dims(d)) return rc;
+  if (n == 0) return 0;
+  if (!pts || !out) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  const int dp = pick_dp((int)d);
+  const int npad = round_up((int)n, kWave);
+  const int ntiles = npad / kWave;
+  if (int rc = stage_live_points(pts, n, d, dp, npad, false)) return rc;
+  CK(c.flags.reserve(n * (size_t)ntiles * sizeof(unsigned long long)));
+  CK(c.out.reserve(n * d * sizeof(double)));
+  ScanArgs a{};
+  a.refT = c.refT.as<double>();
+  a.n = (int)n;
+  a.npad = npad;
+  a.ntiles = ntiles;
+  a.q = c.src.as<double>();
+  a.ldq = (long long)d;
+  a.nq = (long long)n;
+  a.d = (int)d;
+  a.r2 = radiussq;
+  a.mode = SCAN_FLAGS;
+  a.out_flags = c.flags.as<unsigned long long>();
+  CK(launch_scan(dp, a, c.stream));
+  launch_subtract_accum(c.src.as<double>(), (int)n, (int)d, c.flags.as<unsigned long long>(), ntiles,
+                        c.out.as<double>(), c.stream);
+  CK(hipGetLastError());
+  CK(hipMemcpyAsync(out, c.out.p, n * d * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ K4 ---------
+int mlf_maxradiussq_bootstrap(const double *pts, size_t n, size_t d, const uint8_t *selected,
+                              size_t B, double *maxd_out, uint8_t *skipped_out) {
+  if (int rc = check_dims(d)) return rc;
+  if (B == 0) return 0;
+  if (!pts || !selected || !maxd_out || n == 0) return fail_arg(MLF_E_BADARG, "null pointer or no points");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  const int dp = pick_dp((int)d);
+  const int npad = round_up((int)n, kWave);
+  if (int rc = stage_live_points(pts, n, d, dp, npad, true)) return rc;
+  if (int rc = upload(c.selbytes, selected, B * n, c.stream)) return rc;
+  CK(c.sel.reserve((size_t)npad * sizeof(unsigned)));
+  CK(c.M.reserve((size_t)kBootGroup * npad * sizeof(unsigned long long)));
+  CK(c.small0.reserve(B * sizeof(double)));
+  CK(c.small1.reserve(B));
+  // enough live-point chunks to put ~2 waves on every SIMD of the chip
+  const int rowblocks = npad / kWave;
+  int want_chunks = (2048 + rowblocks - 1) / rowblocks;
+  if (want_chunks < 1) want_chunks = 1;
+  int chunk = round_up(((int)n + want_chunks - 1) / want_chunks, kBootTI);
+  const int nchunks = ((int)n + chunk - 1) / chunk;
+  const double init = 1e300;
+  unsigned long long init_bits;
+  memcpy(&init_bits, &init, sizeof init_bits);
+  for (size_t b0 = 0; b0 < B; b0 += kBootGroup) {
+    const int nb = (int)((B - b0) < (size_t)kBootGroup ? (B - b0) : (size_t)kBootGroup);
+    launch_pack_selection(c.selbytes.as<uint8_t>(), (int)n, npad, (int)b0, nb, c.sel.as<unsigned>(),
+                          c.stream);
+    launch_fill_u64(c.M.as<unsigned long long>(), (long long)kBootGroup * npad, init_bits, c.stream);
+    BootArgs a{};
+    a.refT = c.refT.as<double>();
+    a.refR = c.refR.as<double>();
+    a.sel = c.sel.as<unsigned>();
+    a.n = (int)n;
+    a.npad = npad;
+    a.chunk = chunk;
+    a.M = c.M.as<unsigned long long>();
+    CK(launch_boot(dp, a, nchunks, c.stream));
+    launch_boot_final(c.M.as<unsigned long long>(), c.sel.as<unsigned>(), (int)n, npad, nb,
+                      c.small0.as<double>() + b0, c.small1.as<uint8_t>() + b0, c.stream);
+    CK(hipGetLastError());
+  }
+  CK(hipMemcpyAsync(maxd_out, c.small0.p, B * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  std::vector<uint8_t> sk(B);
+  CK(hipMemcpyAsync(sk.data(), c.small1.p, B, hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+  if (skipped_out) memcpy(skipped_out, sk.data(), B);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ K5 ---------
+int mlf_pair_dist2_lower(const double *pts, size_t n, size_t d, double *dist2_out) {
+  if (int rc = check_dims(d)) return rc;
+  if (n < 2) return 0;
+  if (!pts || !dist2_out) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  const size_t npairs = n * (n - 1) / 2;
+  if (int rc = upload(c.src, pts, n * d * sizeof(double), c.stream)) return rc;
+  CK(c.out.reserve(npairs * sizeof(double)));
+  launch_pair_dist2_lower(c.src.as<double>(), (int)n, (int)d, c.out.as<double>(), c.stream);
+  CK(hipGetLastError());
+  CK(hipMemcpyAsync(dist2_out, c.out.p, npairs * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ H3 / T1 ----
+int mlf_inside_ellipsoid(const double *pts, size_t np, size_t d, const double *ctr,
+                         const double *invcov, double sqradius, uint8_t *mask, double *q_out) {
+  if (int rc = check_dims(d)) return rc;
+  if (np == 0) return 0;
+  if (!pts || !ctr || !invcov || !mask) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  const int dp = pick_dp((int)d);
+  if (int rc = prep_consts(c.small0, c.small1, ctr, invcov, (int)d, dp, false, c.stream)) return rc;
+  if (int rc = upload(c.q, pts, np * d * sizeof(double), c.stream)) return rc;
+  CK(c.mask.reserve(np));
+  CK(c.out.reserve(np * sizeof(double)));
+  PrepArgs a{};
+  a.pts = c.q.as<double>();
+  a.np = (long long)np;
+  a.d = (int)d;
+  a.do_ell = 1;
+  a.ell_ctr = c.small0.as<double>();
+  a.ell_A = c.small1.as<double>();
+  a.enlarge = sqradius;
+  a.mask = c.mask.as<uint8_t>();
+  a.q_out = c.out.as<double>();
+  CK(launch_prep(dp, a, c.stream));
+  CK(hipMemcpyAsync(mask, c.mask.p, np, hipMemcpyDeviceToHost, c.stream));
+  if (q_out) CK(hipMemcpyAsync(q_out, c.out.p, np * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+int mlf_affine_transform(const double *pts, size_t np, size_t d, const double *ctr, const double *T,
+                         const double *wrap_shift, double *out) {
+  if (int rc = check_dims(d)) return rc;
+  if (np == 0) return 0;
+  if (!pts || !ctr || !T || !out) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  const int dp = pick_dp((int)d);
+  if (int rc = prep_consts(c.small0, c.small1, ctr, T, (int)d, dp, true, c.stream)) return rc;
+  if (wrap_shift) {
+    std::vector<double> w = pad_vector(wrap_shift, (int)d, dp, NAN);
+    if (int rc = upload(c.small2, w.data(), w.size() * sizeof(double), c.stream)) return rc;
+    CK(hipStreamSynchronize(c.stream));
+  }
+  if (int rc = upload(c.q, pts, np * d * sizeof(double), c.stream)) return rc;
+  CK(c.out.reserve(np * d * sizeof(double)));
+  PrepArgs a{};
+  a.pts = c.q.as<double>();
+  a.np = (long long)np;
+  a.d = (int)d;
+  a.do_tr = 1;
+  a.lay_ctr = c.small0.as<double>();
+  a.lay_Tt = c.small1.as<double>();
+  a.wrap_shift = wrap_shift ? c.small2.as<double>() : nullptr;
+  a.t_out = c.out.as<double>();
+  a.ldt = (long long)d;
+  CK(launch_prep(dp, a, c.stream));
+  CK(hipMemcpyAsync(out, c.out.p, np * d * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+// ------------------------------------------------------------- bootstrap ellipsoid stats ----
+int mlf_bootstrap_moments(const double *u, size_t n, size_t d, const uint8_t *selected, size_t B,
+                          double *mean_out, double *cov_out) {
+  if (int rc = check_dims(d)) return rc;
+  if (B == 0) return 0;
+  if (!u || !selected || !mean_out || !cov_out || n == 0) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  if (int rc = upload(c.src, u, n * d * sizeof(double), c.stream)) return rc;
+  if (int rc = upload(c.selbytes, selected, B * n, c.stream)) return rc;
+  CK(c.small0.reserve(B * d * sizeof(double)));
+  CK(c.small1.reserve(B * sizeof(int)));
+  CK(c.out.reserve(B * d * d * sizeof(double)));
+  launch_boot_moments(c.src.as<double>(), (int)n, (int)d, c.selbytes.as<uint8_t>(), (int)B,
+                      c.small0.as<double>(), c.small1.as<int>(), c.out.as<double>(), c.stream);
+  CK(hipGetLastError());
+  CK(hipMemcpyAsync(mean_out, c.small0.p, B * d * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  CK(hipMemcpyAsync(cov_out, c.out.p, B * d * d * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+int mlf_bootstrap_quadform_max(const double *u, size_t n, size_t d, const uint8_t *selected,
+                               size_t B, const double *ctr, const double *invcov, double *f_out) {
+  if (int rc = check_dims(d)) return rc;
+  if (B == 0) return 0;
+  if (!u || !selected || !ctr || !invcov || !f_out || n == 0) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  const int dp = pick_dp((int)d);
+  if (int rc = upload(c.src, u, n * d * sizeof(double), c.stream)) return rc;
+  if (int rc = upload(c.selbytes, selected, B * n, c.stream)) return rc;
+  // all B padded centres / matrices in one upload
+  std::vector<double> pc((size_t)B * dp, 0.0), pm((size_t)B * d * dp, 0.0);
+  for (size_t b = 0; b < B; ++b) {
+    for (size_t k = 0; k < d; ++k) pc[b * dp + k] = ctr[b * d + k];
+    for (size_t r = 0; r < d; ++r)
+      for (size_t k = 0; k < d; ++k) pm[(b * d + r) * dp + k] = invcov[(b * d + r) * d + k];
+  }
+  if (int rc = upload(c.small0, pc.data(), pc.size() * sizeof(double), c.stream)) return rc;
+  if (int rc = upload(c.small1, pm.data(), pm.size() * sizeof(double), c.stream)) return rc;
+  CK(c.mask.reserve(n));
+  CK(c.out.reserve(n * sizeof(double)));
+  CK(c.small2.reserve(B * sizeof(double)));
+  for (size_t b = 0; b < B; ++b) {
+    PrepArgs a{};
+    a.pts = c.src.as<double>();
+    a.np = (long long)n;
+    a.d = (int)d;
+    a.do_ell = 1;
+    a.ell_ctr = c.small0.as<double>() + b * dp;
+    a.ell_A = c.small1.as<double>() + b * d * dp;
+    a.enlarge = 0.0;
+    a.mask = c.mask.as<uint8_t>();
+    a.q_out = c.out.as<double>();
+    CK(launch_prep(dp, a, c.stream));
+    launch_masked_max(c.out.as<double>(), c.selbytes.as<uint8_t>() + b * n, (int)n,
+                      c.small2.as<double>() + b, c.stream);
+    CK(hipGetLastError());
+  }
+  CK(hipMemcpyAsync(f_out, c.small2.p, B * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ region -----
+int mlf_region_create(mlf_region **out) {
+  if (!out) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (int rc = ensure_ctx()) return rc;
+  *out = new mlf_region();
+  return 0;
+}
+
+int mlf_region_destroy(mlf_region *r) {
+  if (!r) return 0;
+  DevBuf *bufs[] = {&r->refT, &r->refR, &r->lay_ctr, &r->lay_mat, &r->wrap, &r->ell_ctr,
+                    &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row};
+  for (DevBuf *b : bufs) b->release();
+  for (hipEvent_t e : r->events) (void)hipEventDestroy(e);
+  delete r;
+  return 0;
+}
+
+int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int layer_kind,
+                   const double *layer_ctr, const double *layer_T, const double *wrap_shift,
+                   const double *ell_center, const double *ell_invcov, double enlarge,
+                   double radiussq, int use_scan) {
+  if (!r) return fail_arg(MLF_E_BADARG, "null region");
+  if (int rc = check_dims(d)) return rc;
+  if (!ell_center || !ell_invcov) return fail_arg(MLF_E_BADARG, "null ellipsoid");
+  if (use_scan && (!unormed || !layer_ctr || !layer_T || n == 0))
+    return fail_arg(MLF_E_BADARG, "scan regions need live points and a layer");
+  if (layer_kind != 0 && layer_kind != 1) return fail_arg(MLF_E_BADARG, "layer_kind must be 0 or 1");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  r->ready = false;
+  r->n = (int)n;
+  r->d = (int)d;
+  r->dp = pick_dp((int)d);
+  r->npad = round_up((int)n, kWave);
+  r->layer_kind = layer_kind;
+  r->use_scan = use_scan ? 1 : 0;
+  r->enlarge = enlarge;
+  r->r2 = radiussq;
+  r->has_wrap = wrap_shift != nullptr;
+  const int dp = r->dp;
+  if (int rc = prep_consts(r->ell_ctr, r->ell_A, ell_center, ell_invcov, (int)d, dp, false, c.stream))
+    return rc;
+  if (use_scan) {
+    if (int rc = upload(c.src, unormed, n * d * sizeof(double), c.stream)) return rc;
+    CK(r->refT.reserve((size_t)r->npad * dp * sizeof(double)));
+    CK(r->refR.reserve((size_t)r->npad * dp * sizeof(double)));
+    launch_build_layouts(c.src.as<double>(), (int)n, (int)d, dp, r->npad, r->refT.as<double>(),
+                         r->refR.as<double>(), c.stream);
+    CK(hipGetLastError());
+    if (layer_kind == 0) {
+      if (int rc = prep_consts(r->lay_ctr, r->lay_mat, layer_ctr, layer_T, (int)d, dp, true, c.stream))
+        return rc;
+    } else {
+      if (int rc = upload(r->lay_ctr, layer_ctr, d * sizeof(double), c.stream)) return rc;
+      if (int rc = upload(r->lay_mat, layer_T, d * sizeof(double), c.stream)) return rc;
+    }
+    if (wrap_shift) {
+      std::vector<double> w = pad_vector(wrap_shift, (int)d, dp, NAN);
+      if (int rc = upload(r->wrap, w.data(), w.size() * sizeof(double), c.stream)) return rc;
+      CK(hipStreamSynchronize(c.stream));  // w goes out of scope
+    }
+  }
+  CK(hipStreamSynchronize(c.stream));
+  r->ready = true;
+  return 0;
+}
+
+int mlf_region_update_point(mlf_region *r, size_t row, const double *unormed_row) {
+  if (!r || !unormed_row) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (!r->ready || !r->use_scan) return fail_arg(MLF_E_STATE, "region has no live points set");
+  if (row >= (size_t)r->n) return fail_arg(MLF_E_BADARG, "row out of range");
+  Ctx &c = g_ctx;
+  if (int rc = upload(r->row, unormed_row, r->d * sizeof(double), c.stream)) return rc;
+  launch_update_row(r->row.as<double>(), r->d, r->dp, r->npad, (int)row, r->refT.as<double>(),
+                    r->refR.as<double>(), c.stream);
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+int mlf_region_set_thresholds(mlf_region *r, double enlarge, double radiussq) {
+  if (!r) return fail_arg(MLF_E_BADARG, "null region");
+  r->enlarge = enlarge;
+  r->r2 = radiussq;
+  return 0;
+}
+
+int mlf_region_set_ellipsoid_center(mlf_region *r, const double *ell_center) {
+  if (!r || !ell_center) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (!r->ready) return fail_arg(MLF_E_STATE, "region not set");
+  Ctx &c = g_ctx;
+  std::vector<double> pc = pad_vector(ell_center, r->d, r->dp);
+  if (int rc = upload(r->ell_ctr, pc.data(), pc.size() * sizeof(double), c.stream)) return rc;
+  CK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+int mlf_region_inside(mlf_region *r, const double *pts, size_t np, uint8_t *mask) {
+  if (!r) return fail_arg(MLF_E_BADARG, "null region");
+  if (!r->ready) return fail_arg(MLF_E_STATE, "region used before mlf_region_set");
+  if (np == 0) return 0;
+  if (!pts || !mask) return fail_arg(MLF_E_BADARG, "null pointer");
+  Ctx &c = g_ctx;
+  if (int rc = upload(r->pts, pts, np * (size_t)r->d * sizeof(double), c.stream)) return rc;
+  CK(r->mask.reserve(np));
+  if (int rc = region_inside_enqueue(r, r->pts.as<double>(), np, r->mask.as<uint8_t>(), c.stream, nullptr))
+    return rc;
+  CK(hipMemcpyAsync(mask, r->mask.p, np, hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+int mlf_region_inside_dev(mlf_region *r, const double *d_pts, size_t np, uint8_t *d_mask,
+                          void *stream) {
+  if (!r) return fail_arg(MLF_E_BADARG, "null region");
+  if (!r->ready) return fail_arg(MLF_E_STATE, "region used before mlf_region_set");
+  if (np && (!d_pts || !d_mask)) return fail_arg(MLF_E_BADARG, "null pointer");
+  return region_inside_enqueue(r, d_pts, np, d_mask, (hipStream_t)stream, nullptr);
+}
+
+int mlf_region_find_nearby_dev(mlf_region *r, const double *d_tpts, size_t np, int64_t *d_idx,
+                               void *stream) {
+  if (!r) return fail_arg(MLF_E_BADARG, "null region");
+  if (!r->ready || !r->use_scan) return fail_arg(MLF_E_STATE, "region has no live points set");
+  if (np == 0) return 0;
+  if (!d_tpts || !d_idx) return fail_arg(MLF_E_BADARG, "null pointer");
+  ScanArgs a{};
+  a.refT = r->refT.as<double>();
+  a.n = r->n;
+  a.npad = r->npad;
+  a.ntiles = r->npad / kWave;
+  a.q = d_tpts;
+  a.ldq = r->d;
+  a.nq = (long long)np;
+  a.d = r->d;
+  a.r2 = r->r2;
+  a.mode = SCAN_FIRST;
+  a.out_idx = reinterpret_cast<long long *>(d_idx);
+  CK(launch_scan(r->dp, a, (hipStream_t)stream));
+  return 0;
+}
+
+int mlf_region_first_index_dev(mlf_region *r, const double *d_pts, size_t np, int64_t *d_idx,
+                               void *stream) {
+  if (!r) return fail_arg(MLF_E_BADARG, "null region");
+  if (!r->ready) return fail_arg(MLF_E_STATE, "region used before mlf_region_set");
+  if (np && (!d_pts || !d_idx)) return fail_arg(MLF_E_BADARG, "null pointer");
+  return region_inside_enqueue(r, d_pts, np, nullptr, (hipStream_t)stream, nullptr,
+                               reinterpret_cast<long long *>(d_idx));
+}
+
+int mlf_region_inside_dev_timed(mlf_region *r, const double *d_pts, size_t np, uint8_t *d_mask,
+                                void *stream) {
+  if (!r) return fail_arg(MLF_E_BADARG, "null region");
+  if (!r->ready) return fail_arg(MLF_E_STATE, "region used before mlf_region_set");
+  if (!np || !d_pts || !d_mask) return fail_arg(MLF_E_BADARG, "bad argument");
+  while (r->events.size() < r->events_used + 3) {
+    hipEvent_t e;
+    CK(hipEventCreate(&e));
+    r->events.push_back(e);
+  }
+  hipEvent_t *ev = r->events.data() + r->events_used;
+  r->events_used += 3;
+  return region_inside_enqueue(r, d_pts, np, d_mask, (hipStream_t)stream, ev);
+}
+
+int mlf_region_timing_collect(mlf_region *r, int *ncalls, double *ms_prep, double *ms_scan) {
+  if (!r || !ncalls || !ms_prep || !ms_scan) return fail_arg(MLF_E_BADARG, "null pointer");
+  double prep = 0.0, scan = 0.0;
+  const size_t calls = r->events_used / 3;
+  for (size_t i = 0; i < calls; ++i) {
+    hipEvent_t *ev = r->events.data() + 3 * i;
+    CK(hipEventSynchronize(ev[2]));
+    float a = 0.f, b = 0.f;
+    CK(hipEventElapsedTime(&a, ev[0], ev[1]));
+    CK(hipEventElapsedTime(&b, ev[1], ev[2]));
+    prep += a;
+    scan += b;
+  }
+  r->events_used = 0;
+  *ncalls = (int)calls;
+  *ms_prep = prep;
+  *ms_scan = scan;
+  return 0;
+}
+
+int mlf_bench_fp64_valu(double *tflops) {
+  if (!tflops) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  CK(c.out.reserve(1 << 20));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int blocks = 256 * 8, iters = 2000;
+  double ops = launch_fp64_probe(c.out.as<double>(), blocks, iters, c.stream);  // warm-up
+  CK(hipEventRecord(e0, c.stream));
+  ops = launch_fp64_probe(c.out.as<double>(), blocks, iters, c.stream);
+  CK(hipEventRecord(e1, c.stream));
+  CK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipEventDestroy(e0));
+  CK(hipEventDestroy(e1));
+  *tflops = ops / (ms * 1e-3) / 1e12;
+  return 0;
+}
+
+int mlf_region_time_inside_dev(mlf_region *r, const double *d_pts, size_t np, uint8_t *d_mask,
+                               void *stream, int reps, float *ms_total, float *ms_scan) {
+  if (!r) return fail_arg(MLF_E_BADARG, "null region");
+  if (!r->ready) return fail_arg(MLF_E_STATE, "region used before mlf_region_set");
+  if (!d_pts || !d_mask || !ms_total || !ms_scan || reps <= 0 || np == 0)
+    return fail_arg(MLF_E_BADARG, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t ev[3];
+  for (auto &e : ev) CK(hipEventCreate(&e));
+  double tot = 0.0, scan = 0.0;
+  for (int i = 0; i < reps; ++i) {
+    if (int rc = region_inside_enqueue(r, d_pts, np, d_mask, s, ev)) return rc;
+    CK(hipEventSynchronize(ev[2]));
+    float a = 0.f, b = 0.f;
+    CK(hipEventElapsedTime(&a, ev[0], ev[2]));
+    CK(hipEventElapsedTime(&b, ev[1], ev[2]));
+    tot += a;
+    scan += b;
+  }
+  for (auto &e : ev) CK(hipEventDestroy(e));
+  *ms_total = (float)(tot / reps);
+  *ms_scan = (float)(scan / reps);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ likelihoods -
+static int loglike_host(int kind, const double *params, size_t d, size_t n, const double *aux,
+                        double sigma, double *like) {
+  if (d == 0) return fail_arg(MLF_E_BADARG, "dimensionality must be positive");
+  if (n == 0) return 0;
+  if (!params || !like || (kind == 0 && !aux)) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  if (int rc = upload(c.q, params, n * d * sizeof(double), c.stream)) return rc;
+  if (aux)
+    if (int rc = upload(c.small0, aux, d * sizeof(double), c.stream)) return rc;
+  CK(c.out.reserve(n * sizeof(double)));
+  launch_loglike(kind, c.q.as<double>(), (int)d, (long long)n, aux ? c.small0.as<double>() : nullptr,
+                 sigma, c.out.as<double>(), c.stream);
+  CK(hipGetLastError());
+  CK(hipMemcpyAsync(like, c.out.p, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+int mlf_loglike_gauss(const double *params, size_t d, size_t n, const double *centers, double sigma,
+                      double *like) {
+  return loglike_host(0, params, d, n, centers, sigma, like);
+}
+int mlf_loglike_eggbox(const double *params, size_t d, size_t n, double *like) {
+  return loglike_host(1, params, d, n, nullptr, 0.0, like);
+}
+int mlf_loglike_eggbox2(const double *params, size_t d, size_t n, double *like) {
+  return loglike_host(2, params, d, n, nullptr, 0.0, like);
+}
+int mlf_loglike_rosenbrock(const double *params, size_t d, size_t n, double *like) {
+  return loglike_host(3, params, d, n, nullptr, 0.0, like);
+}
+
+int mlf_loglike_dev(int kind, const double *d_params, size_t d, size_t n, const double *d_aux,
+                    double sigma, double *d_like, void *stream) {
+  if (kind < 0 || kind > 3 || d == 0) return fail_arg(MLF_E_BADARG, "bad likelihood kind / dimension");
+  if (n == 0) return 0;
+  if (!d_params || !d_like || (kind == 0 && !d_aux)) return fail_arg(MLF_E_BADARG, "null pointer");
+  launch_loglike(kind, d_params, (int)d, (long long)n, d_aux, sigma, d_like, (hipStream_t)stream);
+  CK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"
+
+namespace mlf {
+
+int pick_dp(int d) {
+#define X(D) \
+  if (d <= D) return D;
+  MLF_FOR_EACH_DP(X)
+#undef X
+  return -1;
+}
+
+}  // namespace mlf

@@ -1,0 +1,353 @@
+// mlf_misc.hip -- layout, reduction and likelihood kernels around the two distance kernels.
+// Compiled with -ffp-contract=off; fused multiply-adds appear only where written as fma().
+#include "mlf_misc.hpp"
+
+#include <math.h>
+
+namespace mlf {
+
+// ---------------------------------------------------------------- layouts ----------------
+// row-major (n, d)  ->  refT [dp][npad] (coordinate-major) and refR [npad][dp], zero padded
+__global__ void k_build_layouts(const double *src, int n, int d, int dp, int npad, double *refT,
+                                double *refR) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)npad * dp;
+  if (e >= total) return;
+  // thread e covers refR element (i, k) and refT element (k', i') of the same flat index
+  {
+    const int i = (int)(e / dp), k = (int)(e - (long long)i * dp);
+    refR[e] = (i < n && k < d) ? src[(long long)i * d + k] : 0.0;
+  }
+  {
+    const int k = (int)(e / npad), i = (int)(e - (long long)k * npad);
+    refT[e] = (i < n && k < d) ? src[(long long)i * d + k] : 0.0;
+  }
+}
+
+void launch_build_layouts(const double *src, int n, int d, int dp, int npad, double *refT,
+                          double *refR, hipStream_t s) {
+  const long long total = (long long)npad * dp;
+  hipLaunchKernelGGL(k_build_layouts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n,
+                     d, dp, npad, refT, refR);
+}
+
+__global__ void k_update_row(const double *row, int d, int dp, int npad, int i, double *refT,
+                             double *refR) {
+  const int k = threadIdx.x;
+  if (k >= dp) return;
+  const double v = k < d ? row[k] : 0.0;
+  refR[(long long)i * dp + k] = v;
+  refT[(long long)k * npad + i] = v;
+}
+
+void launch_update_row(const double *row, int d, int dp, int npad, int i, double *refT,
+                       double *refR, hipStream_t s) {
+  hipLaunchKernelGGL(k_update_row, dim3(1), dim3(128), 0, s, row, d, dp, npad, i, refT, refR);
+}
+
+__global__ void k_fill_u64(unsigned long long *p, long long n, unsigned long long v) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) p[e] = v;
+}
+
+void launch_fill_u64(unsigned long long *p, long long n, unsigned long long v, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+}
+
+// (B, n) byte masks -> one 32-bit word per live point, bit r = selected in round b0 + r
+__global__ void k_pack_selection(const uint8_t *selected, int n, int npad, int b0, int nb,
+                                 unsigned *sel) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npad) return;
+  unsigned w = 0;
+  if (i < n)
+    for (int r = 0; r < nb; ++r)
+      if (selected[(long long)(b0 + r) * n + i]) w |= 1u << r;
+  sel[i] = w;
+}
+
+void launch_pack_selection(const uint8_t *selected, int n, int npad, int b0, int nb, unsigned *sel,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_selection, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s,
+                     selected, n, npad, b0, nb, sel);
+}
+
+// ------------------------------------------------------- K4 epilogue ---------------------
+// maxd[r] = (double)(float) max over unselected j of M[r][j]   (reference :222-224: the
+// `cdef float` return narrows to binary32, round-to-nearest-even = v_cvt_f32_f64)
+__global__ __launch_bounds__(256) void k_boot_final(const unsigned long long *M, const unsigned *sel,
+                                                    int n, int npad, double *maxd,
+                                                    uint8_t *skipped) {
+  __shared__ unsigned long long smax[256];
+  __shared__ int scnt[256];
+  const int r = blockIdx.x;
+  unsigned long long best = 0ull;  // +0.0, reference maxd = 0 (:209)
+  int nsel = 0;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    if ((sel[j] >> r) & 1u) {
+      ++nsel;
+    } else {
+      const unsigned long long v = M[(long long)r * npad + j];
+      best = v > best ? v : best;
+    }
+  }
+  smax[threadIdx.x] = best;
+  scnt[threadIdx.x] = nsel;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) {
+      const unsigned long long o = smax[threadIdx.x + w];
+      if (o > smax[threadIdx.x]) smax[threadIdx.x] = o;
+      scnt[threadIdx.x] += scnt[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const bool skip = scnt[0] == 0 || scnt[0] == n;  // reference :1048
+    const double m = __longlong_as_double((long long)smax[0]);
+    maxd[r] = skip ? 0.0 : (double)(float)m;
+    skipped[r] = skip ? 1 : 0;
+  }
+}
+
+void launch_boot_final(const unsigned long long *M, const unsigned *sel, int n, int npad, int nb,
+                       double *maxd, uint8_t *skipped, hipStream_t s) {
+  hipLaunchKernelGGL(k_boot_final, dim3(nb), dim3(256), 0, s, M, sel, n, npad, maxd, skipped);
+}
+
+// ------------------------------------------------------- K3 pass 2 -----------------------
+// One wave per point j, lane = coordinate.  Neighbours are visited in ascending i from the hit
+// ballots, so the sum has the reference's order (:100-109); then pts[j] - sum / (double)nn.
+__global__ __launch_bounds__(kWave) void k_subtract_accum(const double *pts, int n, int d,
+                                                           const unsigned long long *flags,
+                                                           int ntiles, double *out) {
+  const int j = blockIdx.x;
+  const int lane = threadIdx.x;
+  for (int k = lane; k < d; k += kWave) {
+    double sum = 0.0;
+    long long nn = 0;
+    for (int t = 0; t < ntiles; ++t) {
+      unsigned long long m = flags[(long long)j * ntiles + t];
+      while (m) {
+        const int i = t * kWave + __ffsll((long long)m) - 1;
+        m &= m - 1;
+        sum += pts[(long long)i * d + k];
+        ++nn;
+      }
+    }
+    out[(long long)j * d + k] = pts[(long long)j * d + k] - sum / (double)nn;
+  }
+}
+
+void launch_subtract_accum(const double *pts, int n, int d, const unsigned long long *flags,
+                           int ntiles, double *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_subtract_accum, dim3(n), dim3(kWave), 0, s, pts, n, d, flags, ntiles, out);
+}
+
+// ------------------------------------------------------- K5 ------------------------------
+// packed strict lower triangle of squared pair distances; diff = pts[i] - pts[j] (:265)
+__global__ __launch_bounds__(256) void k_pair_dist2_lower(const double *pts, int n, int d,
+                                                           double *out) {
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int j = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (j >= n || i >= j) return;
+  const double *pi = pts + (long long)i * d;
+  const double *pj = pts + (long long)j * d;
+  double acc = 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double df = pi[k] - pj[k];
+    acc += df * df;
+  }
+  out[(long long)j * (j - 1) / 2 + i] = acc;
+}
+
+void launch_pair_dist2_lower(const double *pts, int n, int d, double *out, hipStream_t s) {
+  const unsigned g = (unsigned)((n + 15) / 16);
+  hipLaunchKernelGGL(k_pair_dist2_lower, dim3(g, g), dim3(256), 0, s, pts, n, d, out);
+}
+
+// ------------------------------------------------------- ScalingLayer.transform ----------
+// t = (wrap(u) - mean) / std, elementwise (reference :605-611); bit-exact (IEEE division)
+__global__ void k_scaling_transform(const double *pts, long long np, int d, const double *mean,
+                                    const double *std, const double *wrap_shift,
+                                    const uint8_t *gate, double *out, long long ldt) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= np * d) return;
+  const long long p = e / d;
+  const int k = (int)(e - p * d);
+  if (gate && !gate[p]) return;
+  double w = pts[e];
+  if (wrap_shift) {
+    const double sh = wrap_shift[k];
+    if (sh == sh) w = fmod(w + sh, 1.0);
+  }
+  out[p * ldt + k] = (w - mean[k]) / std[k];
+}
+
+void launch_scaling_transform(const double *pts, long long np, int d, const double *mean,
+                              const double *std, const double *wrap_shift, const uint8_t *gate,
+                              double *out, long long ldt, hipStream_t s) {
+  const long long total = np * d;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(k_scaling_transform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pts,
+                     np, d, mean, std, wrap_shift, gate, out, ldt);
+}
+
+// ------------------------------------------------------- masked max ----------------------
+// out[0] = max over i with selected[i] == 0 of q[i]  (bootstrap enlargement f, reference :1062)
+__global__ __launch_bounds__(256) void k_masked_max(const double *q, const uint8_t *selected, int n,
+                                                    double *out) {
+  __shared__ double smax[256];
+  double best = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += 256)
+    if (!selected[i]) best = fmax(best, q[i]);
+  smax[threadIdx.x] = best;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + w]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = smax[0];
+}
+
+void launch_masked_max(const double *q, const uint8_t *selected, int n, double *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_masked_max, dim3(1), dim3(256), 0, s, q, selected, n, out);
+}
+
+// ------------------------------------------------------- bootstrap moments ---------------
+// mean[b][k] over selected rows (block = bootstrap b; 4 row groups x 64 coordinate lanes)
+__global__ __launch_bounds__(256) void k_boot_mean(const double *u, int n, int d,
+                                                   const uint8_t *selected, double *mean,
+                                                   int *count) {
+  __shared__ double part[4][128];
+  __shared__ int cpart[4];
+  const int b = blockIdx.x;
+  const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint8_t *sel = selected + (long long)b * n;
+  double s0 = 0.0, s1 = 0.0;
+  int c = 0;
+  for (int i = g; i < n; i += 4) {
+    if (!sel[i]) continue;
+    ++c;
+    if (lane < d) s0 += u[(long long)i * d + lane];
+    if (lane + 64 < d) s1 += u[(long long)i * d + lane + 64];
+  }
+  part[g][lane] = s0;
+  part[g][lane + 64] = s1;
+  if (lane == 0) cpart[g] = c;
+  __syncthreads();
+  if (threadIdx.x < 128 && threadIdx.x < d) {
+    const int k = threadIdx.x;
+    const int cnt = cpart[0] + cpart[1] + cpart[2] + cpart[3];
+    mean[(long long)b * d + k] = (part[0][k] + part[1][k] + part[2][k] + part[3][k]) / (double)cnt;
+    if (k == 0) count[b] = cnt;
+  }
+}
+
+// cov[b][k][l] = sum_sel (u_ik - m_k)(u_il - m_l) / (cnt - 1); thread = (k, l)
+__global__ __launch_bounds__(256) void k_boot_cov(const double *u, int n, int d,
+                                                  const uint8_t *selected, const double *mean,
+                                                  const int *count, double *cov) {
+  const int b = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= d * d) return;
+  const int k = e / d, l = e - k * d;
+  const uint8_t *sel = selected + (long long)b * n;
+  const double mk = mean[(long long)b * d + k], ml = mean[(long long)b * d + l];
+  double acc = 0.0;
+  for (int i = 0; i < n; ++i) {
+    if (!sel[i]) continue;
+    acc = __builtin_fma(u[(long long)i * d + k] - mk, u[(long long)i * d + l] - ml, acc);
+  }
+  cov[(long long)b * d * d + e] = acc / (double)(count[b] - 1);
+}
+
+void launch_boot_moments(const double *u, int n, int d, const uint8_t *selected, int B, double *mean,
+                         int *count, double *cov, hipStream_t s) {
+  hipLaunchKernelGGL(k_boot_mean, dim3(B), dim3(256), 0, s, u, n, d, selected, mean, count);
+  hipLaunchKernelGGL(k_boot_cov, dim3((unsigned)((d * d + 255) / 256), (unsigned)B), dim3(256), 0, s, u,
+                     n, d, selected, mean, count, cov);
+}
+
+// ------------------------------------------------------- likelihoods (V1, L1-L3) ---------
+// One lane per parameter vector; (params, d, n, like) convention of reference
+// languages/c/mylib.c:33.  Tolerance class (1e-12 relative): numpy's pairwise sum / libm cos
+// are not bit-reproduced.
+__global__ void k_loglike(int kind, const double *params, int d, long long n, const double *aux,
+                          double sigma, double *like) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const double *x = params + j * d;
+  double out;
+  if (kind == 0) {  // docs/gauss.py:25-27
+    double s = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double z = (x[k] - aux[k]) / sigma;
+      s += z * z;
+    }
+    out = -0.5 * s - 0.5 * log(2.0 * M_PI * sigma * sigma) * (double)d;
+  } else if (kind == 1) {  // examples/testeggbox.py:9-11
+    double chi = 1.0;
+    for (int k = 0; k < d; ++k) chi *= cos(x[k] / 2.0);
+    const double base = 2.0 + chi;
+    const double b2 = base * base;
+    out = b2 * b2 * base;
+  } else if (kind == 2) {  // examples/test_PopSliceSampler.py:69-71
+    double chi = 1.0;
+    for (int k = 0; k < d; ++k) chi *= cos(x[k]);
+    out = chi * chi;
+  } else {  // examples/testrosenbrock.py:10-13
+    double s = 0.0;
+    for (int k = 0; k + 1 < d; ++k) {
+      const double av = x[k], bv = x[k + 1];
+      const double t = bv - av * av;
+      const double w = 1.0 - av;
+      s += 100.0 * (t * t) + w * w;
+    }
+    out = -2.0 * s;
+  }
+  like[j] = out;
+}
+
+void launch_loglike(int kind, const double *params, int d, long long n, const double *aux,
+                    double sigma, double *like, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_loglike, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kind, params, d, n,
+                     aux, sigma, like);
+}
+
+// idx[p] = -2 where the ellipsoid gate rejected proposal p (scan wrote -1 there)
+__global__ void k_mark_gated(const uint8_t *gate, long long n, long long *idx) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n && !gate[e]) idx[e] = -2;
+}
+
+void launch_mark_gated(const uint8_t *gate, long long n, long long *idx, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_mark_gated, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gate, n, idx);
+}
+
+// ------------------------------------------------------- FP64 VALU rate probe ------------
+// 8 independent add/mul chains per lane: measures the issue rate of non-fused v_add_f64 /
+// v_mul_f64, the ceiling of the distance kernels (which may not use FMA).
+__global__ __launch_bounds__(256) void k_fp64_probe(double *sink, int iters) {
+  double x0 = threadIdx.x * 1e-3, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+  double x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+  const double a = 1.0000001, b = 1e-9;
+  for (int i = 0; i < iters; ++i) {
+    x0 = x0 * a; x1 = x1 + b; x2 = x2 * a; x3 = x3 + b;
+    x4 = x4 * a; x5 = x5 + b; x6 = x6 * a; x7 = x7 + b;
+    x0 = x0 + b; x1 = x1 * a; x2 = x2 + b; x3 = x3 * a;
+    x4 = x4 + b; x5 = x5 * a; x6 = x6 + b; x7 = x7 * a;
+  }
+  const double r = ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
+  if (r == 123.456) sink[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+double launch_fp64_probe(double *sink, int blocks, int iters, hipStream_t s) {
+  hipLaunchKernelGGL(k_fp64_probe, dim3(blocks), dim3(256), 0, s, sink, iters);
+  return (double)blocks * 256.0 * (double)iters * 16.0;
+}
+
+}  // namespace mlf

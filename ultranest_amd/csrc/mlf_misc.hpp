@@ -1,0 +1,32 @@
+// mlf_misc.hpp -- launchers of the layout / reduction / likelihood kernels (mlf_misc.hip)
+#pragma once
+#include "mlf_common.hpp"
+
+namespace mlf {
+
+void launch_build_layouts(const double *src, int n, int d, int dp, int npad, double *refT,
+                          double *refR, hipStream_t s);
+void launch_update_row(const double *row, int d, int dp, int npad, int i, double *refT,
+                       double *refR, hipStream_t s);
+void launch_fill_u64(unsigned long long *p, long long n, unsigned long long v, hipStream_t s);
+void launch_pack_selection(const uint8_t *selected, int n, int npad, int b0, int nb, unsigned *sel,
+                           hipStream_t s);
+void launch_boot_final(const unsigned long long *M, const unsigned *sel, int n, int npad, int nb,
+                       double *maxd, uint8_t *skipped, hipStream_t s);
+void launch_subtract_accum(const double *pts, int n, int d, const unsigned long long *flags,
+                           int ntiles, double *out, hipStream_t s);
+void launch_pair_dist2_lower(const double *pts, int n, int d, double *out, hipStream_t s);
+void launch_scaling_transform(const double *pts, long long np, int d, const double *mean,
+                              const double *std, const double *wrap_shift, const uint8_t *gate,
+                              double *out, long long ldt, hipStream_t s);
+void launch_masked_max(const double *q, const uint8_t *selected, int n, double *out, hipStream_t s);
+void launch_boot_moments(const double *u, int n, int d, const uint8_t *selected, int B, double *mean,
+                         int *count, double *cov, hipStream_t s);
+void launch_loglike(int kind, const double *params, int d, long long n, const double *aux,
+                    double sigma, double *like, hipStream_t s);
+
+void launch_mark_gated(const uint8_t *gate, long long n, long long *idx, hipStream_t s);
+// returns the number of FP64 lane-operations the probe executes
+double launch_fp64_probe(double *sink, int blocks, int iters, hipStream_t s);
+
+}  // namespace mlf

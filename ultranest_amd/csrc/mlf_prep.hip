@@ -1,0 +1,109 @@
+// mlf_prep.hip -- per-proposal stages in front of the neighbour scan:
+//   H3  _inside_ellipsoid  (reference mlfriends.pyx:882-912)
+//   T1  AffineLayer.transform (:737-743) incl. the wrap of circular dims (:529-536)
+//
+// Mapping: one LANE owns one proposal; its centred coordinates live in registers (DP doubles),
+// the d x d matrix (inverse covariance, then T^T) is staged in LDS and broadcast.
+//
+// H3 is evaluated in exactly the order numpy's three-operand c_einsum uses for
+// 'ij,jk,ik->i' (probed bit-for-bit against numpy 2.2.6): ONE accumulator per point,
+// j outer / k inner, term = (delta_j * A_jk) * delta_k, no FMA (-ffp-contract=off).
+// T1 is a k-ascending fused-multiply-add chain (explicit fma(): BLAS order is implementation
+// defined, this is what OpenBLAS produced for most probed shapes; tolerance class).
+#include "mlf_common.hpp"
+
+namespace mlf {
+
+template <int DP>
+__global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double mat[];  // [d][DP]
+
+  const int tid = threadIdx.x;
+  const long long p = (long long)blockIdx.x * 256 + tid;
+  const bool live = p < a.np;
+  const double *row = a.pts + (live ? p : 0) * (long long)a.d;
+  const int d = a.d;
+  bool inside = live;
+
+  if (a.do_ell) {
+    for (int e = tid; e < d * DP; e += 256) mat[e] = a.ell_A[e];
+    double dl[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) dl[k] = (k < d) ? row[k] - a.ell_ctr[k] : 0.0;
+    __syncthreads();
+    double acc = 0.0;
+    for (int j = 0; j < d; ++j) {
+      const double dj = row[j] - a.ell_ctr[j];  // same subtraction as dl[j], bit-identical
+      const double2 *arow = reinterpret_cast<const double2 *>(mat + j * DP);
+#pragma unroll
+      for (int k = 0; k < DP; k += 2) {
+        const double2 v = arow[k >> 1];
+        acc += (dj * v.x) * dl[k];
+        acc += (dj * v.y) * dl[k + 1];
+      }
+    }
+    inside = live && (acc <= a.enlarge);
+    if (live) {
+      a.mask[p] = inside ? 1 : 0;
+      if (a.q_out) a.q_out[p] = acc;
+    }
+    __syncthreads();  // mat is reused below
+  }
+
+  if (a.do_tr) {
+    for (int e = tid; e < d * DP; e += 256) mat[e] = a.lay_Tt[e];
+    __syncthreads();
+    if (__any(inside)) {  // a wave with no surviving proposal skips the d^2 work
+      double dl[DP];
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        double w = 0.0;
+        if (k < d) {
+          w = row[k];
+          if (a.wrap_shift) {
+            const double sh = a.wrap_shift[k];
+            if (sh == sh) w = fmod(w + sh, 1.0);  // NaN marks an unwrapped dimension
+          }
+          w -= a.lay_ctr[k];
+        }
+        dl[k] = w;
+      }
+      for (int c = 0; c < d; ++c) {
+        const double2 *trow = reinterpret_cast<const double2 *>(mat + c * DP);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DP; k += 2) {
+          const double2 v = trow[k >> 1];
+          acc = __builtin_fma(dl[k], v.x, acc);
+          acc = __builtin_fma(dl[k + 1], v.y, acc);
+        }
+        if (inside) a.t_out[p * a.ldt + c] = acc;
+      }
+    }
+  }
+}
+
+hipError_t launch_prep(int dp, const PrepArgs &a, hipStream_t s) {
+  if (a.np <= 0) return hipSuccess;
+  const unsigned grid = (unsigned)((a.np + 255) / 256);
+  const size_t lds = (size_t)a.d * dp * sizeof(double);
+  switch (dp) {
+#define X(D)                                                                            \
+  case D:                                                                               \
+    if (lds > 48 * 1024) {                                                              \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep<D>),    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                         (int)lds);                                     \
+      if (e != hipSuccess) return e;                                                    \
+    }                                                                                   \
+    hipLaunchKernelGGL(k_prep<D>, dim3(grid), dim3(256), lds, s, a);                    \
+    break;
+    MLF_FOR_EACH_DP(X)
+#undef X
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace mlf

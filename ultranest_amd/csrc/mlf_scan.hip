@@ -1,0 +1,114 @@
+// mlf_scan.hip -- the neighbour-scan kernel behind K1 (find_nearby, reference mlfriends.pyx:143),
+// K2 (count_nearby :31), pass 1 of K3 (_subtract_nearby :73) and the scan stage of
+// MLFriends.inside (:1186).
+//
+// Mapping (CDNA4, wave64): one LANE owns one LIVE POINT, held in registers for the whole pass
+// over the workgroup's queries; the 64 queries of a workgroup sit in LDS and are broadcast to
+// the wave (every lane reads the same 16 bytes -> conflict-free ds_read_b128).  A wave therefore
+// evaluates 64 squared distances per query step and decides "any within r2" with one ballot;
+// the lowest set bit of the first hitting tile is the reference's first-hit index.
+// Early exit is per QUERY (not per lane): a query that has its answer is skipped by all four
+// waves of the workgroup, so accepted proposals stop costing anything after their first hit.
+//
+// Arithmetic contract (bit-exact with the reference): acc = 0; for k ascending:
+// diff = live[k] - query[k]; acc += diff*diff  with sub, mul, add individually rounded --
+// this file is compiled with -ffp-contract=off so no v_fma_f64 is formed.
+#include "mlf_common.hpp"
+
+namespace mlf {
+
+template <int DP>
+__global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) double qs[kScanQB * DP];
+  __shared__ int state[kScanQB];  // SCAN_FIRST/MASK: first-hit index or kNone; -1 = inactive
+  __shared__ int cnt[kScanQB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const long long q0 = (long long)blockIdx.x * kScanQB;
+  const long long left = a.nq - q0;
+  const int nqb = left < kScanQB ? (int)left : kScanQB;
+
+  // stage this workgroup's queries, zero padded to DP
+  for (int e = tid; e < kScanQB * DP; e += kScanThreads) {
+    const int qq = e / DP;
+    const int k = e - qq * DP;
+    double v = 0.0;
+    if (qq < nqb && k < a.d) v = a.q[(q0 + qq) * a.ldq + k];
+    qs[e] = v;
+  }
+  if (tid < kScanQB) {
+    const bool active = tid < nqb && (a.gate == nullptr || a.gate[q0 + tid] != 0);
+    state[tid] = active ? kNone : -1;
+    cnt[tid] = 0;
+  }
+  __syncthreads();
+
+  const int mode = a.mode;
+  for (int t = wave; t < a.ntiles; t += kScanThreads / kWave) {
+    const int base = t * kWave;
+    double r[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) r[k] = a.refT[(size_t)k * a.npad + base + lane];
+    const bool valid = base + lane < a.n;
+
+    for (int qq = 0; qq < nqb; ++qq) {
+      const int st = __builtin_amdgcn_readfirstlane(*(volatile int *)&state[qq]);
+      if (st < 0) continue;                                 // gated out
+      if (mode == SCAN_FIRST && st < base) continue;        // an earlier tile already hit
+      if (mode == SCAN_MASK && st != kNone) continue;       // any hit settles the mask
+
+      const double2 *qrow = reinterpret_cast<const double2 *>(qs + qq * DP);
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < DP; k += 2) {
+        const double2 v = qrow[k >> 1];
+        const double d0 = r[k] - v.x;
+        acc += d0 * d0;
+        const double d1 = r[k + 1] - v.y;
+        acc += d1 * d1;
+      }
+      const bool hit = valid && (acc <= a.r2);
+      const unsigned long long m = __ballot(hit);
+      if (mode == SCAN_FLAGS) {
+        if (lane == 0) a.out_flags[(size_t)(q0 + qq) * a.ntiles + t] = m;
+      } else if (m != 0ull && lane == 0) {
+        if (mode == SCAN_COUNT)
+          atomicAdd(&cnt[qq], __popcll(m));
+        else
+          atomicMin(&state[qq], base + __ffsll((long long)m) - 1);
+      }
+    }
+  }
+  __syncthreads();
+
+  if (tid < nqb) {
+    const int st = state[tid];
+    const bool found = st >= 0 && st != kNone;
+    if (mode == SCAN_FIRST)
+      a.out_idx[q0 + tid] = found ? (long long)st : -1ll;
+    else if (mode == SCAN_COUNT)
+      a.out_idx[q0 + tid] = (long long)cnt[tid];
+    else if (mode == SCAN_MASK)
+      a.out_mask[q0 + tid] = found ? 1 : 0;
+  }
+}
+
+hipError_t launch_scan(int dp, const ScanArgs &a, hipStream_t s) {
+  if (a.nq <= 0) return hipSuccess;
+  const unsigned grid = (unsigned)((a.nq + kScanQB - 1) / kScanQB);
+  switch (dp) {
+#define X(D)                                                       \
+  case D:                                                          \
+    hipLaunchKernelGGL(k_scan<D>, dim3(grid), dim3(kScanThreads), 0, s, a); \
+    break;
+    MLF_FOR_EACH_DP(X)
+#undef X
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace mlf

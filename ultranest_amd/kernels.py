@@ -1,0 +1,232 @@
+"""numpy-facing wrappers of the HIP kernels: the functions the reference exposes from
+``ultranest/mlfriends.pyx`` as module-level (c)def kernels, same names and argument meaning.
+
+Every function here runs on the MI355X through libmlfriends_hip.so; none has a CPU path.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f64, ptr
+
+int_dtype = np.int64   # reference mlfriends.pyx:26
+
+
+def find_nearby(apts, bpts, radiussq, nnearby):
+    """Index of the first point of `apts` within square radius `radiussq` of each `bpts` row,
+    -1 if none; written into `nnearby` (int64, len(bpts)).  Reference mlfriends.pyx:143-183."""
+    apts, bpts = f64(apts), f64(bpts)
+    if apts.ndim != 2 or bpts.ndim != 2:
+        raise ValueError("apts and bpts must be 2-d")
+    nb = bpts.shape[0]
+    d = bpts.shape[1] if nb else apts.shape[1]
+    if nb and apts.shape[0] and apts.shape[1] != bpts.shape[1]:
+        raise ValueError("dimensionality mismatch")
+    if nnearby.dtype != int_dtype or nnearby.ndim != 1 or len(nnearby) != nb:
+        raise ValueError("nnearby must be an int64 vector of len(bpts)")
+    out = nnearby if nnearby.flags.c_contiguous else np.empty(nb, dtype=int_dtype)
+    check(_lib.lib().mlf_find_nearby(ptr(apts), apts.shape[0], ptr(bpts), nb, d, float(radiussq), ptr(out)))
+    if out is not nnearby:
+        nnearby[:] = out
+
+
+def count_nearby(apts, bpts, radiussq, nnearby):
+    """Number of `apts` within `radiussq` of each `bpts` row.  Reference mlfriends.pyx:31-68."""
+    apts, bpts = f64(apts), f64(bpts)
+    nb = bpts.shape[0]
+    d = bpts.shape[1] if nb else apts.shape[1]
+    out = nnearby if nnearby.flags.c_contiguous else np.empty(nb, dtype=int_dtype)
+    check(_lib.lib().mlf_count_nearby(ptr(apts), apts.shape[0], ptr(bpts), nb, d, float(radiussq), ptr(out)))
+    if out is not nnearby:
+        nnearby[:] = out
+
+
+def subtract_nearby(upoints, maxradiussq):
+    """upoints minus the mean of the points within `maxradiussq`.  Reference mlfriends.pyx:118-138."""
+    pts = f64(upoints)
+    out = np.empty_like(pts)
+    if pts.shape[0]:
+        check(_lib.lib().mlf_subtract_nearby(ptr(pts), pts.shape[0], pts.shape[1], float(maxradiussq), ptr(out)))
+    return out
+
+
+def maxradiussq_bootstrap(unormed, selected):
+    """Per-bootstrap ``compute_maxradiussq(unormed[sel], unormed[~sel])`` (reference
+    mlfriends.pyx:188-224, called at :1012 and :1052) for a (B, N) boolean selection matrix.
+
+    Returns (r2[B] -- already float32-rounded like the reference's ``cdef float`` --, skipped[B])."""
+    pts = f64(unormed)
+    sel = np.ascontiguousarray(selected, dtype=np.uint8)
+    if sel.ndim == 1:
+        sel = sel[None, :]
+    B, n = sel.shape
+    if n != pts.shape[0]:
+        raise ValueError("selection mask length != number of points")
+    r2 = np.empty(B, dtype=np.float64)
+    skipped = np.empty(B, dtype=np.uint8)
+    check(_lib.lib().mlf_maxradiussq_bootstrap(ptr(pts), n, pts.shape[1], ptr(sel), B, ptr(r2), ptr(skipped)))
+    return r2, skipped.astype(bool)
+
+
+def compute_mean_pair_distance(pts, clusterids):
+    """Mean distance between same-cluster pairs (cluster id 0 = unassigned is excluded).
+    Reference mlfriends.pyx:229-270.  The N^2 d squared distances are computed on the GPU; the
+    square root and the reference's single running sum (j outer, i<j inner) are applied on the
+    host, which keeps the result bit-identical."""
+    pts = f64(pts)
+    ids = np.asarray(clusterids)
+    n = pts.shape[0]
+    if n < 2:
+        return np.float64(np.nan)
+    d2 = np.empty(n * (n - 1) // 2, dtype=np.float64)
+    check(_lib.lib().mlf_pair_dist2_lower(ptr(pts), n, pts.shape[1], ptr(d2)))
+    jj, ii = np.tril_indices(n, -1)            # row-major lower triangle == (j outer, i inner)
+    keep = (ids[jj] != 0) & (ids[jj] == ids[ii])
+    vals = np.sqrt(d2[keep])
+    npairs = int(keep.sum())
+    total = np.cumsum(vals)[-1] if npairs else 0.0   # cumsum = strictly sequential summation
+    assert np.isfinite(total), total
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return np.float64(total) / npairs if npairs else np.float64(np.nan)
+
+
+def inside_ellipsoid(points, ellipsoid_center, ellipsoid_invcov, square_radius, return_q=False):
+    """``einsum('ij,jk,ik->i', d, invcov, d) <= square_radius``; reference mlfriends.pyx:882-912."""
+    pts = f64(points)
+    ctr, inv = f64(ellipsoid_center), f64(ellipsoid_invcov)
+    n = pts.shape[0]
+    mask = np.empty(n, dtype=np.uint8)
+    q = np.empty(n, dtype=np.float64) if return_q else None
+    if n:
+        check(_lib.lib().mlf_inside_ellipsoid(ptr(pts), n, pts.shape[1], ptr(ctr), ptr(inv),
+                                              float(square_radius), ptr(mask), ptr(q)))
+    mask = mask.view(np.bool_)
+    return (mask, q) if return_q else mask
+
+
+def affine_transform(points, ctr, T, wrap_shift=None):
+    """``np.dot(wrap(points) - ctr, T)``; reference mlfriends.pyx:737-743."""
+    pts = f64(points)
+    d = pts.shape[1]
+    ctr = f64(np.broadcast_to(ctr, (d,)))
+    T = f64(T)
+    out = np.empty_like(pts)
+    ws = None if wrap_shift is None else f64(wrap_shift)
+    if pts.shape[0]:
+        check(_lib.lib().mlf_affine_transform(ptr(pts), pts.shape[0], d, ptr(ctr), ptr(T), ptr(ws), ptr(out)))
+    return out
+
+
+def bootstrap_moments(u, selected):
+    """mean (B, d) and ddof=1 sample covariance (B, d, d) of the selected rows per bootstrap."""
+    u = f64(u)
+    sel = np.ascontiguousarray(selected, dtype=np.uint8)
+    B, n = sel.shape
+    d = u.shape[1]
+    mean = np.empty((B, d))
+    cov = np.empty((B, d, d))
+    check(_lib.lib().mlf_bootstrap_moments(ptr(u), n, d, ptr(sel), B, ptr(mean), ptr(cov)))
+    return mean, cov
+
+
+def bootstrap_quadform_max(u, selected, ctr, invcov):
+    """f[b] = max over rows NOT selected in bootstrap b of (u-ctr_b)^T invcov_b (u-ctr_b);
+    reference mlfriends.pyx:1060-1062."""
+    u = f64(u)
+    sel = np.ascontiguousarray(selected, dtype=np.uint8)
+    B, n = sel.shape
+    ctr, invcov = f64(ctr), f64(invcov)
+    f = np.empty(B)
+    check(_lib.lib().mlf_bootstrap_quadform_max(ptr(u), n, u.shape[1], ptr(sel), B, ptr(ctr), ptr(invcov), ptr(f)))
+    return f
+
+
+class DeviceRegion(object):
+    """Device-resident state of one region (live points in both layouts, layer, wrapping
+    ellipsoid, thresholds) behind the opaque ``mlf_region`` handle."""
+
+    def __init__(self):
+        self._h = ctypes.c_void_p()
+        check(_lib.lib().mlf_region_create(ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _lib.lib().mlf_region_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set(self, unormed, layer_kind, layer_ctr, layer_T, wrap_shift, ell_center, ell_invcov,
+            enlarge, radiussq, use_scan=True):
+        d = len(ell_center)
+        un = None if unormed is None else f64(unormed)
+        n = 0 if un is None else un.shape[0]
+        lc = None if layer_ctr is None else f64(np.broadcast_to(layer_ctr, (d,)))
+        if layer_T is None:
+            lt = None
+        elif layer_kind == 1:
+            lt = f64(np.broadcast_to(layer_T, (d,)))
+        else:
+            lt = f64(layer_T)
+        ws = None if wrap_shift is None else f64(wrap_shift)
+        self._keep = (un, lc, lt, ws)
+        check(_lib.lib().mlf_region_set(self._h, ptr(un), n, d, int(layer_kind), ptr(lc), ptr(lt), ptr(ws),
+                                        ptr(f64(ell_center)), ptr(f64(ell_invcov)), float(enlarge),
+                                        float(radiussq), int(bool(use_scan))))
+
+    def set_thresholds(self, enlarge, radiussq):
+        check(_lib.lib().mlf_region_set_thresholds(self._h, float(enlarge), float(radiussq)))
+
+    def set_ellipsoid_center(self, ctr):
+        check(_lib.lib().mlf_region_set_ellipsoid_center(self._h, ptr(f64(ctr))))
+
+    def update_point(self, row, unormed_row):
+        check(_lib.lib().mlf_region_update_point(self._h, int(row), ptr(f64(unormed_row))))
+
+    def inside(self, pts):
+        pts = f64(pts)
+        mask = np.empty(pts.shape[0], dtype=np.uint8)
+        if pts.shape[0]:
+            check(_lib.lib().mlf_region_inside(self._h, ptr(pts), pts.shape[0], ptr(mask)))
+        return mask.view(np.bool_)
+
+    # device-pointer entry points (integers from e.g. torch.Tensor.data_ptr())
+    def inside_dev(self, d_pts, npts, d_mask, stream=0):
+        check(_lib.lib().mlf_region_inside_dev(self._h, ctypes.c_void_p(d_pts), npts, ctypes.c_void_p(d_mask),
+                                               ctypes.c_void_p(stream)))
+
+    def find_nearby_dev(self, d_tpts, npts, d_idx, stream=0):
+        check(_lib.lib().mlf_region_find_nearby_dev(self._h, ctypes.c_void_p(d_tpts), npts,
+                                                    ctypes.c_void_p(d_idx), ctypes.c_void_p(stream)))
+
+    def first_index_dev(self, d_pts, npts, d_idx, stream=0):
+        check(_lib.lib().mlf_region_first_index_dev(self._h, ctypes.c_void_p(d_pts), npts,
+                                                    ctypes.c_void_p(d_idx), ctypes.c_void_p(stream)))
+
+    def inside_dev_timed(self, d_pts, npts, d_mask, stream=0):
+        check(_lib.lib().mlf_region_inside_dev_timed(self._h, ctypes.c_void_p(d_pts), npts,
+                                                     ctypes.c_void_p(d_mask), ctypes.c_void_p(stream)))
+
+    def timing_collect(self):
+        n, a, b = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
+        check(_lib.lib().mlf_region_timing_collect(self._h, ctypes.byref(n), ctypes.byref(a), ctypes.byref(b)))
+        return n.value, a.value, b.value
+
+    def time_inside_dev(self, d_pts, npts, d_mask, stream=0, reps=3):
+        tot, scan = ctypes.c_float(0), ctypes.c_float(0)
+        check(_lib.lib().mlf_region_time_inside_dev(self._h, ctypes.c_void_p(d_pts), npts, ctypes.c_void_p(d_mask),
+                                                    ctypes.c_void_p(stream), int(reps), ctypes.byref(tot),
+                                                    ctypes.byref(scan)))
+        return tot.value, scan.value
+
+
+def bench_fp64_valu():
+    """Measured non-fused FP64 vector issue rate in TFLOP/s (one flop per v_add_f64/v_mul_f64 lane)."""
+    t = ctypes.c_double(0)
+    check(_lib.lib().mlf_bench_fp64_valu(ctypes.byref(t)))
+    return t.value
