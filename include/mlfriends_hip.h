@@ -101,13 +101,18 @@ typedef struct mlf_region mlf_region;
 int mlf_region_create(mlf_region **out);
 int mlf_region_destroy(mlf_region *r);
 /* layer_kind: 0 = AffineLayer family (ctr[d], T[d,d]); 1 = ScalingLayer (ctr = mean[d],
- * T = std[d]).  use_scan = 0 gives RobustEllipsoidRegion.inside (:1374-1390, H3 only). */
-int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int layer_kind,
-                   const double *layer_ctr, const double *layer_T, const double *wrap_shift,
-                   const double *ell_center, const double *ell_invcov, double enlarge,
-                   double radiussq, int use_scan);
-/* in-place live point replacement, integrator.py:2753-2754 */
-int mlf_region_update_point(mlf_region *r, size_t row, const double *unormed_row);
+ * T = std[d]).  use_scan = 0 gives RobustEllipsoidRegion.inside (:1374-1390, H3 only).
+ * live_space: 0 = `live` rows are already whitened (region.unormed); 1 = `live` rows are
+ * cube-space points (region.u) and are whitened on the device with the SAME kernel that whitens
+ * proposals, so that a live point tested against its own region is at distance exactly 0
+ * (the `d <= r2` pin of reference tests/test_regionsampling.py:46-48). */
+int mlf_region_set(mlf_region *r, const double *live, size_t n, size_t d, int live_space,
+                   int layer_kind, const double *layer_ctr, const double *layer_T,
+                   const double *wrap_shift, const double *ell_center, const double *ell_invcov,
+                   double enlarge, double radiussq, int use_scan);
+/* in-place live point replacement, integrator.py:2753-2754; the row is in the space given by
+ * live_space at mlf_region_set */
+int mlf_region_update_point(mlf_region *r, size_t row, const double *live_row);
 int mlf_region_set_thresholds(mlf_region *r, double enlarge, double radiussq);
 int mlf_region_set_ellipsoid_center(mlf_region *r, const double *ell_center);
 int mlf_region_inside(mlf_region *r, const double *pts, size_t np, uint8_t *mask);

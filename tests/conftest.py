@@ -32,3 +32,16 @@ def oracle():
     from oracle import oracle as orc
     orc.lib()
     return orc
+
+
+@pytest.fixture(params=["oracle-stub", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request, monkeypatch):
+    """Host-logic tests run twice: on CPU with the kernels monkeypatched to the oracle (no GPU
+    needed; exercises the Python layer only) and unpatched on the MI355X (`-m gpu`)."""
+    if request.param == "oracle-stub":
+        import oracle_backend
+        oracle_backend.install(monkeypatch)
+    else:
+        from ultranest_amd import _lib
+        assert _lib.device_count() >= 1
+    return request.param

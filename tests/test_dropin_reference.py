@@ -1,0 +1,60 @@
+"""Drop-in check against the REAL reference driver (dev container only: needs /root/reference and
+the scratch Cython build made by tests/golden/make_golden.py; skipped elsewhere, never on the GPU
+box).  The stock ``ReactiveNestedSampler`` is run UNMODIFIED with this package's region / layer
+classes plugged in through its own plug points (``run(region_class=...)``, the
+``transform_layer_class`` attribute, and the names integrator.py imports from .mlfriends), with
+``vectorized=True``.  Kernels are the oracle stub here (no GPU in this container); because masks
+are bit-exact and the np.random call order is preserved, the run must reproduce the stock run's
+trajectory EXACTLY (same ncall, niter, logz as fixture g8_c1_run.json)."""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+REF = "/root/reference"
+SCRATCH = os.environ.get("ULTRANEST_REFBUILD") or os.path.join(tempfile.gettempdir(), "ultranest_refbuild")
+have_ref = os.path.isdir(REF) and os.path.isdir(os.path.join(SCRATCH, "ultranest"))
+
+pytestmark = pytest.mark.skipif(not have_ref, reason="reference tree / scratch build not present (dev container only)")
+
+
+def test_c1_run_reproduces_stock_trajectory(monkeypatch):
+    import oracle_backend
+    oracle_backend.install(monkeypatch)
+    sys.path.insert(0, SCRATCH)
+    try:
+        import ultranest
+        import ultranest.integrator as integ
+    finally:
+        sys.path.remove(SCRATCH)
+    import ultranest_amd.mlfriends as mine
+    for name in ("AffineLayer", "LocalAffineLayer", "MLFriends", "RobustEllipsoidRegion", "ScalingLayer",
+                 "WrappingEllipsoid", "find_nearby"):
+        assert hasattr(integ, name)
+        monkeypatch.setattr(integ, name, getattr(mine, name))
+
+    ndim, sigma = 5, 0.01
+    centers = np.ones(ndim) * 0.5
+    ncalls = [0]
+
+    def loglike(theta):
+        assert theta.ndim == 2 and theta.flags.c_contiguous
+        ncalls[0] += len(theta)
+        return -0.5 * (((theta - centers) / sigma) ** 2).sum(axis=1) - 0.5 * np.log(2 * np.pi * sigma ** 2) * ndim
+
+    np.random.seed(1)
+    sampler = ultranest.ReactiveNestedSampler(["p%d" % i for i in range(ndim)], loglike,
+                                              transform=lambda x: x, vectorized=True, log_dir=None)
+    assert sampler.transform_layer_class is mine.LocalAffineLayer
+    res = sampler.run(min_num_live_points=400, viz_callback=None, show_status=False, region_class=mine.MLFriends)
+    assert isinstance(sampler.region, mine.MLFriends)
+    assert isinstance(sampler.transformLayer, mine.LocalAffineLayer)
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g8_c1_run.json")))
+    assert int(res["ncall"]) == gold["ncall"]
+    assert ncalls[0] == gold["ncall"] + 2          # + the 2 test points of _check_likelihood_function (integrator.py:1270)
+    assert int(res["niter"]) == gold["niter"]
+    assert res["logz"] == gold["logz"] and res["logzerr"] == gold["logzerr"]
+    assert abs(res["logz"]) < 3 * res["logzerr"] + 0.5          # analytic logZ = 0

@@ -38,7 +38,7 @@ SIGNATURES = {
     "mlf_bootstrap_quadform_max": [_vp, _sz, _sz, _vp, _sz, _vp, _vp, _vp],
     "mlf_region_create": [_vp],
     "mlf_region_destroy": [_vp],
-    "mlf_region_set": [_vp, _vp, _sz, _sz, _int, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int],
+    "mlf_region_set": [_vp, _vp, _sz, _sz, _int, _int, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int],
     "mlf_region_update_point": [_vp, _sz, _vp],
     "mlf_region_set_thresholds": [_vp, _dbl, _dbl],
     "mlf_region_set_ellipsoid_center": [_vp, _vp],

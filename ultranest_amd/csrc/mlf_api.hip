@@ -179,7 +179,7 @@ int prep_consts(DevBuf &ctr_b, DevBuf &mat_b, const double *ctr, const double *m
 struct mlf_region {
   bool ready = false;
   int n = 0, d = 0, dp = 0, npad = 0;
-  int layer_kind = 0, use_scan = 1;
+  int layer_kind = 0, use_scan = 1, live_space = 0;
   bool has_wrap = false;
   double enlarge = 0.0, r2 = 0.0;
   DevBuf refT, refR, lay_ctr, lay_mat, wrap, ell_ctr, ell_A;
@@ -189,6 +189,29 @@ struct mlf_region {
 };
 
 namespace {
+
+// whiten `n` cube-space rows already on the device with the region's own layer (same kernels and
+// arithmetic as for proposals, so a live point is at distance exactly 0 from itself)
+int region_whiten_rows(mlf_region *r, const double *d_u, size_t n, double *d_t, hipStream_t s) {
+  if (r->layer_kind == 0) {
+    PrepArgs pa{};
+    pa.pts = d_u;
+    pa.np = (long long)n;
+    pa.d = r->d;
+    pa.do_tr = 1;
+    pa.lay_ctr = r->lay_ctr.as<double>();
+    pa.lay_Tt = r->lay_mat.as<double>();
+    pa.wrap_shift = r->has_wrap ? r->wrap.as<double>() : nullptr;
+    pa.t_out = d_t;
+    pa.ldt = r->d;
+    CK(launch_prep(r->dp, pa, s));
+  } else {
+    launch_scaling_transform(d_u, (long long)n, r->d, r->lay_ctr.as<double>(), r->lay_mat.as<double>(),
+                             r->has_wrap ? r->wrap.as<double>() : nullptr, nullptr, d_t, r->d, s);
+    CK(hipGetLastError());
+  }
+  return 0;
+}
 
 int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t *d_mask,
                           hipStream_t s, hipEvent_t *ev /* 3 events or null */,
@@ -548,10 +571,10 @@ int mlf_region_destroy(mlf_region *r) {
   return 0;
 }
 
-int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int layer_kind,
-                   const double *layer_ctr, const double *layer_T, const double *wrap_shift,
-                   const double *ell_center, const double *ell_invcov, double enlarge,
-                   double radiussq, int use_scan) {
+int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int live_space,
+                   int layer_kind, const double *layer_ctr, const double *layer_T,
+                   const double *wrap_shift, const double *ell_center, const double *ell_invcov,
+                   double enlarge, double radiussq, int use_scan) {
   if (!r) return fail_arg(MLF_E_BADARG, "null region");
   if (int rc = check_dims(d)) return rc;
   if (!ell_center || !ell_invcov) return fail_arg(MLF_E_BADARG, "null ellipsoid");
@@ -566,6 +589,7 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
   r->dp = pick_dp((int)d);
   r->npad = round_up((int)n, kWave);
   r->layer_kind = layer_kind;
+  r->live_space = live_space ? 1 : 0;
   r->use_scan = use_scan ? 1 : 0;
   r->enlarge = enlarge;
   r->r2 = radiussq;
@@ -574,12 +598,6 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
   if (int rc = prep_consts(r->ell_ctr, r->ell_A, ell_center, ell_invcov, (int)d, dp, false, c.stream))
     return rc;
   if (use_scan) {
-    if (int rc = upload(c.src, unormed, n * d * sizeof(double), c.stream)) return rc;
-    CK(r->refT.reserve((size_t)r->npad * dp * sizeof(double)));
-    CK(r->refR.reserve((size_t)r->npad * dp * sizeof(double)));
-    launch_build_layouts(c.src.as<double>(), (int)n, (int)d, dp, r->npad, r->refT.as<double>(),
-                         r->refR.as<double>(), c.stream);
-    CK(hipGetLastError());
     if (layer_kind == 0) {
       if (int rc = prep_consts(r->lay_ctr, r->lay_mat, layer_ctr, layer_T, (int)d, dp, true, c.stream))
         return rc;
@@ -592,6 +610,18 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
       if (int rc = upload(r->wrap, w.data(), w.size() * sizeof(double), c.stream)) return rc;
       CK(hipStreamSynchronize(c.stream));  // w goes out of scope
     }
+    if (int rc = upload(c.src, unormed, n * d * sizeof(double), c.stream)) return rc;
+    const double *rows = c.src.as<double>();
+    if (r->live_space) {  // rows are cube-space live points: whiten them on the device
+      CK(c.tq.reserve(n * d * sizeof(double)));
+      if (int rc = region_whiten_rows(r, c.src.as<double>(), n, c.tq.as<double>(), c.stream)) return rc;
+      rows = c.tq.as<double>();
+    }
+    CK(r->refT.reserve((size_t)r->npad * dp * sizeof(double)));
+    CK(r->refR.reserve((size_t)r->npad * dp * sizeof(double)));
+    launch_build_layouts(rows, (int)n, (int)d, dp, r->npad, r->refT.as<double>(), r->refR.as<double>(),
+                         c.stream);
+    CK(hipGetLastError());
   }
   CK(hipStreamSynchronize(c.stream));
   r->ready = true;
@@ -603,8 +633,15 @@ int mlf_region_update_point(mlf_region *r, size_t row, const double *unormed_row
   if (!r->ready || !r->use_scan) return fail_arg(MLF_E_STATE, "region has no live points set");
   if (row >= (size_t)r->n) return fail_arg(MLF_E_BADARG, "row out of range");
   Ctx &c = g_ctx;
+  CK(r->row.reserve(2 * (size_t)r->d * sizeof(double)));
   if (int rc = upload(r->row, unormed_row, r->d * sizeof(double), c.stream)) return rc;
-  launch_update_row(r->row.as<double>(), r->d, r->dp, r->npad, (int)row, r->refT.as<double>(),
+  const double *src = r->row.as<double>();
+  if (r->live_space) {
+    double *dst = r->row.as<double>() + r->d;
+    if (int rc = region_whiten_rows(r, src, 1, dst, c.stream)) return rc;
+    src = dst;
+  }
+  launch_update_row(src, r->d, r->dp, r->npad, (int)row, r->refT.as<double>(),
                     r->refR.as<double>(), c.stream);
   CK(hipGetLastError());
   CK(hipStreamSynchronize(c.stream));

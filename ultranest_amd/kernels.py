@@ -161,10 +161,12 @@ class DeviceRegion(object):
         except Exception:
             pass
 
-    def set(self, unormed, layer_kind, layer_ctr, layer_T, wrap_shift, ell_center, ell_invcov,
-            enlarge, radiussq, use_scan=True):
+    def set(self, live, layer_kind, layer_ctr, layer_T, wrap_shift, ell_center, ell_invcov,
+            enlarge, radiussq, use_scan=True, live_space=0):
+        """`live` holds region.unormed (live_space=0) or region.u (live_space=1: whitened on the
+        device with the proposal kernel, see include/mlfriends_hip.h)."""
         d = len(ell_center)
-        un = None if unormed is None else f64(unormed)
+        un = None if live is None else f64(live)
         n = 0 if un is None else un.shape[0]
         lc = None if layer_ctr is None else f64(np.broadcast_to(layer_ctr, (d,)))
         if layer_T is None:
@@ -175,7 +177,7 @@ class DeviceRegion(object):
             lt = f64(layer_T)
         ws = None if wrap_shift is None else f64(wrap_shift)
         self._keep = (un, lc, lt, ws)
-        check(_lib.lib().mlf_region_set(self._h, ptr(un), n, d, int(layer_kind), ptr(lc), ptr(lt), ptr(ws),
+        check(_lib.lib().mlf_region_set(self._h, ptr(un), n, d, int(live_space), int(layer_kind), ptr(lc), ptr(lt), ptr(ws),
                                         ptr(f64(ell_center)), ptr(f64(ell_invcov)), float(enlarge),
                                         float(radiussq), int(bool(use_scan))))
 

@@ -1,0 +1,488 @@
+"""Region classes with the API of the reference's ``MLFriends``, ``RobustEllipsoidRegion``,
+``SimpleRegion`` and ``WrappingEllipsoid`` (reference ultranest/mlfriends.pyx:915-1649), built on
+the MI355X kernels.
+
+The driver (reference integrator.py, not part of this package) only ever does
+``region_class(active_u, transformLayer)`` (:1996, :2079) and then reads / MUTATES attributes
+(``u``, ``unormed``, ``maxradiussq``, ``enlarge``, ``ellipsoid_center`` ... :2749-2765, :2827), so
+these classes keep plain numpy attributes on the host as the source of truth and mirror them to
+the device lazily: before every device call the host arrays are diffed against the last uploaded
+snapshot and only what changed is sent (usually one live-point row per iteration).
+
+What runs where:
+  GPU   pair distances (bootstrapped radius K4, neighbour scans K1/K2, subtract_nearby K3),
+        ellipsoid quadratic forms over batches (H3), affine transform of proposal batches (T1),
+        bootstrap moments + enlargement factor
+  host  d x d LAPACK (cov inverse, eigh), random draws (the reference's ``np.random`` call
+        order is preserved so seeded runs follow the same trajectory)
+"""
+import numpy as np
+
+from . import kernels
+from .layers import int_dtype
+
+# When True, ``MLFriends.inside`` transforms ellipsoid-passing points on the host with the same
+# ``np.dot`` the reference uses (bit-identical t-space points on the same machine) and only the
+# neighbour scan runs on the GPU.  Default: fully device-side pipeline.
+STRICT_HOST_TRANSFORM = False
+# When True, bootstrap ellipsoid moments come from numpy (mean / cov exactly as the reference
+# computes them); default: GPU two-pass moments (agree to ~1e-13 relative).
+STRICT_HOST_MOMENTS = False
+
+
+def vol_prefactor(n):
+    """Volume of the unit n-ball (reference mlfriends.pyx:853-879): recurrence
+    V_n = V_{n-2} * 2 pi / n from V_0 = 1, V_1 = 2."""
+    n = int(n)
+    vol = 1. if n % 2 == 0 else 2.
+    for i in range(2 if n % 2 == 0 else 3, n + 1, 2):
+        vol *= 2. / i * np.pi
+    return vol
+
+
+def make_eigvals_positive(a, targetprod):
+    """Lift (near-)zero eigenvalues of the symmetric matrix `a` so that the product of all
+    eigenvalues reaches `targetprod` (reference mlfriends.pyx:389-421)."""
+    assert np.isfinite(a).all(), a
+    w, v = np.linalg.eigh(a)
+    tiny = w < max(1.e-10, 1e-300**(1. / len(a)))
+    if np.any(tiny):
+        w[tiny] = (targetprod / np.prod(w[~tiny])) ** (1. / tiny.sum())
+        a = np.dot(np.dot(v, np.diag(w)), np.linalg.inv(v))
+    return a
+
+
+def bounding_ellipsoid(x, minvol=0.):
+    """Centre and (d+2)-inflated sample covariance of the points `x`
+    (reference mlfriends.pyx:426-476)."""
+    ndim = x.shape[1]
+    ctr = np.mean(x, axis=0)
+    cov = np.cov(x - ctr, rowvar=0)
+    assert np.isfinite(cov).all(), (cov, x)
+    if ndim == 1:
+        cov = np.atleast_2d(cov)
+    cov *= (ndim + 2)
+    if minvol > 0:
+        cov = make_eigvals_positive(cov, minvol)
+    return ctr, cov
+
+
+def _inside_ellipsoid(points, ellipsoid_center, ellipsoid_invcov, square_radius):
+    """``(p-c)^T invcov (p-c) <= square_radius`` per row (reference mlfriends.pyx:882-912); the
+    quadratic form is evaluated on the GPU in numpy's einsum order."""
+    return kernels.inside_ellipsoid(points, ellipsoid_center, ellipsoid_invcov, square_radius)
+
+
+def _draw_selection(rng, npoints, nbootstraps):
+    """(B, N) bootstrap selection masks; ONE ``rng.randint(N, size=N)`` per round, drawn before
+    any validity check, exactly like the reference (mlfriends.pyx:1044-1047)."""
+    masks = np.zeros((nbootstraps, npoints), dtype=bool)
+    for b in range(nbootstraps):
+        masks[b, rng.randint(npoints, size=npoints)] = True
+    return masks
+
+
+def _bootstrap_enlargement(u, masks, minvol):
+    """Per-round wrapping-ellipsoid enlargement f_b (reference mlfriends.pyx:1056-1066):
+    ellipsoid of the selected points, largest Mahalanobis distance of the left-out ones."""
+    nrounds, ndim = len(masks), u.shape[1]
+    if STRICT_HOST_MOMENTS:
+        ctrs = np.empty((nrounds, ndim))
+        covs = np.empty((nrounds, ndim, ndim))
+        for b, m in enumerate(masks):
+            ctrs[b], covs[b] = bounding_ellipsoid(u[m], minvol=minvol)
+    else:
+        ctrs, covs = kernels.bootstrap_moments(u, masks)
+        assert np.isfinite(covs).all(), (covs, u)
+        covs *= (ndim + 2)
+        if minvol > 0:
+            for b in range(nrounds):
+                covs[b] = make_eigvals_positive(covs[b], minvol)
+    precisions = np.linalg.inv(covs)      # LinAlgError on a singular round, as in the reference
+    return kernels.bootstrap_quadform_max(u, masks, ctrs, precisions)
+
+
+class _DeviceState(object):
+    """Lazy mirror of a region's host attributes on the GPU (see module docstring).
+
+    The small constants (layer, ellipsoid matrix) are compared BY VALUE with the last upload;
+    the live points are diffed row-wise so that the driver's in-place replacement of one live
+    point per iteration costs one row upload."""
+
+    def __init__(self):
+        self.handle = None
+        self.consts = None
+        self.live = None
+        self.ell_center = None
+        self.thresholds = None
+
+    @staticmethod
+    def _same(a, b):
+        if len(a) != len(b):
+            return False
+        for x, y in zip(a, b):
+            if x is None or y is None or np.isscalar(x) or np.isscalar(y):
+                if not (x is None and y is None) and not (np.isscalar(x) and np.isscalar(y) and x == y):
+                    return False
+            elif x.shape != y.shape or not np.array_equal(x, y, equal_nan=True):
+                return False
+        return True
+
+    def sync(self, region, use_scan):
+        ndim = region.u.shape[1]
+        if use_scan:
+            if region.maxradiussq is None:
+                raise TypeError("region.maxradiussq is None: bootstrap the radius before testing membership")
+            kind, lctr, lmat = region.transformLayer.device_params(ndim)
+            shift = region.transformLayer.wrap_shift_vector(ndim)
+            r2 = float(region.maxradiussq)
+            nlive = len(region.u)
+        else:
+            kind, lctr, lmat, shift, r2, nlive = 0, None, None, None, 1e300, 0
+        consts = (kind, lctr, lmat, shift, np.asarray(region.ellipsoid_invcov), int(use_scan), nlive)
+        thresholds = (float(region.enlarge), r2)
+        if self.handle is None:
+            self.handle = kernels.DeviceRegion()
+        full = self.consts is None or not self._same(consts, self.consts)
+        changed = ()
+        if not full and use_scan:
+            changed = np.flatnonzero((self.live != region.u).any(axis=1))
+            full = len(changed) > max(8, nlive // 8)
+        if full:
+            # the device whitens region.u itself (live_space=1): live points and proposals then go
+            # through the same arithmetic, so a live point is at distance exactly 0 from itself
+            self.handle.set(region.u if use_scan else None, kind, lctr, lmat, shift,
+                            region.ellipsoid_center, region.ellipsoid_invcov, thresholds[0], thresholds[1],
+                            use_scan=use_scan, live_space=1)
+            self.consts = tuple(None if c is None else (c if np.isscalar(c) else np.array(c, dtype=float)) for c in consts)
+            self.live = np.array(region.u, dtype=float) if use_scan else None
+            self.ell_center = np.array(region.ellipsoid_center, dtype=float)
+            self.thresholds = thresholds
+            return self.handle
+        for row in changed:
+            self.handle.update_point(row, region.u[row])
+            self.live[row] = region.u[row]
+        if not np.array_equal(self.ell_center, region.ellipsoid_center):
+            self.handle.set_ellipsoid_center(region.ellipsoid_center)
+            self.ell_center = np.array(region.ellipsoid_center, dtype=float)
+        if thresholds != self.thresholds:
+            self.handle.set_thresholds(*thresholds)
+            self.thresholds = thresholds
+        return self.handle
+
+
+class MLFriends(object):
+    """MLFriends region: the union of balls of radius sqrt(maxradiussq) around the whitened
+    live points, intersected with a wrapping ellipsoid (reference mlfriends.pyx:915-1257)."""
+
+    def __init__(self, u, transformLayer):
+        ok = np.logical_and(u > 0, u < 1)
+        if not ok.all():
+            raise ValueError("not all u values are between 0 and 1: %s" % u[~ok.all(axis=1)])
+        self.u = u
+        self.enlarge = None
+        self._dev = _DeviceState()
+        self.set_transformLayer(transformLayer)
+        self.sampling_methods = [
+            self.sample_from_transformed_boundingbox,
+            self.sample_from_boundingbox,
+            self.sample_from_points,
+            self.sample_from_wrapping_ellipsoid,
+        ]
+        self.current_sampling_method = self.sample_from_boundingbox
+        self.vol_prefactor = vol_prefactor(self.u.shape[1])
+
+    # ---- geometry state ------------------------------------------------------------------
+    def set_transformLayer(self, transformLayer):
+        """Adopt a new whitening layer; the radius becomes invalid (reference :972-986)."""
+        self.transformLayer = transformLayer
+        self.unormed = self.transformLayer.transform(self.u)
+        assert np.isfinite(self.unormed).all(), (self.unormed, self.u)
+        self.bbox_lo = self.unormed.min(axis=0)
+        self.bbox_hi = self.unormed.max(axis=0)
+        self.maxradiussq = None
+
+    def estimate_volume(self):
+        """log-volume scale of one ball in u-space: logvolscale + d*log(r) (reference :953-970)."""
+        r = self.maxradiussq**0.5
+        ndim = self.u.shape[1]
+        return self.transformLayer.logvolscale + np.log(r) * ndim
+
+    def create_ellipsoid(self, minvol=0.0):
+        """Wrapping ellipsoid of all live points and its principal axes (reference :1213-1237)."""
+        assert self.enlarge is not None
+        ctr, cov = bounding_ellipsoid(self.u, minvol=minvol)
+        precision = np.linalg.inv(cov)
+        self.ellipsoid_center = ctr
+        self.ellipsoid_invcov = precision
+        self.ellipsoid_cov = cov
+        self._set_axes(precision, cov)
+
+    def _set_axes(self, precision, cov):
+        lam, vec = np.linalg.eigh(precision)
+        self.ellipsoid_axlens = 1. / np.sqrt(lam)
+        self.ellipsoid_axes = np.dot(vec, np.diag(self.ellipsoid_axlens))
+        self.ellipsoid_axes_T = self.ellipsoid_axes.transpose()
+        lam2, vec2 = np.linalg.eigh(cov)
+        self.ellipsoid_inv_axlens = 1. / np.sqrt(lam2)
+        self.ellipsoid_inv_axes = np.dot(vec2, np.diag(self.ellipsoid_inv_axlens))
+
+    # ---- bootstrapping ---------------------------------------------------------------------
+    def compute_maxradiussq(self, nbootstraps=50):
+        """Bootstrapped MLFriends radius only, global ``np.random`` stream, no all/none guard
+        (reference :988-1015).  All rounds run in one GPU pass."""
+        npoints = len(self.u)
+        masks = _draw_selection(np.random, npoints, nbootstraps)
+        r2, _ = kernels.maxradiussq_bootstrap(self.unormed, masks)
+        maxd = float(max(0.0, r2.max())) if len(r2) else 0.0
+        assert maxd > 0, (maxd, self.u)
+        return maxd
+
+    def compute_enlargement(self, nbootstraps=50, minvol=0., rng=np.random):
+        """(maxradiussq, enlarge) from `nbootstraps` leave-out rounds (reference :1017-1070).
+        Rounds that select all or no points contribute nothing (:1048)."""
+        npoints = len(self.u)
+        assert np.isfinite(self.unormed).all(), self.unormed
+        masks = _draw_selection(rng, npoints, nbootstraps)
+        r2, skipped = kernels.maxradiussq_bootstrap(self.unormed, masks)
+        use = ~skipped
+        maxd, maxf = 0.0, 0.0
+        if use.any():
+            maxd = float(r2[use].max())
+            f = _bootstrap_enlargement(self.u, masks[use], minvol)
+            assert np.isfinite(f).all(), (f, self.unormed)
+            if not (f > 0).all():
+                raise np.linalg.LinAlgError("Distances are not positive")
+            maxf = float(f.max())
+        assert maxd > 0, (maxd, self.u, self.unormed)
+        assert maxf > 0, (maxf, self.u, self.unormed)
+        return maxd, maxf
+
+    # ---- membership ------------------------------------------------------------------------
+    def inside_ellipsoid(self, u):
+        return _inside_ellipsoid(u, self.ellipsoid_center, self.ellipsoid_invcov, self.enlarge)
+
+    def inside(self, pts):
+        """True where `pts` lie in the wrapping ellipsoid AND within the radius of some live
+        point (reference :1186-1211).  One device pipeline: quadratic form -> whitening ->
+        neighbour scan gated on the ellipsoid result."""
+        pts = np.asarray(pts)
+        if STRICT_HOST_TRANSFORM:
+            mask = self.inside_ellipsoid(pts)
+            if mask.any():
+                tpts = self.transformLayer.transform(pts[mask, :])
+                idnearby = np.empty(len(tpts), dtype=int_dtype)
+                kernels.find_nearby(self.unormed, tpts, self.maxradiussq, idnearby)
+                mask[mask] = idnearby >= 0
+            return mask
+        return self._dev.sync(self, True).inside(pts)
+
+    def compute_mean_pair_distance(self):
+        return kernels.compute_mean_pair_distance(self.unormed, self.transformLayer.clusterids)
+
+    # ---- proposal generators (np.random call order = reference) -------
+    def _near_live_points(self, tpts):
+        idnearby = np.empty(len(tpts), dtype=int_dtype)
+        kernels.find_nearby(self.unormed, tpts, self.maxradiussq, idnearby)
+        return idnearby >= 0
+
+    def sample_from_points(self, nsamples=100):
+        """Pick live points at random, draw uniformly in their balls, thin by 1/multiplicity
+        (reference :1072-1094)."""
+        npoints, ndim = self.u.shape
+        which = np.random.randint(npoints, size=nsamples)
+        direction = np.random.normal(size=(nsamples, ndim))
+        direction *= (np.random.uniform(size=nsamples)**(1. / ndim) / np.linalg.norm(direction, axis=1)).reshape((-1, 1))
+        tpts = self.unormed[which, :] + direction * self.maxradiussq**0.5
+        multiplicity = np.empty(nsamples, dtype=int_dtype)
+        kernels.count_nearby(self.unormed, tpts, self.maxradiussq, multiplicity)
+        keep = np.random.uniform(high=multiplicity) < 1
+        w = self.transformLayer.untransform(tpts[keep, :])
+        ok = np.logical_and(w > 0, w < 1).all(axis=1)
+        ok[ok] = self.inside_ellipsoid(w[ok])
+        return w[ok, :]
+
+    def sample_from_boundingbox(self, nsamples=100):
+        """Uniform in the unit cube, filtered by the region (reference :1096-1112)."""
+        ndim = self.u.shape[1]
+        u = np.random.uniform(size=(nsamples, ndim))
+        return u[self.inside(u), :]
+
+    def sample_from_transformed_boundingbox(self, nsamples=100):
+        """Uniform in the padded t-space bounding box (reference :1114-1133)."""
+        ndim = self.u.shape[1]
+        pad = self.maxradiussq**0.5
+        tpts = np.random.uniform(self.bbox_lo - pad, self.bbox_hi + pad, size=(nsamples, ndim))
+        w = self.transformLayer.untransform(tpts[self._near_live_points(tpts), :])
+        ok = np.logical_and(w > 0, w < 1).all(axis=1)
+        ok[ok] = self.inside_ellipsoid(w[ok])
+        return w[ok, :]
+
+    def _draw_in_ellipsoid(self, nsamples):
+        ndim = self.u.shape[1]
+        z = np.random.normal(size=(nsamples, ndim))
+        norm2 = (z**2).sum(axis=1)
+        assert (norm2 > 0).all(), norm2
+        z /= (norm2**0.5).reshape((nsamples, 1))
+        assert self.enlarge > 0, self.enlarge
+        z = z * self.enlarge**0.5 * np.random.uniform(size=(nsamples, 1))**(1. / ndim)
+        w = self.ellipsoid_center + np.dot(z, self.ellipsoid_axes_T)
+        return w[np.logical_and(w > 0, w < 1).all(axis=1), :]
+
+    def sample_from_wrapping_ellipsoid(self, nsamples=100):
+        """Uniform in the wrapping ellipsoid, filtered by cube and neighbour scan
+        (reference :1135-1160)."""
+        w = self._draw_in_ellipsoid(nsamples)
+        return w[self._near_live_points(self.transformLayer.transform(w)), :]
+
+    def sample(self, nsamples=100):
+        """Accepted draws of the current method; an empty batch re-rolls the method
+        (reference :1162-1184)."""
+        samples = self.current_sampling_method(nsamples=nsamples)
+        if len(samples) == 0:
+            self.current_sampling_method = self.sampling_methods[np.random.randint(len(self.sampling_methods))]
+        return samples
+
+
+class RobustEllipsoidRegion(MLFriends):
+    """Single bootstrapped ellipsoid; no neighbour scan (reference mlfriends.pyx:1260-1457)."""
+
+    def __init__(self, u, transformLayer):
+        MLFriends.__init__(self, u, transformLayer)
+        self.sampling_methods = [
+            self.sample_from_boundingbox,
+            self.sample_from_wrapping_ellipsoid,
+        ]
+        self.current_sampling_method = self.sample_from_boundingbox
+
+    def sample_from_boundingbox(self, nsamples=100):
+        ndim = self.u.shape[1]
+        u = np.random.uniform(size=(nsamples, ndim))
+        return u[self.inside_ellipsoid(u), :]
+
+    def sample_from_transformed_boundingbox(self, nsamples=100):
+        # pads by maxradiussq (not its root) like the reference (:1319); not in sampling_methods
+        ndim = self.u.shape[1]
+        tpts = np.random.uniform(self.bbox_lo - self.maxradiussq, self.bbox_hi + self.maxradiussq, size=(nsamples, ndim))
+        w = self.transformLayer.untransform(tpts)
+        ok = np.logical_and(w > 0, w < 1).all(axis=1)
+        ok[ok] = self.inside_ellipsoid(w[ok])
+        return w[ok, :]
+
+    def sample_from_wrapping_ellipsoid(self, nsamples=100):
+        return self._draw_in_ellipsoid(nsamples)
+
+    def inside(self, pts):
+        return self.inside_ellipsoid(pts)
+
+    def inside_ellipsoid(self, u):
+        return self._dev.sync(self, False).inside(np.asarray(u))
+
+    def _selected_stats(self, sel):
+        return bounding_ellipsoid(self.u[sel, :])
+
+    def compute_enlargement(self, nbootstraps=50, minvol=0., rng=np.random):
+        """Bootstrapped ellipsoid enlargement; the radius is reported as 1e300
+        (reference :1392-1440)."""
+        npoints, ndim = self.u.shape
+        if npoints < ndim + 1:
+            raise FloatingPointError('not enough live points to compute covariance')
+        assert np.isfinite(self.unormed).all(), self.unormed
+        masks = _draw_selection(rng, npoints, nbootstraps)
+        f = _bootstrap_enlargement(self.u, masks, 0.)
+        assert np.isfinite(f).all(), (f, self.unormed)
+        if not (f > 0).all():
+            raise np.linalg.LinAlgError("Distances are not positive")
+        maxf = float(f.max()) if len(f) else 0.0
+        assert maxf > 0, (maxf, self.u, self.unormed)
+        return 1e300, maxf
+
+    def estimate_volume(self):
+        """log-volume of the ellipsoid (reference :1442-1457)."""
+        ndim = len(self.ellipsoid_cov)
+        sign, logvol = np.linalg.slogdet(self.ellipsoid_cov)
+        if sign > 0:
+            return logvol + ndim * np.log(self.enlarge)
+        return -1e300
+
+
+class SimpleRegion(RobustEllipsoidRegion):
+    """Axis-aligned ellipsoid (reference mlfriends.pyx:1460-1548)."""
+
+    def create_ellipsoid(self, minvol=0.0):
+        assert self.enlarge is not None
+        var = np.var(self.u, axis=0)
+        self.ellipsoid_center = np.mean(self.u, axis=0)
+        self.ellipsoid_invcov = np.diag(1. / var)
+        self.ellipsoid_cov = np.diag(var)
+        self._set_axes(self.ellipsoid_invcov, self.ellipsoid_cov)
+
+    def compute_enlargement(self, nbootstraps=50, minvol=0., rng=np.random):
+        """Per-axis variant.  NOTE the reference sums the normalised squared offsets over the
+        POINTS (axis 0) and maximises over dimensions (:1540); reproduced as is."""
+        npoints, ndim = self.u.shape
+        assert np.isfinite(self.u).all(), self.u
+        assert np.isfinite(self.unormed).all(), self.unormed
+        if npoints < ndim + 1:
+            raise FloatingPointError('not enough live points to compute variance')
+        maxf = 0.0
+        for sel in _draw_selection(rng, npoints, nbootstraps):
+            ctr = np.mean(self.u[sel, :], axis=0)
+            var = np.var(self.u[sel, :], axis=0)
+            f = np.sum((self.u[~sel, :] - ctr.reshape((1, -1)))**2 / var, axis=0).max()
+            assert np.isfinite(f), (self.u, ctr, var, self.unormed, f)
+            if not f > 0:
+                raise np.linalg.LinAlgError("Distances are not positive")
+            maxf = max(maxf, f)
+        assert maxf > 0, (maxf, self.u, self.unormed)
+        return 1e300, maxf
+
+
+class WrappingEllipsoid(object):
+    """Bootstrapped ellipsoid around points in the user's parameter space, applied to every
+    proposal batch by the driver (reference mlfriends.pyx:1551-1649, integrator.py:1794).
+    Dimensions in which all points coincide are checked for equality instead."""
+
+    def __init__(self, u):
+        self.u = u
+        self.variable_dims = np.std(self.u, axis=0) > 0
+        if self.variable_dims.all():
+            self.variable_dims = Ellipsis
+        self.enlarge = None
+
+    def compute_enlargement(self, nbootstraps=50, rng=np.random):
+        npoints = len(self.u)
+        v = np.ascontiguousarray(self.u[:, self.variable_dims])
+        masks = _draw_selection(rng, npoints, nbootstraps)
+        f = _bootstrap_enlargement(v, masks, 0.)
+        if not (f > 0).all():
+            raise np.linalg.LinAlgError("Distances are not positive")
+        maxf = float(f.max()) if len(f) else 0.0
+        assert maxf > 0, (maxf, self.u)
+        return maxf
+
+    def create_ellipsoid(self, minvol=0.0):
+        assert self.enlarge is not None
+        ctr, cov = bounding_ellipsoid(self.u[:, self.variable_dims], minvol=minvol)
+        precision = np.linalg.inv(cov)
+        self.ellipsoid_center = ctr
+        self.ellipsoid_invcov = precision
+        self.ellipsoid_cov = cov
+        lam, vec = np.linalg.eigh(precision)
+        self.ellipsoid_axlens = 1. / np.sqrt(lam)
+        self.ellipsoid_axes = np.dot(vec, np.diag(self.ellipsoid_axlens))
+
+    def update_center(self, ctr):
+        if self.variable_dims is Ellipsis:
+            self.ellipsoid_center = ctr
+        else:
+            self.ellipsoid_center = ctr[self.variable_dims]
+
+    def inside(self, u):
+        u = np.asarray(u)
+        inside_variable = _inside_ellipsoid(u[:, self.variable_dims], self.ellipsoid_center,
+                                            self.ellipsoid_invcov, self.enlarge)
+        if self.variable_dims is Ellipsis:
+            return inside_variable
+        inside_fixed = np.all(self.u[0, ~self.variable_dims] == u[:, ~self.variable_dims], axis=1)
+        return np.logical_and(inside_fixed, inside_variable)
