@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the MLFriends hot path on MI355X (BASELINE.json metric):
+proposal points filtered per second through MLFriends.inside + region-rebuild ms, N=4000 live
+points, d=50.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of MLFriends.inside (wrapping-ellipsoid test -> whitening -> neighbour
+scan) over one batch of P = 10^6 synthetic proposals that is already resident in HBM when the
+timed region starts.  Weak scaling: every rank (one process per GPU) filters its own batch of P
+proposals against the replicated region; there is no collective in the data path.  The region
+itself is built with the sharded bootstrap (RCCL max-all-reduce of 3 doubles when N > 1).
+
+Workload (configuration C5): live points u = 0.5 + 0.05*normal (RandomState(1)),
+AffineLayer, 30 bootstrap rounds, proposal set "E" = uniform draws inside the wrapping
+ellipsoid (every proposal passes the ellipsoid test and reaches the neighbour scan).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_LIVE, NDIM, NPROPOSALS, NBOOT = 4000, 50, 1000000, 30
+FP64_VALU_PEAK_TFLOPS = 39.3     # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz, one flop per non-fused v_*_f64
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def build_region(group):
+    import ultranest_amd.mlfriends as M
+    from ultranest_amd import distributed
+    rs = np.random.RandomState(1)
+    u = 0.5 + 0.05 * rs.normal(size=(N_LIVE, NDIM))
+    assert np.logical_and(u > 0, u < 1).all()
+    layer = M.AffineLayer()
+    layer.optimize(u, u)
+    region = M.MLFriends(u, layer)
+    distributed.update_region_bootstrap(region, NBOOT, minvol=0., group=group, rng=rs)
+    region.create_ellipsoid(minvol=0.)
+    return u, region
+
+
+def proposals_in_ellipsoid(region, p, seed, dev):
+    """set E on the device: center + (z/|z| * sqrt(enlarge) * U^(1/d)) @ axes^T"""
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    d = len(region.ellipsoid_center)
+    z = torch.randn(p, d, dtype=torch.float64, device=dev, generator=g)
+    z /= z.norm(dim=1, keepdim=True)
+    z *= region.enlarge ** 0.5 * torch.rand(p, 1, dtype=torch.float64, device=dev, generator=g) ** (1.0 / d)
+    pts = torch.as_tensor(region.ellipsoid_center, device=dev) + z @ torch.as_tensor(region.ellipsoid_axes_T.copy(), device=dev)
+    return pts.contiguous()
+
+
+def time_rebuild(u, group):
+    """Steady-state region rebuild (harness counterpart of the driver's _update_region: LocalAffineLayer
+    create_new incl. clustering + subtract_nearby, region ctor, 30 bootstrap rounds, create_ellipsoid,
+    inside(live points), shrink test) on the SURVEY 8d rebuild input."""
+    import ultranest_amd.mlfriends as M
+    from ultranest_amd.harness import RegionUpdater
+    rs = np.random.RandomState(7)
+    upd = RegionUpdater(NDIM, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer, group=group)
+    np.random.seed(11)
+    t0 = time.perf_counter()
+    upd.update(u, nbootstraps=NBOOT, minvol=0.)
+    first_ms = (time.perf_counter() - t0) * 1e3
+    steady = []
+    for rep in range(3):
+        u2 = u.copy()
+        u2[:N_LIVE // 10] = 0.5 + 0.045 * rs.normal(size=(N_LIVE // 10, NDIM))
+        t0 = time.perf_counter()
+        upd.update(u2, nbootstraps=NBOOT, minvol=0.)
+        steady.append((time.perf_counter() - t0) * 1e3)
+    return first_ms, float(np.median(steady))
+
+
+def cpu_baseline(region, pts_host, u):
+    """The CPU oracle (single-threaded C restatement of the reference's Cython loops,
+    oracle/mlfriends_oracle.c) on a bounded sample of the same proposals, on this box's host."""
+    from oracle import oracle as orc
+    layer = region.transformLayer
+    sample = pts_host
+    t0 = time.perf_counter()
+    mask = orc.region_inside(sample, region.unormed, layer.ctr, layer.T, region.ellipsoid_center,
+                             region.ellipsoid_invcov, region.enlarge, region.maxradiussq)
+    dt = time.perf_counter() - t0
+    rs = np.random.RandomState(3)
+    masks = orc.draw_bootstrap_masks(rs, N_LIVE, 3)
+    t0 = time.perf_counter()
+    orc.maxradiussq_bootstrap(region.unormed, masks)
+    boot_ms = (time.perf_counter() - t0) * 1e3 / 3 * NBOOT
+    return mask, dict(value=len(sample) / dt, unit="proposals/s", cores=1, kind="port",
+                      sample="first %d proposals of the timed batch (%.1f s); oracle/mlfriends_oracle.c, gcc -O3 "
+                             "-ffp-contract=off, 1 thread" % (len(sample), dt),
+                      bootstrap30_ms=boot_ms, host_cores_available=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu-sample", type=int, default=150000, help="proposals timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1 and args.gpus == 1, "launch one process per GPU (torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from ultranest_amd import _lib, kernels
+    _lib.set_device(local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    u, region = build_region(group)
+    handle = region._dev.sync(region, True)          # device-resident region state
+    pts = proposals_in_ellipsoid(region, NPROPOSALS, 1000 + rank, dev)
+    mask = torch.empty(NPROPOSALS, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    for _ in range(args.warmup):
+        handle.inside_dev(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
+    handle.timing_collect()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        handle.inside_dev_timed(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ncalls, ms_prep, ms_scan = handle.timing_collect()
+    accept = float(mask.float().mean().item())
+
+    # algorithmic work of the neighbour scan on this batch: the reference's loop stops at the first
+    # hit, so a proposal costs 3*d flops per live point visited = (first index + 1), or N if none
+    idx = torch.empty(NPROPOSALS, dtype=torch.int64, device=dev)
+    handle.first_index_dev(pts.data_ptr(), NPROPOSALS, idx.data_ptr(), stream)
+    torch.cuda.synchronize()
+    visited = torch.where(idx >= 0, idx + 1, torch.full_like(idx, N_LIVE))
+    visited = torch.where(idx == -2, torch.zeros_like(idx), visited)
+    scan_flops = 3.0 * NDIM * float(visited.sum().item())
+    ell_pass = float((idx != -2).float().mean().item())
+    assert bool(((idx >= 0) == (mask != 0)).all().item()), "index and mask pipelines disagree"
+
+    first_ms, rebuild_ms = time_rebuild(u, group)
+
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+
+    scan_ms = ms_scan / max(ncalls, 1)
+    prep_ms = ms_prep / max(ncalls, 1)
+    value = NPROPOSALS * world * args.steps / elapsed
+    alg_bytes = NPROPOSALS * (8 * NDIM + 1) + 8 * N_LIVE * NDIM + 2 * 8 * NDIM * NDIM
+    achieved_tflops = scan_flops / (scan_ms * 1e-3) / 1e12
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_scan_traffic.json")
+    if os.path.exists(pmc_file):
+        traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+    out = {
+        "metric": "proposal-points filtered/sec (MLFriends.inside) + region-rebuild ms, N=4000 d=50",
+        "value": value, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "C5: N=4000 live points, d=50, P=1e6 proposals/step/GPU drawn uniformly inside the "
+                               "wrapping ellipsoid (set E), AffineLayer, 30 bootstraps; one step = MLFriends.inside "
+                               "on a batch resident in HBM",
+                   "n_live": N_LIVE, "d": NDIM, "proposals_per_step_per_gpu": NPROPOSALS, "bootstraps": NBOOT,
+                   "parallelism": "proposal rows sharded over %d GPU(s), region replicated" % world},
+        "rebuild_ms": rebuild_ms, "rebuild_first_ms": first_ms,
+        "accept_fraction": accept, "ellipsoid_pass_fraction": ell_pass,
+        "kernel_ms": {"k_prep(ellipsoid+whiten)": prep_ms, "k_scan(neighbour scan)": scan_ms},
+        "roofline": {
+            "bound": "valu_fp64",
+            "note": "the scan is compute bound on NON-FUSED FP64 vector ops (bit-exactness forbids FMA and MFMA); "
+                    "SURVEY.md 8d. HBM figures are reported alongside as north_star asks.",
+            "achieved": achieved_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved_tflops / FP64_VALU_PEAK_TFLOPS,
+            "algorithmic_flops_per_launch": scan_flops,
+            "measured_valu_probe_tflops": kernels.bench_fp64_valu(),
+            "traffic": traffic,
+            "hbm": {"algorithmic_bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / (scan_ms * 1e-3) / 1e9,
+                    "peak_GBps": HBM_PEAK_GBPS, "frac": alg_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+        },
+    }
+    if world == 1 and not args.no_cpu:
+        sample = pts[:args.cpu_sample].cpu().numpy()
+        cmask, base = cpu_baseline(region, sample, u)
+        gmask = mask[:args.cpu_sample].cpu().numpy().astype(bool)
+        base["gpu_mask_equals_cpu_mask_on_sample"] = bool(np.array_equal(cmask, gmask))
+        base["speedup_1gpu_vs_1core"] = value / base["value"]
+        out["cpu_baseline"] = base
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

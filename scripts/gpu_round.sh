@@ -1,0 +1,28 @@
+#!/bin/bash
+# One GPU-box session: parity tests, smoke, headline bench, rocprofv3 kernel stats, PMC passes.
+# Everything lands under gpurun_out/ (merged back by gpurun); scripts/collect_profiles.py then
+# copies the summaries that are to be judged into profiles/.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
+echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+echo "== bench"; timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err; tail -c 2500 $O/bench.json; tail -3 $O/bench.err
+if [ "$1" != "noprof" ]; then
+cd /tmp && export TMPDIR=/tmp
+echo "== rocprofv3 stats"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu > $O/prof_stats.log 2>&1
+tail -2 $O/prof_stats.log
+for C in FETCH_SIZE WRITE_SIZE; do
+  echo "== rocprofv3 pmc $C"
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_$C -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu > $O/pmc_$C.log 2>&1
+  tail -1 $O/pmc_$C.log
+done
+echo "== rocprofv3 pmc SQ"
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_SQ -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu > $O/pmc_SQ.log 2>&1
+tail -1 $O/pmc_SQ.log
+find $O -name "*.csv" | head -30
+# keep the merge-back small: drop anything big
+find $O -size +8M -delete
+fi

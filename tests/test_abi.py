@@ -1,0 +1,69 @@
+"""C-ABI boundary (CPU): libmlfriends_hip.so loads without a GPU, exports every symbol that
+include/mlfriends_hip.h declares, the ctypes table binds each with the declared number of
+arguments, and compute calls FAIL LOUDLY when no device is present (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mlfriends_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(?:int|const char \*)\s*(mlf_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        decls[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    return decls
+
+
+def test_header_symbols_exported_and_bound():
+    from ultranest_amd import _lib
+    decls = _declared()
+    assert len(decls) >= 30
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name, nargs in decls.items():
+        assert hasattr(L, name), "symbol %s declared in the header but not exported" % name
+        assert name in _lib.SIGNATURES, "symbol %s not bound by ultranest_amd._lib" % name
+        assert len(_lib.SIGNATURES[name]) == nargs, (name, nargs, len(_lib.SIGNATURES[name]))
+    assert set(_lib.SIGNATURES) == set(decls), set(_lib.SIGNATURES) ^ set(decls)
+    assert _lib.lib().mlf_abi_version() == _lib.ABI_VERSION
+
+
+def test_no_cpu_fallback_without_device():
+    from ultranest_amd import _lib, kernels
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    out = np.empty(2, dtype=np.int64)
+    with pytest.raises(_lib.HipLibraryError):
+        kernels.find_nearby(np.zeros((3, 2)), np.zeros((2, 2)), 1.0, out)
+    with pytest.raises(_lib.HipLibraryError):
+        kernels.maxradiussq_bootstrap(np.zeros((4, 2)), np.ones((1, 4), dtype=bool))
+    with pytest.raises(_lib.HipLibraryError):
+        kernels.DeviceRegion()
+    import ultranest_amd.likelihoods as L
+    with pytest.raises(_lib.HipLibraryError):
+        L.eggbox_loglike(np.zeros((2, 2)))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "ultranest_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), "product file %s mentions the oracle" % f
+
+
+def test_argument_validation_is_host_side():
+    from ultranest_amd import kernels
+    with pytest.raises(ValueError):
+        kernels.find_nearby(np.zeros((3, 2)), np.zeros((2, 3)), 1.0, np.empty(2, dtype=np.int64))
+    with pytest.raises(ValueError):
+        kernels.find_nearby(np.zeros((3, 2)), np.zeros((2, 2)), 1.0, np.empty(2, dtype=np.int32))
+    with pytest.raises(ValueError):
+        kernels.maxradiussq_bootstrap(np.zeros((4, 2)), np.ones((1, 5), dtype=bool))

@@ -1,0 +1,101 @@
+"""N > 1 path on CPU: world_size-2/3 `gloo` process groups (one process per would-be GPU).  The
+kernels are the oracle stub (no GPU here); what is under test is the HOST logic of
+ultranest_amd.distributed: mask broadcast, balanced sharding, the MAX all-reduce, error
+propagation -- and that the result is bit-identical to the single-process run for any world size.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_cover_exactly():
+    from ultranest_amd.distributed import shard_bounds
+    for n in (0, 1, 7, 30, 64, 1000003):
+        for w in (1, 2, 3, 8, 64):
+            seen = []
+            for r in range(w):
+                lo, hi = shard_bounds(n, r, w)
+                assert 0 <= hi - lo <= n // w + 1
+                seen.extend(range(lo, hi)) if n < 2000 else None
+                if r == w - 1:
+                    assert hi == n
+            if n < 2000:
+                assert seen == list(range(n))
+    assert [shard_bounds(30, r, 8) for r in range(8)] == [(0, 4), (4, 8), (8, 12), (12, 16), (16, 20), (20, 24), (24, 27), (27, 30)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world_size, port, singular, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import torch.distributed as dist
+    import oracle_backend
+    import ultranest_amd.kernels as K
+    import ultranest_amd.mlfriends as M
+    for name in oracle_backend.PATCHED:                     # plain (non-pytest) install of the stub
+        setattr(K, name, getattr(oracle_backend, name))
+        if hasattr(M, name):
+            setattr(M, name, getattr(oracle_backend, name))
+    from ultranest_amd import distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        u = inputs.live_points(31, 300, 4)
+        if singular:
+            u[:, 3] = u[:, 0]
+        layer = M.AffineLayer() if not singular else M.ScalingLayer()
+        layer.optimize(u, u)
+        region = M.MLFriends(u, layer)
+        # every rank passes a DIFFERENT stream: only rank 0's draws may matter
+        rng = np.random.RandomState(1234 if rank == 0 else 999 + rank)
+        try:
+            r, f = distributed.update_region_bootstrap(region, 30, minvol=0., rng=rng)
+            out[rank] = (r, f, region.maxradiussq, region.enlarge)
+        except np.linalg.LinAlgError:
+            out[rank] = "LinAlgError"
+        t = distributed.allreduce_max([float(rank), -float(rank)])
+        assert list(t) == [world_size - 1.0, 0.0]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world_size", [2, 3])
+def test_sharded_bootstrap_bit_identical_to_single_process(world_size, monkeypatch):
+    import torch.multiprocessing as mp
+    import oracle_backend
+    oracle_backend.install(monkeypatch)
+    import ultranest_amd.mlfriends as M
+    u = inputs.live_points(31, 300, 4)
+    layer = M.AffineLayer()
+    layer.optimize(u, u)
+    region = M.MLFriends(u, layer)
+    r1, f1 = region.compute_enlargement(nbootstraps=30, rng=np.random.RandomState(1234))
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world_size, _free_port(), False, out), nprocs=world_size, join=True)
+    for rank in range(world_size):
+        assert out[rank] == (r1, f1, r1, f1), (rank, out[rank], (r1, f1))
+
+
+def test_error_flag_reaches_every_rank(monkeypatch):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), True, out), nprocs=2, join=True)
+    assert out[0] == "LinAlgError" and out[1] == "LinAlgError"

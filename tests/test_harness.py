@@ -1,0 +1,63 @@
+"""Driver-counterpart harness (ultranest_amd.harness): the region rebuild sequence and one
+proposal batch through the vectorized callbacks.  Mirrors what reference
+tests/test_clustering.py:152-225 does with its MockIntegrator (drive `_update_region` twice on
+clustered points and check the cluster structure)."""
+import numpy as np
+
+import inputs
+
+
+def test_rebuild_sequence_and_proposal_batch(backend, golden):
+    import ultranest_amd.mlfriends as M
+    from ultranest_amd.harness import RegionUpdater, refill_samples
+    np.random.seed(3)
+    u = inputs.live_points(41, 600, 4)
+    upd = RegionUpdater(4, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer)
+    assert upd.update(u, nbootstraps=30, minvol=0., active_p=u.copy())
+    first = upd.region
+    assert first.inside(u).all() and upd.tregion.inside(u).all()
+    assert first.maxradiussq > 0 and first.enlarge > 0
+    # steady state: replace a tenth of the points by tighter draws -> volume shrinks, region accepted
+    u2 = u.copy()
+    u2[:60] = 0.5 + 0.045 * np.random.normal(size=(60, 4))
+    upd.update(u2, nbootstraps=30, minvol=0., active_p=u2.copy())
+    assert upd.region.inside(u2).all()
+    assert len(upd.region.u) == len(upd.transformLayer.clusterids)
+    # radius invalidation path (driver sets maxradiussq = None when a live point dies)
+    upd.region.maxradiussq = None
+    assert upd.update(u2, nbootstraps=30, minvol=0.)
+    assert upd.region.maxradiussq > 0 and not (upd.transformLayer.clusterids == 0).any()
+
+    # one proposal batch through vectorized callbacks
+    calls = []
+
+    def transform(x):
+        calls.append(("t", x.shape))
+        return x * 2 - 1
+
+    def loglike(p):
+        assert p.ndim == 2 and p.flags.c_contiguous
+        calls.append(("l", p.shape))
+        return -0.5 * (p ** 2).sum(axis=1)
+
+    upd.update(u2, nbootstraps=30, minvol=0., active_p=transform(u2))
+    nu, nv, nl, nc = refill_samples(upd.region, upd.tregion, transform, loglike, Lmin=-1.0, ndraw=4000)
+    assert nc == calls[-1][1][0] and (nl > -1.0).all() and len(nu) == len(nv) == len(nl)
+    assert upd.region.inside(nu).all()
+
+
+def test_clustered_points_keep_structure(backend, golden):
+    """eggboxregion.txt (the reference's fixture): two rebuilds keep 14 < nclusters < 20 and no
+    singleton cluster (pins of reference tests/test_clustering.py:152-225)."""
+    import ultranest_amd.mlfriends as M
+    from ultranest_amd.harness import RegionUpdater
+    g = golden("g456_region")
+    np.random.seed(1)
+    u = g["g5_u"]
+    upd = RegionUpdater(2, region_class=M.MLFriends, transform_layer_class=M.AffineLayer)
+    upd.update(u, nbootstraps=30, minvol=0.)
+    upd.update(u, nbootstraps=30, minvol=0.)
+    nclusters = upd.transformLayer.nclusters
+    assert 14 < nclusters < 20, nclusters
+    _, sizes = np.unique(upd.transformLayer.clusterids, return_counts=True)
+    assert sizes.min() > 1

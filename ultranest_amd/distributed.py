@@ -1,0 +1,120 @@
+"""Multi-GPU sharding of the region rebuild and of proposal batches: one process per GPU,
+``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+
+What the reference does (integrator.py:375-415, `_update_region_bootstrap`): every MPI rank runs
+``nbootstraps // mpi_size`` rounds on identical live points with its OWN random seed, then the
+per-rank maxima are exchanged with pickle gather + bcast and maximised.  Consequences: the
+number of rounds actually run depends on the rank count (30 // 8 * 8 = 24) and results are not
+reproducible across rank counts.
+
+What this module does instead: rank 0 draws all B selection masks from ONE stream (the same
+draws a single-process run makes) and broadcasts them (B*N bytes); ranks take contiguous shards
+of the rounds (sizes differ by at most one: 30 over 8 GPUs = 4,4,4,4,4,4,3,3); each computes its
+shard's maxima on its GPU; ONE all-reduce(MAX) of three doubles (radius^2, enlargement, error
+flag) finishes the step.  max is exact and order independent and the float32 rounding of the
+radius is monotone, so the result is bit-identical for every world size.  An error on any rank
+travels as the explicit flag (not as a NaN through MAX) and is re-raised on all ranks after the
+collective, which keeps the ranks in step -- the property the reference protects with its
+try/except around compute_enlargement (integrator.py:385-411).
+
+Proposal batches shard by rows with NO collective: rows are independent and every rank holds the
+(1.6 MB) region state; `shard_bounds` gives the slice.
+"""
+import numpy as np
+
+from . import regions
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world(group=None):
+    """(rank, world_size) of the default/group process group; (0, 1) when not initialised."""
+    try:
+        dist = _dist()
+    except ImportError:
+        return 0, 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def shard_bounds(nitems, rank, world_size):
+    """Contiguous, balanced [lo, hi) slice of `nitems` work items for `rank`; the first
+    ``nitems % world_size`` ranks take one extra item."""
+    base, extra = divmod(int(nitems), int(world_size))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _tensor_device(group=None):
+    import torch
+    dist = _dist()
+    backend = dist.get_backend(group)
+    if backend == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def broadcast_masks(masks, npoints, nbootstraps, group=None, src=0):
+    """Rank `src` provides the (B, N) bool masks; every rank returns the same array."""
+    rank, size = world(group)
+    if size == 1:
+        return masks
+    import torch
+    dist = _dist()
+    dev = _tensor_device(group)
+    if rank == src:
+        buf = torch.from_numpy(np.ascontiguousarray(masks, dtype=np.uint8)).to(dev)
+    else:
+        buf = torch.empty((nbootstraps, npoints), dtype=torch.uint8, device=dev)
+    dist.broadcast(buf, src=src, group=group)
+    return buf.cpu().numpy().astype(bool)
+
+
+def allreduce_max(values, group=None):
+    """Element-wise MAX of a small float64 vector over all ranks (RCCL ncclMax on the GPU box)."""
+    rank, size = world(group)
+    values = np.asarray(values, dtype=np.float64)
+    if size == 1:
+        return values
+    import torch
+    dist = _dist()
+    t = torch.from_numpy(values.copy()).to(_tensor_device(group))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t.cpu().numpy()
+
+
+def sharded_enlargement(region, nbootstraps, minvol=0., rng=np.random, group=None):
+    """(maxradiussq, enlarge) over `nbootstraps` rounds sharded across the process group.
+    Single process: identical to ``region.compute_enlargement`` (same draws, same bits)."""
+    rank, size = world(group)
+    npoints = len(region.u)
+    masks = regions._draw_selection(rng, npoints, nbootstraps) if rank == 0 else None
+    masks = broadcast_masks(masks, npoints, nbootstraps, group=group)
+    lo, hi = shard_bounds(nbootstraps, rank, size)
+    error = None
+    r = f = 0.0
+    try:
+        out = region.enlargement_from_masks(masks[lo:hi], minvol=minvol) if hi > lo else (0.0, 0.0)
+        r, f = out if isinstance(out, tuple) else (0.0, out)
+    except np.linalg.LinAlgError as e:
+        error = e
+    r, f, flag = allreduce_max([r, f, 0.0 if error is None else 1.0], group=group)
+    if flag > 0:
+        raise error if error is not None else np.linalg.LinAlgError("compute_enlargement failed on another rank")
+    return float(r), float(f)
+
+
+def update_region_bootstrap(region, nbootstraps, minvol=0., group=None, rng=np.random):
+    """Counterpart of the reference's ``_update_region_bootstrap`` (integrator.py:375-415): sets
+    ``region.maxradiussq`` and ``region.enlarge`` and returns them."""
+    assert nbootstraps > 0, nbootstraps
+    r, f = sharded_enlargement(region, nbootstraps, minvol=minvol, rng=rng, group=group)
+    if not (r > 0 and f > 0 and np.isfinite(r) and np.isfinite(f)):
+        raise np.linalg.LinAlgError("compute_enlargement failed")
+    region.maxradiussq = r
+    region.enlarge = f
+    return r, f

@@ -1,0 +1,129 @@
+"""Counterpart of the reference DRIVER's calls into the region path, for benchmarking and
+end-to-end parity of that path without shipping the driver: the region rebuild
+(reference integrator.py `_update_region` :1952-2159, call stack A of SURVEY.md 3) and one
+proposal batch through the vectorized-likelihood callbacks (`_refill_samples` :1773-1837, stack
+B).  Control flow only; every numerical stage is a call into ultranest_amd.mlfriends /
+ultranest_amd.distributed.  The reference's own driver can be used instead, unmodified, by
+passing these classes through its plug points."""
+import numpy as np
+
+from . import distributed
+from .mlfriends import LocalAffineLayer, MLFriends, WrappingEllipsoid, find_nearby, int_dtype
+
+
+class RegionUpdater(object):
+    """Holds (region, transformLayer, tregion) like the driver does and rebuilds them from the
+    current live points."""
+
+    def __init__(self, x_dim, region_class=MLFriends, transform_layer_class=LocalAffineLayer,
+                 wrapped_axes=(), group=None, build_tregion=True):
+        self.x_dim = x_dim
+        self.region_class = region_class
+        self.transform_layer_class = transform_layer_class
+        self.wrapped_axes = list(wrapped_axes)
+        self.group = group
+        self.build_tregion = build_tregion
+        self.region = None
+        self.transformLayer = None
+        self.tregion = None
+
+    def _bootstrap(self, region, nbootstraps, minvol):
+        return distributed.update_region_bootstrap(region, nbootstraps, minvol, group=self.group)
+
+    def _revalidate_radius(self, active_u, nbootstraps, minvol):
+        """Radius was invalidated (driver sets maxradiussq = None, :2827): bootstrap it again on
+        the current layer and carry the cluster labels over by proximity (:2009-2053)."""
+        old_u = self.region.u
+        self.region.u = active_u
+        self.region.set_transformLayer(self.transformLayer)
+        self._bootstrap(self.region, nbootstraps, minvol)
+        old_t = self.transformLayer.transform(old_u)
+        old_ids = self.transformLayer.clusterids
+        labels = np.zeros(len(active_u), dtype=int_dtype)
+        hit = np.empty(len(self.region.unormed), dtype=int_dtype)
+        for cid in np.unique(old_ids):
+            if cid == 0:
+                continue
+            find_nearby(old_t[old_ids == cid], self.region.unormed, self.region.maxradiussq, hit)
+            near = hit != 0           # the driver's test (:2042), see SURVEY.md appendix A5
+            labels[near] = np.where(labels[near] == 0, cid, -1)
+        labels[labels == -1] = 0
+        self.transformLayer.clusterids = labels
+        self.region.create_ellipsoid(minvol=minvol)
+        return (labels == 0).any()
+
+    def update(self, active_u, nbootstraps=30, minvol=0., active_p=None):
+        """Returns True if the region object was (re)built or replaced."""
+        assert nbootstraps > 0
+        updated = False
+        if self.region is None:
+            self.transformLayer = self.transform_layer_class(wrapped_dims=self.wrapped_axes)
+            self.transformLayer.optimize(active_u, active_u, minvol=minvol)
+            self.region = self.region_class(active_u, self.transformLayer)
+            self._bootstrap(self.region, nbootstraps, minvol)
+            self.region.create_ellipsoid(minvol=minvol)
+            updated = True
+        need_accept = False
+        if self.region.maxradiussq is None:
+            need_accept = self._revalidate_radius(active_u, nbootstraps, minvol)
+            updated = True
+
+        with np.errstate(all='raise'):
+            try:
+                nxt_layer = self.transformLayer.create_new(active_u, self.region.maxradiussq, minvol=minvol)
+                assert not (nxt_layer.clusterids == 0).any()
+                _, sizes = np.unique(nxt_layer.clusterids, return_counts=True)
+                nxt = self.region_class(active_u, nxt_layer)
+                self._bootstrap(nxt, nbootstraps, minvol)
+                nxt.create_ellipsoid(minvol=minvol)
+                contains_live = nxt.inside(active_u).all()
+                sensible = nxt_layer.nclusters < len(nxt.u) and sizes.max() >= nxt.u.shape[1]
+                shrinks = need_accept or nxt.estimate_volume() <= self.region.estimate_volume()
+                if contains_live and shrinks and sensible:
+                    self.region = nxt
+                    self.transformLayer = nxt_layer
+                    updated = True
+            except (Warning, FloatingPointError, np.linalg.LinAlgError):
+                pass                  # keep the previous region, as the driver does (:2123-2131)
+
+        if active_p is None or not self.build_tregion:
+            self.tregion = None
+        else:
+            try:
+                with np.errstate(invalid='raise'):
+                    tregion = WrappingEllipsoid(active_p)
+                    rank, size = distributed.world(self.group)
+                    masks = distributed.broadcast_masks(
+                        None if rank else _draw(len(active_p), nbootstraps), len(active_p), nbootstraps, group=self.group)
+                    lo, hi = distributed.shard_bounds(nbootstraps, rank, size)
+                    f = tregion.enlargement_from_masks(masks[lo:hi]) if hi > lo else 0.0
+                    tregion.enlarge = float(distributed.allreduce_max([f], group=self.group)[0])
+                    tregion.create_ellipsoid()
+                    self.tregion = tregion
+            except (FloatingPointError, np.linalg.LinAlgError):
+                self.tregion = None
+        return updated
+
+
+def _draw(npoints, nbootstraps):
+    from .regions import _draw_selection
+    return _draw_selection(np.random, npoints, nbootstraps)
+
+
+def refill_samples(region, tregion, transform, loglike, Lmin, ndraw):
+    """One proposal batch (reference `_refill_samples`, integrator.py:1773-1837 with
+    draw_multiple=True): region.sample -> transform -> tregion.inside -> loglike on the accepted
+    rows -> keep logl > Lmin.  Returns (u, v, logl, ncalls)."""
+    u = region.sample(nsamples=ndraw)
+    assert np.logical_and(u > 0, u < 1).all(), u
+    nu = u.shape[0]
+    if nu == 0:
+        return u, np.empty((0, 0)), np.empty(0), 0
+    v = transform(u)
+    logl = np.ones(nu) * -np.inf
+    accepted = tregion.inside(v) if tregion is not None else np.ones(nu, dtype=bool)
+    nc = int(accepted.sum())
+    if nc > 0:
+        logl[accepted] = loglike(v[accepted, :])
+    keep = logl > Lmin
+    return u[keep, :], v[keep, :], logl[keep], nc

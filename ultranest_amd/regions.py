@@ -241,12 +241,22 @@ class MLFriends(object):
     def compute_enlargement(self, nbootstraps=50, minvol=0., rng=np.random):
         """(maxradiussq, enlarge) from `nbootstraps` leave-out rounds (reference :1017-1070).
         Rounds that select all or no points contribute nothing (:1048)."""
-        npoints = len(self.u)
         assert np.isfinite(self.unormed).all(), self.unormed
-        masks = _draw_selection(rng, npoints, nbootstraps)
+        masks = _draw_selection(rng, len(self.u), nbootstraps)
+        maxd, maxf = self.enlargement_from_masks(masks, minvol=minvol)
+        assert maxd > 0, (maxd, self.u, self.unormed)
+        assert maxf > 0, (maxf, self.u, self.unormed)
+        return maxd, maxf
+
+    def enlargement_from_masks(self, masks, minvol=0.):
+        """(max radius^2, max enlargement) over the given pre-drawn (B, N) selection masks; 0.0
+        for an empty set.  This is the unit of work that ``ultranest_amd.distributed`` shards
+        over GPUs (max is exact and order independent, so any sharding gives identical bits)."""
+        maxd, maxf = 0.0, 0.0
+        if len(masks) == 0:
+            return maxd, maxf
         r2, skipped = kernels.maxradiussq_bootstrap(self.unormed, masks)
         use = ~skipped
-        maxd, maxf = 0.0, 0.0
         if use.any():
             maxd = float(r2[use].max())
             f = _bootstrap_enlargement(self.u, masks[use], minvol)
@@ -254,8 +264,6 @@ class MLFriends(object):
             if not (f > 0).all():
                 raise np.linalg.LinAlgError("Distances are not positive")
             maxf = float(f.max())
-        assert maxd > 0, (maxd, self.u, self.unormed)
-        assert maxf > 0, (maxf, self.u, self.unormed)
         return maxd, maxf
 
     # ---- membership ------------------------------------------------------------------------
@@ -389,13 +397,18 @@ class RobustEllipsoidRegion(MLFriends):
             raise FloatingPointError('not enough live points to compute covariance')
         assert np.isfinite(self.unormed).all(), self.unormed
         masks = _draw_selection(rng, npoints, nbootstraps)
+        maxd, maxf = self.enlargement_from_masks(masks)
+        assert maxf > 0, (maxf, self.u, self.unormed)
+        return maxd, maxf
+
+    def enlargement_from_masks(self, masks, minvol=0.):
+        if len(masks) == 0:
+            return 1e300, 0.0
         f = _bootstrap_enlargement(self.u, masks, 0.)
         assert np.isfinite(f).all(), (f, self.unormed)
         if not (f > 0).all():
             raise np.linalg.LinAlgError("Distances are not positive")
-        maxf = float(f.max()) if len(f) else 0.0
-        assert maxf > 0, (maxf, self.u, self.unormed)
-        return 1e300, maxf
+        return 1e300, float(f.max())
 
     def estimate_volume(self):
         """log-volume of the ellipsoid (reference :1442-1457)."""
@@ -425,8 +438,13 @@ class SimpleRegion(RobustEllipsoidRegion):
         assert np.isfinite(self.unormed).all(), self.unormed
         if npoints < ndim + 1:
             raise FloatingPointError('not enough live points to compute variance')
+        maxd, maxf = self.enlargement_from_masks(_draw_selection(rng, npoints, nbootstraps))
+        assert maxf > 0, (maxf, self.u, self.unormed)
+        return maxd, maxf
+
+    def enlargement_from_masks(self, masks, minvol=0.):
         maxf = 0.0
-        for sel in _draw_selection(rng, npoints, nbootstraps):
+        for sel in masks:
             ctr = np.mean(self.u[sel, :], axis=0)
             var = np.var(self.u[sel, :], axis=0)
             f = np.sum((self.u[~sel, :] - ctr.reshape((1, -1)))**2 / var, axis=0).max()
@@ -434,7 +452,6 @@ class SimpleRegion(RobustEllipsoidRegion):
             if not f > 0:
                 raise np.linalg.LinAlgError("Distances are not positive")
             maxf = max(maxf, f)
-        assert maxf > 0, (maxf, self.u, self.unormed)
         return 1e300, maxf
 
 
@@ -451,15 +468,19 @@ class WrappingEllipsoid(object):
         self.enlarge = None
 
     def compute_enlargement(self, nbootstraps=50, rng=np.random):
-        npoints = len(self.u)
+        masks = _draw_selection(rng, len(self.u), nbootstraps)
+        maxf = self.enlargement_from_masks(masks)
+        assert maxf > 0, (maxf, self.u)
+        return maxf
+
+    def enlargement_from_masks(self, masks):
+        if len(masks) == 0:
+            return 0.0
         v = np.ascontiguousarray(self.u[:, self.variable_dims])
-        masks = _draw_selection(rng, npoints, nbootstraps)
         f = _bootstrap_enlargement(v, masks, 0.)
         if not (f > 0).all():
             raise np.linalg.LinAlgError("Distances are not positive")
-        maxf = float(f.max()) if len(f) else 0.0
-        assert maxf > 0, (maxf, self.u)
-        return maxf
+        return float(f.max())
 
     def create_ellipsoid(self, minvol=0.0):
         assert self.enlarge is not None
