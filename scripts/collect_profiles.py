@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of a GPU session from gpurun_out/ (scratch) into profiles/ (tracked):
+rocprofv3 kernel stats, per-kernel PMC averages for the headline launches, the bench line, test logs.
+
+    python scripts/collect_profiles.py r01
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+os.makedirs(P, exist_ok=True)
+
+HEADLINE_GRID = {"k_scan": 15625 * 256, "k_prep": 3907 * 256}     # 1e6 proposals / launch
+
+
+def cp(src, dst):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, dst))
+        print("copied", dst)
+
+
+cp("prof_stats/bench_kernel_stats.csv", "%s_rocprofv3_kernel_stats.csv" % tag)
+cp("bench.json", "%s_bench.json" % tag)
+cp("pytest_gpu.log", "%s_pytest_gpu.log" % tag)
+cp("smoke.log", "%s_smoke.log" % tag)
+cp("microbench.log", "%s_microbench.log" % tag)
+
+# kernel-trace: average duration of the headline launches only (the stats CSV mixes them with the
+# small scans of the region rebuild)
+trace = os.path.join(G, "prof_stats", "bench_kernel_trace.csv")
+summary = {}
+if os.path.exists(trace):
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        name = r["Kernel_Name"]
+        for key, grid in HEADLINE_GRID.items():
+            if key in name and int(r["Grid_Size_X"]) == grid:
+                dur[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+    for key, v in dur.items():
+        summary[key] = dict(headline_launches=len(v), avg_ms=sum(v) / len(v), min_ms=min(v), max_ms=max(v))
+
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ"):
+    f = os.path.join(G, sub, "bench_counter_collection.csv")
+    if not os.path.exists(f):
+        continue
+    for r in csv.DictReader(open(f)):
+        for key, grid in HEADLINE_GRID.items():
+            if key in r["Kernel_Name"] and int(r["Grid_Size"]) == grid:
+                pmc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                pmc[key]["VGPR_Count"] = [float(r["VGPR_Count"])]
+                pmc[key]["LDS_Block_Size"] = [float(r["LDS_Block_Size"])]
+for key in pmc:
+    summary.setdefault(key, {})["pmc_avg_per_launch"] = {c: sum(v) / len(v) for c, v in pmc[key].items()}
+
+if "k_scan" in pmc and "FETCH_SIZE" in pmc["k_scan"]:
+    fetch_kb = sum(pmc["k_scan"]["FETCH_SIZE"]) / len(pmc["k_scan"]["FETCH_SIZE"])
+    write_kb = sum(pmc["k_scan"].get("WRITE_SIZE", [0])) / max(1, len(pmc["k_scan"].get("WRITE_SIZE", [0])))
+    # MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+    # reports half the bytes of a wide coalesced read -> doubled as the guide prescribes (upper estimate:
+    # the calibration is for 16 B/lane loads, k_scan issues 8 B/lane loads)
+    traffic = (2.0 * fetch_kb + write_kb) * 1024.0
+    summary["k_scan"]["hbm_traffic"] = dict(FETCH_SIZE_KiB=fetch_kb, WRITE_SIZE_KiB=write_kb,
+                                            bytes_raw=(fetch_kb + write_kb) * 1024.0,
+                                            bytes_gfx950_corrected=traffic)
+    json.dump(dict(hbm_bytes_per_launch=traffic, source="%s_pmc_summary.json" % tag,
+                   note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, k_scan<50> launches of 1e6 "
+                        "proposals; (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md"),
+              open(os.path.join(P, "pmc_scan_traffic.json"), "w"), indent=1)
+json.dump(summary, open(os.path.join(P, "%s_pmc_summary.json" % tag), "w"), indent=1)
+print(json.dumps(summary, indent=1))
