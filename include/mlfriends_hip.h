@@ -41,6 +41,9 @@ int mlf_device_count(int *count);
 int mlf_set_device(int device);            /* device used by this process (default 0)      */
 int mlf_device_name(char *buf, size_t buflen);
 int mlf_synchronize(void);
+/* tuning switches: "filter" (1/0: MFMA pre-filter in front of the exact neighbour scan; results are
+ * identical either way), "filter_min_queries" (batches below this size use the exact scan only) */
+int mlf_set_option(const char *name, long long value);
 
 /* ---- K1: find_nearby -- ultranest/mlfriends.pyx:143-183 -----------------------------------
  * out[j] = lowest i with sum_k (apts[i,k]-bpts[j,k])^2 <= radiussq (k ascending, no FMA),

@@ -1,0 +1,167 @@
+"""MFMA pre-filter (csrc/mlf_filter.hip) vs the exact scan and the CPU oracle: the filter may only
+change speed, never a result bit.  Adversarial cases: radii that coincide exactly with a pair
+distance (and one ulp below), badly scaled / offset data, queries outside the binary16 range,
+uncertain-pair list overflow."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from ultranest_amd import _lib, kernels
+    assert _lib.device_count() >= 1
+    _lib.set_option("filter", 1)
+    _lib.set_option("filter_min_queries", 64)      # let small test batches take the filter path
+    yield kernels
+    _lib.set_option("filter_min_queries", 2048)
+    _lib.set_option("filter", 1)
+
+
+def _find(K, apts, bpts, r2, filt):
+    from ultranest_amd import _lib
+    _lib.set_option("filter", 1 if filt else 0)
+    out = np.empty(len(bpts), dtype=np.int64)
+    K.find_nearby(apts, bpts, r2, out)
+    _lib.set_option("filter", 1)
+    return out
+
+
+def _exact_d2(a, b):
+    acc = np.zeros(len(a))
+    for k in range(a.shape[1]):
+        diff = a[:, k] - b[k]
+        acc = acc + diff * diff
+    return acc
+
+
+@pytest.mark.parametrize("n,d,p", [(256, 1, 300), (300, 2, 257), (1000, 10, 2100), (4000, 50, 2500),
+                                   (2000, 20, 3000), (777, 58, 400), (640, 59, 333), (500, 90, 200),
+                                   (300, 122, 100), (260, 128, 70)])
+def test_filter_equals_exact_and_oracle(n, d, p, K, oracle):
+    rs = np.random.RandomState(n + d)
+    a = rs.normal(size=(n, d))
+    b = np.where((np.arange(p) % 2 == 0)[:, None], a[rs.randint(n, size=p)] + 0.4 * rs.normal(size=(p, d)),
+                 rs.normal(size=(p, d)))
+    nn = np.array([_exact_d2(a, b[j]).min() for j in range(0, p, max(1, p // 64))])
+    for r2 in (float(np.median(nn)), float(np.percentile(nn, 10)), float(nn.max() * 1.5)):
+        want = oracle.find_nearby(a, b, r2)
+        assert np.array_equal(_find(K, a, b, r2, True), want), (n, d, p, r2)
+        assert np.array_equal(_find(K, a, b, r2, False), want)
+
+
+def test_radius_exactly_on_a_pair_distance(K, oracle):
+    """r2 == the reference's own value for one pair: that pair must hit (<=); one ulp lower: miss."""
+    rs = np.random.RandomState(11)
+    n, d, p = 600, 20, 512
+    a = rs.normal(size=(n, d))
+    b = rs.normal(size=(p, d))
+    for j in rs.randint(p, size=12):
+        d2 = _exact_d2(a, b[j])
+        i = int(np.argsort(d2)[rs.randint(3)])
+        for r2 in (d2[i], np.nextafter(d2[i], 0.0), np.nextafter(d2[i], np.inf)):
+            want = oracle.find_nearby(a, b, float(r2))
+            got = _find(K, a, b, float(r2), True)
+            assert np.array_equal(got, want), (j, i, r2)
+
+
+@pytest.mark.parametrize("scale,offset", [(1e-6, 0.0), (1e6, 0.0), (1.0, 1000.0), (1e-5, 0.5), (3.0, -70000.0)])
+def test_scaled_and_offset_data(scale, offset, K, oracle):
+    rs = np.random.RandomState(5)
+    n, d, p = 900, 7, 1000
+    a = offset + scale * rs.normal(size=(n, d))
+    b = offset + scale * rs.normal(size=(p, d))
+    b[::50] = offset + scale * 1e6 * rs.normal(size=(len(b[::50]), d))     # far outside the binary16 range
+    b[7] = np.inf
+    b[9, 2] = np.nan
+    r2 = float(np.median([_exact_d2(a, b[j]).min() for j in range(1, 200, 3)]))
+    want = oracle.find_nearby(a, b, r2)
+    assert np.array_equal(_find(K, a, b, r2, True), want)
+
+
+def test_uncertain_list_overflow_falls_back_exactly(K, oracle):
+    """all live points coincide and every query sits at the threshold: every pair is uncertain,
+    the list overflows and the exact scan must take over."""
+    n, d, p = 512, 4, 4096
+    a = np.tile(np.array([[0.25, 0.5, 0.75, 0.125]]), (n, 1))
+    rs = np.random.RandomState(1)
+    dirs = rs.normal(size=(p, d))
+    dirs /= np.sqrt((dirs ** 2).sum(axis=1, keepdims=True))
+    b = a[0] + dirs * (1.0 + 1e-7 * rs.normal(size=(p, 1)))
+    want = oracle.find_nearby(a, b, 1.0)
+    assert 0.2 < (want >= 0).mean() < 0.8
+    assert np.array_equal(_find(K, a, b, 1.0, True), want)
+
+
+def test_region_inside_filter_vs_exact(K, oracle):
+    import inputs
+    from ultranest_amd import _lib
+    n, d, p = 3000, 30, 20000
+    u = inputs.live_points(3, n, d)
+    ctr = u.mean(axis=0)
+    cov = np.cov(u, rowvar=0) * (d + 2)
+    w, v = np.linalg.eigh(cov)
+    T = v * w ** -0.5
+    inv = np.linalg.inv(cov)
+    pts = inputs.proposal_mix(4, u, p, shell_q=2.0)
+    reg = K.DeviceRegion()
+    reg.set(u, 0, ctr, T, None, ctr, inv, 2.0, 1.2, live_space=1)
+    res = {}
+    for filt in (1, 0):
+        _lib.set_option("filter", filt)
+        res[filt] = reg.inside(pts)
+        for row in (0, 17, 2999):                      # in-place replacement requantises the live set
+            reg.update_point(row, pts[row])
+        res[filt, "upd"] = reg.inside(pts)
+        reg.set(u, 0, ctr, T, None, ctr, inv, 2.0, 1.2, live_space=1)
+    _lib.set_option("filter", 1)
+    assert np.array_equal(res[1], res[0]) and np.array_equal(res[1, "upd"], res[0, "upd"])
+    assert 0.05 < res[1].mean() < 0.95
+    unormed = oracle.affine_transform(u, ctr, T)
+    assert np.array_equal(res[1], oracle.region_inside(pts, unormed, ctr, T, ctr, inv, 2.0, 1.2))
+    reg.close()
+
+
+@pytest.mark.parametrize("n,d,p", [(500, 3, 4097), (1200, 20, 5000), (4000, 50, 6001), (300, 64, 2500), (300, 70, 2500)])
+def test_fused_prep_matches_unfused(n, d, p, K, oracle):
+    """k_prep2 (coalesced staging, coordinate-major whitened output, fused binary16 quantisation)
+    vs the unfused kernels, filter on and off, ragged batch sizes, wrapped axis; all four
+    combinations must give the oracle's mask."""
+    import inputs
+    from ultranest_amd import _lib
+    u = inputs.live_points(9, n, d)
+    u[:, 0] = np.fmod(u[:, 0] + 0.55, 1.0)                   # straddles the border: wrapped axis
+    cut = 0.5
+    shift = np.full(d, np.nan)
+    shift[0] = 1 - cut
+    w = u.copy()
+    w[:, 0] = np.fmod(w[:, 0] + shift[0], 1)
+    ctr = w.mean(axis=0)
+    cov = np.cov(w, rowvar=0) * (d + 2)
+    ev, evec = np.linalg.eigh(cov)
+    T = evec * ev ** -0.5
+    ectr = u.mean(axis=0)
+    einv = np.linalg.inv(np.cov(u, rowvar=0) * (d + 2))
+    pts = inputs.proposal_mix(10, w, p, shell_q=2.0)
+    pts[:, 0] = np.fmod(pts[:, 0] + cut + 1.0, 1.0)          # back to the unwrapped cube
+    reg = K.DeviceRegion()
+    reg.set(u, 0, ctr, T, shift, ectr, einv, 60.0, 1.1, live_space=1)
+    got = {}
+    for fused in (1, 0):
+        for filt in (1, 0):
+            _lib.set_option("fused_prep", fused)
+            _lib.set_option("filter", filt)
+            got[fused, filt] = reg.inside(pts)
+    _lib.set_option("fused_prep", 1)
+    _lib.set_option("filter", 1)
+    wp = pts.copy()
+    wp[:, 0] = np.fmod(wp[:, 0] + shift[0], 1)
+    emask = oracle.inside_ellipsoid(pts, ectr, einv, 60.0)
+    tl = oracle.affine_transform(w, ctr, T)
+    idx = oracle.find_nearby(tl, oracle.affine_transform(wp, ctr, T), 1.1)
+    want = emask & (idx >= 0)
+    for key, m in got.items():
+        assert np.array_equal(m, want), key
+    assert 0.02 < want.mean() < 0.98
+    reg.close()

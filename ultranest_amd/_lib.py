@@ -27,6 +27,7 @@ SIGNATURES = {
     "mlf_set_device": [_int],
     "mlf_device_name": [_vp, _sz],
     "mlf_synchronize": [],
+    "mlf_set_option": [ctypes.c_char_p, ctypes.c_longlong],
     "mlf_find_nearby": [_vp, _sz, _vp, _sz, _sz, _dbl, _vp],
     "mlf_count_nearby": [_vp, _sz, _vp, _sz, _sz, _dbl, _vp],
     "mlf_subtract_nearby": [_vp, _sz, _sz, _dbl, _vp],
@@ -119,3 +120,8 @@ def device_name():
 
 def set_device(i):
     check(lib().mlf_set_device(int(i)))
+
+
+def set_option(name, value):
+    """Tuning switch of the library (e.g. set_option("filter", 0) forces the exact scan only)."""
+    check(lib().mlf_set_option(name.encode(), int(value)))

@@ -9,7 +9,9 @@
 #include <vector>
 
 #include "../../include/mlfriends_hip.h"
+#include "mlf_filter.hpp"
 #include "mlf_misc.hpp"
+#include "mlf_prep2.hpp"
 
 namespace {
 
@@ -63,12 +65,31 @@ struct DevBuf {
   }
 };
 
+// Buffers and host-side state of the MFMA pre-filter (mlf_filter.hip) for one set of live points.
+struct FilterCtx {
+  bool refs_ready = false;   // live points quantised
+  bool usable = false;       // statistics are finite and the dimensionality is covered
+  int ks = 0, ntiles32 = 0;
+  double sigma = 1.0, amax = 0.0;
+  DevBuf stats, refF, qF, tlo, thi, route, best, counters, list, gate2;
+  void release() {
+    DevBuf *b[] = {&stats, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &gate2};
+    for (DevBuf *x : b) x->release();
+    refs_ready = usable = false;
+  }
+};
+
+bool g_filter_enabled = true;         // mlf_set_option("filter", 0/1)
+bool g_fused_prep = true;             // mlf_set_option("fused_prep", 0/1)
+long long g_filter_min_queries = 2048;  // smaller batches go straight to the exact scan
+
 struct Ctx {
   bool ready = false;
   int device = 0;
   hipStream_t stream = nullptr;
   // scratch used by the stateless host-pointer entry points
   DevBuf src, refT, refR, q, out, flags, sel, selbytes, M, small0, small1, small2, small3, mask, tq;
+  FilterCtx filter;
 };
 
 Ctx g_ctx;
@@ -129,6 +150,131 @@ int stage_live_points(const double *pts, size_t n, size_t d, int dp, int npad, b
   return 0;
 }
 
+// Quantise the live points for the filter.  host_sync = true also fetches the statistics that the
+// host-side eligibility test uses (done when the live set is installed, not per batch).
+int filter_prepare_refs(FilterCtx &f, const double *refR, int n, int d, int dp, hipStream_t s,
+                        bool host_sync) {
+  f.refs_ready = false;
+  const int ks = (d + 6 + 15) / 16;
+  if (ks > 9 || n < 1) {
+    f.usable = false;
+    return 0;
+  }
+  f.ks = ks;
+  const int npad32 = round_up(n, 32);
+  f.ntiles32 = npad32 / 32;
+  CK(f.stats.reserve((8 + MLF_FILTER_MAXD) * sizeof(double)));
+  CK(f.refF.reserve((size_t)npad32 * ks * 16 * 2));
+  launch_ref_stats(refR, n, d, dp, f.stats.as<double>(), s);
+  launch_quant_refs(refR, n, npad32, d, dp, ks, f.stats.as<double>(), f.refF.p, s);
+  CK(hipGetLastError());
+  if (host_sync) {
+    double h[4];
+    CK(hipMemcpyAsync(h, f.stats.p, sizeof h, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    f.sigma = h[0];
+    f.amax = h[2];
+    f.usable = h[3] == 1.0 && h[2] > 0.0 && h[2] < 1e150;
+  }
+  f.refs_ready = true;
+  return 0;
+}
+
+// host-side eligibility of one batch (the kernels re-check per query and fall back on their own)
+bool filter_applies(const FilterCtx &f, long long nq, double r2) {
+  if (!g_filter_enabled || !f.refs_ready || !f.usable || nq < g_filter_min_queries) return false;
+  if (!(r2 > 0.0) || !(r2 < 1e150)) return false;
+  const double sr2 = f.sigma * f.sigma * r2;
+  return sr2 < 4096.0 && sr2 > 1e-30;
+}
+
+// Device buffers of one filtered batch.
+int filter_reserve(FilterCtx &f, long long nq, unsigned *cap_out) {
+  const long long nqpad = (nq + 31) / 32 * 32;
+  const size_t cap64 = (size_t)nq * 16 + (1u << 20);
+  const unsigned cap = cap64 > 0x7fffffffu ? 0x7fffffffu : (unsigned)cap64;
+  CK(f.qF.reserve((size_t)nqpad * f.ks * 16 * 2));
+  CK(f.tlo.reserve((size_t)nqpad * sizeof(float)));
+  CK(f.thi.reserve((size_t)nqpad * sizeof(float)));
+  CK(f.route.reserve((size_t)nq));
+  CK(f.best.reserve((size_t)nq * sizeof(int)));
+  CK(f.counters.reserve(4 * sizeof(unsigned)));
+  CK(f.list.reserve((size_t)cap * sizeof(unsigned long long)));
+  CK(f.gate2.reserve((size_t)nq));
+  *cap_out = cap;
+  return 0;
+}
+
+// Filter pipeline on device data: answers for all nq queries in out_mask (bytes) and/or out_idx.
+// Query element (j, k) is q[j*ldq + k*ldk].  quantised = true: the fused k_prep2 has already
+// produced the binary16 fragments, thresholds and routes of this batch.
+int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int npad, int d, int dp,
+               const double *q, long long ldq, long long ldk, long long nq, double r2, const uint8_t *gate,
+               uint8_t *out_mask, long long *out_idx, hipStream_t s, bool quantised) {
+  const long long ngroups = (nq + 31) / 32;
+  const long long nqpad = ngroups * 32;
+  unsigned cap = 0;
+  if (int rc = filter_reserve(f, nq, &cap)) return rc;
+  if (!quantised)
+  launch_quant_queries(q, ldq, nq, nqpad, d, f.ks, f.stats.as<double>(), r2, gate, f.qF.p, f.tlo.as<float>(),
+                       f.thi.as<float>(), f.route.as<uint8_t>(), f.best.as<int>(), f.counters.as<unsigned>(), s);
+  CK(hipGetLastError());
+  FilterArgs fa{};
+  fa.refF = f.refF.p;
+  fa.qF = f.qF.p;
+  fa.tlo = f.tlo.as<float>();
+  fa.thi = f.thi.as<float>();
+  fa.ntiles32 = f.ntiles32;
+  fa.ngroups = ngroups;
+  fa.nq = nq;
+  fa.best = f.best.as<int>();
+  fa.list = f.list.as<unsigned long long>();
+  fa.list_cap = cap;
+  fa.counters = f.counters.as<unsigned>();
+  CK(launch_filter(f.ks, fa, out_idx != nullptr, s));
+  RecheckArgs ra{};
+  ra.list = f.list.as<unsigned long long>();
+  ra.list_cap = cap;
+  ra.counters = f.counters.as<unsigned>();
+  ra.refR = refR;
+  ra.n = n;
+  ra.d = d;
+  ra.dp = dp;
+  ra.q = q;
+  ra.ldq = ldq;
+  ra.ldk = ldk;
+  ra.nq = nq;
+  ra.r2 = r2;
+  ra.best = f.best.as<int>();
+  launch_recheck(ra, s);
+  CK(hipGetLastError());
+  // exact scan for (a) queries that do not fit binary16 and (b) everything if the list overflowed
+  for (int which = 2; which >= 1; --which) {
+    launch_route_gate(f.route.as<uint8_t>(), f.counters.as<unsigned>(), nq, which, f.gate2.as<uint8_t>(), s);
+    ScanArgs a{};
+    a.refT = refT;
+    a.n = n;
+    a.npad = npad;
+    a.ntiles = npad / kWave;
+    a.q = q;
+    a.ldq = ldq;
+    a.ldk = ldk;
+    a.nq = nq;
+    a.d = d;
+    a.r2 = r2;
+    a.mode = out_idx ? SCAN_FIRST : SCAN_MASK;
+    a.gate = f.gate2.as<uint8_t>();
+    a.out_idx = out_idx;
+    a.out_mask = out_mask;
+    a.only_gated = 1;   // leave the outputs of ungated queries alone
+    CK(launch_scan(dp, a, s));
+  }
+  launch_filter_finalize(f.route.as<uint8_t>(), f.best.as<int>(), f.counters.as<unsigned>(), nq, out_mask,
+                         out_idx, s);
+  CK(hipGetLastError());
+  return 0;
+}
+
 int scan_host(const double *apts, size_t na, const double *bpts, size_t nb, size_t d, double r2,
               int mode, int64_t *out) {
   if (int rc = check_dims(d)) return rc;
@@ -157,7 +303,18 @@ int scan_host(const double *apts, size_t na, const double *bpts, size_t nb, size
   a.r2 = r2;
   a.mode = mode;
   a.out_idx = c.out.as<long long>();
-  CK(launch_scan(dp, a, c.stream));
+  bool filtered = false;
+  if (mode == SCAN_FIRST && g_filter_enabled && (long long)nb >= g_filter_min_queries && na >= 256) {
+    if (int rc = filter_prepare_refs(c.filter, c.refR.as<double>(), (int)na, (int)d, dp, c.stream, true)) return rc;
+    if (filter_applies(c.filter, (long long)nb, r2)) {
+      if (int rc = filter_run(c.filter, c.refT.as<double>(), c.refR.as<double>(), (int)na, npad, (int)d, dp,
+                              c.q.as<double>(), (long long)d, 1, (long long)nb, r2, nullptr, nullptr,
+                              c.out.as<long long>(), c.stream, false))
+        return rc;
+      filtered = true;
+    }
+  }
+  if (!filtered) CK(launch_scan(dp, a, c.stream));
   CK(hipMemcpyAsync(out, c.out.p, nb * sizeof(long long), hipMemcpyDeviceToHost, c.stream));
   CK(hipStreamSynchronize(c.stream));
   return 0;
@@ -184,6 +341,7 @@ struct mlf_region {
   double enlarge = 0.0, r2 = 0.0;
   DevBuf refT, refR, lay_ctr, lay_mat, wrap, ell_ctr, ell_A;
   DevBuf tq, gate, pts, mask, row;
+  FilterCtx filter;
   std::vector<hipEvent_t> events;  // 3 per timed call
   size_t events_used = 0;
 };
@@ -220,44 +378,92 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
   if (d_idx && !r->use_scan) return fail_arg(MLF_E_STATE, "region has no live points set");
   CK(r->gate.reserve(np));
   uint8_t *gate = r->use_scan ? r->gate.as<uint8_t>() : d_mask;
-  PrepArgs pa{};
-  pa.pts = d_pts;
-  pa.np = (long long)np;
-  pa.d = r->d;
-  pa.do_ell = 1;
-  pa.ell_ctr = r->ell_ctr.as<double>();
-  pa.ell_A = r->ell_A.as<double>();
-  pa.enlarge = r->enlarge;
-  pa.mask = gate;
-  pa.q_out = nullptr;
-  if (r->use_scan) {
-    CK(r->tq.reserve(np * (size_t)r->d * sizeof(double)));
-    pa.t_out = r->tq.as<double>();
-    pa.ldt = r->d;
-    if (r->layer_kind == 0) {
+  const bool use_filter = r->use_scan && filter_applies(r->filter, (long long)np, r->r2);
+  // fused stage (coalesced staging, coordinate-major output, optional quantisation) for affine layers
+  const bool fused = r->layer_kind == 0 && g_fused_prep && prep2_waves(r->d, r->dp) > 0 && r->dp <= 64;
+  long long ldq = r->d, ldk = 1;
+  if (r->use_scan) CK(r->tq.reserve(np * (size_t)r->d * sizeof(double)));
+  if (ev) CK(hipEventRecord(ev[0], s));
+  if (fused) {
+    Prep2Args pa{};
+    pa.pts = d_pts;
+    pa.np = (long long)np;
+    pa.d = r->d;
+    pa.ell_ctr = r->ell_ctr.as<double>();
+    pa.ell_A = r->ell_A.as<double>();
+    pa.enlarge = r->enlarge;
+    pa.gate = gate;
+    if (r->use_scan) {
       pa.do_tr = 1;
       pa.lay_ctr = r->lay_ctr.as<double>();
       pa.lay_Tt = r->lay_mat.as<double>();
       pa.wrap_shift = r->has_wrap ? r->wrap.as<double>() : nullptr;
+      pa.t_out = r->tq.as<double>();
+      pa.t_ldq = 1;
+      pa.t_ldk = (long long)np;
+      ldq = 1;
+      ldk = (long long)np;
+      if (use_filter) {
+        unsigned cap = 0;
+        FilterCtx &f = r->filter;
+        if (int rc = filter_reserve(f, (long long)np, &cap)) return rc;
+        pa.qF = f.qF.p;
+        pa.tlo = f.tlo.as<float>();
+        pa.thi = f.thi.as<float>();
+        pa.route = f.route.as<uint8_t>();
+        pa.best = f.best.as<int>();
+        pa.counters = f.counters.as<unsigned>();
+        pa.stats = f.stats.as<double>();
+        pa.r2 = r->r2;
+        pa.ks = f.ks;
+        pa.nqpad = ((long long)np + 31) / 32 * 32;
+      }
+    }
+    CK(launch_prep2(r->dp, pa, s));
+  } else {
+    PrepArgs pa{};
+    pa.pts = d_pts;
+    pa.np = (long long)np;
+    pa.d = r->d;
+    pa.do_ell = 1;
+    pa.ell_ctr = r->ell_ctr.as<double>();
+    pa.ell_A = r->ell_A.as<double>();
+    pa.enlarge = r->enlarge;
+    pa.mask = gate;
+    pa.q_out = nullptr;
+    if (r->use_scan) {
+      pa.t_out = r->tq.as<double>();
+      pa.ldt = r->d;
+      if (r->layer_kind == 0) {
+        pa.do_tr = 1;
+        pa.lay_ctr = r->lay_ctr.as<double>();
+        pa.lay_Tt = r->lay_mat.as<double>();
+        pa.wrap_shift = r->has_wrap ? r->wrap.as<double>() : nullptr;
+      }
+    }
+    CK(launch_prep(r->dp, pa, s));
+    if (r->use_scan && r->layer_kind == 1) {
+      launch_scaling_transform(d_pts, (long long)np, r->d, r->lay_ctr.as<double>(), r->lay_mat.as<double>(),
+                               r->has_wrap ? r->wrap.as<double>() : nullptr, gate, r->tq.as<double>(),
+                               r->d, s);
+      CK(hipGetLastError());
     }
   }
-  if (ev) CK(hipEventRecord(ev[0], s));
-  CK(launch_prep(r->dp, pa, s));
-  if (r->use_scan && r->layer_kind == 1) {
-    launch_scaling_transform(d_pts, (long long)np, r->d, r->lay_ctr.as<double>(), r->lay_mat.as<double>(),
-                             r->has_wrap ? r->wrap.as<double>() : nullptr, gate, r->tq.as<double>(),
-                             r->d, s);
-    CK(hipGetLastError());
-  }
   if (ev) CK(hipEventRecord(ev[1], s));
-  if (r->use_scan) {
+  if (use_filter) {
+    if (int rc = filter_run(r->filter, r->refT.as<double>(), r->refR.as<double>(), r->n, r->npad, r->d, r->dp,
+                            r->tq.as<double>(), ldq, ldk, (long long)np, r->r2, gate, d_idx ? nullptr : d_mask,
+                            d_idx, s, fused))
+      return rc;
+  } else if (r->use_scan) {
     ScanArgs a{};
     a.refT = r->refT.as<double>();
     a.n = r->n;
     a.npad = r->npad;
     a.ntiles = r->npad / kWave;
     a.q = r->tq.as<double>();
-    a.ldq = r->d;
+    a.ldq = ldq;
+    a.ldk = ldk;
     a.nq = (long long)np;
     a.d = r->d;
     a.r2 = r->r2;
@@ -305,6 +511,23 @@ int mlf_device_name(char *buf, size_t buflen) {
   CK(hipGetDeviceProperties(&prop, g_ctx.device));
   snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
   return 0;
+}
+
+int mlf_set_option(const char *name, long long value) {
+  if (!name) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (!strcmp(name, "filter")) {
+    g_filter_enabled = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "fused_prep")) {
+    g_fused_prep = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "filter_min_queries")) {
+    g_filter_min_queries = value;
+    return 0;
+  }
+  return fail_arg(MLF_E_BADARG, "unknown option");
 }
 
 int mlf_synchronize(void) {
@@ -567,6 +790,7 @@ int mlf_region_destroy(mlf_region *r) {
                     &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row};
   for (DevBuf *b : bufs) b->release();
   for (hipEvent_t e : r->events) (void)hipEventDestroy(e);
+  r->filter.release();
   delete r;
   return 0;
 }
@@ -622,6 +846,8 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
     launch_build_layouts(rows, (int)n, (int)d, dp, r->npad, r->refT.as<double>(), r->refR.as<double>(),
                          c.stream);
     CK(hipGetLastError());
+    if (int rc = filter_prepare_refs(r->filter, r->refR.as<double>(), (int)n, (int)d, dp, c.stream, true))
+      return rc;
   }
   CK(hipStreamSynchronize(c.stream));
   r->ready = true;
@@ -644,6 +870,9 @@ int mlf_region_update_point(mlf_region *r, size_t row, const double *unormed_row
   launch_update_row(src, r->d, r->dp, r->npad, (int)row, r->refT.as<double>(),
                     r->refR.as<double>(), c.stream);
   CK(hipGetLastError());
+  if (r->filter.refs_ready)  // centre / scale / norms depend on every row: requantise (two small kernels)
+    if (int rc = filter_prepare_refs(r->filter, r->refR.as<double>(), r->n, r->d, r->dp, c.stream, false))
+      return rc;
   CK(hipStreamSynchronize(c.stream));
   return 0;
 }

@@ -31,13 +31,15 @@ enum ScanMode : int {
 struct ScanArgs {
   const double *refT;
   int n, npad, ntiles;
-  const double *q;
+  const double *q;        // query element (j, k) at q[j*ldq + k*ldk]
   long long ldq;
+  long long ldk;          // 0 or 1: row-major; > 1: coordinate-major
   long long nq;
   int d;
   double r2;
   int mode;
   const uint8_t *gate;            // optional, per query: 0 = do not scan (result: none)
+  int only_gated;                 // 1: write outputs only for gated-in queries; idle workgroups exit early
   long long *out_idx;             // SCAN_FIRST / SCAN_COUNT
   unsigned long long *out_flags;  // SCAN_FLAGS  [nq][ntiles]
   uint8_t *out_mask;              // SCAN_MASK

@@ -1,0 +1,417 @@
+// mlf_filter.hip -- exactness-preserving MFMA pre-filter for the neighbour scan (K1 / R3).
+//
+// The exact scan (mlf_scan.hip) is bound by the non-fused FP64 vector rate: 3 v_*_f64 per
+// (live point, query, coordinate).  Almost all of the 4e9 pair tests of a 10^6-proposal batch are
+// nowhere near the threshold r2, so they can be DECIDED with a much cheaper bound and only the
+// few pairs that fall inside a rigorous uncertainty band are re-evaluated with the reference's
+// exact binary64 arithmetic.  The final answers (masks, first-hit indices) are bit-identical to
+// the exact scan.
+//
+//   1. live points and queries are centred (c = mean live point), scaled by a power of two
+//      sigma (|sigma*(a-c)| <= 1) and rounded to binary16:  ah = f16(sigma (a-c)),
+//      bh = f16(sigma (b-c)).
+//   2. one v_mfma_f32_32x32x16_f16 chain per 32x32 block of pairs gives
+//         Dt = |ah|^2 + |bh|^2 - 2 ah.bh     (f32 accumulate)
+//      The two squared norms ride along as spare K columns (each split into three f16 pieces
+//      against a column of ones), and the factor -2 is folded into the query operand, so the
+//      matrix core emits Dt directly and the epilogue is two compares per pair.
+//   3. per query two thresholds (derivation: DESIGN.md section 4b)
+//         Dt <= T_lo  =>  reference distance <= r2   (certain hit)
+//         Dt >  T_hi  =>  reference distance >  r2   (certain miss)
+//      with  lo = sigma*sqrt(r2)(1-2^-30) - Delta,  hi = sigma*sqrt(r2)(1+2^-30) + Delta,
+//            Delta = 2^-11(1+2^-9)(max|sigma a'| + |sigma b'|) + 2 sqrt(K) 2^-24 + 2^-40(...)   [input rounding]
+//            T_lo = lo^2 - Eacc,  T_hi = hi^2 + Eacc,  Eacc = 2^-15 (|ah|max+|bh|)^2 + 2^-22      [f32 accumulation]
+//   4. pairs with T_lo < Dt <= T_hi (or NaN) are appended to a list and re-evaluated exactly
+//      (k_recheck: the reference's sequential sub/mul/add in binary64, no FMA).
+//   Queries whose scaled coordinates do not fit binary16 are routed to the exact scan kernel;
+//   if the list overflows, the exact scan kernel redoes every filtered query (device-side flag,
+//   no host round trip).
+//
+// Fragment layout for v_mfma_f32_32x32x16_f16 (A = live points, M x K; B = queries, K x N):
+//   lane l holds 8 consecutive k (k = 8*(l>>5) + j) of row / column (l & 31); C[row][col] with
+//   col = l & 31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  Both operands are stored
+//   FRAGMENT-MAJOR in HBM ([tile32][kstep][lane][8 halves]) so that every wave-wide load is one
+//   contiguous, perfectly coalesced 1 KiB read.
+#include "mlf_filter.hpp"
+#include "mlf_filter_dev.hpp"
+
+#include <math.h>
+
+namespace mlf {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+typedef __attribute__((ext_vector_type(16))) float float16v;
+
+// ---------------------------------------------------------------- live-point statistics -----
+// single workgroup: centre c[k] = mean_i a_ik, amax = max |a_ik - c_k|, sigma = 2^-ceil(log2 amax),
+// namax = max_i |sigma (a_i - c)|.  stats: [0]=sigma [1]=namax [2]=amax [3]=finite flag; c follows at [8..]
+__global__ __launch_bounds__(1024) void k_ref_stats(const double *refR, int n, int d, int dp,
+                                                    double *stats) {
+  __shared__ double red[1024];
+  __shared__ double cc[MLF_FILTER_MAXD];
+  const int tid = threadIdx.x;
+  for (int k = 0; k < d; ++k) {
+    double s = 0.0;
+    for (int i = tid; i < n; i += 1024) s += refR[(size_t)i * dp + k];
+    red[tid] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+      if (tid < w) red[tid] += red[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) cc[k] = red[0] / (double)n;
+    __syncthreads();
+  }
+  double amax = 0.0;
+  bool finite = true;
+  for (int e = tid; e < n * d; e += 1024) {
+    const int i = e / d, k = e - i * d;
+    const double v = refR[(size_t)i * dp + k] - cc[k];
+    if (!(fabs(v) <= 1.7e308)) finite = false;
+    amax = fmax(amax, fabs(v));
+  }
+  red[tid] = finite ? amax : INFINITY;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if (tid < w) red[tid] = fmax(red[tid], red[tid + w]);
+    __syncthreads();
+  }
+  const double amax_all = red[0];
+  __syncthreads();
+  double sigma = 1.0;
+  if (amax_all > 0.0 && amax_all < 1e300) {
+    int e;
+    frexp(amax_all, &e);  // amax = m * 2^e, m in [0.5, 1)  ->  sigma*amax in [0.5, 1)
+    sigma = ldexp(1.0, -e);
+  }
+  double nmax = 0.0;
+  for (int i = tid; i < n; i += 1024) {
+    double s = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double v = sigma * (refR[(size_t)i * dp + k] - cc[k]);
+      s += v * v;
+    }
+    nmax = fmax(nmax, sqrt(s));
+  }
+  red[tid] = nmax;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if (tid < w) red[tid] = fmax(red[tid], red[tid + w]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    stats[0] = sigma;
+    stats[1] = red[0] * (1.0 + 1e-12);
+    stats[2] = amax_all;
+    stats[3] = (amax_all < 1e300) ? 1.0 : 0.0;
+  }
+  for (int k = tid; k < d; k += 1024) stats[8 + k] = cc[k];
+}
+
+// ---------------------------------------------------------------- live points -> f16 fragments
+// one thread per live-point row (rows >= n are sentinels that can never be hit)
+__global__ void k_quant_refs(const double *refR, int n, int npad32, int d, int dp, int ks,
+                             const double *stats, half_t *refF) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npad32) return;
+  const int K = ks * 16;
+  const double sigma = stats[0];
+  double na = 0.0;
+  for (int k = 0; k < d; ++k) {
+    half_t h = (half_t)0.0f;
+    if (i < n) {
+      h = (half_t)(float)(sigma * (refR[(size_t)i * dp + k] - stats[8 + k]));
+      const double hv = (double)(float)h;
+      na += hv * hv;  // exact: 22-bit products, <= 128 terms
+    }
+    refF[frag_index(i, k, ks)] = h;
+  }
+  half_t p[3];
+  if (i < n) {
+    split3(na, p);
+  } else {
+    p[0] = (half_t)60000.0f;  // sentinel row: Dt >= 60000 > every admissible T_hi
+    p[1] = p[2] = (half_t)0.0f;
+  }
+  for (int j = 0; j < 3; ++j) refF[frag_index(i, d + j, ks)] = p[j];       // x 1 in the queries
+  for (int j = 3; j < 6; ++j) refF[frag_index(i, d + j, ks)] = (half_t)1.0f;  // x |bh|^2 pieces
+  for (int k = d + 6; k < K; ++k) refF[frag_index(i, k, ks)] = (half_t)0.0f;
+}
+
+// ---------------------------------------------------------------- queries -> f16 fragments ---
+// one thread per query.  route: 0 = not scanned (gated out), 1 = filtered, 2 = exact scan only.
+__global__ void k_quant_queries(const double *q, long long ldq, long long nq, long long nqpad,
+                                int d, int ks, const double *stats, double r2,
+                                const uint8_t *gate, half_t *qF, float *tlo, float *thi,
+                                uint8_t *route, int *best, unsigned *counters) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p == 0) {
+    counters[0] = 0;  // list length
+    counters[1] = 0;  // overflow flag
+  }
+  if (p >= nqpad) return;
+  const int K = ks * 16;
+  const double sigma = stats[0], namax = stats[1];
+  int rt = 0;
+  if (p < nq && (gate == nullptr || gate[p])) rt = 1;
+  double nb = 0.0, nbn2 = 0.0;
+  if (rt == 1) {
+    for (int k = 0; k < d; ++k) {
+      const double x = sigma * (q[p * ldq + k] - stats[8 + k]);
+      if (!(fabs(x) <= 16000.0)) rt = 2;  // -2x must stay well inside binary16; NaN lands here too
+      nbn2 += x * x;
+    }
+    if (!(nbn2 <= 30000.0)) rt = 2;
+  }
+  for (int k = 0; k < d; ++k) {
+    half_t h = (half_t)0.0f;
+    if (rt == 1) {
+      h = (half_t)(float)(sigma * (q[p * ldq + k] - stats[8 + k]));
+      const double hv = (double)(float)h;
+      nb += hv * hv;
+      h = (half_t)(-2.0f * (float)h);  // exact
+    }
+    qF[frag_index((int)(p & 31), k, ks) + (size_t)(p >> 5) * ((size_t)ks * 512)] = h;
+  }
+  half_t pc[3] = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+  float lo_f = -1.0f, hi_f = -1.0f;
+  if (rt == 1) {
+    split3(nb, pc);
+    if (!filter_thresholds(sigma, namax, nbn2, r2, K, &lo_f, &hi_f)) {
+      rt = 2;
+      lo_f = hi_f = -1.0f;
+      pc[0] = pc[1] = pc[2] = (half_t)0.0f;
+    }
+  }
+  const size_t gbase = (size_t)(p >> 5) * ((size_t)ks * 512);
+  const int pr = (int)(p & 31);
+  if (rt != 1)
+    for (int k = 0; k < d; ++k) qF[gbase + frag_index(pr, k, ks)] = (half_t)0.0f;
+  for (int j = 0; j < 3; ++j) qF[gbase + frag_index(pr, d + j, ks)] = (half_t)(rt == 1 ? 1.0f : 0.0f);
+  for (int j = 3; j < 6; ++j) qF[gbase + frag_index(pr, d + j, ks)] = pc[j - 3];
+  for (int k = d + 6; k < K; ++k) qF[gbase + frag_index(pr, k, ks)] = (half_t)0.0f;
+  tlo[p] = lo_f;
+  thi[p] = hi_f;
+  if (p < nq) {
+    route[p] = (uint8_t)rt;
+    best[p] = kNone;
+  }
+}
+
+// ---------------------------------------------------------------- the MFMA filter ------------
+// One wave owns QW groups of 32 queries (B fragments resident in registers) and sweeps ALL
+// live-point tiles; a workgroup is 4 independent waves.
+template <int KS, int QW, bool FIRST>
+__global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long g0 = wave * QW;  // first query group of this wave
+  if (g0 >= a.ngroups) return;
+
+  const half8 *qF = reinterpret_cast<const half8 *>(a.qF);
+  const half8 *refF = reinterpret_cast<const half8 *>(a.refF);
+
+  half8 bq[QW][KS];
+  float tlo[QW], thi[QW];
+  int first[QW];
+  unsigned long long anyhit[QW];
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+    const long long grp = (g0 + g < a.ngroups) ? g0 + g : a.ngroups - 1;  // clamp (results discarded)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bq[g][s] = qF[((size_t)grp * KS + s) * 64 + lane];
+    const long long qi = grp * 32 + (lane & 31);
+    tlo[g] = (g0 + g < a.ngroups) ? a.tlo[qi] : -1.0f;
+    thi[g] = (g0 + g < a.ngroups) ? a.thi[qi] : -1.0f;
+    first[g] = kNone;
+    anyhit[g] = 0ull;
+  }
+  const int rowbase = 4 * (lane >> 5);
+
+  half8 af[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) af[s] = refF[(size_t)s * 64 + lane];
+
+  for (int t = 0; t < a.ntiles32; ++t) {
+    half8 an[KS];
+    const int tn = (t + 1 < a.ntiles32) ? t + 1 : t;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) an[s] = refF[((size_t)tn * KS + s) * 64 + lane];  // prefetch
+
+#pragma unroll
+    for (int g = 0; g < QW; ++g) {
+      float16v acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bq[g][s], acc, 0, 0, 0);
+
+      // All 16 values of a lane belong to ONE query (column = lane & 31) and 16 live points, so
+      // the lane-wise minimum decides the common case with 8 v_min3 + 2 compares:
+      //   vmin >  T_hi : nothing within reach in this block (certain misses)
+      //   vmin <= T_lo : the query has a certain hit (mask mode needs nothing more)
+      // Operands are finite binary16 values of bounded size, so acc holds no NaN / inf.
+      const float m0 = fminf(fminf(acc[0], acc[1]), acc[2]);
+      const float m1 = fminf(fminf(acc[3], acc[4]), acc[5]);
+      const float m2 = fminf(fminf(acc[6], acc[7]), acc[8]);
+      const float m3 = fminf(fminf(acc[9], acc[10]), acc[11]);
+      const float m4 = fminf(fminf(acc[12], acc[13]), acc[14]);
+      const float vmin = fminf(fminf(fminf(m0, m1), fminf(m2, m3)), fminf(m4, acc[15]));
+      const bool cand = vmin <= thi[g];
+      bool detail = cand;
+      if (!FIRST) {
+        const bool sure = vmin <= tlo[g];
+        anyhit[g] |= __ballot(sure);
+        detail = cand && !sure;
+      }
+      if (__ballot(detail) != 0ull) {   // wave-uniform; rare in mask mode
+        if (detail) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[r];
+            const int idx = t * 32 + rowbase + (r & 3) + 8 * (r >> 2);
+            if (v <= tlo[g]) {
+              if (FIRST) first[g] = idx < first[g] ? idx : first[g];
+            } else if (v <= thi[g]) {   // uncertainty band: exact re-check later
+              const unsigned slot = atomicAdd(&a.counters[0], 1u);
+              const unsigned long long qi = (unsigned long long)((g0 + g) * 32 + (lane & 31));
+              if (slot < a.list_cap)
+                a.list[slot] = (qi << 32) | (unsigned)idx;
+              else
+                a.counters[1] = 1u;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) af[s] = an[s];
+  }
+
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+    if (g0 + g >= a.ngroups) continue;
+    const long long qi = (g0 + g) * 32 + (lane & 31);
+    int res;
+    if (FIRST) {
+      const int other = __shfl_xor(first[g], 32);
+      res = first[g] < other ? first[g] : other;
+    } else {
+      const unsigned long long m = anyhit[g] | (anyhit[g] >> 32);
+      res = ((m >> (lane & 31)) & 1ull) ? 0 : kNone;
+    }
+    if (lane < 32 && qi < a.nq && res != kNone) a.best[qi] = res;
+  }
+}
+
+// ---------------------------------------------------------------- exact re-check --------------
+// list entry = (query << 32) | live index.  The reference's arithmetic: acc = 0; k ascending:
+// diff = a[k] - b[k]; acc += diff*diff (this file is compiled with -ffp-contract=off).
+__global__ void k_recheck(RecheckArgs a) {
+  const unsigned total = a.counters[0] < a.list_cap ? a.counters[0] : a.list_cap;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const unsigned long long ent = a.list[e];
+    const long long qi = (long long)(ent >> 32);
+    const int i = (int)(ent & 0xffffffffu);
+    if (i >= a.n || qi >= a.nq) continue;
+    const double *ar = a.refR + (size_t)i * a.dp;
+    const double *br = a.q + qi * a.ldq;
+    const long long ldk = a.ldk > 1 ? a.ldk : 1;
+    double acc = 0.0;
+    for (int k = 0; k < a.d; ++k) {
+      const double df = ar[k] - br[k * ldk];
+      acc += df * df;
+    }
+    if (acc <= a.r2) atomicMin(&a.best[qi], i);
+  }
+}
+
+// route 1 queries take their answer from best[]; route 0 = gated out; route 2 were written by the
+// exact scan kernel.  If the uncertain-pair list overflowed, route 1 answers also come from the
+// exact scan (second launch, gate = overflow), so nothing is written here.
+__global__ void k_filter_finalize(const uint8_t *route, const int *best, const unsigned *counters,
+                                  long long nq, uint8_t *out_mask, long long *out_idx) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nq) return;
+  const int rt = route[p];
+  if (rt == 2) return;
+  if (rt == 1 && counters[1] != 0u) return;
+  const int b = best[p];
+  const bool found = rt == 1 && b != kNone;
+  if (out_mask) out_mask[p] = found ? 1 : 0;
+  if (out_idx) out_idx[p] = rt == 0 ? -2ll : (found ? (long long)b : -1ll);
+}
+
+// gate for the exact scan kernel: which == 2 -> queries routed to the exact path;
+// which == 1 -> filtered queries, but only if the list overflowed
+__global__ void k_route_gate(const uint8_t *route, const unsigned *counters, long long nq, int which,
+                             uint8_t *gate) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nq) return;
+  gate[p] = (which == 2) ? (route[p] == 2) : (route[p] == 1 && counters[1] != 0u);
+}
+
+// ---------------------------------------------------------------- launchers -------------------
+void launch_ref_stats(const double *refR, int n, int d, int dp, double *stats, hipStream_t s) {
+  hipLaunchKernelGGL(k_ref_stats, dim3(1), dim3(1024), 0, s, refR, n, d, dp, stats);
+}
+
+void launch_quant_refs(const double *refR, int n, int npad32, int d, int dp, int ks,
+                       const double *stats, void *refF, hipStream_t s) {
+  hipLaunchKernelGGL(k_quant_refs, dim3((unsigned)((npad32 + 127) / 128)), dim3(128), 0, s, refR, n, npad32,
+                     d, dp, ks, stats, reinterpret_cast<half_t *>(refF));
+}
+
+void launch_quant_queries(const double *q, long long ldq, long long nq, long long nqpad, int d, int ks,
+                          const double *stats, double r2, const uint8_t *gate, void *qF, float *tlo,
+                          float *thi, uint8_t *route, int *best, unsigned *counters, hipStream_t s) {
+  hipLaunchKernelGGL(k_quant_queries, dim3((unsigned)((nqpad + 127) / 128)), dim3(128), 0, s, q, ldq, nq,
+                     nqpad, d, ks, stats, r2, gate, reinterpret_cast<half_t *>(qF), tlo, thi, route, best,
+                     counters);
+}
+
+template <int KS, int QW>
+static hipError_t launch_filter_t(const FilterArgs &a, bool first, hipStream_t s) {
+  const long long waves = (a.ngroups + QW - 1) / QW;
+  const unsigned grid = (unsigned)((waves + 3) / 4);
+  if (first)
+    hipLaunchKernelGGL((k_filter<KS, QW, true>), dim3(grid), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_filter<KS, QW, false>), dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_filter(int ks, const FilterArgs &a, bool first, hipStream_t s) {
+  if (a.ngroups <= 0) return hipSuccess;
+  switch (ks) {
+    case 1: return launch_filter_t<1, 4>(a, first, s);
+    case 2: return launch_filter_t<2, 4>(a, first, s);
+    case 3: return launch_filter_t<3, 4>(a, first, s);
+    case 4: return launch_filter_t<4, 4>(a, first, s);
+    case 5: return launch_filter_t<5, 2>(a, first, s);
+    case 6: return launch_filter_t<6, 2>(a, first, s);
+    case 7: return launch_filter_t<7, 2>(a, first, s);
+    case 8: return launch_filter_t<8, 2>(a, first, s);
+    case 9: return launch_filter_t<9, 1>(a, first, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+void launch_recheck(const RecheckArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(k_recheck, dim3(512), dim3(256), 0, s, a);
+}
+
+void launch_filter_finalize(const uint8_t *route, const int *best, const unsigned *counters, long long nq,
+                            uint8_t *out_mask, long long *out_idx, hipStream_t s) {
+  if (nq <= 0) return;
+  hipLaunchKernelGGL(k_filter_finalize, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, route, best,
+                     counters, nq, out_mask, out_idx);
+}
+
+void launch_route_gate(const uint8_t *route, const unsigned *counters, long long nq, int which,
+                       uint8_t *gate, hipStream_t s) {
+  if (nq <= 0) return;
+  hipLaunchKernelGGL(k_route_gate, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, route, counters, nq,
+                     which, gate);
+}
+
+}  // namespace mlf

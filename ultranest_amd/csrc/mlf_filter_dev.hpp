@@ -1,0 +1,54 @@
+// mlf_filter_dev.hpp -- device helpers shared by the query quantisation kernels
+// (k_quant_queries in mlf_filter.hip, the fused k_prep2 in mlf_prep2.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace mlf {
+
+typedef _Float16 half_t;
+
+__device__ __forceinline__ size_t frag_index(int row, int k, int ks) {
+  // element (row, k) of a [rows][16*ks] matrix in fragment-major order
+  const int tile = row >> 5, rr = row & 31;
+  const int kstep = k >> 4, kk = k & 15;
+  const int lane = rr + ((kk >> 3) << 5);
+  return ((((size_t)tile * ks + kstep) * 64 + lane) << 3) + (kk & 7);
+}
+
+// three binary16 pieces of a non-negative value < 60000 (covers ~33 bits)
+__device__ __forceinline__ void split3(double v, half_t *p) {
+  const half_t p1 = (half_t)(float)v;
+  const double r1 = v - (double)(float)p1;
+  const half_t p2 = (half_t)(float)r1;
+  const double r2 = r1 - (double)(float)p2;
+  p[0] = p1;
+  p[1] = p2;
+  p[2] = (half_t)(float)r2;
+}
+
+// Certain-hit / certain-miss thresholds of one query (derivation: header of mlf_filter.hip and
+// DESIGN.md 4b).  nbn2 = |sigma (b - c)|^2 of the unrounded query.  Returns false if the query
+// must take the exact scan instead (sentinel rows would not be certain misses any more).
+__device__ __forceinline__ bool filter_thresholds(double sigma, double namax, double nbn2, double r2,
+                                                  int K, float *lo_f, float *hi_f) {
+  const double nbn = sqrt(nbn2);
+  const double delta = 0x1p-11 * (1.0 + 0x1p-9) * (namax + nbn) + 2.0 * sqrt((double)K) * 0x1p-24 +
+                       0x1p-40 * (namax + nbn);
+  const double w = namax + nbn + 0x1p-8;
+  const double eacc = 0x1p-15 * w * w + 0x1p-22;
+  const double sr = sigma * sqrt(r2);
+  const double lo = sr * (1.0 - 0x1p-30) - delta;
+  const double hi = sr * (1.0 + 0x1p-30) + delta;
+  const double t_lo = lo > 0.0 ? lo * lo - eacc : -1.0;
+  const double t_hi = hi * hi + eacc;
+  float l = (float)t_lo;
+  if ((double)l > t_lo) l = nextafterf(l, -INFINITY);
+  float h = (float)t_hi;
+  if ((double)h < t_hi) h = nextafterf(h, INFINITY);
+  *lo_f = l;
+  *hi_f = h;
+  return t_hi < 30000.0;
+}
+
+}  // namespace mlf

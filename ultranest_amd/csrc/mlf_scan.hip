@@ -30,13 +30,32 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
   const long long left = a.nq - q0;
   const int nqb = left < kScanQB ? (int)left : kScanQB;
 
+  if (a.only_gated) {  // second-stage use behind the MFMA filter: usually nothing to do
+    __shared__ int any_active;
+    if (tid == 0) any_active = 0;
+    __syncthreads();
+    if (tid < nqb && a.gate[q0 + tid] != 0) any_active = 1;
+    __syncthreads();
+    if (!any_active) return;
+  }
+
   // stage this workgroup's queries, zero padded to DP
-  for (int e = tid; e < kScanQB * DP; e += kScanThreads) {
-    const int qq = e / DP;
-    const int k = e - qq * DP;
-    double v = 0.0;
-    if (qq < nqb && k < a.d) v = a.q[(q0 + qq) * a.ldq + k];
-    qs[e] = v;
+  if (a.ldk <= 1) {
+    for (int e = tid; e < kScanQB * DP; e += kScanThreads) {
+      const int qq = e / DP;
+      const int k = e - qq * DP;
+      double v = 0.0;
+      if (qq < nqb && k < a.d) v = a.q[(q0 + qq) * a.ldq + k];
+      qs[e] = v;
+    }
+  } else {  // coordinate-major source: consecutive threads read consecutive queries
+    for (int e = tid; e < kScanQB * DP; e += kScanThreads) {
+      const int k = e / kScanQB;
+      const int qq = e - k * kScanQB;
+      double v = 0.0;
+      if (qq < nqb && k < a.d) v = a.q[(q0 + qq) * a.ldq + (long long)k * a.ldk];
+      qs[qq * DP + k] = v;
+    }
   }
   if (tid < kScanQB) {
     const bool active = tid < nqb && (a.gate == nullptr || a.gate[q0 + tid] != 0);
@@ -83,7 +102,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
   }
   __syncthreads();
 
-  if (tid < nqb) {
+  if (tid < nqb && !(a.only_gated && a.gate[q0 + tid] == 0)) {
     const int st = state[tid];
     const bool found = st >= 0 && st != kNone;
     if (mode == SCAN_FIRST)
