@@ -39,7 +39,8 @@ def region_state(n, d, seed=1):
 def main():
     dev = torch.device("cuda:0")
     print(json.dumps(dict(what="fp64_valu_probe_TFLOPs", value=K.bench_fp64_valu())), flush=True)
-    for (n, d, p) in ((4000, 50, 1000000), (2000, 20, 100000), (4000, 50, 100000)):
+    quick = len(sys.argv) > 1 and sys.argv[1] == 'quick'
+    for (n, d, p) in (((4000, 50, 1000000),) if quick else ((4000, 50, 1000000), (2000, 20, 100000), (4000, 50, 100000))):
         u, ctr, T, unormed, cov, inv, r2, enlarge = region_state(n, d)
         reg = K.DeviceRegion()
         reg.set(unormed, 0, ctr, T, None, ctr, inv, enlarge, r2)
@@ -56,7 +57,9 @@ def main():
         mask = torch.empty(p, dtype=torch.uint8, device=dev)
         idx = torch.empty(p, dtype=torch.int64, device=dev)
         stream = torch.cuda.current_stream().cuda_stream
-        for label, rr in (("E", r2), ("F", 1e-300)):
+        from ultranest_amd import _lib
+        for label, rr in ((("E", r2), ("E-noband", r2), ("E-nothing", r2)) if quick else (("E", r2), ("F", 1e-300))):
+            _lib.set_option("debug_noband", {"E-noband": 1, "E-nothing": 2}.get(label, 0))
             reg.set_thresholds(enlarge, rr)
             reg.first_index_dev(pts.data_ptr(), p, idx.data_ptr(), stream)
             torch.cuda.synchronize()

@@ -71,16 +71,18 @@ struct FilterCtx {
   bool usable = false;       // statistics are finite and the dimensionality is covered
   int ks = 0, ntiles32 = 0;
   double sigma = 1.0, amax = 0.0;
-  DevBuf stats, refF, qF, tlo, thi, route, best, counters, list, gate2;
+  DevBuf stats, refF, qF, tlo, thi, route, best, counters, list, segcnt, gate2;
   void release() {
-    DevBuf *b[] = {&stats, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &gate2};
+    DevBuf *b[] = {&stats, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2};
     for (DevBuf *x : b) x->release();
     refs_ready = usable = false;
   }
 };
 
+constexpr unsigned kFilterSegCap = 2048;
 bool g_filter_enabled = true;         // mlf_set_option("filter", 0/1)
 bool g_fused_prep = true;             // mlf_set_option("fused_prep", 0/1)
+int g_debug_noband = 0;               // TIMING EXPERIMENTS ONLY: collapse the uncertainty band (wrong results)
 long long g_filter_min_queries = 2048;  // smaller batches go straight to the exact scan
 
 struct Ctx {
@@ -155,7 +157,7 @@ int stage_live_points(const double *pts, size_t n, size_t d, int dp, int npad, b
 int filter_prepare_refs(FilterCtx &f, const double *refR, int n, int d, int dp, hipStream_t s,
                         bool host_sync) {
   f.refs_ready = false;
-  const int ks = (d + 6 + 15) / 16;
+  const int ks = (dp + 6 + 15) / 16;   // filter dimensionality = padded DP (zero columns are harmless)
   if (ks > 9 || n < 1) {
     f.usable = false;
     return 0;
@@ -165,8 +167,9 @@ int filter_prepare_refs(FilterCtx &f, const double *refR, int n, int d, int dp, 
   f.ntiles32 = npad32 / 32;
   CK(f.stats.reserve((8 + MLF_FILTER_MAXD) * sizeof(double)));
   CK(f.refF.reserve((size_t)npad32 * ks * 16 * 2));
-  launch_ref_stats(refR, n, d, dp, f.stats.as<double>(), s);
-  launch_quant_refs(refR, n, npad32, d, dp, ks, f.stats.as<double>(), f.refF.p, s);
+  (void)d;
+  launch_ref_stats(refR, n, dp, dp, f.stats.as<double>(), s);
+  launch_quant_refs(refR, n, npad32, dp, dp, ks, f.stats.as<double>(), f.refF.p, s);
   CK(hipGetLastError());
   if (host_sync) {
     double h[4];
@@ -191,15 +194,16 @@ bool filter_applies(const FilterCtx &f, long long nq, double r2) {
 // Device buffers of one filtered batch.
 int filter_reserve(FilterCtx &f, long long nq, unsigned *cap_out) {
   const long long nqpad = (nq + 31) / 32 * 32;
-  const size_t cap64 = (size_t)nq * 16 + (1u << 20);
-  const unsigned cap = cap64 > 0x7fffffffu ? 0x7fffffffu : (unsigned)cap64;
+  const long long nwaves = filter_wave_count(f.ks, nqpad / 32);
+  const unsigned cap = kFilterSegCap;   // uncertain pairs per filter wave (expected: tens)
   CK(f.qF.reserve((size_t)nqpad * f.ks * 16 * 2));
   CK(f.tlo.reserve((size_t)nqpad * sizeof(float)));
   CK(f.thi.reserve((size_t)nqpad * sizeof(float)));
   CK(f.route.reserve((size_t)nq));
   CK(f.best.reserve((size_t)nq * sizeof(int)));
   CK(f.counters.reserve(4 * sizeof(unsigned)));
-  CK(f.list.reserve((size_t)cap * sizeof(unsigned long long)));
+  CK(f.list.reserve((size_t)nwaves * cap * sizeof(unsigned long long)));
+  CK(f.segcnt.reserve((size_t)nwaves * sizeof(unsigned)));
   CK(f.gate2.reserve((size_t)nq));
   *cap_out = cap;
   return 0;
@@ -216,7 +220,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   unsigned cap = 0;
   if (int rc = filter_reserve(f, nq, &cap)) return rc;
   if (!quantised)
-  launch_quant_queries(q, ldq, nq, nqpad, d, f.ks, f.stats.as<double>(), r2, gate, f.qF.p, f.tlo.as<float>(),
+  launch_quant_queries(q, ldq, nq, nqpad, d, dp, f.ks, f.stats.as<double>(), r2, gate, f.qF.p, f.tlo.as<float>(),
                        f.thi.as<float>(), f.route.as<uint8_t>(), f.best.as<int>(), f.counters.as<unsigned>(), s);
   CK(hipGetLastError());
   FilterArgs fa{};
@@ -229,13 +233,14 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   fa.nq = nq;
   fa.best = f.best.as<int>();
   fa.list = f.list.as<unsigned long long>();
-  fa.list_cap = cap;
+  fa.seg_cap = cap;
+  fa.seg_count = f.segcnt.as<unsigned>();
   fa.counters = f.counters.as<unsigned>();
   CK(launch_filter(f.ks, fa, out_idx != nullptr, s));
   RecheckArgs ra{};
   ra.list = f.list.as<unsigned long long>();
-  ra.list_cap = cap;
-  ra.counters = f.counters.as<unsigned>();
+  ra.seg_cap = cap;
+  ra.seg_count = f.segcnt.as<unsigned>();
   ra.refR = refR;
   ra.n = n;
   ra.d = d;
@@ -246,7 +251,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   ra.nq = nq;
   ra.r2 = r2;
   ra.best = f.best.as<int>();
-  launch_recheck(ra, s);
+  launch_recheck(ra, filter_wave_count(f.ks, ngroups), s);
   CK(hipGetLastError());
   // exact scan for (a) queries that do not fit binary16 and (b) everything if the list overflowed
   for (int which = 2; which >= 1; --which) {
@@ -339,7 +344,9 @@ struct mlf_region {
   int layer_kind = 0, use_scan = 1, live_space = 0;
   bool has_wrap = false;
   double enlarge = 0.0, r2 = 0.0;
-  DevBuf refT, refR, lay_ctr, lay_mat, wrap, ell_ctr, ell_A;
+  DevBuf refT, refR, lay_ctr, lay_mat, lay_T8, wrap, ell_ctr, ell_A, ell_Lt;
+  bool chol_ready = false, chol_ok = false;
+  double ell_eps_scale = 0.0;
   DevBuf tq, gate, pts, mask, row;
   FilterCtx filter;
   std::vector<hipEvent_t> events;  // 3 per timed call
@@ -380,7 +387,7 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
   uint8_t *gate = r->use_scan ? r->gate.as<uint8_t>() : d_mask;
   const bool use_filter = r->use_scan && filter_applies(r->filter, (long long)np, r->r2);
   // fused stage (coalesced staging, coordinate-major output, optional quantisation) for affine layers
-  const bool fused = r->layer_kind == 0 && g_fused_prep && prep2_waves(r->d, r->dp) > 0 && r->dp <= 64;
+  const bool fused = r->layer_kind == 0 && g_fused_prep && prep2_usable(r->dp) && r->chol_ready;
   long long ldq = r->d, ldk = 1;
   if (r->use_scan) CK(r->tq.reserve(np * (size_t)r->d * sizeof(double)));
   if (ev) CK(hipEventRecord(ev[0], s));
@@ -393,10 +400,13 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
     pa.ell_A = r->ell_A.as<double>();
     pa.enlarge = r->enlarge;
     pa.gate = gate;
+    pa.ell_Lt = r->ell_Lt.as<double>();
+    pa.ell_eps_scale = r->ell_eps_scale;
+    pa.chol_ok = r->chol_ok ? 1 : 0;
     if (r->use_scan) {
       pa.do_tr = 1;
       pa.lay_ctr = r->lay_ctr.as<double>();
-      pa.lay_Tt = r->lay_mat.as<double>();
+      pa.lay_T8 = r->lay_T8.as<double>();
       pa.wrap_shift = r->has_wrap ? r->wrap.as<double>() : nullptr;
       pa.t_out = r->tq.as<double>();
       pa.t_ldq = 1;
@@ -417,6 +427,7 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
         pa.r2 = r->r2;
         pa.ks = f.ks;
         pa.nqpad = ((long long)np + 31) / 32 * 32;
+        pa.debug_noband = g_debug_noband;
       }
     }
     CK(launch_prep2(r->dp, pa, s));
@@ -517,6 +528,10 @@ int mlf_set_option(const char *name, long long value) {
   if (!name) return fail_arg(MLF_E_BADARG, "null pointer");
   if (!strcmp(name, "filter")) {
     g_filter_enabled = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "debug_noband")) {
+    g_debug_noband = (int)value;
     return 0;
   }
   if (!strcmp(name, "fused_prep")) {
@@ -786,7 +801,7 @@ int mlf_region_create(mlf_region **out) {
 
 int mlf_region_destroy(mlf_region *r) {
   if (!r) return 0;
-  DevBuf *bufs[] = {&r->refT, &r->refR, &r->lay_ctr, &r->lay_mat, &r->wrap, &r->ell_ctr,
+  DevBuf *bufs[] = {&r->refT, &r->refR, &r->lay_ctr, &r->lay_mat, &r->lay_T8, &r->ell_Lt, &r->wrap, &r->ell_ctr,
                     &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row};
   for (DevBuf *b : bufs) b->release();
   for (hipEvent_t e : r->events) (void)hipEventDestroy(e);
@@ -821,10 +836,51 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
   const int dp = r->dp;
   if (int rc = prep_consts(r->ell_ctr, r->ell_A, ell_center, ell_invcov, (int)d, dp, false, c.stream))
     return rc;
+  {  // Cholesky factor + Frobenius norm of the ellipsoid matrix for the bounded H3 evaluation (k_prep2)
+    std::vector<double> L((size_t)d * d, 0.0), Lt((size_t)dp * dp, 0.0);
+    bool ok = true;
+    double fro = 0.0;
+    for (size_t e = 0; e < d * d; ++e) fro += ell_invcov[e] * ell_invcov[e];
+    for (size_t j = 0; j < d && ok; ++j) {
+      double diag = ell_invcov[j * d + j];
+      for (size_t k = 0; k < j; ++k) diag -= L[j * d + k] * L[j * d + k];
+      if (!(diag > 0.0) || !std::isfinite(diag)) {
+        ok = false;
+        break;
+      }
+      const double ljj = std::sqrt(diag);
+      L[j * d + j] = ljj;
+      for (size_t i = j + 1; i < d; ++i) {
+        double v = 0.5 * (ell_invcov[i * d + j] + ell_invcov[j * d + i]);
+        for (size_t k = 0; k < j; ++k) v -= L[i * d + k] * L[j * d + k];
+        L[i * d + j] = v / ljj;
+      }
+    }
+    // the bound assumes a symmetric matrix: an asymmetric one takes the exact path
+    for (size_t i = 0; i < d && ok; ++i)
+      for (size_t j = 0; j < i; ++j)
+        if (std::fabs(ell_invcov[i * d + j] - ell_invcov[j * d + i]) >
+            1e-14 * (std::fabs(ell_invcov[i * d + i]) + std::fabs(ell_invcov[j * d + j])))
+          ok = false;
+    if (ok)
+      for (size_t k = 0; k < d; ++k)
+        for (size_t j = 0; j < d; ++j) Lt[k * dp + j] = L[j * d + k];
+    r->chol_ok = ok && std::isfinite(fro);
+    r->ell_eps_scale = std::ldexp(1.0, -34) * std::sqrt(fro);
+    if (int rc = upload(r->ell_Lt, Lt.data(), Lt.size() * sizeof(double), c.stream)) return rc;
+    CK(hipStreamSynchronize(c.stream));
+    r->chol_ready = true;
+  }
   if (use_scan) {
     if (layer_kind == 0) {
       if (int rc = prep_consts(r->lay_ctr, r->lay_mat, layer_ctr, layer_T, (int)d, dp, true, c.stream))
         return rc;
+      const int dp8 = (dp + 7) / 8 * 8;
+      std::vector<double> t8((size_t)dp * dp8, 0.0);
+      for (size_t k = 0; k < d; ++k)
+        for (size_t cc = 0; cc < d; ++cc) t8[k * dp8 + cc] = layer_T[k * d + cc];
+      if (int rc = upload(r->lay_T8, t8.data(), t8.size() * sizeof(double), c.stream)) return rc;
+      CK(hipStreamSynchronize(c.stream));
     } else {
       if (int rc = upload(r->lay_ctr, layer_ctr, d * sizeof(double), c.stream)) return rc;
       if (int rc = upload(r->lay_mat, layer_T, d * sizeof(double), c.stream)) return rc;

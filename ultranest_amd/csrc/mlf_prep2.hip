@@ -1,193 +1,273 @@
 // mlf_prep2.hip -- fused per-proposal stage of MLFriends.inside for AffineLayer-family regions:
-//   H3 ellipsoid test (reference mlfriends.pyx:882-912, numpy-einsum order, no FMA)
-//   T1 whitening      (:737-743 incl. wraps :529-536, FMA chain)
+//   H3 ellipsoid test (reference mlfriends.pyx:882-912)
+//   T1 whitening      (:737-743 incl. wraps :529-536; k-ascending FMA chain as in k_prep)
 //   + binary16 quantisation and thresholds for the MFMA pre-filter (mlf_filter.hip)
-// in ONE pass over the proposals, with HBM traffic at the algorithmic minimum:
-//   * a wave's 64 proposal rows (64*d contiguous doubles) are read with fully coalesced loads
-//     into an LDS staging area (row stride DP+1 doubles -> conflict-free per-lane row reads);
-//     the first version read rows lane-strided and fetched every row ~3.7x (rocprofv3 FETCH_SIZE)
-//   * whitened coordinates are written COORDINATE-major (t[c*P + p]): coalesced
-//   * the binary16 query fragments are written as 16-byte pieces that are contiguous across lanes
-// Arithmetic of H3 / T1 is identical to k_prep (mlf_prep.hip); -ffp-contract=off.
+// One lane = one proposal, everything in registers (compile-time indices only), both d x d
+// matrices resident in LDS and broadcast:
+//
+//   * H3 costs 3 d^2 non-fused FP64 ops in the reference's (numpy einsum) order.  Here a bound is
+//     evaluated first: with the Cholesky factor A = L L^T (host),  qt = |L^T delta|^2  needs d^2
+//     FMAs, and |qt - q_ref| <= 2^-34 |A|_F |delta|^2 (far above the rounding of both forms:
+//     (d^2+2) 2^-52 for the einsum order, O(d^1.5) 2^-53 for the factorised form).  Only proposals
+//     with |qt - enlarge| inside that band take the exact einsum-order evaluation, so the mask is
+//     bit-identical to k_prep's at a third of the arithmetic.
+//   * the whitened coordinates are produced eight at a time (eight independent FMA chains per
+//     coordinate block), written coordinate-major (coalesced) and quantised on the fly into
+//     16-byte binary16 fragment pieces that are contiguous across lanes.
+//   * HBM traffic: the proposal row is read twice (the second read applies wraps / the layer
+//     centre), 8d + 2K + 9 bytes are written per proposal.
+// -ffp-contract=off; FMAs only where written.
 #include "mlf_filter_dev.hpp"
 #include "mlf_prep2.hpp"
 
 namespace mlf {
 
-template <int DP>
-__global__ __launch_bounds__(256) void k_prep2(Prep2Args a) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int DPS = DP + 1;  // padded staging row stride (doubles)
-  const int d = a.d;
-  double *mat = lds;                                   // [d][DP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nw = blockDim.x >> 6;
-  double *stage = lds + (size_t)d * DP + (size_t)wave * 64 * DPS;
+// circular dimensions are rare: keep the (large) inline expansion of fmod out of the unrolled loop
+__device__ __attribute__((noinline)) double wrap_coordinate(double w, double shift) {
+  return fmod(w + shift, 1.0);
+}
 
-  const long long p0 = ((long long)blockIdx.x * nw + wave) * 64;  // first proposal of this wave
-  const long long p = p0 + lane;
+template <int DP, bool WRAP>
+__global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
+  constexpr int DP8 = (DP + 7) / 8 * 8;
+  constexpr int KS = (DP + 6 + 15) / 16;
+  constexpr int K = KS * 16;
+  constexpr int NFULL = DP / 8;         // complete blocks of 8 real coordinates
+  constexpr int C0T = NFULL * 8;        // first column of the tail
+  constexpr int NTAIL = K - C0T;        // tail columns: remaining coordinates, norm pieces, zeros
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double *Lt = lds;                     // [DP][DP]   Lt[k][j] = L[j][k]
+  double *Tm = lds + DP * DP;           // [DP][DP8]  Tm[k][c] = T[k][c]
+
+  const int tid = threadIdx.x;
+  const int d = a.d;
+  const long long p = (long long)blockIdx.x * 256 + tid;
   const bool live = p < a.np;
+  const double *row = a.pts + (live ? p : 0) * (long long)d;
 
   if (blockIdx.x == 0 && tid == 0 && a.counters) {
     a.counters[0] = 0;
     a.counters[1] = 0;
   }
-
-  // ---- phase 0: coalesced copy of this wave's rows into LDS, zero padded ------------------
-  {
-    const long long rows_left = a.np - p0;
-    const int nrows = rows_left >= 64 ? 64 : (rows_left > 0 ? (int)rows_left : 0);
-    const double *src = a.pts + p0 * d;
-    const int total = nrows * d;
-    for (int e = lane; e < 64 * d; e += 64) {
-      const int row = e / d, k = e - row * d;
-      stage[row * DPS + k] = e < total ? src[e] : 0.0;
-    }
-    for (int e = lane; e < 64 * (DPS - d); e += 64) {
-      const int row = e / (DPS - d), k = d + e - row * (DPS - d);
-      stage[row * DPS + k] = 0.0;
-    }
-  }
-  for (int e = tid; e < d * DP; e += blockDim.x) mat[e] = a.ell_A[e];
+  for (int e = tid; e < DP * DP; e += 256) Lt[e] = a.ell_Lt[e];
+  if (a.do_tr)
+    for (int e = tid; e < DP * DP8; e += 256) Tm[e] = a.lay_T8[e];
   __syncthreads();
 
-  const double *row = stage + lane * DPS;
-
-  // ---- phase 1: ellipsoid quadratic form, numpy c_einsum order ---------------------------
-  bool inside;
+  // ---- H3 -----------------------------------------------------------------------------------
+  bool inside = false;
   {
     double dl[DP];
+    double nrm2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < DP; ++k) dl[k] = (k < d) ? row[k] - a.ell_ctr[k] : 0.0;
-    double acc = 0.0;
-    for (int j = 0; j < d; ++j) {
-      const double dj = row[j] - a.ell_ctr[j];
-      const double2 *arow = reinterpret_cast<const double2 *>(mat + j * DP);
+    for (int k = 0; k < DP; ++k) {
+      // clamped address + select instead of a branch per coordinate (rows hold d <= DP values;
+      // the centre arrays are zero padded to DP)
+      const double v = row[k < d ? k : d - 1] - a.ell_ctr[k];
+      dl[k] = (k < d) ? v : 0.0;
+      nrm2 = __builtin_fma(dl[k], dl[k], nrm2);
+    }
+    double qt = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double2 *lrow = reinterpret_cast<const double2 *>(Lt + k * DP);
+      double y = 0.0;
 #pragma unroll
-      for (int k = 0; k < DP; k += 2) {
-        const double2 v = arow[k >> 1];
-        acc += (dj * v.x) * dl[k];
-        acc += (dj * v.y) * dl[k + 1];
+      for (int j = 0; j < DP; j += 2) {
+        const double2 v = lrow[j >> 1];
+        y = __builtin_fma(dl[j], v.x, y);
+        y = __builtin_fma(dl[j + 1], v.y, y);
+      }
+      qt = __builtin_fma(y, y, qt);
+    }
+    const double eps = a.ell_eps_scale * nrm2;
+    const bool sure_in = a.chol_ok && (qt + eps < a.enlarge);
+    const bool sure_out = a.chol_ok && (qt - eps > a.enlarge);
+    inside = sure_in;
+    const bool need_exact = live && !sure_in && !sure_out;   // also every NaN
+    if (__any(need_exact)) {
+      if (need_exact) {   // the reference's arithmetic: one accumulator, j outer, (d_j*A_jk)*d_k
+        double acc = 0.0;
+        for (int j = 0; j < d; ++j) {
+          const double dj = row[j] - a.ell_ctr[j];
+          const double *arow = a.ell_A + (size_t)j * DP;
+#pragma unroll
+          for (int k = 0; k < DP; ++k) acc += (dj * arow[k]) * dl[k];
+        }
+        inside = acc <= a.enlarge;
       }
     }
-    inside = live && (acc <= a.enlarge);
+    inside = inside && live;
     if (live) a.gate[p] = inside ? 1 : 0;
   }
   if (!a.do_tr) return;
-  __syncthreads();
-  for (int e = tid; e < d * DP; e += blockDim.x) mat[e] = a.lay_Tt[e];
-  __syncthreads();
 
-  // ---- phase 2: whitening + quantisation ------------------------------------------------
+  // ---- T1 + quantisation --------------------------------------------------------------------
   const bool quant = a.qF != nullptr;
-  const int K = a.ks * 16;
-  half_t *hrow = reinterpret_cast<half_t *>(stage + lane * DPS);  // reuses the lane's own row
+  if (!quant && !__any(inside)) return;
+  const long long grp = p >> 5;
+  const int r = (int)(p & 31);
+  uint4 *qdst = reinterpret_cast<uint4 *>(a.qF);
+  const bool wr = quant && p < a.nqpad;
+  const double sigma = quant ? a.stats[0] : 1.0;
+
+  double dl[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) {
+    double w = row[k < d ? k : d - 1];
+    {
+      if (WRAP) {
+        const double sh = a.wrap_shift[k];
+        if (sh == sh) {   // NaN marks an unwrapped dimension
+          // fmod(w + sh, 1): for 0 <= x < 2 (cube coordinates) it is x or x - 1, both exact
+          const double x = w + sh;
+          w = (x >= 0.0 && x < 2.0) ? (x >= 1.0 ? x - 1.0 : x) : wrap_coordinate(w, sh);
+        }
+      }
+      w -= a.lay_ctr[k];
+    }
+    dl[k] = (k < d) ? w : 0.0;
+  }
+
   double nb = 0.0, nbn2 = 0.0;
   bool fits = true;
-  if (__any(inside)) {
-    double dl[DP];
+
+  // quantise one whitened coordinate; returns the operand value -2*f16(sigma (t - c))
+  auto quantise = [&](double t, int c) -> half_t {
+    const double x = sigma * (t - a.stats[8 + c]);
+    if (!(fabs(x) <= 16000.0)) fits = false;   // NaN lands here too
+    nbn2 = __builtin_fma(x, x, nbn2);
+    const half_t h = (half_t)(float)x;
+    const double hv = (double)(float)h;
+    nb += hv * hv;                              // exact
+    return (half_t)(-2.0f * (float)h);
+  };
+  auto piece_index = [&](int c0) -> size_t {   // 16-byte piece holding columns c0 .. c0+7
+    return ((size_t)grp * KS + (c0 >> 4)) * 64 + r + 32 * ((c0 >> 3) & 1);
+  };
+  auto pack2 = [](half_t lo, half_t hi) -> unsigned {
+    return (unsigned)__builtin_bit_cast(unsigned short, lo) |
+           ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+  };
+
+#pragma unroll 1
+  for (int cc = 0; cc < NFULL; ++cc) {
+    const double *tbase = Tm + cc * 8;
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < DP; ++k) {
-      double w = 0.0;
-      if (k < d) {
-        w = row[k];
-        if (a.wrap_shift) {
-          const double sh = a.wrap_shift[k];
-          if (sh == sh) w = fmod(w + sh, 1.0);
-        }
-        w -= a.lay_ctr[k];
-      }
-      dl[k] = w;
+      const double2 *tk = reinterpret_cast<const double2 *>(tbase + k * DP8);
+      const double2 v0 = tk[0], v1 = tk[1], v2 = tk[2], v3 = tk[3];
+      acc[0] = __builtin_fma(dl[k], v0.x, acc[0]);
+      acc[1] = __builtin_fma(dl[k], v0.y, acc[1]);
+      acc[2] = __builtin_fma(dl[k], v1.x, acc[2]);
+      acc[3] = __builtin_fma(dl[k], v1.y, acc[3]);
+      acc[4] = __builtin_fma(dl[k], v2.x, acc[4]);
+      acc[5] = __builtin_fma(dl[k], v2.y, acc[5]);
+      acc[6] = __builtin_fma(dl[k], v3.x, acc[6]);
+      acc[7] = __builtin_fma(dl[k], v3.y, acc[7]);
+      // keep the evaluation k-major: without this pin hipcc (ROCm 7.2) evaluates one accumulator chain
+      // at a time and spills the other seven operands of every LDS read to scratch (2.6 KB/lane)
+      if ((k & 1) == 1)
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
+                     "+v"(acc[6]), "+v"(acc[7]));
     }
-    const double sigma = quant ? a.stats[0] : 1.0;
-    for (int c = 0; c < d; ++c) {
-      const double2 *trow = reinterpret_cast<const double2 *>(mat + c * DP);
-      double acc = 0.0;
+    half_t hq[8];
 #pragma unroll
-      for (int k = 0; k < DP; k += 2) {
-        const double2 v = trow[k >> 1];
-        acc = __builtin_fma(dl[k], v.x, acc);
-        acc = __builtin_fma(dl[k + 1], v.y, acc);
-      }
-      if (inside) a.t_out[p * a.t_ldq + (long long)c * a.t_ldk] = acc;
-      if (quant) {
-        const double x = sigma * (acc - a.stats[8 + c]);
-        if (!(fabs(x) <= 16000.0)) fits = false;   // NaN lands here too
-        nbn2 += x * x;
-        const half_t h = (half_t)(float)x;
-        const double hv = (double)(float)h;
-        nb += hv * hv;
-        hrow[c] = (half_t)(-2.0f * (float)h);
-      }
+    for (int i = 0; i < 8; ++i) {
+      const int c = cc * 8 + i;
+      if (inside && c < d) a.t_out[p * a.t_ldq + (long long)c * a.t_ldk] = acc[i];
+      hq[i] = (quant && inside) ? quantise(acc[i], c) : (half_t)0.0f;
     }
+    if (wr)
+      qdst[piece_index(cc * 8)] = make_uint4(pack2(hq[0], hq[1]), pack2(hq[2], hq[3]), pack2(hq[4], hq[5]),
+                                             pack2(hq[6], hq[7]));
+  }
+
+  // tail: remaining real coordinates, then the norm / ones columns, then zero padding
+  half_t tail[NTAIL];
+#pragma unroll
+  for (int i = 0; i < NTAIL; ++i) tail[i] = (half_t)0.0f;
+#pragma unroll
+  for (int i = 0; i < DP - C0T; ++i) {
+    const int c = C0T + i;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) acc = __builtin_fma(dl[k], Tm[k * DP8 + c], acc);
+    if (inside && c < d) a.t_out[p * a.t_ldq + (long long)c * a.t_ldk] = acc;
+    if (quant && inside) tail[i] = quantise(acc, c);
   }
   if (!quant) return;
 
   int rt = inside ? 1 : 0;
   if (rt == 1 && (!fits || !(nbn2 <= 30000.0))) rt = 2;
-  half_t pc[3] = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
   float lo_f = -1.0f, hi_f = -1.0f;
   if (rt == 1) {
+    half_t pc[3];
     split3(nb, pc);
-    if (!filter_thresholds(a.stats[0], a.stats[1], nbn2, a.r2, K, &lo_f, &hi_f)) {
+    if (filter_thresholds(a.stats[0], a.stats[1], nbn2, a.r2, K, &lo_f, &hi_f)) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        tail[DP - C0T + j] = (half_t)1.0f;     // x |ah|^2 pieces of the live point
+        tail[DP - C0T + 3 + j] = pc[j];        // x ones column of the live point
+      }
+    } else {
       rt = 2;
       lo_f = hi_f = -1.0f;
-      pc[0] = pc[1] = pc[2] = (half_t)0.0f;
     }
   }
-  if (rt != 1)
-    for (int k = 0; k < d; ++k) hrow[k] = (half_t)0.0f;
-  for (int j = 0; j < 3; ++j) hrow[d + j] = (half_t)(rt == 1 ? 1.0f : 0.0f);
-  for (int j = 3; j < 6; ++j) hrow[d + j] = pc[j - 3];
-  for (int k = d + 6; k < K; ++k) hrow[k] = (half_t)0.0f;
-
-  __syncthreads();  // LDS half rows complete (also a compiler barrier for the re-typed reads below)
-  if (p < a.nqpad) {
-    a.tlo[p] = lo_f;
-    a.thi[p] = hi_f;
-    if (live) {
-      a.route[p] = (uint8_t)rt;
-      a.best[p] = kNone;
-    }
-    // 16-byte fragment pieces: (group, kstep, half) -> lane r + 32*half holds k = 16*kstep + 8*half + 0..7
-    const long long grp = p >> 5;
-    const int r = (int)(p & 31);
-    uint4 *dst = reinterpret_cast<uint4 *>(a.qF);
-    const uint2 *h2 = reinterpret_cast<const uint2 *>(hrow);   // rows are 8-byte aligned
-    for (int s = 0; s < a.ks; ++s)
-      for (int hf = 0; hf < 2; ++hf) {
-        const uint2 lo2 = h2[(s * 16 + hf * 8) >> 2];
-        const uint2 hi2 = h2[((s * 16 + hf * 8) >> 2) + 1];
-        dst[((size_t)grp * a.ks + s) * 64 + r + 32 * hf] = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
-      }
+  if (a.debug_noband == 1) hi_f = lo_f;
+  if (a.debug_noband == 2) lo_f = hi_f = -1.0f;
+  if (!wr) return;
+  if (rt != 1) {   // not filtered after all: every operand column of this query must be zero
+#pragma unroll
+    for (int i = 0; i < NTAIL; ++i) tail[i] = (half_t)0.0f;
+    if (rt == 2)
+      for (int cc = 0; cc < NFULL; ++cc) qdst[piece_index(cc * 8)] = make_uint4(0u, 0u, 0u, 0u);
+  }
+#pragma unroll
+  for (int i = 0; i < NTAIL; i += 8)
+    qdst[piece_index(C0T + i)] = make_uint4(pack2(tail[i], tail[i + 1]), pack2(tail[i + 2], tail[i + 3]),
+                                            pack2(tail[i + 4], tail[i + 5]), pack2(tail[i + 6], tail[i + 7]));
+  a.tlo[p] = lo_f;
+  a.thi[p] = hi_f;
+  if (live) {
+    a.route[p] = (uint8_t)rt;
+    a.best[p] = kNone;
   }
 }
 
-size_t prep2_lds_bytes(int d, int dp, int nw) {
-  return ((size_t)d * dp + (size_t)nw * 64 * (dp + 1)) * sizeof(double);
+static size_t prep2_lds_bytes(int dp) {
+  const int dp8 = (dp + 7) / 8 * 8;
+  return ((size_t)dp * dp + (size_t)dp * dp8) * sizeof(double);
 }
 
-int prep2_waves(int d, int dp) {
-  for (int nw = 4; nw >= 1; --nw)
-    if (prep2_lds_bytes(d, dp, nw) <= 160 * 1024) return nw;
-  return 0;
-}
+bool prep2_usable(int dp) { return dp <= 64 && prep2_lds_bytes(dp) <= 80 * 1024; }
 
 hipError_t launch_prep2(int dp, const Prep2Args &a, hipStream_t s) {
   if (a.np <= 0) return hipSuccess;
-  const int nw = prep2_waves(a.d, dp);
-  if (nw == 0) return hipErrorInvalidValue;
+  if (!prep2_usable(dp)) return hipErrorInvalidValue;
   const long long rows = a.qF ? a.nqpad : a.np;
-  const unsigned grid = (unsigned)((rows + 64 * nw - 1) / (64 * nw));
-  const size_t lds = prep2_lds_bytes(a.d, dp, nw);
+  const unsigned grid = (unsigned)((rows + 255) / 256);
+  const size_t lds = prep2_lds_bytes(dp);
+  const bool wrap = a.wrap_shift != nullptr;
   switch (dp) {
-#define X(D)                                                                                   \
-  case D: {                                                                                    \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep2<D>),           \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (e != hipSuccess) return e;                                                             \
-    hipLaunchKernelGGL(k_prep2<D>, dim3(grid), dim3(64 * nw), lds, s, a);                      \
-    break;                                                                                     \
+#define X(D)                                                                                      \
+  case D: {                                                                                       \
+    static bool attr_set = false;                                                                 \
+    if (!attr_set && lds > 48 * 1024) {                                                           \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep2<D, false>),     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      if (e == hipSuccess)                                                                        \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep2<D, true>),               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+      if (e != hipSuccess) return e;                                                              \
+      attr_set = true;                                                                            \
+    }                                                                                             \
+    if (wrap)                                                                                     \
+      hipLaunchKernelGGL((k_prep2<D, true>), dim3(grid), dim3(256), lds, s, a);                   \
+    else                                                                                          \
+      hipLaunchKernelGGL((k_prep2<D, false>), dim3(grid), dim3(256), lds, s, a);                  \
+    break;                                                                                        \
   }
     MLF_FOR_EACH_DP_PREP2(X)
 #undef X
