@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 N_LIVE, NDIM, NPROPOSALS, NBOOT = 4000, 50, 1000000, 30
 FP64_VALU_PEAK_TFLOPS = 39.3     # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz, one flop per non-fused v_*_f64
+F16_MFMA_PEAK_TFLOPS = 2500.0    # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -140,22 +141,35 @@ def main():
     mask = torch.empty(NPROPOSALS, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    for _ in range(args.warmup):
-        handle.inside_dev(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
-    handle.timing_collect()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        handle.inside_dev_timed(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ncalls, ms_prep, ms_scan = handle.timing_collect()
+    from ultranest_amd import _lib as lib_mod
+
+    def timed_steps(nsteps):
+        for _ in range(args.warmup):
+            handle.inside_dev(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
+        handle.timing_collect()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            handle.inside_dev_timed(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, handle.timing_collect()
+
+    elapsed, (ncalls, ms_prep, ms_scan, ms_rest) = timed_steps(args.steps)
     accept = float(mask.float().mean().item())
+    filter_on, kdim, ntiles32 = handle.filter_info(NPROPOSALS)
+    mask_filter = mask.clone()
+    # reference point: the exact FP64 scan kernel alone (MFMA pre-filter switched off), same batch
+    nsteps_x = max(3, args.steps // 4)
+    lib_mod.set_option("filter", 0)
+    exact_elapsed, (ncalls_x, ms_prep_x, ms_scan_x, ms_rest_x) = timed_steps(nsteps_x)
+    lib_mod.set_option("filter", 1)
+    assert bool((mask == mask_filter).all().item()), "filter and exact scan disagree"
 
     # algorithmic work of the neighbour scan on this batch: the reference's loop stops at the first
     # hit, so a proposal costs 3*d flops per live point visited = (first index + 1), or N if none
@@ -178,13 +192,42 @@ def main():
 
     scan_ms = ms_scan / max(ncalls, 1)
     prep_ms = ms_prep / max(ncalls, 1)
+    rest_ms = ms_rest / max(ncalls, 1)
+    scan_x_ms = ms_scan_x / max(ncalls_x, 1)
     value = NPROPOSALS * world * args.steps / elapsed
     alg_bytes = NPROPOSALS * (8 * NDIM + 1) + 8 * N_LIVE * NDIM + 2 * 8 * NDIM * NDIM
-    achieved_tflops = scan_flops / (scan_ms * 1e-3) / 1e12
+    exact_tflops = scan_flops / (scan_x_ms * 1e-3) / 1e12
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_scan_traffic.json")
     if os.path.exists(pmc_file):
         traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+    exact_roof = {
+        "kernel": "k_scan<50> (exact FP64 neighbour scan; the whole scan when the pre-filter is off, "
+                  "the re-check arithmetic when it is on)",
+        "bound": "valu_fp64", "achieved": exact_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": exact_tflops / FP64_VALU_PEAK_TFLOPS, "ms_per_launch": scan_x_ms,
+        "algorithmic_flops_per_launch": scan_flops,
+        "measured_valu_probe_tflops": kernels.bench_fp64_valu(),
+        "proposals_per_s_filter_off": NPROPOSALS * world * nsteps_x / exact_elapsed,
+        "note": "bit-exactness forbids FMA/MFMA in the distance itself: peak = non-fused FP64 vector issue rate"}
+    stage_ms = prep_ms + scan_ms + rest_ms
+    hbm = {"algorithmic_bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / (stage_ms * 1e-3) / 1e9,
+           "peak_GBps": HBM_PEAK_GBPS, "frac": alg_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    if filter_on:
+        # f16 GEMM of the pre-filter: every (live point, proposal) pair costs 2*(d+6) flops
+        # (d coordinates + 6 norm columns ride the matrix core); the executed K is padded to kdim
+        mfma_flops = 2.0 * N_LIVE * NPROPOSALS * (NDIM + 6)
+        ach = mfma_flops / (scan_ms * 1e-3) / 1e12
+        roofline = {"kernel": "k_filter (v_mfma_f32_32x32x16_f16 bound on every pair distance)",
+                    "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / F16_MFMA_PEAK_TFLOPS, "ms_per_launch": scan_ms,
+                    "algorithmic_flops_per_launch": mfma_flops, "executed_k_columns": kdim,
+                    "traffic": traffic, "hbm": hbm}
+    else:
+        roofline = dict(exact_roof)
+        roofline["traffic"] = traffic
+        roofline["hbm"] = hbm
+    prep_bytes = NPROPOSALS * (2 * 8 * NDIM + 8 * NDIM + 2 * kdim + 9)
     out = {
         "metric": "proposal-points filtered/sec (MLFriends.inside) + region-rebuild ms, N=4000 d=50",
         "value": value, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -194,22 +237,21 @@ def main():
                                "wrapping ellipsoid (set E), AffineLayer, 30 bootstraps; one step = MLFriends.inside "
                                "on a batch resident in HBM",
                    "n_live": N_LIVE, "d": NDIM, "proposals_per_step_per_gpu": NPROPOSALS, "bootstraps": NBOOT,
-                   "parallelism": "proposal rows sharded over %d GPU(s), region replicated" % world},
+                   "parallelism": "proposal rows sharded over " + str(world) + " GPU(s), region replicated",
+                   "mfma_prefilter": bool(filter_on)},
         "rebuild_ms": rebuild_ms, "rebuild_first_ms": first_ms,
         "accept_fraction": accept, "ellipsoid_pass_fraction": ell_pass,
-        "kernel_ms": {"k_prep(ellipsoid+whiten)": prep_ms, "k_scan(neighbour scan)": scan_ms},
-        "roofline": {
-            "bound": "valu_fp64",
-            "note": "the scan is compute bound on NON-FUSED FP64 vector ops (bit-exactness forbids FMA and MFMA); "
-                    "SURVEY.md 8d. HBM figures are reported alongside as north_star asks.",
-            "achieved": achieved_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved_tflops / FP64_VALU_PEAK_TFLOPS,
-            "algorithmic_flops_per_launch": scan_flops,
-            "measured_valu_probe_tflops": kernels.bench_fp64_valu(),
-            "traffic": traffic,
-            "hbm": {"algorithmic_bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / (scan_ms * 1e-3) / 1e9,
-                    "peak_GBps": HBM_PEAK_GBPS, "frac": alg_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-        },
+        "kernel_ms": {"per-proposal stage (k_prep2: ellipsoid + whitening + f16 quantisation)": prep_ms,
+                      ("scan kernel (k_filter)" if filter_on else "scan kernel (k_scan)"): scan_ms,
+                      "rest of scan stage (exact re-check of uncertain pairs, routing, finalise)": rest_ms},
+        "roofline": roofline,
+        "roofline_exact_scan": exact_roof,
+        "roofline_prep": {"kernel": "k_prep2<50>", "bound": "hbm", "unit": "GB/s",
+                          "achieved": prep_bytes / (prep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                          "frac": prep_bytes / (prep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                          "algorithmic_bytes_per_launch": prep_bytes,
+                          "note": "reads each proposal row twice, writes whitened f64 + f16 fragments; also "
+                                  "~5.4e3 FP64 FMAs per proposal with LDS-broadcast operands"},
     }
     if world == 1 and not args.no_cpu:
         sample = pts[:args.cpu_sample].cpu().numpy()

@@ -153,11 +153,16 @@ int mlf_region_time_inside_dev(mlf_region *r, const double *d_pts, size_t np, ui
 
 /* mlf_region_inside_dev with hipEvents recorded around the per-proposal stage and the
  * neighbour scan, on `stream`, without synchronising.  mlf_region_timing_collect waits for the
- * recorded events and returns the number of timed calls and the summed milliseconds of each
- * stage since the last collect. */
+ * recorded events and returns the number of timed calls and the summed milliseconds since the last
+ * collect of: the per-proposal stage (k_prep*), the scan kernel (k_filter, or k_scan when the filter
+ * is off), and the rest of the scan stage (exact re-check, routing, finalisation). */
 int mlf_region_inside_dev_timed(mlf_region *r, const double *d_pts, size_t np, uint8_t *d_mask,
                                 void *stream);
-int mlf_region_timing_collect(mlf_region *r, int *ncalls, double *ms_prep, double *ms_scan);
+int mlf_region_timing_collect(mlf_region *r, int *ncalls, double *ms_prep, double *ms_scan,
+                              double *ms_rest);
+/* whether a batch of np proposals takes the MFMA pre-filter, and its GEMM shape (K columns per pair,
+ * number of 32-row live-point tiles) */
+int mlf_region_filter_info(mlf_region *r, size_t np, int *active, int *kdim, int *ntiles32);
 /* Measured issue rate of independent v_add_f64/v_mul_f64 (the non-fused FP64 vector rate that
  * bounds the distance kernels), in Tera-instructions*lanes per second (= TFLOP/s, 1 flop each). */
 int mlf_bench_fp64_valu(double *tflops);

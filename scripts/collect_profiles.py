@@ -17,7 +17,8 @@ P = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs(P, exist_ok=True)
 
-HEADLINE_GRID = {"k_scan": 15625 * 256, "k_prep": 3907 * 256}     # 1e6 proposals / launch
+HEADLINE_GRID = {"k_scan": 15625 * 256, "k_prep<": 3907 * 256, "k_prep2": 3907 * 256,
+                 "k_filter<4, 4, false>": 1954 * 256, "k_recheck": 7813 * 64}     # 1e6 proposals / launch
 
 
 def cp(src, dst):
@@ -60,18 +61,24 @@ for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ"):
 for key in pmc:
     summary.setdefault(key, {})["pmc_avg_per_launch"] = {c: sum(v) / len(v) for c, v in pmc[key].items()}
 
-if "k_scan" in pmc and "FETCH_SIZE" in pmc["k_scan"]:
-    fetch_kb = sum(pmc["k_scan"]["FETCH_SIZE"]) / len(pmc["k_scan"]["FETCH_SIZE"])
-    write_kb = sum(pmc["k_scan"].get("WRITE_SIZE", [0])) / max(1, len(pmc["k_scan"].get("WRITE_SIZE", [0])))
+traffic_total = 0.0
+for key in pmc:
+    if "FETCH_SIZE" in pmc[key]:
+        f_kb = sum(pmc[key]["FETCH_SIZE"]) / len(pmc[key]["FETCH_SIZE"])
+        w = pmc[key].get("WRITE_SIZE", [0.0])
+        w_kb = sum(w) / max(1, len(w))
+        summary[key]["hbm_traffic"] = dict(FETCH_SIZE_KiB=f_kb, WRITE_SIZE_KiB=w_kb, bytes_raw=(f_kb + w_kb) * 1024.0,
+                                           bytes_gfx950_corrected=(2.0 * f_kb + w_kb) * 1024.0)
+mainkey = "k_filter<4, 4, false>" if "k_filter<4, 4, false>" in pmc else "k_scan"
+if mainkey in pmc and "FETCH_SIZE" in pmc[mainkey]:
+    fetch_kb = sum(pmc[mainkey]["FETCH_SIZE"]) / len(pmc[mainkey]["FETCH_SIZE"])
+    write_kb = sum(pmc[mainkey].get("WRITE_SIZE", [0])) / max(1, len(pmc[mainkey].get("WRITE_SIZE", [0])))
     # MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
     # reports half the bytes of a wide coalesced read -> doubled as the guide prescribes (upper estimate:
     # the calibration is for 16 B/lane loads, k_scan issues 8 B/lane loads)
     traffic = (2.0 * fetch_kb + write_kb) * 1024.0
-    summary["k_scan"]["hbm_traffic"] = dict(FETCH_SIZE_KiB=fetch_kb, WRITE_SIZE_KiB=write_kb,
-                                            bytes_raw=(fetch_kb + write_kb) * 1024.0,
-                                            bytes_gfx950_corrected=traffic)
     json.dump(dict(hbm_bytes_per_launch=traffic, source="%s_pmc_summary.json" % tag,
-                   note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, k_scan<50> launches of 1e6 "
+                   kernel=mainkey, note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, launches of 1e6 "
                         "proposals; (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md"),
               open(os.path.join(P, "pmc_scan_traffic.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(P, "%s_pmc_summary.json" % tag), "w"), indent=1)

@@ -54,7 +54,8 @@ SIGNATURES = {
     "mlf_region_time_inside_dev": [_vp, _vp, _sz, _vp, _vp, _int, _vp, _vp],
     "mlf_region_first_index_dev": [_vp, _vp, _sz, _vp, _vp],
     "mlf_region_inside_dev_timed": [_vp, _vp, _sz, _vp, _vp],
-    "mlf_region_timing_collect": [_vp, _vp, _vp, _vp],
+    "mlf_region_timing_collect": [_vp, _vp, _vp, _vp, _vp],
+    "mlf_region_filter_info": [_vp, _sz, _vp, _vp, _vp],
     "mlf_bench_fp64_valu": [_vp],
 }
 

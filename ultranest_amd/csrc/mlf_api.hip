@@ -214,7 +214,8 @@ int filter_reserve(FilterCtx &f, long long nq, unsigned *cap_out) {
 // produced the binary16 fragments, thresholds and routes of this batch.
 int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int npad, int d, int dp,
                const double *q, long long ldq, long long ldk, long long nq, double r2, const uint8_t *gate,
-               uint8_t *out_mask, long long *out_idx, hipStream_t s, bool quantised) {
+               uint8_t *out_mask, long long *out_idx, hipStream_t s, bool quantised,
+               hipEvent_t ev_after_filter = nullptr) {
   const long long ngroups = (nq + 31) / 32;
   const long long nqpad = ngroups * 32;
   unsigned cap = 0;
@@ -237,6 +238,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   fa.seg_count = f.segcnt.as<unsigned>();
   fa.counters = f.counters.as<unsigned>();
   CK(launch_filter(f.ks, fa, out_idx != nullptr, s));
+  if (ev_after_filter) CK(hipEventRecord(ev_after_filter, s));
   RecheckArgs ra{};
   ra.list = f.list.as<unsigned long long>();
   ra.seg_cap = cap;
@@ -379,7 +381,7 @@ int region_whiten_rows(mlf_region *r, const double *d_u, size_t n, double *d_t, 
 }
 
 int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t *d_mask,
-                          hipStream_t s, hipEvent_t *ev /* 3 events or null */,
+                          hipStream_t s, hipEvent_t *ev /* 4 events or null */,
                           long long *d_idx = nullptr) {
   if (np == 0) return 0;
   if (d_idx && !r->use_scan) return fail_arg(MLF_E_STATE, "region has no live points set");
@@ -464,7 +466,7 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
   if (use_filter) {
     if (int rc = filter_run(r->filter, r->refT.as<double>(), r->refR.as<double>(), r->n, r->npad, r->d, r->dp,
                             r->tq.as<double>(), ldq, ldk, (long long)np, r->r2, gate, d_idx ? nullptr : d_mask,
-                            d_idx, s, fused))
+                            d_idx, s, fused, ev ? ev[2] : nullptr))
       return rc;
   } else if (r->use_scan) {
     ScanArgs a{};
@@ -483,12 +485,16 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
     a.out_mask = d_mask;
     a.out_idx = d_idx;
     CK(launch_scan(r->dp, a, s));
+    if (ev) CK(hipEventRecord(ev[2], s));
     if (d_idx) {
       launch_mark_gated(gate, (long long)np, d_idx, s);
       CK(hipGetLastError());
     }
   }
-  if (ev) CK(hipEventRecord(ev[2], s));
+  if (ev) {
+    if (!r->use_scan) CK(hipEventRecord(ev[2], s));
+    CK(hipEventRecord(ev[3], s));
+  }
   return 0;
 }
 
@@ -1009,33 +1015,45 @@ int mlf_region_inside_dev_timed(mlf_region *r, const double *d_pts, size_t np, u
   if (!r) return fail_arg(MLF_E_BADARG, "null region");
   if (!r->ready) return fail_arg(MLF_E_STATE, "region used before mlf_region_set");
   if (!np || !d_pts || !d_mask) return fail_arg(MLF_E_BADARG, "bad argument");
-  while (r->events.size() < r->events_used + 3) {
+  while (r->events.size() < r->events_used + 4) {
     hipEvent_t e;
     CK(hipEventCreate(&e));
     r->events.push_back(e);
   }
   hipEvent_t *ev = r->events.data() + r->events_used;
-  r->events_used += 3;
+  r->events_used += 4;
   return region_inside_enqueue(r, d_pts, np, d_mask, (hipStream_t)stream, ev);
 }
 
-int mlf_region_timing_collect(mlf_region *r, int *ncalls, double *ms_prep, double *ms_scan) {
-  if (!r || !ncalls || !ms_prep || !ms_scan) return fail_arg(MLF_E_BADARG, "null pointer");
-  double prep = 0.0, scan = 0.0;
-  const size_t calls = r->events_used / 3;
+int mlf_region_timing_collect(mlf_region *r, int *ncalls, double *ms_prep, double *ms_scan,
+                              double *ms_rest) {
+  if (!r || !ncalls || !ms_prep || !ms_scan || !ms_rest) return fail_arg(MLF_E_BADARG, "null pointer");
+  double prep = 0.0, scan = 0.0, rest = 0.0;
+  const size_t calls = r->events_used / 4;
   for (size_t i = 0; i < calls; ++i) {
-    hipEvent_t *ev = r->events.data() + 3 * i;
-    CK(hipEventSynchronize(ev[2]));
-    float a = 0.f, b = 0.f;
+    hipEvent_t *ev = r->events.data() + 4 * i;
+    CK(hipEventSynchronize(ev[3]));
+    float a = 0.f, b = 0.f, c2 = 0.f;
     CK(hipEventElapsedTime(&a, ev[0], ev[1]));
     CK(hipEventElapsedTime(&b, ev[1], ev[2]));
+    CK(hipEventElapsedTime(&c2, ev[2], ev[3]));
     prep += a;
     scan += b;
+    rest += c2;
   }
   r->events_used = 0;
   *ncalls = (int)calls;
   *ms_prep = prep;
   *ms_scan = scan;
+  *ms_rest = rest;
+  return 0;
+}
+
+int mlf_region_filter_info(mlf_region *r, size_t np, int *active, int *kdim, int *ntiles32) {
+  if (!r || !active || !kdim || !ntiles32) return fail_arg(MLF_E_BADARG, "null pointer");
+  *active = (r->ready && r->use_scan && filter_applies(r->filter, (long long)np, r->r2)) ? 1 : 0;
+  *kdim = r->filter.ks * 16;
+  *ntiles32 = r->filter.ntiles32;
   return 0;
 }
 
@@ -1068,15 +1086,15 @@ int mlf_region_time_inside_dev(mlf_region *r, const double *d_pts, size_t np, ui
   if (!d_pts || !d_mask || !ms_total || !ms_scan || reps <= 0 || np == 0)
     return fail_arg(MLF_E_BADARG, "bad argument");
   hipStream_t s = (hipStream_t)stream;
-  hipEvent_t ev[3];
+  hipEvent_t ev[4];
   for (auto &e : ev) CK(hipEventCreate(&e));
   double tot = 0.0, scan = 0.0;
   for (int i = 0; i < reps; ++i) {
     if (int rc = region_inside_enqueue(r, d_pts, np, d_mask, s, ev)) return rc;
-    CK(hipEventSynchronize(ev[2]));
+    CK(hipEventSynchronize(ev[3]));
     float a = 0.f, b = 0.f;
-    CK(hipEventElapsedTime(&a, ev[0], ev[2]));
-    CK(hipEventElapsedTime(&b, ev[1], ev[2]));
+    CK(hipEventElapsedTime(&a, ev[0], ev[3]));
+    CK(hipEventElapsedTime(&b, ev[1], ev[3]));
     tot += a;
     scan += b;
   }

@@ -215,9 +215,17 @@ class DeviceRegion(object):
                                                      ctypes.c_void_p(d_mask), ctypes.c_void_p(stream)))
 
     def timing_collect(self):
-        n, a, b = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
-        check(_lib.lib().mlf_region_timing_collect(self._h, ctypes.byref(n), ctypes.byref(a), ctypes.byref(b)))
-        return n.value, a.value, b.value
+        """(ncalls, ms per-proposal stage, ms scan kernel, ms rest of scan stage) since last collect."""
+        n, a, b, c = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        check(_lib.lib().mlf_region_timing_collect(self._h, ctypes.byref(n), ctypes.byref(a), ctypes.byref(b),
+                                                   ctypes.byref(c)))
+        return n.value, a.value, b.value, c.value
+
+    def filter_info(self, npts):
+        """(filter active for this batch size, K columns of the f16 GEMM, number of 32-row live tiles)"""
+        act, k, t = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        check(_lib.lib().mlf_region_filter_info(self._h, int(npts), ctypes.byref(act), ctypes.byref(k), ctypes.byref(t)))
+        return bool(act.value), k.value, t.value
 
     def time_inside_dev(self, d_pts, npts, d_mask, stream=0, reps=3):
         tot, scan = ctypes.c_float(0), ctypes.c_float(0)
