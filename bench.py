@@ -187,6 +187,7 @@ def main():
     if rank != 0:
         if world > 1:
             import torch.distributed as dist
+            dist.barrier()          # rank 0 reaches this after assembling the JSON line
             dist.destroy_process_group()
         return
 
@@ -265,6 +266,7 @@ def main():
     print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

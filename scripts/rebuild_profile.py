@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Where does a steady-state region rebuild spend its time (GPU box)?  cProfile of
+harness.RegionUpdater.update at C4/C5 size + likelihood kernel throughput."""
+import cProfile
+import io
+import os
+import pstats
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ultranest_amd.mlfriends as M  # noqa: E402
+from ultranest_amd import likelihoods as L  # noqa: E402
+from ultranest_amd.harness import RegionUpdater  # noqa: E402
+
+N, D = 4000, 50
+rs = np.random.RandomState(1)
+u = 0.5 + 0.05 * rs.normal(size=(N, D))
+upd = RegionUpdater(D, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer)
+np.random.seed(11)
+upd.update(u, nbootstraps=30, minvol=0.)
+u2 = u.copy()
+u2[:N // 10] = 0.5 + 0.045 * rs.normal(size=(N // 10, D))
+upd.update(u2, nbootstraps=30, minvol=0.)
+u3 = u2.copy()
+u3[N // 10:N // 5] = 0.5 + 0.04 * rs.normal(size=(N // 10, D))
+pr = cProfile.Profile()
+t0 = time.perf_counter()
+pr.enable()
+upd.update(u3, nbootstraps=30, minvol=0.)
+pr.disable()
+print("rebuild ms:", (time.perf_counter() - t0) * 1e3)
+out = io.StringIO()
+pstats.Stats(pr, stream=out).sort_stats("cumulative").print_stats(28)
+print("\n".join(l[:150] for l in out.getvalue().splitlines()[:60]))
+
+# likelihood batch throughput through the host-pointer ABI (includes H2D/D2H) at 1e6 x 50
+x = rs.uniform(size=(1000000, D))
+for name, fn in (("gauss", L.GaussLikelihood.docs_gauss(D)), ("eggbox", L.eggbox_loglike), ("rosenbrock", L.rosenbrock_loglike)):
+    fn(x[:1000])
+    t0 = time.perf_counter()
+    fn(x)
+    dt = time.perf_counter() - t0
+    print("loglike %-10s 1e6x50 host call: %.1f ms (%.2e points/s incl. PCIe)" % (name, dt * 1e3, len(x) / dt))

@@ -773,27 +773,28 @@ int mlf_bootstrap_quadform_max(const double *u, size_t n, size_t d, const uint8_
   }
   if (int rc = upload(c.small0, pc.data(), pc.size() * sizeof(double), c.stream)) return rc;
   if (int rc = upload(c.small1, pm.data(), pm.size() * sizeof(double), c.stream)) return rc;
-  CK(c.mask.reserve(n));
-  CK(c.out.reserve(n * sizeof(double)));
-  CK(c.small2.reserve(B * sizeof(double)));
-  for (size_t b = 0; b < B; ++b) {
-    PrepArgs a{};
-    a.pts = c.src.as<double>();
-    a.np = (long long)n;
-    a.d = (int)d;
-    a.do_ell = 1;
-    a.ell_ctr = c.small0.as<double>() + b * dp;
-    a.ell_A = c.small1.as<double>() + b * d * dp;
-    a.enlarge = 0.0;
-    a.mask = c.mask.as<uint8_t>();
-    a.q_out = c.out.as<double>();
-    CK(launch_prep(dp, a, c.stream));
-    launch_masked_max(c.out.as<double>(), c.selbytes.as<uint8_t>() + b * n, (int)n,
-                      c.small2.as<double>() + b, c.stream);
-    CK(hipGetLastError());
-  }
-  CK(hipMemcpyAsync(f_out, c.small2.p, B * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  const size_t nblk = (n + 255) / 256;
+  CK(c.small2.reserve(B * nblk * sizeof(double)));
+  QuadMaxArgs qa{};
+  qa.u = c.src.as<double>();
+  qa.n = (int)n;
+  qa.d = (int)d;
+  qa.selected = c.selbytes.as<uint8_t>();
+  qa.ctr = c.small0.as<double>();
+  qa.invcov = c.small1.as<double>();
+  qa.part = c.small2.as<double>();
+  CK(launch_boot_quadmax(dp, qa, (int)B, c.stream));
+  std::vector<double> part(B * nblk);
+  CK(hipMemcpyAsync(part.data(), c.small2.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, c.stream));
   CK(hipStreamSynchronize(c.stream));
+  for (size_t b = 0; b < B; ++b) {
+    double m = -INFINITY;
+    for (size_t k = 0; k < nblk; ++k) {
+      const double o = part[b * nblk + k];
+      m = (o > m || o != o) ? o : m;
+    }
+    f_out[b] = m;
+  }
   return 0;
 }
 

@@ -72,12 +72,22 @@ struct PrepArgs {
   long long ldt;
 };
 
+struct QuadMaxArgs {
+  const double *u;          // (n, d) row-major points
+  int n, d;
+  const uint8_t *selected;  // (B, n)
+  const double *ctr;        // [B][DP]
+  const double *invcov;     // [B][d][DP]
+  double *part;             // [B][ceil(n/256)] per-workgroup maxima
+};
+
 // smallest instantiated DP >= d, or -1 (d > MLF_MAX_DIM)
 int pick_dp(int d);
 
 hipError_t launch_scan(int dp, const ScanArgs &a, hipStream_t s);
 hipError_t launch_boot(int dp, const BootArgs &a, int nchunks, hipStream_t s);
 hipError_t launch_prep(int dp, const PrepArgs &a, hipStream_t s);
+hipError_t launch_boot_quadmax(int dp, const QuadMaxArgs &a, int B, hipStream_t s);
 
 // instantiated dimensionalities: every even value up to 32, every 4th up to 64 (+50, the
 // headline configuration), every 16th up to 128

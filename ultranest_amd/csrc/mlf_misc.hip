@@ -129,11 +129,26 @@ __global__ __launch_bounds__(kWave) void k_subtract_accum(const double *pts, int
     long long nn = 0;
     for (int t = 0; t < ntiles; ++t) {
       unsigned long long m = flags[(long long)j * ntiles + t];
+      // the additions must stay in ascending-i order, the LOADS need not wait for them: fetch up
+      // to eight neighbours at once (with the LocalAffineLayer radius quirk every point is a
+      // neighbour of every point, so this loop runs N times per output value)
       while (m) {
-        const int i = t * kWave + __ffsll((long long)m) - 1;
-        m &= m - 1;
-        sum += pts[(long long)i * d + k];
-        ++nn;
+        double v[8];
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          v[q] = 0.0;
+          if (m) {
+            const int i = t * kWave + __ffsll((long long)m) - 1;
+            m &= m - 1;
+            v[q] = pts[(long long)i * d + k];
+            cnt = q + 1;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q < cnt) sum += v[q];
+        nn += cnt;
       }
     }
     out[(long long)j * d + k] = pts[(long long)j * d + k] - sum / (double)nn;
@@ -245,29 +260,40 @@ __global__ __launch_bounds__(256) void k_boot_mean(const double *u, int n, int d
   }
 }
 
-// cov[b][k][l] = sum_sel (u_ik - m_k)(u_il - m_l) / (cnt - 1); thread = (k, l)
+// cov[b][k][l] = sum_sel (u_ik - m_k)(u_il - m_l) / (cnt - 1); workgroup = (bootstrap b, row k),
+// thread = (row group g of 4, column l): coalesced reads of u[i][:], 4-way split of the rows
 __global__ __launch_bounds__(256) void k_boot_cov(const double *u, int n, int d,
                                                   const uint8_t *selected, const double *mean,
                                                   const int *count, double *cov) {
-  const int b = blockIdx.y;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= d * d) return;
-  const int k = e / d, l = e - k * d;
+  __shared__ double part[4][128];
+  const int b = blockIdx.y, k = blockIdx.x;
+  const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint8_t *sel = selected + (long long)b * n;
-  const double mk = mean[(long long)b * d + k], ml = mean[(long long)b * d + l];
-  double acc = 0.0;
-  for (int i = 0; i < n; ++i) {
+  const double mk = mean[(long long)b * d + k];
+  const double ml0 = lane < d ? mean[(long long)b * d + lane] : 0.0;
+  const double ml1 = lane + 64 < d ? mean[(long long)b * d + lane + 64] : 0.0;
+  double a0 = 0.0, a1 = 0.0;
+  for (int i = g; i < n; i += 4) {
     if (!sel[i]) continue;
-    acc = __builtin_fma(u[(long long)i * d + k] - mk, u[(long long)i * d + l] - ml, acc);
+    const double dk = u[(long long)i * d + k] - mk;
+    if (lane < d) a0 = __builtin_fma(dk, u[(long long)i * d + lane] - ml0, a0);
+    if (lane + 64 < d) a1 = __builtin_fma(dk, u[(long long)i * d + lane + 64] - ml1, a1);
   }
-  cov[(long long)b * d * d + e] = acc / (double)(count[b] - 1);
+  part[g][lane] = a0;
+  part[g][lane + 64] = a1;
+  __syncthreads();
+  if (threadIdx.x < 128 && threadIdx.x < d) {
+    const int l = threadIdx.x;
+    cov[((long long)b * d + k) * d + l] =
+        ((part[0][l] + part[1][l]) + (part[2][l] + part[3][l])) / (double)(count[b] - 1);
+  }
 }
 
 void launch_boot_moments(const double *u, int n, int d, const uint8_t *selected, int B, double *mean,
                          int *count, double *cov, hipStream_t s) {
   hipLaunchKernelGGL(k_boot_mean, dim3(B), dim3(256), 0, s, u, n, d, selected, mean, count);
-  hipLaunchKernelGGL(k_boot_cov, dim3((unsigned)((d * d + 255) / 256), (unsigned)B), dim3(256), 0, s, u,
-                     n, d, selected, mean, count, cov);
+  hipLaunchKernelGGL(k_boot_cov, dim3((unsigned)d, (unsigned)B), dim3(256), 0, s, u, n, d, selected, mean,
+                     count, cov);
 }
 
 // ------------------------------------------------------- likelihoods (V1, L1-L3) ---------

@@ -83,6 +83,76 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
   }
 }
 
+// Bootstrap enlargement (reference mlfriends.pyx:1060-1062) for ALL rounds in one launch:
+// workgroup = (256 rows, round b); A_b in LDS; q in numpy-einsum order like k_prep; rows selected
+// in round b do not take part; per-workgroup maxima go to part[b][blockIdx.x] (NaN propagates).
+template <int DP>
+__global__ __launch_bounds__(256) void k_boot_quadmax(QuadMaxArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double mat[];
+  __shared__ double red[256];
+  const int tid = threadIdx.x, b = blockIdx.y, d = a.d;
+  const int i = blockIdx.x * 256 + tid;
+  const double *A = a.invcov + (size_t)b * d * DP;
+  const double *ctr = a.ctr + (size_t)b * DP;
+  for (int e = tid; e < d * DP; e += 256) mat[e] = A[e];
+  __syncthreads();
+  const bool use = i < a.n && !a.selected[(size_t)b * a.n + i];
+  double q = -INFINITY;
+  if (__any(use)) {
+    const double *row = a.u + (size_t)(i < a.n ? i : 0) * d;
+    double dl[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      const double v = row[k < d ? k : d - 1] - ctr[k];
+      dl[k] = (k < d) ? v : 0.0;
+    }
+    double acc = 0.0;
+    for (int j = 0; j < d; ++j) {
+      const double dj = row[j] - ctr[j];
+      const double2 *arow = reinterpret_cast<const double2 *>(mat + j * DP);
+#pragma unroll
+      for (int k = 0; k < DP; k += 2) {
+        const double2 v = arow[k >> 1];
+        acc += (dj * v.x) * dl[k];
+        acc += (dj * v.y) * dl[k + 1];
+      }
+    }
+    if (use) q = acc;
+  }
+  red[tid] = q;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) {
+      const double o = red[tid + w], m = red[tid];
+      red[tid] = (o > m || o != o) ? o : m;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) a.part[(size_t)b * gridDim.x + blockIdx.x] = red[0];
+}
+
+hipError_t launch_boot_quadmax(int dp, const QuadMaxArgs &a, int B, hipStream_t s) {
+  if (a.n <= 0 || B <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((a.n + 255) / 256), (unsigned)B);
+  const size_t lds = (size_t)a.d * dp * sizeof(double);
+  switch (dp) {
+#define X(D)                                                                                   \
+  case D:                                                                                      \
+    if (lds > 48 * 1024) {                                                                     \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_boot_quadmax<D>),   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return e;                                                           \
+    }                                                                                          \
+    hipLaunchKernelGGL(k_boot_quadmax<D>, grid, dim3(256), lds, s, a);                         \
+    break;
+    MLF_FOR_EACH_DP(X)
+#undef X
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_prep(int dp, const PrepArgs &a, hipStream_t s) {
   if (a.np <= 0) return hipSuccess;
   const unsigned grid = (unsigned)((a.np + 255) / 256);

@@ -127,3 +127,87 @@ def refill_samples(region, tregion, transform, loglike, Lmin, ndraw):
         logl[accepted] = loglike(v[accepted, :])
     keep = logl > Lmin
     return u[keep, :], v[keep, :], logl[keep], nc
+
+
+class StaticNestedSampler(object):
+    """Minimal static nested sampler over the GPU region path -- NOT a re-implementation of the
+    reference's ReactiveNestedSampler (tree search, bootstrapped error bars, dynamic live points,
+    resume, MPI, plots are all out of scope).  It exists so that the region path can be driven end to
+    end on a machine where the reference cannot travel: fixed number of live points, region proposals
+    in large vectorized batches (`draw_multiple=True` style, reference integrator.py:1773-1837),
+    region rebuild whenever the remaining volume shrank by 20 % (reference :2555, :2680-2698),
+    in-place live-point replacement (:2749-2765), classic ln Z accumulation with X_i = exp(-i/N).
+
+    loglike / transform follow the reference's ``vectorized=True`` callback contract."""
+
+    def __init__(self, x_dim, loglike, transform=None, num_live_points=400, ndraw=4096,
+                 region_class=MLFriends, transform_layer_class=LocalAffineLayer, nbootstraps=30, seed=1):
+        self.x_dim = x_dim
+        self.loglike = loglike
+        self.transform = transform if transform is not None else (lambda u: u)
+        self.nlive = num_live_points
+        self.ndraw = ndraw
+        self.nbootstraps = nbootstraps
+        self.updater = RegionUpdater(x_dim, region_class=region_class, transform_layer_class=transform_layer_class,
+                                     build_tregion=False)
+        self.seed = seed
+        self.ncall = 0
+        self.ncall_region = 0
+
+    def run(self, dlogz=0.5, max_iters=200000):
+        np.random.seed(self.seed)
+        N = self.nlive
+        u = np.random.uniform(size=(N, self.x_dim))
+        logl = np.asarray(self.loglike(self.transform(u)), dtype=float)
+        self.ncall += N
+        logz = -np.inf
+        h_terms = []
+        logvol = 0.0
+        next_update_logvol = 0.0
+        pending_u, pending_l = np.empty((0, self.x_dim)), np.empty(0)
+        it = 0
+        while it < max_iters:
+            if logvol <= next_update_logvol:
+                self.updater.update(u, nbootstraps=self.nbootstraps, minvol=np.exp(logvol))
+                next_update_logvol = logvol + np.log(0.8)
+            region = self.updater.region
+            worst = int(np.argmin(logl))
+            Lmin = logl[worst]
+            # weight of the dying point: shell between X_it and X_(it+1)
+            logw = logvol + np.log1p(-np.exp(-1.0 / N)) + Lmin
+            logz = np.logaddexp(logz, logw)
+            h_terms.append((logw, Lmin))
+            logvol -= 1.0 / N
+            # remaining evidence bound: live points times remaining volume
+            logz_remain = np.max(logl) + logvol
+            if np.logaddexp(logz, logz_remain) - logz < dlogz and it > N:
+                break
+            # a replacement above Lmin from the region
+            while True:
+                keep = pending_l > Lmin
+                pending_u, pending_l = pending_u[keep], pending_l[keep]
+                if len(pending_l):
+                    newu, newl = pending_u[0], pending_l[0]
+                    pending_u, pending_l = pending_u[1:], pending_l[1:]
+                    break
+                nu, nv, nl, nc = refill_samples(region, None, self.transform, self.loglike, Lmin, self.ndraw)
+                self.ncall += nc
+                self.ncall_region += self.ndraw
+                pending_u, pending_l = nu, nl
+            # in-place replacement exactly as the driver does it
+            region.u[worst] = newu
+            region.unormed[worst] = region.transformLayer.transform(newu)
+            region.ellipsoid_center = np.mean(region.u, axis=0)
+            region.transformLayer.clusterids[worst] = 0
+            u = region.u
+            logl[worst] = newl
+            it += 1
+        # remainder: the live points share the remaining volume equally
+        logz_live = np.logaddexp.reduce(logl) + logvol - np.log(N)
+        logz = np.logaddexp(logz, logz_live)
+        logws = np.array([w for w, _ in h_terms])
+        Ls = np.array([l for _, l in h_terms])
+        p = np.exp(logws - logz)
+        info = float(np.sum(p * (Ls - logz)))
+        return dict(logz=float(logz), logzerr=float(np.sqrt(max(info, 0.0) / N)), niter=it, ncall=self.ncall,
+                    ncall_region=self.ncall_region, nclusters=int(self.updater.transformLayer.nclusters))
