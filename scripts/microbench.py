@@ -58,8 +58,10 @@ def main():
         idx = torch.empty(p, dtype=torch.int64, device=dev)
         stream = torch.cuda.current_stream().cuda_stream
         from ultranest_amd import _lib
-        for label, rr in ((("E", r2), ("E-noband", r2), ("E-nothing", r2)) if quick else (("E", r2), ("F", 1e-300))):
-            _lib.set_option("debug_noband", {"E-noband": 1, "E-nothing": 2}.get(label, 0))
+        variants = {"E-noband": 1, "E-nothing": 2, "E-noH3": 4, "E-noT1": 8, "E-noTstore": 16, "E-noFstore": 32,
+                    "E-noH3noT1": 12, "E-nostores": 48}
+        for label, rr in ((("E", r2),) + tuple((k, r2) for k in variants) if quick else (("E", r2), ("F", 1e-300))):
+            _lib.set_option("debug_noband", variants.get(label, 0))
             reg.set_thresholds(enlarge, rr)
             reg.first_index_dev(pts.data_ptr(), p, idx.data_ptr(), stream)
             torch.cuda.synchronize()
@@ -67,6 +69,7 @@ def main():
             work = torch.where(idx == -2, torch.zeros_like(idx), work).sum().item()
             tot, scan = reg.time_inside_dev(pts.data_ptr(), p, mask.data_ptr(), stream, reps=3)
             flops = 3.0 * d * work
+            print("%-12s prep %.3f ms  scan-stage %.3f ms" % (label, tot - scan, scan), flush=True)
             print(json.dumps(dict(what="inside", set=label, n=n, d=d, p=p, accept=float(mask.float().mean()),
                                   ell_pass=float((idx != -2).float().mean()),
                                   ms_total=tot, ms_scan=scan, proposals_per_s=p / (tot * 1e-3),

@@ -38,6 +38,10 @@ __global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double *Lt = lds;                     // [DP][DP]   Lt[k][j] = L[j][k]
   double *Tm = lds + DP * DP;           // [DP][DP8]  Tm[k][c] = T[k][c]
+  // wave-private staging for 16 proposal rows: rows are fetched with fully coalesced loads (a wave's
+  // 64 rows are contiguous in HBM) and redistributed lane = row through LDS; reading them
+  // lane-strided straight from global memory cost 0.5 ms per 10^6 x 50 batch (rocprofv3 ablation)
+  double *stage = lds + DP * DP + DP * DP8 + (threadIdx.x >> 6) * (16 * DP);
 
   const int tid = threadIdx.x;
   const int d = a.d;
@@ -49,10 +53,48 @@ __global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
     a.counters[0] = 0;
     a.counters[1] = 0;
   }
-  for (int e = tid; e < DP * DP; e += 256) Lt[e] = a.ell_Lt[e];
-  if (a.do_tr)
-    for (int e = tid; e < DP * DP8; e += 256) Tm[e] = a.lay_T8[e];
+  {  // stage both matrices: all loads in flight before the first LDS store (a plain copy loop waits
+     // for every load in turn: ~20 serialized L2 round trips per workgroup)
+    constexpr int NL = (DP * DP + 255) / 256, NT = (DP * DP8 + 255) / 256;
+    double tl[NL], tt[NT];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) tl[i] = (tid + 256 * i < DP * DP) ? a.ell_Lt[tid + 256 * i] : 0.0;
+    if (a.do_tr) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) tt[i] = (tid + 256 * i < DP * DP8) ? a.lay_T8[tid + 256 * i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (tid + 256 * i < DP * DP) Lt[tid + 256 * i] = tl[i];
+    if (a.do_tr) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        if (tid + 256 * i < DP * DP8) Tm[tid + 256 * i] = tt[i];
+    }
+  }
   __syncthreads();
+
+  const int lane = tid & 63;
+  const long long p0w = p - lane;                    // first proposal of this wave
+  const long long rows_left = a.np - p0w;
+  const int wave_rows = rows_left >= 64 ? 64 : (rows_left > 0 ? (int)rows_left : 0);
+  const double *wsrc = a.pts + (wave_rows > 0 ? p0w : 0) * (long long)d;
+  // copies rows [16c, 16c+16) of this wave into `stage` (row stride d), zero filled past the batch end
+  auto stage_rows = [&](int c) {
+    constexpr int NIT = (16 * DP + 63) / 64;
+    const int base = c * 16 * d, valid = wave_rows * d, chunk = 16 * d;
+    double tmp[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {   // all loads first, then the LDS stores
+      const int e = lane + 64 * it;
+      tmp[it] = (e < chunk && base + e < valid) ? wsrc[base + e] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = lane + 64 * it;
+      if (e < chunk) stage[e] = tmp[it];
+    }
+  };
 
   // ---- H3 -----------------------------------------------------------------------------------
   bool inside = false;
@@ -60,24 +102,44 @@ __global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
     double dl[DP];
     double nrm2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < DP; ++k) {
-      // clamped address + select instead of a branch per coordinate (rows hold d <= DP values;
-      // the centre arrays are zero padded to DP)
-      const double v = row[k < d ? k : d - 1] - a.ell_ctr[k];
-      dl[k] = (k < d) ? v : 0.0;
-      nrm2 = __builtin_fma(dl[k], dl[k], nrm2);
-    }
-    double qt = 0.0;
-    for (int k = 0; k < d; ++k) {
-      const double2 *lrow = reinterpret_cast<const double2 *>(Lt + k * DP);
-      double y = 0.0;
+    for (int c = 0; c < 4; ++c) {
+      stage_rows(c);
+      if ((lane >> 4) == c) {
+        const double *srow = stage + (lane & 15) * d;
 #pragma unroll
-      for (int j = 0; j < DP; j += 2) {
-        const double2 v = lrow[j >> 1];
-        y = __builtin_fma(dl[j], v.x, y);
-        y = __builtin_fma(dl[j + 1], v.y, y);
+        for (int k = 0; k < DP; ++k) {
+          // rows hold d <= DP values (the centre arrays are zero padded to DP): clamped address + select
+          const double v = srow[k < d ? k : d - 1] - a.ell_ctr[k];
+          dl[k] = (k < d) ? v : 0.0;
+        }
       }
-      qt = __builtin_fma(y, y, qt);
+    }
+#pragma unroll
+    for (int k = 0; k < DP; ++k) nrm2 = __builtin_fma(dl[k], dl[k], nrm2);
+    // qt = |L^T delta|^2, four columns of L at a time (four independent FMA chains); column k of L
+    // is zero above row k, so the j-loop of a block starts at the block's first column: half the
+    // work of the square loop.  Fully unrolled: every dl[] index is a compile-time constant.
+    double qt = 0.0;
+    if (!(a.debug_noband & 4)) {
+#pragma unroll
+      for (int kb = 0; kb < DP; kb += 4) {
+        double y[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = kb & ~1; j < DP; j += 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (kb + i < DP) {
+              const double2 v = reinterpret_cast<const double2 *>(Lt + (kb + i) * DP)[j >> 1];
+              y[i] = __builtin_fma(dl[j], v.x, y[i]);
+              y[i] = __builtin_fma(dl[j + 1], v.y, y[i]);
+            }
+          }
+          if ((j & 6) == 6) asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (kb + i < DP) qt = __builtin_fma(y[i], y[i], qt);
+      }
     }
     const double eps = a.ell_eps_scale * nrm2;
     const bool sure_in = a.chol_ok && (qt + eps < a.enlarge);
@@ -112,20 +174,25 @@ __global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
 
   double dl[DP];
 #pragma unroll
-  for (int k = 0; k < DP; ++k) {
-    double w = row[k < d ? k : d - 1];
-    {
-      if (WRAP) {
-        const double sh = a.wrap_shift[k];
-        if (sh == sh) {   // NaN marks an unwrapped dimension
-          // fmod(w + sh, 1): for 0 <= x < 2 (cube coordinates) it is x or x - 1, both exact
-          const double x = w + sh;
-          w = (x >= 0.0 && x < 2.0) ? (x >= 1.0 ? x - 1.0 : x) : wrap_coordinate(w, sh);
+  for (int c = 0; c < 4; ++c) {
+    stage_rows(c);
+    if ((lane >> 4) == c) {
+      const double *srow = stage + (lane & 15) * d;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        double w = srow[k < d ? k : d - 1];
+        if (WRAP) {
+          const double sh = a.wrap_shift[k];
+          if (sh == sh) {   // NaN marks an unwrapped dimension
+            // fmod(w + sh, 1): for 0 <= x < 2 (cube coordinates) it is x or x - 1, both exact
+            const double xs = w + sh;
+            w = (xs >= 0.0 && xs < 2.0) ? (xs >= 1.0 ? xs - 1.0 : xs) : wrap_coordinate(w, sh);
+          }
         }
+        w -= a.lay_ctr[k];
+        dl[k] = (k < d) ? w : 0.0;
       }
-      w -= a.lay_ctr[k];
     }
-    dl[k] = (k < d) ? w : 0.0;
   }
 
   double nb = 0.0, nbn2 = 0.0;
@@ -150,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
   };
 
 #pragma unroll 1
-  for (int cc = 0; cc < NFULL; ++cc) {
+  for (int cc = 0; cc < ((a.debug_noband & 8) ? 1 : NFULL); ++cc) {
     const double *tbase = Tm + cc * 8;
     double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -175,10 +242,10 @@ __global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = cc * 8 + i;
-      if (inside && c < d) a.t_out[p * a.t_ldq + (long long)c * a.t_ldk] = acc[i];
+      if (inside && c < d && !(a.debug_noband & 16)) a.t_out[p * a.t_ldq + (long long)c * a.t_ldk] = acc[i];
       hq[i] = (quant && inside) ? quantise(acc[i], c) : (half_t)0.0f;
     }
-    if (wr)
+    if (wr && !(a.debug_noband & 32))
       qdst[piece_index(cc * 8)] = make_uint4(pack2(hq[0], hq[1]), pack2(hq[2], hq[3]), pack2(hq[4], hq[5]),
                                              pack2(hq[6], hq[7]));
   }
@@ -238,10 +305,10 @@ __global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
 
 static size_t prep2_lds_bytes(int dp) {
   const int dp8 = (dp + 7) / 8 * 8;
-  return ((size_t)dp * dp + (size_t)dp * dp8) * sizeof(double);
+  return ((size_t)dp * dp + (size_t)dp * dp8 + (size_t)4 * 16 * dp) * sizeof(double);
 }
 
-bool prep2_usable(int dp) { return dp <= 64 && prep2_lds_bytes(dp) <= 80 * 1024; }
+bool prep2_usable(int dp) { return dp <= 64 && prep2_lds_bytes(dp) <= 100 * 1024; }
 
 hipError_t launch_prep2(int dp, const Prep2Args &a, hipStream_t s) {
   if (a.np <= 0) return hipSuccess;
