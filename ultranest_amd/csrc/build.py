@@ -22,6 +22,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-result"]
 
 
+# keep MFMA accumulators in VGPRs: the epilogue reads every accumulator, AGPR form costs one
+# v_accvgpr_read per value (40 % of the filter kernel's VALU instructions)
+EXTRA_FLAGS = {"mlf_filter.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -40,7 +45,8 @@ def build(force=False, verbose=True):
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            extra = EXTRA_FLAGS.get(src, [])
+            jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

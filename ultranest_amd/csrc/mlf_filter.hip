@@ -199,6 +199,16 @@ __global__ void k_quant_queries(const double *q, long long ldq, long long nq, lo
   }
 }
 
+// Minimum of three MFMA results through their bit patterns (v_min3_i32): fminf() makes hipcc
+// canonicalise every operand first (one extra v_max per value), and an inline-asm v_min3_f32 would
+// read the MFMA result without the wait states the compiler only inserts for its own instructions.
+// Signed-integer order equals float order for values >= 0; a (tiny, rounding-induced) negative value
+// has a negative pattern and so still wins the minimum, which is all the threshold tests need.
+__device__ __forceinline__ int min3i(int a, int b, int c) {
+  const int m = a < b ? a : b;
+  return m < c ? m : c;
+}
+
 // ---------------------------------------------------------------- the MFMA filter ------------
 // One wave owns QW groups of 32 queries (B fragments resident in registers) and sweeps ALL
 // live-point tiles; a workgroup is 4 independent waves.
@@ -268,18 +278,20 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
       //   vmin <= T_lo : the query has a certain hit (mask mode needs nothing more)
       // Operands are finite binary16 values of bounded size, so acc holds no NaN / inf.
       const float16v &c = acc[g];
-      const float m0 = fminf(fminf(c[0], c[1]), c[2]);
-      const float m1 = fminf(fminf(c[3], c[4]), c[5]);
-      const float m2 = fminf(fminf(c[6], c[7]), c[8]);
-      const float m3 = fminf(fminf(c[9], c[10]), c[11]);
-      const float m4 = fminf(fminf(c[12], c[13]), c[14]);
-      const float vmin = fminf(fminf(fminf(m0, m1), fminf(m2, m3)), fminf(m4, c[15]));
+      const int m0 = min3i(__float_as_int(c[0]), __float_as_int(c[1]), __float_as_int(c[2]));
+      const int m1 = min3i(__float_as_int(c[3]), __float_as_int(c[4]), __float_as_int(c[5]));
+      const int m2 = min3i(__float_as_int(c[6]), __float_as_int(c[7]), __float_as_int(c[8]));
+      const int m3 = min3i(__float_as_int(c[9]), __float_as_int(c[10]), __float_as_int(c[11]));
+      const int m4 = min3i(__float_as_int(c[12]), __float_as_int(c[13]), __float_as_int(c[14]));
+      const float vmin = __int_as_float(min3i(min3i(m0, m1, m2), min3i(m3, m4, __float_as_int(c[15])), m0));
       const bool cand = vmin <= thi[g];
       bool detail = cand;
       if (!FIRST) {
         const bool sure = vmin <= tlo[g];
         anyhit[g] |= __ballot(sure);
-        detail = cand && !sure;
+        // a query that already has a certain hit (in any earlier tile) needs no re-check entries
+        const unsigned long long hitq = anyhit[g] | (anyhit[g] >> 32);
+        detail = cand && !((hitq >> (lane & 31)) & 1ull);
       }
       if (__ballot(detail) != 0ull) {   // wave-uniform; rare in mask mode
         if (detail) {
@@ -348,11 +360,13 @@ __global__ __launch_bounds__(64) void k_recheck(RecheckArgs a) {
     const long long qi = (long long)(ent >> 32);
     const int i = (int)(ent & 0xffffffffu);
     if (i >= a.n || qi >= a.nq) continue;
+    if (a.best[qi] <= i) continue;   // a certain hit at a lower (mask mode: any) index settles this query
     const double *ar = a.refR + (size_t)i * a.dp;
     const double *br = a.q + qi * a.ldq;
     const long long ldk = a.ldk > 1 ? a.ldk : 1;
     double acc = 0.0;
-    for (int k = 0; k < a.d; ++k) {
+#pragma unroll 10
+    for (int k = 0; k < a.d; ++k) {   // loads are independent of the sum: keep ten in flight
       const double df = ar[k] - br[k * ldk];
       acc += df * df;
     }
