@@ -96,29 +96,38 @@ __global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
     }
   };
 
-  // ---- H3 -----------------------------------------------------------------------------------
-  bool inside = false;
-  {
-    double dl[DP];
-    double nrm2 = 0.0;
+  // Up to DP = 52 the proposal row stays in registers for both stages (the workgroup is LDS-limited
+  // to two waves per SIMD anyway, so the extra 2*DP VGPRs are free): one pass over HBM instead of
+  // two.  Wider rows are staged a second time instead (they would spill).
+  constexpr bool KEEPX = DP <= 52;
+  double x[KEEPX ? DP : 2];
+  // stages this wave's rows chunk by chunk and hands lane = row its coordinates: sink(k, value)
+  auto fetch_row = [&](auto &&sink) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       stage_rows(c);
       if ((lane >> 4) == c) {
         const double *srow = stage + (lane & 15) * d;
 #pragma unroll
-        for (int k = 0; k < DP; ++k) {
-          // rows hold d <= DP values (the centre arrays are zero padded to DP): clamped address + select
-          const double v = srow[k < d ? k : d - 1] - a.ell_ctr[k];
-          dl[k] = (k < d) ? v : 0.0;
-        }
+        for (int k = 0; k < DP; ++k) sink(k, srow[k < d ? k : d - 1]);   // clamped: rows hold d <= DP values
       }
+    }
+  };
+
+  // ---- H3 -----------------------------------------------------------------------------------
+  bool inside = false;
+  {
+    double dl[DP];
+    double nrm2 = 0.0;
+    if constexpr (KEEPX) {
+      fetch_row([&](int k, double v) { x[k] = v; });
+#pragma unroll
+      for (int k = 0; k < DP; ++k) dl[k] = (k < d) ? x[k] - a.ell_ctr[k] : 0.0;   // centres are zero padded
+    } else {
+      fetch_row([&](int k, double v) { dl[k] = (k < d) ? v - a.ell_ctr[k] : 0.0; });
     }
 #pragma unroll
     for (int k = 0; k < DP; ++k) nrm2 = __builtin_fma(dl[k], dl[k], nrm2);
-    // qt = |L^T delta|^2, four columns of L at a time (four independent FMA chains); column k of L
-    // is zero above row k, so the j-loop of a block starts at the block's first column: half the
-    // work of the square loop.  Fully unrolled: every dl[] index is a compile-time constant.
     double qt = 0.0;
     if (!(a.debug_noband & 4)) {
 #pragma unroll
@@ -173,26 +182,23 @@ __global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
   const double sigma = quant ? a.stats[0] : 1.0;
 
   double dl[DP];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    stage_rows(c);
-    if ((lane >> 4) == c) {
-      const double *srow = stage + (lane & 15) * d;
-#pragma unroll
-      for (int k = 0; k < DP; ++k) {
-        double w = srow[k < d ? k : d - 1];
-        if (WRAP) {
-          const double sh = a.wrap_shift[k];
-          if (sh == sh) {   // NaN marks an unwrapped dimension
-            // fmod(w + sh, 1): for 0 <= x < 2 (cube coordinates) it is x or x - 1, both exact
-            const double xs = w + sh;
-            w = (xs >= 0.0 && xs < 2.0) ? (xs >= 1.0 ? xs - 1.0 : xs) : wrap_coordinate(w, sh);
-          }
-        }
-        w -= a.lay_ctr[k];
-        dl[k] = (k < d) ? w : 0.0;
+  auto whiten_input = [&](int k, double w) {
+    if (WRAP) {
+      const double sh = a.wrap_shift[k];
+      if (sh == sh) {   // NaN marks an unwrapped dimension
+        // fmod(w + sh, 1): for 0 <= x < 2 (cube coordinates) it is x or x - 1, both exact
+        const double xs = w + sh;
+        w = (xs >= 0.0 && xs < 2.0) ? (xs >= 1.0 ? xs - 1.0 : xs) : wrap_coordinate(w, sh);
       }
     }
+    w -= a.lay_ctr[k];
+    dl[k] = (k < d) ? w : 0.0;
+  };
+  if constexpr (KEEPX) {
+#pragma unroll
+    for (int k = 0; k < DP; ++k) whiten_input(k, x[k]);
+  } else {
+    fetch_row(whiten_input);
   }
 
   double nb = 0.0, nbn2 = 0.0;
