@@ -32,6 +32,7 @@ cp("bench.json", "%s_bench.json" % tag)
 cp("pytest_gpu.log", "%s_pytest_gpu.log" % tag)
 cp("smoke.log", "%s_smoke.log" % tag)
 cp("microbench.log", "%s_microbench.log" % tag)
+cp("config_bench.json", "%s_config_bench.json" % tag)
 
 # kernel-trace: average duration of the headline launches only (the stats CSV mixes them with the
 # small scans of the region rebuild)

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Numbers for the BASELINE.json configurations other than the headline (GPU box): proposal sets
+E (inside the wrapping ellipsoid), U (uniform cube: ellipsoid test only), F (no neighbour within
+reach: full scan) through MLFriends.inside, region rebuild, bootstrap sharding unit, likelihood
+kernels.  One JSON object on stdout; scripts/collect_profiles.py stores it under profiles/."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ultranest_amd.mlfriends as M  # noqa: E402
+from ultranest_amd import _lib, kernels as K  # noqa: E402
+from ultranest_amd.harness import RegionUpdater  # noqa: E402
+
+dev = torch.device("cuda:0")
+stream = torch.cuda.current_stream().cuda_stream
+out = {"device": _lib.device_name()}
+
+
+def region_for(n, d):
+    rs = np.random.RandomState(1)
+    u = 0.5 + 0.05 * rs.normal(size=(n, d))
+    layer = M.AffineLayer()
+    layer.optimize(u, u)
+    region = M.MLFriends(u, layer)
+    t0 = time.perf_counter()
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=30, rng=rs)
+    boot_ms = (time.perf_counter() - t0) * 1e3
+    region.create_ellipsoid()
+    return u, region, boot_ms
+
+
+def timed_inside(handle, pts, reps=5):
+    p = pts.shape[0]
+    mask = torch.empty(p, dtype=torch.uint8, device=dev)
+    handle.inside_dev(pts.data_ptr(), p, mask.data_ptr(), stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        handle.inside_dev(pts.data_ptr(), p, mask.data_ptr(), stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return p / dt, float(mask.float().mean().item())
+
+
+for name, n, d, p in (("C2", 2000, 20, 100000), ("C5", 4000, 50, 1000000), ("C1-size", 400, 5, 100000)):
+    u, region, boot_ms = region_for(n, d)
+    handle = region._dev.sync(region, True)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    z = torch.randn(p, d, dtype=torch.float64, device=dev, generator=g)
+    z /= z.norm(dim=1, keepdim=True)
+    z *= region.enlarge ** 0.5 * torch.rand(p, 1, dtype=torch.float64, device=dev, generator=g) ** (1.0 / d)
+    E = (torch.as_tensor(region.ellipsoid_center, device=dev) + z @ torch.as_tensor(region.ellipsoid_axes_T.copy(), device=dev)).contiguous()
+    U = torch.rand(p, d, dtype=torch.float64, device=dev, generator=g)
+    res = {"bootstrap30_ms": boot_ms}
+    for label, pts, r2 in (("E", E, region.maxradiussq), ("U", U, region.maxradiussq), ("F", E, 1e-300)):
+        handle.set_thresholds(region.enlarge, r2)
+        rate, acc = timed_inside(handle, pts)
+        res[label] = {"proposals_per_s": rate, "accept": acc}
+    upd = RegionUpdater(d, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer)
+    np.random.seed(11)
+    upd.update(u, nbootstraps=30, minvol=0.)
+    rs = np.random.RandomState(7)
+    ts = []
+    for rep in range(3):
+        u2 = u.copy()
+        u2[:n // 10] = 0.5 + 0.045 * rs.normal(size=(n // 10, d))
+        t0 = time.perf_counter()
+        upd.update(u2, nbootstraps=30, minvol=0.)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    res["rebuild_ms"] = float(np.median(ts))
+    out[name + " N=%d d=%d P=%d" % (n, d, p)] = res
+
+# likelihood kernels on device-resident batches (hipEvents through torch on the launch stream)
+lib = _lib.lib()
+import ctypes  # noqa: E402
+for kind, name, d in ((0, "gauss", 50), (1, "eggbox", 10), (1, "eggbox", 50), (3, "rosenbrock", 50)):
+    n = 1000000
+    x = torch.rand(n, d, dtype=torch.float64, device=dev)
+    aux = torch.full((d,), 0.5, dtype=torch.float64, device=dev)
+    like = torch.empty(n, dtype=torch.float64, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for it in range(2):
+        e0.record()
+        _lib.check(lib.mlf_loglike_dev(kind, ctypes.c_void_p(x.data_ptr()), d, n, ctypes.c_void_p(aux.data_ptr()), 0.1,
+                                       ctypes.c_void_p(like.data_ptr()), ctypes.c_void_p(stream)))
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    out["loglike %s d=%d n=1e6" % (name, d)] = {"ms": ms, "points_per_s": n / (ms * 1e-3), "GBps": n * (8 * d + 8) / (ms * 1e-3) / 1e9}
+print(json.dumps(out, indent=1))

@@ -9,6 +9,7 @@ cd $R
 echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 echo "== bench"; timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err; tail -c 2500 $O/bench.json; tail -3 $O/bench.err
+echo "== config bench"; timeout 600 python scripts/config_bench.py > $O/config_bench.json 2> $O/config_bench.err; tail -2 $O/config_bench.err
 if [ "$1" != "noprof" ]; then
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprofv3 stats"

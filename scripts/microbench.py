@@ -58,10 +58,7 @@ def main():
         idx = torch.empty(p, dtype=torch.int64, device=dev)
         stream = torch.cuda.current_stream().cuda_stream
         from ultranest_amd import _lib
-        variants = {"E-noband": 1, "E-nothing": 2, "E-noH3": 4, "E-noT1": 8, "E-noTstore": 16, "E-noFstore": 32,
-                    "E-noH3noT1": 12, "E-nostores": 48}
-        for label, rr in ((("E", r2),) + tuple((k, r2) for k in variants) if quick else (("E", r2), ("F", 1e-300))):
-            _lib.set_option("debug_noband", variants.get(label, 0))
+        for label, rr in ((("E", r2),) if quick else (("E", r2), ("F", 1e-300))):
             reg.set_thresholds(enlarge, rr)
             reg.first_index_dev(pts.data_ptr(), p, idx.data_ptr(), stream)
             torch.cuda.synchronize()

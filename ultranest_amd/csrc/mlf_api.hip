@@ -82,7 +82,6 @@ struct FilterCtx {
 constexpr unsigned kFilterSegCap = 2048;
 bool g_filter_enabled = true;         // mlf_set_option("filter", 0/1)
 bool g_fused_prep = true;             // mlf_set_option("fused_prep", 0/1)
-int g_debug_noband = 0;               // TIMING EXPERIMENTS ONLY: collapse the uncertainty band (wrong results)
 long long g_filter_min_queries = 2048;  // smaller batches go straight to the exact scan
 
 struct Ctx {
@@ -429,7 +428,6 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
         pa.r2 = r->r2;
         pa.ks = f.ks;
         pa.nqpad = ((long long)np + 31) / 32 * 32;
-        pa.debug_noband = g_debug_noband;
       }
     }
     CK(launch_prep2(r->dp, pa, s));
@@ -534,10 +532,6 @@ int mlf_set_option(const char *name, long long value) {
   if (!name) return fail_arg(MLF_E_BADARG, "null pointer");
   if (!strcmp(name, "filter")) {
     g_filter_enabled = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "debug_noband")) {
-    g_debug_noband = (int)value;
     return 0;
   }
   if (!strcmp(name, "fused_prep")) {

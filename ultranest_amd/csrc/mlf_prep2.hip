@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
 #pragma unroll
     for (int k = 0; k < DP; ++k) nrm2 = __builtin_fma(dl[k], dl[k], nrm2);
     double qt = 0.0;
-    if (!(a.debug_noband & 4)) {
+    {
 #pragma unroll
       for (int kb = 0; kb < DP; kb += 4) {
         double y[4] = {0.0, 0.0, 0.0, 0.0};
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
   };
 
 #pragma unroll 1
-  for (int cc = 0; cc < ((a.debug_noband & 8) ? 1 : NFULL); ++cc) {
+  for (int cc = 0; cc < NFULL; ++cc) {
     const double *tbase = Tm + cc * 8;
     double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -248,10 +248,10 @@ __global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = cc * 8 + i;
-      if (inside && c < d && !(a.debug_noband & 16)) a.t_out[p * a.t_ldq + (long long)c * a.t_ldk] = acc[i];
+      if (inside && c < d) a.t_out[p * a.t_ldq + (long long)c * a.t_ldk] = acc[i];
       hq[i] = (quant && inside) ? quantise(acc[i], c) : (half_t)0.0f;
     }
-    if (wr && !(a.debug_noband & 32))
+    if (wr)
       qdst[piece_index(cc * 8)] = make_uint4(pack2(hq[0], hq[1]), pack2(hq[2], hq[3]), pack2(hq[4], hq[5]),
                                              pack2(hq[6], hq[7]));
   }
@@ -288,8 +288,6 @@ __global__ __launch_bounds__(256, 2) void k_prep2(Prep2Args a) {
       lo_f = hi_f = -1.0f;
     }
   }
-  if (a.debug_noband == 1) hi_f = lo_f;
-  if (a.debug_noband == 2) lo_f = hi_f = -1.0f;
   if (!wr) return;
   if (rt != 1) {   // not filtered after all: every operand column of this query must be zero
 #pragma unroll

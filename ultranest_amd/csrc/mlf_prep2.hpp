@@ -31,7 +31,6 @@ struct Prep2Args {
   double r2;
   int ks;
   long long nqpad;
-  int debug_noband;       // timing experiments only
 };
 
 #define MLF_FOR_EACH_DP_PREP2(X)                                                              \
