@@ -140,6 +140,20 @@ int mlf_loglike_rosenbrock(const double *params, size_t d, size_t n, double *lik
 int mlf_loglike_dev(int kind, const double *d_params, size_t d, size_t n, const double *d_aux,
                     double sigma, double *d_like, void *stream);
 
+/* ---- device-side proposal generation (opt-in) ---------------------------
+ * Replaces the host draws of MLFriends.sample_from_boundingbox (mlfriends.pyx:1096-1112, method 0:
+ * uniform in the unit cube) and sample_from_wrapping_ellipsoid (:1135-1160, method 1: uniform in the
+ * wrapping ellipsoid, cube test) by a Philox-4x32-10 stream keyed by `seed`, starting at counter
+ * `offset`; the nsamples proposals go through the region's membership pipeline on the device and
+ * only the accepted rows (at most `capacity`, in draw order) are copied to `out`.  The random
+ * stream differs from numpy's, so agreement with the reference is statistical.
+ * mlf_region_set_axes provides ellipsoid_axes_T (d x d, reference :1232-1233) for method 1. */
+int mlf_region_set_axes(mlf_region *r, const double *axes_T);
+int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset,
+                      double *out, size_t capacity, size_t *naccepted, uint64_t *next_offset);
+/* raw Philox blocks (counter = (i, 0, stream, 0), key = seed) for known-answer tests */
+int mlf_debug_philox(uint64_t seed, unsigned stream, size_t nblocks, uint32_t *out);
+
 /* H3 -> T1 -> K1 with the index kept: d_idx[p] = first live point within radiussq (>= 0),
  * -1 = inside the ellipsoid but no neighbour, -2 = outside the wrapping ellipsoid. */
 int mlf_region_first_index_dev(mlf_region *r, const double *d_pts, size_t np, int64_t *d_idx,

@@ -99,3 +99,41 @@ def test_error_flag_reaches_every_rank(monkeypatch):
     out = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), True, out), nprocs=2, join=True)
     assert out[0] == "LinAlgError" and out[1] == "LinAlgError"
+
+
+def _gpu_worker(rank, world_size, port, out):
+    """two ranks, gloo for the (tiny) collectives, REAL HIP kernels for the compute (both ranks share
+    GPU 0 on the single-GPU test box; on an 8-GPU node each rank would own one GPU and RCCL)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import torch.distributed as dist
+    import ultranest_amd.mlfriends as M
+    from ultranest_amd import distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        u = inputs.live_points(31, 1500, 12)
+        layer = M.AffineLayer()
+        layer.optimize(u, u)
+        region = M.MLFriends(u, layer)
+        rng = np.random.RandomState(1234 if rank == 0 else 5 + rank)
+        r, f = distributed.update_region_bootstrap(region, 30, minvol=0., rng=rng)
+        out[rank] = (r, f)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_bootstrap_with_hip_kernels():
+    import torch.multiprocessing as mp
+    import ultranest_amd.mlfriends as M
+    u = inputs.live_points(31, 1500, 12)
+    layer = M.AffineLayer()
+    layer.optimize(u, u)
+    region = M.MLFriends(u, layer)
+    r1, f1 = region.compute_enlargement(nbootstraps=30, rng=np.random.RandomState(1234))
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gpu_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] == out[1] == (r1, f1), (dict(out), (r1, f1))

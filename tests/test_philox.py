@@ -1,0 +1,158 @@
+"""Device-side proposal generation: the Philox restatement against the
+Random123 known-answer vectors (CPU), the device stream against the restatement (bit-exact), and
+the sampled proposals against the reference's distributions (statistical)."""
+import numpy as np
+import pytest
+
+from oracle import philox
+
+from golden import inputs
+
+# Random123 kat_vectors, philox4x32 with 10 rounds: (counter, key, expected)
+KAT = [
+    ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+@pytest.mark.parametrize("ctr,key,expected", KAT)
+def test_restatement_known_answers(ctr, key, expected):
+    out = philox.philox4x32_10(np.array([ctr], dtype=np.uint32), key)
+    assert tuple(int(x) for x in out[0]) == expected
+
+
+def test_restatement_uniform_range_and_moments():
+    pts, nxt = philox.cube_points(7, 0, 20000, 5)
+    assert nxt == 50000
+    assert pts.min() > 0 and pts.max() < 1
+    assert abs(pts.mean() - 0.5) < 0.005
+    assert abs(pts.var() - 1 / 12.) < 0.002
+    # odd element count: the last block contributes one double only
+    a, na = philox.cube_points(7, 3, 3, 3)
+    assert a.shape == (3, 3) and na == 3 + 5
+
+
+def test_restatement_ball_is_uniform():
+    z, nxt = philox.ball_points(3, 11, 20000, 7, 2.5)
+    assert nxt == 11 + 20000 * 5
+    rad = np.sqrt((z**2).sum(axis=1) / 2.5)
+    assert rad.max() <= 1.0
+    from scipy import stats
+    assert stats.kstest(rad**7, "uniform").pvalue > 1e-3
+    assert np.abs(z.mean(axis=0)).max() < 0.02
+
+
+def _region(kind, n, d, seed):
+    import ultranest_amd.mlfriends as m
+    from ultranest_amd.regions import DeviceRNG
+    rng = np.random.RandomState(seed)
+    u = 0.5 + 0.08 * rng.normal(size=(n, d)) * np.linspace(0.5, 1.5, d)
+    u = u[np.logical_and(u > 0, u < 1).all(axis=1)]
+    layer = m.AffineLayer()
+    layer.optimize(u, u)
+    region = getattr(m, kind)(u, layer)
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=10, rng=rng)
+    region.create_ellipsoid()
+    return region, DeviceRNG
+
+
+@pytest.mark.gpu
+def test_device_stream_matches_restatement():
+    from ultranest_amd import kernels
+    got = kernels.philox_blocks(0, 0, 1)
+    assert tuple(int(x) for x in got[0]) == KAT[0][2]
+    for seed, stream in [(0, 0), (12345678901234567, 1), (2**64 - 1, 2)]:
+        got = kernels.philox_blocks(seed, stream, 5000)
+        want = philox.blocks(seed, stream, np.arange(5000, dtype=np.uint64))
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["MLFriends", "RobustEllipsoidRegion"])
+@pytest.mark.parametrize("d", [2, 7, 50])
+def test_cube_sampling_is_the_host_pipeline_on_the_philox_batch(kind, d):
+    """method 0: the accepted rows are exactly inside() applied to the restated Philox batch, in
+    draw order; the counter advances by the blocks consumed."""
+    region, DeviceRNG = _region(kind, 400, d, d)
+    nsamples = 20011
+    for seed, offset in [(5, 0), (99, 123456789012)]:
+        pts, nxt = philox.cube_points(seed, offset, nsamples, d)
+        want = pts[region.inside(pts)]
+        region.device_rng = DeviceRNG(seed)
+        region.device_rng.offset = offset
+        got = region.sample_from_boundingbox(nsamples)
+        assert region.device_rng.offset == nxt
+        assert got.shape == want.shape
+        assert np.array_equal(got, want)
+        if d == 2:
+            assert len(got) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["MLFriends", "RobustEllipsoidRegion"])
+@pytest.mark.parametrize("d", [3, 8, 50])
+def test_ellipsoid_sampling_matches_restatement_and_region(kind, d):
+    region, DeviceRNG = _region(kind, 400, d, 100 + d)
+    nsamples = 30000
+    region.device_rng = DeviceRNG(17)
+    got = region.sample_from_wrapping_ellipsoid(nsamples)
+    z, nxt = philox.ball_points(17, 0, nsamples, d, region.enlarge)
+    assert region.device_rng.offset == nxt
+    w = region.ellipsoid_center + np.dot(z, region.ellipsoid_axes_T)
+    ok = np.logical_and(w > 0, w < 1).all(axis=1)
+    region.device_rng = None
+    ok[ok] = region.inside(w[ok])
+    want = w[ok]
+    # libm vs device transcendental functions: a handful of boundary points may flip
+    assert abs(len(got) - len(want)) <= max(3, len(want) // 2000)
+    if len(got) == len(want):
+        assert np.allclose(got, want, rtol=0, atol=1e-12)
+    assert len(got) > 0
+    assert region.inside(got).mean() > 0.999
+    assert np.logical_and(got > 0, got < 1).all()
+
+
+@pytest.mark.gpu
+def test_ellipsoid_sampling_is_uniform_in_the_ellipsoid():
+    region, DeviceRNG = _region("RobustEllipsoidRegion", 400, 6, 3)
+    region.device_rng = DeviceRNG(2)
+    got = region.sample_from_wrapping_ellipsoid(40000)
+    delta = got - region.ellipsoid_center
+    q = np.einsum("ij,jk,ik->i", delta, region.ellipsoid_invcov, delta) / region.enlarge
+    assert q.max() <= 1 + 1e-9
+    if len(got) > 39000:     # ellipsoid (almost) entirely in the cube: radial law is exact
+        from scipy import stats
+        assert stats.kstest(q**3, "uniform").pvalue > 1e-3
+
+
+@pytest.mark.gpu
+def test_capacity_and_empty():
+    from ultranest_amd._lib import HipLibraryError
+    region, DeviceRNG = _region("MLFriends", 200, 2, 9)
+    handle = region._dev.sync(region, True)
+    full, nxt = handle.sample(0, 5000, 1, 0)
+    part, nxt2 = handle.sample(0, 5000, 1, 0, capacity=7)
+    assert nxt == nxt2 == 5000
+    assert len(part) == 7 and np.array_equal(part, full[:7])
+    none, nxt3 = handle.sample(0, 0, 1, 0, capacity=4)
+    assert len(none) == 0 and nxt3 == 0
+    with pytest.raises((ValueError, HipLibraryError)):
+        handle.sample(1, 10, 1, 0)       # axes not provided
+
+
+@pytest.mark.gpu
+def test_sampler_with_device_rng_recovers_gaussian_evidence():
+    from ultranest_amd.harness import StaticNestedSampler
+    from ultranest_amd.regions import DeviceRNG
+    d = 4
+    sigma = 0.05
+
+    def ll(v):
+        return -0.5 * (((v - 0.5) / sigma)**2).sum(axis=1)
+
+    s = StaticNestedSampler(d, ll, num_live_points=400, ndraw=8192, seed=3, device_rng=DeviceRNG(11))
+    res = s.run(dlogz=0.1)
+    want = d * np.log(sigma * np.sqrt(2 * np.pi))
+    assert abs(res["logz"] - want) < 5 * res["logzerr"] + 0.1, (res, want)

@@ -12,6 +12,7 @@
 #include "mlf_filter.hpp"
 #include "mlf_misc.hpp"
 #include "mlf_prep2.hpp"
+#include "mlf_sample.hpp"
 
 namespace {
 
@@ -350,7 +351,9 @@ struct mlf_region {
   double ell_eps_scale = 0.0;
   DevBuf tq, gate, pts, mask, row;
   FilterCtx filter;
-  std::vector<hipEvent_t> events;  // 3 per timed call
+  DevBuf gen, gen2, cube, smask, blk, sout, ax_zero, ax_mat;   // device-side sampling
+  bool axes_ready = false;
+  std::vector<hipEvent_t> events;  // 4 per timed call
   size_t events_used = 0;
 };
 
@@ -381,7 +384,7 @@ int region_whiten_rows(mlf_region *r, const double *d_u, size_t n, double *d_t, 
 
 int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t *d_mask,
                           hipStream_t s, hipEvent_t *ev /* 4 events or null */,
-                          long long *d_idx = nullptr) {
+                          long long *d_idx = nullptr, const uint8_t *pregate = nullptr) {
   if (np == 0) return 0;
   if (d_idx && !r->use_scan) return fail_arg(MLF_E_STATE, "region has no live points set");
   CK(r->gate.reserve(np));
@@ -459,6 +462,12 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
                                r->d, s);
       CK(hipGetLastError());
     }
+  }
+  if (pregate) {   // proposals rejected before the region test (outside the unit cube): never scanned
+    const bool ff = fused && use_filter;
+    launch_apply_pregate(pregate, (long long)np, gate, ff ? r->filter.route.as<uint8_t>() : nullptr,
+                         ff ? r->filter.tlo.as<float>() : nullptr, ff ? r->filter.thi.as<float>() : nullptr, s);
+    CK(hipGetLastError());
   }
   if (ev) CK(hipEventRecord(ev[1], s));
   if (use_filter) {
@@ -803,7 +812,8 @@ int mlf_region_create(mlf_region **out) {
 int mlf_region_destroy(mlf_region *r) {
   if (!r) return 0;
   DevBuf *bufs[] = {&r->refT, &r->refR, &r->lay_ctr, &r->lay_mat, &r->lay_T8, &r->ell_Lt, &r->wrap, &r->ell_ctr,
-                    &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row};
+                    &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row,
+                    &r->gen, &r->gen2, &r->cube, &r->smask, &r->blk, &r->sout, &r->ax_zero, &r->ax_mat};
   for (DevBuf *b : bufs) b->release();
   for (hipEvent_t e : r->events) (void)hipEventDestroy(e);
   r->filter.release();
@@ -993,6 +1003,94 @@ int mlf_region_find_nearby_dev(mlf_region *r, const double *d_tpts, size_t np, i
   a.mode = SCAN_FIRST;
   a.out_idx = reinterpret_cast<long long *>(d_idx);
   CK(launch_scan(r->dp, a, (hipStream_t)stream));
+  return 0;
+}
+
+int mlf_region_set_axes(mlf_region *r, const double *axes_T) {
+  if (!r || !axes_T) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (!r->ready) return fail_arg(MLF_E_STATE, "region not set");
+  Ctx &c = g_ctx;
+  const int d = r->d, dp = r->dp;
+  std::vector<double> zero((size_t)dp, 0.0);
+  // k_prep computes (x - ctr) . T from T^T rows: with T = axes_T the staged matrix is axes itself
+  std::vector<double> m = pad_matrix(axes_T, d, dp, true);
+  if (int rc = upload(r->ax_zero, zero.data(), zero.size() * sizeof(double), c.stream)) return rc;
+  if (int rc = upload(r->ax_mat, m.data(), m.size() * sizeof(double), c.stream)) return rc;
+  CK(hipStreamSynchronize(c.stream));
+  r->axes_ready = true;
+  return 0;
+}
+
+int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset,
+                      double *out, size_t capacity, size_t *naccepted, uint64_t *next_offset) {
+  if (!r || !out || !naccepted || !next_offset) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (!r->ready) return fail_arg(MLF_E_STATE, "region used before mlf_region_set");
+  if (method != 0 && method != 1) return fail_arg(MLF_E_BADARG, "method must be 0 (cube) or 1 (wrapping ellipsoid)");
+  if (method == 1 && !r->axes_ready) return fail_arg(MLF_E_STATE, "mlf_region_set_axes not called");
+  *naccepted = 0;
+  *next_offset = offset;
+  if (nsamples == 0 || capacity == 0) return 0;
+  Ctx &c = g_ctx;
+  hipStream_t s = c.stream;
+  const long long n = (long long)nsamples;
+  const int d = r->d;
+  const int nblk = (int)((n + 255) / 256);
+  CK(r->gen.reserve((size_t)n * d * sizeof(double)));
+  CK(r->smask.reserve((size_t)n));
+  CK(r->blk.reserve(((size_t)nblk + 1) * sizeof(unsigned)));
+  CK(r->sout.reserve(capacity * (size_t)d * sizeof(double)));
+  const uint8_t *pregate = nullptr;
+  if (method == 0) {
+    launch_generate_cube(r->gen.as<double>(), n * d, seed, offset, s);
+    *next_offset = offset + (uint64_t)((n * d + 1) / 2);
+  } else {
+    CK(r->gen2.reserve((size_t)n * d * sizeof(double)));
+    CK(r->cube.reserve((size_t)n));
+    launch_generate_ball(r->gen2.as<double>(), n, d, r->enlarge, seed, offset, s);
+    *next_offset = offset + (uint64_t)n * (uint64_t)((d + 1) / 2 + 1);
+    PrepArgs pa{};
+    pa.pts = r->gen2.as<double>();
+    pa.np = n;
+    pa.d = d;
+    pa.do_tr = 1;
+    pa.lay_ctr = r->ax_zero.as<double>();
+    pa.lay_Tt = r->ax_mat.as<double>();
+    pa.t_out = r->gen.as<double>();
+    pa.ldt = d;
+    CK(launch_prep(r->dp, pa, s));
+    launch_center_and_cube(r->gen.as<double>(), n, d, r->ell_ctr.as<double>(), r->cube.as<uint8_t>(), s);
+    pregate = r->cube.as<uint8_t>();
+  }
+  CK(hipGetLastError());
+  if (int rc = region_inside_enqueue(r, r->gen.as<double>(), nsamples, r->smask.as<uint8_t>(), s, nullptr,
+                                     nullptr, pregate))
+    return rc;
+  const unsigned cap = capacity > 0xffffffffu ? 0xffffffffu : (unsigned)capacity;
+  launch_compact(r->gen.as<double>(), r->smask.as<uint8_t>(), n, d, r->blk.as<unsigned>(), r->sout.as<double>(),
+                 cap, s);
+  CK(hipGetLastError());
+  unsigned count = 0;
+  CK(hipMemcpyAsync(&count, r->blk.as<unsigned>() + nblk, sizeof count, hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  const size_t take = count < cap ? count : cap;
+  if (take) {
+    CK(hipMemcpyAsync(out, r->sout.p, take * (size_t)d * sizeof(double), hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+  }
+  *naccepted = take;
+  return 0;
+}
+
+int mlf_debug_philox(uint64_t seed, unsigned stream, size_t nblocks, uint32_t *out) {
+  if (!out) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (nblocks == 0) return 0;
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  CK(c.out.reserve(nblocks * 4 * sizeof(unsigned)));
+  launch_philox_words(seed, stream, (long long)nblocks, c.out.as<unsigned>(), c.stream);
+  CK(hipGetLastError());
+  CK(hipMemcpyAsync(out, c.out.p, nblocks * 4 * sizeof(unsigned), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
   return 0;
 }
 

@@ -1,0 +1,215 @@
+// mlf_sample.hip -- device-side proposal generation and stream compaction for region.sample()
+// (reference MLFriends.sample_from_boundingbox mlfriends.pyx:1096-1112 and
+// sample_from_wrapping_ellipsoid :1135-1160).  Opt-in: the stream is Philox-4x32-10 (counter based,
+// reproducible for a given (seed, offset) on any grid), not numpy's MT19937, so runs agree with
+// the reference statistically, not draw by draw.
+//
+// With the host path a 10^6 x 50 batch costs 0.3-0.5 s of np.random.uniform plus a 400 MB upload
+// in front of a ~1 ms membership kernel; here the proposals never leave HBM and only the accepted
+// rows travel back.
+#include "mlf_sample.hpp"
+
+#include <math.h>
+
+namespace mlf {
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                              unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    const unsigned n3 = (unsigned)p0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+  out[2] = c2;
+  out[3] = c3;
+}
+
+// 53-bit uniform strictly inside (0, 1) from two 32-bit words
+__device__ __forceinline__ double u01(unsigned hi, unsigned lo) {
+  const unsigned long long m = ((unsigned long long)(hi >> 5) << 26) | (unsigned long long)(lo >> 6);
+  return ((double)m + 0.5) * 0x1p-53;
+}
+
+// raw Philox words for testing: out[4*i .. 4*i+3] = philox(counter = (i, 0, stream, 0), key = seed)
+__global__ void k_philox_words(unsigned long long seed, unsigned stream, long long n, unsigned *out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned w[4];
+  philox4x32_10((unsigned)i, (unsigned)((unsigned long long)i >> 32), stream, 0u, (unsigned)seed,
+                (unsigned)(seed >> 32), w);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[4 * i + j] = w[j];
+}
+
+// element e of the batch = uniform(0,1); counter = offset + e/2 (two doubles per Philox block)
+__global__ void k_generate_cube(double *pts, long long nelem, unsigned long long seed,
+                                unsigned long long offset) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // Philox block index
+  if (2 * b >= nelem) return;
+  const unsigned long long ctr = offset + (unsigned long long)b;
+  unsigned w[4];
+  philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w);
+  pts[2 * b] = u01(w[0], w[1]);
+  if (2 * b + 1 < nelem) pts[2 * b + 1] = u01(w[2], w[3]);
+}
+
+// one thread per proposal: z ~ N(0, I_d), scaled to a uniform draw in the ball of radius
+// sqrt(enlarge):  z / |z| * sqrt(enlarge) * U^(1/d)   (reference :1145-1149)
+__global__ void k_generate_ball(double *z, long long n, int d, double enlarge, unsigned long long seed,
+                                unsigned long long offset) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  double *row = z + p * d;
+  double norm2 = 0.0;
+  const int npairs = (d + 1) / 2;
+  for (int j = 0; j < npairs; ++j) {
+    const unsigned long long ctr = offset + (unsigned long long)p * (unsigned long long)(npairs + 1) + j;
+    unsigned w[4];
+    philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 1u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w);
+    const double r = sqrt(-2.0 * log(u01(w[0], w[1])));
+    const double ang = 2.0 * M_PI * u01(w[2], w[3]);
+    const double g0 = r * cos(ang), g1 = r * sin(ang);
+    row[2 * j] = g0;
+    norm2 += g0 * g0;
+    if (2 * j + 1 < d) {
+      row[2 * j + 1] = g1;
+      norm2 += g1 * g1;
+    }
+  }
+  const unsigned long long ctr = offset + (unsigned long long)p * (unsigned long long)(npairs + 1) + npairs;
+  unsigned w[4];
+  philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 1u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w);
+  const double scale = sqrt(enlarge) * pow(u01(w[0], w[1]), 1.0 / (double)d) / sqrt(norm2);
+  for (int k = 0; k < d; ++k) row[k] *= scale;
+}
+
+// w = center + (z @ axes_T) was produced without the centre by the whitening kernel; add it and
+// record whether the point lies strictly inside the unit cube (reference :1154)
+__global__ void k_center_and_cube(double *w, long long n, int d, const double *center, uint8_t *in_cube) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  bool ok = true;
+  for (int k = 0; k < d; ++k) {
+    const double v = w[p * d + k] + center[k];
+    w[p * d + k] = v;
+    ok = ok && (v > 0.0) && (v < 1.0);
+  }
+  in_cube[p] = ok ? 1 : 0;
+}
+
+// proposals with pregate == 0 (outside the cube) leave the membership pipeline after the
+// per-proposal stage: gate 0 (exact scan skips them), route 0 ("not scanned" for the MFMA
+// pre-filter's finalise step) and thresholds -1 (no candidate pairs, no re-check entries)
+__global__ void k_apply_pregate(const uint8_t *pregate, long long n, uint8_t *gate, uint8_t *route, float *tlo,
+                                float *thi) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n || pregate[p] != 0) return;
+  gate[p] = 0;
+  if (route) {
+    route[p] = 0;
+    tlo[p] = -1.0f;
+    thi[p] = -1.0f;
+  }
+}
+
+// ---- deterministic stream compaction of the accepted rows (256 proposals per workgroup) -------
+__global__ __launch_bounds__(256) void k_count_accepted(const uint8_t *mask, long long n, unsigned *blk) {
+  __shared__ unsigned wsum[4];
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool acc = p < n && mask[p] != 0;
+  const unsigned long long b = __ballot(acc);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (unsigned)__popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of the per-workgroup counts (single workgroup); total -> blk[nblk]
+__global__ __launch_bounds__(1024) void k_scan_counts(unsigned *blk, int nblk) {
+  __shared__ unsigned part[1024];
+  const int tid = threadIdx.x;
+  const int per = (nblk + 1023) / 1024;
+  const int lo = tid * per, hi = lo + per < nblk ? lo + per : nblk;
+  unsigned s = 0;
+  for (int i = lo; i < hi; ++i) s += blk[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+    const unsigned v = tid >= off ? part[tid - off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  unsigned run = part[tid] - s;
+  for (int i = lo; i < hi; ++i) {
+    const unsigned c = blk[i];
+    blk[i] = run;
+    run += c;
+  }
+  if (tid == 1023) blk[nblk] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_scatter_accepted(const double *pts, const uint8_t *mask,
+                                                          long long n, int d, const unsigned *blk,
+                                                          double *out, unsigned capacity) {
+  __shared__ unsigned wsum[4];
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool acc = p < n && mask[p] != 0;
+  const unsigned long long b = __ballot(acc);
+  if (lane == 0) wsum[wave] = (unsigned)__popcll(b);
+  __syncthreads();
+  unsigned base = blk[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const unsigned rank = base + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+  if (acc && rank < capacity)
+    for (int k = 0; k < d; ++k) out[(size_t)rank * d + k] = pts[p * d + k];
+}
+
+// ---------------------------------------------------------------- launchers -------------------
+void launch_philox_words(unsigned long long seed, unsigned stream, long long n, unsigned *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_philox_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed, stream, n, out);
+}
+
+void launch_generate_cube(double *pts, long long nelem, unsigned long long seed, unsigned long long offset,
+                          hipStream_t s) {
+  const long long nb = (nelem + 1) / 2;
+  hipLaunchKernelGGL(k_generate_cube, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, pts, nelem, seed, offset);
+}
+
+void launch_generate_ball(double *z, long long n, int d, double enlarge, unsigned long long seed,
+                          unsigned long long offset, hipStream_t s) {
+  hipLaunchKernelGGL(k_generate_ball, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, n, d, enlarge, seed,
+                     offset);
+}
+
+void launch_center_and_cube(double *w, long long n, int d, const double *center, uint8_t *in_cube, hipStream_t s) {
+  hipLaunchKernelGGL(k_center_and_cube, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n, d, center, in_cube);
+}
+
+void launch_apply_pregate(const uint8_t *pregate, long long n, uint8_t *gate, uint8_t *route, float *tlo,
+                          float *thi, hipStream_t s) {
+  hipLaunchKernelGGL(k_apply_pregate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pregate, n, gate, route,
+                     tlo, thi);
+}
+
+void launch_compact(const double *pts, const uint8_t *mask, long long n, int d, unsigned *blk, double *out,
+                    unsigned capacity, hipStream_t s) {
+  const int nblk = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(k_count_accepted, dim3(nblk), dim3(256), 0, s, mask, n, blk);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, blk, nblk);
+  hipLaunchKernelGGL(k_scatter_accepted, dim3(nblk), dim3(256), 0, s, pts, mask, n, d, blk, out, capacity);
+}
+
+}  // namespace mlf

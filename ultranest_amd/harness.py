@@ -141,8 +141,11 @@ class StaticNestedSampler(object):
     loglike / transform follow the reference's ``vectorized=True`` callback contract."""
 
     def __init__(self, x_dim, loglike, transform=None, num_live_points=400, ndraw=4096,
-                 region_class=MLFriends, transform_layer_class=LocalAffineLayer, nbootstraps=30, seed=1):
+                 region_class=MLFriends, transform_layer_class=LocalAffineLayer, nbootstraps=30, seed=1,
+                 device_rng=None):
         self.x_dim = x_dim
+        # optional regions.DeviceRNG: proposals are then drawn, tested and compacted on the GPU
+        self.device_rng = device_rng
         self.loglike = loglike
         self.transform = transform if transform is not None else (lambda u: u)
         self.nlive = num_live_points
@@ -171,6 +174,7 @@ class StaticNestedSampler(object):
                 self.updater.update(u, nbootstraps=self.nbootstraps, minvol=np.exp(logvol))
                 next_update_logvol = logvol + np.log(0.8)
             region = self.updater.region
+            region.device_rng = self.device_rng
             worst = int(np.argmin(logl))
             Lmin = logl[worst]
             # weight of the dying point: shell between X_it and X_(it+1)

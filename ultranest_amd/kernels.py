@@ -166,6 +166,7 @@ class DeviceRegion(object):
         """`live` holds region.unormed (live_space=0) or region.u (live_space=1: whitened on the
         device with the proposal kernel, see include/mlfriends_hip.h)."""
         d = len(ell_center)
+        self._d = d
         un = None if live is None else f64(live)
         n = 0 if un is None else un.shape[0]
         lc = None if layer_ctr is None else f64(np.broadcast_to(layer_ctr, (d,)))
@@ -206,6 +207,20 @@ class DeviceRegion(object):
         check(_lib.lib().mlf_region_find_nearby_dev(self._h, ctypes.c_void_p(d_tpts), npts,
                                                     ctypes.c_void_p(d_idx), ctypes.c_void_p(stream)))
 
+    def set_axes(self, axes_T):
+        check(_lib.lib().mlf_region_set_axes(self._h, ptr(f64(axes_T))))
+
+    def sample(self, method, nsamples, seed, offset, capacity=None):
+        """Device-side draw + membership test + compaction.  Returns (accepted rows (k, d), next offset)."""
+        d = self._d
+        cap = int(nsamples if capacity is None else capacity)
+        out = np.empty((cap, d), dtype=np.float64)
+        nacc, nxt = ctypes.c_size_t(0), ctypes.c_uint64(0)
+        check(_lib.lib().mlf_region_sample(self._h, int(method), int(nsamples), ctypes.c_uint64(int(seed)),
+                                           ctypes.c_uint64(int(offset)), ptr(out), cap, ctypes.byref(nacc),
+                                           ctypes.byref(nxt)))
+        return out[:nacc.value], nxt.value
+
     def first_index_dev(self, d_pts, npts, d_idx, stream=0):
         check(_lib.lib().mlf_region_first_index_dev(self._h, ctypes.c_void_p(d_pts), npts,
                                                     ctypes.c_void_p(d_idx), ctypes.c_void_p(stream)))
@@ -240,3 +255,10 @@ def bench_fp64_valu():
     t = ctypes.c_double(0)
     check(_lib.lib().mlf_bench_fp64_valu(ctypes.byref(t)))
     return t.value
+
+
+def philox_blocks(seed, stream, nblocks):
+    """Raw Philox-4x32-10 output blocks of the device generator (known-answer tests)."""
+    out = np.empty((int(nblocks), 4), dtype=np.uint32)
+    check(_lib.lib().mlf_debug_philox(ctypes.c_uint64(int(seed)), int(stream), int(nblocks), ptr(out)))
+    return out

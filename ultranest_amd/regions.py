@@ -30,6 +30,20 @@ STRICT_HOST_TRANSFORM = False
 STRICT_HOST_MOMENTS = False
 
 
+class DeviceRNG(object):
+    """Opt-in counter-based random stream for DEVICE-SIDE proposal generation (SURVEY.md 8f row
+    f2): Philox-4x32-10 keyed by `seed`; the counter advances by what every draw consumed, so a
+    run is reproducible for a given seed.  Assign an instance to ``region.device_rng`` (or pass
+    ``device_rng=`` to the harness) and ``sample_from_boundingbox`` /
+    ``sample_from_wrapping_ellipsoid`` draw, test and compact on the GPU; only the accepted
+    points come back.  The stream is not numpy's MT19937: agreement with the reference is then
+    statistical (same distribution), not draw by draw."""
+
+    def __init__(self, seed=0):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+
+
 def vol_prefactor(n):
     """Volume of the unit n-ball (reference mlfriends.pyx:853-879): recurrence
     V_n = V_{n-2} * 2 pi / n from V_0 = 1, V_1 = 2."""
@@ -115,6 +129,19 @@ class _DeviceState(object):
         self.live = None
         self.ell_center = None
         self.thresholds = None
+        self.axes_T = None
+
+    def sample(self, region, use_scan, method, nsamples):
+        """Device-side draw + membership + compaction with the region's ``device_rng``."""
+        handle = self.sync(region, use_scan)
+        if method == 1:
+            axes_T = np.asarray(region.ellipsoid_axes_T, dtype=float)
+            if self.axes_T is None or not np.array_equal(self.axes_T, axes_T):
+                handle.set_axes(axes_T)
+                self.axes_T = axes_T.copy()
+        rng = region.device_rng
+        pts, rng.offset = handle.sample(method, nsamples, rng.seed, rng.offset)
+        return pts
 
     @staticmethod
     def _same(a, b):
@@ -181,6 +208,7 @@ class MLFriends(object):
             raise ValueError("not all u values are between 0 and 1: %s" % u[~ok.all(axis=1)])
         self.u = u
         self.enlarge = None
+        self.device_rng = None
         self._dev = _DeviceState()
         self.set_transformLayer(transformLayer)
         self.sampling_methods = [
@@ -312,6 +340,8 @@ class MLFriends(object):
 
     def sample_from_boundingbox(self, nsamples=100):
         """Uniform in the unit cube, filtered by the region (reference :1096-1112)."""
+        if self.device_rng is not None:
+            return self._dev.sample(self, True, 0, nsamples)
         ndim = self.u.shape[1]
         u = np.random.uniform(size=(nsamples, ndim))
         return u[self.inside(u), :]
@@ -340,6 +370,8 @@ class MLFriends(object):
     def sample_from_wrapping_ellipsoid(self, nsamples=100):
         """Uniform in the wrapping ellipsoid, filtered by cube and neighbour scan
         (reference :1135-1160)."""
+        if self.device_rng is not None:
+            return self._dev.sample(self, True, 1, nsamples)
         w = self._draw_in_ellipsoid(nsamples)
         return w[self._near_live_points(self.transformLayer.transform(w)), :]
 
@@ -364,6 +396,8 @@ class RobustEllipsoidRegion(MLFriends):
         self.current_sampling_method = self.sample_from_boundingbox
 
     def sample_from_boundingbox(self, nsamples=100):
+        if self.device_rng is not None:
+            return self._dev.sample(self, False, 0, nsamples)
         ndim = self.u.shape[1]
         u = np.random.uniform(size=(nsamples, ndim))
         return u[self.inside_ellipsoid(u), :]
@@ -378,6 +412,8 @@ class RobustEllipsoidRegion(MLFriends):
         return w[ok, :]
 
     def sample_from_wrapping_ellipsoid(self, nsamples=100):
+        if self.device_rng is not None:
+            return self._dev.sample(self, False, 1, nsamples)
         return self._draw_in_ellipsoid(nsamples)
 
     def inside(self, pts):
