@@ -154,6 +154,78 @@ int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed,
 /* raw Philox blocks (counter = (i, 0, stream, 0), key = seed) for known-answer tests */
 int mlf_debug_philox(uint64_t seed, unsigned stream, size_t nblocks, uint32_t *out);
 
+/* ---- population step sampler -------------------------------------------
+ * Stateless forms: one call = the reference function of the same name on host arrays
+ * (ultranest/stepfuncs.pyx within_unit_cube :36-51, evolve :249-261 [mlf_evolve_propose],
+ * evolve_update :99-183, step_back :285-334, update_vectorised_slice_sampler :537-630;
+ * ultranest/popstepsampler.py unitcube_line_intersection :26-61, the distance part of
+ * diagnose_move_distances :64-94).  Flags are uint8 (numpy bool), indices int64.
+ *   mlf_evolve_propose: unif_full (one U[0,1) per walker, used by bisecting walkers:
+ *     currentt = left + (right-left)*U, numpy's legacy uniform) may be NULL when currentt already
+ *     holds the drawn coordinate; writes currentt, unew = u + v*t and the cube test.
+ *   mlf_evolve_update: Lnew_full has one entry per walker (ignored where acceptable == 0).     */
+int mlf_within_unit_cube(const double *u, size_t n, size_t d, uint8_t *out);
+int mlf_evolve_propose(const double *currentu, const double *currentv, const double *left,
+                       const double *right, const uint8_t *searching_left,
+                       const uint8_t *searching_right, const double *unif_full, double *currentt,
+                       size_t n, size_t d, double *unew, uint8_t *acceptable);
+int mlf_evolve_update(const uint8_t *acceptable, const double *Lnew_full, double Lmin,
+                      double *currentt, double *left, double *right, uint8_t *searching_left,
+                      uint8_t *searching_right, uint8_t *success, size_t n);
+int mlf_step_back(double Lmin, double *allL, size_t n, size_t ngen, int64_t *generation,
+                  double *currentt);
+int mlf_unitcube_line_intersection(const double *origin, const double *direction, size_t n,
+                                   size_t d, double *tleft, double *tright);
+int mlf_update_vectorised_slice_sampler(const double *t, double *tleft, double *tright,
+                                        const double *proposed_L, const double *proposed_u,
+                                        const double *proposed_p, int64_t *worker_running,
+                                        int64_t *status, double threshold, double shrink_factor,
+                                        double *allu, double *allL, double *allp, size_t popsize,
+                                        size_t d, size_t nparams, int64_t *discarded);
+int mlf_row_dist2(const double *a, const double *b, size_t n, size_t d, double *out);
+
+/* Resident walker population = the state of PopulationSliceSampler (popstepsampler.py:347-697:
+ * allu, allL, generation, currentt, currentv, current_left/right, searching_left/right,
+ * currentp) kept in HBM.  One sampler step (= one __next__ of the reference, :610-697) is
+ *   begin   : step_back(Lmin); returns generation[P] and flags[P]
+ *             (bit0 bracket undefined, bit1 searching_left, bit2 searching_right)
+ *   start   : setup_start for the listed walkers (:443-470)
+ *   brackets: setup_brackets (:483-505) with host directions, or _philox with a device draw
+ *             (kind 0-6 = the seven generate_*direction functions of stepfuncs.pyx:348-535)
+ *   propose : evolve's proposal for all walkers with generation < nsteps; with unew_out the
+ *             acceptable rows come back compacted in walker order for a host likelihood
+ *   finish  : evolve_update + advance() bookkeeping + harvest of walker `ringindex`;
+ *             finish_dev evaluates transform (tkind 0 identity, 1 x*a+b, 2 (x*a)*b) and
+ *             likelihood (kind as in mlf_loglike_dev) on the device instead.
+ * rec (9 + d + nparams doubles): [0] harvested, [1] L, [2] current_left, [3] current_right of the
+ * ring walker, [4] nc (likelihood evaluations), [5] walkers moved on, [6] successes, [7] moves
+ * farther than the MLFriends radius, [8] sum log(distance/radius + 1e-10), then u and p.        */
+typedef struct mlf_walkers mlf_walkers;
+int mlf_walkers_create(mlf_walkers **out, size_t popsize, size_t nsteps, size_t d);
+int mlf_walkers_destroy(mlf_walkers *w);
+int mlf_walkers_reset(mlf_walkers *w);
+int mlf_walkers_begin(mlf_walkers *w, double Lmin, int64_t *generation, uint8_t *flags);
+int mlf_walkers_start(mlf_walkers *w, const int64_t *idx, size_t n, const double *u_rows,
+                      const double *L);
+int mlf_walkers_points(mlf_walkers *w, const int64_t *idx, size_t n, double *out_rows);
+int mlf_walkers_brackets(mlf_walkers *w, const int64_t *idx, size_t n, double scale,
+                         const double *v_rows);
+int mlf_walkers_set_direction_data(mlf_walkers *w, const double *axes, const double *live,
+                                   size_t nlive, const double *std);
+int mlf_walkers_brackets_philox(mlf_walkers *w, double scale, int kind, double dirscale,
+                                uint64_t seed, uint64_t offset, uint64_t *next_offset);
+int mlf_walkers_set_layer(mlf_walkers *w, int kind, const double *ctr, const double *mat,
+                          const double *wrap, double maxradiussq);
+int mlf_walkers_propose(mlf_walkers *w, const double *unif, uint64_t seed, uint64_t offset,
+                        double *unew_out, size_t *nacc);
+int mlf_walkers_finish(mlf_walkers *w, double Lmin, const double *pnew, const double *Lnew,
+                       size_t nacc, size_t nparams, int64_t ringindex, double *rec);
+int mlf_walkers_finish_dev(mlf_walkers *w, double Lmin, int tkind, double ta, double tb, int lkind,
+                           const double *aux, double sigma, int64_t ringindex, double *rec);
+int mlf_walkers_export(mlf_walkers *w, double *allu, double *allL, int64_t *generation,
+                       double *currentt, double *currentv, double *left, double *right,
+                       uint8_t *searching_left, uint8_t *searching_right);
+
 /* H3 -> T1 -> K1 with the index kept: d_idx[p] = first live point within radiussq (>= 0),
  * -1 = inside the ellipsoid but no neighbour, -2 = outside the wrapping ellipsoid. */
 int mlf_region_first_index_dev(mlf_region *r, const double *d_pts, size_t np, int64_t *d_idx,

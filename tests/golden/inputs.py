@@ -94,3 +94,93 @@ def proposal_mix(seed, u, p, shell_q=2.0):
 def likelihood_inputs(seed, n, d, lo, hi):
     rs = np.random.RandomState(seed)
     return rs.uniform(lo, hi, size=(n, d))
+
+
+# ---------------------------------------------------------------- G9: population step sampler ----
+
+STEP_CASES = [(901, 257, 5), (902, 64, 50), (903, 1, 3), (904, 1000, 2)]
+
+
+def walker_state(seed, n, d):
+    """One population of slice-sampling walkers in a mix of the three states (stepping out left,
+    stepping out right, bisecting), some of them about to leave the unit cube."""
+    rs = np.random.RandomState(seed)
+    s = dict()
+    s["currentu"] = rs.uniform(0.02, 0.98, size=(n, d))
+    s["currentv"] = rs.normal(size=(n, d)) * 0.3
+    s["current_left"] = -rs.uniform(0.01, 2.0, size=n)
+    s["current_right"] = rs.uniform(0.01, 2.0, size=n)
+    state = rs.randint(4, size=n)          # 0 both, 1 right only, 2 bisecting, 3 left only
+    s["searching_left"] = np.logical_or(state == 0, state == 3)
+    s["searching_right"] = np.logical_or(state == 0, state == 1)
+    s["currentt"] = rs.uniform(-1, 1, size=n) * np.where(state == 2, 1.0, 0.0)
+    s["currentL"] = rs.normal(size=n)
+    s["Lmin"] = -0.3
+    return s
+
+
+def walker_loglike(p):
+    """Likelihood callback used for the evolve / sampler-trace vectors (numpy on both sides)."""
+    return -0.5 * (((p - 0.5) / 0.2)**2).sum(axis=1)
+
+
+def walker_transform(u):
+    return u * 1.0
+
+
+def update_inputs(seed, n):
+    """Inputs of evolve_update drawn independently of any geometry."""
+    rs = np.random.RandomState(seed)
+    s = walker_state(seed + 1000, n, 2)
+    acceptable = rs.uniform(size=n) < 0.8
+    Lnew = rs.normal(size=int(acceptable.sum()))
+    return s, acceptable, Lnew
+
+
+def step_back_state(seed, n, ngen):
+    """Chains of different lengths whose likelihoods partly fall below the new threshold."""
+    rs = np.random.RandomState(seed)
+    generation = rs.randint(-1, ngen, size=n).astype(np.int64)
+    allL = np.full((n, ngen), np.nan)
+    for i in range(n):
+        g = generation[i]
+        if g >= 0:
+            allL[i, :g + 1] = np.sort(rs.normal(size=g + 1)) if rs.uniform() < 0.5 else rs.normal(size=g + 1)
+    currentt = rs.normal(size=n)
+    currentt[rs.uniform(size=n) < 0.2] = np.nan
+    return allL, generation, currentt, 0.1
+
+
+def line_inputs(seed, n, d):
+    rs = np.random.RandomState(seed)
+    origin = rs.uniform(size=(n, d))
+    direction = rs.normal(size=(n, d))
+    direction[rs.uniform(size=(n, d)) < 0.15] = 0.0       # axis-parallel components
+    direction[0, :] = 0.0
+    direction[0, 0] = 1.0
+    origin[1, 0] = 0.5
+    direction[1, 0] = 0.0                                  # 0 * inf -> NaN entry, must be skipped
+    origin[2 % n, :] = 0.0                                 # starts on the boundary
+    return origin, direction
+
+
+def slice_update_inputs(seed, popsize, d, nparams, npoints_busy):
+    """State of PopulationSimpleSliceSampler in the middle of its shrinking loop: several
+    workers serve the same unfinished point."""
+    rs = np.random.RandomState(seed)
+    status = np.ones(popsize, dtype=np.int64)
+    busy = rs.choice(popsize, size=npoints_busy, replace=False)
+    status[busy] = 0
+    worker_running = np.sort(busy[rs.randint(npoints_busy, size=popsize)]).astype(np.int64)
+    tleft = -rs.uniform(0.2, 1.0, size=popsize)
+    tright = rs.uniform(0.2, 1.0, size=popsize)
+    t = rs.uniform(-1.1, 1.1, size=popsize)
+    proposed_L = rs.normal(size=popsize)
+    proposed_u = rs.uniform(size=(popsize, d))
+    proposed_p = rs.normal(size=(popsize, nparams))
+    allu = rs.uniform(size=(popsize, d))
+    allL = rs.normal(size=popsize)
+    allp = rs.normal(size=(popsize, nparams))
+    return dict(t=t, tleft=tleft, tright=tright, proposed_L=proposed_L, proposed_u=proposed_u,
+                proposed_p=proposed_p, worker_running=worker_running, status=status, allu=allu, allL=allL,
+                allp=allp, threshold=0.2)

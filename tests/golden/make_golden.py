@@ -340,7 +340,115 @@ def g8(ref):
         json.dump(meta, f, indent=1)
 
 
-GROUPS = dict(g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8)
+# ------------------------------------------------------------------ G9 ------
+
+DIRECTIONS = ["generate_cube_oriented_direction", "generate_cube_oriented_direction_scaled",
+              "generate_random_direction", "generate_region_oriented_direction",
+              "generate_region_random_direction", "generate_differential_direction",
+              "generate_mixture_random_direction"]
+
+
+def g9(ref):
+    """Population step-sampler state machine: every function of
+    ultranest/stepfuncs.pyx plus the geometry helpers and the PopulationSliceSampler loop of
+    ultranest/popstepsampler.py, run on seeded inputs."""
+    import ultranest.popstepsampler as pop
+    import ultranest.stepfuncs as sf
+    out = {}
+    # evolve_update / evolve_prepare / within_unit_cube
+    for seed, n, d in inputs.STEP_CASES:
+        s, acceptable, Lnew = inputs.update_inputs(seed, n)
+        search_right, bisecting = sf.evolve_prepare(s["searching_left"], s["searching_right"])
+        success = np.zeros(n, dtype=bool)
+        t, lo, hi = s["currentt"].copy(), s["current_left"].copy(), s["current_right"].copy()
+        sl, sr = s["searching_left"].copy(), s["searching_right"].copy()
+        sf.evolve_update(acceptable, Lnew, s["Lmin"], search_right, bisecting, t, lo, hi, sl, sr, success)
+        k = "upd%d_" % seed
+        out.update({k + "search_right": search_right, k + "bisecting": bisecting, k + "t": t, k + "left": lo,
+                    k + "right": hi, k + "sl": sl, k + "sr": sr, k + "success": success})
+        # full evolve with the global numpy stream
+        s = inputs.walker_state(seed, n, d)
+        np.random.seed(seed)
+        args = [s[key].copy() for key in ("currentu", "currentL", "currentt", "currentv", "current_left",
+                                          "current_right", "searching_left", "searching_right")]
+        (t, v, lo, hi, sl, sr), (success, unew, pnew, Lnew), nc = sf.evolve(
+            inputs.walker_transform, inputs.walker_loglike, s["Lmin"], *args)
+        k = "evo%d_" % seed
+        out.update({k + "t": t, k + "left": lo, k + "right": hi, k + "sl": sl, k + "sr": sr,
+                    k + "success": success, k + "unew": unew, k + "pnew": pnew, k + "Lnew": Lnew,
+                    k + "nc": np.int64(nc), k + "currentu_after": args[0],
+                    k + "cube": sf.within_unit_cube(args[0]), k + "next_random": np.random.uniform()})
+    # step_back
+    for seed, n, ngen in [(911, 40, 6), (912, 300, 21), (913, 5, 1)]:
+        allL, generation, currentt, Lmin = inputs.step_back_state(seed, n, ngen)
+        sf.step_back(Lmin, allL, generation, currentt)
+        k = "back%d_" % seed
+        out.update({k + "allL": allL, k + "generation": generation, k + "t": currentt})
+    # unit-cube line intersection
+    for seed, n, d in [(921, 200, 3), (922, 50, 50), (923, 7, 1)]:
+        origin, direction = inputs.line_inputs(seed, n, d)
+        with np.errstate(all="ignore"):
+            lo, hi = pop.unitcube_line_intersection(origin, direction)
+        out["line%d_left" % seed], out["line%d_right" % seed] = lo, hi
+    # shrinking loop of the simple slice sampler
+    for seed, popsize, d, nparams, busy in [(931, 12, 1, 1, 3), (932, 200, 7, 9, 40), (933, 64, 3, 3, 1)]:
+        for shrink in (1.0, 1.5):
+            a = inputs.slice_update_inputs(seed, popsize, d, nparams, busy)
+            res = sf.update_vectorised_slice_sampler(
+                a["t"], a["tleft"], a["tright"], a["proposed_L"], a["proposed_u"], a["proposed_p"],
+                a["worker_running"], a["status"], a["threshold"], shrink, a["allu"], a["allL"], a["allp"], popsize)
+            k = "slice%d_%d_" % (seed, int(shrink * 10))
+            for name, val in zip(("tleft", "tright", "worker_running", "status", "allu", "allL", "allp", "discarded"), res):
+                out[k + name] = np.asarray(val)
+    # direction generators + move diagnostics on a real region
+    u = inputs.live_points(940, 300, 6)
+    rng = np.random.RandomState(940)
+    layer = ref.AffineLayer()
+    layer.optimize(u, u)
+    region = ref.MLFriends(u, layer)
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=10, rng=rng)
+    region.create_ellipsoid()
+    out["region_axes"] = np.array(layer.axes)
+    out["region_T"], out["region_ctr"] = np.array(layer.T), np.array(layer.ctr)
+    out["region_maxradiussq"] = np.float64(region.maxradiussq)
+    ui = u[:50]
+    for name in DIRECTIONS:
+        np.random.seed(941)
+        out["dir_" + name] = getattr(sf, name)(ui, region, scale=0.7)
+    ufinal = np.clip(ui + rng.normal(size=ui.shape) * 0.02, 1e-3, 1 - 1e-3)
+    far, (dist, refdist) = pop.diagnose_move_distances(region, ui, ufinal)
+    out["diag_ufinal"], out["diag_far"], out["diag_dist"], out["diag_ref"] = ufinal, far, dist, np.float64(refdist)
+    # PopulationSliceSampler traces: fixed live points, rising threshold
+    Ls = inputs.walker_loglike(u)
+    for name, popsize, nsteps in [("generate_cube_oriented_direction", 13, 7),
+                                  ("generate_mixture_random_direction", 40, 5),
+                                  ("generate_region_random_direction", 1, 4)]:
+        np.random.seed(950)
+        sampler = pop.PopulationSliceSampler(popsize=popsize, nsteps=nsteps, generate_direction=getattr(sf, name),
+                                             scale=0.8)
+        order = np.argsort(Ls)
+        rows = []
+        nfound = 0
+        for it in range(400):
+            Lmin = Ls[order[min(nfound // 3, len(order) - 50)]]
+            unew, pnew, Lnew, nc = sampler.__next__(region, Lmin, u, Ls, inputs.walker_transform,
+                                                     inputs.walker_loglike)
+            if unew is None:
+                rows.append(np.concatenate([[0, nc, np.nan], np.full(2 * u.shape[1], np.nan)]))
+            else:
+                nfound += 1
+                rows.append(np.concatenate([[1, nc, Lnew], unew, pnew]))
+        k = "trace_%s_" % name
+        out[k + "rows"] = np.array(rows)
+        out[k + "scale"] = np.float64(sampler.scale)
+        out[k + "generation"] = sampler.generation
+        out[k + "allL"] = sampler.allL
+        out[k + "next_random"] = np.float64(np.random.uniform())
+        print("  trace", name, "found", nfound, "of 400 calls")
+    save("g9_stepfuncs", **out)
+
+
+GROUPS = dict(g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9)
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

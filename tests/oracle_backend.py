@@ -128,3 +128,140 @@ def install(monkeypatch):
         monkeypatch.setattr(K, name, g[name])
         if hasattr(M, name):
             monkeypatch.setattr(M, name, g[name])
+    install_stepfuncs(monkeypatch)
+
+
+# ---- population step sampler (row f1) ------------------------------------------------------------
+class OracleWalkers(object):
+    """Test-only stand-in for ultranest_amd.popstepsampler._Walkers: the resident state as numpy
+    arrays, advanced with the CPU oracle's restatement of the reference functions.  Lets the
+    sampler's host logic (draw order, ring index, bookkeeping) run without a GPU."""
+
+    def __init__(self, popsize, nsteps, ndim):
+        from oracle import stepfuncs as osf
+        self.osf = osf
+        self.popsize, self.nsteps, self.ndim, self.nparams = popsize, nsteps, ndim, None
+        P, G = popsize, nsteps + 1
+        self.allu = np.full((P, G, ndim), np.nan)
+        self.allL = np.full((P, G), np.nan)
+        self.generation = np.zeros(P, dtype=np.int64) - 1
+        self.currentt = np.full(P, np.nan)
+        self.currentv = np.full((P, ndim), np.nan)
+        self.left, self.right = np.zeros(P), np.zeros(P)
+        self.sl, self.sr = np.zeros(P, dtype=bool), np.zeros(P, dtype=bool)
+        self.currentp = None
+        self.layer = None
+
+    def begin(self, Lmin):
+        self.osf.step_back(Lmin, self.allL, self.generation, self.currentt)
+        flags = (~np.isfinite(self.currentt)) * 1 + self.sl * 2 + self.sr * 4
+        return self.generation.copy(), flags.astype(np.uint8)
+
+    def start(self, idx, rows, L):
+        self.allu[idx, 0] = rows
+        self.allL[idx, 0] = L
+        self.generation[idx] = 0
+
+    def points(self, idx):
+        return self.allu[idx, self.generation[idx]]
+
+    def brackets(self, idx, scale, v):
+        self.left[idx], self.right[idx] = -scale, scale
+        self.sl[idx] = self.sr[idx] = True
+        self.currentt[idx] = 0
+        self.currentv[idx] = v
+
+    def set_layer(self, kind, ctr, mat, wrap, r2):
+        self.layer = None if kind < 0 else (kind, np.array(ctr), np.array(mat), wrap, r2)
+
+    def set_direction_data(self, **kw):
+        raise AssertionError("device directions need the GPU")
+
+    def propose(self, unif=None, rng=None, fetch=True):
+        assert rng is None, "the Philox stream lives on the GPU"
+        self.movable = self.generation < self.nsteps
+        m = np.flatnonzero(self.movable)
+        bis = ~np.logical_or(self.sl, self.sr)
+        t = self.currentt.copy()
+        draw = np.logical_and(bis, self.movable)
+        scaled = (self.right - self.left) * unif
+        t[draw] = (self.left + scaled)[draw]
+        self.currentt = t
+        u0 = np.ascontiguousarray(self.allu[m, self.generation[m]])
+        unew = np.empty_like(u0)
+        # named temporaries: the raw addresses must stay alive for the duration of the call
+        v, lo, hi = (np.ascontiguousarray(a[m]) for a in (self.currentv, self.left, self.right))
+        sl, sr = np.ascontiguousarray(self.sl[m]).view(np.uint8), np.ascontiguousarray(self.sr[m]).view(np.uint8)
+        tm = np.ascontiguousarray(self.currentt[m])
+        self.osf.lib().orc_evolve_propose(u0.ctypes.data, v.ctypes.data, lo.ctypes.data, hi.ctypes.data,
+                                          sl.ctypes.data, sr.ctypes.data, tm.ctypes.data, len(m), self.ndim,
+                                          unew.ctypes.data)
+        self.unew = np.full((self.popsize, self.ndim), np.nan)
+        self.unew[m] = unew
+        self.acceptable = np.zeros(self.popsize, dtype=bool)
+        self.acceptable[m] = self.osf.within_unit_cube(unew) if len(m) else False
+        return self.unew[self.acceptable] if fetch else None
+
+    def finish(self, Lmin, pnew, Lnew, ringindex):
+        P = self.popsize
+        if len(Lnew):
+            self.nparams = pnew.shape[1]
+        elif self.nparams is None:
+            self.nparams = self.ndim
+        if self.currentp is None:
+            self.currentp = np.full((P, self.nparams), np.nan)
+        m = self.movable
+        sright, bis = self.osf.evolve_prepare(self.sl[m], self.sr[m])
+        t, lo, hi = (np.ascontiguousarray(a[m]) for a in (self.currentt, self.left, self.right))
+        sl, sr = np.ascontiguousarray(self.sl[m]), np.ascontiguousarray(self.sr[m])
+        success_m = np.zeros(int(m.sum()), dtype=bool)
+        self.osf.evolve_update(self.acceptable[m], Lnew, Lmin, sright, bis, t, lo, hi, sl, sr, success_m)
+        self.currentt[m], self.left[m], self.right[m], self.sl[m], self.sr[m] = t, lo, hi, sl, sr
+        success = np.zeros(P, dtype=bool)
+        success[m] = success_m
+        Lfull, pfull = np.full(P, np.nan), np.full((P, self.nparams), np.nan)
+        Lfull[self.acceptable] = Lnew
+        if len(Lnew):
+            pfull[self.acceptable] = pnew
+        uorig = self.allu[success, self.generation[success]]
+        self.generation[success] += 1
+        self.allu[success, self.generation[success]] = self.unew[success]
+        self.allL[success, self.generation[success]] = Lfull[success]
+        self.currentp[success] = pfull[success]
+        nfar, sumlog = 0.0, 0.0
+        if self.layer is not None and success.any():
+            kind, ctr, mat, wrap, r2 = self.layer
+            tr = (lambda x: np.dot(x - ctr, mat)) if kind == 0 else (lambda x: (x - ctr) / mat)
+            d2 = ((tr(uorig) - tr(self.unew[success]))**2).sum(axis=1)
+            nfar = float((d2 > r2).sum())
+            sumlog = float(np.log(d2**0.5 / r2**0.5 + 1e-10).sum())
+        rec = dict(found=bool(self.generation[ringindex] == self.nsteps), L=np.nan, left=self.left[ringindex],
+                   right=self.right[ringindex], nc=int(self.acceptable.sum()), nmovable=int(m.sum()),
+                   nsuccess=int(success.sum()), nfar=nfar, sumlog=sumlog, u=None, p=None)
+        if rec["found"]:
+            rec["L"] = self.allL[ringindex, self.nsteps]
+            rec["u"] = self.allu[ringindex, self.nsteps].copy()
+            rec["p"] = self.currentp[ringindex].copy()
+            self.generation[ringindex] = -1
+            self.currentt[ringindex] = np.nan
+            self.allu[ringindex] = np.nan
+            self.allL[ringindex] = np.nan
+        return rec
+
+    def export(self):
+        return dict(allu=self.allu.copy(), allL=self.allL.copy(), generation=self.generation.copy(),
+                    currentt=self.currentt.copy(), currentv=self.currentv.copy(), current_left=self.left.copy(),
+                    current_right=self.right.copy(), searching_left=self.sl.copy(), searching_right=self.sr.copy())
+
+
+def install_stepfuncs(monkeypatch):
+    """Route the host-array step functions and the resident walker handle through the oracle."""
+    import ultranest_amd.popstepsampler as P
+    import ultranest_amd.stepfuncs as S
+    from oracle import stepfuncs as osf
+    for name in ("within_unit_cube", "evolve_update", "evolve", "step_back", "update_vectorised_slice_sampler",
+                 "unitcube_line_intersection", "row_dist2"):
+        monkeypatch.setattr(S, name, getattr(osf, name))
+        if hasattr(P, name):
+            monkeypatch.setattr(P, name, getattr(osf, name))
+    monkeypatch.setattr(P, "_Walkers", OracleWalkers)

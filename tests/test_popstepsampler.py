@@ -1,0 +1,219 @@
+"""PopulationSliceSampler against call-by-call traces recorded from the
+reference sampler (tests/golden/make_golden.py g9): same np.random seed, same live points and
+thresholds -> the same (u, p, L, nc) out of every __next__, the same final chain state and the
+same position of the numpy stream.  `backend` = oracle stand-in (CPU, host logic) or the resident
+HIP state machine (`-m gpu`)."""
+import types
+
+import numpy as np
+import pytest
+
+from golden import inputs
+
+
+def _region(g, real=False):
+    u = inputs.live_points(940, 300, 6)
+    layer = types.SimpleNamespace(axes=g["region_axes"], T=g["region_T"], ctr=g["region_ctr"])
+    return types.SimpleNamespace(u=u, transformLayer=layer, maxradiussq=float(g["region_maxradiussq"]))
+
+
+TRACES = [("generate_cube_oriented_direction", 13, 7), ("generate_mixture_random_direction", 40, 5),
+          ("generate_region_random_direction", 1, 4)]
+
+
+@pytest.mark.parametrize("name,popsize,nsteps", TRACES)
+def test_trace_equals_reference(backend, golden, name, popsize, nsteps):
+    import ultranest_amd.popstepsampler as pop
+    g = golden("g9_stepfuncs")
+    region = _region(g)
+    u = region.u
+    Ls = inputs.walker_loglike(u)
+    order = np.argsort(Ls)
+    want = g["trace_%s_rows" % name]
+    np.random.seed(950)
+    sampler = pop.PopulationSliceSampler(popsize=popsize, nsteps=nsteps, generate_direction=getattr(pop, name),
+                                         scale=0.8)
+    nfound = 0
+    d = u.shape[1]
+    for it in range(len(want)):
+        Lmin = Ls[order[min(nfound // 3, len(order) - 50)]]
+        unew, pnew, Lnew, nc = sampler.__next__(region, Lmin, u, Ls, inputs.walker_transform, inputs.walker_loglike)
+        row = want[it]
+        assert nc == int(row[1]), (it, nc, row[1])
+        if row[0] == 0:
+            assert unew is None and pnew is None and Lnew is None, it
+        else:
+            nfound += 1
+            assert Lnew == row[2], it
+            assert np.array_equal(unew, row[3:3 + d]) and np.array_equal(pnew, row[3 + d:3 + 2 * d]), it
+    assert np.random.uniform() == float(g["trace_%s_next_random" % name])
+    assert sampler.scale == float(g["trace_%s_scale" % name])
+    state = sampler.state()
+    assert np.array_equal(state["generation"], g["trace_%s_generation" % name])
+    assert np.array_equal(state["allL"], g["trace_%s_allL" % name], equal_nan=True)
+    assert len(sampler.logstat) > 0 and np.isfinite(sampler.far_enough_fraction)
+    assert isinstance(sampler.status, str)
+
+
+def test_simple_slice_sampler_moves_points_above_threshold(backend, golden):
+    """Sanity of the PopulationSimpleSliceSampler loop (cf. reference
+    tests/test_popstepsampling.py:222-260): accepted points beat Lmin and stay in the cube."""
+    import ultranest_amd.popstepsampler as pop
+    g = golden("g9_stepfuncs")
+    region = _region(g)
+    u = region.u
+    Ls = inputs.walker_loglike(u)
+    Lmin = np.sort(Ls)[20]
+    np.random.seed(4)
+    sampler = pop.PopulationSimpleSliceSampler(popsize=50, nsteps=3, generate_direction=pop.generate_random_direction)
+    region.transformLayer.transform = lambda x: np.dot(x - g["region_ctr"], g["region_T"])
+    out = [sampler.__next__(region, Lmin, u, Ls, inputs.walker_transform, inputs.walker_loglike) for _ in range(50)]
+    L = np.array([o[2] for o in out])
+    pts = np.array([o[0] for o in out])
+    assert (L > Lmin).all()
+    assert np.logical_and(pts > 0, pts < 1).all()
+    assert out[0][3] > 0 and all(o[3] == 0 for o in out[1:])
+    assert np.allclose(L, inputs.walker_loglike(pts))
+
+
+def test_random_walk_sampler(backend, golden):
+    import ultranest_amd.popstepsampler as pop
+    g = golden("g9_stepfuncs")
+    region = _region(g)
+    region.transformLayer.transform = lambda x: np.dot(x - g["region_ctr"], g["region_T"])
+    u = region.u
+    Ls = inputs.walker_loglike(u)
+    Lmin = np.sort(Ls)[2]
+    np.random.seed(5)
+    sampler = pop.PopulationRandomWalkSampler(popsize=30, nsteps=40, generate_direction=pop.generate_random_direction,
+                                              scale=0.05)
+    out = [sampler.__next__(region, Lmin, u, Ls, inputs.walker_transform, inputs.walker_loglike) for _ in range(30)]
+    L = np.array([o[2] for o in out])
+    assert (L > Lmin).all() and out[0][3] == 1200
+    assert sampler.scale != 0.05
+
+
+# ---- GPU-only: resident likelihood and the Philox stream -----------------------------------------
+
+def _ball_problem(d, nlive, seed):
+    """Gaussian shell threshold: {L > Lmin} is a ball of radius R around 0.5; live points uniform in it."""
+    rs = np.random.RandomState(seed)
+    R = 0.3
+    z = rs.normal(size=(nlive, d))
+    z *= (R * rs.uniform(size=(nlive, 1))**(1. / d)) / np.linalg.norm(z, axis=1).reshape((-1, 1))
+    u = 0.5 + z
+    sigma = 0.1
+    Lmin = -0.5 * (R / sigma)**2
+    return u, sigma, Lmin, R
+
+
+def _gpu_region(u):
+    import ultranest_amd.mlfriends as m
+    layer = m.AffineLayer()
+    layer.optimize(u, u)
+    region = m.MLFriends(u, layer)
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=10, rng=np.random.RandomState(2))
+    region.create_ellipsoid()
+    return region
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["numpy", "philox"])
+@pytest.mark.parametrize("direction", ["generate_random_direction", "generate_mixture_random_direction",
+                                       "generate_region_random_direction", "generate_cube_oriented_direction"])
+def test_slice_sampling_is_uniform_under_the_threshold(mode, direction):
+    """Slice sampling inside a hard likelihood contour leaves the uniform distribution invariant:
+    the points returned are uniform in the ball, for both random sources and a resident
+    (device-evaluated) Gaussian likelihood."""
+    from scipy import stats
+    import ultranest_amd.popstepsampler as pop
+    from ultranest_amd import likelihoods
+    from ultranest_amd.regions import DeviceRNG
+    d = 3
+    u, sigma, Lmin, R = _ball_problem(d, 400, 11)
+    region = _gpu_region(u)
+    loglike = likelihoods.GaussLikelihood(0.5, sigma, d)
+    norm = -0.5 * np.log(2 * np.pi * sigma**2) * d
+    Ls = loglike(u)
+    np.random.seed(21)
+    sampler = pop.PopulationSliceSampler(popsize=256, nsteps=12, generate_direction=getattr(pop, direction), scale=0.3,
+                                         device_rng=DeviceRNG(5) if mode == "philox" else None)
+    pts, Lout, ncall = [], [], 0
+    for _ in range(6000):
+        unew, pnew, Lnew, nc = sampler.__next__(region, Lmin + norm, u, Ls, likelihoods.identity_transform, loglike)
+        ncall += nc
+        if unew is not None:
+            pts.append(unew)
+            Lout.append(Lnew)
+            assert np.array_equal(unew, pnew)
+        if len(pts) >= 1500:
+            break
+    pts, Lout = np.array(pts), np.array(Lout)
+    assert len(pts) >= 1500, len(pts)
+    assert (Lout > Lmin + norm).all()
+    assert np.allclose(Lout, loglike(pts), rtol=1e-12, atol=1e-12)
+    r = np.linalg.norm(pts - 0.5, axis=1) / R
+    assert r.max() < 1
+    # thin to reduce the correlation between walkers that shared a start point
+    assert stats.kstest(r[::3]**d, "uniform").pvalue > 1e-3
+    assert np.abs((pts - 0.5).mean(axis=0)).max() < 0.03
+    assert sampler.far_enough_fraction > 0.1 and np.isfinite(sampler.mean_jump_distance)
+
+
+@pytest.mark.gpu
+def test_resident_likelihood_equals_host_callbacks_on_rosenbrock():
+    """Same numpy stream, once with numpy callbacks and once with the device-evaluated Rosenbrock
+    likelihood + affine transform: transformed points are bit-identical, likelihoods agree to
+    1e-12, so the trajectories coincide."""
+    import ultranest_amd.popstepsampler as pop
+    from ultranest_amd import likelihoods
+    d = 6
+    rs = np.random.RandomState(3)
+    u = 0.5 + 0.04 * rs.normal(size=(300, d))
+    region = _gpu_region(u)
+
+    def host_transform(x):
+        return x * 20 - 10
+
+    def host_loglike(theta):
+        a, b = theta[:, :-1], theta[:, 1:]
+        return -2 * (100 * (b - a**2)**2 + (1 - a)**2).sum(axis=1)
+
+    Ls = host_loglike(host_transform(u))
+    Lmin = np.sort(Ls)[5]
+    runs = []
+    for transform, loglike in [(host_transform, host_loglike),
+                               (likelihoods.rosenbrock_transform, likelihoods.rosenbrock_loglike)]:
+        np.random.seed(8)
+        sampler = pop.PopulationSliceSampler(popsize=32, nsteps=6, generate_direction=pop.generate_mixture_random_direction,
+                                             scale=0.5)
+        out = [sampler.__next__(region, Lmin, u, Ls, transform, loglike) for _ in range(300)]
+        runs.append(out)
+    nfound = 0
+    for (ua, pa, La, nca), (ub, pb, Lb, ncb) in zip(*runs):
+        assert nca == ncb
+        assert (ua is None) == (ub is None)
+        if ua is not None:
+            nfound += 1
+            assert np.array_equal(ua, ub) and np.array_equal(pa, pb)
+            assert abs(La - Lb) <= 1e-12 * abs(La)
+    assert nfound > 20
+
+
+@pytest.mark.gpu
+def test_nested_sampling_with_the_population_slice_sampler():
+    """End to end: static nested sampling of a 6-d Gaussian with step-sampled replacements
+    (Philox stream, resident likelihood) recovers the analytic evidence."""
+    import ultranest_amd.popstepsampler as pop
+    from ultranest_amd import likelihoods
+    from ultranest_amd.harness import StaticNestedSampler
+    from ultranest_amd.regions import DeviceRNG
+    d, sigma = 6, 0.05
+    loglike = likelihoods.GaussLikelihood(0.5, sigma, d)
+    step = pop.PopulationSliceSampler(popsize=128, nsteps=2 * d, generate_direction=pop.generate_mixture_random_direction,
+                                      scale=0.5, device_rng=DeviceRNG(4))
+    s = StaticNestedSampler(d, loglike, transform=likelihoods.identity_transform, num_live_points=200, seed=2,
+                            stepsampler=step)
+    res = s.run(dlogz=0.2)
+    assert abs(res["logz"] - 0.0) < 4 * res["logzerr"] + 0.2, res
+    assert 0 < step.far_enough_fraction <= 1 and step.mean_jump_distance > 0

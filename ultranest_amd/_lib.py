@@ -56,6 +56,28 @@ SIGNATURES = {
     "mlf_region_set_axes": [_vp, _vp],
     "mlf_region_sample": [_vp, _int, _sz, ctypes.c_uint64, ctypes.c_uint64, _vp, _sz, _vp, _vp],
     "mlf_debug_philox": [ctypes.c_uint64, ctypes.c_uint, _sz, _vp],
+    "mlf_within_unit_cube": [_vp, _sz, _sz, _vp],
+    "mlf_evolve_propose": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp],
+    "mlf_evolve_update": [_vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _sz],
+    "mlf_step_back": [_dbl, _vp, _sz, _sz, _vp, _vp],
+    "mlf_unitcube_line_intersection": [_vp, _vp, _sz, _sz, _vp, _vp],
+    "mlf_update_vectorised_slice_sampler": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, _vp, _vp, _sz,
+                                            _sz, _sz, _vp],
+    "mlf_row_dist2": [_vp, _vp, _sz, _sz, _vp],
+    "mlf_walkers_create": [_vp, _sz, _sz, _sz],
+    "mlf_walkers_destroy": [_vp],
+    "mlf_walkers_reset": [_vp],
+    "mlf_walkers_begin": [_vp, _dbl, _vp, _vp],
+    "mlf_walkers_start": [_vp, _vp, _sz, _vp, _vp],
+    "mlf_walkers_points": [_vp, _vp, _sz, _vp],
+    "mlf_walkers_brackets": [_vp, _vp, _sz, _dbl, _vp],
+    "mlf_walkers_set_direction_data": [_vp, _vp, _vp, _sz, _vp],
+    "mlf_walkers_brackets_philox": [_vp, _dbl, _int, _dbl, ctypes.c_uint64, ctypes.c_uint64, _vp],
+    "mlf_walkers_set_layer": [_vp, _int, _vp, _vp, _vp, _dbl],
+    "mlf_walkers_propose": [_vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp],
+    "mlf_walkers_finish": [_vp, _dbl, _vp, _vp, _sz, _sz, ctypes.c_int64, _vp],
+    "mlf_walkers_finish_dev": [_vp, _dbl, _int, _dbl, _dbl, _int, _vp, _dbl, ctypes.c_int64, _vp],
+    "mlf_walkers_export": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlf_region_inside_dev_timed": [_vp, _vp, _sz, _vp, _vp],
     "mlf_region_timing_collect": [_vp, _vp, _vp, _vp, _vp],
     "mlf_region_filter_info": [_vp, _sz, _vp, _vp, _vp],

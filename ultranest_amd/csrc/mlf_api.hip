@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/mlfriends_hip.h"
+#include "mlf_ctx.hpp"
 #include "mlf_filter.hpp"
 #include "mlf_misc.hpp"
 #include "mlf_prep2.hpp"
@@ -38,33 +39,6 @@ int fail_arg(int code, const char *msg) {
     hipError_t e_ = (x);                                        \
     if (e_ != hipSuccess) return fail_hip(e_, #x, __LINE__);    \
   } while (0)
-
-// grow-only device buffer
-struct DevBuf {
-  void *p = nullptr;
-  size_t cap = 0;
-  hipError_t reserve(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    if (p) {
-      hipError_t e = hipFree(p);
-      p = nullptr;
-      cap = 0;
-      if (e != hipSuccess) return e;
-    }
-    const size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) return e;
-    cap = want;
-    return hipSuccess;
-  }
-  template <class T>
-  T *as() const { return static_cast<T *>(p); }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-};
 
 // Buffers and host-side state of the MFMA pre-filter (mlf_filter.hip) for one set of live points.
 struct FilterCtx {
@@ -506,6 +480,18 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
 }
 
 }  // namespace
+
+namespace mlf {
+int ctx_ensure() { return ensure_ctx(); }
+hipStream_t ctx_stream() { return g_ctx.stream; }
+int ctx_fail_hip(hipError_t e, const char *what, const char *file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+  g_err = buf;
+  return -(int)e;
+}
+int ctx_fail_arg(int code, const char *msg) { return fail_arg(code, msg); }
+}  // namespace mlf
 
 extern "C" {
 

@@ -1,0 +1,684 @@
+// mlf_walk.hip -- population step-sampler state machine, resident in HBM.
+//
+// One lane per walker.  A walker's state is a few scalars plus two d-vectors (position, slice
+// direction), so every kernel here is a short HBM-bound pass over P walkers; what the device
+// buys is that (u, v, t, brackets, chain history) never cross PCIe between likelihood batches.
+// Arithmetic that the reference performs in a fixed order (u + v*t, bracket doubling, the
+// bisection draw low + (high-low)*U) is done in the same order without FMA (the file is compiled
+// with -ffp-contract=off), so the state machine is bit-identical to ultranest/stepfuncs.pyx for
+// the same random numbers; tests/test_stepfuncs_golden.py checks that against recorded vectors.
+#include "mlf_walk.hpp"
+
+#include <math.h>
+
+#include "mlf_philox_dev.hpp"
+
+namespace mlf {
+
+namespace {
+
+__device__ __forceinline__ double qnan() { return __longlong_as_double(0x7ff8000000000000ll); }
+
+__device__ __forceinline__ bool inside_open_unit(double x) { return 0.0 < x && x < 1.0; }
+
+// evolve_update for one walker (stepfuncs.pyx:160-183); returns the final success flag
+__device__ __forceinline__ bool update_walker(bool hit, double &t, double &left, double &right, uint8_t &sl,
+                                              uint8_t &sr) {
+  const bool l = sl != 0, r = sr != 0;
+  const bool search_right = !l && r, bisecting = !(l || r);
+  bool success = hit;
+  if (success) {
+    if (l)
+      left *= 2;
+    else if (search_right)
+      right *= 2;
+  } else {
+    if (l)
+      sl = 0;
+    else if (search_right)
+      sr = 0;
+  }
+  if (bisecting) {
+    if (t < 0)
+      left = t;
+    else
+      right = t;
+    if (success) t = qnan();
+  } else {
+    success = false;
+  }
+  return success;
+}
+
+// step_back for one walker (stepfuncs.pyx:285-334).  `width` = max generation + 1 over the
+// population.  Exact for generation >= 0; a walker that unwinds below generation 0 with
+// below-threshold entries left (a state the sampler never produces) stops at -1.
+__device__ __forceinline__ void step_back_walker(double Lmin, double *L, int G, long long width, long long &gen,
+                                                 double &t) {
+  if (width > G) width = G;
+  int nbelow = 0;
+  for (long long k = 0; k < width; ++k) nbelow += (L[k] < Lmin) ? 1 : 0;
+  while (nbelow > 0) {
+    const long long g = gen;
+    if (g < 0 || g >= width) break;
+    gen = g - 1;
+    t = qnan();
+    if (L[g] < Lmin) --nbelow;
+    L[g] = qnan();
+  }
+}
+
+// whitened coordinates of one point (T1: fmod wrap, centre, k-ascending FMA chain like BLAS)
+__device__ __forceinline__ void whiten_point(const WalkLayer &ly, const double *x, int d, int c, double &out) {
+  if (ly.kind == 1) {
+    double v = x[c];
+    if (ly.wrap && !isnan(ly.wrap[c])) v = fmod(v + ly.wrap[c], 1.0);
+    out = (v - ly.ctr[c]) / ly.mat[c];
+    return;
+  }
+  double acc = 0.0;
+  for (int k = 0; k < d; ++k) {
+    double v = x[k];
+    if (ly.wrap && !isnan(ly.wrap[k])) v = fmod(v + ly.wrap[k], 1.0);
+    acc = __builtin_fma(v - ly.ctr[k], ly.mat[(size_t)k * d + c], acc);
+  }
+  out = acc;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ resident state ---------------
+__global__ void k_walk_reset(WalkState w) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nu = (long long)w.P * w.G * w.d;
+  if (e < nu) w.allu[e] = qnan();
+  if (e < (long long)w.P * w.G) w.allL[e] = qnan();
+  if (e < (long long)w.P * w.d) w.currentv[e] = qnan();
+  if (e < w.P) {
+    w.generation[e] = -1;
+    w.currentt[e] = qnan();
+    w.left[e] = 0.0;
+    w.right[e] = 0.0;
+    w.sl[e] = 0;
+    w.sr[e] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_max_generation(const long long *generation, int n, long long *gmax) {
+  __shared__ long long part[256];
+  long long m = -(1ll << 62);
+  for (int i = threadIdx.x; i < n; i += 256) m = generation[i] > m ? generation[i] : m;
+  part[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off && part[threadIdx.x + off] > part[threadIdx.x]) part[threadIdx.x] = part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *gmax = part[0];
+}
+
+__global__ void k_step_back(double Lmin, double *allL, int n, int G, long long *generation, double *currentt,
+                            const long long *gmax, const uint8_t *sl, const uint8_t *sr, uint8_t *flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  long long gen = generation[i];
+  double t = currentt[i];
+  step_back_walker(Lmin, allL + (size_t)i * G, G, *gmax + 1, gen, t);
+  generation[i] = gen;
+  currentt[i] = t;
+  if (flags) flags[i] = (uint8_t)((isfinite(t) ? 0 : 1) | (sl[i] ? 2 : 0) | (sr[i] ? 4 : 0));
+}
+
+__global__ void k_walk_start(WalkState w, const long long *idx, int n, const double *rows, const double *L) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * w.d) return;
+  const int j = e / w.d, k = e % w.d;
+  const long long i = idx[j];
+  w.allu[((size_t)i * w.G) * w.d + k] = rows[(size_t)j * w.d + k];
+  if (k == 0) {
+    w.allL[(size_t)i * w.G] = L[j];
+    w.generation[i] = 0;
+  }
+}
+
+__global__ void k_walk_points(WalkState w, const long long *idx, int n, double *out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * w.d) return;
+  const int j = e / w.d, k = e % w.d;
+  const long long i = idx[j];
+  long long g = w.generation[i];
+  if (g < 0) g += w.G;
+  out[(size_t)j * w.d + k] = w.allu[((size_t)i * w.G + g) * w.d + k];
+}
+
+// setup_brackets with host-provided directions (popstepsampler.py:483-505)
+__global__ void k_walk_brackets(WalkState w, const long long *idx, int n, double scale, const double *v_rows) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * w.d) return;
+  const int j = e / w.d, k = e % w.d;
+  const long long i = idx[j];
+  w.currentv[(size_t)i * w.d + k] = v_rows[(size_t)j * w.d + k];
+  if (k == 0) {
+    w.left[i] = -scale;
+    w.right[i] = scale;
+    w.sl[i] = 1;
+    w.sr[i] = 1;
+    w.currentt[i] = 0.0;
+  }
+}
+
+// setup_brackets with a device-side direction draw for every walker whose bracket is undefined.
+// Philox stream 2, (npairs + 2) blocks per walker: block 0 = integer picks + mixture coin,
+// blocks 1.. = Box-Muller pairs.
+__global__ void k_walk_brackets_philox(WalkState w, double scale, int kind, double dirscale, WalkDirData dd,
+                                       unsigned long long seed, unsigned long long offset) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w.P) return;
+  if (isfinite(w.currentt[i])) return;
+  const int d = w.d;
+  double *v = w.currentv + (size_t)i * d;
+  const int npairs = (d + 1) / 2;
+  const unsigned long long base = offset + (unsigned long long)i * (unsigned long long)(npairs + 2);
+  unsigned pick[4];
+  philox_block(seed, 2u, base, pick);
+  int k = kind;
+  if (k == DIR_MIXTURE) k = (u01(pick[2], pick[3]) < 0.5) ? DIR_DIFFERENTIAL : DIR_REGION_ORIENTED;
+  if (k == DIR_CUBE_ORIENTED || k == DIR_CUBE_ORIENTED_SCALED) {
+    const int j = (int)below(pick[0], (unsigned)d);
+    for (int c = 0; c < d; ++c) v[c] = 0.0;
+    v[j] = (k == DIR_CUBE_ORIENTED) ? dirscale : dirscale * dd.std[j];
+  } else if (k == DIR_REGION_ORIENTED) {
+    const int j = (int)below(pick[0], (unsigned)d);
+    for (int c = 0; c < d; ++c) v[c] = dd.axes[(size_t)j * d + c] * dirscale;
+  } else if (k == DIR_DIFFERENTIAL) {
+    const unsigned a = below(pick[0], (unsigned)dd.nlive);
+    unsigned b = below(pick[1], (unsigned)(dd.nlive - 1));
+    if (b >= a) ++b;
+    for (int c = 0; c < d; ++c) v[c] = (dd.live[(size_t)a * d + c] - dd.live[(size_t)b * d + c]) * dirscale;
+  } else {   // DIR_RANDOM, DIR_REGION_RANDOM: isotropic unit vector of length dirscale
+    double norm2 = 0.0;
+    for (int j = 0; j < npairs; ++j) {
+      unsigned r4[4];
+      philox_block(seed, 2u, base + 1 + j, r4);
+      const double rad = sqrt(-2.0 * log(u01(r4[0], r4[1])));
+      const double ang = 2.0 * M_PI * u01(r4[2], r4[3]);
+      const double g0 = rad * cos(ang), g1 = rad * sin(ang);
+      v[2 * j] = g0;
+      norm2 += g0 * g0;
+      if (2 * j + 1 < d) {
+        v[2 * j + 1] = g1;
+        norm2 += g1 * g1;
+      }
+    }
+    const double f = dirscale / sqrt(norm2);
+    if (k == DIR_RANDOM) {
+      for (int c = 0; c < d; ++c) v[c] *= f;
+    } else {   // v[i] = sum_j axes[i][j] * v1[j]; v1 is parked in unew (free before propose)
+      double *v1 = w.unew + (size_t)i * d;
+      for (int c = 0; c < d; ++c) v1[c] = v[c] * f;
+      for (int r = 0; r < d; ++r) {
+        double acc = 0.0;
+        for (int c = 0; c < d; ++c) acc += dd.axes[(size_t)r * d + c] * v1[c];
+        v[r] = acc;
+      }
+    }
+  }
+  w.left[i] = -scale;
+  w.right[i] = scale;
+  w.sl[i] = 1;
+  w.sr[i] = 1;
+  w.currentt[i] = 0.0;
+}
+
+// evolve, first half (stepfuncs.pyx:249-261): slice coordinate, proposed point, cube test
+__global__ void k_walk_propose(WalkState w, const double *unif, unsigned long long seed, unsigned long long offset) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w.P) return;
+  const long long g = w.generation[i];
+  const bool movable = g >= 0 && g < w.G - 1;
+  w.movable[i] = movable ? 1 : 0;
+  if (!movable) {
+    w.acceptable[i] = 0;
+    return;
+  }
+  const bool l = w.sl[i] != 0, r = w.sr[i] != 0;
+  double t;
+  if (l) {
+    t = w.left[i];
+  } else if (r) {
+    t = w.right[i];
+  } else {
+    double u;
+    if (unif) {
+      u = unif[i];
+    } else {
+      unsigned r4[4];
+      philox_block(seed, 3u, offset + (unsigned long long)i, r4);
+      u = u01(r4[0], r4[1]);
+    }
+    const double lo = w.left[i];
+    const double range = w.right[i] - lo;
+    const double scaled = range * u;
+    t = lo + scaled;
+    w.currentt[i] = t;
+  }
+  const double *u0 = w.allu + ((size_t)i * w.G + g) * w.d;
+  const double *v = w.currentv + (size_t)i * w.d;
+  double *un = w.unew + (size_t)i * w.d;
+  bool ok = true;
+  for (int k = 0; k < w.d; ++k) {
+    const double step = v[k] * t;
+    const double x = u0[k] + step;
+    un[k] = x;
+    ok = ok && inside_open_unit(x);
+  }
+  w.acceptable[i] = ok ? 1 : 0;
+}
+
+__global__ void k_walk_transform(WalkState w, int tkind, double a, double b) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)w.P * w.d) return;
+  const double x = w.unew[e];
+  double p = x;
+  if (tkind == 1) {
+    const double m = x * a;
+    p = m + b;
+  } else if (tkind == 2) {
+    const double m = x * a;
+    p = m * b;
+  }
+  w.pnew[e] = p;
+}
+
+// blk = exclusive per-256 offsets of the acceptable walkers (launch_compact); walker i takes row
+// rank(i) of the compacted host results
+__global__ __launch_bounds__(256) void k_walk_expand(WalkState w, const unsigned *blk, const double *pc,
+                                                     const double *Lc) {
+  __shared__ unsigned wsum[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool acc = i < w.P && w.acceptable[i] != 0;
+  const unsigned long long b = __ballot(acc);
+  if (lane == 0) wsum[wave] = (unsigned)__popcll(b);
+  __syncthreads();
+  unsigned base = blk[blockIdx.x];
+  for (int k = 0; k < wave; ++k) base += wsum[k];
+  const unsigned rank = base + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+  if (!acc) return;
+  w.Lnew[i] = Lc[rank];
+  for (int k = 0; k < w.nparams; ++k) w.pnew[(size_t)i * w.nparams + k] = pc[(size_t)rank * w.nparams + k];
+}
+
+// evolve, second half (evolve_update) + PopulationSliceSampler.advance bookkeeping
+// (popstepsampler.py:585-603) + move diagnostics (diagnose_move_distances :64-94)
+__global__ void k_walk_update(WalkState w, double Lmin, WalkLayer ly) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w.P) return;
+  w.dist2[i] = qnan();
+  if (!w.movable[i]) {
+    w.success[i] = 0;
+    return;
+  }
+  const bool hit = w.acceptable[i] != 0 && w.Lnew[i] > Lmin;
+  double t = w.currentt[i], left = w.left[i], right = w.right[i];
+  uint8_t sl = w.sl[i], sr = w.sr[i];
+  const bool success = update_walker(hit, t, left, right, sl, sr);
+  w.currentt[i] = t;
+  w.left[i] = left;
+  w.right[i] = right;
+  w.sl[i] = sl;
+  w.sr[i] = sr;
+  w.success[i] = success ? 1 : 0;
+  if (!success) return;
+  const long long g0 = w.generation[i];
+  const long long g = g0 + 1;
+  w.generation[i] = g;
+  const double *un = w.unew + (size_t)i * w.d;
+  const double *uo = w.allu + ((size_t)i * w.G + g0) * w.d;
+  double *dst = w.allu + ((size_t)i * w.G + g) * w.d;
+  for (int k = 0; k < w.d; ++k) dst[k] = un[k];
+  w.allL[(size_t)i * w.G + g] = w.Lnew[i];
+  for (int k = 0; k < w.nparams; ++k) w.currentp[(size_t)i * w.nparams + k] = w.pnew[(size_t)i * w.nparams + k];
+  if (ly.kind >= 0) {
+    double acc = 0.0;
+    for (int c = 0; c < w.d; ++c) {
+      double ta, tb;
+      whiten_point(ly, uo, w.d, c, ta);
+      whiten_point(ly, un, w.d, c, tb);
+      const double diff = ta - tb;
+      acc += diff * diff;
+    }
+    w.dist2[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_walk_harvest(WalkState w, long long ring, double r2, double *rec) {
+  __shared__ double part[256][5];
+  double nc = 0, nmov = 0, nsucc = 0, nfar = 0, slog = 0;
+  const double ref = sqrt(r2);
+  for (int i = threadIdx.x; i < w.P; i += 256) {
+    if (!w.movable[i]) continue;
+    nmov += 1;
+    nc += w.acceptable[i] ? 1 : 0;
+    if (w.success[i]) {
+      nsucc += 1;
+      const double d2 = w.dist2[i];
+      if (!isnan(d2)) {
+        nfar += (d2 > r2) ? 1 : 0;
+        slog += log(sqrt(d2) / ref + 1e-10);
+      }
+    }
+  }
+  part[threadIdx.x][0] = nc;
+  part[threadIdx.x][1] = nmov;
+  part[threadIdx.x][2] = nsucc;
+  part[threadIdx.x][3] = nfar;
+  part[threadIdx.x][4] = slog;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+      for (int c = 0; c < 5; ++c) part[threadIdx.x][c] += part[threadIdx.x + off][c];
+    __syncthreads();
+  }
+  const bool found = w.generation[ring] == (long long)(w.G - 1);
+  const size_t row = ((size_t)ring * w.G + (w.G - 1)) * w.d;
+  if (threadIdx.x == 0) {
+    rec[0] = found ? 1.0 : 0.0;
+    rec[1] = found ? w.allL[(size_t)ring * w.G + (w.G - 1)] : qnan();
+    rec[2] = w.left[ring];
+    rec[3] = w.right[ring];
+    for (int c = 0; c < 5; ++c) rec[4 + c] = part[0][c];
+  }
+  if (found) {
+    for (int k = threadIdx.x; k < w.d; k += 256) rec[9 + k] = w.allu[row + k];
+    for (int k = threadIdx.x; k < w.nparams; k += 256) rec[9 + w.d + k] = w.currentp[(size_t)ring * w.nparams + k];
+  }
+  __syncthreads();
+  if (found) {   // popstepsampler.py:678-681
+    for (int e = threadIdx.x; e < w.G * w.d; e += 256) w.allu[(size_t)ring * w.G * w.d + e] = qnan();
+    for (int e = threadIdx.x; e < w.G; e += 256) w.allL[(size_t)ring * w.G + e] = qnan();
+    if (threadIdx.x == 0) {
+      w.generation[ring] = -1;
+      w.currentt[ring] = qnan();
+    }
+  }
+}
+
+// ------------------------------------------------------------------ stateless forms ------------
+__global__ void k_within_unit_cube(const double *u, int n, int d, uint8_t *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool ok = true;
+  for (int k = 0; k < d; ++k) ok = ok && inside_open_unit(u[(size_t)i * d + k]);
+  out[i] = ok ? 1 : 0;
+}
+
+__global__ void k_bisect_draw(const double *left, const double *right, const uint8_t *sl, const uint8_t *sr,
+                              const double *unif, int n, double *currentt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || sl[i] || sr[i]) return;
+  const double range = right[i] - left[i];
+  const double scaled = range * unif[i];
+  currentt[i] = left[i] + scaled;
+}
+
+__global__ void k_evolve_propose(const double *currentu, const double *currentv, const double *left,
+                                 const double *right, const uint8_t *sl, const uint8_t *sr, const double *currentt,
+                                 int n, int d, double *unew) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * d) return;
+  const int i = e / d;
+  const double t = sl[i] ? left[i] : (sr[i] ? right[i] : currentt[i]);
+  const double step = currentv[e] * t;
+  unew[e] = currentu[e] + step;
+}
+
+__global__ void k_evolve_update(const uint8_t *acceptable, const double *Lnew, double Lmin, double *currentt,
+                                double *left, double *right, uint8_t *sl, uint8_t *sr, uint8_t *success, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool hit = acceptable[i] != 0 && Lnew[i] > Lmin;
+  success[i] = update_walker(hit, currentt[i], left[i], right[i], sl[i], sr[i]) ? 1 : 0;
+}
+
+// popstepsampler.py:26-61; nanmax / nanmin semantics
+__global__ void k_line_intersection(const double *origin, const double *direction, int n, int d, double *tleft,
+                                    double *tright) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double lo = qnan(), hi = qnan();
+  for (int k = 0; k < d; ++k) {
+    const double m = 1.0 / direction[(size_t)i * d + k];
+    const double nn = m * (origin[(size_t)i * d + k] - 0.5);
+    const double kk = fabs(m) * 0.5;
+    const double t1 = -nn - kk;
+    const double t2 = -nn + kk;
+    if (!isnan(t1) && (isnan(lo) || t1 > lo)) lo = t1;
+    if (!isnan(t2) && (isnan(hi) || t2 < hi)) hi = t2;
+  }
+  tleft[i] = lo;
+  tright[i] = hi;
+}
+
+// stepfuncs.pyx:537-630 in one workgroup.  Workers are read in order l = 0..popsize-1 and only
+// interact through the point they serve, so the points are processed in parallel (one lane per
+// point walks the worker list in order); the worker list is staged through LDS in tiles.
+__global__ __launch_bounds__(1024) void k_slice_update(const double *t, double *tleft, double *tright,
+                                                       const double *pL, const double *pu, const double *pp,
+                                                       long long *worker_running, long long *status,
+                                                       double threshold, double shrink, double *allu, double *allL,
+                                                       double *allp, int popsize, int d, int nparams,
+                                                       long long *discarded, long long *zlist) {
+  __shared__ double s_t[1024], s_L[1024];
+  __shared__ int s_w[1024];
+  __shared__ unsigned s_scan[1024];
+  __shared__ long long s_disc[1024];
+  __shared__ unsigned s_total;
+  const int tid = threadIdx.x;
+  long long ndisc = 0;
+  for (int w0 = 0; w0 < popsize; w0 += 1024) {   // points w0 .. w0+1023
+    const int w = w0 + tid;
+    double lo = 0, hi = 0;
+    long long st = 1;
+    int taken = -1;
+    if (w < popsize) {
+      lo = tleft[w];
+      hi = tright[w];
+      st = status[w];
+    }
+    for (int l0 = 0; l0 < popsize; l0 += 1024) {
+      __syncthreads();
+      if (l0 + tid < popsize) {
+        s_t[tid] = t[l0 + tid];
+        s_L[tid] = pL[l0 + tid];
+        s_w[tid] = (int)worker_running[l0 + tid];
+      }
+      __syncthreads();
+      const int m = popsize - l0 < 1024 ? popsize - l0 : 1024;
+      if (w < popsize)
+        for (int j = 0; j < m; ++j) {
+          if (s_w[j] != w) continue;
+          const double tl = s_t[j];
+          if (tl > hi || tl < lo) {
+            if (s_L[j] > threshold) ++ndisc;
+            continue;
+          }
+          if (0 < tl && tl < hi) hi = tl / shrink;
+          if (0 > tl && tl > lo) lo = tl / shrink;
+          if (s_L[j] > threshold && st == 0) {
+            st = 1;
+            taken = l0 + j;
+          }
+        }
+    }
+    if (w < popsize) {
+      tleft[w] = lo;
+      tright[w] = hi;
+      status[w] = st;
+      if (taken >= 0) {
+        for (int k = 0; k < d; ++k) allu[(size_t)w * d + k] = pu[(size_t)taken * d + k];
+        allL[w] = pL[taken];
+        for (int k = 0; k < nparams; ++k) allp[(size_t)w * nparams + k] = pp[(size_t)taken * nparams + k];
+      }
+    }
+  }
+  s_disc[tid] = ndisc;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (tid < off) s_disc[tid] += s_disc[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *discarded = s_disc[0];
+    s_total = 0;
+  }
+  __syncthreads();
+  // unfinished points in ascending order, then dealt round-robin to the workers
+  for (int k0 = 0; k0 < popsize; k0 += 1024) {
+    const int k = k0 + tid;
+    const unsigned flag = (k < popsize && status[k] == 0) ? 1u : 0u;
+    s_scan[tid] = flag;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const unsigned v = tid >= off ? s_scan[tid - off] : 0u;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    const unsigned base = s_total;
+    if (flag) zlist[base + s_scan[tid] - 1] = k;
+    __syncthreads();
+    if (tid == 1023) s_total = base + s_scan[1023];
+    __syncthreads();
+  }
+  const unsigned nz = s_total;
+  if (nz > 0)
+    for (int j = tid; j < popsize; j += 1024) worker_running[j] = zlist[j % nz];
+}
+
+__global__ void k_row_dist2(const double *a, const double *b, int n, int d, double *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double acc = 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double diff = a[(size_t)i * d + k] - b[(size_t)i * d + k];
+    acc += diff * diff;
+  }
+  out[i] = acc;
+}
+
+// ------------------------------------------------------------------ launchers -------------------
+static inline dim3 grid_for(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+void launch_walk_reset(const WalkState &w, hipStream_t s) {
+  const long long n = (long long)w.P * w.G * w.d;
+  hipLaunchKernelGGL(k_walk_reset, grid_for(n), dim3(256), 0, s, w);
+}
+
+void launch_walk_step_back(const WalkState &w, double Lmin, long long *gmax_scratch, uint8_t *flags, hipStream_t s) {
+  hipLaunchKernelGGL(k_max_generation, dim3(1), dim3(256), 0, s, w.generation, w.P, gmax_scratch);
+  hipLaunchKernelGGL(k_step_back, grid_for(w.P), dim3(256), 0, s, Lmin, w.allL, w.P, w.G, w.generation, w.currentt,
+                     gmax_scratch, w.sl, w.sr, flags);
+}
+
+void launch_walk_start(const WalkState &w, const long long *idx, int n, const double *rows, const double *L,
+                       hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_walk_start, grid_for((long long)n * w.d), dim3(256), 0, s, w, idx, n, rows, L);
+}
+
+void launch_walk_points(const WalkState &w, const long long *idx, int n, double *out, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_walk_points, grid_for((long long)n * w.d), dim3(256), 0, s, w, idx, n, out);
+}
+
+void launch_walk_brackets(const WalkState &w, const long long *idx, int n, double scale, const double *v_rows,
+                          hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_walk_brackets, grid_for((long long)n * w.d), dim3(256), 0, s, w, idx, n, scale, v_rows);
+}
+
+void launch_walk_brackets_philox(const WalkState &w, double scale, int kind, double dirscale, WalkDirData dd,
+                                 unsigned long long seed, unsigned long long offset, hipStream_t s) {
+  hipLaunchKernelGGL(k_walk_brackets_philox, grid_for(w.P, 64), dim3(64), 0, s, w, scale, kind, dirscale, dd, seed,
+                     offset);
+}
+
+void launch_walk_propose(const WalkState &w, const double *unif, unsigned long long seed, unsigned long long offset,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(k_walk_propose, grid_for(w.P, 64), dim3(64), 0, s, w, unif, seed, offset);
+}
+
+void launch_walk_transform(const WalkState &w, int tkind, double a, double b, hipStream_t s) {
+  hipLaunchKernelGGL(k_walk_transform, grid_for((long long)w.P * w.d), dim3(256), 0, s, w, tkind, a, b);
+}
+
+void launch_walk_expand(const WalkState &w, const unsigned *blk, const double *pc, const double *Lc, hipStream_t s) {
+  hipLaunchKernelGGL(k_walk_expand, grid_for(w.P), dim3(256), 0, s, w, blk, pc, Lc);
+}
+
+void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStream_t s) {
+  hipLaunchKernelGGL(k_walk_update, grid_for(w.P, 64), dim3(64), 0, s, w, Lmin, layer);
+}
+
+void launch_walk_harvest(const WalkState &w, long long ring, double r2, double *rec, hipStream_t s) {
+  hipLaunchKernelGGL(k_walk_harvest, dim3(1), dim3(256), 0, s, w, ring, r2, rec);
+}
+
+void launch_within_unit_cube(const double *u, int n, int d, uint8_t *out, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_within_unit_cube, grid_for(n), dim3(256), 0, s, u, n, d, out);
+}
+
+void launch_evolve_propose(const double *currentu, const double *currentv, const double *left, const double *right,
+                           const uint8_t *sl, const uint8_t *sr, const double *currentt, int n, int d, double *unew,
+                           hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_evolve_propose, grid_for((long long)n * d), dim3(256), 0, s, currentu, currentv, left, right,
+                     sl, sr, currentt, n, d, unew);
+}
+
+void launch_bisect_draw(const double *left, const double *right, const uint8_t *sl, const uint8_t *sr,
+                        const double *unif_full, int n, double *currentt, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_bisect_draw, grid_for(n), dim3(256), 0, s, left, right, sl, sr, unif_full, n, currentt);
+}
+
+void launch_evolve_update(const uint8_t *acceptable, const double *Lnew_full, double Lmin, double *currentt,
+                          double *left, double *right, uint8_t *sl, uint8_t *sr, uint8_t *success, int n,
+                          hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_evolve_update, grid_for(n), dim3(256), 0, s, acceptable, Lnew_full, Lmin, currentt, left,
+                     right, sl, sr, success, n);
+}
+
+void launch_step_back(double Lmin, double *allL, int n, int G, long long *generation, double *currentt,
+                      long long *gmax_scratch, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_max_generation, dim3(1), dim3(256), 0, s, generation, n, gmax_scratch);
+  hipLaunchKernelGGL(k_step_back, grid_for(n), dim3(256), 0, s, Lmin, allL, n, G, generation, currentt, gmax_scratch,
+                     (const uint8_t *)nullptr, (const uint8_t *)nullptr, (uint8_t *)nullptr);
+}
+
+void launch_line_intersection(const double *origin, const double *direction, int n, int d, double *tleft,
+                              double *tright, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_line_intersection, grid_for(n), dim3(256), 0, s, origin, direction, n, d, tleft, tright);
+}
+
+void launch_slice_update(const double *t, double *tleft, double *tright, const double *pL, const double *pu,
+                         const double *pp, long long *worker_running, long long *status, double threshold,
+                         double shrink, double *allu, double *allL, double *allp, int popsize, int d, int nparams,
+                         long long *discarded, hipStream_t s) {
+  if (popsize <= 0) return;
+  // zlist: the caller provides popsize int64 after `discarded`
+  hipLaunchKernelGGL(k_slice_update, dim3(1), dim3(1024), 0, s, t, tleft, tright, pL, pu, pp, worker_running, status,
+                     threshold, shrink, allu, allL, allp, popsize, d, nparams, discarded, discarded + 1);
+}
+
+void launch_row_dist2(const double *a, const double *b, int n, int d, double *out, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_row_dist2, grid_for(n), dim3(256), 0, s, a, b, n, d, out);
+}
+
+}  // namespace mlf

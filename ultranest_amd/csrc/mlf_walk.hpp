@@ -1,0 +1,105 @@
+// mlf_walk.hpp -- population step-sampler state machine on the device (mlf_walk.hip).
+// reference ultranest/stepfuncs.pyx (evolve :189-282, evolve_update :99-183,
+// step_back :285-334, direction generators :348-533, update_vectorised_slice_sampler :537-630)
+// and ultranest/popstepsampler.py (unitcube_line_intersection :26-61, diagnose_move_distances
+// :64-94, PopulationSliceSampler :347-697).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mlf {
+
+// Device-resident state of one walker population (PopulationSliceSampler attributes of the same
+// names, reference popstepsampler.py:383-437).  P walkers, G = nsteps + 1 chain slots, d dims.
+struct WalkState {
+  int P, G, d, nparams;
+  double *allu;            // [P][G][d]
+  double *allL;            // [P][G]
+  long long *generation;   // [P]   -1 = not started
+  double *currentt;        // [P]   NaN = bracket undefined
+  double *currentv;        // [P][d]
+  double *left, *right;    // [P]
+  uint8_t *sl, *sr;        // [P]   searching_left / searching_right
+  double *currentp;        // [P][nparams]
+  // per-step scratch
+  double *unew;            // [P][d]
+  uint8_t *movable;        // [P]   generation < nsteps at propose time
+  uint8_t *acceptable;     // [P]
+  uint8_t *success;        // [P]
+  double *pnew;            // [P][nparams]   (full size; host results are expanded into it)
+  double *Lnew;            // [P]
+  double *dist2;           // [P]   t-space move distance^2 of successful walkers, NaN otherwise
+};
+
+// layer description for the move diagnostics (T1 of the region path)
+struct WalkLayer {
+  int kind;                // 0 affine (ctr, T row-major d x d), 1 scaling (mean, std), -1 none
+  const double *ctr;
+  const double *mat;
+  const double *wrap;      // (1 - cut) per wrapped axis, NaN elsewhere; nullptr = no wraps
+  double r2;               // maxradiussq
+};
+
+// direction generators on the device (Philox); kinds follow the reference functions
+enum WalkDirection {
+  DIR_CUBE_ORIENTED = 0,          // stepfuncs.pyx:348-370
+  DIR_CUBE_ORIENTED_SCALED = 1,   // :373-399
+  DIR_RANDOM = 2,                 // :401-422
+  DIR_REGION_ORIENTED = 3,        // :425-450
+  DIR_REGION_RANDOM = 4,          // :453-478
+  DIR_DIFFERENTIAL = 5,           // :480-508
+  DIR_MIXTURE = 6                 // :512-535
+};
+
+struct WalkDirData {
+  const double *axes;      // transformLayer.axes, d x d row-major (kinds 3, 4, 6)
+  const double *live;      // region.u, nlive x d (kinds 5, 6)
+  int nlive;
+  const double *std;       // region.u.std(axis=0) (kind 1)
+};
+
+void launch_walk_reset(const WalkState &w, hipStream_t s);
+// step_back + snapshot: flags[i] = bit0 !isfinite(currentt) | bit1 searching_left | bit2 searching_right
+void launch_walk_step_back(const WalkState &w, double Lmin, long long *gmax_scratch, uint8_t *flags, hipStream_t s);
+void launch_walk_start(const WalkState &w, const long long *idx, int n, const double *rows, const double *L,
+                       hipStream_t s);
+void launch_walk_points(const WalkState &w, const long long *idx, int n, double *out, hipStream_t s);
+void launch_walk_brackets(const WalkState &w, const long long *idx, int n, double scale, const double *v_rows,
+                          hipStream_t s);
+void launch_walk_brackets_philox(const WalkState &w, double scale, int kind, double dirscale, WalkDirData dd,
+                                 unsigned long long seed, unsigned long long offset, hipStream_t s);
+// unif: one U[0,1) per walker (host stream) or nullptr -> Philox(seed, offset + walker)
+void launch_walk_propose(const WalkState &w, const double *unif, unsigned long long seed,
+                         unsigned long long offset, hipStream_t s);
+// p = transform(unew) for every walker: tkind 0 identity, 1 x*a + b, 2 (x*a)*b
+void launch_walk_transform(const WalkState &w, int tkind, double a, double b, hipStream_t s);
+// host likelihood: compacted (pnew, Lnew) of the acceptable walkers -> full-size arrays
+void launch_walk_expand(const WalkState &w, const unsigned *blk, const double *pc, const double *Lc,
+                        hipStream_t s);
+void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStream_t s);
+// rec: [0] harvested flag, [1] L, [2] left, [3] right, [4] nc, [5] nmovable, [6] nsuccess, [7] nfar,
+//      [8] sum log(dist/ref + 1e-10), [9 ..] u (d) then p (nparams)
+void launch_walk_harvest(const WalkState &w, long long ring, double r2, double *rec, hipStream_t s);
+
+// ---- stateless forms on device arrays (the parity boundary of ultranest.stepfuncs) -------------
+void launch_within_unit_cube(const double *u, int n, int d, uint8_t *out, hipStream_t s);
+void launch_evolve_propose(const double *currentu, const double *currentv, const double *left,
+                           const double *right, const uint8_t *sl, const uint8_t *sr, const double *currentt,
+                           int n, int d, double *unew, hipStream_t s);
+void launch_bisect_draw(const double *left, const double *right, const uint8_t *sl, const uint8_t *sr,
+                        const double *unif_full, int n, double *currentt, hipStream_t s);
+void launch_evolve_update(const uint8_t *acceptable, const double *Lnew_full, double Lmin, double *currentt,
+                          double *left, double *right, uint8_t *sl, uint8_t *sr, uint8_t *success, int n,
+                          hipStream_t s);
+void launch_step_back(double Lmin, double *allL, int n, int G, long long *generation, double *currentt,
+                      long long *gmax_scratch, hipStream_t s);
+void launch_line_intersection(const double *origin, const double *direction, int n, int d, double *tleft,
+                              double *tright, hipStream_t s);
+void launch_slice_update(const double *t, double *tleft, double *tright, const double *pL, const double *pu,
+                         const double *pp, long long *worker_running, long long *status, double threshold,
+                         double shrink, double *allu, double *allL, double *allp, int popsize, int d, int nparams,
+                         long long *discarded, hipStream_t s);
+void launch_row_dist2(const double *a, const double *b, int n, int d, double *out, hipStream_t s);
+
+}  // namespace mlf

@@ -142,8 +142,12 @@ class StaticNestedSampler(object):
 
     def __init__(self, x_dim, loglike, transform=None, num_live_points=400, ndraw=4096,
                  region_class=MLFriends, transform_layer_class=LocalAffineLayer, nbootstraps=30, seed=1,
-                 device_rng=None):
+                 device_rng=None, stepsampler=None):
         self.x_dim = x_dim
+        # optional population step sampler (ultranest_amd.popstepsampler): replaces region
+        # rejection sampling by its __next__, called like the reference's driver does
+        # (integrator.py:1839-1950)
+        self.stepsampler = stepsampler
         # optional regions.DeviceRNG: proposals are then drawn, tested and compacted on the GPU
         self.device_rng = device_rng
         self.loglike = loglike
@@ -173,6 +177,8 @@ class StaticNestedSampler(object):
             if logvol <= next_update_logvol:
                 self.updater.update(u, nbootstraps=self.nbootstraps, minvol=np.exp(logvol))
                 next_update_logvol = logvol + np.log(0.8)
+                if self.stepsampler is not None:
+                    self.stepsampler.region_changed(logl, self.updater.region)
             region = self.updater.region
             region.device_rng = self.device_rng
             worst = int(np.argmin(logl))
@@ -187,7 +193,13 @@ class StaticNestedSampler(object):
             if np.logaddexp(logz, logz_remain) - logz < dlogz and it > N:
                 break
             # a replacement above Lmin from the region
-            while True:
+            while self.stepsampler is not None:
+                newu, _, newl, nc = self.stepsampler.__next__(region, Lmin, region.u, logl, self.transform,
+                                                               self.loglike)
+                self.ncall += nc
+                if newu is not None:
+                    break
+            while self.stepsampler is None:
                 keep = pending_l > Lmin
                 pending_u, pending_l = pending_u[keep], pending_l[keep]
                 if len(pending_l):

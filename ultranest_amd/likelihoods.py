@@ -38,6 +38,11 @@ class GaussLikelihood(object):
         width = max(0, 1 - 5 * sigma)
         return cls((np.sin(np.arange(ndim) / 2.) * width + 1.) / 2., sigma, ndim)
 
+    @property
+    def device_spec(self):
+        """(kind, aux, sigma) of mlf_loglike_dev: lets device-resident callers evaluate in place"""
+        return 0, self.centers, self.sigma
+
     def __call__(self, theta):
         p = _batch(theta)
         if p.shape[1] != self.ndim:
@@ -79,3 +84,18 @@ def rosenbrock_loglike(theta):
 def rosenbrock_transform(u):
     """``u * 20 - 10``"""
     return np.asarray(u) * 20 - 10
+
+
+def identity_transform(u):
+    """``p = u``"""
+    return np.array(u, dtype=float)
+
+
+# (kind, aux, sigma) of mlf_loglike_dev and (tkind, a, b) of mlf_walkers_finish_dev: samplers that
+# keep their points on the device (ultranest_amd.popstepsampler) evaluate these in place
+eggbox_loglike.device_spec = (1, None, 0.0)
+eggbox2_loglike.device_spec = (2, None, 0.0)
+rosenbrock_loglike.device_spec = (3, None, 0.0)
+identity_transform.device_spec = (0, 0.0, 0.0)
+eggbox_transform.device_spec = (2, 10.0, np.pi)       # (x * 10) * pi
+rosenbrock_transform.device_spec = (1, 20.0, -10.0)   # x * 20 - 10

@@ -1,0 +1,539 @@
+"""Vectorized population step samplers with the API of the reference's
+``ultranest.popstepsampler`` (reference ultranest/popstepsampler.py), built on the device-resident
+walker state machine (csrc/mlf_walk.hip).
+
+``PopulationSliceSampler`` is the stepsampler object the reference's driver calls once per
+iteration (``sampler.stepsampler = PopulationSliceSampler(...)``; integrator.py:1839-1950 calls
+``__next__(region, Lmin, us, Ls, transform, loglike, ...)`` until it returns a point).  Here the
+whole population -- chain history ``allu/allL``, slice coordinate, direction, brackets, flags,
+transformed point -- lives in HBM; one call uploads only what the host decided (start rows,
+directions or random numbers) and downloads one small record.
+
+Two random sources:
+  * default: the reference's ``np.random`` stream, drawn on the host in the reference's order
+    (start picks, directions, one uniform per bisecting walker).  A seeded run then returns the
+    same points as the reference, call by call (tests/test_popstepsampler.py).
+  * ``device_rng=DeviceRNG(seed)``: directions and bisection draws come from Philox on the
+    device (nothing but the start rows is uploaded); statistically equivalent, not draw-identical.
+
+Likelihood: any ``loglike(p) -> L`` / ``transform(u) -> p`` numpy callbacks (the accepted
+proposals then make one round trip), or the device likelihoods of ``ultranest_amd.likelihoods``
+(objects with ``device_spec``), which are evaluated in place on the device.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f64, ptr
+from .regions import DeviceRNG
+from .stepfuncs import (evolve, generate_cube_oriented_direction,  # noqa: F401
+                        generate_cube_oriented_direction_scaled, generate_differential_direction,
+                        generate_mixture_random_direction, generate_random_direction,
+                        generate_region_oriented_direction, generate_region_random_direction, int_dtype,
+                        row_dist2, step_back, unitcube_line_intersection, update_vectorised_slice_sampler)
+
+
+def diagnose_move_distances(region, ustart, ufinal):
+    """Whitened-space distance travelled by each walker against the MLFriends radius
+    (reference popstepsampler.py:64-94): ``(far_enough, [distance, radius])``."""
+    assert ustart.shape == ufinal.shape, (ustart.shape, ufinal.shape)
+    tstart = region.transformLayer.transform(ustart)
+    tfinal = region.transformLayer.transform(ufinal)
+    d2 = row_dist2(tstart, tfinal) if len(tstart) else np.empty(0)
+    return d2 > region.maxradiussq, [d2**0.5, region.maxradiussq**0.5]
+
+
+def slice_limit_to_unitcube(tleft, tright):
+    """Slice limits = intersection with the unit cube (reference popstepsampler.py:700-722)."""
+    return np.array(tleft, dtype=float), np.array(tright, dtype=float)
+
+
+def slice_limit_to_scale(tleft, tright):
+    """Slice limits clipped to [-1, +1] (reference popstepsampler.py:725-744)."""
+    tleft, tright = np.asarray(tleft, dtype=float), np.asarray(tright, dtype=float)
+    return np.fmax(tleft, -1.0), np.fmin(tright, 1.0)
+
+
+class GenericPopulationSampler(object):
+    """Step statistics shared by the population samplers (reference popstepsampler.py:97-194;
+    the matplotlib plots of the reference are outside this package's scope)."""
+
+    logstat_labels = ['accept_rate', 'efficiency', 'scale', 'far_enough', 'mean_rel_jump']
+
+    @property
+    def mean_jump_distance(self):
+        """Geometric mean jump distance, weighted by acceptance rate."""
+        if len(self.logstat) == 0:
+            return np.nan
+        return np.exp(np.average(np.log([row[-1] + 1e-10 for row in self.logstat]),
+                                 weights=[row[0] for row in self.logstat]))
+
+    @property
+    def far_enough_fraction(self):
+        """Fraction of jumps exceeding the MLFriends radius."""
+        if len(self.logstat) == 0:
+            return np.nan
+        return np.average([row[-2] for row in self.logstat], weights=[row[0] for row in self.logstat])
+
+    def get_info_dict(self):
+        have = len(self.logstat) > 0
+        col = lambda i: np.nanmean([row[i] for row in self.logstat]) if have else np.nan  # noqa: E731
+        return dict(num_logs=len(self.logstat), rejection_rate=1 - col(0), mean_scale=col(1), mean_nsteps=col(2),
+                    mean_distance=self.mean_jump_distance, frac_far_enough=self.far_enough_fraction,
+                    last_logstat=dict(zip(self.logstat_labels,
+                                          self.logstat[-1] if len(self.logstat) > 1 else [np.nan] * 5)))
+
+    def print_diagnostic(self):
+        if len(self.logstat) == 0:
+            print("diagnostic unavailable, no recorded steps found")
+            return
+        frac = self.far_enough_fraction
+        if frac < 0.5:
+            advice = ': very fishy. Double nsteps and see if fraction and lnZ change)'
+        elif frac < 0.66:
+            advice = ': fishy. Double nsteps and see if fraction and lnZ change)'
+        else:
+            advice = ' (should be >50%)'
+        print('step sampler diagnostic: jump distance %.2f (should be >1), far enough fraction: %.2f%% %s' % (
+            self.mean_jump_distance, frac * 100, advice))
+
+    def region_changed(self, Ls, region):
+        pass
+
+
+class _Walkers(object):
+    """Owner of one ``mlf_walkers`` handle (include/mlfriends_hip.h)."""
+
+    def __init__(self, popsize, nsteps, ndim):
+        self.popsize, self.nsteps, self.ndim = int(popsize), int(nsteps), int(ndim)
+        handle = ctypes.c_void_p()
+        check(_lib.lib().mlf_walkers_create(ctypes.byref(handle), self.popsize, self.nsteps, self.ndim))
+        self._h = handle
+        self.nparams = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().mlf_walkers_destroy(h)
+            except Exception:
+                pass
+
+    def begin(self, Lmin):
+        generation = np.empty(self.popsize, dtype=np.int64)
+        flags = np.empty(self.popsize, dtype=np.uint8)
+        check(_lib.lib().mlf_walkers_begin(self._h, float(Lmin), ptr(generation), ptr(flags)))
+        return generation, flags
+
+    def start(self, idx, rows, L):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        check(_lib.lib().mlf_walkers_start(self._h, ptr(idx), len(idx), ptr(f64(rows)), ptr(f64(L))))
+
+    def points(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        out = np.empty((len(idx), self.ndim))
+        check(_lib.lib().mlf_walkers_points(self._h, ptr(idx), len(idx), ptr(out)))
+        return out
+
+    def brackets(self, idx, scale, v):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        v = f64(v)
+        if v.shape != (len(idx), self.ndim):
+            raise ValueError("generate_direction returned shape %s, expected %s" % (v.shape, (len(idx), self.ndim)))
+        check(_lib.lib().mlf_walkers_brackets(self._h, ptr(idx), len(idx), float(scale), ptr(v)))
+
+    def set_direction_data(self, axes=None, live=None, std=None):
+        live = None if live is None else f64(live)
+        check(_lib.lib().mlf_walkers_set_direction_data(
+            self._h, ptr(None if axes is None else f64(axes)), ptr(live), 0 if live is None else len(live),
+            ptr(None if std is None else f64(std))))
+
+    def brackets_philox(self, scale, kind, dirscale, rng):
+        nxt = ctypes.c_uint64(0)
+        check(_lib.lib().mlf_walkers_brackets_philox(self._h, float(scale), int(kind), float(dirscale),
+                                                     ctypes.c_uint64(rng.seed), ctypes.c_uint64(rng.offset),
+                                                     ctypes.byref(nxt)))
+        rng.offset = nxt.value
+
+    def set_layer(self, kind, ctr, mat, wrap, maxradiussq):
+        check(_lib.lib().mlf_walkers_set_layer(self._h, int(kind), ptr(None if ctr is None else f64(ctr)),
+                                               ptr(None if mat is None else f64(mat)),
+                                               ptr(None if wrap is None else f64(wrap)), float(maxradiussq)))
+
+    def propose(self, unif=None, rng=None, fetch=True):
+        """unif: one U[0,1) per walker (host stream) or None with rng = DeviceRNG.  Returns the
+        acceptable proposals (walker order) when fetch, else None."""
+        seed, offset = (rng.seed, rng.offset) if rng is not None else (0, 0)
+        if rng is not None:
+            rng.offset += self.popsize
+        unif = None if unif is None else f64(unif)
+        if not fetch:
+            check(_lib.lib().mlf_walkers_propose(self._h, ptr(unif), ctypes.c_uint64(seed), ctypes.c_uint64(offset),
+                                                 None, None))
+            return None
+        out = np.empty((self.popsize, self.ndim))
+        nacc = ctypes.c_size_t(0)
+        check(_lib.lib().mlf_walkers_propose(self._h, ptr(unif), ctypes.c_uint64(seed), ctypes.c_uint64(offset),
+                                             ptr(out), ctypes.byref(nacc)))
+        return out[:nacc.value]
+
+    def _record(self, rec, nparams):
+        d = self.ndim
+        return dict(found=rec[0] == 1.0, L=rec[1], left=rec[2], right=rec[3], nc=int(rec[4]), nmovable=int(rec[5]),
+                    nsuccess=int(rec[6]), nfar=rec[7], sumlog=rec[8], u=rec[9:9 + d].copy(),
+                    p=rec[9 + d:9 + d + nparams].copy())
+
+    def finish(self, Lmin, pnew, Lnew, ringindex):
+        pnew, Lnew = f64(pnew), f64(Lnew)
+        nacc = len(Lnew)
+        if nacc:
+            if pnew.ndim != 2 or pnew.shape[0] != nacc:
+                raise ValueError("transform must return one row per proposed point")
+            self.nparams = pnew.shape[1]
+        elif self.nparams is None:
+            self.nparams = self.ndim
+        rec = np.empty(9 + self.ndim + self.nparams)
+        check(_lib.lib().mlf_walkers_finish(self._h, float(Lmin), ptr(pnew), ptr(Lnew), nacc, self.nparams,
+                                            int(ringindex), ptr(rec)))
+        return self._record(rec, self.nparams)
+
+    def finish_dev(self, Lmin, tspec, lspec, ringindex):
+        self.nparams = self.ndim
+        tkind, ta, tb = tspec
+        lkind, aux, sigma = lspec
+        rec = np.empty(9 + 2 * self.ndim)
+        check(_lib.lib().mlf_walkers_finish_dev(self._h, float(Lmin), int(tkind), float(ta), float(tb), int(lkind),
+                                                ptr(None if aux is None else f64(aux)), float(sigma),
+                                                int(ringindex), ptr(rec)))
+        return self._record(rec, self.ndim)
+
+    def export(self):
+        """Host copies of the resident state (tests, debugging)."""
+        P, G, d = self.popsize, self.nsteps + 1, self.ndim
+        s = dict(allu=np.empty((P, G, d)), allL=np.empty((P, G)), generation=np.empty(P, dtype=np.int64),
+                 currentt=np.empty(P), currentv=np.empty((P, d)), current_left=np.empty(P), current_right=np.empty(P),
+                 searching_left=np.empty(P, dtype=np.uint8), searching_right=np.empty(P, dtype=np.uint8))
+        check(_lib.lib().mlf_walkers_export(self._h, ptr(s["allu"]), ptr(s["allL"]), ptr(s["generation"]),
+                                            ptr(s["currentt"]), ptr(s["currentv"]), ptr(s["current_left"]),
+                                            ptr(s["current_right"]), ptr(s["searching_left"]),
+                                            ptr(s["searching_right"])))
+        s["searching_left"] = s["searching_left"].view(np.bool_)
+        s["searching_right"] = s["searching_right"].view(np.bool_)
+        return s
+
+
+class PopulationSliceSampler(GenericPopulationSampler):
+    """Vectorized slice/HARM sampler over a device-resident walker population
+    (reference popstepsampler.py:347-697; same constructor and ``__next__`` contract)."""
+
+    def __init__(self, popsize, nsteps, generate_direction, scale=1.0, scale_adapt_factor=0.9, log=False,
+                 logfile=None, device_rng=None):
+        self.nsteps = nsteps
+        self.nrejects = 0
+        self.scale = scale
+        self.scale_adapt_factor = scale_adapt_factor
+        self.ringindex = 0
+        self.log = log
+        self.logfile = logfile
+        self.logstat = []
+        self.popsize = popsize
+        self.generate_direction = generate_direction
+        if device_rng is not None and not isinstance(device_rng, DeviceRNG):
+            raise TypeError("device_rng must be an ultranest_amd.regions.DeviceRNG")
+        self.device_rng = device_rng
+        self._walkers = None
+        self._generation = np.zeros(popsize, dtype=int_dtype) - 1
+        self._flags = np.ones(popsize, dtype=np.uint8)
+        self._seen = dict(region=None, layer=None, r2=None, calls=0)
+
+    def __str__(self):
+        return 'PopulationSliceSampler(popsize=%d, nsteps=%d, generate_direction=%s, scale=%.g)' % (
+            self.popsize, self.nsteps, self.generate_direction, self.scale)
+
+    # ---- introspection (host copies) -------------------------------------------------------
+    @property
+    def generation(self):
+        return self._generation
+
+    @property
+    def status(self):
+        """Compact string of the walker states after the last call (reference :472-481)."""
+        gen = 'G:' + ''.join(['%d' % g if g >= 0 else '_' for g in self._generation])
+        st = 'S:' + ''.join(['S' if f & 1 else 'L' if f & 2 else 'R' if f & 4 else 'B' for f in self._flags])
+        return gen + '  ' + st
+
+    def state(self):
+        """dict of host copies of allu, allL, generation, currentt, currentv, brackets, flags."""
+        if self._walkers is None:
+            raise RuntimeError("the sampler has not been called yet")
+        return self._walkers.export()
+
+    def region_changed(self, Ls, region):
+        """The driver rebuilt the region: refresh the device copies derived from it."""
+        self._seen["region"] = None
+        if self.logfile:
+            self.logfile.write("region-update\t%g\t%g\n" % (self.scale, region.u.std(axis=1).mean()))
+
+    def shift(self):
+        """Advance the ring index of the walker harvested next (reference :605-609)."""
+        self.ringindex = (self.ringindex + 1) % self.popsize
+
+    # ---- device copies of what the region contributes -----------------------------------------
+    def _sync_region(self, region):
+        w, seen = self._walkers, self._seen
+        layer = region.transformLayer
+        r2 = region.maxradiussq
+        if seen["region"] is not region or seen["layer"] is not layer or seen["r2"] != r2:
+            ndim = self._walkers.ndim
+            try:
+                kind, ctr, mat = layer.device_params(ndim)
+                wrap = layer.wrap_shift_vector(ndim)
+            except AttributeError:      # a foreign layer object: whiten through its numpy attributes
+                kind, ctr, mat, wrap = 0, np.broadcast_to(layer.ctr, (ndim,)), layer.T, None
+            if r2 is None:
+                w.set_layer(-1, None, None, None, 1.0)
+            else:
+                w.set_layer(kind, ctr, mat, wrap, r2)
+            seen.update(layer=layer, r2=r2)
+        kind = getattr(self.generate_direction, "device_kind", None)
+        if self.device_rng is not None and kind is not None:
+            fresh = seen["region"] is not region
+            if kind in (3, 4, 6) and fresh:
+                w.set_direction_data(axes=region.transformLayer.axes)
+            if kind == 1 and (fresh or seen["calls"] % 32 == 0):
+                w.set_direction_data(std=region.u.std(axis=0))
+            if kind in (5, 6) and (fresh or region.u.size <= 32768 or seen["calls"] % 32 == 0):
+                w.set_direction_data(live=region.u)
+        seen["region"] = region
+        seen["calls"] += 1
+
+    # ---- one sampler step ------------------------------------------------------------------------
+    def __next__(self, region, Lmin, us, Ls, transform, loglike, ndraw=10, plot=False, tregion=None, log=False):
+        """Advance every walker by one likelihood evaluation; return ``(u, p, L, nc)`` of the
+        next finished walker, or ``(None, None, None, nc)`` (reference :610-697)."""
+        nlive, ndim = us.shape
+        if self._walkers is None:
+            self._walkers = _Walkers(self.popsize, self.nsteps, ndim)
+        w = self._walkers
+        self._sync_region(region)
+
+        # step_back on the device; the host learns which walkers need what
+        generation, flags = w.begin(Lmin)
+        starting = generation < 0
+        if starting.any():
+            above = np.flatnonzero(Ls > Lmin)
+            pick = above[np.random.randint(len(above), size=int(starting.sum()))]
+            if not starting.all():
+                while starting[self.ringindex]:
+                    self.shift()
+            w.start(np.flatnonzero(starting), us[pick], Ls[pick])
+            generation[starting] = 0
+        assert (generation >= 0).all(), generation
+
+        undefined = (flags & 1).astype(bool)            # bracket undefined: new slice
+        device_kind = getattr(self.generate_direction, "device_kind", None)
+        on_device = self.device_rng is not None and device_kind is not None
+        if undefined.any():
+            if on_device:
+                w.brackets_philox(self.scale, device_kind, 1.0, self.device_rng)
+            else:
+                idx = np.flatnonzero(undefined)
+                if getattr(self.generate_direction, "needs_points", True):
+                    start_points = w.points(idx)
+                else:
+                    start_points = np.zeros((len(idx), ndim))
+                w.brackets(idx, self.scale, self.generate_direction(start_points, region))
+
+        movable = generation < self.nsteps
+        stepping = np.logical_and((flags & 6) != 0, ~undefined)
+        bisecting = np.logical_and(movable, ~np.logical_or(stepping, undefined))
+        tspec, lspec = getattr(transform, "device_spec", None), getattr(loglike, "device_spec", None)
+        resident_likelihood = tspec is not None and lspec is not None
+        if self.device_rng is not None:
+            unif, rng = None, self.device_rng
+        else:
+            unif, rng = np.zeros(self.popsize), None
+            unif[bisecting] = np.random.random_sample(int(bisecting.sum()))
+        if resident_likelihood:
+            w.propose(unif, rng, fetch=False)
+            rec = w.finish_dev(Lmin, tspec, lspec, self.ringindex)
+        else:
+            unew = w.propose(unif, rng, fetch=True)
+            if len(unew):
+                pnew = transform(unew)
+                Lnew = loglike(pnew)
+            else:
+                pnew, Lnew = np.empty((0, w.nparams or ndim)), np.empty(0)
+            rec = w.finish(Lmin, pnew, Lnew, self.ringindex)
+        nc = rec["nc"]
+
+        if rec["nsuccess"] > 0:
+            ns = rec["nsuccess"]
+            have_diag = region.maxradiussq is not None
+            self.logstat.append([ns / max(rec["nmovable"], 1), self.scale, self.nsteps,
+                                 rec["nfar"] / ns if have_diag else 0, np.exp(rec["sumlog"] / ns) if have_diag else 0])
+            if self.logfile:
+                self.logfile.write("rescale\t%.4f\t%.4f\t%g\t%.4f%g\n" % tuple(self.logstat[-1]))
+
+        self._generation, self._flags = generation, flags
+        if rec["found"]:
+            u, p, L = rec["u"], rec["p"], rec["L"]
+            assert np.isfinite(u).all(), u
+            assert np.isfinite(p).all(), p
+            newscale = (rec["right"] - rec["left"]) / 2
+            self.scale = self.scale * 0.9 + 0.1 * newscale
+            self.shift()
+            return u, p, L, nc
+        return None, None, None, nc
+
+
+class PopulationRandomWalkSampler(GenericPopulationSampler):
+    """Vectorized Gaussian random walk (reference popstepsampler.py:197-344): `nsteps` truncated
+    normal steps along `generate_direction` for `popsize` walkers, adapting the step scale to a
+    23.4 % acceptance rate.  Host numpy around the unit-cube intersection kernel."""
+
+    def __init__(self, popsize, nsteps, generate_direction, scale, scale_adapt_factor=0.9, scale_min=1e-20,
+                 scale_max=20, log=False, logfile=None):
+        assert scale_adapt_factor <= 1
+        self.nsteps, self.popsize = nsteps, popsize
+        self.nrejects, self.ncalls = 0, 0
+        self.scale, self.scale_adapt_factor = scale, scale_adapt_factor
+        self.scale_min, self.scale_max = scale_min, scale_max
+        self.log, self.logfile = log, logfile
+        self.logstat = []
+        self.prepared_samples = []
+        self.generate_direction = generate_direction
+
+    def __str__(self):
+        return 'PopulationRandomWalkSampler(popsize=%d, nsteps=%d, generate_direction=%s, scale=%.g)' % (
+            self.popsize, self.nsteps, self.generate_direction, self.scale)
+
+    def __next__(self, region, Lmin, us, Ls, transform, loglike, ndraw=10, plot=False, tregion=None, log=False):
+        import scipy.stats
+        nlive, ndim = us.shape
+        nc = 0
+        if len(self.prepared_samples) == 0:
+            ilive = np.random.randint(0, nlive, size=self.popsize)
+            allu, allp, allL = us[ilive, :], None, Ls[ilive]
+            nc = self.nsteps * self.popsize
+            target_rejects = self.nsteps * self.popsize * (1 - 0.234)
+            nrejects_expected = self.nrejects + target_rejects
+            for _ in range(self.nsteps):
+                v = self.generate_direction(allu, region, self.scale)
+                tleft, tright = unitcube_line_intersection(allu, v)
+                step = scipy.stats.truncnorm.rvs(tleft, tright, loc=0, scale=1).reshape((-1, 1))
+                proposed_u = allu + v * step
+                outside = ~np.logical_and(proposed_u > 0, proposed_u < 1).all(axis=1)
+                assert not outside.any(), proposed_u[outside, :]
+                proposed_p = transform(proposed_u)
+                proposed_L = loglike(proposed_p)
+                accept = proposed_L > Lmin
+                self.nrejects += (~accept).sum()
+                allu[accept, :] = proposed_u[accept, :]
+                if allp is None:
+                    allp = proposed_p * np.nan
+                allp[accept, :] = proposed_p[accept, :]
+                allL[accept] = proposed_L[accept]
+            assert np.isfinite(allp).all(), 'some walkers never moved! Double nsteps of PopulationRandomWalkSampler.'
+            far_enough, (move_distance, reference_distance) = diagnose_move_distances(
+                region, us[ilive[accept], :], allu[accept, :])
+            self.prepared_samples = list(zip(allu, allp, allL))
+            self.logstat.append([
+                accept.mean(),
+                1 - (self.nrejects - (nrejects_expected - target_rejects)) / (self.nsteps * self.popsize),
+                self.scale, self.nsteps, np.mean(far_enough),
+                np.exp(np.mean(np.log(move_distance / reference_distance + 1e-10)))])
+            if self.nrejects > nrejects_expected and self.scale > self.scale_min:
+                self.scale *= self.scale_adapt_factor
+            elif self.nrejects < nrejects_expected and self.scale < self.scale_max:
+                self.scale /= self.scale_adapt_factor
+        u, p, L = self.prepared_samples.pop(0)
+        return u, p, L, nc
+
+
+class PopulationSimpleSliceSampler(GenericPopulationSampler):
+    """Vectorized slice sampler without stepping out (reference popstepsampler.py:747-1000): every
+    likelihood batch has exactly `popsize` rows; workers that finished their point help the
+    unfinished ones.  The shrinking bookkeeping is ``update_vectorised_slice_sampler``."""
+
+    def __init__(self, popsize, nsteps, generate_direction, scale_adapt_factor=1.0, adapt_slice_scale_target=2.0,
+                 scale=1.0, scale_jitter_func=None, slice_limit=slice_limit_to_unitcube, max_it=100,
+                 shrink_factor=1.0):
+        assert shrink_factor >= 1.0, "The shrink factor should be greater than 1.0 to be efficient"
+        self.nsteps, self.popsize, self.max_it = nsteps, popsize, max_it
+        self.nrejects, self.ncalls, self.discarded = 0, 0, 0
+        self.generate_direction = generate_direction
+        self.scale_adapt_factor = scale_adapt_factor
+        self.shrink_factor = shrink_factor
+        self.scale = float(scale)
+        self.adapt_slice_scale_target = adapt_slice_scale_target
+        self.scale_jitter_func = scale_jitter_func if scale_jitter_func is not None else (lambda: 1.)
+        self.prepared_samples = []
+        self.slice_limit = slice_limit
+        self.logstat = []
+
+    def __str__(self):
+        return 'PopulationSimpleSliceSampler(popsize=%d, nsteps=%d, generate_direction=%s, scale=%.g)' % (
+            self.popsize, self.nsteps, self.generate_direction, self.scale)
+
+    def __next__(self, region, Lmin, us, Ls, transform, loglike, ndraw=10, plot=False, tregion=None, log=False,
+                 test=False):
+        nlive, ndim = us.shape
+        nc = 0
+        if len(self.prepared_samples) == 0:
+            ilive = np.random.randint(0, nlive, size=self.popsize)
+            allu = np.array(us[ilive, :]) if not test else np.array(us)
+            allp = np.zeros((self.popsize, ndim)) * np.nan
+            allL = np.array(Ls[ilive])
+            n_discarded = 0
+            interval_final = 0.
+            for _ in range(self.nsteps):
+                factor_scale = self.scale_jitter_func()
+                v = self.generate_direction(allu, region, scale=1.0) * self.scale * factor_scale
+                cube_left, cube_right = unitcube_line_intersection(allu, v)
+                tleft_worker, tright_worker = self.slice_limit(cube_left, cube_right)
+                tleft, tright = self.slice_limit(cube_left, cube_right)
+                worker_running = np.arange(self.popsize, dtype=int_dtype)
+                status = np.zeros(self.popsize, dtype=int_dtype)
+                for _it in range(self.max_it):
+                    position = np.random.uniform(size=(self.popsize,))
+                    t = tleft_worker + (tright_worker - tleft_worker) * position
+                    proposed_u = allu[worker_running, :] + t.reshape((-1, 1)) * v[worker_running, :]
+                    proposed_p = transform(proposed_u)
+                    proposed_L = loglike(proposed_p)
+                    nc += self.popsize
+                    if allp.shape[1] != proposed_p.shape[1]:
+                        allp = np.zeros((self.popsize, proposed_p.shape[1])) * np.nan
+                    tleft, tright, worker_running, status, allu, allL, allp, ndisc = update_vectorised_slice_sampler(
+                        t, tleft, tright, proposed_L, proposed_u, proposed_p, worker_running, status, Lmin,
+                        self.shrink_factor, allu, allL, allp, self.popsize)
+                    n_discarded += ndisc
+                    tleft_worker, tright_worker = tleft[worker_running], tright[worker_running]
+                    if not np.any(status == 0):
+                        break
+                interval_final += np.median(tright - tleft)
+            interval_final = interval_final / self.nsteps
+            self.discarded += n_discarded
+            self.ncalls += nc
+            assert np.isfinite(allp).all(), 'some walkers never moved! Double nsteps of PopulationSimpleSliceSampler.'
+            far_enough, (move_distance, reference_distance) = diagnose_move_distances(region, us[ilive, :], allu)
+            self.prepared_samples = list(zip(allu, allp, allL))
+            self.logstat.append([self.popsize / nc, self.scale, self.nsteps,
+                                 np.mean(far_enough) if len(far_enough) > 0 else 0,
+                                 np.exp(np.mean(np.log(move_distance / reference_distance + 1e-10)))
+                                 if len(far_enough) > 0 else 0])
+            if interval_final >= 1. / self.adapt_slice_scale_target:
+                self.scale *= 1. / self.scale_adapt_factor
+            else:
+                self.scale *= self.scale_adapt_factor
+        u, p, L = self.prepared_samples.pop(0)
+        return u, p, L, nc
+
+
+__all__ = [
+    "generate_cube_oriented_direction", "generate_cube_oriented_direction_scaled", "generate_random_direction",
+    "generate_region_oriented_direction", "generate_region_random_direction", "generate_differential_direction",
+    "generate_mixture_random_direction", "PopulationRandomWalkSampler", "PopulationSliceSampler",
+    "PopulationSimpleSliceSampler", "unitcube_line_intersection", "diagnose_move_distances",
+    "slice_limit_to_unitcube", "slice_limit_to_scale", "int_dtype"]
