@@ -9,6 +9,9 @@ cd $R
 echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 echo "== bench"; timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err; tail -c 2500 $O/bench.json; tail -3 $O/bench.err
+echo "== step sampler bench (row f1)"; timeout 600 python scripts/walk_bench.py device > $O/walk_bench.log 2>&1; tail -3 $O/walk_bench.log
+echo "== device sampling bench (row f2)"; timeout 300 python scripts/sample_bench.py > $O/sample_bench.json 2> $O/sample_bench.err; tail -3 $O/sample_bench.err
+echo "== bench via torchrun (1 rank, RCCL init)"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu > $O/bench_torchrun.json 2> $O/bench_torchrun.err; echo "torchrun rc=$?"
 echo "== config bench"; timeout 600 python scripts/config_bench.py > $O/config_bench.json 2> $O/config_bench.err; tail -2 $O/config_bench.err
 if [ "$1" != "noprof" ]; then
 cd /tmp && export TMPDIR=/tmp

@@ -58,3 +58,38 @@ def test_c1_run_reproduces_stock_trajectory(monkeypatch):
     assert int(res["niter"]) == gold["niter"]
     assert res["logz"] == gold["logz"] and res["logzerr"] == gold["logzerr"]
     assert abs(res["logz"]) < 3 * res["logzerr"] + 0.5          # analytic logZ = 0
+
+
+def test_population_slice_sampler_under_the_stock_driver(monkeypatch):
+    """The stock driver with ``sampler.stepsampler = <this package's PopulationSliceSampler>``
+    (the reference's own plug point, cf. its tests/test_popstepsampling.py:41-52) against the same
+    run with the reference's sampler: identical trajectories (ncall, niter, logz).  The bimodal
+    likelihood is the one of the reference's test."""
+    import oracle_backend
+    oracle_backend.install(monkeypatch)
+    sys.path.insert(0, SCRATCH)
+    try:
+        import ultranest
+        import ultranest.popstepsampler as refpop
+    finally:
+        sys.path.remove(SCRATCH)
+    import ultranest_amd.popstepsampler as mypop
+
+    def loglike(z):
+        a = -0.5 * (((z - 0.7 + np.arange(z.shape[1]) * 0.001) / 0.1)**2).sum(axis=1)
+        b = -0.5 * (((z - 0.3 - np.arange(z.shape[1]) * 0.001) / 0.1)**2).sum(axis=1)
+        return np.logaddexp(a, b)
+
+    results = []
+    for module in (refpop, mypop):
+        np.random.seed(3)
+        nsteps = np.random.randint(10, 50)
+        popsize = np.random.randint(1, 20)
+        sampler = ultranest.ReactiveNestedSampler(["a", "b", "c"], loglike, transform=lambda x: x, vectorized=True,
+                                                  log_dir=None)
+        sampler.stepsampler = module.PopulationSliceSampler(
+            popsize=popsize, nsteps=nsteps, generate_direction=module.generate_cube_oriented_direction)
+        res = sampler.run(viz_callback=None, show_status=False, max_iters=1500, max_num_improvement_loops=0)
+        results.append((int(res["ncall"]), int(res["niter"]), res["logz"], res["logzerr"], sampler.stepsampler.scale))
+        assert np.isfinite(sampler.stepsampler.far_enough_fraction)
+    assert results[0] == results[1], results

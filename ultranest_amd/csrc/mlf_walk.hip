@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_walk_expand(WalkState w, const unsigned
 
 // evolve, second half (evolve_update) + PopulationSliceSampler.advance bookkeeping
 // (popstepsampler.py:585-603) + move diagnostics (diagnose_move_distances :64-94)
-__global__ void k_walk_update(WalkState w, double Lmin, WalkLayer ly) {
+__global__ void k_walk_update(WalkState w, double Lmin) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w.P) return;
   w.dist2[i] = qnan();
@@ -334,22 +334,31 @@ __global__ void k_walk_update(WalkState w, double Lmin, WalkLayer ly) {
   const long long g = g0 + 1;
   w.generation[i] = g;
   const double *un = w.unew + (size_t)i * w.d;
-  const double *uo = w.allu + ((size_t)i * w.G + g0) * w.d;
   double *dst = w.allu + ((size_t)i * w.G + g) * w.d;
   for (int k = 0; k < w.d; ++k) dst[k] = un[k];
   w.allL[(size_t)i * w.G + g] = w.Lnew[i];
   for (int k = 0; k < w.nparams; ++k) w.currentp[(size_t)i * w.nparams + k] = w.pnew[(size_t)i * w.nparams + k];
-  if (ly.kind >= 0) {
-    double acc = 0.0;
-    for (int c = 0; c < w.d; ++c) {
-      double ta, tb;
-      whiten_point(ly, uo, w.d, c, ta);
-      whiten_point(ly, un, w.d, c, tb);
-      const double diff = ta - tb;
-      acc += diff * diff;
-    }
-    w.dist2[i] = acc;
+}
+
+// diagnose_move_distances for the walkers that moved: one wave per walker, lane = whitened
+// coordinate (T rows are read coalesced), squared differences summed by a fixed shuffle tree
+__global__ __launch_bounds__(64) void k_walk_diag(WalkState w, WalkLayer ly) {
+  const int i = blockIdx.x;
+  if (!w.success[i]) return;
+  const int lane = threadIdx.x;
+  const long long g = w.generation[i];          // already advanced by k_walk_update
+  const double *uo = w.allu + ((size_t)i * w.G + (g - 1)) * w.d;
+  const double *un = w.unew + (size_t)i * w.d;
+  double acc = 0.0;
+  for (int c = lane; c < w.d; c += 64) {
+    double ta, tb;
+    whiten_point(ly, uo, w.d, c, ta);
+    whiten_point(ly, un, w.d, c, tb);
+    const double diff = ta - tb;
+    acc += diff * diff;
   }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) w.dist2[i] = acc;
 }
 
 __global__ __launch_bounds__(256) void k_walk_harvest(WalkState w, long long ring, double r2, double *rec) {
@@ -618,7 +627,8 @@ void launch_walk_expand(const WalkState &w, const unsigned *blk, const double *p
 }
 
 void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStream_t s) {
-  hipLaunchKernelGGL(k_walk_update, grid_for(w.P, 64), dim3(64), 0, s, w, Lmin, layer);
+  hipLaunchKernelGGL(k_walk_update, grid_for(w.P, 64), dim3(64), 0, s, w, Lmin);
+  if (layer.kind >= 0) hipLaunchKernelGGL(k_walk_diag, dim3(w.P), dim3(64), 0, s, w, layer);
 }
 
 void launch_walk_harvest(const WalkState &w, long long ring, double r2, double *rec, hipStream_t s) {

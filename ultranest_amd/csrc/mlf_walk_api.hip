@@ -24,7 +24,7 @@ struct mlf_walkers {
   int P = 0, nsteps = 0, d = 0, nparams = 0;
   DevBuf allu, allL, generation, currentt, currentv, left, right, sl, sr, currentp;
   DevBuf unew, movable, acceptable, success, pnew, Lnew, dist2;
-  DevBuf gmax, flags, idx, rows, vals, vidx, vrows, unif, blk, compact, pc, Lc, rec, aux;
+  DevBuf gmax, flags, snap, idx, rows, vals, vidx, vrows, unif, blk, compact, pc, Lc, rec, aux;
   DevBuf axes, live, std, lay_ctr, lay_mat, lay_wrap;
   int nlive = 0;
   bool have_axes = false, have_live = false, have_std = false;
@@ -33,6 +33,7 @@ struct mlf_walkers {
   double r2 = 1.0;
   unsigned nblk = 0;
   bool proposed = false, compacted = false;
+  std::vector<uint8_t> host_snap;
 };
 
 namespace {
@@ -167,7 +168,7 @@ int mlf_walkers_destroy(mlf_walkers *w) {
   if (!w) return 0;
   DevBuf *all[] = {&w->allu, &w->allL, &w->generation, &w->currentt, &w->currentv, &w->left, &w->right, &w->sl,
                    &w->sr, &w->currentp, &w->unew, &w->movable, &w->acceptable, &w->success, &w->pnew, &w->Lnew,
-                   &w->dist2, &w->gmax, &w->flags, &w->idx, &w->rows, &w->vals, &w->vidx, &w->vrows, &w->unif, &w->blk, &w->compact,
+                   &w->dist2, &w->gmax, &w->flags, &w->snap, &w->idx, &w->rows, &w->vals, &w->vidx, &w->vrows, &w->unif, &w->blk, &w->compact,
                    &w->pc, &w->Lc, &w->rec, &w->aux, &w->axes, &w->live, &w->std, &w->lay_ctr, &w->lay_mat,
                    &w->lay_wrap};
   for (DevBuf *b : all) b->release();
@@ -187,11 +188,18 @@ int mlf_walkers_reset(mlf_walkers *w) {
 int mlf_walkers_begin(mlf_walkers *w, double Lmin, int64_t *generation, uint8_t *flags) {
   if (!w || !generation || !flags) return ctx_fail_arg(MLF_E_BADARG, "null pointer");
   hipStream_t s = ctx_stream();
-  launch_walk_step_back(state_of(w), Lmin, w->gmax.as<long long>(), w->flags.as<uint8_t>(), s);
+  const size_t P = (size_t)w->P;
+  // snapshot = generation (8 P bytes) followed by the flags (P bytes): one device-to-host copy
+  CK(w->snap.reserve(9 * P));
+  uint8_t *d_flags = w->snap.as<uint8_t>() + 8 * P;
+  launch_walk_step_back(state_of(w), Lmin, w->gmax.as<long long>(), d_flags, s);
   CK(hipGetLastError());
-  if (int rc = download(generation, w->generation, (size_t)w->P * 8, s)) return rc;
-  if (int rc = download(flags, w->flags, (size_t)w->P, s)) return rc;
+  CK(hipMemcpyAsync(w->snap.p, w->generation.p, 8 * P, hipMemcpyDeviceToDevice, s));
+  w->host_snap.resize(9 * P);
+  CK(hipMemcpyAsync(w->host_snap.data(), w->snap.p, 9 * P, hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));
+  memcpy(generation, w->host_snap.data(), 8 * P);
+  memcpy(flags, w->host_snap.data() + 8 * P, P);
   return 0;
 }
 
