@@ -123,7 +123,8 @@ def test_region_inside_filter_vs_exact(K, oracle):
     reg.close()
 
 
-@pytest.mark.parametrize("n,d,p", [(500, 3, 4097), (1200, 20, 5000), (4000, 50, 6001), (300, 64, 2500), (300, 70, 2500)])
+@pytest.mark.parametrize("n,d,p", [(500, 3, 4097), (700, 1, 3000), (900, 17, 2049), (1200, 20, 5000), (4000, 50, 6001),
+                                   (300, 64, 2500), (300, 70, 2500)])
 def test_fused_prep_matches_unfused(n, d, p, K, oracle):
     """k_prep2 (coalesced staging, coordinate-major whitened output, fused binary16 quantisation)
     vs the unfused kernels, filter on and off, ragged batch sizes, wrapped axis; all four
@@ -138,22 +139,25 @@ def test_fused_prep_matches_unfused(n, d, p, K, oracle):
     w = u.copy()
     w[:, 0] = np.fmod(w[:, 0] + shift[0], 1)
     ctr = w.mean(axis=0)
-    cov = np.cov(w, rowvar=0) * (d + 2)
+    cov = np.atleast_2d(np.cov(w, rowvar=0)) * (d + 2)
     ev, evec = np.linalg.eigh(cov)
     T = evec * ev ** -0.5
     ectr = u.mean(axis=0)
-    einv = np.linalg.inv(np.cov(u, rowvar=0) * (d + 2))
+    einv = np.linalg.inv(np.atleast_2d(np.cov(u, rowvar=0)) * (d + 2))
     pts = inputs.proposal_mix(10, w, p, shell_q=2.0)
     pts[:, 0] = np.fmod(pts[:, 0] + cut + 1.0, 1.0)          # back to the unwrapped cube
     reg = K.DeviceRegion()
     reg.set(u, 0, ctr, T, shift, ectr, einv, 60.0, 1.1, live_space=1)
     got = {}
-    for fused in (1, 0):
+    # matrix = k_prep3 (FP64 matrix cores), vector = k_prep2, unfused = k_prep + separate quantisation
+    for mode, (fused, matrix) in dict(matrix=(1, 1), vector=(1, 0), unfused=(0, 0)).items():
         for filt in (1, 0):
             _lib.set_option("fused_prep", fused)
+            _lib.set_option("prep_matrix", matrix)
             _lib.set_option("filter", filt)
-            got[fused, filt] = reg.inside(pts)
+            got[mode, filt] = reg.inside(pts)
     _lib.set_option("fused_prep", 1)
+    _lib.set_option("prep_matrix", 1)
     _lib.set_option("filter", 1)
     wp = pts.copy()
     wp[:, 0] = np.fmod(wp[:, 0] + shift[0], 1)

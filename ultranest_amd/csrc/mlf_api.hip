@@ -13,6 +13,7 @@
 #include "mlf_filter.hpp"
 #include "mlf_misc.hpp"
 #include "mlf_prep2.hpp"
+#include "mlf_prep3.hpp"
 #include "mlf_sample.hpp"
 
 namespace {
@@ -57,6 +58,7 @@ struct FilterCtx {
 constexpr unsigned kFilterSegCap = 2048;
 bool g_filter_enabled = true;         // mlf_set_option("filter", 0/1)
 bool g_fused_prep = true;             // mlf_set_option("fused_prep", 0/1)
+bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
 long long g_filter_min_queries = 2048;  // smaller batches go straight to the exact scan
 
 struct Ctx {
@@ -320,7 +322,7 @@ struct mlf_region {
   int layer_kind = 0, use_scan = 1, live_space = 0;
   bool has_wrap = false;
   double enlarge = 0.0, r2 = 0.0;
-  DevBuf refT, refR, lay_ctr, lay_mat, lay_T8, wrap, ell_ctr, ell_A, ell_Lt;
+  DevBuf refT, refR, lay_ctr, lay_mat, lay_T8, wrap, ell_ctr, ell_A, ell_Lt, ell_LtF, lay_TtF;
   bool chol_ready = false, chol_ok = false;
   double ell_eps_scale = 0.0;
   DevBuf tq, gate, pts, mask, row;
@@ -369,7 +371,49 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
   long long ldq = r->d, ldk = 1;
   if (r->use_scan) CK(r->tq.reserve(np * (size_t)r->d * sizeof(double)));
   if (ev) CK(hipEventRecord(ev[0], s));
-  if (fused) {
+  if (fused && g_prep_matrix && prep3_usable(r->d)) {   // FP64 matrix-core version of the fused stage
+    Prep3Args pa{};
+    pa.pts = d_pts;
+    pa.np = (long long)np;
+    pa.d = r->d;
+    pa.dp = r->dp;
+    pa.nk = (r->d + 3) / 4;
+    pa.ell_ctr = r->ell_ctr.as<double>();
+    pa.ell_A = r->ell_A.as<double>();
+    pa.lda = r->dp;
+    pa.LtF = r->ell_LtF.as<double>();
+    pa.ell_eps_scale = r->ell_eps_scale;
+    pa.chol_ok = r->chol_ok ? 1 : 0;
+    pa.enlarge = r->enlarge;
+    pa.gate = gate;
+    if (r->use_scan) {
+      pa.do_tr = 1;
+      pa.lay_ctr = r->lay_ctr.as<double>();
+      pa.TtF = r->lay_TtF.as<double>();
+      pa.wrap_shift = r->has_wrap ? r->wrap.as<double>() : nullptr;
+      pa.t_out = r->tq.as<double>();
+      pa.t_ldq = 1;
+      pa.t_ldk = (long long)np;
+      ldq = 1;
+      ldk = (long long)np;
+      if (use_filter) {
+        unsigned cap = 0;
+        FilterCtx &f = r->filter;
+        if (int rc = filter_reserve(f, (long long)np, &cap)) return rc;
+        pa.qF = f.qF.p;
+        pa.tlo = f.tlo.as<float>();
+        pa.thi = f.thi.as<float>();
+        pa.route = f.route.as<uint8_t>();
+        pa.best = f.best.as<int>();
+        pa.counters = f.counters.as<unsigned>();
+        pa.stats = f.stats.as<double>();
+        pa.r2 = r->r2;
+        pa.ks = f.ks;
+        pa.nqpad = ((long long)np + 31) / 32 * 32;
+      }
+    }
+    CK(launch_prep3(pa, s));
+  } else if (fused) {
     Prep2Args pa{};
     pa.pts = d_pts;
     pa.np = (long long)np;
@@ -531,6 +575,10 @@ int mlf_set_option(const char *name, long long value) {
   }
   if (!strcmp(name, "fused_prep")) {
     g_fused_prep = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "prep_matrix")) {
+    g_prep_matrix = value != 0;
     return 0;
   }
   if (!strcmp(name, "filter_min_queries")) {
@@ -797,7 +845,7 @@ int mlf_region_create(mlf_region **out) {
 
 int mlf_region_destroy(mlf_region *r) {
   if (!r) return 0;
-  DevBuf *bufs[] = {&r->refT, &r->refR, &r->lay_ctr, &r->lay_mat, &r->lay_T8, &r->ell_Lt, &r->wrap, &r->ell_ctr,
+  DevBuf *bufs[] = {&r->refT, &r->refR, &r->lay_ctr, &r->lay_mat, &r->lay_T8, &r->ell_Lt, &r->ell_LtF, &r->lay_TtF, &r->wrap, &r->ell_ctr,
                     &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row,
                     &r->gen, &r->gen2, &r->cube, &r->smask, &r->blk, &r->sout, &r->ax_zero, &r->ax_mat};
   for (DevBuf *b : bufs) b->release();
@@ -865,6 +913,11 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
     r->chol_ok = ok && std::isfinite(fro);
     r->ell_eps_scale = std::ldexp(1.0, -34) * std::sqrt(fro);
     if (int rc = upload(r->ell_Lt, Lt.data(), Lt.size() * sizeof(double), c.stream)) return rc;
+    if (prep3_usable((int)d)) {   // the same factor as 16 x 4 matrix-core fragments: (row kb, k j) = L[j][kb]
+      std::vector<double> frag(prep3_fragment_count((int)d));
+      prep3_fragments(L.data(), (int)d, true, frag.data());
+      if (int rc = upload(r->ell_LtF, frag.data(), frag.size() * sizeof(double), c.stream)) return rc;
+    }
     CK(hipStreamSynchronize(c.stream));
     r->chol_ready = true;
   }
@@ -877,6 +930,11 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
       for (size_t k = 0; k < d; ++k)
         for (size_t cc = 0; cc < d; ++cc) t8[k * dp8 + cc] = layer_T[k * d + cc];
       if (int rc = upload(r->lay_T8, t8.data(), t8.size() * sizeof(double), c.stream)) return rc;
+      if (prep3_usable((int)d)) {   // (row c, k) = T[k][c]
+        std::vector<double> frag(prep3_fragment_count((int)d));
+        prep3_fragments(layer_T, (int)d, true, frag.data());
+        if (int rc = upload(r->lay_TtF, frag.data(), frag.size() * sizeof(double), c.stream)) return rc;
+      }
       CK(hipStreamSynchronize(c.stream));
     } else {
       if (int rc = upload(r->lay_ctr, layer_ctr, d * sizeof(double), c.stream)) return rc;
