@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 N_LIVE, NDIM, NPROPOSALS, NBOOT = 4000, 50, 1000000, 30
 FP64_VALU_PEAK_TFLOPS = 39.3     # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz, one flop per non-fused v_*_f64
 F16_MFMA_PEAK_TFLOPS = 2500.0    # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix = vector FMA peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -228,7 +229,8 @@ def main():
         roofline = dict(exact_roof)
         roofline["traffic"] = traffic
         roofline["hbm"] = hbm
-    prep_bytes = NPROPOSALS * (2 * 8 * NDIM + 8 * NDIM + 2 * kdim + 9)
+    prep_bytes = NPROPOSALS * (8 * NDIM + 8 * NDIM + 2 * kdim + 9)      # row in, whitened f64 + f16 fragments + flags out
+    prep_flops = NPROPOSALS * 2.0 * (NDIM * NDIM + NDIM * (NDIM + 1) / 2)
     out = {
         "metric": "proposal-points filtered/sec (MLFriends.inside) + region-rebuild ms, N=4000 d=50",
         "value": value, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -242,17 +244,22 @@ def main():
                    "mfma_prefilter": bool(filter_on)},
         "rebuild_ms": rebuild_ms, "rebuild_first_ms": first_ms,
         "accept_fraction": accept, "ellipsoid_pass_fraction": ell_pass,
-        "kernel_ms": {"per-proposal stage (k_prep2: ellipsoid + whitening + f16 quantisation)": prep_ms,
+        "kernel_ms": {"per-proposal stage (k_prep3: ellipsoid + whitening on the FP64 matrix cores + f16 quantisation)": prep_ms,
                       ("scan kernel (k_filter)" if filter_on else "scan kernel (k_scan)"): scan_ms,
                       "rest of scan stage (exact re-check of uncertain pairs, routing, finalise)": rest_ms},
         "roofline": roofline,
         "roofline_exact_scan": exact_roof,
-        "roofline_prep": {"kernel": "k_prep2<50>", "bound": "hbm", "unit": "GB/s",
-                          "achieved": prep_bytes / (prep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
-                          "frac": prep_bytes / (prep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                          "algorithmic_bytes_per_launch": prep_bytes,
-                          "note": "reads each proposal row twice, writes whitened f64 + f16 fragments; also "
-                                  "~5.4e3 FP64 FMAs per proposal with LDS-broadcast operands"},
+        "roofline_prep": {"kernel": "k_prep3<13> (v_mfma_f64_16x16x4_f64)", "bound": "mfma_fp64", "unit": "TFLOP/s",
+                          "achieved": prep_flops / (prep_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                          "frac": prep_flops / (prep_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                          "algorithmic_flops_per_launch": prep_flops,
+                          "hbm": {"algorithmic_bytes_per_launch": prep_bytes,
+                                  "achieved_GBps": prep_bytes / (prep_ms * 1e-3) / 1e9,
+                                  "frac": prep_bytes / (prep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                          "note": "algorithmic flops = 2*(d^2 + d(d+1)/2) per proposal (whitening + triangular "
+                                  "factor of the ellipsoid form); the kernel executes 80 of 104 16x16x4 tiles per "
+                                  "16 proposals (d = 50 padded to 52 x 64); measured v_mfma_f64 issue rate on this "
+                                  "part: 68-76 TFLOP/s (scripts/probes/mfma64_probe.hip)"},
     }
     if world == 1 and not args.no_cpu:
         sample = pts[:args.cpu_sample].cpu().numpy()

@@ -915,7 +915,7 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
     if (int rc = upload(r->ell_Lt, Lt.data(), Lt.size() * sizeof(double), c.stream)) return rc;
     if (prep3_usable((int)d)) {   // the same factor as 16 x 4 matrix-core fragments: (row kb, k j) = L[j][kb]
       std::vector<double> frag(prep3_fragment_count((int)d));
-      prep3_fragments(L.data(), (int)d, true, frag.data());
+      prep3_fragments(L.data(), (int)d, true, true, frag.data());
       if (int rc = upload(r->ell_LtF, frag.data(), frag.size() * sizeof(double), c.stream)) return rc;
     }
     CK(hipStreamSynchronize(c.stream));
@@ -932,7 +932,7 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
       if (int rc = upload(r->lay_T8, t8.data(), t8.size() * sizeof(double), c.stream)) return rc;
       if (prep3_usable((int)d)) {   // (row c, k) = T[k][c]
         std::vector<double> frag(prep3_fragment_count((int)d));
-        prep3_fragments(layer_T, (int)d, true, frag.data());
+        prep3_fragments(layer_T, (int)d, true, false, frag.data());
         if (int rc = upload(r->lay_TtF, frag.data(), frag.size() * sizeof(double), c.stream)) return rc;
       }
       CK(hipStreamSynchronize(c.stream));

@@ -16,8 +16,11 @@
 //
 // Layout per 16-proposal tile: lane l holds proposal (l & 15); of every 16-row block of an output
 // it holds rows (l >> 4) + 4 r, r = 0..3.  Per-proposal scalars are therefore reduced over the four
-// lanes l, l^16, l^32, l^48.  binary16 fragment pieces (8 consecutive columns) are assembled
-// through a wave-private LDS transpose.
+// lanes l, l^16, l^32, l^48.  Proposal rows are fetched with contiguous 8-byte-per-lane loads (a
+// tile's 16 rows are one contiguous block) and redistributed into operand order through a
+// wave-private LDS buffer (row stride = 4 mod 8 dwords: conflict-free ds_read_b64); fetching them
+// in operand order straight from HBM (32-byte segments) cost 0.15 ms per 10^6 x 50 batch.  The same
+// buffer is reused for the binary16 transpose (8 consecutive columns per 16-byte fragment piece).
 // -ffp-contract=off; FMAs only where written.
 #include "mlf_prep3.hpp"
 
@@ -40,17 +43,27 @@ __device__ __forceinline__ double quad_sum(double v) {   // sum over lanes l, l^
 }
 
 constexpr int kTileRowHalfs = 136;   // binary16 columns per proposal in the transpose buffer (128 + pad)
+constexpr int kWaveBufBytes = 8704;  // per-wave staging: 16 rows x <= 132 dwords, or 16 x 136 binary16
 
 }  // namespace
 
-// NC = ceil(d / 16) output row tiles
-template <int NC, bool WRAP>
+// NK = k-steps of 4 coordinates (the host pads d up to 4 NK with zero matrix rows / columns)
+template <int NK, bool WRAP>
 __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
   extern __shared__ __attribute__((aligned(16))) double lds3[];
-  const int nk = a.nk;
-  double *LtF = lds3;                         // [NC][nk][64]
-  double *TtF = lds3 + (size_t)NC * nk * 64;  // [NC][nk][64]
-  half_t *tbuf = reinterpret_cast<half_t *>(lds3 + (size_t)2 * NC * nk * 64) + (threadIdx.x >> 6) * (16 * kTileRowHalfs);
+  constexpr int nk = NK;
+  constexpr int NC = (NK + 3) / 4;   // output row tiles of 16
+  // Lt fragments: only the tiles on and right of the diagonal are stored (ks >= 4 ct)
+  double *LtF = lds3;
+  const int nlt = a.nlt;                      // number of stored Lt tiles
+  double *TtF = lds3 + (size_t)nlt * 64;      // [NC][nk][64]
+  // per-coordinate constants (centres, wrap shifts, quantisation centres): read per tile, so they
+  // live in LDS -- as global loads they were three exposed L2 round trips per tile
+  double *c_ell = lds3 + (size_t)nlt * 64 + (size_t)NC * nk * 64;   // [64] each
+  double *c_lay = c_ell + 64, *c_wrap = c_ell + 128, *c_stat = c_ell + 192;
+  char *wbuf = reinterpret_cast<char *>(c_ell + 256) + (threadIdx.x >> 6) * kWaveBufBytes;
+  double *xbuf = reinterpret_cast<double *>(wbuf);
+  half_t *tbuf = reinterpret_cast<half_t *>(wbuf);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -64,9 +77,15 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
     a.counters[0] = 0;
     a.counters[1] = 0;
   }
-  for (int e = tid; e < NC * nk * 64; e += 256) {
-    LtF[e] = a.LtF[e];
-    if (a.do_tr) TtF[e] = a.TtF[e];
+  for (int e = tid; e < nlt * 64; e += 256) LtF[e] = a.LtF[e];
+  if (a.do_tr)
+    for (int e = tid; e < NC * nk * 64; e += 256) TtF[e] = a.TtF[e];
+  if (tid < 64) {
+    const bool in = tid < a.d;
+    c_ell[tid] = in ? a.ell_ctr[tid] : 0.0;
+    c_lay[tid] = (in && a.do_tr) ? a.lay_ctr[tid] : 0.0;
+    c_wrap[tid] = (in && a.do_tr && a.wrap_shift) ? a.wrap_shift[tid] : __longlong_as_double(0x7ff8000000000000ll);
+    c_stat[tid] = (in && a.qF) ? a.stats[8 + tid] : 0.0;
   }
   __syncthreads();
 
@@ -75,24 +94,34 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
   const long long wave_id = (long long)blockIdx.x * 4 + (tid >> 6);
   const long long nwaves = (long long)gridDim.x * 4;
   const double sigma = quant ? a.stats[0] : 1.0;
+  const double namax = quant ? a.stats[1] : 0.0;
   uint4 *qdst = reinterpret_cast<uint4 *>(a.qF);
 
-  // raw coordinates of one tile in operand order: x[ks] = pts[tile*16 + pl][4 ks + kq] (0 outside)
-  auto load_tile = [&](long long tile, double *x) {
-    const long long p = tile * 16 + pl;
-    const bool live = tile < ntiles && p < a.np;
-    const double *row = a.pts + (live ? p : 0) * (long long)d;
+  // A tile's 16 rows are 16 d contiguous doubles: element e = lane + 64 i goes to LDS row e / d,
+  // column e % d (row stride xs2 doubles)
+  const int xs2 = a.xstride;                 // doubles per staged row; 2 * xs2 = 4 mod 8 dwords
+  const int nelem = 16 * d;
+  int xoff[NK];
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int k = 4 * ks + kq;
-      x[ks] = (ks < nk && live && k < d) ? row[k] : 0.0;
+  for (int i = 0; i < NK; ++i) {
+    const int e = lane + 64 * i;
+    const int rr = e / d;
+    xoff[i] = e < nelem ? rr * xs2 + (e - rr * d) : -1;
+  }
+  auto load_tile = [&](long long tile, double *x) {
+    const long long base = tile * 16 * (long long)d;
+    const long long total = a.np * (long long)d;
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+      const long long g = base + lane + 64 * i;
+      x[i] = (xoff[i] >= 0 && tile < ntiles && g < total) ? a.pts[g] : 0.0;
     }
   };
 
   // four consecutive tiles (64 proposals) per wave and step: the proposals of a binary16 fragment
   // group (32 rows) stay within one wave.  The next tile's rows are requested before the current
   // tile's matrix products are issued (one wave has ~5000 cycles of MFMA work per tile to hide them).
-  double xcur[16];
+  double xcur[NK];
   if (wave_id * 4 < ntiles) load_tile(wave_id * 4, xcur);
   for (long long t4 = wave_id; t4 * 4 < ntiles; t4 += nwaves) {
     for (int sub = 0; sub < 4; ++sub) {
@@ -102,31 +131,45 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
       const bool live = p < a.np;
       const double *row = a.pts + (live ? p : 0) * (long long)d;
 
+      // redistribute: coalesced order -> operand order
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < NK; ++i)
+        if (xoff[i] >= 0) xbuf[xoff[i]] = xcur[i];
+      __builtin_amdgcn_wave_barrier();
+      double xop[NK];
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        const int k = 4 * ks + kq;
+        xop[ks] = (k < d) ? xbuf[pl * xs2 + k] : 0.0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      load_tile(sub < 3 ? tile + 1 : (t4 + nwaves) * 4, xcur);   // prefetch
+
       // ---- operands: 4 coordinates x 16 proposals per k-step -------------------------------
-      double dl[16], dw[16];
+      double dl[NK], dw[NK];
       double nrm2 = 0.0;
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
+      for (int ks = 0; ks < NK; ++ks) {
         dl[ks] = 0.0;
         dw[ks] = 0.0;
-        if (ks < nk) {
+        {
           const int k = 4 * ks + kq;
           const bool ok = live && k < d;
-          const double x = xcur[ks];
+          const double x = xop[ks];
           double w = x;
           if (WRAP && ok && a.do_tr) {
-            const double sh = a.wrap_shift[k];
+            const double sh = c_wrap[k];
             if (sh == sh) {   // NaN marks an unwrapped dimension
               const double xs = w + sh;
               w = (xs >= 0.0 && xs < 2.0) ? (xs >= 1.0 ? xs - 1.0 : xs) : wrap_coordinate3(w, sh);
             }
           }
-          dl[ks] = ok ? x - a.ell_ctr[k] : 0.0;
-          dw[ks] = (ok && a.do_tr) ? w - a.lay_ctr[k] : 0.0;
+          dl[ks] = ok ? x - c_ell[k] : 0.0;
+          dw[ks] = (ok && a.do_tr) ? w - c_lay[k] : 0.0;
           nrm2 = __builtin_fma(dl[ks], dl[ks], nrm2);
         }
       }
-      load_tile(sub < 3 ? tile + 1 : (t4 + nwaves) * 4, xcur);   // prefetch
       nrm2 = quad_sum(nrm2);
 
       // ---- H3 bound: Y = Lt . delta, qt = |Y|^2 ---------------------------------------------
@@ -136,12 +179,12 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
 #pragma unroll
         for (int ct = 0; ct < NC; ++ct) y[ct] = (double4v){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          if (ks < nk) {
+        for (int ks = 0; ks < NK; ++ks) {
+          {
 #pragma unroll
             for (int ct = 0; ct < NC; ++ct)
-              if (4 * ks + 3 >= 16 * ct)   // Lt[kb][j] = 0 for j < kb: tiles left of the diagonal are empty
-                y[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(LtF[((size_t)ct * nk + ks) * 64 + lane], dl[ks], y[ct], 0, 0, 0);
+              if (ks >= 4 * ct)   // Lt[kb][j] = 0 for j < kb: tiles left of the diagonal are empty and not stored
+                y[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(LtF[(size_t)(ct * nk - 2 * ct * (ct - 1) + ks - 4 * ct) * 64 + lane], dl[ks], y[ct], 0, 0, 0);
           }
         }
 #pragma unroll
@@ -180,8 +223,8 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
       for (int ct = 0; ct < NC; ++ct) t[ct] = (double4v){0.0, 0.0, 0.0, 0.0};
       if (__any(inside)) {
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          if (ks < nk) {
+        for (int ks = 0; ks < NK; ++ks) {
+          {
 #pragma unroll
             for (int ct = 0; ct < NC; ++ct)
               t[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(TtF[((size_t)ct * nk + ks) * 64 + lane], dw[ks], t[ct], 0, 0, 0);
@@ -204,9 +247,7 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
       double nb = 0.0, nbn2 = 0.0;
       bool fits = true;
       const int K = KS * 16;
-      // zero the whole row first (columns >= d, and everything for proposals that are not filtered)
-      for (int c = kq; c < K; c += 4) trow[c] = (half_t)0.0f;
-      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_wave_barrier();   // the staged rows have been consumed: the buffer becomes the transpose
       if (inside) {
 #pragma unroll
         for (int ct = 0; ct < NC; ++ct)
@@ -214,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
           for (int r = 0; r < 4; ++r) {
             const int c = 16 * ct + kq + 4 * r;
             if (c < d) {
-              const double x = sigma * (t[ct][r] - a.stats[8 + c]);
+              const double x = sigma * (t[ct][r] - c_stat[c]);
               if (!(fabs(x) <= 16000.0)) fits = false;   // NaN lands here too
               nbn2 = __builtin_fma(x, x, nbn2);
               const half_t h = (half_t)(float)x;
@@ -239,32 +280,30 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
       half_t pc[3] = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
       if (rt == 1) {
         split3(nb, pc);
-        if (!filter_thresholds(a.stats[0], a.stats[1], nbn2, a.r2, K, &lo_f, &hi_f)) {
+        if (!filter_thresholds(sigma, namax, nbn2, a.r2, K, &lo_f, &hi_f)) {
           rt = 2;
           lo_f = hi_f = -1.0f;
         }
       }
-      __builtin_amdgcn_wave_barrier();
-      if (rt == 1) {
-        if (kq == 0) {
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            trow[a.dp + j] = (half_t)1.0f;     // x |ah|^2 pieces of the live point
-            trow[a.dp + 3 + j] = pc[j];        // x ones column of the live point
-          }
-        }
-      } else {   // not filtered: every operand column of this query must be zero
-        for (int c = kq; c < K; c += 4) trow[c] = (half_t)0.0f;
+      // columns d .. K-1 of the row: zeros, except the six norm columns at dp (shared by the four lanes)
+      for (int c = d + kq; c < K; c += 4) {
+        half_t v = (half_t)0.0f;
+        if (c >= a.dp && c < a.dp + 3) v = (half_t)1.0f;                 // x |ah|^2 pieces of the live point
+        if (c >= a.dp + 3 && c < a.dp + 6) v = pc[c - a.dp - 3];         // x ones column of the live point
+        trow[c] = v;
       }
       __builtin_amdgcn_wave_barrier();
-      // 16 proposals x (K / 8) pieces of 16 bytes, contiguous across proposals in the fragment layout
-      if (p - pl < a.nqpad) {
+      // 16 proposals x (K / 8) pieces of 16 bytes, contiguous across proposals in the fragment layout;
+      // a proposal that is not filtered (gated out / exact scan) gets all-zero operand columns
+      {
         const int npieces = 16 * (K >> 3);
         for (int q = lane; q < npieces; q += 64) {
           const int qp = q & 15, c0 = (q >> 4) << 3;
           const long long pp = tile * 16 + qp;
+          const int rt_q = __shfl(rt, qp, 64);
           if (pp < a.nqpad) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(tbuf + qp * kTileRowHalfs + c0);
+            uint4 v = *reinterpret_cast<const uint4 *>(tbuf + qp * kTileRowHalfs + c0);
+            if (rt_q != 1) v = make_uint4(0u, 0u, 0u, 0u);
             const long long grp = pp >> 5;
             const int r32 = (int)(pp & 31);
             qdst[((size_t)grp * KS + (c0 >> 4)) * 64 + r32 + 32 * ((c0 >> 3) & 1)] = v;
@@ -284,27 +323,58 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
   }
 }
 
-size_t prep3_fragment_count(int d) { return (size_t)((d + 15) / 16) * ((d + 3) / 4) * 64; }
+int prep3_ksteps(int d) {   // instantiated k-step counts; d is padded up with zero rows / columns
+  static const int sizes[] = {1, 2, 3, 4, 5, 6, 8, 10, 13, 16};
+  for (int v : sizes)
+    if (4 * v >= d) return v;
+  return 16;
+}
 
-void prep3_fragments(const double *M, int d, bool transpose, double *out) {
-  const int nc = (d + 15) / 16, nk = (d + 3) / 4;
+size_t prep3_fragment_count(int d) {
+  const int nk = prep3_ksteps(d);
+  return (size_t)((nk + 3) / 4) * nk * 64;
+}
+
+void prep3_fragments(const double *M, int d, bool transpose, bool upper_only, double *out) {
+  const int nk = prep3_ksteps(d), nc = (nk + 3) / 4;
+  size_t tile = 0;
   for (int ct = 0; ct < nc; ++ct)
-    for (int ks = 0; ks < nk; ++ks)
+    for (int ks = 0; ks < nk; ++ks) {
+      if (upper_only && ks < 4 * ct) continue;   // all k < first row of the tile: empty for an upper factor
       for (int l = 0; l < 64; ++l) {
         const int row = 16 * ct + (l & 15), k = 4 * ks + (l >> 4);
         double v = 0.0;
         if (row < d && k < d) v = transpose ? M[(size_t)k * d + row] : M[(size_t)row * d + k];
-        out[((size_t)ct * nk + ks) * 64 + l] = v;
+        out[tile * 64 + l] = v;
       }
+      ++tile;
+    }
+}
+
+int prep3_lt_tiles(int d) {
+  const int nk = prep3_ksteps(d), nc = (nk + 3) / 4;
+  int n = 0;
+  for (int ct = 0; ct < nc; ++ct) n += nk > 4 * ct ? nk - 4 * ct : 0;
+  return n;
+}
+
+int prep3_xstride(int d) {   // doubles per staged row: >= d, and 2 * stride = 4 (mod 8) dwords
+  int s = d;
+  while ((2 * s) % 8 != 4) ++s;
+  return s;
 }
 
 static size_t prep3_lds_bytes(int d) {
-  return 2 * prep3_fragment_count(d) * sizeof(double) + (size_t)4 * 16 * kTileRowHalfs * sizeof(half_t);
+  return ((size_t)prep3_lt_tiles(d) * 64 + prep3_fragment_count(d) + 256) * sizeof(double) + (size_t)4 * kWaveBufBytes;
 }
 
 bool prep3_usable(int d) { return d >= 1 && d <= 64; }
 
-hipError_t launch_prep3(const Prep3Args &a, hipStream_t s) {
+hipError_t launch_prep3(const Prep3Args &a_in, hipStream_t s) {
+  Prep3Args a = a_in;
+  a.nk = prep3_ksteps(a.d);
+  a.nlt = prep3_lt_tiles(a.d);
+  a.xstride = prep3_xstride(a.d);
   if (a.np <= 0) return hipSuccess;
   if (!prep3_usable(a.d)) return hipErrorInvalidValue;
   const long long rows = a.qF ? a.nqpad : a.np;
@@ -312,30 +382,28 @@ hipError_t launch_prep3(const Prep3Args &a, hipStream_t s) {
   long long grid = (chunks + 3) / 4;
   if (grid > 512) grid = 512;                           // persistent: 2 workgroups per CU
   const size_t lds = prep3_lds_bytes(a.d);
-  const int nc = (a.d + 15) / 16;
   const bool wrap = a.wrap_shift != nullptr;
-#define LAUNCH3(NCV)                                                                                        \
-  {                                                                                                         \
+#define LAUNCH3(NKV)                                                                                        \
+  case NKV: {                                                                                               \
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep3<NCV, false>),              \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);            \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep3<NKV, false>),              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);           \
       if (e == hipSuccess)                                                                                  \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep3<NCV, true>),                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                     \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep3<NKV, true>),                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);                    \
       if (e != hipSuccess) return e;                                                                        \
       attr_set = true;                                                                                      \
     }                                                                                                       \
     if (wrap)                                                                                               \
-      hipLaunchKernelGGL((k_prep3<NCV, true>), dim3((unsigned)grid), dim3(256), lds, s, a);                 \
+      hipLaunchKernelGGL((k_prep3<NKV, true>), dim3((unsigned)grid), dim3(256), lds, s, a);                 \
     else                                                                                                    \
-      hipLaunchKernelGGL((k_prep3<NCV, false>), dim3((unsigned)grid), dim3(256), lds, s, a);                \
+      hipLaunchKernelGGL((k_prep3<NKV, false>), dim3((unsigned)grid), dim3(256), lds, s, a);                \
+    break;                                                                                                  \
   }
-  switch (nc) {
-    case 1: LAUNCH3(1) break;
-    case 2: LAUNCH3(2) break;
-    case 3: LAUNCH3(3) break;
-    default: LAUNCH3(4) break;
+  switch (a.nk) {
+    LAUNCH3(1) LAUNCH3(2) LAUNCH3(3) LAUNCH3(4) LAUNCH3(5) LAUNCH3(6) LAUNCH3(8) LAUNCH3(10) LAUNCH3(13) LAUNCH3(16)
+    default: return hipErrorInvalidValue;
   }
 #undef LAUNCH3
   return hipGetLastError();

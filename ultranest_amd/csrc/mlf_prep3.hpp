@@ -9,11 +9,11 @@ struct Prep3Args {
   long long np;
   int d;
   int dp;                 // padded dimensionality of the live-point layouts (norm columns of the filter operand start here)
-  int nk;                 // k-steps of 4 coordinates: ceil(d / 4)
+  int nk;                 // k-steps of 4 coordinates (filled in by launch_prep3: prep3_ksteps(d))
   const double *ell_ctr;  // [>= d]
   const double *ell_A;    // [d][lda]  exact path (rare)
   int lda;
-  const double *LtF;      // [NC][nk][64] A-fragments: Lt[kb = 16 ct + (lane & 15)][j = 4 ks + (lane >> 4)]
+  const double *LtF;      // A-fragments Lt[kb = 16 ct + (lane & 15)][j = 4 ks + (lane >> 4)], tiles with ks >= 4 ct only
   double ell_eps_scale;   // 2^-34 |A|_F
   int chol_ok;
   double enlarge;
@@ -34,12 +34,15 @@ struct Prep3Args {
   double r2;
   int ks;                 // filter k-steps of 16 binary16 columns
   long long nqpad;
+  int nlt, xstride;       // filled in by launch_prep3
 };
 
 bool prep3_usable(int d);
+int prep3_ksteps(int d);
 // host helper: d x d row-major M -> fragment order; transpose = false: element (row, k) = M[row][k]
 // (rows = output index), transpose = true: element (row, k) = M[k][row]
-void prep3_fragments(const double *M, int d, bool transpose, double *out /* [NC][nk][64] */);
+// upper_only: keep only the tiles with ks >= 4 ct (a factor with M-element (row, k) = 0 for k < row)
+void prep3_fragments(const double *M, int d, bool transpose, bool upper_only, double *out);
 size_t prep3_fragment_count(int d);
 hipError_t launch_prep3(const Prep3Args &a, hipStream_t s);
 
