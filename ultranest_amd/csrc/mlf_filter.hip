@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
   half8 af[KS];
   // Waves start at different live-point tiles (results are order independent): all waves
   // sweeping the same 4 KB tile at the same moment would queue on one L2 channel.
-  const int tstart = (int)((wave * 37) % a.ntiles32);
+  const int tstart = (int)(((long long)blockIdx.x * 37) % a.ntiles32);   // one sweep order per workgroup: its 4 waves share L1 lines
 #pragma unroll
   for (int s = 0; s < KS; ++s) af[s] = refF[((size_t)tstart * KS + s) * 64 + lane];
 
@@ -270,13 +270,18 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
       for (int g = 0; g < QW; ++g)
         acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bq[g][s], acc[g], 0, 0, 0);
 
+    // All 16 values of a lane belong to ONE query (column = lane & 31) and 16 live points, so the
+    // lane-wise minimum decides the common case with 8 v_min3 + 2 compares per group:
+    //   vmin >  T_hi : nothing within reach in this block (certain misses)
+    //   vmin <= T_lo : the query has a certain hit (mask mode needs nothing more)
+    // Operands are finite binary16 values of bounded size, so acc holds no NaN / inf.
+    // The per-group decisions are wave masks combined on the scalar unit; the common path has a
+    // single branch per tile (one branch per group kept the scheduler from overlapping the
+    // epilogue with the next matrix products).
+    unsigned long long candm[QW];
+    unsigned long long need = 0ull;
 #pragma unroll
     for (int g = 0; g < QW; ++g) {
-      // All 16 values of a lane belong to ONE query (column = lane & 31) and 16 live points, so
-      // the lane-wise minimum decides the common case with 8 v_min3 + 2 compares:
-      //   vmin >  T_hi : nothing within reach in this block (certain misses)
-      //   vmin <= T_lo : the query has a certain hit (mask mode needs nothing more)
-      // Operands are finite binary16 values of bounded size, so acc holds no NaN / inf.
       const float16v &c = acc[g];
       const int m0 = min3i(__float_as_int(c[0]), __float_as_int(c[1]), __float_as_int(c[2]));
       const int m1 = min3i(__float_as_int(c[3]), __float_as_int(c[4]), __float_as_int(c[5]));
@@ -284,16 +289,23 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
       const int m3 = min3i(__float_as_int(c[9]), __float_as_int(c[10]), __float_as_int(c[11]));
       const int m4 = min3i(__float_as_int(c[12]), __float_as_int(c[13]), __float_as_int(c[14]));
       const float vmin = __int_as_float(min3i(min3i(m0, m1, m2), min3i(m3, m4, __float_as_int(c[15])), m0));
-      const bool cand = vmin <= thi[g];
-      bool detail = cand;
+      unsigned long long cm = __ballot(vmin <= thi[g]);
       if (!FIRST) {
-        const bool sure = vmin <= tlo[g];
-        anyhit[g] |= __ballot(sure);
-        // a query that already has a certain hit (in any earlier tile) needs no re-check entries
-        const unsigned long long hitq = anyhit[g] | (anyhit[g] >> 32);
-        detail = cand && !((hitq >> (lane & 31)) & 1ull);
+        anyhit[g] |= __ballot(vmin <= tlo[g]);
+        // a query that already has a certain hit (in any tile so far) needs no re-check entries;
+        // both lanes of a query (l, l + 32) see the union of their halves
+        const unsigned long long hit = anyhit[g] | (anyhit[g] >> 32);
+        cm &= ~((hit & 0xffffffffull) | (hit << 32));
       }
-      if (__ballot(detail) != 0ull) {   // wave-uniform; rare in mask mode
+      candm[g] = cm;
+      need |= cm;
+    }
+    if (need != 0ull) {   // wave-uniform; rare in mask mode
+#pragma unroll
+      for (int g = 0; g < QW; ++g) {
+        if (candm[g] == 0ull) continue;
+        const float16v &c = acc[g];
+        const bool detail = (candm[g] >> lane) & 1ull;
         if (detail) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
