@@ -226,6 +226,28 @@ int mlf_walkers_export(mlf_walkers *w, double *allu, double *allL, int64_t *gene
                        double *currentt, double *currentv, double *left, double *right,
                        uint8_t *searching_left, uint8_t *searching_right);
 
+/* ---- integrator bookkeeping on the host (no GPU involved) -----------------
+ * MultiCounter.passing_node of ultranest/netiter.py:721-855 for (nbootstraps + 1) counters, with the
+ * insertion-order U test of ultranest/ordertest.py.  member: [ncounters][nroots] uint8, row 0 all
+ * ones (reference MultiCounter.__init__ :611-621 draws it).  passing_node: the node (root id, value
+ * Li, values of its children) leaves the active set whose root ids / values are given; logwidth
+ * (ncounters) is what the reference appends to `logweights`; random_beta = the
+ * np.random.beta(1, nlive) draws when the counter was created with random != 0 (else NULL).
+ * state: scalars[10] = logZ, logZerr, logVolremaining, logZremainMax, logZremain, remainder_ratio,
+ * remainder_fraction, accumulator N, accumulator U, iterations; arrays of ncounters (any NULL). */
+typedef struct mlf_counter mlf_counter;
+int mlf_counter_create(mlf_counter **out, size_t nroots, size_t ncounters, const uint8_t *member,
+                       int random, int check_insertion_order);
+int mlf_counter_destroy(mlf_counter *c);
+int mlf_counter_reset(mlf_counter *c);
+int mlf_counter_passing_node(mlf_counter *c, int64_t rootid, double Li, size_t nchildren,
+                             const double *child_values, const int64_t *rootids,
+                             const double *parallel_values, size_t nparallel,
+                             const double *random_beta, double *logwidth);
+int mlf_counter_state(const mlf_counter *c, double *scalars, double *all_H, double *all_logZ,
+                      double *all_logVolremaining, double *all_logZremain, int64_t *runs,
+                      size_t runs_capacity, size_t *nruns);
+
 /* H3 -> T1 -> K1 with the index kept: d_idx[p] = first live point within radiussq (>= 0),
  * -1 = inside the ellipsoid but no neighbour, -2 = outside the wrapping ellipsoid. */
 int mlf_region_first_index_dev(mlf_region *r, const double *d_pts, size_t np, int64_t *d_idx,

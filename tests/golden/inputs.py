@@ -184,3 +184,36 @@ def slice_update_inputs(seed, popsize, d, nparams, npoints_busy):
     return dict(t=t, tleft=tleft, tright=tright, proposed_L=proposed_L, proposed_u=proposed_u,
                 proposed_p=proposed_p, worker_running=worker_running, status=status, allu=allu, allL=allL,
                 allp=allp, threshold=0.2)
+
+
+# ---------------------------------------------------------------- G10: tree + counters ----------
+
+def random_tree(seed, nroots, nnodes):
+    """A nested-sampling-like tree as plain lists: node k has value values[k] and the children
+    children[k] (indices); roots are nodes 0 .. nroots-1.  Mostly single-child chains with rising
+    values, some branchings (added live points) and some dead ends, like a reactive run."""
+    rs = np.random.RandomState(seed)
+    values = list(np.sort(rs.normal(size=nroots)) - 5.0)
+    rs.shuffle(values)
+    children = [[] for _ in range(nroots)]
+    active = list(range(nroots))
+    while len(values) < nnodes and active:
+        k = min(active, key=lambda i: values[i])
+        active.remove(k)
+        roll = rs.uniform()
+        nkids = 1 if roll < 0.93 else (2 if roll < 0.97 else 0)
+        for _ in range(nkids):
+            top = max(values[i] for i in active) if active else values[k] + 1
+            v = values[k] + (top - values[k]) * rs.uniform() + 1e-3 * rs.uniform()
+            values.append(float(v))
+            children.append([])
+            children[k].append(len(values) - 1)
+            active.append(len(values) - 1)
+    return np.array(values), children
+
+
+def build_nodes(cls, values, children, nroots):
+    nodes = [cls(value=float(v), id=i) for i, v in enumerate(values)]
+    for node, kids in zip(nodes, children):
+        node.children = [nodes[j] for j in kids]
+    return nodes[:nroots]

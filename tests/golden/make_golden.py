@@ -448,7 +448,53 @@ def g9(ref):
     save("g9_stepfuncs", **out)
 
 
-GROUPS = dict(g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9)
+# ------------------------------------------------------------------ G10 -----
+
+def explore(netiter, seed, nroots, nnodes, nbootstraps, random):
+    """Run the driver's explorer / counter loop (integrator.py:2650-2832) over a seeded tree."""
+    values, children = inputs.random_tree(seed, nroots, nnodes)
+    roots = inputs.build_nodes(netiter.TreeNode, values, children, nroots)
+    np.random.seed(seed)
+    explorer = netiter.BreadthFirstIterator(roots)
+    counter = netiter.MultiCounter(nroots=nroots, nbootstraps=nbootstraps, random=random, check_insertion_order=True)
+    trace = []
+    while True:
+        nxt = explorer.next_node()
+        if nxt is None:
+            break
+        rootid, node, (_, active_rootids, active_values, active_node_ids) = nxt
+        counter.passing_node(rootid, node, active_rootids, active_values)
+        trace.append([node.id, rootid, len(active_values), counter.logZ, counter.logZerr, counter.logVolremaining,
+                      counter.logZremain, counter.logZremainMax, counter.remainder_ratio, counter.remainder_fraction,
+                      len(counter.insertion_order_accumulator), counter.insertion_order_accumulator.zscore])
+        explorer.expand_children_of(rootid, node)
+    return dict(trace=np.array(trace, dtype=float), logweights=np.array(counter.logweights),
+                istail=np.array(counter.istail), all_logZ=np.array(counter.all_logZ), all_H=np.array(counter.all_H),
+                all_logVolremaining=np.array(counter.all_logVolremaining), rootids=np.array(counter.rootids),
+                runs=np.array(counter.insertion_order_runs, dtype=np.int64), logZ_bs=np.float64(counter.logZ_bs),
+                logZerr_bs=np.float64(counter.logZerr_bs), next_random=np.float64(np.random.uniform()))
+
+
+G10_CASES = [(1001, 40, 900, 10, False), (1002, 400, 4000, 30, False), (1003, 25, 600, 5, True), (1004, 1, 50, 3, False)]
+
+
+def g10(ref):
+    """Integrator bookkeeping: BreadthFirstIterator + MultiCounter traces."""
+    import ultranest.netiter as netiter
+    out = {}
+    for seed, nroots, nnodes, nboot, random in G10_CASES:
+        with np.errstate(all="ignore"):
+            res = explore(netiter, seed, nroots, nnodes, nboot, random)
+        if len(res["trace"]) > 1000:       # keep the fixture small: every 16th iteration of the big case
+            res["logweights"] = res["logweights"][::16]
+            res["trace"] = res["trace"][::16]
+        for k, v in res.items():
+            out["c%d_%s" % (seed, k)] = v
+        print("  tree", seed, "iterations", len(res["trace"]), "logZ", res["trace"][-1][3], "runs", res["runs"])
+    save("g10_netiter", **out)
+
+
+GROUPS = dict(g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9, g10=g10)
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

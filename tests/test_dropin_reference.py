@@ -93,3 +93,31 @@ def test_population_slice_sampler_under_the_stock_driver(monkeypatch):
         results.append((int(res["ncall"]), int(res["niter"]), res["logz"], res["logzerr"], sampler.stepsampler.scale))
         assert np.isfinite(sampler.stepsampler.far_enough_fraction)
     assert results[0] == results[1], results
+
+
+def test_compiled_counter_under_the_stock_driver(monkeypatch):
+    """integrator.py's names ``MultiCounter`` / ``BreadthFirstIterator`` (imported from .netiter,
+    integrator.py:31) replaced by this package's: the C1 run must keep its trajectory (same ncall and
+    niter as fixture g8) with logz equal to rounding (libm vs numpy exp/log)."""
+    sys.path.insert(0, SCRATCH)
+    try:
+        import ultranest
+        import ultranest.integrator as integ
+    finally:
+        sys.path.remove(SCRATCH)
+    import ultranest_amd.netiter as mine
+    monkeypatch.setattr(integ, "MultiCounter", mine.MultiCounter)
+    monkeypatch.setattr(integ, "BreadthFirstIterator", mine.BreadthFirstIterator)
+    ndim, sigma = 5, 0.01
+    centers = np.ones(ndim) * 0.5
+
+    def loglike(theta):
+        return -0.5 * (((theta - centers) / sigma) ** 2).sum(axis=1) - 0.5 * np.log(2 * np.pi * sigma ** 2) * ndim
+
+    np.random.seed(1)
+    sampler = ultranest.ReactiveNestedSampler(["p%d" % i for i in range(ndim)], loglike,
+                                              transform=lambda x: x, vectorized=True, log_dir=None)
+    res = sampler.run(min_num_live_points=400, viz_callback=None, show_status=False)
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g8_c1_run.json")))
+    assert int(res["ncall"]) == gold["ncall"] and int(res["niter"]) == gold["niter"]
+    assert abs(res["logz"] - gold["logz"]) < 1e-9 and abs(res["logzerr"] - gold["logzerr"]) < 1e-9

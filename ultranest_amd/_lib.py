@@ -78,6 +78,11 @@ SIGNATURES = {
     "mlf_walkers_finish": [_vp, _dbl, _vp, _vp, _sz, _sz, ctypes.c_int64, _vp],
     "mlf_walkers_finish_dev": [_vp, _dbl, _int, _dbl, _dbl, _int, _vp, _dbl, ctypes.c_int64, _vp],
     "mlf_walkers_export": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlf_counter_create": [_vp, _sz, _sz, _vp, _int, _int],
+    "mlf_counter_destroy": [_vp],
+    "mlf_counter_reset": [_vp],
+    "mlf_counter_passing_node": [_vp, ctypes.c_int64, _dbl, _sz, _vp, _vp, _vp, _sz, _vp, _vp],
+    "mlf_counter_state": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mlf_region_inside_dev_timed": [_vp, _vp, _sz, _vp, _vp],
     "mlf_region_timing_collect": [_vp, _vp, _vp, _vp, _vp],
     "mlf_region_filter_info": [_vp, _sz, _vp, _vp, _vp],
