@@ -17,7 +17,7 @@ P = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs(P, exist_ok=True)
 
-HEADLINE_GRID = {"k_scan": 15625 * 256, "k_prep<": 3907 * 256, "k_prep2": 3907 * 256,
+HEADLINE_GRID = {"k_scan": 15625 * 256, "k_prep<": 3907 * 256, "k_prep2": 3907 * 256, "k_prep3": 512 * 256,
                  "k_filter<4, 4, false>": 1954 * 256, "k_recheck": 7813 * 64}     # 1e6 proposals / launch
 
 
