@@ -161,6 +161,11 @@ def main():
             dt = float(t.item())
         return dt, handle.timing_collect()
 
+    # single-sweep variant of the pre-filter (no compaction between live-point ranges), for the record
+    lib_mod.set_option("filter_phases", 0)
+    _, (ncalls_single, _, ms_scan_single, _) = timed_steps(max(3, args.steps // 4))
+    ms_scan_single /= max(ncalls_single, 1)
+    lib_mod.set_option("filter_phases", 1)
     elapsed, (ncalls, ms_prep, ms_scan, ms_rest) = timed_steps(args.steps)
     accept = float(mask.float().mean().item())
     filter_on, kdim, ntiles32 = handle.filter_info(NPROPOSALS)
@@ -246,7 +251,8 @@ def main():
         "accept_fraction": accept, "ellipsoid_pass_fraction": ell_pass,
         "kernel_ms": {"per-proposal stage (k_prep3: ellipsoid + whitening on the FP64 matrix cores + f16 quantisation)": prep_ms,
                       ("scan kernel (k_filter)" if filter_on else "scan kernel (k_scan)"): scan_ms,
-                      "rest of scan stage (exact re-check of uncertain pairs, routing, finalise)": rest_ms},
+                      "rest of scan stage (exact re-check of uncertain pairs, routing, finalise)": rest_ms,
+                      "scan kernel as a single sweep over all live points (phases off)": ms_scan_single},
         "roofline": roofline,
         "roofline_exact_scan": exact_roof,
         "roofline_prep": {"kernel": "k_prep3<13> (v_mfma_f64_16x16x4_f64)", "bound": "mfma_fp64", "unit": "TFLOP/s",

@@ -48,8 +48,11 @@ struct FilterCtx {
   int ks = 0, ntiles32 = 0;
   double sigma = 1.0, amax = 0.0;
   DevBuf stats, refF, qF, tlo, thi, route, best, counters, list, segcnt, gate2;
+  // phased sweep: two compacted query sets (ping-pong)
+  DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png, pflags, pblk;
   void release() {
-    DevBuf *b[] = {&stats, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2};
+    DevBuf *b[] = {&stats, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2,
+                   &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png, &pflags, &pblk};
     for (DevBuf *x : b) x->release();
     refs_ready = usable = false;
   }
@@ -58,6 +61,8 @@ struct FilterCtx {
 constexpr unsigned kFilterSegCap = 2048;
 bool g_filter_enabled = true;         // mlf_set_option("filter", 0/1)
 bool g_fused_prep = true;             // mlf_set_option("fused_prep", 0/1)
+bool g_filter_phases = true;          // mlf_set_option("filter_phases", 0/1): phased sweep with query compaction
+long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
 bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
 long long g_filter_min_queries = 2048;  // smaller batches go straight to the exact scan
 
@@ -213,7 +218,56 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   fa.seg_cap = cap;
   fa.seg_count = f.segcnt.as<unsigned>();
   fa.counters = f.counters.as<unsigned>();
-  CK(launch_filter(f.ks, fa, out_idx != nullptr, s));
+  // Phased sweep: the live-point tiles are split into nphase ranges; after each range the queries that
+  // are decided (certain hit) leave, the rest is compacted into fresh 32-query groups.  Every launch
+  // is sized for the worst case and reads the actual group count from device memory: no host sync.
+  int nphase = 1;
+  if (g_filter_phases && nq >= g_filter_phase_min_queries) nphase = f.ntiles32 >= 16 ? 2 : 1;
+  if (nphase > 1) {
+    for (int i = 0; i < 2; ++i) {
+      CK(f.pqF[i].reserve((size_t)nqpad * f.ks * 16 * 2));
+      CK(f.ptlo[i].reserve((size_t)nqpad * sizeof(float)));
+      CK(f.pthi[i].reserve((size_t)nqpad * sizeof(float)));
+      CK(f.pmap[i].reserve((size_t)nqpad * sizeof(int)));
+    }
+    CK(f.png.reserve(2 * sizeof(unsigned)));
+    CK(f.pflags.reserve((size_t)nqpad));
+    CK(f.pblk.reserve(((size_t)nqpad / 256 + 2) * sizeof(unsigned)));
+  }
+  for (int ph = 0; ph < nphase; ++ph) {
+    fa.tile0 = (int)((long long)f.ntiles32 * ph / nphase);
+    fa.tile1 = (int)((long long)f.ntiles32 * (ph + 1) / nphase);
+    fa.append = ph > 0;
+    if (ph > 0) {   // compact the undecided queries of the previous set into set (ph - 1) & 1
+      const int dst = (ph - 1) & 1, src = ph & 1;
+      PhaseArgs pa{};
+      pa.qF_src = ph == 1 ? f.qF.p : f.pqF[src].p;
+      pa.tlo_src = ph == 1 ? f.tlo.as<float>() : f.ptlo[src].as<float>();
+      pa.thi_src = ph == 1 ? f.thi.as<float>() : f.pthi[src].as<float>();
+      pa.qmap_src = ph == 1 ? nullptr : f.pmap[src].as<int>();
+      pa.ngroups_src = ph == 1 ? nullptr : f.png.as<unsigned>() + src;
+      pa.qF_dst = f.pqF[dst].p;
+      pa.tlo_dst = f.ptlo[dst].as<float>();
+      pa.thi_dst = f.pthi[dst].as<float>();
+      pa.qmap_dst = f.pmap[dst].as<int>();
+      pa.ngroups_dst = f.png.as<unsigned>() + dst;
+      pa.nslots_max = nqpad;
+      pa.nq = nq;
+      pa.route = f.route.as<uint8_t>();
+      pa.best = f.best.as<int>();
+      pa.ks = f.ks;
+      pa.flags = f.pflags.as<uint8_t>();
+      pa.blk = f.pblk.as<unsigned>();
+      launch_phase_compact(pa, s);
+      CK(hipGetLastError());
+      fa.qF = f.pqF[dst].p;
+      fa.tlo = f.ptlo[dst].as<float>();
+      fa.thi = f.pthi[dst].as<float>();
+      fa.qmap = f.pmap[dst].as<int>();
+      fa.ngroups_dev = f.png.as<unsigned>() + dst;
+    }
+    CK(launch_filter(f.ks, fa, out_idx != nullptr, s));
+  }
   if (ev_after_filter) CK(hipEventRecord(ev_after_filter, s));
   RecheckArgs ra{};
   ra.list = f.list.as<unsigned long long>();
@@ -575,6 +629,14 @@ int mlf_set_option(const char *name, long long value) {
   }
   if (!strcmp(name, "fused_prep")) {
     g_fused_prep = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "filter_phase_min_queries")) {
+    g_filter_phase_min_queries = value;
+    return 0;
+  }
+  if (!strcmp(name, "filter_phases")) {
+    g_filter_phases = value != 0;
     return 0;
   }
   if (!strcmp(name, "prep_matrix")) {

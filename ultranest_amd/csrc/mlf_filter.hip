@@ -34,6 +34,7 @@
 //   contiguous, perfectly coalesced 1 KiB read.
 #include "mlf_filter.hpp"
 #include "mlf_filter_dev.hpp"
+#include "mlf_sample.hpp"
 
 #include <math.h>
 
@@ -217,7 +218,11 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long g0 = wave * QW;  // first query group of this wave
-  if (g0 >= a.ngroups) return;
+  const long long ngroups = a.ngroups_dev ? (long long)*a.ngroups_dev : a.ngroups;
+  if (g0 >= ngroups) {
+    if (lane == 0 && !a.append) a.seg_count[wave] = 0;
+    return;
+  }
 
   const half8 *qF = reinterpret_cast<const half8 *>(a.qF);
   const half8 *refF = reinterpret_cast<const half8 *>(a.refF);
@@ -228,31 +233,32 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
   unsigned long long anyhit[QW];
 #pragma unroll
   for (int g = 0; g < QW; ++g) {
-    const long long grp = (g0 + g < a.ngroups) ? g0 + g : a.ngroups - 1;  // clamp (results discarded)
+    const long long grp = (g0 + g < ngroups) ? g0 + g : ngroups - 1;  // clamp (results discarded)
 #pragma unroll
     for (int s = 0; s < KS; ++s) bq[g][s] = qF[((size_t)grp * KS + s) * 64 + lane];
     const long long qi = grp * 32 + (lane & 31);
-    tlo[g] = (g0 + g < a.ngroups) ? a.tlo[qi] : -1.0f;
-    thi[g] = (g0 + g < a.ngroups) ? a.thi[qi] : -1.0f;
+    tlo[g] = (g0 + g < ngroups) ? a.tlo[qi] : -1.0f;
+    thi[g] = (g0 + g < ngroups) ? a.thi[qi] : -1.0f;
     first[g] = kNone;
     anyhit[g] = 0ull;
   }
   const int rowbase = 4 * (lane >> 5);
-  unsigned cursor = 0;                                           // wave-uniform
+  unsigned cursor = a.append ? a.seg_count[wave] : 0u;           // wave-uniform
   unsigned long long *seg = a.list + (size_t)wave * a.seg_cap;   // this wave's list segment
 
   half8 af[KS];
   // Waves start at different live-point tiles (results are order independent): all waves
   // sweeping the same 4 KB tile at the same moment would queue on one L2 channel.
-  const int tstart = (int)(((long long)blockIdx.x * 37) % a.ntiles32);   // one sweep order per workgroup: its 4 waves share L1 lines
+  const int ntl = a.tile1 - a.tile0;   // tiles of this phase
+  const int tstart = a.tile0 + (int)(((long long)blockIdx.x * 37) % ntl);   // one sweep order per workgroup: its 4 waves share L1 lines
 #pragma unroll
   for (int s = 0; s < KS; ++s) af[s] = refF[((size_t)tstart * KS + s) * 64 + lane];
 
-  for (int it = 0; it < a.ntiles32; ++it) {
+  for (int it = 0; it < ntl; ++it) {
     int t = tstart + it;
-    if (t >= a.ntiles32) t -= a.ntiles32;
+    if (t >= a.tile1) t -= ntl;
     int tn = t + 1;
-    if (tn >= a.ntiles32) tn = 0;
+    if (tn >= a.tile1) tn = a.tile0;
     half8 an[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) an[s] = refF[((size_t)tn * KS + s) * 64 + lane];  // prefetch
@@ -329,8 +335,9 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
             const unsigned slot = cursor + below;
             if (band && slot < a.seg_cap) {
               const int idx = t * 32 + rowbase + (r & 3) + 8 * (r >> 2);
-              const unsigned long long qi = (unsigned long long)((g0 + g) * 32 + (lane & 31));
-              seg[slot] = (qi << 32) | (unsigned)idx;
+              const long long slot_q = (g0 + g) * 32 + (lane & 31);
+              const long long qi = a.qmap ? (long long)a.qmap[slot_q] : slot_q;
+              seg[slot] = qi >= 0 ? (((unsigned long long)qi << 32) | (unsigned)idx) : ~0ull;
             }
             cursor += (unsigned)__popcll(bm);
           }
@@ -343,8 +350,9 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
 
 #pragma unroll
   for (int g = 0; g < QW; ++g) {
-    if (g0 + g >= a.ngroups) continue;
-    const long long qi = (g0 + g) * 32 + (lane & 31);
+    if (g0 + g >= ngroups) continue;
+    const long long slot_q = (g0 + g) * 32 + (lane & 31);
+    const long long qi = a.qmap ? (long long)a.qmap[slot_q] : slot_q;
     int res;
     if (FIRST) {
       const int other = __shfl_xor(first[g], 32);
@@ -353,12 +361,82 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
       const unsigned long long m = anyhit[g] | (anyhit[g] >> 32);
       res = ((m >> (lane & 31)) & 1ull) ? 0 : kNone;
     }
-    if (lane < 32 && qi < a.nq && res != kNone) a.best[qi] = res;
+    if (lane < 32 && qi >= 0 && qi < a.nq && res != kNone) a.best[qi] = res;
   }
   if (lane == 0) {
     a.seg_count[wave] = cursor < a.seg_cap ? cursor : a.seg_cap;
     if (cursor > a.seg_cap) a.counters[1] = 1u;   // overflow: the exact scan redoes the batch
   }
+}
+
+// ---------------------------------------------------------------- phase compaction -------------
+// In mask mode a query with a certain hit is decided, in first-index mode every later tile can only
+// give a larger index: either way it leaves the sweep.  With 1-3 neighbours per accepted proposal the
+// first hit sits anywhere in the live set, so splitting the sweep into phases and compacting the
+// undecided queries in between removes ~40 % of the matrix work at N = 4000.
+__global__ __launch_bounds__(256) void k_phase_select(PhaseArgs a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.nslots_max) return;
+  const long long nslots = a.ngroups_src ? 32ll * (long long)*a.ngroups_src : a.nslots_max;
+  uint8_t keep = 0;
+  if (i < nslots) {
+    const long long q = a.qmap_src ? (long long)a.qmap_src[i] : i;
+    if (q >= 0 && q < a.nq && a.route[q] == 1 && a.best[q] == kNone) keep = 1;
+  }
+  a.flags[i] = keep;
+}
+
+__global__ __launch_bounds__(256) void k_phase_gather(PhaseArgs a) {
+  __shared__ unsigned wsum[4];
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool keep = i < a.nslots_max && a.flags[i] != 0;
+  const unsigned long long b = __ballot(keep);
+  if (lane == 0) wsum[wave] = (unsigned)__popcll(b);
+  __syncthreads();
+  unsigned base = a.blk[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const uint4 *src = reinterpret_cast<const uint4 *>(a.qF_src);
+  uint4 *dst = reinterpret_cast<uint4 *>(a.qF_dst);
+  const int KS = a.ks;
+  if (keep) {
+    const unsigned rank = base + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+    const long long gs = i >> 5, gd = rank >> 5;
+    const int rs = (int)(i & 31), rd = (int)(rank & 31);
+    for (int s = 0; s < KS; ++s) {
+      dst[((size_t)gd * KS + s) * 64 + rd] = src[((size_t)gs * KS + s) * 64 + rs];
+      dst[((size_t)gd * KS + s) * 64 + rd + 32] = src[((size_t)gs * KS + s) * 64 + rs + 32];
+    }
+    a.tlo_dst[rank] = a.tlo_src[i];
+    a.thi_dst[rank] = a.thi_src[i];
+    a.qmap_dst[rank] = a.qmap_src ? a.qmap_src[i] : (int)i;
+  }
+  // padding of the last group + the group count (first workgroup)
+  if (blockIdx.x == 0) {
+    const unsigned total = a.blk[(a.nslots_max + 255) / 256];
+    const unsigned ngroups = (total + 31) / 32;
+    if (threadIdx.x == 0) *a.ngroups_dst = ngroups;
+    const unsigned slot = total + threadIdx.x;
+    if (threadIdx.x < 32 && slot < 32 * ngroups) {
+      const long long gd = slot >> 5;
+      const int rd = (int)(slot & 31);
+      for (int s = 0; s < KS; ++s) {
+        dst[((size_t)gd * KS + s) * 64 + rd] = make_uint4(0u, 0u, 0u, 0u);
+        dst[((size_t)gd * KS + s) * 64 + rd + 32] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      a.tlo_dst[slot] = -1.0f;
+      a.thi_dst[slot] = -1.0f;
+      a.qmap_dst[slot] = -1;
+    }
+  }
+}
+
+void launch_phase_compact(const PhaseArgs &a, hipStream_t s) {
+  if (a.nslots_max <= 0) return;
+  const unsigned grid = (unsigned)((a.nslots_max + 255) / 256);
+  hipLaunchKernelGGL(k_phase_select, dim3(grid), dim3(256), 0, s, a);
+  launch_mask_offsets(a.flags, a.nslots_max, a.blk, s);
+  hipLaunchKernelGGL(k_phase_gather, dim3(grid), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------- exact re-check --------------

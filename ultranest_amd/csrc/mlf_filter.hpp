@@ -18,7 +18,33 @@ struct FilterArgs {
   unsigned seg_cap;
   unsigned *seg_count;        // [nwaves]
   unsigned *counters;         // [1] overflow flag
+  // phased sweep (see filter_run): live-point tiles [tile0, tile1) only; queries may be a compacted
+  // subset: qmap[slot] = original query (-1 = padding), ngroups_dev = number of slot groups
+  int tile0, tile1;
+  const int *qmap;
+  const unsigned *ngroups_dev;
+  int append;                 // 1: keep the list entries of the earlier phases (cursor starts at seg_count)
 };
+
+// compaction of the queries that are still undecided after a phase
+struct PhaseArgs {
+  const void *qF_src;
+  void *qF_dst;
+  const float *tlo_src, *thi_src;
+  float *tlo_dst, *thi_dst;
+  const int *qmap_src;        // nullptr = identity (first compaction)
+  int *qmap_dst;
+  const unsigned *ngroups_src;   // nullptr: nslots_max / 32
+  unsigned *ngroups_dst;
+  long long nslots_max;       // worst-case number of source slots (multiple of 32)
+  long long nq;
+  const uint8_t *route;
+  const int *best;
+  int ks;
+  uint8_t *flags;             // [nslots_max]
+  unsigned *blk;              // [nslots_max / 256 + 2]
+};
+void launch_phase_compact(const PhaseArgs &a, hipStream_t s);
 
 struct RecheckArgs {
   const unsigned long long *list;

@@ -176,6 +176,13 @@ void launch_apply_pregate(const uint8_t *pregate, long long n, uint8_t *gate, ui
                      tlo, thi);
 }
 
+// blk[i] = number of set mask bytes before block i (256 entries per block), blk[nblk] = total
+void launch_mask_offsets(const uint8_t *mask, long long n, unsigned *blk, hipStream_t s) {
+  const int nblk = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(k_count_accepted, dim3(nblk), dim3(256), 0, s, mask, n, blk);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, blk, nblk);
+}
+
 void launch_compact(const double *pts, const uint8_t *mask, long long n, int d, unsigned *blk, double *out,
                     unsigned capacity, hipStream_t s) {
   const int nblk = (int)((n + 255) / 256);
