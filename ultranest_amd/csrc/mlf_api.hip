@@ -285,9 +285,11 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   ra.best = f.best.as<int>();
   launch_recheck(ra, filter_wave_count(f.ks, ngroups), s);
   CK(hipGetLastError());
-  // exact scan for (a) queries that do not fit binary16 and (b) everything if the list overflowed
-  for (int which = 2; which >= 1; --which) {
-    launch_route_gate(f.route.as<uint8_t>(), f.counters.as<unsigned>(), nq, which, f.gate2.as<uint8_t>(), s);
+  // answers of the filtered queries + the gate of the exact scan that follows: (a) queries that do not
+  // fit binary16 and (b) every filtered query if the uncertain-pair list overflowed
+  launch_filter_finalize(f.route.as<uint8_t>(), f.best.as<int>(), f.counters.as<unsigned>(), nq, out_mask,
+                         out_idx, f.gate2.as<uint8_t>(), s);
+  {
     ScanArgs a{};
     a.refT = refT;
     a.n = n;
@@ -306,8 +308,6 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     a.only_gated = 1;   // leave the outputs of ungated queries alone
     CK(launch_scan(dp, a, s));
   }
-  launch_filter_finalize(f.route.as<uint8_t>(), f.best.as<int>(), f.counters.as<unsigned>(), nq, out_mask,
-                         out_idx, s);
   CK(hipGetLastError());
   return 0;
 }

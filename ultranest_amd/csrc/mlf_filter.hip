@@ -468,12 +468,13 @@ __global__ __launch_bounds__(64) void k_recheck(RecheckArgs a) {
 // exact scan kernel.  If the uncertain-pair list overflowed, route 1 answers also come from the
 // exact scan (second launch, gate = overflow), so nothing is written here.
 __global__ void k_filter_finalize(const uint8_t *route, const int *best, const unsigned *counters,
-                                  long long nq, uint8_t *out_mask, long long *out_idx) {
+                                  long long nq, uint8_t *out_mask, long long *out_idx, uint8_t *exact_gate) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nq) return;
   const int rt = route[p];
-  if (rt == 2) return;
-  if (rt == 1 && counters[1] != 0u) return;
+  const bool to_scan = rt == 2 || (rt == 1 && counters[1] != 0u);
+  if (exact_gate) exact_gate[p] = to_scan ? 1 : 0;   // gate of the exact scan launch that follows
+  if (to_scan) return;
   const int b = best[p];
   const bool found = rt == 1 && b != kNone;
   if (out_mask) out_mask[p] = found ? 1 : 0;
@@ -486,7 +487,8 @@ __global__ void k_route_gate(const uint8_t *route, const unsigned *counters, lon
                              uint8_t *gate) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nq) return;
-  gate[p] = (which == 2) ? (route[p] == 2) : (route[p] == 1 && counters[1] != 0u);
+  const bool exact_only = route[p] == 2, redo = route[p] == 1 && counters[1] != 0u;
+  gate[p] = (which == 2) ? exact_only : (which == 1 ? redo : (exact_only || redo));
 }
 
 // ---------------------------------------------------------------- launchers -------------------
@@ -546,10 +548,10 @@ long long filter_wave_count(int ks, long long ngroups) {
 }
 
 void launch_filter_finalize(const uint8_t *route, const int *best, const unsigned *counters, long long nq,
-                            uint8_t *out_mask, long long *out_idx, hipStream_t s) {
+                            uint8_t *out_mask, long long *out_idx, uint8_t *exact_gate, hipStream_t s) {
   if (nq <= 0) return;
   hipLaunchKernelGGL(k_filter_finalize, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, route, best,
-                     counters, nq, out_mask, out_idx);
+                     counters, nq, out_mask, out_idx, exact_gate);
 }
 
 void launch_route_gate(const uint8_t *route, const unsigned *counters, long long nq, int which,
