@@ -222,7 +222,9 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   // are decided (certain hit) leave, the rest is compacted into fresh 32-query groups.  Every launch
   // is sized for the worst case and reads the actual group count from device memory: no host sync.
   int nphase = 1;
-  if (g_filter_phases && nq >= g_filter_phase_min_queries) nphase = f.ntiles32 >= 16 ? 2 : 1;
+  // worth it when the sweep is long compared with one compaction (~25 us + 40 us per 10^6 queries)
+  if (g_filter_phases && nq >= g_filter_phase_min_queries && (g_filter_phase_min_queries < 32768 || nq * f.ntiles32 >= 30000000ll))
+    nphase = f.ntiles32 >= 16 ? 2 : 1;
   if (nphase > 1) {
     for (int i = 0; i < 2; ++i) {
       CK(f.pqF[i].reserve((size_t)nqpad * f.ks * 16 * 2));
