@@ -494,7 +494,32 @@ def g10(ref):
     save("g10_netiter", **out)
 
 
-GROUPS = dict(g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9, g10=g10)
+# ------------------------------------------------------------------ G11 -----
+
+def g11(ref):
+    """Point-store file written by the reference's TextPointStore, and its pop order."""
+    import importlib
+    import ultranest.store as store
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    rows = importlib.import_module("test_store")._rows()
+    path = os.path.join(HERE, "g11_pointstore.tsv")
+    if os.path.exists(path):
+        os.remove(path)
+    s = store.TextPointStore(path, 8)
+    for i, row in enumerate(rows):
+        s.add(row, 10 + i)
+    s.close()
+    s = store.TextPointStore(path, 8)
+    pops = []
+    for Lmin in [-np.inf, -np.inf, -1.0, -0.5, -1.0, 0.0, 0.3, 0.5, 0.5, 2.0, -np.inf, 1e-300, 5.0] * 4:
+        idx, row = s.pop(Lmin)
+        pops.append([Lmin, -1 if idx is None else idx])
+    s.close()
+    np.savetxt(os.path.join(HERE, "g11_pointstore_pops.txt"), np.array(pops))
+    print("  wrote g11_pointstore.tsv", os.path.getsize(path), "bytes;", len(pops), "pops")
+
+
+GROUPS = dict(g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

@@ -110,7 +110,7 @@ def _draw(npoints, nbootstraps):
     return _draw_selection(np.random, npoints, nbootstraps)
 
 
-def refill_samples(region, tregion, transform, loglike, Lmin, ndraw):
+def refill_samples(region, tregion, transform, loglike, Lmin, ndraw, pointstore=None, ncall=0):
     """One proposal batch (reference `_refill_samples`, integrator.py:1773-1837 with
     draw_multiple=True): region.sample -> transform -> tregion.inside -> loglike on the accepted
     rows -> keep logl > Lmin.  Returns (u, v, logl, ncalls)."""
@@ -125,6 +125,9 @@ def refill_samples(region, tregion, transform, loglike, Lmin, ndraw):
     nc = int(accepted.sum())
     if nc > 0:
         logl[accepted] = loglike(v[accepted, :])
+    if pointstore is not None:   # every evaluated proposal: [Lmin, L, quality, u..., p...] (integrator.py:1937-1939)
+        for ui, vi, li in zip(u[accepted], v[accepted], logl[accepted]):
+            pointstore.add([Lmin, li, ndraw] + list(ui) + list(vi), ncall + nc)
     keep = logl > Lmin
     return u[keep, :], v[keep, :], logl[keep], nc
 
@@ -142,8 +145,11 @@ class StaticNestedSampler(object):
 
     def __init__(self, x_dim, loglike, transform=None, num_live_points=400, ndraw=4096,
                  region_class=MLFriends, transform_layer_class=LocalAffineLayer, nbootstraps=30, seed=1,
-                 device_rng=None, stepsampler=None):
+                 device_rng=None, stepsampler=None, pointstore=None):
         self.x_dim = x_dim
+        # optional ultranest_amd.store point store: every likelihood evaluation is logged in the
+        # reference's row format, and stored points are replayed before new ones are drawn (resume)
+        self.pointstore = pointstore
         # optional population step sampler (ultranest_amd.popstepsampler): replaces region
         # rejection sampling by its __next__, called like the reference's driver does
         # (integrator.py:1839-1950)
@@ -165,8 +171,28 @@ class StaticNestedSampler(object):
         np.random.seed(self.seed)
         N = self.nlive
         u = np.random.uniform(size=(N, self.x_dim))
-        logl = np.asarray(self.loglike(self.transform(u)), dtype=float)
-        self.ncall += N
+        # initial live points: stored rows with threshold -inf are reused (reference integrator.py:1501),
+        # the rest is evaluated and logged as [-inf, L, 0, u, p] (:1556)
+        stored = []
+        if self.pointstore is not None:
+            while len(stored) < N:
+                _, row = self.pointstore.pop(-np.inf)
+                if row is None:
+                    break
+                stored.append(np.asarray(row, dtype=float))
+        nold = len(stored)
+        logl = np.empty(N)
+        if nold:
+            rows = np.array(stored)
+            u[:nold] = rows[:, 3:3 + self.x_dim]
+            logl[:nold] = rows[:, 1]
+        if nold < N:
+            v_new = self.transform(u[nold:])
+            logl[nold:] = np.asarray(self.loglike(v_new), dtype=float)
+            self.ncall += N - nold
+            if self.pointstore is not None:
+                for ui, vi, li in zip(u[nold:], np.asarray(v_new), logl[nold:]):
+                    self.pointstore.add([-np.inf, li, 0.0] + list(ui) + list(vi), self.ncall)
         logz = -np.inf
         h_terms = []
         logvol = 0.0
@@ -206,7 +232,14 @@ class StaticNestedSampler(object):
                     newu, newl = pending_u[0], pending_l[0]
                     pending_u, pending_l = pending_u[1:], pending_l[1:]
                     break
-                nu, nv, nl, nc = refill_samples(region, None, self.transform, self.loglike, Lmin, self.ndraw)
+                if self.pointstore is not None and not self.pointstore.stack_empty:
+                    _, row = self.pointstore.pop(Lmin)       # resume: replay stored evaluations first
+                    if row is not None:
+                        pending_u = np.array([row[3:3 + self.x_dim]])
+                        pending_l = np.array([row[1]])
+                        continue
+                nu, nv, nl, nc = refill_samples(region, None, self.transform, self.loglike, Lmin, self.ndraw,
+                                                pointstore=self.pointstore, ncall=self.ncall)
                 self.ncall += nc
                 self.ncall_region += self.ndraw
                 pending_u, pending_l = nu, nl
