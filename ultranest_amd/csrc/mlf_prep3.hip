@@ -42,8 +42,11 @@ __device__ __forceinline__ double quad_sum(double v) {   // sum over lanes l, l^
   return v;
 }
 
+// instantiated k-step counts are 1,2,3,4,5,6,8,10,13,16: an instance NK serves 4 prev(NK) < d <= 4 NK
+constexpr int prev_ksteps(int nk) { return nk == 16 ? 13 : nk == 13 ? 10 : nk == 10 ? 8 : nk == 8 ? 6 : nk - 1; }
+
 constexpr int kTileRowHalfs = 136;   // binary16 columns per proposal in the transpose buffer (128 + pad)
-constexpr int kWaveBufBytes = 8704;  // per-wave staging: 16 rows x <= 132 dwords, or 16 x 136 binary16
+constexpr int kWaveBufBytes = 9216;  // per-wave staging: 16 rows x <= 66 doubles + 64 spare doubles, or 16 x 136 binary16
 
 }  // namespace
 
@@ -101,20 +104,30 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
   // column e % d (row stride xs2 doubles)
   const int xs2 = a.xstride;                 // doubles per staged row; 2 * xs2 = 4 mod 8 dwords
   const int nelem = 16 * d;
+  // elements past the tile (16 d is not a multiple of 64) go to a spare slot behind the rows: the
+  // stores need no predicate
+  const int xdummy = 16 * xs2 + lane;
   int xoff[NK];
 #pragma unroll
   for (int i = 0; i < NK; ++i) {
     const int e = lane + 64 * i;
     const int rr = e / d;
-    xoff[i] = e < nelem ? rr * xs2 + (e - rr * d) : -1;
+    xoff[i] = e < nelem ? rr * xs2 + (e - rr * d) : xdummy;
   }
+  const long long total = a.np * (long long)d;
   auto load_tile = [&](long long tile, double *x) {
     const long long base = tile * 16 * (long long)d;
-    const long long total = a.np * (long long)d;
+    if (base + 64 * NK <= total) {   // wave-uniform: the whole 64 NK window is inside the batch
 #pragma unroll
-    for (int i = 0; i < NK; ++i) {
-      const long long g = base + lane + 64 * i;
-      x[i] = (xoff[i] >= 0 && tile < ntiles && g < total) ? a.pts[g] : 0.0;
+      for (int i = 0; i < NK; ++i) x[i] = a.pts[base + lane + 64 * i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NK; ++i) {   // clamped address + select: no branch around the load
+        const long long g = base + lane + 64 * i;
+        const bool ok = g < total;
+        const double v = a.pts[ok ? g : total - 1];
+        x[i] = ok ? v : 0.0;
+      }
     }
   };
 
@@ -134,14 +147,14 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
       // redistribute: coalesced order -> operand order
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int i = 0; i < NK; ++i)
-        if (xoff[i] >= 0) xbuf[xoff[i]] = xcur[i];
+      for (int i = 0; i < NK; ++i) xbuf[xoff[i]] = xcur[i];
       __builtin_amdgcn_wave_barrier();
       double xop[NK];
 #pragma unroll
       for (int ks = 0; ks < NK; ++ks) {
         const int k = 4 * ks + kq;
-        xop[ks] = (k < d) ? xbuf[pl * xs2 + k] : 0.0;
+        // columns below 4 prev(NK) + 1 exist for every d this instance serves
+        xop[ks] = (4 * ks + 3 < 4 * prev_ksteps(NK) + 1 || k < d) ? xbuf[pl * xs2 + k] : 0.0;
       }
       __builtin_amdgcn_wave_barrier();
       load_tile(sub < 3 ? tile + 1 : (t4 + nwaves) * 4, xcur);   // prefetch
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
         dw[ks] = 0.0;
         {
           const int k = 4 * ks + kq;
-          const bool ok = live && k < d;
+          const bool ok = 4 * ks + 3 < 4 * prev_ksteps(NK) + 1 || k < d;   // rows past the batch carry zeros and are discarded
           const double x = xop[ks];
           double w = x;
           if (WRAP && ok && a.do_tr) {
@@ -232,12 +245,16 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
         }
       }
       if (inside) {
+        double *tp = a.t_out + p * a.t_ldq + (long long)kq * a.t_ldk;   // coordinate kq; +4 coordinates per step
+        const long long step4 = 4 * a.t_ldk;
 #pragma unroll
         for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int c = 16 * ct + kq + 4 * r;
-            if (c < d) a.t_out[p * a.t_ldq + (long long)c * a.t_ldk] = t[ct][r];
+            constexpr int kAlways = 4 * prev_ksteps(NK) + 1;   // coordinates below this exist for every d of this instance
+            const int cbase = 16 * ct + 4 * r;                   // + kq (0..3)
+            if (cbase + 3 < kAlways || cbase + kq < d) *tp = t[ct][r];
+            tp += step4;
           }
       }
       if (!quant) continue;
@@ -254,7 +271,8 @@ __global__ __launch_bounds__(256, 2) void k_prep3(Prep3Args a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int c = 16 * ct + kq + 4 * r;
-            if (c < d) {
+            constexpr int kAlwaysQ = 4 * prev_ksteps(NK) + 1;
+            if (16 * ct + 4 * r + 3 < kAlwaysQ || c < d) {
               const double x = sigma * (t[ct][r] - c_stat[c]);
               if (!(fabs(x) <= 16000.0)) fits = false;   // NaN lands here too
               nbn2 = __builtin_fma(x, x, nbn2);
