@@ -268,6 +268,9 @@ int mlf_region_inside_dev_timed(mlf_region *r, const double *d_pts, size_t np, u
                                 void *stream);
 int mlf_region_timing_collect(mlf_region *r, int *ncalls, double *ms_prep, double *ms_scan,
                               double *ms_rest);
+/* k_filter launches of the timed calls since the last collect: their number and summed duration
+ * (events bracket each launch on `stream`; the compaction kernels between phases are excluded) */
+int mlf_region_timing_filter_launches(mlf_region *r, int *nlaunches, double *ms_total);
 /* whether a batch of np proposals takes the MFMA pre-filter, and its GEMM shape (K columns per pair,
  * number of 32-row live-point tiles) */
 int mlf_region_filter_info(mlf_region *r, size_t np, int *active, int *kdim, int *ntiles32);

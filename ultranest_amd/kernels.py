@@ -236,6 +236,12 @@ class DeviceRegion(object):
                                                    ctypes.byref(c)))
         return n.value, a.value, b.value, c.value
 
+    def timing_filter_launches(self):
+        """(number of k_filter launches, their summed ms) of the timed calls since the last collect"""
+        n, ms = ctypes.c_int(0), ctypes.c_double(0)
+        check(_lib.lib().mlf_region_timing_filter_launches(self._h, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
     def filter_info(self, npts):
         """(filter active for this batch size, K columns of the f16 GEMM, number of 32-row live tiles)"""
         act, k, t = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
