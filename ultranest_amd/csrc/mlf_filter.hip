@@ -374,16 +374,20 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
 // give a larger index: either way it leaves the sweep.  With 1-3 neighbours per accepted proposal the
 // first hit sits anywhere in the live set, so splitting the sweep into phases and compacting the
 // undecided queries in between removes ~40 % of the matrix work at N = 4000.
-__global__ __launch_bounds__(256) void k_phase_select(PhaseArgs a) {
+__global__ __launch_bounds__(256) void k_phase_select(PhaseArgs a) {   // flags + per-workgroup counts
+  __shared__ unsigned wsum[4];
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.nslots_max) return;
   const long long nslots = a.ngroups_src ? 32ll * (long long)*a.ngroups_src : a.nslots_max;
-  uint8_t keep = 0;
+  bool keep = false;
   if (i < nslots) {
     const long long q = a.qmap_src ? (long long)a.qmap_src[i] : i;
-    if (q >= 0 && q < a.nq && a.route[q] == 1 && a.best[q] == kNone) keep = 1;
+    keep = q >= 0 && q < a.nq && a.route[q] == 1 && a.best[q] == kNone;
   }
-  a.flags[i] = keep;
+  if (i < a.nslots_max) a.flags[i] = keep ? 1 : 0;
+  const unsigned long long b = __ballot(keep);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (unsigned)__popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) a.blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 __global__ __launch_bounds__(256) void k_phase_gather(PhaseArgs a) {
@@ -435,7 +439,7 @@ void launch_phase_compact(const PhaseArgs &a, hipStream_t s) {
   if (a.nslots_max <= 0) return;
   const unsigned grid = (unsigned)((a.nslots_max + 255) / 256);
   hipLaunchKernelGGL(k_phase_select, dim3(grid), dim3(256), 0, s, a);
-  launch_mask_offsets(a.flags, a.nslots_max, a.blk, s);
+  launch_scan_counts(a.blk, (int)grid, s);
   hipLaunchKernelGGL(k_phase_gather, dim3(grid), dim3(256), 0, s, a);
 }
 

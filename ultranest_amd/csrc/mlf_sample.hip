@@ -176,6 +176,11 @@ void launch_apply_pregate(const uint8_t *pregate, long long n, uint8_t *gate, ui
                      tlo, thi);
 }
 
+// exclusive scan of nblk per-block counts in place, total -> blk[nblk]
+void launch_scan_counts(unsigned *blk, int nblk, hipStream_t s) {
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, blk, nblk);
+}
+
 // blk[i] = number of set mask bytes before block i (256 entries per block), blk[nblk] = total
 void launch_mask_offsets(const uint8_t *mask, long long n, unsigned *blk, hipStream_t s) {
   const int nblk = (int)((n + 255) / 256);

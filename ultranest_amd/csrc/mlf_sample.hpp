@@ -12,6 +12,7 @@ void launch_generate_ball(double *z, long long n, int d, double enlarge, unsigne
 void launch_center_and_cube(double *w, long long n, int d, const double *center, uint8_t *in_cube, hipStream_t s);
 void launch_apply_pregate(const uint8_t *pregate, long long n, uint8_t *gate, uint8_t *route, float *tlo,
                           float *thi, hipStream_t s);
+void launch_scan_counts(unsigned *blk, int nblk, hipStream_t s);
 void launch_mask_offsets(const uint8_t *mask, long long n, unsigned *blk, hipStream_t s);
 // blk: (ceil(n/256) + 1) counters; after the call blk[ceil(n/256)] holds the number of accepted rows
 void launch_compact(const double *pts, const uint8_t *mask, long long n, int d, unsigned *blk, double *out,
