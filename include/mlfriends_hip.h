@@ -147,8 +147,14 @@ int mlf_loglike_dev(int kind, const double *d_params, size_t d, size_t n, const 
  * `offset`; the nsamples proposals go through the region's membership pipeline on the device and
  * only the accepted rows (at most `capacity`, in draw order) are copied to `out`.  The random
  * stream differs from numpy's, so agreement with the reference is statistical.
- * mlf_region_set_axes provides ellipsoid_axes_T (d x d, reference :1232-1233) for method 1. */
+ * mlf_region_set_axes provides ellipsoid_axes_T (d x d, reference :1232-1233) for method 1.
+ * Methods 2 and 3 draw in whitened space: 2 = uniform in the padded bounding box of the live points
+ * (sample_from_transformed_boundingbox :1114-1133), 3 = around random live points, thinned by the
+ * number of balls containing the draw (sample_from_points :1072-1094); both are untransformed with
+ * invT (AffineLayer.untransform :745-752), cube- and ellipsoid-tested.  mlf_region_set_sampling_data
+ * provides invT (d x d) and bbox_lo / bbox_hi (reference :983-984). */
 int mlf_region_set_axes(mlf_region *r, const double *axes_T);
+int mlf_region_set_sampling_data(mlf_region *r, const double *invT, const double *bbox_lo, const double *bbox_hi);
 int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset,
                       double *out, size_t capacity, size_t *naccepted, uint64_t *next_offset);
 /* raw Philox blocks (counter = (i, 0, stream, 0), key = seed) for known-answer tests */

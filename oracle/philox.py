@@ -82,3 +82,40 @@ def ball_points(seed, offset, nsamples, ndim, enlarge):
     w = blocks(seed, 1, base + np.uint64(npairs))
     scale = np.sqrt(enlarge) * u01(w[:, 0], w[:, 1])**(1.0 / ndim) / np.sqrt((z**2).sum(axis=1))
     return z * scale[:, None], offset + nsamples * per
+
+
+def tbox_points(seed, offset, nsamples, ndim, lo, hi, pad):
+    """Method 2's whitened-space batch: low + (high - low) * U with low = lo - pad, high = hi + pad
+    (stream 5, two doubles per block) and the next counter offset."""
+    nelem = nsamples * ndim
+    nb = (nelem + 1) // 2
+    w = blocks(seed, 5, np.uint64(offset) + np.arange(nb, dtype=np.uint64))
+    flat = np.empty(2 * nb)
+    flat[0::2] = u01(w[:, 0], w[:, 1])
+    flat[1::2] = u01(w[:, 2], w[:, 3])
+    U = flat[:nelem].reshape(nsamples, ndim)
+    low, high = np.asarray(lo) - pad, np.asarray(hi) + pad
+    return low + (high - low) * U, offset + nb
+
+
+def around_points(seed, offset, nsamples, ndim, unormed, r2):
+    """Method 3's draw: (t-space proposals, thinning uniforms, chosen live indices, next offset);
+    stream 6, (npairs + 2) blocks per proposal.  libm tolerance like ball_points."""
+    npairs = (ndim + 1) // 2
+    per = npairs + 2
+    base = np.uint64(offset) + np.arange(nsamples, dtype=np.uint64) * np.uint64(per)
+    w0 = blocks(seed, 6, base)
+    which = ((w0[:, 0].astype(np.uint64) * np.uint64(len(unormed))) >> np.uint64(32)).astype(np.int64)
+    radial = u01(w0[:, 2], w0[:, 3])
+    w1 = blocks(seed, 6, base + np.uint64(1))
+    thin = u01(w1[:, 0], w1[:, 1])
+    z = np.empty((nsamples, 2 * npairs))
+    for j in range(npairs):
+        w = blocks(seed, 6, base + np.uint64(2 + j))
+        r = np.sqrt(-2.0 * np.log(u01(w[:, 0], w[:, 1])))
+        ang = 2.0 * np.pi * u01(w[:, 2], w[:, 3])
+        z[:, 2 * j] = r * np.cos(ang)
+        z[:, 2 * j + 1] = r * np.sin(ang)
+    z = z[:, :ndim]
+    f = radial**(1.0 / ndim) / np.sqrt((z**2).sum(axis=1)) * np.sqrt(r2)
+    return unormed[which] + z * f[:, None], thin, which, offset + nsamples * per

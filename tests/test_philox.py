@@ -156,3 +156,62 @@ def test_sampler_with_device_rng_recovers_gaussian_evidence():
     res = s.run(dlogz=0.1)
     want = d * np.log(sigma * np.sqrt(2 * np.pi))
     assert abs(res["logz"] - want) < 5 * res["logzerr"] + 0.1, (res, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [2, 7, 30])
+def test_transformed_boundingbox_sampling_matches_restatement(d):
+    """method 2: the restated Philox batch in whitened space pushed through the host pipeline of the
+    reference (neighbour test, untransform, cube, ellipsoid) gives the device's accepted points."""
+    region, DeviceRNG = _region("MLFriends", 400, d, 200 + d)
+    nsamples = 40000
+    region.device_rng = DeviceRNG(23)
+    region.device_rng.offset = 77
+    got = region.sample_from_transformed_boundingbox(nsamples)
+    pad = region.maxradiussq**0.5
+    tpts, nxt = philox.tbox_points(23, 77, nsamples, d, region.bbox_lo, region.bbox_hi, pad)
+    assert region.device_rng.offset == nxt
+    region.device_rng = None
+    near = region._near_live_points(tpts)
+    w = region.transformLayer.untransform(tpts[near])
+    ok = np.logical_and(w > 0, w < 1).all(axis=1)
+    ok[ok] = region.inside_ellipsoid(w[ok])
+    want = w[ok]
+    assert abs(len(got) - len(want)) <= max(2, len(want) // 2000)      # np.dot vs the device FMA chain at the borders
+    if len(got) == len(want):
+        assert np.allclose(got, want, rtol=0, atol=1e-12)
+    if d <= 7:
+        assert len(got) > 50
+    assert region.inside(got).mean() > 0.999 if len(got) else True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [2, 6])
+def test_sampling_from_points_matches_restatement_and_is_uniform(d):
+    """method 3: same draws as the restatement; thinning by multiplicity makes the accepted points
+    uniform over the union of balls -- compared with the bounding-box method on the same region."""
+    region, DeviceRNG = _region("MLFriends", 300, d, 300 + d)
+    nsamples = 60000
+    region.device_rng = DeviceRNG(31)
+    got = region.sample_from_points(nsamples)
+    tpts, thin, which, nxt = philox.around_points(31, 0, nsamples, d, region.unormed, region.maxradiussq)
+    assert region.device_rng.offset == nxt
+    from ultranest_amd import kernels
+    mult = np.empty(nsamples, dtype=np.int64)
+    kernels.count_nearby(region.unormed, tpts, region.maxradiussq, mult)
+    keep = thin * mult < 1
+    region.device_rng = None
+    w = region.transformLayer.untransform(tpts[keep])
+    ok = np.logical_and(w > 0, w < 1).all(axis=1)
+    ok[ok] = region.inside_ellipsoid(w[ok])
+    want = w[ok]
+    assert abs(len(got) - len(want)) <= max(3, len(want) // 500)       # libm vs device log / cos / pow at the ball borders
+    assert len(got) > 500
+    assert region.inside(got).mean() > 0.999
+    # uniformity: first and second moments agree with the (independent) bounding-box sampler
+    region.device_rng = DeviceRNG(32)
+    ref = region.sample_from_boundingbox(400000)
+    assert len(ref) > 1000
+    se = ref.std(axis=0) * np.sqrt(1.0 / len(ref) + 1.0 / len(got))
+    assert (np.abs(got.mean(axis=0) - ref.mean(axis=0)) < 5 * se).all()
+    assert np.allclose(got.std(axis=0), ref.std(axis=0), rtol=0.1)

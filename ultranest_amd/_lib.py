@@ -54,6 +54,7 @@ SIGNATURES = {
     "mlf_region_time_inside_dev": [_vp, _vp, _sz, _vp, _vp, _int, _vp, _vp],
     "mlf_region_first_index_dev": [_vp, _vp, _sz, _vp, _vp],
     "mlf_region_set_axes": [_vp, _vp],
+    "mlf_region_set_sampling_data": [_vp, _vp, _vp, _vp],
     "mlf_region_sample": [_vp, _int, _sz, ctypes.c_uint64, ctypes.c_uint64, _vp, _sz, _vp, _vp],
     "mlf_debug_philox": [ctypes.c_uint64, ctypes.c_uint, _sz, _vp],
     "mlf_within_unit_cube": [_vp, _sz, _sz, _vp],

@@ -399,7 +399,8 @@ struct mlf_region {
   DevBuf tq, gate, pts, mask, row;
   FilterCtx filter;
   DevBuf gen, gen2, cube, smask, blk, sout, ax_zero, ax_mat;   // device-side sampling
-  bool axes_ready = false;
+  DevBuf s_invT, s_lo, s_hi, s_thin, s_count;
+  bool axes_ready = false, sampling_ready = false;
   std::vector<hipEvent_t> events;  // 4 per timed call
   size_t events_used = 0;
 };
@@ -926,7 +927,8 @@ int mlf_region_destroy(mlf_region *r) {
   if (!r) return 0;
   DevBuf *bufs[] = {&r->refT, &r->refR, &r->lay_ctr, &r->lay_mat, &r->lay_T8, &r->ell_Lt, &r->ell_LtF, &r->lay_TtF, &r->wrap, &r->ell_ctr,
                     &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row,
-                    &r->gen, &r->gen2, &r->cube, &r->smask, &r->blk, &r->sout, &r->ax_zero, &r->ax_mat};
+                    &r->gen, &r->gen2, &r->cube, &r->smask, &r->blk, &r->sout, &r->ax_zero, &r->ax_mat,
+                    &r->s_invT, &r->s_lo, &r->s_hi, &r->s_thin, &r->s_count};
   for (DevBuf *b : bufs) b->release();
   for (hipEvent_t e : r->events) (void)hipEventDestroy(e);
   r->filter.release();
@@ -1144,15 +1146,140 @@ int mlf_region_set_axes(mlf_region *r, const double *axes_T) {
   return 0;
 }
 
+int mlf_region_set_sampling_data(mlf_region *r, const double *invT, const double *bbox_lo, const double *bbox_hi) {
+  if (!r || !invT || !bbox_lo || !bbox_hi) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (!r->ready || !r->use_scan) return fail_arg(MLF_E_STATE, "region has no live points set");
+  if (r->layer_kind != 0) return fail_arg(MLF_E_STATE, "t-space sampling needs an affine layer");
+  Ctx &c = g_ctx;
+  const size_t d = (size_t)r->d;
+  if (int rc = upload(r->s_invT, invT, d * d * sizeof(double), c.stream)) return rc;
+  if (int rc = upload(r->s_lo, bbox_lo, d * sizeof(double), c.stream)) return rc;
+  if (int rc = upload(r->s_hi, bbox_hi, d * sizeof(double), c.stream)) return rc;
+  CK(hipStreamSynchronize(c.stream));
+  r->sampling_ready = true;
+  return 0;
+}
+
+namespace {
+
+// neighbour test of t-space points against the resident live points (MFMA pre-filter when it applies)
+int region_scan_mask(mlf_region *r, const double *d_t, long long np, uint8_t *d_mask, hipStream_t s) {
+  if (filter_applies(r->filter, np, r->r2))
+    return filter_run(r->filter, r->refT.as<double>(), r->refR.as<double>(), r->n, r->npad, r->d, r->dp, d_t,
+                      (long long)r->d, 1, np, r->r2, nullptr, d_mask, nullptr, s, false);
+  ScanArgs a{};
+  a.refT = r->refT.as<double>();
+  a.n = r->n;
+  a.npad = r->npad;
+  a.ntiles = r->npad / kWave;
+  a.q = d_t;
+  a.ldq = r->d;
+  a.nq = np;
+  a.d = r->d;
+  a.r2 = r->r2;
+  a.mode = SCAN_MASK;
+  a.out_mask = d_mask;
+  CK(launch_scan(r->dp, a, s));
+  return 0;
+}
+
+// methods 2 and 3 of MLFriends.sample: proposals are born in t-space
+int region_sample_tspace(mlf_region *r, int method, long long n, uint64_t seed, uint64_t offset, double *out,
+                         size_t capacity, size_t *naccepted, uint64_t *next_offset) {
+  Ctx &c = g_ctx;
+  hipStream_t s = c.stream;
+  const int d = r->d;
+  const int nblk = (int)((n + 255) / 256);
+  CK(r->gen.reserve((size_t)n * d * sizeof(double)));
+  CK(r->gen2.reserve((size_t)n * d * sizeof(double)));
+  CK(r->smask.reserve((size_t)n));
+  CK(r->cube.reserve((size_t)n));
+  CK(r->blk.reserve(((size_t)nblk + 1) * sizeof(unsigned)));
+  double *t = r->gen.as<double>();
+  uint8_t *mask = r->smask.as<uint8_t>();
+  if (method == 2) {
+    launch_generate_tbox(t, n, d, r->s_lo.as<double>(), r->s_hi.as<double>(), std::sqrt(r->r2), seed, offset, s);
+    CK(hipGetLastError());
+    *next_offset = offset + (uint64_t)((n * d + 1) / 2);
+    if (int rc = region_scan_mask(r, t, n, mask, s)) return rc;
+  } else {
+    CK(r->s_thin.reserve((size_t)n * sizeof(double)));
+    CK(r->s_count.reserve((size_t)n * sizeof(long long)));
+    launch_generate_around_points(t, r->s_thin.as<double>(), n, d, r->refR.as<double>(), r->n, r->dp, r->r2, seed,
+                                  offset, s);
+    CK(hipGetLastError());
+    *next_offset = offset + (uint64_t)n * (uint64_t)((d + 1) / 2 + 2);
+    ScanArgs a{};   // multiplicity: how many balls contain the proposal (no early exit, reference :1087-1088)
+    a.refT = r->refT.as<double>();
+    a.n = r->n;
+    a.npad = r->npad;
+    a.ntiles = r->npad / kWave;
+    a.q = t;
+    a.ldq = d;
+    a.nq = n;
+    a.d = d;
+    a.r2 = r->r2;
+    a.mode = SCAN_COUNT;
+    a.out_idx = r->s_count.as<long long>();
+    CK(launch_scan(r->dp, a, s));
+    launch_thin_by_multiplicity(r->s_count.as<long long>(), r->s_thin.as<double>(), n, mask, s);
+    CK(hipGetLastError());
+  }
+  // survivors of the neighbour test, compacted; everything after works on those rows only
+  launch_compact(t, mask, n, d, r->blk.as<unsigned>(), r->gen2.as<double>(), (unsigned)n, s);
+  CK(hipGetLastError());
+  unsigned k1 = 0;
+  CK(hipMemcpyAsync(&k1, r->blk.as<unsigned>() + nblk, sizeof k1, hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  *naccepted = 0;
+  if (k1 == 0) return 0;
+  double *w = r->gen.as<double>();   // the t-space batch is not needed any more
+  launch_untransform_rows(r->gen2.as<double>(), k1, d, r->s_invT.as<double>(), r->lay_ctr.as<double>(),
+                          r->has_wrap ? r->wrap.as<double>() : nullptr, w, r->cube.as<uint8_t>(), s);
+  PrepArgs pa{};
+  pa.pts = w;
+  pa.np = k1;
+  pa.d = d;
+  pa.do_ell = 1;
+  pa.ell_ctr = r->ell_ctr.as<double>();
+  pa.ell_A = r->ell_A.as<double>();
+  pa.enlarge = r->enlarge;
+  pa.mask = mask;
+  CK(launch_prep(r->dp, pa, s));
+  launch_mask_and(mask, r->cube.as<uint8_t>(), k1, s);
+  CK(r->sout.reserve(capacity * (size_t)d * sizeof(double)));
+  const unsigned cap = capacity > 0xffffffffu ? 0xffffffffu : (unsigned)capacity;
+  launch_compact(w, mask, k1, d, r->blk.as<unsigned>(), r->sout.as<double>(), cap, s);
+  CK(hipGetLastError());
+  unsigned count = 0;
+  const int nblk1 = (int)((k1 + 255) / 256);
+  CK(hipMemcpyAsync(&count, r->blk.as<unsigned>() + nblk1, sizeof count, hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  const size_t take = count < cap ? count : cap;
+  if (take) {
+    CK(hipMemcpyAsync(out, r->sout.p, take * (size_t)d * sizeof(double), hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+  }
+  *naccepted = take;
+  return 0;
+}
+
+}  // namespace
+
 int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset,
                       double *out, size_t capacity, size_t *naccepted, uint64_t *next_offset) {
   if (!r || !out || !naccepted || !next_offset) return fail_arg(MLF_E_BADARG, "null pointer");
   if (!r->ready) return fail_arg(MLF_E_STATE, "region used before mlf_region_set");
-  if (method != 0 && method != 1) return fail_arg(MLF_E_BADARG, "method must be 0 (cube) or 1 (wrapping ellipsoid)");
+  if (method < 0 || method > 3)
+    return fail_arg(MLF_E_BADARG, "method must be 0 (cube), 1 (wrapping ellipsoid), 2 (t-space box) or 3 (live points)");
   if (method == 1 && !r->axes_ready) return fail_arg(MLF_E_STATE, "mlf_region_set_axes not called");
+  if (method >= 2 && (!r->use_scan || !r->sampling_ready))
+    return fail_arg(MLF_E_STATE, "mlf_region_set_sampling_data not called (or region without live points)");
   *naccepted = 0;
   *next_offset = offset;
   if (nsamples == 0 || capacity == 0) return 0;
+  if (method >= 2)
+    return region_sample_tspace(r, method, (long long)nsamples, seed, offset, out, capacity, naccepted, next_offset);
   Ctx &c = g_ctx;
   hipStream_t s = c.stream;
   const long long n = (long long)nsamples;

@@ -81,6 +81,99 @@ __global__ void k_center_and_cube(double *w, long long n, int d, const double *c
   in_cube[p] = ok ? 1 : 0;
 }
 
+// method 2 (reference mlfriends.pyx:1114-1133): uniform in the padded t-space bounding box,
+// low + (high - low) * U per coordinate with low = bbox_lo - pad, high = bbox_hi + pad
+__global__ void k_generate_tbox(double *t, long long nelem, int d, const double *lo, const double *hi, double pad,
+                                unsigned long long seed, unsigned long long offset) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // Philox block index
+  if (2 * b >= nelem) return;
+  unsigned w[4];
+  philox_block(seed, 5u, offset + (unsigned long long)b, w);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const long long e = 2 * b + j;
+    if (e < nelem) {
+      const int k = (int)(e % d);
+      const double low = lo[k] - pad, high = hi[k] + pad;
+      const double range = high - low;
+      const double scaled = range * u01(w[2 * j], w[2 * j + 1]);
+      t[e] = low + scaled;
+    }
+  }
+}
+
+// method 3 (reference :1072-1094): a random live point plus a uniform draw in its ball of radius sqrt(r2).
+// Philox stream 6, (npairs + 2) blocks per proposal: block 0 = live index + radial uniform + thinning uniform
+// (kept in thin_u), blocks 1.. = Box-Muller pairs.
+__global__ void k_generate_around_points(double *t, double *thin_u, long long n, int d, const double *refR, int nlive,
+                                         int dp, double r2, unsigned long long seed, unsigned long long offset) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int npairs = (d + 1) / 2;
+  const unsigned long long base = offset + (unsigned long long)p * (unsigned long long)(npairs + 2);
+  unsigned w0[4];
+  philox_block(seed, 6u, base, w0);
+  const unsigned which = below(w0[0], (unsigned)nlive);
+  unsigned w1[4];
+  philox_block(seed, 6u, base + 1, w1);
+  const double radial = u01(w0[2], w0[3]);
+  thin_u[p] = u01(w1[0], w1[1]);
+  double *row = t + p * d;
+  double norm2 = 0.0;
+  for (int j = 0; j < npairs; ++j) {
+    unsigned r4[4];
+    philox_block(seed, 6u, base + 2 + j, r4);
+    const double rad = sqrt(-2.0 * log(u01(r4[0], r4[1])));
+    const double ang = 2.0 * M_PI * u01(r4[2], r4[3]);
+    const double g0 = rad * cos(ang), g1 = rad * sin(ang);
+    row[2 * j] = g0;
+    norm2 += g0 * g0;
+    if (2 * j + 1 < d) {
+      row[2 * j + 1] = g1;
+      norm2 += g1 * g1;
+    }
+  }
+  const double f = pow(radial, 1.0 / (double)d) / sqrt(norm2) * sqrt(r2);
+  const double *a = refR + (size_t)which * dp;
+  for (int k = 0; k < d; ++k) row[k] = a[k] + row[k] * f;
+}
+
+// keep a proposal with probability 1 / multiplicity (reference :1089: uniform(high=multiplicity) < 1)
+__global__ void k_thin_by_multiplicity(const long long *count, const double *thin_u, long long n, uint8_t *mask) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const double m = (double)count[p];
+  mask[p] = (count[p] > 0 && thin_u[p] * m < 1.0) ? 1 : 0;
+}
+
+// AffineLayer.untransform (reference mlfriends.pyx:745-752, unwrap :538-545): w = t . invT + ctr with a
+// k-ascending FMA chain, circular axes rotated back; also the unit-cube test.  One thread per row
+// and coordinate block would be faster; the rows here are the (few) survivors of the scan.
+__global__ void k_untransform_rows(const double *t, long long n, int d, const double *invT, const double *ctr,
+                                   const double *wrap_shift, double *w, uint8_t *in_cube) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const double *row = t + p * d;
+  bool ok = true;
+  for (int c = 0; c < d; ++c) {
+    double acc = 0.0;
+    for (int k = 0; k < d; ++k) acc = __builtin_fma(row[k], invT[(size_t)k * d + c], acc);
+    double v = acc + ctr[c];
+    if (wrap_shift) {
+      const double sh = wrap_shift[c];
+      if (sh == sh) v = fmod(v + (1.0 - sh), 1.0);   // cut = 1 - shift
+    }
+    w[p * d + c] = v;
+    ok = ok && (v > 0.0) && (v < 1.0);
+  }
+  in_cube[p] = ok ? 1 : 0;
+}
+
+__global__ void k_mask_and(uint8_t *mask, const uint8_t *other, long long n) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) mask[p] = (mask[p] && other[p]) ? 1 : 0;
+}
+
 // proposals with pregate == 0 (outside the cube) leave the membership pipeline after the
 // per-proposal stage: gate 0 (exact scan skips them), route 0 ("not scanned" for the MFMA
 // pre-filter's finalise step) and thresholds -1 (no candidate pairs, no re-check entries)
@@ -168,6 +261,35 @@ void launch_generate_ball(double *z, long long n, int d, double enlarge, unsigne
 
 void launch_center_and_cube(double *w, long long n, int d, const double *center, uint8_t *in_cube, hipStream_t s) {
   hipLaunchKernelGGL(k_center_and_cube, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n, d, center, in_cube);
+}
+
+void launch_generate_tbox(double *t, long long n, int d, const double *lo, const double *hi, double pad,
+                          unsigned long long seed, unsigned long long offset, hipStream_t s) {
+  const long long nb = (n * d + 1) / 2;
+  hipLaunchKernelGGL(k_generate_tbox, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, t, n * d, d, lo, hi, pad, seed,
+                     offset);
+}
+
+void launch_generate_around_points(double *t, double *thin_u, long long n, int d, const double *refR, int nlive, int dp,
+                                   double r2, unsigned long long seed, unsigned long long offset, hipStream_t s) {
+  hipLaunchKernelGGL(k_generate_around_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t, thin_u, n, d, refR,
+                     nlive, dp, r2, seed, offset);
+}
+
+void launch_thin_by_multiplicity(const long long *count, const double *thin_u, long long n, uint8_t *mask, hipStream_t s) {
+  hipLaunchKernelGGL(k_thin_by_multiplicity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, count, thin_u, n, mask);
+}
+
+void launch_untransform_rows(const double *t, long long n, int d, const double *invT, const double *ctr,
+                             const double *wrap_shift, double *w, uint8_t *in_cube, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_untransform_rows, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, t, n, d, invT, ctr, wrap_shift, w,
+                     in_cube);
+}
+
+void launch_mask_and(uint8_t *mask, const uint8_t *other, long long n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_mask_and, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mask, other, n);
 }
 
 void launch_apply_pregate(const uint8_t *pregate, long long n, uint8_t *gate, uint8_t *route, float *tlo,

@@ -10,6 +10,14 @@ void launch_generate_cube(double *pts, long long nelem, unsigned long long seed,
 void launch_generate_ball(double *z, long long n, int d, double enlarge, unsigned long long seed,
                           unsigned long long offset, hipStream_t s);
 void launch_center_and_cube(double *w, long long n, int d, const double *center, uint8_t *in_cube, hipStream_t s);
+void launch_generate_tbox(double *t, long long n, int d, const double *lo, const double *hi, double pad,
+                          unsigned long long seed, unsigned long long offset, hipStream_t s);
+void launch_generate_around_points(double *t, double *thin_u, long long n, int d, const double *refR, int nlive, int dp,
+                                   double r2, unsigned long long seed, unsigned long long offset, hipStream_t s);
+void launch_thin_by_multiplicity(const long long *count, const double *thin_u, long long n, uint8_t *mask, hipStream_t s);
+void launch_untransform_rows(const double *t, long long n, int d, const double *invT, const double *ctr,
+                             const double *wrap_shift, double *w, uint8_t *in_cube, hipStream_t s);
+void launch_mask_and(uint8_t *mask, const uint8_t *other, long long n, hipStream_t s);
 void launch_apply_pregate(const uint8_t *pregate, long long n, uint8_t *gate, uint8_t *route, float *tlo,
                           float *thi, hipStream_t s);
 void launch_scan_counts(unsigned *blk, int nblk, hipStream_t s);

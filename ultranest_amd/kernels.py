@@ -210,6 +210,9 @@ class DeviceRegion(object):
     def set_axes(self, axes_T):
         check(_lib.lib().mlf_region_set_axes(self._h, ptr(f64(axes_T))))
 
+    def set_sampling_data(self, invT, bbox_lo, bbox_hi):
+        check(_lib.lib().mlf_region_set_sampling_data(self._h, ptr(f64(invT)), ptr(f64(bbox_lo)), ptr(f64(bbox_hi))))
+
     def sample(self, method, nsamples, seed, offset, capacity=None):
         """Device-side draw + membership test + compaction.  Returns (accepted rows (k, d), next offset)."""
         d = self._d

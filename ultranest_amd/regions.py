@@ -130,6 +130,7 @@ class _DeviceState(object):
         self.ell_center = None
         self.thresholds = None
         self.axes_T = None
+        self.sampling_data = None
 
     def sample(self, region, use_scan, method, nsamples):
         """Device-side draw + membership + compaction with the region's ``device_rng``."""
@@ -139,6 +140,13 @@ class _DeviceState(object):
             if self.axes_T is None or not np.array_equal(self.axes_T, axes_T):
                 handle.set_axes(axes_T)
                 self.axes_T = axes_T.copy()
+        if method >= 2:
+            layer = region.transformLayer
+            data = (np.asarray(layer.invT, dtype=float), np.asarray(region.bbox_lo, dtype=float),
+                    np.asarray(region.bbox_hi, dtype=float))
+            if self.sampling_data is None or not all(np.array_equal(a, b) for a, b in zip(self.sampling_data, data)):
+                handle.set_sampling_data(*data)
+                self.sampling_data = tuple(a.copy() for a in data)
         rng = region.device_rng
         pts, rng.offset = handle.sample(method, nsamples, rng.seed, rng.offset)
         return pts
@@ -325,6 +333,8 @@ class MLFriends(object):
     def sample_from_points(self, nsamples=100):
         """Pick live points at random, draw uniformly in their balls, thin by 1/multiplicity
         (reference :1072-1094)."""
+        if self._device_tspace():
+            return self._dev.sample(self, True, 3, nsamples)
         npoints, ndim = self.u.shape
         which = np.random.randint(npoints, size=nsamples)
         direction = np.random.normal(size=(nsamples, ndim))
@@ -348,6 +358,8 @@ class MLFriends(object):
 
     def sample_from_transformed_boundingbox(self, nsamples=100):
         """Uniform in the padded t-space bounding box (reference :1114-1133)."""
+        if self._device_tspace():
+            return self._dev.sample(self, True, 2, nsamples)
         ndim = self.u.shape[1]
         pad = self.maxradiussq**0.5
         tpts = np.random.uniform(self.bbox_lo - pad, self.bbox_hi + pad, size=(nsamples, ndim))
@@ -355,6 +367,10 @@ class MLFriends(object):
         ok = np.logical_and(w > 0, w < 1).all(axis=1)
         ok[ok] = self.inside_ellipsoid(w[ok])
         return w[ok, :]
+
+    def _device_tspace(self):
+        """Device-side t-space draws need the Philox stream and an affine layer (ctr, T, invT)."""
+        return self.device_rng is not None and np.ndim(getattr(self.transformLayer, "invT", 1)) == 2
 
     def _draw_in_ellipsoid(self, nsamples):
         ndim = self.u.shape[1]
