@@ -101,10 +101,52 @@ def cpu_baseline(region, pts_host, u):
     t0 = time.perf_counter()
     orc.maxradiussq_bootstrap(region.unormed, masks)
     boot_ms = (time.perf_counter() - t0) * 1e3 / 3 * NBOOT
-    return mask, dict(value=len(sample) / dt, unit="proposals/s", cores=1, kind="port",
+    parallel = cpu_baseline_parallel(region, sample, min(32, os.cpu_count() or 1))
+    return mask, dict(value=len(sample) / dt, unit="proposals/s", cores=1, kind="port", parallel=parallel,
                       sample="first %d proposals of the timed batch (%.1f s); oracle/mlfriends_oracle.c, gcc -O3 "
                              "-ffp-contract=off, 1 thread" % (len(sample), dt),
                       bootstrap30_ms=boot_ms, host_cores_available=os.cpu_count())
+
+
+_WORKER = """
+import sys, time, numpy as np
+sys.path.insert(0, %r)
+from oracle import oracle as orc
+z = np.load(sys.argv[1])
+orc.lib()
+t0 = time.perf_counter()
+orc.region_inside(z['pts'], z['unormed'], z['ctr'], z['T'], z['ectr'], z['einv'], float(z['enlarge']), float(z['r2']))
+print(time.perf_counter() - t0)
+"""
+
+
+def cpu_baseline_parallel(region, sample, nproc):
+    """The same oracle pass in `nproc` independent processes at once (the reference's `mpiexec -np k`
+    mode, docs/performance.rst:355-371, has no shared state in this path): host throughput when all
+    of them run concurrently, each on the same sample."""
+    import subprocess
+    import tempfile
+    if nproc <= 1:
+        return None
+    layer = region.transformLayer
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "sample.npz")
+        np.savez(path, pts=sample, unormed=region.unormed, ctr=layer.ctr, T=layer.T, ectr=region.ellipsoid_center,
+                 einv=region.ellipsoid_invcov, enlarge=region.enlarge, r2=region.maxradiussq)
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, "-c", _WORKER % ROOT, path], stdout=subprocess.PIPE, text=True)
+                 for _ in range(nproc)]
+        inner = []
+        for p in procs:
+            out, _ = p.communicate(timeout=300)
+            if p.returncode == 0:
+                inner.append(float(out.strip().splitlines()[-1]))
+        wall = time.perf_counter() - t0
+    if len(inner) != nproc:
+        return None
+    return dict(cores=nproc, value=nproc * len(sample) / max(inner), unit="proposals/s",
+                sample="%d processes, each the %d-proposal sample; slowest pass %.1f s, wall incl. start-up %.1f s"
+                       % (nproc, len(sample), max(inner), wall))
 
 
 def main():
