@@ -12,6 +12,7 @@ echo "== bench"; timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench.js
 echo "== step sampler bench (row f1)"; timeout 600 python scripts/walk_bench.py device > $O/walk_bench.log 2>&1; tail -3 $O/walk_bench.log
 echo "== device sampling bench (row f2)"; timeout 300 python scripts/sample_bench.py > $O/sample_bench.json 2> $O/sample_bench.err; tail -3 $O/sample_bench.err
 echo "== bench via torchrun (1 rank, RCCL init)"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu > $O/bench_torchrun.json 2> $O/bench_torchrun.err; echo "torchrun rc=$?"
+echo "== size check (P = 8e6, N = 2e5)"; timeout 600 python scripts/big_batch_check.py > $O/big_batch.json 2> $O/big_batch.err; tail -4 $O/big_batch.json
 echo "== config bench"; timeout 600 python scripts/config_bench.py > $O/config_bench.json 2> $O/config_bench.err; tail -2 $O/config_bench.err
 if [ "$1" != "noprof" ]; then
 cd /tmp && export TMPDIR=/tmp
