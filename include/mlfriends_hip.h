@@ -228,6 +228,14 @@ int mlf_walkers_finish(mlf_walkers *w, double Lmin, const double *pnew, const do
                        size_t nacc, size_t nparams, int64_t ringindex, double *rec);
 int mlf_walkers_finish_dev(mlf_walkers *w, double Lmin, int tkind, double ta, double tb, int lkind,
                            const double *aux, double sigma, int64_t ringindex, double *rec);
+/* Whole step on the device (Philox stream, resident likelihood): step_back, restarts from the live
+ * points uploaded by mlf_walkers_set_live (uniform among those with L > Lmin), ring index kept on the
+ * device, new slices, proposal, transform + likelihood, update, harvest -- one record back, one
+ * synchronisation.  rec has 10 + 2 d doubles: as above, then the ring index after the step. */
+int mlf_walkers_set_live(mlf_walkers *w, const double *us, const double *Ls, size_t nlive);
+int mlf_walkers_step_dev(mlf_walkers *w, double Lmin, double scale, int dirkind, double dirscale,
+                         uint64_t seed, uint64_t offset, int tkind, double ta, double tb, int lkind,
+                         const double *aux, double sigma, double *rec, uint64_t *next_offset);
 int mlf_walkers_export(mlf_walkers *w, double *allu, double *allL, int64_t *generation,
                        double *currentt, double *currentv, double *left, double *right,
                        uint8_t *searching_left, uint8_t *searching_right);

@@ -361,8 +361,10 @@ __global__ __launch_bounds__(64) void k_walk_diag(WalkState w, WalkLayer ly) {
   if (lane == 0) w.dist2[i] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_walk_harvest(WalkState w, long long ring, double r2, double *rec) {
+__global__ __launch_bounds__(256) void k_walk_harvest(WalkState w, long long ring_host, long long *ring_dev, double r2,
+                                                      double *rec) {
   __shared__ double part[256][5];
+  const long long ring = ring_dev ? *ring_dev : ring_host;
   double nc = 0, nmov = 0, nsucc = 0, nfar = 0, slog = 0;
   const double ref = sqrt(r2);
   for (int i = threadIdx.x; i < w.P; i += 256) {
@@ -411,6 +413,54 @@ __global__ __launch_bounds__(256) void k_walk_harvest(WalkState w, long long rin
       w.currentt[ring] = qnan();
     }
   }
+  if (threadIdx.x == 0 && ring_dev) {   // device-side ring index: advance past the harvested walker (shift(), :605-609)
+    const long long next = found ? (ring + 1) % w.P : ring;
+    *ring_dev = next;
+    rec[9 + w.d + w.nparams] = (double)next;
+  }
+}
+
+// setup_start on the device (popstepsampler.py:443-470): the ring index skips walkers that are being
+// restarted (unless all of them are), then every walker with generation < 0 starts from a random
+// live point above the threshold.  Philox stream 4, up to 64 blocks per walker (rejection of the
+// few live points at or below Lmin; a linear search is the fallback).
+__global__ __launch_bounds__(256) void k_walk_ring_shift(WalkState w, long long *ring) {
+  __shared__ int nstart[256];
+  int n = 0;
+  for (int i = threadIdx.x; i < w.P; i += 256) n += w.generation[i] < 0 ? 1 : 0;
+  nstart[threadIdx.x] = n;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) nstart[threadIdx.x] += nstart[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && nstart[0] > 0 && nstart[0] < w.P) {
+    long long r = *ring;
+    for (int guard = 0; guard < w.P && w.generation[r] < 0; ++guard) r = (r + 1) % w.P;
+    *ring = r;
+  }
+}
+
+__global__ void k_walk_restart_philox(WalkState w, const double *live, const double *Ls, int nlive, double Lmin,
+                                      unsigned long long seed, unsigned long long offset) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w.P || w.generation[i] >= 0) return;
+  int pick = -1;
+  for (int attempt = 0; attempt < 64 && pick < 0; ++attempt) {
+    unsigned r4[4];
+    philox_block(seed, 4u, offset + (unsigned long long)i * 64ull + attempt, r4);
+#pragma unroll
+    for (int j = 0; j < 4 && pick < 0; ++j) {
+      const int cand = (int)below(r4[j], (unsigned)nlive);
+      if (Ls[cand] > Lmin) pick = cand;
+    }
+  }
+  for (int j = 0; j < nlive && pick < 0; ++j)
+    if (Ls[j] > Lmin) pick = j;
+  if (pick < 0) return;   // no live point above the threshold: the walker stays unstarted
+  for (int k = 0; k < w.d; ++k) w.allu[((size_t)i * w.G) * w.d + k] = live[(size_t)pick * w.d + k];
+  w.allL[(size_t)i * w.G] = Ls[pick];
+  w.generation[i] = 0;
 }
 
 // ------------------------------------------------------------------ stateless forms ------------
@@ -590,6 +640,12 @@ void launch_walk_step_back(const WalkState &w, double Lmin, long long *gmax_scra
                      gmax_scratch, w.sl, w.sr, flags);
 }
 
+void launch_walk_restart_philox(const WalkState &w, const double *live, const double *Ls, int nlive, double Lmin,
+                                unsigned long long seed, unsigned long long offset, long long *ring, hipStream_t s) {
+  hipLaunchKernelGGL(k_walk_ring_shift, dim3(1), dim3(256), 0, s, w, ring);
+  hipLaunchKernelGGL(k_walk_restart_philox, grid_for(w.P, 64), dim3(64), 0, s, w, live, Ls, nlive, Lmin, seed, offset);
+}
+
 void launch_walk_start(const WalkState &w, const long long *idx, int n, const double *rows, const double *L,
                        hipStream_t s) {
   if (n <= 0) return;
@@ -631,8 +687,8 @@ void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStr
   if (layer.kind >= 0) hipLaunchKernelGGL(k_walk_diag, dim3(w.P), dim3(64), 0, s, w, layer);
 }
 
-void launch_walk_harvest(const WalkState &w, long long ring, double r2, double *rec, hipStream_t s) {
-  hipLaunchKernelGGL(k_walk_harvest, dim3(1), dim3(256), 0, s, w, ring, r2, rec);
+void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, hipStream_t s) {
+  hipLaunchKernelGGL(k_walk_harvest, dim3(1), dim3(256), 0, s, w, ring, ring_dev, r2, rec);
 }
 
 void launch_within_unit_cube(const double *u, int n, int d, uint8_t *out, hipStream_t s) {

@@ -80,7 +80,12 @@ void launch_walk_expand(const WalkState &w, const unsigned *blk, const double *p
 void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStream_t s);
 // rec: [0] harvested flag, [1] L, [2] left, [3] right, [4] nc, [5] nmovable, [6] nsuccess, [7] nfar,
 //      [8] sum log(dist/ref + 1e-10), [9 ..] u (d) then p (nparams)
-void launch_walk_harvest(const WalkState &w, long long ring, double r2, double *rec, hipStream_t s);
+// ring_dev != nullptr: the ring index lives on the device (read, advanced when a walker was harvested, and
+// reported in rec[9 + d + nparams])
+void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, hipStream_t s);
+// device-side setup_start: ring index skips restarting walkers, restarts draw live points with L > Lmin
+void launch_walk_restart_philox(const WalkState &w, const double *live, const double *Ls, int nlive, double Lmin,
+                                unsigned long long seed, unsigned long long offset, long long *ring, hipStream_t s);
 
 // ---- stateless forms on device arrays (the parity boundary of ultranest.stepfuncs) -------------
 void launch_within_unit_cube(const double *u, int n, int d, uint8_t *out, hipStream_t s);

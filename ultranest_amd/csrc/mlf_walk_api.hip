@@ -25,7 +25,8 @@ struct mlf_walkers {
   DevBuf allu, allL, generation, currentt, currentv, left, right, sl, sr, currentp;
   DevBuf unew, movable, acceptable, success, pnew, Lnew, dist2;
   DevBuf gmax, flags, snap, idx, rows, vals, vidx, vrows, unif, blk, compact, pc, Lc, rec, aux;
-  DevBuf axes, live, std, lay_ctr, lay_mat, lay_wrap;
+  DevBuf axes, live, std, lay_ctr, lay_mat, lay_wrap, liveL, ring;
+  bool have_liveL = false;
   int nlive = 0;
   bool have_axes = false, have_live = false, have_std = false;
   int layer_kind = -1;
@@ -114,7 +115,7 @@ int finish_common(mlf_walkers *w, double Lmin, int64_t ringindex, double *rec) {
   CK(w->rec.reserve(nrec * sizeof(double)));
   const WalkState st = state_of(w);
   launch_walk_update(st, Lmin, layer_of(w), s);
-  launch_walk_harvest(st, ringindex, w->r2, w->rec.as<double>(), s);
+  launch_walk_harvest(st, ringindex, nullptr, w->r2, w->rec.as<double>(), s);
   CK(hipGetLastError());
   if (int rc = download(rec, w->rec, nrec * sizeof(double), s)) return rc;
   CK(hipStreamSynchronize(s));
@@ -170,7 +171,7 @@ int mlf_walkers_destroy(mlf_walkers *w) {
                    &w->sr, &w->currentp, &w->unew, &w->movable, &w->acceptable, &w->success, &w->pnew, &w->Lnew,
                    &w->dist2, &w->gmax, &w->flags, &w->snap, &w->idx, &w->rows, &w->vals, &w->vidx, &w->vrows, &w->unif, &w->blk, &w->compact,
                    &w->pc, &w->Lc, &w->rec, &w->aux, &w->axes, &w->live, &w->std, &w->lay_ctr, &w->lay_mat,
-                   &w->lay_wrap};
+                   &w->lay_wrap, &w->liveL, &w->ring};
   for (DevBuf *b : all) b->release();
   delete w;
   return 0;
@@ -180,6 +181,7 @@ int mlf_walkers_reset(mlf_walkers *w) {
   if (!w) return ctx_fail_arg(MLF_E_BADARG, "null pointer");
   launch_walk_reset(state_of(w), ctx_stream());
   if (w->nparams) CK(hipMemsetAsync(w->currentp.p, 0xff, (size_t)w->P * w->nparams * sizeof(double), ctx_stream()));
+  if (w->ring.p) CK(hipMemsetAsync(w->ring.p, 0, 8, ctx_stream()));
   CK(hipGetLastError());
   w->proposed = false;
   return 0;
@@ -373,6 +375,63 @@ int mlf_walkers_finish_dev(mlf_walkers *w, double Lmin, int tkind, double ta, do
   launch_loglike(lkind, st.pnew, w->d, w->P, w->aux.as<double>(), sigma, st.Lnew, s);
   CK(hipGetLastError());
   return finish_common(w, Lmin, ringindex, rec);
+}
+
+int mlf_walkers_set_live(mlf_walkers *w, const double *us, const double *Ls, size_t nlive) {
+  if (!w || !us || !Ls) return ctx_fail_arg(MLF_E_BADARG, "null pointer");
+  if (nlive < 2) return ctx_fail_arg(MLF_E_BADARG, "at least two live points are needed");
+  hipStream_t s = ctx_stream();
+  if (int rc = upload(w->live, us, nlive * (size_t)w->d * 8, s)) return rc;
+  if (int rc = upload(w->liveL, Ls, nlive * 8, s)) return rc;
+  w->nlive = (int)nlive;
+  w->have_live = true;
+  w->have_liveL = true;
+  return 0;
+}
+
+int mlf_walkers_step_dev(mlf_walkers *w, double Lmin, double scale, int dirkind, double dirscale, uint64_t seed,
+                         uint64_t offset, int tkind, double ta, double tb, int lkind, const double *aux, double sigma,
+                         double *rec, uint64_t *next_offset) {
+  if (!w || !rec || !next_offset) return ctx_fail_arg(MLF_E_BADARG, "null pointer");
+  if (!w->have_liveL) return ctx_fail_arg(MLF_E_STATE, "mlf_walkers_set_live not called");
+  if (dirkind < 0 || dirkind > DIR_MIXTURE) return ctx_fail_arg(MLF_E_BADARG, "unknown direction kind");
+  if (tkind < 0 || tkind > 2 || lkind < 0 || lkind > 3) return ctx_fail_arg(MLF_E_BADARG, "unknown transform / likelihood kind");
+  if (lkind == 0 && !aux) return ctx_fail_arg(MLF_E_BADARG, "the Gaussian likelihood needs its centres");
+  const bool need_axes = dirkind == DIR_REGION_ORIENTED || dirkind == DIR_REGION_RANDOM || dirkind == DIR_MIXTURE;
+  if ((need_axes && !w->have_axes) || (dirkind == DIR_CUBE_ORIENTED_SCALED && !w->have_std))
+    return ctx_fail_arg(MLF_E_STATE, "mlf_walkers_set_direction_data has not provided what this direction kind needs");
+  if (int rc = ensure_params(w, (size_t)w->d)) return rc;
+  hipStream_t s = ctx_stream();
+  if (!w->ring.p) {
+    CK(w->ring.reserve(8));
+    CK(hipMemsetAsync(w->ring.p, 0, 8, s));
+  }
+  const size_t nrec = 10 + 2 * (size_t)w->d;
+  CK(w->rec.reserve(nrec * sizeof(double)));
+  if (aux)
+    if (int rc = upload(w->aux, aux, (size_t)w->d * 8, s)) return rc;
+  const WalkState st = state_of(w);
+  WalkDirData dd{};
+  dd.axes = w->axes.as<double>();
+  dd.live = w->live.as<double>();
+  dd.nlive = w->nlive;
+  dd.std = w->std.as<double>();
+  // one stream of kernels, one record back: step_back, restarts, new slices, proposal, likelihood, update, harvest
+  launch_walk_step_back(st, Lmin, w->gmax.as<long long>(), nullptr, s);
+  launch_walk_restart_philox(st, w->live.as<double>(), w->liveL.as<double>(), w->nlive, Lmin, seed, offset,
+                             w->ring.as<long long>(), s);
+  launch_walk_brackets_philox(st, scale, dirkind, dirscale, dd, seed, offset, s);
+  launch_walk_propose(st, nullptr, seed, offset, s);
+  launch_walk_transform(st, tkind, ta, tb, s);
+  launch_loglike(lkind, st.pnew, w->d, w->P, w->aux.as<double>(), sigma, st.Lnew, s);
+  launch_walk_update(st, Lmin, layer_of(w), s);
+  launch_walk_harvest(st, 0, w->ring.as<long long>(), w->r2, w->rec.as<double>(), s);
+  CK(hipGetLastError());
+  if (int rc = download(rec, w->rec, nrec * sizeof(double), s)) return rc;
+  CK(hipStreamSynchronize(s));
+  const uint64_t per = (uint64_t)((w->d + 1) / 2 + 2);
+  *next_offset = offset + (uint64_t)w->P * (per > 64 ? per : 64);
+  return 0;
 }
 
 int mlf_walkers_export(mlf_walkers *w, double *allu, double *allL, int64_t *generation, double *currentt,

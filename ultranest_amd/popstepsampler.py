@@ -208,6 +208,26 @@ class _Walkers(object):
                                                 int(ringindex), ptr(rec)))
         return self._record(rec, self.ndim)
 
+    def set_live(self, us, Ls):
+        us, Ls = f64(us), f64(Ls)
+        check(_lib.lib().mlf_walkers_set_live(self._h, ptr(us), ptr(Ls), len(Ls)))
+
+    def step_dev(self, Lmin, scale, kind, dirscale, rng, tspec, lspec):
+        """Whole sampler step on the device; returns the record (with the ring index after the step)."""
+        self.nparams = self.ndim
+        tkind, ta, tb = tspec
+        lkind, aux, sigma = lspec
+        rec = np.empty(10 + 2 * self.ndim)
+        nxt = ctypes.c_uint64(0)
+        check(_lib.lib().mlf_walkers_step_dev(self._h, float(Lmin), float(scale), int(kind), float(dirscale),
+                                              ctypes.c_uint64(rng.seed), ctypes.c_uint64(rng.offset), int(tkind),
+                                              float(ta), float(tb), int(lkind), ptr(None if aux is None else f64(aux)),
+                                              float(sigma), ptr(rec), ctypes.byref(nxt)))
+        rng.offset = nxt.value
+        out = self._record(rec, self.ndim)
+        out["ring"] = int(rec[9 + 2 * self.ndim])
+        return out
+
     def export(self):
         """Host copies of the resident state (tests, debugging)."""
         P, G, d = self.popsize, self.nsteps + 1, self.ndim
@@ -272,6 +292,7 @@ class PopulationSliceSampler(GenericPopulationSampler):
     def region_changed(self, Ls, region):
         """The driver rebuilt the region: refresh the device copies derived from it."""
         self._seen["region"] = None
+        self._seen["live_age"] = None
         if self.logfile:
             self.logfile.write("region-update\t%g\t%g\n" % (self.scale, region.u.std(axis=1).mean()))
 
@@ -280,7 +301,7 @@ class PopulationSliceSampler(GenericPopulationSampler):
         self.ringindex = (self.ringindex + 1) % self.popsize
 
     # ---- device copies of what the region contributes -----------------------------------------
-    def _sync_region(self, region):
+    def _sync_region(self, region, skip_live=False):
         w, seen = self._walkers, self._seen
         layer = region.transformLayer
         r2 = region.maxradiussq
@@ -303,7 +324,8 @@ class PopulationSliceSampler(GenericPopulationSampler):
                 w.set_direction_data(axes=region.transformLayer.axes)
             if kind == 1 and (fresh or seen["calls"] % 32 == 0):
                 w.set_direction_data(std=region.u.std(axis=0))
-            if kind in (5, 6) and (fresh or region.u.size <= 32768 or seen["calls"] % 32 == 0):
+            # (the whole-step path keeps live points and their likelihoods together: set_live)
+            if kind in (5, 6) and not skip_live and (fresh or region.u.size <= 32768 or seen["calls"] % 32 == 0):
                 w.set_direction_data(live=region.u)
         seen["region"] = region
         seen["calls"] += 1
@@ -316,7 +338,12 @@ class PopulationSliceSampler(GenericPopulationSampler):
         if self._walkers is None:
             self._walkers = _Walkers(self.popsize, self.nsteps, ndim)
         w = self._walkers
-        self._sync_region(region)
+        tspec, lspec = getattr(transform, "device_spec", None), getattr(loglike, "device_spec", None)
+        device_kind = getattr(self.generate_direction, "device_kind", None)
+        whole_step = self.device_rng is not None and device_kind is not None and tspec is not None and lspec is not None
+        self._sync_region(region, skip_live=whole_step)
+        if whole_step:
+            return self._next_on_device(region, Lmin, us, Ls, device_kind, tspec, lspec)
 
         # step_back on the device; the host learns which walkers need what
         generation, flags = w.begin(Lmin)
@@ -332,7 +359,6 @@ class PopulationSliceSampler(GenericPopulationSampler):
         assert (generation >= 0).all(), generation
 
         undefined = (flags & 1).astype(bool)            # bracket undefined: new slice
-        device_kind = getattr(self.generate_direction, "device_kind", None)
         on_device = self.device_rng is not None and device_kind is not None
         if undefined.any():
             if on_device:
@@ -348,7 +374,6 @@ class PopulationSliceSampler(GenericPopulationSampler):
         movable = generation < self.nsteps
         stepping = np.logical_and((flags & 6) != 0, ~undefined)
         bisecting = np.logical_and(movable, ~np.logical_or(stepping, undefined))
-        tspec, lspec = getattr(transform, "device_spec", None), getattr(loglike, "device_spec", None)
         resident_likelihood = tspec is not None and lspec is not None
         if self.device_rng is not None:
             unif, rng = None, self.device_rng
@@ -366,8 +391,28 @@ class PopulationSliceSampler(GenericPopulationSampler):
             else:
                 pnew, Lnew = np.empty((0, w.nparams or ndim)), np.empty(0)
             rec = w.finish(Lmin, pnew, Lnew, self.ringindex)
-        nc = rec["nc"]
+        self._generation, self._flags = generation, flags
+        return self._finish_call(rec, region)
 
+    def _next_on_device(self, region, Lmin, us, Ls, device_kind, tspec, lspec):
+        """Philox stream + resident likelihood: the whole step is one sequence of kernels
+        (``mlf_walkers_step_dev``): restarts draw from a device copy of the live points and the ring
+        index lives on the device; one record comes back."""
+        w, seen = self._walkers, self._seen
+        # the device copy of (us, Ls) is refreshed when it is cheap or has become old; live points that
+        # were replaced meanwhile fail the L > Lmin test of the restart kernel, so a stale copy only
+        # misses the newest points
+        if seen.get("live_age", None) is None or us.size <= 32768 or seen["live_age"] >= 32:
+            w.set_live(us, Ls)
+            seen["live_age"] = 0
+        seen["live_age"] += 1
+        rec = w.step_dev(Lmin, self.scale, device_kind, 1.0, self.device_rng, tspec, lspec)
+        out = self._finish_call(rec, region, shift=False)
+        self.ringindex = rec["ring"]
+        return out
+
+    def _finish_call(self, rec, region, shift=True):
+        nc = rec["nc"]
         if rec["nsuccess"] > 0:
             ns = rec["nsuccess"]
             have_diag = region.maxradiussq is not None
@@ -375,15 +420,14 @@ class PopulationSliceSampler(GenericPopulationSampler):
                                  rec["nfar"] / ns if have_diag else 0, np.exp(rec["sumlog"] / ns) if have_diag else 0])
             if self.logfile:
                 self.logfile.write("rescale\t%.4f\t%.4f\t%g\t%.4f%g\n" % tuple(self.logstat[-1]))
-
-        self._generation, self._flags = generation, flags
         if rec["found"]:
             u, p, L = rec["u"], rec["p"], rec["L"]
             assert np.isfinite(u).all(), u
             assert np.isfinite(p).all(), p
             newscale = (rec["right"] - rec["left"]) / 2
             self.scale = self.scale * 0.9 + 0.1 * newscale
-            self.shift()
+            if shift:
+                self.shift()
             return u, p, L, nc
         return None, None, None, nc
 
