@@ -157,6 +157,14 @@ int mlf_region_set_axes(mlf_region *r, const double *axes_T);
 int mlf_region_set_sampling_data(mlf_region *r, const double *invT, const double *bbox_lo, const double *bbox_hi);
 int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset,
                       double *out, size_t capacity, size_t *naccepted, uint64_t *next_offset);
+/* One proposal batch of the driver's _refill_samples (integrator.py:1773-1837) without leaving the
+ * device: mlf_region_sample's accepted points -> prior transform (tkind 0 identity, 1 x*a+b,
+ * 2 (x*a)*b) -> likelihood (kind as in mlf_loglike_dev) -> only the points with L > Lmin are copied
+ * back (u, p, L; at most `capacity`).  nevaluated = region-accepted proposals = likelihood evaluations. */
+int mlf_region_refill(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset,
+                      double Lmin, int tkind, double ta, double tb, int lkind, const double *aux,
+                      double sigma, double *out_u, double *out_p, double *out_L, size_t capacity,
+                      size_t *nevaluated, size_t *nkept, uint64_t *next_offset);
 /* raw Philox blocks (counter = (i, 0, stream, 0), key = seed) for known-answer tests */
 int mlf_debug_philox(uint64_t seed, unsigned stream, size_t nblocks, uint32_t *out);
 

@@ -215,3 +215,50 @@ def test_sampling_from_points_matches_restatement_and_is_uniform(d):
     se = ref.std(axis=0) * np.sqrt(1.0 / len(ref) + 1.0 / len(got))
     assert (np.abs(got.mean(axis=0) - ref.mean(axis=0)) < 5 * se).all()
     assert np.allclose(got.std(axis=0), ref.std(axis=0), rtol=0.1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method_name", ["sample_from_boundingbox", "sample_from_wrapping_ellipsoid",
+                                         "sample_from_transformed_boundingbox", "sample_from_points"])
+def test_device_refill_equals_sample_then_callbacks(method_name):
+    """mlf_region_refill = the same draw as region.sample() followed by the prior transform, the
+    likelihood and the L > Lmin cut, with only the survivors copied back."""
+    from ultranest_amd import likelihoods
+    region, DeviceRNG = _region("MLFriends", 400, 4, 77)
+    region.current_sampling_method = getattr(region, method_name)
+    loglike = likelihoods.GaussLikelihood(0.5, 0.08, 4)
+    nsamples = 30000
+    region.device_rng = DeviceRNG(41)
+    pts = region.sample(nsamples)
+    nxt = region.device_rng.offset
+    p_host = likelihoods.rosenbrock_transform(pts)
+    L_host = likelihoods.rosenbrock_loglike(p_host)
+    Lmin = np.median(L_host)
+    region.device_rng = DeviceRNG(41)
+    region.current_sampling_method = getattr(region, method_name)
+    u, p, L, nc = region.refill(nsamples, Lmin, likelihoods.rosenbrock_transform, likelihoods.rosenbrock_loglike)
+    assert region.device_rng.offset == nxt and nc == len(pts)
+    keep = L_host > Lmin
+    assert abs(len(u) - keep.sum()) <= 2
+    if len(u) == keep.sum():
+        assert np.array_equal(u, pts[keep]) and np.array_equal(p, p_host[keep])
+        assert np.allclose(L, L_host[keep], rtol=1e-12, atol=1e-12)
+    assert (L > Lmin).all() and len(u) > 100
+    # callbacks without a device form: the caller is told to take the host route
+    assert region.refill(100, Lmin, lambda x: x, loglike) is None
+
+
+@pytest.mark.gpu
+def test_fully_resident_nested_sampling_run():
+    """Region proposals, prior transform, likelihood and threshold cut all on the device: only live-point
+    replacements reach the host.  5-d Gaussian, analytic evidence 0."""
+    from ultranest_amd import likelihoods
+    from ultranest_amd.harness import StaticNestedSampler
+    from ultranest_amd.regions import DeviceRNG
+    d, sigma = 5, 0.05
+    loglike = likelihoods.GaussLikelihood(0.5, sigma, d)
+    s = StaticNestedSampler(d, loglike, transform=likelihoods.identity_transform, num_live_points=400, ndraw=16384, seed=5,
+                            device_rng=DeviceRNG(13))
+    res = s.run(dlogz=0.1)
+    assert abs(res["logz"]) < 4 * res["logzerr"] + 0.15, res
+    assert res["ncall"] > 5000

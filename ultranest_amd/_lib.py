@@ -56,6 +56,8 @@ SIGNATURES = {
     "mlf_region_set_axes": [_vp, _vp],
     "mlf_region_set_sampling_data": [_vp, _vp, _vp, _vp],
     "mlf_region_sample": [_vp, _int, _sz, ctypes.c_uint64, ctypes.c_uint64, _vp, _sz, _vp, _vp],
+    "mlf_region_refill": [_vp, _int, _sz, ctypes.c_uint64, ctypes.c_uint64, _dbl, _int, _dbl, _dbl, _int, _vp, _dbl, _vp, _vp,
+                          _vp, _sz, _vp, _vp, _vp],
     "mlf_debug_philox": [ctypes.c_uint64, ctypes.c_uint, _sz, _vp],
     "mlf_within_unit_cube": [_vp, _sz, _sz, _vp],
     "mlf_evolve_propose": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp],

@@ -399,7 +399,7 @@ struct mlf_region {
   DevBuf tq, gate, pts, mask, row;
   FilterCtx filter;
   DevBuf gen, gen2, cube, smask, blk, sout, ax_zero, ax_mat;   // device-side sampling
-  DevBuf s_invT, s_lo, s_hi, s_thin, s_count;
+  DevBuf s_invT, s_lo, s_hi, s_thin, s_count, rf_p, rf_L, rf_out, rf_aux;
   bool axes_ready = false, sampling_ready = false;
   std::vector<hipEvent_t> events;  // 4 per timed call
   size_t events_used = 0;
@@ -928,7 +928,7 @@ int mlf_region_destroy(mlf_region *r) {
   DevBuf *bufs[] = {&r->refT, &r->refR, &r->lay_ctr, &r->lay_mat, &r->lay_T8, &r->ell_Lt, &r->ell_LtF, &r->lay_TtF, &r->wrap, &r->ell_ctr,
                     &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row,
                     &r->gen, &r->gen2, &r->cube, &r->smask, &r->blk, &r->sout, &r->ax_zero, &r->ax_mat,
-                    &r->s_invT, &r->s_lo, &r->s_hi, &r->s_thin, &r->s_count};
+                    &r->s_invT, &r->s_lo, &r->s_hi, &r->s_thin, &r->s_count, &r->rf_p, &r->rf_L, &r->rf_out, &r->rf_aux};
   for (DevBuf *b : bufs) b->release();
   for (hipEvent_t e : r->events) (void)hipEventDestroy(e);
   r->filter.release();
@@ -1185,7 +1185,7 @@ int region_scan_mask(mlf_region *r, const double *d_t, long long np, uint8_t *d_
 
 // methods 2 and 3 of MLFriends.sample: proposals are born in t-space
 int region_sample_tspace(mlf_region *r, int method, long long n, uint64_t seed, uint64_t offset, double *out,
-                         size_t capacity, size_t *naccepted, uint64_t *next_offset) {
+                         size_t capacity, size_t *naccepted, uint64_t *next_offset, bool fetch) {
   Ctx &c = g_ctx;
   hipStream_t s = c.stream;
   const int d = r->d;
@@ -1256,7 +1256,7 @@ int region_sample_tspace(mlf_region *r, int method, long long n, uint64_t seed, 
   CK(hipMemcpyAsync(&count, r->blk.as<unsigned>() + nblk1, sizeof count, hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));
   const size_t take = count < cap ? count : cap;
-  if (take) {
+  if (take && fetch) {
     CK(hipMemcpyAsync(out, r->sout.p, take * (size_t)d * sizeof(double), hipMemcpyDeviceToHost, s));
     CK(hipStreamSynchronize(s));
   }
@@ -1266,9 +1266,19 @@ int region_sample_tspace(mlf_region *r, int method, long long n, uint64_t seed, 
 
 }  // namespace
 
-int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset,
-                      double *out, size_t capacity, size_t *naccepted, uint64_t *next_offset) {
-  if (!r || !out || !naccepted || !next_offset) return fail_arg(MLF_E_BADARG, "null pointer");
+// fetch = false leaves the accepted rows in r->sout (device) for mlf_region_refill
+static int region_sample_impl(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset, double *out,
+                              size_t capacity, size_t *naccepted, uint64_t *next_offset, bool fetch);
+
+int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset, double *out,
+                      size_t capacity, size_t *naccepted, uint64_t *next_offset) {
+  if (!out) return fail_arg(MLF_E_BADARG, "null pointer");
+  return region_sample_impl(r, method, nsamples, seed, offset, out, capacity, naccepted, next_offset, true);
+}
+
+static int region_sample_impl(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset,
+                      double *out, size_t capacity, size_t *naccepted, uint64_t *next_offset, bool fetch) {
+  if (!r || !naccepted || !next_offset) return fail_arg(MLF_E_BADARG, "null pointer");
   if (!r->ready) return fail_arg(MLF_E_STATE, "region used before mlf_region_set");
   if (method < 0 || method > 3)
     return fail_arg(MLF_E_BADARG, "method must be 0 (cube), 1 (wrapping ellipsoid), 2 (t-space box) or 3 (live points)");
@@ -1279,7 +1289,7 @@ int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed,
   *next_offset = offset;
   if (nsamples == 0 || capacity == 0) return 0;
   if (method >= 2)
-    return region_sample_tspace(r, method, (long long)nsamples, seed, offset, out, capacity, naccepted, next_offset);
+    return region_sample_tspace(r, method, (long long)nsamples, seed, offset, out, capacity, naccepted, next_offset, fetch);
   Ctx &c = g_ctx;
   hipStream_t s = c.stream;
   const long long n = (long long)nsamples;
@@ -1323,11 +1333,61 @@ int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed,
   CK(hipMemcpyAsync(&count, r->blk.as<unsigned>() + nblk, sizeof count, hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));
   const size_t take = count < cap ? count : cap;
-  if (take) {
+  if (take && fetch) {
     CK(hipMemcpyAsync(out, r->sout.p, take * (size_t)d * sizeof(double), hipMemcpyDeviceToHost, s));
     CK(hipStreamSynchronize(s));
   }
   *naccepted = take;
+  return 0;
+}
+
+int mlf_region_refill(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset, double Lmin, int tkind,
+                      double ta, double tb, int lkind, const double *aux, double sigma, double *out_u, double *out_p,
+                      double *out_L, size_t capacity, size_t *nevaluated, size_t *nkept, uint64_t *next_offset) {
+  if (!r || !out_u || !out_p || !out_L || !nevaluated || !nkept || !next_offset)
+    return fail_arg(MLF_E_BADARG, "null pointer");
+  if (tkind < 0 || tkind > 2 || lkind < 0 || lkind > 3) return fail_arg(MLF_E_BADARG, "unknown transform / likelihood kind");
+  if (lkind == 0 && !aux) return fail_arg(MLF_E_BADARG, "the Gaussian likelihood needs its centres");
+  *nevaluated = 0;
+  *nkept = 0;
+  size_t nacc = 0;
+  if (int rc = region_sample_impl(r, method, nsamples, seed, offset, nullptr, nsamples, &nacc, next_offset, false)) return rc;
+  *nevaluated = nacc;
+  if (nacc == 0 || capacity == 0) return 0;
+  Ctx &c = g_ctx;
+  hipStream_t s = c.stream;
+  const int d = r->d;
+  const long long n = (long long)nacc;
+  const int nblk = (int)((n + 255) / 256);
+  CK(r->rf_p.reserve((size_t)n * d * sizeof(double)));
+  CK(r->rf_L.reserve((size_t)n * sizeof(double)));
+  CK(r->rf_out.reserve(capacity * (2 * (size_t)d + 1) * sizeof(double)));
+  CK(r->smask.reserve((size_t)n));
+  CK(r->blk.reserve(((size_t)nblk + 1) * sizeof(unsigned)));
+  if (aux)
+    if (int rc = upload(r->rf_aux, aux, (size_t)d * sizeof(double), s)) return rc;
+  // prior transform + likelihood on the accepted proposals, where they are (reference _refill_samples,
+  // integrator.py:1789-1804); only the points above the threshold travel to the host
+  launch_elementwise_affine(r->sout.as<double>(), n * d, tkind, ta, tb, r->rf_p.as<double>(), s);
+  launch_loglike(lkind, r->rf_p.as<double>(), d, n, r->rf_aux.as<double>(), sigma, r->rf_L.as<double>(), s);
+  launch_mask_greater(r->rf_L.as<double>(), n, Lmin, r->smask.as<uint8_t>(), s);
+  const unsigned cap = capacity > 0xffffffffu ? 0xffffffffu : (unsigned)capacity;
+  double *ou = r->rf_out.as<double>(), *op = ou + capacity * (size_t)d, *oL = op + capacity * (size_t)d;
+  launch_compact(r->sout.as<double>(), r->smask.as<uint8_t>(), n, d, r->blk.as<unsigned>(), ou, cap, s);
+  launch_compact(r->rf_p.as<double>(), r->smask.as<uint8_t>(), n, d, r->blk.as<unsigned>(), op, cap, s);
+  launch_compact(r->rf_L.as<double>(), r->smask.as<uint8_t>(), n, 1, r->blk.as<unsigned>(), oL, cap, s);
+  CK(hipGetLastError());
+  unsigned count = 0;
+  CK(hipMemcpyAsync(&count, r->blk.as<unsigned>() + nblk, sizeof count, hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  const size_t take = count < cap ? count : cap;
+  if (take) {
+    CK(hipMemcpyAsync(out_u, ou, take * (size_t)d * sizeof(double), hipMemcpyDeviceToHost, s));
+    CK(hipMemcpyAsync(out_p, op, take * (size_t)d * sizeof(double), hipMemcpyDeviceToHost, s));
+    CK(hipMemcpyAsync(out_L, oL, take * sizeof(double), hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+  }
+  *nkept = take;
   return 0;
 }
 

@@ -169,6 +169,27 @@ __global__ void k_untransform_rows(const double *t, long long n, int d, const do
   in_cube[p] = ok ? 1 : 0;
 }
 
+// prior transforms of the benchmark problems, elementwise: 0 identity, 1 x*a + b, 2 (x*a)*b
+__global__ void k_elementwise_affine(const double *x, long long n, int tkind, double a, double b, double *out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const double v = x[e];
+  double p = v;
+  if (tkind == 1) {
+    const double m = v * a;
+    p = m + b;
+  } else if (tkind == 2) {
+    const double m = v * a;
+    p = m * b;
+  }
+  out[e] = p;
+}
+
+__global__ void k_mask_greater(const double *v, long long n, double threshold, uint8_t *mask) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) mask[e] = v[e] > threshold ? 1 : 0;
+}
+
 __global__ void k_mask_and(uint8_t *mask, const uint8_t *other, long long n) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n) mask[p] = (mask[p] && other[p]) ? 1 : 0;
@@ -285,6 +306,16 @@ void launch_untransform_rows(const double *t, long long n, int d, const double *
   if (n <= 0) return;
   hipLaunchKernelGGL(k_untransform_rows, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, t, n, d, invT, ctr, wrap_shift, w,
                      in_cube);
+}
+
+void launch_elementwise_affine(const double *x, long long n, int tkind, double a, double b, double *out, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_elementwise_affine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, tkind, a, b, out);
+}
+
+void launch_mask_greater(const double *v, long long n, double threshold, uint8_t *mask, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_mask_greater, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, n, threshold, mask);
 }
 
 void launch_mask_and(uint8_t *mask, const uint8_t *other, long long n, hipStream_t s) {

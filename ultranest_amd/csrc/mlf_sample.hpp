@@ -17,6 +17,8 @@ void launch_generate_around_points(double *t, double *thin_u, long long n, int d
 void launch_thin_by_multiplicity(const long long *count, const double *thin_u, long long n, uint8_t *mask, hipStream_t s);
 void launch_untransform_rows(const double *t, long long n, int d, const double *invT, const double *ctr,
                              const double *wrap_shift, double *w, uint8_t *in_cube, hipStream_t s);
+void launch_elementwise_affine(const double *x, long long n, int tkind, double a, double b, double *out, hipStream_t s);
+void launch_mask_greater(const double *v, long long n, double threshold, uint8_t *mask, hipStream_t s);
 void launch_mask_and(uint8_t *mask, const uint8_t *other, long long n, hipStream_t s);
 void launch_apply_pregate(const uint8_t *pregate, long long n, uint8_t *gate, uint8_t *route, float *tlo,
                           float *thi, hipStream_t s);

@@ -114,6 +114,10 @@ def refill_samples(region, tregion, transform, loglike, Lmin, ndraw, pointstore=
     """One proposal batch (reference `_refill_samples`, integrator.py:1773-1837 with
     draw_multiple=True): region.sample -> transform -> tregion.inside -> loglike on the accepted
     rows -> keep logl > Lmin.  Returns (u, v, logl, ncalls)."""
+    if tregion is None and pointstore is None and hasattr(region, "refill"):
+        got = region.refill(ndraw, Lmin, transform, loglike)     # device-resident batch when possible
+        if got is not None:
+            return got
     u = region.sample(nsamples=ndraw)
     assert np.logical_and(u > 0, u < 1).all(), u
     nu = u.shape[0]

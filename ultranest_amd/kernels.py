@@ -224,6 +224,22 @@ class DeviceRegion(object):
                                            ctypes.byref(nxt)))
         return out[:nacc.value], nxt.value
 
+    def refill(self, method, nsamples, seed, offset, Lmin, tspec, lspec, capacity=None):
+        """Device-resident proposal batch: draw + region test + prior transform + likelihood; returns the
+        points above `Lmin` as (u, p, L), the number of likelihood evaluations and the next offset."""
+        d = self._d
+        cap = int(nsamples if capacity is None else capacity)
+        u, p, L = np.empty((cap, d)), np.empty((cap, d)), np.empty(cap)
+        nev, nkept, nxt = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_uint64(0)
+        tkind, ta, tb = tspec
+        lkind, aux, sigma = lspec
+        check(_lib.lib().mlf_region_refill(self._h, int(method), int(nsamples), ctypes.c_uint64(int(seed)),
+                                           ctypes.c_uint64(int(offset)), float(Lmin), int(tkind), float(ta), float(tb),
+                                           int(lkind), ptr(None if aux is None else f64(aux)), float(sigma), ptr(u), ptr(p),
+                                           ptr(L), cap, ctypes.byref(nev), ctypes.byref(nkept), ctypes.byref(nxt)))
+        k = nkept.value
+        return u[:k], p[:k], L[:k], nev.value, nxt.value
+
     def first_index_dev(self, d_pts, npts, d_idx, stream=0):
         check(_lib.lib().mlf_region_first_index_dev(self._h, ctypes.c_void_p(d_pts), npts,
                                                     ctypes.c_void_p(d_idx), ctypes.c_void_p(stream)))

@@ -132,8 +132,21 @@ class _DeviceState(object):
         self.axes_T = None
         self.sampling_data = None
 
+    def refill(self, region, use_scan, method, nsamples, Lmin, tspec, lspec):
+        """Device-resident proposal batch (draw, region test, prior transform, likelihood, threshold)."""
+        handle = self._prepare_sampling(region, use_scan, method)
+        rng = region.device_rng
+        u, p, L, nev, rng.offset = handle.refill(method, nsamples, rng.seed, rng.offset, Lmin, tspec, lspec)
+        return u, p, L, nev
+
     def sample(self, region, use_scan, method, nsamples):
         """Device-side draw + membership + compaction with the region's ``device_rng``."""
+        handle = self._prepare_sampling(region, use_scan, method)
+        rng = region.device_rng
+        pts, rng.offset = handle.sample(method, nsamples, rng.seed, rng.offset)
+        return pts
+
+    def _prepare_sampling(self, region, use_scan, method):
         handle = self.sync(region, use_scan)
         if method == 1:
             axes_T = np.asarray(region.ellipsoid_axes_T, dtype=float)
@@ -147,9 +160,7 @@ class _DeviceState(object):
             if self.sampling_data is None or not all(np.array_equal(a, b) for a, b in zip(self.sampling_data, data)):
                 handle.set_sampling_data(*data)
                 self.sampling_data = tuple(a.copy() for a in data)
-        rng = region.device_rng
-        pts, rng.offset = handle.sample(method, nsamples, rng.seed, rng.offset)
-        return pts
+        return handle
 
     @staticmethod
     def _same(a, b):
@@ -400,6 +411,30 @@ class MLFriends(object):
         return samples
 
 
+    _DEVICE_METHOD = dict(sample_from_boundingbox=0, sample_from_wrapping_ellipsoid=1,
+                          sample_from_transformed_boundingbox=2, sample_from_points=3)
+
+    def refill(self, nsamples, Lmin, transform, loglike):
+        """One proposal batch of the driver's ``_refill_samples`` (reference integrator.py:1773-1837)
+        without leaving the device: draw with the current sampling method, region test, prior
+        transform, likelihood, and only the points with L > Lmin come back as ``(u, p, L, nc)``.
+        Needs ``device_rng`` and ``device_spec`` on both callbacks (ultranest_amd.likelihoods);
+        returns None if that does not hold (the caller then uses sample() + callbacks)."""
+        tspec, lspec = getattr(transform, "device_spec", None), getattr(loglike, "device_spec", None)
+        method = self._DEVICE_METHOD.get(getattr(self.current_sampling_method, "__name__", ""), None)
+        if self.device_rng is None or tspec is None or lspec is None or method is None:
+            return None
+        if method >= 2 and not self._device_tspace():
+            return None
+        u, p, L, nc = self._dev.refill(self, self._uses_scan(), method, nsamples, Lmin, tspec, lspec)
+        if nc == 0:   # the region accepted nothing: re-roll the method like sample() does (:1180-1183)
+            self.current_sampling_method = self.sampling_methods[np.random.randint(len(self.sampling_methods))]
+        return u, p, L, nc
+
+    def _uses_scan(self):
+        return True
+
+
 class RobustEllipsoidRegion(MLFriends):
     """Single bootstrapped ellipsoid; no neighbour scan (reference mlfriends.pyx:1260-1457)."""
 
@@ -410,6 +445,9 @@ class RobustEllipsoidRegion(MLFriends):
             self.sample_from_wrapping_ellipsoid,
         ]
         self.current_sampling_method = self.sample_from_boundingbox
+
+    def _uses_scan(self):
+        return False
 
     def sample_from_boundingbox(self, nsamples=100):
         if self.device_rng is not None:
