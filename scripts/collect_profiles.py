@@ -36,6 +36,7 @@ cp("config_bench.json", "%s_config_bench.json" % tag)
 cp("walk_bench_device.json", "%s_walk_bench.json" % tag)
 cp("sample_bench.json", "%s_sample_bench.json" % tag)
 cp("big_batch.json", "%s_big_batch.json" % tag)
+cp("e2e_run.json", "%s_e2e_run.json" % tag)
 cp("bench_torchrun.json", "%s_bench_torchrun.json" % tag)
 
 # kernel-trace: average duration of the headline launches only (the stats CSV mixes them with the
