@@ -202,6 +202,7 @@ class StaticNestedSampler(object):
         logvol = 0.0
         next_update_logvol = 0.0
         pending_u, pending_l = np.empty((0, self.x_dim)), np.empty(0)
+        ip = 0      # next unused entry of the pending batch (entries at or below a past threshold stay dead)
         it = 0
         while it < max_iters:
             if logvol <= next_update_logvol:
@@ -230,23 +231,26 @@ class StaticNestedSampler(object):
                 if newu is not None:
                     break
             while self.stepsampler is None:
-                keep = pending_l > Lmin
-                pending_u, pending_l = pending_u[keep], pending_l[keep]
-                if len(pending_l):
-                    newu, newl = pending_u[0], pending_l[0]
-                    pending_u, pending_l = pending_u[1:], pending_l[1:]
+                # the threshold only rises: walk the batch once, like the driver's index `ib` (:1942-1950)
+                while ip < len(pending_l) and not (pending_l[ip] > Lmin):
+                    ip += 1
+                if ip < len(pending_l):
+                    newu, newl = pending_u[ip].copy(), pending_l[ip]
+                    ip += 1
                     break
                 if self.pointstore is not None and not self.pointstore.stack_empty:
                     _, row = self.pointstore.pop(Lmin)       # resume: replay stored evaluations first
                     if row is not None:
                         pending_u = np.array([row[3:3 + self.x_dim]])
                         pending_l = np.array([row[1]])
+                        ip = 0
                         continue
                 nu, nv, nl, nc = refill_samples(region, None, self.transform, self.loglike, Lmin, self.ndraw,
                                                 pointstore=self.pointstore, ncall=self.ncall)
                 self.ncall += nc
                 self.ncall_region += self.ndraw
                 pending_u, pending_l = nu, nl
+                ip = 0
             # in-place replacement exactly as the driver does it
             region.u[worst] = newu
             region.unormed[worst] = region.transformLayer.transform(newu)
