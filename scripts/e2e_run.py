@@ -13,6 +13,14 @@ from ultranest_amd.harness import StaticNestedSampler  # noqa: E402
 from ultranest_amd.regions import DeviceRNG  # noqa: E402
 
 out = []
+
+
+def laplace_logz(d):
+    """Eggbox evidence by Laplace's method: 5^d / 2 peaks (boundary peaks count half per axis) of height 243,
+    each a Gaussian of variance 8 / 810 per axis, prior volume (10 pi)^d.  d = 2: 235.85 (quadrature: 235.88)."""
+    return np.log(5.0**d / 2) + 243.0 + 0.5 * d * np.log(2 * np.pi * 8.0 / 810.0) - d * np.log(10 * np.pi)
+
+
 CASES = [(2, 1000, 65536, 200000)]
 if len(sys.argv) > 1:      # the 10-d eggbox (5^10 modes) is optional: it needs minutes
     CASES.append((10, 1000, 262144, int(sys.argv[1])))
@@ -22,9 +30,25 @@ for d, nlive, ndraw, max_iters in CASES:
     t0 = time.perf_counter()
     res = s.run(dlogz=0.5, max_iters=max_iters)
     dt = time.perf_counter() - t0
-    res.update(d=d, nlive=nlive, ndraw=ndraw, seconds=dt, iterations_per_s=res["niter"] / dt,
+    res.update(d=d, nlive=nlive, ndraw=ndraw, laplace_logz=float(laplace_logz(d)), seconds=dt, iterations_per_s=res["niter"] / dt,
                likelihood_evaluations_per_s=res["ncall"] / dt, proposals_per_s=res["ncall_region"] / dt,
                finished=res["niter"] < max_iters)
+    out.append(res)
+    print(json.dumps(res), flush=True)
+# C3 proper: 10-d eggbox (5^10 modes).  Region rejection sampling cannot follow the volume there; the
+# population slice sampler (device-resident walkers, Philox, likelihood evaluated in place) can.
+import ultranest_amd.popstepsampler as pop  # noqa: E402
+for d, nlive, popsize, nsteps in [(2, 1000, 1024, 10), (10, 1000, 1024, 40)]:
+    step = pop.PopulationSliceSampler(popsize=popsize, nsteps=nsteps, generate_direction=pop.generate_mixture_random_direction,
+                                      scale=1.0, device_rng=DeviceRNG(7))
+    s = StaticNestedSampler(d, likelihoods.eggbox_loglike, transform=likelihoods.eggbox_transform, num_live_points=nlive,
+                            seed=1, stepsampler=step)
+    t0 = time.perf_counter()
+    res = s.run(dlogz=0.5, max_iters=400000)
+    dt = time.perf_counter() - t0
+    res.update(d=d, nlive=nlive, laplace_logz=float(laplace_logz(d)), sampler="PopulationSliceSampler(popsize=%d, nsteps=%d, mixture directions)" % (popsize, nsteps),
+               seconds=dt, iterations_per_s=res["niter"] / dt, likelihood_evaluations_per_s=res["ncall"] / dt,
+               far_enough_fraction=float(step.far_enough_fraction), finished=res["niter"] < 400000)
     out.append(res)
     print(json.dumps(res), flush=True)
 json.dump(out, open("gpurun_out/e2e_run.json", "w"), indent=1)
