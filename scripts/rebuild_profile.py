@@ -33,7 +33,7 @@ upd.update(u3, nbootstraps=30, minvol=0.)
 pr.disable()
 print("rebuild ms:", (time.perf_counter() - t0) * 1e3)
 out = io.StringIO()
-pstats.Stats(pr, stream=out).sort_stats("cumulative").print_stats(28)
+pstats.Stats(pr, stream=out).sort_stats("tottime").print_stats(22)
 print("\n".join(l[:150] for l in out.getvalue().splitlines()[:60]))
 
 # likelihood batch throughput through the host-pointer ABI (includes H2D/D2H) at 1e6 x 50

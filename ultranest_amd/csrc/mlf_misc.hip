@@ -129,6 +129,19 @@ __global__ __launch_bounds__(kWave) void k_subtract_accum(const double *pts, int
     long long nn = 0;
     for (int t = 0; t < ntiles; ++t) {
       unsigned long long m = flags[(long long)j * ntiles + t];
+      if (m == ~0ull) {   // whole tile: 64 consecutive rows, no bit scanning; 32 loads in flight per batch
+        const double *col = pts + (long long)t * kWave * d + k;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          double v[32];
+#pragma unroll
+          for (int q = 0; q < 32; ++q) v[q] = col[(long long)(32 * h + q) * d];
+#pragma unroll
+          for (int q = 0; q < 32; ++q) sum += v[q];
+        }
+        nn += 64;
+        continue;
+      }
       // the additions must stay in ascending-i order, the LOADS need not wait for them: fetch up
       // to eight neighbours at once (with the LocalAffineLayer radius quirk every point is a
       // neighbour of every point, so this loop runs N times per output value)
