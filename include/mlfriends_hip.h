@@ -270,6 +270,11 @@ int mlf_counter_state(const mlf_counter *c, double *scalars, double *all_H, doub
                       double *all_logVolremaining, double *all_logZremain, int64_t *runs,
                       size_t runs_capacity, size_t *nruns);
 
+/* host helper (no GPU): rows in which two (n, d) float64 matrices differ bytewise; used by the lazy device
+ * mirror of the live points (the driver replaces one row per iteration in place, integrator.py:2753) */
+int mlf_host_changed_rows(const double *a, const double *b, size_t n, size_t d, int64_t *rows,
+                          size_t capacity, size_t *count);
+
 /* H3 -> T1 -> K1 with the index kept: d_idx[p] = first live point within radiussq (>= 0),
  * -1 = inside the ellipsoid but no neighbour, -2 = outside the wrapping ellipsoid. */
 int mlf_region_first_index_dev(mlf_region *r, const double *d_pts, size_t np, int64_t *d_idx,

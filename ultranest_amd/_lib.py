@@ -84,6 +84,7 @@ SIGNATURES = {
     "mlf_walkers_step_dev": [_vp, _dbl, _dbl, _int, _dbl, ctypes.c_uint64, ctypes.c_uint64, _int, _dbl, _dbl, _int, _vp, _dbl,
                              _vp, _vp],
     "mlf_walkers_export": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlf_host_changed_rows": [_vp, _vp, _sz, _sz, _vp, _sz, _vp],
     "mlf_counter_create": [_vp, _sz, _sz, _vp, _int, _int],
     "mlf_counter_destroy": [_vp],
     "mlf_counter_reset": [_vp],
@@ -163,3 +164,13 @@ def set_device(i):
 def set_option(name, value):
     """Tuning switch of the library (e.g. set_option("filter", 0) forces the exact scan only)."""
     check(lib().mlf_set_option(name.encode(), int(value)))
+
+
+def changed_rows(a, b, capacity=64):
+    """Indices of the rows where two C-contiguous float64 (n, d) arrays differ bytewise, and their total
+    number (compiled memcmp per row)."""
+    rows = np.empty(capacity, dtype=np.int64)
+    count = ctypes.c_size_t(0)
+    check(lib().mlf_host_changed_rows(a.ctypes.data, b.ctypes.data, a.shape[0], a.shape[1], rows.ctypes.data, capacity,
+                                      ctypes.byref(count)))
+    return rows[:min(count.value, capacity)], count.value

@@ -227,6 +227,23 @@ int mlf_counter_passing_node(mlf_counter *c, int64_t rootid, double Li, size_t n
   return 0;
 }
 
+// Host helper of the lazy device mirror (regions._DeviceState): indices of the rows in which two (n, d) float64
+// matrices differ bytewise -- the driver replaces one live point per iteration in place, and finding that
+// row with numpy costs ~0.4 ms at 4000 x 50.  count = number of differing rows (may exceed capacity).
+int mlf_host_changed_rows(const double *a, const double *b, size_t n, size_t d, int64_t *rows, size_t capacity,
+                          size_t *count) {
+  if (!a || !b || !count || (capacity && !rows)) return mlf::ctx_fail_arg(MLF_E_BADARG, "null pointer");
+  size_t c = 0;
+  const size_t bytes = d * sizeof(double);
+  for (size_t i = 0; i < n; ++i)
+    if (memcmp(a + i * d, b + i * d, bytes) != 0) {
+      if (c < capacity) rows[c] = (int64_t)i;
+      ++c;
+    }
+  *count = c;
+  return 0;
+}
+
 int mlf_counter_state(const mlf_counter *c, double *scalars, double *all_H, double *all_logZ, double *all_logVolremaining,
                       double *all_logZremain, int64_t *runs, size_t runs_capacity, size_t *nruns) {
   if (!c || !scalars) return mlf::ctx_fail_arg(MLF_E_BADARG, "null pointer");

@@ -18,7 +18,7 @@ What runs where:
 """
 import numpy as np
 
-from . import kernels
+from . import _lib, kernels
 from .layers import int_dtype
 
 # When True, ``MLFriends.inside`` transforms ellipsoid-passing points on the host with the same
@@ -192,8 +192,14 @@ class _DeviceState(object):
         full = self.consts is None or not self._same(consts, self.consts)
         changed = ()
         if not full and use_scan:
-            changed = np.flatnonzero((self.live != region.u).any(axis=1))
-            full = len(changed) > max(8, nlive // 8)
+            u_now = region.u
+            if u_now.dtype == np.float64 and u_now.flags.c_contiguous and u_now.shape == self.live.shape:
+                limit = max(8, nlive // 8)
+                changed, nchanged = _lib.changed_rows(self.live, u_now, capacity=limit)
+                full = nchanged > limit
+            else:
+                changed = np.flatnonzero((self.live != u_now).any(axis=1))
+                full = len(changed) > max(8, nlive // 8)
         if full:
             # the device whitens region.u itself (live_space=1): live points and proposals then go
             # through the same arithmetic, so a live point is at distance exactly 0 from itself
