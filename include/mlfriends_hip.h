@@ -244,6 +244,12 @@ int mlf_walkers_set_live(mlf_walkers *w, const double *us, const double *Ls, siz
 int mlf_walkers_step_dev(mlf_walkers *w, double Lmin, double scale, int dirkind, double dirscale,
                          uint64_t seed, uint64_t offset, int tkind, double ta, double tb, int lkind,
                          const double *aux, double sigma, double *rec, uint64_t *next_offset);
+/* The same step replayed as one hipGraph launch: the kernel sequence and the record copy are captured once
+ * (and again whenever a captured argument changes: kinds, buffer addresses); Lmin, scale, seed / offset and
+ * the MLFriends radius reach the kernels through a pinned parameter block. */
+int mlf_walkers_step_graph(mlf_walkers *w, double Lmin, double scale, int dirkind, double dirscale,
+                           uint64_t seed, uint64_t offset, int tkind, double ta, double tb, int lkind,
+                           const double *aux, double sigma, double *rec, uint64_t *next_offset);
 int mlf_walkers_export(mlf_walkers *w, double *allu, double *allL, int64_t *generation,
                        double *currentt, double *currentv, double *left, double *right,
                        uint8_t *searching_left, uint8_t *searching_right);

@@ -83,6 +83,8 @@ SIGNATURES = {
     "mlf_walkers_set_live": [_vp, _vp, _vp, _sz],
     "mlf_walkers_step_dev": [_vp, _dbl, _dbl, _int, _dbl, ctypes.c_uint64, ctypes.c_uint64, _int, _dbl, _dbl, _int, _vp, _dbl,
                              _vp, _vp],
+    "mlf_walkers_step_graph": [_vp, _dbl, _dbl, _int, _dbl, ctypes.c_uint64, ctypes.c_uint64, _int, _dbl, _dbl, _int, _vp, _dbl,
+                               _vp, _vp],
     "mlf_walkers_export": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlf_host_changed_rows": [_vp, _vp, _sz, _sz, _vp, _sz, _vp],
     "mlf_counter_create": [_vp, _sz, _sz, _vp, _int, _int],

@@ -118,9 +118,11 @@ __global__ __launch_bounds__(256) void k_max_generation(const long long *generat
 }
 
 __global__ void k_step_back(double Lmin, double *allL, int n, int G, long long *generation, double *currentt,
-                            const long long *gmax, const uint8_t *sl, const uint8_t *sr, uint8_t *flags) {
+                            const long long *gmax, const uint8_t *sl, const uint8_t *sr, uint8_t *flags,
+                            const StepParams *sp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (sp) Lmin = sp->Lmin;
   long long gen = generation[i];
   double t = currentt[i];
   step_back_walker(Lmin, allL + (size_t)i * G, G, *gmax + 1, gen, t);
@@ -171,9 +173,15 @@ __global__ void k_walk_brackets(WalkState w, const long long *idx, int n, double
 // Philox stream 2, (npairs + 2) blocks per walker: block 0 = integer picks + mixture coin,
 // blocks 1.. = Box-Muller pairs.
 __global__ void k_walk_brackets_philox(WalkState w, double scale, int kind, double dirscale, WalkDirData dd,
-                                       unsigned long long seed, unsigned long long offset) {
+                                       unsigned long long seed, unsigned long long offset, const StepParams *sp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w.P) return;
+  if (sp) {
+    scale = sp->scale;
+    dirscale = sp->dirscale;
+    seed = sp->seed;
+    offset = sp->offset;
+  }
   if (isfinite(w.currentt[i])) return;
   const int d = w.d;
   double *v = w.currentv + (size_t)i * d;
@@ -231,9 +239,14 @@ __global__ void k_walk_brackets_philox(WalkState w, double scale, int kind, doub
 }
 
 // evolve, first half (stepfuncs.pyx:249-261): slice coordinate, proposed point, cube test
-__global__ void k_walk_propose(WalkState w, const double *unif, unsigned long long seed, unsigned long long offset) {
+__global__ void k_walk_propose(WalkState w, const double *unif, unsigned long long seed, unsigned long long offset,
+                               const StepParams *sp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w.P) return;
+  if (sp) {
+    seed = sp->seed;
+    offset = sp->offset;
+  }
   const long long g = w.generation[i];
   const bool movable = g >= 0 && g < w.G - 1;
   w.movable[i] = movable ? 1 : 0;
@@ -311,9 +324,10 @@ __global__ __launch_bounds__(256) void k_walk_expand(WalkState w, const unsigned
 
 // evolve, second half (evolve_update) + PopulationSliceSampler.advance bookkeeping
 // (popstepsampler.py:585-603) + move diagnostics (diagnose_move_distances :64-94)
-__global__ void k_walk_update(WalkState w, double Lmin) {
+__global__ void k_walk_update(WalkState w, double Lmin, const StepParams *sp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w.P) return;
+  if (sp) Lmin = sp->Lmin;
   w.dist2[i] = qnan();
   if (!w.movable[i]) {
     w.success[i] = 0;
@@ -362,8 +376,9 @@ __global__ __launch_bounds__(64) void k_walk_diag(WalkState w, WalkLayer ly) {
 }
 
 __global__ __launch_bounds__(256) void k_walk_harvest(WalkState w, long long ring_host, long long *ring_dev, double r2,
-                                                      double *rec) {
+                                                      double *rec, const StepParams *sp) {
   __shared__ double part[256][5];
+  if (sp) r2 = sp->r2;
   const long long ring = ring_dev ? *ring_dev : ring_host;
   double nc = 0, nmov = 0, nsucc = 0, nfar = 0, slog = 0;
   const double ref = sqrt(r2);
@@ -442,7 +457,12 @@ __global__ __launch_bounds__(256) void k_walk_ring_shift(WalkState w, long long 
 }
 
 __global__ void k_walk_restart_philox(WalkState w, const double *live, const double *Ls, int nlive, double Lmin,
-                                      unsigned long long seed, unsigned long long offset) {
+                                      unsigned long long seed, unsigned long long offset, const StepParams *sp) {
+  if (sp) {
+    Lmin = sp->Lmin;
+    seed = sp->seed;
+    offset = sp->offset;
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w.P || w.generation[i] >= 0) return;
   int pick = -1;
@@ -634,16 +654,18 @@ void launch_walk_reset(const WalkState &w, hipStream_t s) {
   hipLaunchKernelGGL(k_walk_reset, grid_for(n), dim3(256), 0, s, w);
 }
 
-void launch_walk_step_back(const WalkState &w, double Lmin, long long *gmax_scratch, uint8_t *flags, hipStream_t s) {
+void launch_walk_step_back(const WalkState &w, double Lmin, long long *gmax_scratch, uint8_t *flags, hipStream_t s,
+                           const StepParams *sp) {
   hipLaunchKernelGGL(k_max_generation, dim3(1), dim3(256), 0, s, w.generation, w.P, gmax_scratch);
   hipLaunchKernelGGL(k_step_back, grid_for(w.P), dim3(256), 0, s, Lmin, w.allL, w.P, w.G, w.generation, w.currentt,
-                     gmax_scratch, w.sl, w.sr, flags);
+                     gmax_scratch, w.sl, w.sr, flags, sp);
 }
 
 void launch_walk_restart_philox(const WalkState &w, const double *live, const double *Ls, int nlive, double Lmin,
-                                unsigned long long seed, unsigned long long offset, long long *ring, hipStream_t s) {
+                                unsigned long long seed, unsigned long long offset, long long *ring, hipStream_t s,
+                                const StepParams *sp) {
   hipLaunchKernelGGL(k_walk_ring_shift, dim3(1), dim3(256), 0, s, w, ring);
-  hipLaunchKernelGGL(k_walk_restart_philox, grid_for(w.P, 64), dim3(64), 0, s, w, live, Ls, nlive, Lmin, seed, offset);
+  hipLaunchKernelGGL(k_walk_restart_philox, grid_for(w.P, 64), dim3(64), 0, s, w, live, Ls, nlive, Lmin, seed, offset, sp);
 }
 
 void launch_walk_start(const WalkState &w, const long long *idx, int n, const double *rows, const double *L,
@@ -664,14 +686,14 @@ void launch_walk_brackets(const WalkState &w, const long long *idx, int n, doubl
 }
 
 void launch_walk_brackets_philox(const WalkState &w, double scale, int kind, double dirscale, WalkDirData dd,
-                                 unsigned long long seed, unsigned long long offset, hipStream_t s) {
+                                 unsigned long long seed, unsigned long long offset, hipStream_t s, const StepParams *sp) {
   hipLaunchKernelGGL(k_walk_brackets_philox, grid_for(w.P, 64), dim3(64), 0, s, w, scale, kind, dirscale, dd, seed,
-                     offset);
+                     offset, sp);
 }
 
 void launch_walk_propose(const WalkState &w, const double *unif, unsigned long long seed, unsigned long long offset,
-                         hipStream_t s) {
-  hipLaunchKernelGGL(k_walk_propose, grid_for(w.P, 64), dim3(64), 0, s, w, unif, seed, offset);
+                         hipStream_t s, const StepParams *sp) {
+  hipLaunchKernelGGL(k_walk_propose, grid_for(w.P, 64), dim3(64), 0, s, w, unif, seed, offset, sp);
 }
 
 void launch_walk_transform(const WalkState &w, int tkind, double a, double b, hipStream_t s) {
@@ -682,13 +704,14 @@ void launch_walk_expand(const WalkState &w, const unsigned *blk, const double *p
   hipLaunchKernelGGL(k_walk_expand, grid_for(w.P), dim3(256), 0, s, w, blk, pc, Lc);
 }
 
-void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStream_t s) {
-  hipLaunchKernelGGL(k_walk_update, grid_for(w.P, 64), dim3(64), 0, s, w, Lmin);
+void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStream_t s, const StepParams *sp) {
+  hipLaunchKernelGGL(k_walk_update, grid_for(w.P, 64), dim3(64), 0, s, w, Lmin, sp);
   if (layer.kind >= 0) hipLaunchKernelGGL(k_walk_diag, dim3(w.P), dim3(64), 0, s, w, layer);
 }
 
-void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, hipStream_t s) {
-  hipLaunchKernelGGL(k_walk_harvest, dim3(1), dim3(256), 0, s, w, ring, ring_dev, r2, rec);
+void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, hipStream_t s,
+                         const StepParams *sp) {
+  hipLaunchKernelGGL(k_walk_harvest, dim3(1), dim3(256), 0, s, w, ring, ring_dev, r2, rec, sp);
 }
 
 void launch_within_unit_cube(const double *u, int n, int d, uint8_t *out, hipStream_t s) {
@@ -723,7 +746,7 @@ void launch_step_back(double Lmin, double *allL, int n, int G, long long *genera
   if (n <= 0) return;
   hipLaunchKernelGGL(k_max_generation, dim3(1), dim3(256), 0, s, generation, n, gmax_scratch);
   hipLaunchKernelGGL(k_step_back, grid_for(n), dim3(256), 0, s, Lmin, allL, n, G, generation, currentt, gmax_scratch,
-                     (const uint8_t *)nullptr, (const uint8_t *)nullptr, (uint8_t *)nullptr);
+                     (const uint8_t *)nullptr, (const uint8_t *)nullptr, (uint8_t *)nullptr, (const StepParams *)nullptr);
 }
 
 void launch_line_intersection(const double *origin, const double *direction, int n, int d, double *tleft,

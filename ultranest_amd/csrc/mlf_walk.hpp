@@ -41,6 +41,13 @@ struct WalkLayer {
   double r2;               // maxradiussq
 };
 
+// Per-call scalars of the whole-step path when it is replayed as a hipGraph: kernel arguments are frozen
+// at capture time, so the values that change from call to call are read from device memory instead.
+struct StepParams {
+  double Lmin, scale, dirscale, r2;
+  unsigned long long seed, offset;
+};
+
 // direction generators on the device (Philox); kinds follow the reference functions
 enum WalkDirection {
   DIR_CUBE_ORIENTED = 0,          // stepfuncs.pyx:348-370
@@ -61,31 +68,35 @@ struct WalkDirData {
 
 void launch_walk_reset(const WalkState &w, hipStream_t s);
 // step_back + snapshot: flags[i] = bit0 !isfinite(currentt) | bit1 searching_left | bit2 searching_right
-void launch_walk_step_back(const WalkState &w, double Lmin, long long *gmax_scratch, uint8_t *flags, hipStream_t s);
+void launch_walk_step_back(const WalkState &w, double Lmin, long long *gmax_scratch, uint8_t *flags, hipStream_t s,
+                           const StepParams *sp = nullptr);
 void launch_walk_start(const WalkState &w, const long long *idx, int n, const double *rows, const double *L,
                        hipStream_t s);
 void launch_walk_points(const WalkState &w, const long long *idx, int n, double *out, hipStream_t s);
 void launch_walk_brackets(const WalkState &w, const long long *idx, int n, double scale, const double *v_rows,
                           hipStream_t s);
 void launch_walk_brackets_philox(const WalkState &w, double scale, int kind, double dirscale, WalkDirData dd,
-                                 unsigned long long seed, unsigned long long offset, hipStream_t s);
+                                 unsigned long long seed, unsigned long long offset, hipStream_t s,
+                                 const StepParams *sp = nullptr);
 // unif: one U[0,1) per walker (host stream) or nullptr -> Philox(seed, offset + walker)
 void launch_walk_propose(const WalkState &w, const double *unif, unsigned long long seed,
-                         unsigned long long offset, hipStream_t s);
+                         unsigned long long offset, hipStream_t s, const StepParams *sp = nullptr);
 // p = transform(unew) for every walker: tkind 0 identity, 1 x*a + b, 2 (x*a)*b
 void launch_walk_transform(const WalkState &w, int tkind, double a, double b, hipStream_t s);
 // host likelihood: compacted (pnew, Lnew) of the acceptable walkers -> full-size arrays
 void launch_walk_expand(const WalkState &w, const unsigned *blk, const double *pc, const double *Lc,
                         hipStream_t s);
-void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStream_t s);
+void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStream_t s, const StepParams *sp = nullptr);
 // rec: [0] harvested flag, [1] L, [2] left, [3] right, [4] nc, [5] nmovable, [6] nsuccess, [7] nfar,
 //      [8] sum log(dist/ref + 1e-10), [9 ..] u (d) then p (nparams)
 // ring_dev != nullptr: the ring index lives on the device (read, advanced when a walker was harvested, and
 // reported in rec[9 + d + nparams])
-void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, hipStream_t s);
+void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, hipStream_t s,
+                         const StepParams *sp = nullptr);
 // device-side setup_start: ring index skips restarting walkers, restarts draw live points with L > Lmin
 void launch_walk_restart_philox(const WalkState &w, const double *live, const double *Ls, int nlive, double Lmin,
-                                unsigned long long seed, unsigned long long offset, long long *ring, hipStream_t s);
+                                unsigned long long seed, unsigned long long offset, long long *ring, hipStream_t s,
+                                const StepParams *sp = nullptr);
 
 // ---- stateless forms on device arrays (the parity boundary of ultranest.stepfuncs) -------------
 void launch_within_unit_cube(const double *u, int n, int d, uint8_t *out, hipStream_t s);

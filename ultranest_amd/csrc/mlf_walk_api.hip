@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <vector>
 
@@ -35,6 +36,13 @@ struct mlf_walkers {
   unsigned nblk = 0;
   bool proposed = false, compacted = false;
   std::vector<uint8_t> host_snap;
+  // whole-step hipGraph: one launch replays the ~12 kernels + the record copy; the values that change per
+  // call travel through a pinned StepParams block
+  hipGraphExec_t gexec = nullptr;
+  StepParams *h_sp = nullptr;      // pinned
+  double *h_rec = nullptr;         // pinned
+  DevBuf d_sp;
+  std::vector<unsigned long long> gkey;
 };
 
 namespace {
@@ -173,6 +181,10 @@ int mlf_walkers_destroy(mlf_walkers *w) {
                    &w->pc, &w->Lc, &w->rec, &w->aux, &w->axes, &w->live, &w->std, &w->lay_ctr, &w->lay_mat,
                    &w->lay_wrap, &w->liveL, &w->ring};
   for (DevBuf *b : all) b->release();
+  w->d_sp.release();
+  if (w->gexec) (void)hipGraphExecDestroy(w->gexec);
+  if (w->h_sp) (void)hipHostFree(w->h_sp);
+  if (w->h_rec) (void)hipHostFree(w->h_rec);
   delete w;
   return 0;
 }
@@ -429,6 +441,91 @@ int mlf_walkers_step_dev(mlf_walkers *w, double Lmin, double scale, int dirkind,
   CK(hipGetLastError());
   if (int rc = download(rec, w->rec, nrec * sizeof(double), s)) return rc;
   CK(hipStreamSynchronize(s));
+  const uint64_t per = (uint64_t)((w->d + 1) / 2 + 2);
+  *next_offset = offset + (uint64_t)w->P * (per > 64 ? per : 64);
+  return 0;
+}
+
+int mlf_walkers_step_graph(mlf_walkers *w, double Lmin, double scale, int dirkind, double dirscale, uint64_t seed,
+                           uint64_t offset, int tkind, double ta, double tb, int lkind, const double *aux, double sigma,
+                           double *rec, uint64_t *next_offset) {
+  if (!w || !rec || !next_offset) return ctx_fail_arg(MLF_E_BADARG, "null pointer");
+  if (!w->have_liveL) return ctx_fail_arg(MLF_E_STATE, "mlf_walkers_set_live not called");
+  if (dirkind < 0 || dirkind > DIR_MIXTURE) return ctx_fail_arg(MLF_E_BADARG, "unknown direction kind");
+  if (tkind < 0 || tkind > 2 || lkind < 0 || lkind > 3) return ctx_fail_arg(MLF_E_BADARG, "unknown transform / likelihood kind");
+  if (lkind == 0 && !aux) return ctx_fail_arg(MLF_E_BADARG, "the Gaussian likelihood needs its centres");
+  const bool need_axes = dirkind == DIR_REGION_ORIENTED || dirkind == DIR_REGION_RANDOM || dirkind == DIR_MIXTURE;
+  if ((need_axes && !w->have_axes) || (dirkind == DIR_CUBE_ORIENTED_SCALED && !w->have_std))
+    return ctx_fail_arg(MLF_E_STATE, "mlf_walkers_set_direction_data has not provided what this direction kind needs");
+  if (int rc = ensure_params(w, (size_t)w->d)) return rc;
+  hipStream_t s = ctx_stream();
+  const size_t nrec = 10 + 2 * (size_t)w->d;
+  if (!w->ring.p) {
+    CK(w->ring.reserve(8));
+    CK(hipMemsetAsync(w->ring.p, 0, 8, s));
+  }
+  if (!w->h_sp) {
+    CK(hipHostMalloc(reinterpret_cast<void **>(&w->h_sp), sizeof(StepParams), hipHostMallocDefault));
+    CK(hipHostMalloc(reinterpret_cast<void **>(&w->h_rec), nrec * sizeof(double), hipHostMallocDefault));
+    CK(w->d_sp.reserve(sizeof(StepParams)));
+  }
+  CK(w->rec.reserve(nrec * sizeof(double)));
+  CK(w->aux.reserve((size_t)w->d * 8));
+  if (aux)
+    if (int rc = upload(w->aux, aux, (size_t)w->d * 8, s)) return rc;
+  // everything a captured kernel argument depends on: a change means a new capture
+  auto bits = [](double v) {
+    unsigned long long u;
+    memcpy(&u, &v, sizeof u);
+    return u;
+  };
+  auto addr = [](const void *p) { return (unsigned long long)(uintptr_t)p; };
+  std::vector<unsigned long long> key = {
+      (unsigned long long)dirkind, (unsigned long long)tkind, bits(ta), bits(tb), (unsigned long long)lkind, bits(sigma),
+      (unsigned long long)(w->layer_kind + 1), (unsigned long long)w->layer_wrap, (unsigned long long)w->nlive,
+      addr(w->live.p), addr(w->liveL.p), addr(w->axes.p), addr(w->std.p), addr(w->lay_ctr.p), addr(w->lay_mat.p),
+      addr(w->lay_wrap.p), addr(w->aux.p), addr(w->rec.p), addr(w->pnew.p), addr(w->currentp.p)};
+  if (!w->gexec || key != w->gkey) {
+    if (w->gexec) {
+      CK(hipGraphExecDestroy(w->gexec));
+      w->gexec = nullptr;
+    }
+    const WalkState st = state_of(w);
+    WalkDirData dd{};
+    dd.axes = w->axes.as<double>();
+    dd.live = w->live.as<double>();
+    dd.nlive = w->nlive;
+    dd.std = w->std.as<double>();
+    const StepParams *sp = w->d_sp.as<StepParams>();
+    CK(hipStreamSynchronize(s));
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    (void)hipMemcpyAsync(w->d_sp.p, w->h_sp, sizeof(StepParams), hipMemcpyHostToDevice, s);
+    launch_walk_step_back(st, 0.0, w->gmax.as<long long>(), nullptr, s, sp);
+    launch_walk_restart_philox(st, w->live.as<double>(), w->liveL.as<double>(), w->nlive, 0.0, 0, 0,
+                               w->ring.as<long long>(), s, sp);
+    launch_walk_brackets_philox(st, 0.0, dirkind, 0.0, dd, 0, 0, s, sp);
+    launch_walk_propose(st, nullptr, 0, 0, s, sp);
+    launch_walk_transform(st, tkind, ta, tb, s);
+    launch_loglike(lkind, st.pnew, w->d, w->P, w->aux.as<double>(), sigma, st.Lnew, s);
+    launch_walk_update(st, 0.0, layer_of(w), s, sp);
+    launch_walk_harvest(st, 0, w->ring.as<long long>(), 0.0, w->rec.as<double>(), s, sp);
+    (void)hipMemcpyAsync(w->h_rec, w->rec.p, nrec * sizeof(double), hipMemcpyDeviceToHost, s);
+    hipGraph_t graph = nullptr;
+    CK(hipStreamEndCapture(s, &graph));
+    hipError_t e = hipGraphInstantiate(&w->gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return ctx_fail_hip(e, "hipGraphInstantiate", "mlf_walk_api.hip", __LINE__);
+    w->gkey = key;
+  }
+  w->h_sp->Lmin = Lmin;
+  w->h_sp->scale = scale;
+  w->h_sp->dirscale = dirscale;
+  w->h_sp->r2 = w->r2;
+  w->h_sp->seed = seed;
+  w->h_sp->offset = offset;
+  CK(hipGraphLaunch(w->gexec, s));
+  CK(hipStreamSynchronize(s));
+  memcpy(rec, w->h_rec, nrec * sizeof(double));
   const uint64_t per = (uint64_t)((w->d + 1) / 2 + 2);
   *next_offset = offset + (uint64_t)w->P * (per > 64 ? per : 64);
   return 0;

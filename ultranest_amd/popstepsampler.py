@@ -212,17 +212,18 @@ class _Walkers(object):
         us, Ls = f64(us), f64(Ls)
         check(_lib.lib().mlf_walkers_set_live(self._h, ptr(us), ptr(Ls), len(Ls)))
 
-    def step_dev(self, Lmin, scale, kind, dirscale, rng, tspec, lspec):
-        """Whole sampler step on the device; returns the record (with the ring index after the step)."""
+    def step_dev(self, Lmin, scale, kind, dirscale, rng, tspec, lspec, graph=True):
+        """Whole sampler step on the device (graph: replayed as one hipGraph launch); returns the record
+        (with the ring index after the step)."""
         self.nparams = self.ndim
         tkind, ta, tb = tspec
         lkind, aux, sigma = lspec
         rec = np.empty(10 + 2 * self.ndim)
         nxt = ctypes.c_uint64(0)
-        check(_lib.lib().mlf_walkers_step_dev(self._h, float(Lmin), float(scale), int(kind), float(dirscale),
-                                              ctypes.c_uint64(rng.seed), ctypes.c_uint64(rng.offset), int(tkind),
-                                              float(ta), float(tb), int(lkind), ptr(None if aux is None else f64(aux)),
-                                              float(sigma), ptr(rec), ctypes.byref(nxt)))
+        fn = _lib.lib().mlf_walkers_step_graph if graph else _lib.lib().mlf_walkers_step_dev
+        check(fn(self._h, float(Lmin), float(scale), int(kind), float(dirscale), ctypes.c_uint64(rng.seed),
+                 ctypes.c_uint64(rng.offset), int(tkind), float(ta), float(tb), int(lkind),
+                 ptr(None if aux is None else f64(aux)), float(sigma), ptr(rec), ctypes.byref(nxt)))
         rng.offset = nxt.value
         out = self._record(rec, self.ndim)
         out["ring"] = int(rec[9 + 2 * self.ndim])
@@ -262,6 +263,7 @@ class PopulationSliceSampler(GenericPopulationSampler):
         if device_rng is not None and not isinstance(device_rng, DeviceRNG):
             raise TypeError("device_rng must be an ultranest_amd.regions.DeviceRNG")
         self.device_rng = device_rng
+        self.use_graph = True     # whole-step path: replay the kernel sequence as one hipGraph launch
         self._walkers = None
         self._generation = np.zeros(popsize, dtype=int_dtype) - 1
         self._flags = np.ones(popsize, dtype=np.uint8)
@@ -406,7 +408,7 @@ class PopulationSliceSampler(GenericPopulationSampler):
             w.set_live(us, Ls)
             seen["live_age"] = 0
         seen["live_age"] += 1
-        rec = w.step_dev(Lmin, self.scale, device_kind, 1.0, self.device_rng, tspec, lspec)
+        rec = w.step_dev(Lmin, self.scale, device_kind, 1.0, self.device_rng, tspec, lspec, graph=self.use_graph)
         out = self._finish_call(rec, region, shift=False)
         self.ringindex = rec["ring"]
         return out
