@@ -172,16 +172,8 @@ __global__ void k_walk_brackets(WalkState w, const long long *idx, int n, double
 // setup_brackets with a device-side direction draw for every walker whose bracket is undefined.
 // Philox stream 2, (npairs + 2) blocks per walker: block 0 = integer picks + mixture coin,
 // blocks 1.. = Box-Muller pairs.
-__global__ void k_walk_brackets_philox(WalkState w, double scale, int kind, double dirscale, WalkDirData dd,
-                                       unsigned long long seed, unsigned long long offset, const StepParams *sp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= w.P) return;
-  if (sp) {
-    scale = sp->scale;
-    dirscale = sp->dirscale;
-    seed = sp->seed;
-    offset = sp->offset;
-  }
+__device__ void d_brackets_philox(const WalkState &w, int i, double scale, int kind, double dirscale, const WalkDirData &dd,
+                                  unsigned long long seed, unsigned long long offset) {
   if (isfinite(w.currentt[i])) return;
   const int d = w.d;
   double *v = w.currentv + (size_t)i * d;
@@ -238,15 +230,22 @@ __global__ void k_walk_brackets_philox(WalkState w, double scale, int kind, doub
   w.currentt[i] = 0.0;
 }
 
-// evolve, first half (stepfuncs.pyx:249-261): slice coordinate, proposed point, cube test
-__global__ void k_walk_propose(WalkState w, const double *unif, unsigned long long seed, unsigned long long offset,
-                               const StepParams *sp) {
+__global__ void k_walk_brackets_philox(WalkState w, double scale, int kind, double dirscale, WalkDirData dd,
+                                       unsigned long long seed, unsigned long long offset, const StepParams *sp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w.P) return;
   if (sp) {
+    scale = sp->scale;
+    dirscale = sp->dirscale;
     seed = sp->seed;
     offset = sp->offset;
   }
+  d_brackets_philox(w, i, scale, kind, dirscale, dd, seed, offset);
+}
+
+// evolve, first half (stepfuncs.pyx:249-261): slice coordinate, proposed point, cube test
+__device__ void d_propose(const WalkState &w, int i, const double *unif, unsigned long long seed,
+                          unsigned long long offset) {
   const long long g = w.generation[i];
   const bool movable = g >= 0 && g < w.G - 1;
   w.movable[i] = movable ? 1 : 0;
@@ -286,6 +285,17 @@ __global__ void k_walk_propose(WalkState w, const double *unif, unsigned long lo
     ok = ok && inside_open_unit(x);
   }
   w.acceptable[i] = ok ? 1 : 0;
+}
+
+__global__ void k_walk_propose(WalkState w, const double *unif, unsigned long long seed, unsigned long long offset,
+                               const StepParams *sp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w.P) return;
+  if (sp) {
+    seed = sp->seed;
+    offset = sp->offset;
+  }
+  d_propose(w, i, unif, seed, offset);
 }
 
 __global__ void k_walk_transform(WalkState w, int tkind, double a, double b) {
@@ -376,10 +386,31 @@ __global__ __launch_bounds__(64) void k_walk_diag(WalkState w, WalkLayer ly) {
 }
 
 __global__ __launch_bounds__(256) void k_walk_harvest(WalkState w, long long ring_host, long long *ring_dev, double r2,
-                                                      double *rec, const StepParams *sp) {
+                                                      double *rec, const StepParams *sp, const uint8_t *was_starting) {
   __shared__ double part[256][5];
+  __shared__ long long s_ring;
   if (sp) r2 = sp->r2;
-  const long long ring = ring_dev ? *ring_dev : ring_host;
+  if (was_starting) {   // setup_start's ring shift (:456-462), deferred from the prologue kernel
+    __shared__ int nstart[256];
+    int n = 0;
+    for (int i = threadIdx.x; i < w.P; i += 256) n += was_starting[i] ? 1 : 0;
+    nstart[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) nstart[threadIdx.x] += nstart[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      long long r = *ring_dev;
+      if (nstart[0] > 0 && nstart[0] < w.P)
+        for (int guard = 0; guard < w.P && was_starting[r]; ++guard) r = (r + 1) % w.P;
+      *ring_dev = r;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) s_ring = ring_dev ? *ring_dev : ring_host;
+  __syncthreads();
+  const long long ring = s_ring;
   double nc = 0, nmov = 0, nsucc = 0, nfar = 0, slog = 0;
   const double ref = sqrt(r2);
   for (int i = threadIdx.x; i < w.P; i += 256) {
@@ -456,15 +487,9 @@ __global__ __launch_bounds__(256) void k_walk_ring_shift(WalkState w, long long 
   }
 }
 
-__global__ void k_walk_restart_philox(WalkState w, const double *live, const double *Ls, int nlive, double Lmin,
-                                      unsigned long long seed, unsigned long long offset, const StepParams *sp) {
-  if (sp) {
-    Lmin = sp->Lmin;
-    seed = sp->seed;
-    offset = sp->offset;
-  }
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= w.P || w.generation[i] >= 0) return;
+__device__ void d_restart_philox(const WalkState &w, int i, const double *live, const double *Ls, int nlive, double Lmin,
+                                 unsigned long long seed, unsigned long long offset) {
+  if (w.generation[i] >= 0) return;
   int pick = -1;
   for (int attempt = 0; attempt < 64 && pick < 0; ++attempt) {
     unsigned r4[4];
@@ -481,6 +506,56 @@ __global__ void k_walk_restart_philox(WalkState w, const double *live, const dou
   for (int k = 0; k < w.d; ++k) w.allu[((size_t)i * w.G) * w.d + k] = live[(size_t)pick * w.d + k];
   w.allL[(size_t)i * w.G] = Ls[pick];
   w.generation[i] = 0;
+}
+
+__global__ void k_walk_restart_philox(WalkState w, const double *live, const double *Ls, int nlive, double Lmin,
+                                      unsigned long long seed, unsigned long long offset, const StepParams *sp) {
+  if (sp) {
+    Lmin = sp->Lmin;
+    seed = sp->seed;
+    offset = sp->offset;
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w.P) return;
+  d_restart_philox(w, i, live, Ls, nlive, Lmin, seed, offset);
+}
+
+// The per-walker front half of a whole step in ONE kernel (each dependent launch costs ~5 us of dispatch
+// latency, and a 100-walker population has nothing else to hide it): step_back, restart, new slice,
+// proposal, prior transform.  was_starting feeds the ring-index shift in the harvest kernel.  step_back
+// looks at all G chain slots: slots past a walker's generation hold NaN, so this equals the reference's
+// window of max(generation) + 1 slots.
+__global__ void k_walk_prologue(WalkState w, const double *live, const double *Ls, int nlive, int dirkind, WalkDirData dd,
+                                int tkind, double ta, double tb, uint8_t *was_starting, StepParams p,
+                                const StepParams *sp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w.P) return;
+  if (sp) p = *sp;
+  long long gen = w.generation[i];
+  double t = w.currentt[i];
+  step_back_walker(p.Lmin, w.allL + (size_t)i * w.G, w.G, w.G, gen, t);
+  w.generation[i] = gen;
+  w.currentt[i] = t;
+  was_starting[i] = gen < 0 ? 1 : 0;
+  d_restart_philox(w, i, live, Ls, nlive, p.Lmin, p.seed, p.offset);
+  d_brackets_philox(w, i, p.scale, dirkind, p.dirscale, dd, p.seed, p.offset);
+  d_propose(w, i, nullptr, p.seed, p.offset);
+  if (w.movable[i]) {
+    const double *un = w.unew + (size_t)i * w.d;
+    double *pn = w.pnew + (size_t)i * w.nparams;
+    for (int k = 0; k < w.d; ++k) {
+      const double x = un[k];
+      double v = x;
+      if (tkind == 1) {
+        const double m = x * ta;
+        v = m + tb;
+      } else if (tkind == 2) {
+        const double m = x * ta;
+        v = m * tb;
+      }
+      pn[k] = v;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ stateless forms ------------
@@ -668,6 +743,13 @@ void launch_walk_restart_philox(const WalkState &w, const double *live, const do
   hipLaunchKernelGGL(k_walk_restart_philox, grid_for(w.P, 64), dim3(64), 0, s, w, live, Ls, nlive, Lmin, seed, offset, sp);
 }
 
+void launch_walk_prologue(const WalkState &w, const double *live, const double *Ls, int nlive, int dirkind, WalkDirData dd,
+                          int tkind, double ta, double tb, uint8_t *was_starting, const StepParams &p, const StepParams *sp,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(k_walk_prologue, grid_for(w.P, 64), dim3(64), 0, s, w, live, Ls, nlive, dirkind, dd, tkind, ta, tb,
+                     was_starting, p, sp);
+}
+
 void launch_walk_start(const WalkState &w, const long long *idx, int n, const double *rows, const double *L,
                        hipStream_t s) {
   if (n <= 0) return;
@@ -710,8 +792,8 @@ void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStr
 }
 
 void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, hipStream_t s,
-                         const StepParams *sp) {
-  hipLaunchKernelGGL(k_walk_harvest, dim3(1), dim3(256), 0, s, w, ring, ring_dev, r2, rec, sp);
+                         const StepParams *sp, const uint8_t *was_starting) {
+  hipLaunchKernelGGL(k_walk_harvest, dim3(1), dim3(256), 0, s, w, ring, ring_dev, r2, rec, sp, was_starting);
 }
 
 void launch_within_unit_cube(const double *u, int n, int d, uint8_t *out, hipStream_t s) {

@@ -92,7 +92,11 @@ void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStr
 // ring_dev != nullptr: the ring index lives on the device (read, advanced when a walker was harvested, and
 // reported in rec[9 + d + nparams])
 void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, hipStream_t s,
-                         const StepParams *sp = nullptr);
+                         const StepParams *sp = nullptr, const uint8_t *was_starting = nullptr);
+// front half of a whole step in one kernel: step_back, restart, new slice, proposal, prior transform
+void launch_walk_prologue(const WalkState &w, const double *live, const double *Ls, int nlive, int dirkind, WalkDirData dd,
+                          int tkind, double ta, double tb, uint8_t *was_starting, const StepParams &p, const StepParams *sp,
+                          hipStream_t s);
 // device-side setup_start: ring index skips restarting walkers, restarts draw live points with L > Lmin
 void launch_walk_restart_philox(const WalkState &w, const double *live, const double *Ls, int nlive, double Lmin,
                                 unsigned long long seed, unsigned long long offset, long long *ring, hipStream_t s,

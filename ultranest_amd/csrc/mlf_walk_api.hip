@@ -429,15 +429,18 @@ int mlf_walkers_step_dev(mlf_walkers *w, double Lmin, double scale, int dirkind,
   dd.nlive = w->nlive;
   dd.std = w->std.as<double>();
   // one stream of kernels, one record back: step_back, restarts, new slices, proposal, likelihood, update, harvest
-  launch_walk_step_back(st, Lmin, w->gmax.as<long long>(), nullptr, s);
-  launch_walk_restart_philox(st, w->live.as<double>(), w->liveL.as<double>(), w->nlive, Lmin, seed, offset,
-                             w->ring.as<long long>(), s);
-  launch_walk_brackets_philox(st, scale, dirkind, dirscale, dd, seed, offset, s);
-  launch_walk_propose(st, nullptr, seed, offset, s);
-  launch_walk_transform(st, tkind, ta, tb, s);
+  StepParams p{};
+  p.Lmin = Lmin;
+  p.scale = scale;
+  p.dirscale = dirscale;
+  p.r2 = w->r2;
+  p.seed = seed;
+  p.offset = offset;
+  launch_walk_prologue(st, w->live.as<double>(), w->liveL.as<double>(), w->nlive, dirkind, dd, tkind, ta, tb,
+                       w->flags.as<uint8_t>(), p, nullptr, s);
   launch_loglike(lkind, st.pnew, w->d, w->P, w->aux.as<double>(), sigma, st.Lnew, s);
   launch_walk_update(st, Lmin, layer_of(w), s);
-  launch_walk_harvest(st, 0, w->ring.as<long long>(), w->r2, w->rec.as<double>(), s);
+  launch_walk_harvest(st, 0, w->ring.as<long long>(), w->r2, w->rec.as<double>(), s, nullptr, w->flags.as<uint8_t>());
   CK(hipGetLastError());
   if (int rc = download(rec, w->rec, nrec * sizeof(double), s)) return rc;
   CK(hipStreamSynchronize(s));
@@ -500,15 +503,11 @@ int mlf_walkers_step_graph(mlf_walkers *w, double Lmin, double scale, int dirkin
     CK(hipStreamSynchronize(s));
     CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     (void)hipMemcpyAsync(w->d_sp.p, w->h_sp, sizeof(StepParams), hipMemcpyHostToDevice, s);
-    launch_walk_step_back(st, 0.0, w->gmax.as<long long>(), nullptr, s, sp);
-    launch_walk_restart_philox(st, w->live.as<double>(), w->liveL.as<double>(), w->nlive, 0.0, 0, 0,
-                               w->ring.as<long long>(), s, sp);
-    launch_walk_brackets_philox(st, 0.0, dirkind, 0.0, dd, 0, 0, s, sp);
-    launch_walk_propose(st, nullptr, 0, 0, s, sp);
-    launch_walk_transform(st, tkind, ta, tb, s);
+    launch_walk_prologue(st, w->live.as<double>(), w->liveL.as<double>(), w->nlive, dirkind, dd, tkind, ta, tb,
+                         w->flags.as<uint8_t>(), StepParams{}, sp, s);
     launch_loglike(lkind, st.pnew, w->d, w->P, w->aux.as<double>(), sigma, st.Lnew, s);
     launch_walk_update(st, 0.0, layer_of(w), s, sp);
-    launch_walk_harvest(st, 0, w->ring.as<long long>(), 0.0, w->rec.as<double>(), s, sp);
+    launch_walk_harvest(st, 0, w->ring.as<long long>(), 0.0, w->rec.as<double>(), s, sp, w->flags.as<uint8_t>());
     (void)hipMemcpyAsync(w->h_rec, w->rec.p, nrec * sizeof(double), hipMemcpyDeviceToHost, s);
     hipGraph_t graph = nullptr;
     CK(hipStreamEndCapture(s, &graph));
