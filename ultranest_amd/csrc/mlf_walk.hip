@@ -169,12 +169,25 @@ __global__ void k_walk_brackets(WalkState w, const long long *idx, int n, double
   }
 }
 
-// setup_brackets with a device-side direction draw for every walker whose bracket is undefined.
+// ---- wave-per-walker kernels: lane = coordinate (d <= 128: two coordinates per lane) ----------------
+// One thread per walker read its rows with a 8 d-byte stride between lanes (every load a different cache
+// line) and walked them serially: 0.93 ms per step at 10^5 walkers x 50, ~25 us of pure latency per kernel at
+// 100 walkers.  Here a wave owns one walker: rows are read coalesced, per-walker scalars are computed by all
+// lanes alike (same inputs, same result) and written by lane 0.
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// setup_brackets with a device-side direction draw for a walker whose bracket is undefined.
 // Philox stream 2, (npairs + 2) blocks per walker: block 0 = integer picks + mixture coin,
-// blocks 1.. = Box-Muller pairs.
-__device__ void d_brackets_philox(const WalkState &w, int i, double scale, int kind, double dirscale, const WalkDirData &dd,
-                                  unsigned long long seed, unsigned long long offset) {
-  if (isfinite(w.currentt[i])) return;
+// blocks 1.. = Box-Muller pairs (coordinate k takes the cosine / sine branch of pair k / 2).
+// `t`, `left`, `right`, `sl`, `sr` are the wave's copies of the walker state (updated here).
+__device__ void dw_brackets_philox(const WalkState &w, int i, int lane, double scale, int kind, double dirscale,
+                                   const WalkDirData &dd, unsigned long long seed, unsigned long long offset, double &t,
+                                   double &left, double &right, bool &sl, bool &sr) {
+  if (isfinite(t)) return;   // wave-uniform
   const int d = w.d;
   double *v = w.currentv + (size_t)i * d;
   const int npairs = (d + 1) / 2;
@@ -185,80 +198,98 @@ __device__ void d_brackets_philox(const WalkState &w, int i, double scale, int k
   if (k == DIR_MIXTURE) k = (u01(pick[2], pick[3]) < 0.5) ? DIR_DIFFERENTIAL : DIR_REGION_ORIENTED;
   if (k == DIR_CUBE_ORIENTED || k == DIR_CUBE_ORIENTED_SCALED) {
     const int j = (int)below(pick[0], (unsigned)d);
-    for (int c = 0; c < d; ++c) v[c] = 0.0;
-    v[j] = (k == DIR_CUBE_ORIENTED) ? dirscale : dirscale * dd.std[j];
+    for (int c = lane; c < d; c += 64) v[c] = c == j ? ((k == DIR_CUBE_ORIENTED) ? dirscale : dirscale * dd.std[j]) : 0.0;
   } else if (k == DIR_REGION_ORIENTED) {
     const int j = (int)below(pick[0], (unsigned)d);
-    for (int c = 0; c < d; ++c) v[c] = dd.axes[(size_t)j * d + c] * dirscale;
+    for (int c = lane; c < d; c += 64) v[c] = dd.axes[(size_t)j * d + c] * dirscale;
   } else if (k == DIR_DIFFERENTIAL) {
     const unsigned a = below(pick[0], (unsigned)dd.nlive);
     unsigned b = below(pick[1], (unsigned)(dd.nlive - 1));
     if (b >= a) ++b;
-    for (int c = 0; c < d; ++c) v[c] = (dd.live[(size_t)a * d + c] - dd.live[(size_t)b * d + c]) * dirscale;
+    for (int c = lane; c < d; c += 64) v[c] = (dd.live[(size_t)a * d + c] - dd.live[(size_t)b * d + c]) * dirscale;
   } else {   // DIR_RANDOM, DIR_REGION_RANDOM: isotropic unit vector of length dirscale
-    double norm2 = 0.0;
-    for (int j = 0; j < npairs; ++j) {
-      unsigned r4[4];
-      philox_block(seed, 2u, base + 1 + j, r4);
-      const double rad = sqrt(-2.0 * log(u01(r4[0], r4[1])));
-      const double ang = 2.0 * M_PI * u01(r4[2], r4[3]);
-      const double g0 = rad * cos(ang), g1 = rad * sin(ang);
-      v[2 * j] = g0;
-      norm2 += g0 * g0;
-      if (2 * j + 1 < d) {
-        v[2 * j + 1] = g1;
-        norm2 += g1 * g1;
+    double g[2] = {0.0, 0.0};
+    double part = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = lane + 64 * h;
+      if (c < d) {
+        unsigned r4[4];
+        philox_block(seed, 2u, base + 1 + (c >> 1), r4);
+        const double rad = sqrt(-2.0 * log(u01(r4[0], r4[1])));
+        const double ang = 2.0 * M_PI * u01(r4[2], r4[3]);
+        g[h] = (c & 1) ? rad * sin(ang) : rad * cos(ang);
+        part += g[h] * g[h];
       }
     }
-    const double f = dirscale / sqrt(norm2);
+    const double f = dirscale / sqrt(wave_sum(part));
+    g[0] *= f;
+    g[1] *= f;
     if (k == DIR_RANDOM) {
-      for (int c = 0; c < d; ++c) v[c] *= f;
-    } else {   // v[i] = sum_j axes[i][j] * v1[j]; v1 is parked in unew (free before propose)
-      double *v1 = w.unew + (size_t)i * d;
-      for (int c = 0; c < d; ++c) v1[c] = v[c] * f;
-      for (int r = 0; r < d; ++r) {
-        double acc = 0.0;
-        for (int c = 0; c < d; ++c) acc += dd.axes[(size_t)r * d + c] * v1[c];
-        v[r] = acc;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (lane + 64 * h < d) v[lane + 64 * h] = g[h];
+    } else {   // v[r] = sum_c axes[r][c] * v1[c]   (einsum 'ij,kj->ki', stepfuncs.pyx:476)
+      double acc[2] = {0.0, 0.0};
+      for (int c = 0; c < d; ++c) {
+        const double v1c = __shfl(c < 64 ? g[0] : g[1], c & 63, 64);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = lane + 64 * h;
+          if (r < d) acc[h] += dd.axes[(size_t)r * d + c] * v1c;
+        }
       }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (lane + 64 * h < d) v[lane + 64 * h] = acc[h];
     }
   }
-  w.left[i] = -scale;
-  w.right[i] = scale;
-  w.sl[i] = 1;
-  w.sr[i] = 1;
-  w.currentt[i] = 0.0;
+  left = -scale;
+  right = scale;
+  sl = true;
+  sr = true;
+  t = 0.0;
+  if (lane == 0) {
+    w.left[i] = left;
+    w.right[i] = right;
+    w.sl[i] = 1;
+    w.sr[i] = 1;
+    w.currentt[i] = 0.0;
+  }
 }
 
-__global__ void k_walk_brackets_philox(WalkState w, double scale, int kind, double dirscale, WalkDirData dd,
-                                       unsigned long long seed, unsigned long long offset, const StepParams *sp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= w.P) return;
+__global__ __launch_bounds__(64) void k_walk_brackets_philox(WalkState w, double scale, int kind, double dirscale,
+                                                             WalkDirData dd, unsigned long long seed,
+                                                             unsigned long long offset, const StepParams *sp) {
+  const int lane = threadIdx.x;
   if (sp) {
     scale = sp->scale;
     dirscale = sp->dirscale;
     seed = sp->seed;
     offset = sp->offset;
   }
-  d_brackets_philox(w, i, scale, kind, dirscale, dd, seed, offset);
+  for (int i = blockIdx.x; i < w.P; i += gridDim.x) {   // several walkers per wave: 10^5 one-wave workgroups are dispatch bound
+    double t = w.currentt[i], left = w.left[i], right = w.right[i];
+    bool sl = w.sl[i] != 0, sr = w.sr[i] != 0;
+    dw_brackets_philox(w, i, lane, scale, kind, dirscale, dd, seed, offset, t, left, right, sl, sr);
+  }
 }
 
-// evolve, first half (stepfuncs.pyx:249-261): slice coordinate, proposed point, cube test
-__device__ void d_propose(const WalkState &w, int i, const double *unif, unsigned long long seed,
-                          unsigned long long offset) {
-  const long long g = w.generation[i];
-  const bool movable = g >= 0 && g < w.G - 1;
-  w.movable[i] = movable ? 1 : 0;
+// evolve, first half (stepfuncs.pyx:249-261): slice coordinate, proposed point, cube test; optionally the
+// prior transform of the proposal (tkind < 0: none).  gen, t, left, right, sl, sr = the wave's copies.
+__device__ void dw_propose(const WalkState &w, int i, int lane, const double *unif, unsigned long long seed,
+                           unsigned long long offset, long long gen, double t, double left, double right, bool sl, bool sr,
+                           int tkind, double ta, double tb) {
+  const bool movable = gen >= 0 && gen < w.G - 1;
+  if (lane == 0) w.movable[i] = movable ? 1 : 0;
   if (!movable) {
-    w.acceptable[i] = 0;
+    if (lane == 0) w.acceptable[i] = 0;
     return;
   }
-  const bool l = w.sl[i] != 0, r = w.sr[i] != 0;
-  double t;
-  if (l) {
-    t = w.left[i];
-  } else if (r) {
-    t = w.right[i];
+  if (sl) {
+    t = left;
+  } else if (sr) {
+    t = right;
   } else {
     double u;
     if (unif) {
@@ -268,34 +299,46 @@ __device__ void d_propose(const WalkState &w, int i, const double *unif, unsigne
       philox_block(seed, 3u, offset + (unsigned long long)i, r4);
       u = u01(r4[0], r4[1]);
     }
-    const double lo = w.left[i];
-    const double range = w.right[i] - lo;
+    const double range = right - left;
     const double scaled = range * u;
-    t = lo + scaled;
-    w.currentt[i] = t;
+    t = left + scaled;
+    if (lane == 0) w.currentt[i] = t;
   }
-  const double *u0 = w.allu + ((size_t)i * w.G + g) * w.d;
+  const double *u0 = w.allu + ((size_t)i * w.G + gen) * w.d;
   const double *v = w.currentv + (size_t)i * w.d;
   double *un = w.unew + (size_t)i * w.d;
   bool ok = true;
-  for (int k = 0; k < w.d; ++k) {
+  for (int k = lane; k < w.d; k += 64) {
     const double step = v[k] * t;
     const double x = u0[k] + step;
     un[k] = x;
     ok = ok && inside_open_unit(x);
+    if (tkind >= 0) {
+      double p = x;
+      if (tkind == 1) {
+        const double m = x * ta;
+        p = m + tb;
+      } else if (tkind == 2) {
+        const double m = x * ta;
+        p = m * tb;
+      }
+      w.pnew[(size_t)i * w.nparams + k] = p;
+    }
   }
-  w.acceptable[i] = ok ? 1 : 0;
+  const bool all_ok = __all(ok);
+  if (lane == 0) w.acceptable[i] = all_ok ? 1 : 0;
 }
 
-__global__ void k_walk_propose(WalkState w, const double *unif, unsigned long long seed, unsigned long long offset,
-                               const StepParams *sp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= w.P) return;
+__global__ __launch_bounds__(64) void k_walk_propose(WalkState w, const double *unif, unsigned long long seed,
+                                                     unsigned long long offset, const StepParams *sp) {
+  const int lane = threadIdx.x;
   if (sp) {
     seed = sp->seed;
     offset = sp->offset;
   }
-  d_propose(w, i, unif, seed, offset);
+  for (int i = blockIdx.x; i < w.P; i += gridDim.x)
+    dw_propose(w, i, lane, unif, seed, offset, w.generation[i], w.currentt[i], w.left[i], w.right[i], w.sl[i] != 0,
+               w.sr[i] != 0, -1, 0.0, 0.0);
 }
 
 __global__ void k_walk_transform(WalkState w, int tkind, double a, double b) {
@@ -334,42 +377,48 @@ __global__ __launch_bounds__(256) void k_walk_expand(WalkState w, const unsigned
 
 // evolve, second half (evolve_update) + PopulationSliceSampler.advance bookkeeping
 // (popstepsampler.py:585-603) + move diagnostics (diagnose_move_distances :64-94)
-__global__ void k_walk_update(WalkState w, double Lmin, const StepParams *sp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= w.P) return;
+__global__ __launch_bounds__(64) void k_walk_update(WalkState w, double Lmin, const StepParams *sp) {
+  const int lane = threadIdx.x;
   if (sp) Lmin = sp->Lmin;
-  w.dist2[i] = qnan();
-  if (!w.movable[i]) {
-    w.success[i] = 0;
-    return;
-  }
+  for (int i = blockIdx.x; i < w.P; i += gridDim.x) {
+  // every lane reads the walker's scalars and derives the same decision; lane 0 writes them back
+  const bool movable = w.movable[i] != 0;
   const bool hit = w.acceptable[i] != 0 && w.Lnew[i] > Lmin;
   double t = w.currentt[i], left = w.left[i], right = w.right[i];
   uint8_t sl = w.sl[i], sr = w.sr[i];
-  const bool success = update_walker(hit, t, left, right, sl, sr);
-  w.currentt[i] = t;
-  w.left[i] = left;
-  w.right[i] = right;
-  w.sl[i] = sl;
-  w.sr[i] = sr;
-  w.success[i] = success ? 1 : 0;
-  if (!success) return;
   const long long g0 = w.generation[i];
-  const long long g = g0 + 1;
-  w.generation[i] = g;
+  const double Lnew = w.Lnew[i];
+  bool success = false;
+  if (movable) success = update_walker(hit, t, left, right, sl, sr);
+  if (lane == 0) {
+    w.dist2[i] = qnan();
+    w.success[i] = success ? 1 : 0;
+    if (movable) {
+      w.currentt[i] = t;
+      w.left[i] = left;
+      w.right[i] = right;
+      w.sl[i] = sl;
+      w.sr[i] = sr;
+    }
+    if (success) {
+      w.generation[i] = g0 + 1;
+      w.allL[(size_t)i * w.G + g0 + 1] = Lnew;
+    }
+  }
+  if (!success) continue;
   const double *un = w.unew + (size_t)i * w.d;
-  double *dst = w.allu + ((size_t)i * w.G + g) * w.d;
-  for (int k = 0; k < w.d; ++k) dst[k] = un[k];
-  w.allL[(size_t)i * w.G + g] = w.Lnew[i];
-  for (int k = 0; k < w.nparams; ++k) w.currentp[(size_t)i * w.nparams + k] = w.pnew[(size_t)i * w.nparams + k];
+  double *dst = w.allu + ((size_t)i * w.G + g0 + 1) * w.d;
+  for (int k = lane; k < w.d; k += 64) dst[k] = un[k];
+  for (int k = lane; k < w.nparams; k += 64) w.currentp[(size_t)i * w.nparams + k] = w.pnew[(size_t)i * w.nparams + k];
+  }
 }
 
 // diagnose_move_distances for the walkers that moved: one wave per walker, lane = whitened
 // coordinate (T rows are read coalesced), squared differences summed by a fixed shuffle tree
 __global__ __launch_bounds__(64) void k_walk_diag(WalkState w, WalkLayer ly) {
-  const int i = blockIdx.x;
-  if (!w.success[i]) return;
   const int lane = threadIdx.x;
+  for (int i = blockIdx.x; i < w.P; i += gridDim.x) {
+  if (!w.success[i]) continue;
   const long long g = w.generation[i];          // already advanced by k_walk_update
   const double *uo = w.allu + ((size_t)i * w.G + (g - 1)) * w.d;
   const double *un = w.unew + (size_t)i * w.d;
@@ -383,10 +432,49 @@ __global__ __launch_bounds__(64) void k_walk_diag(WalkState w, WalkLayer ly) {
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (lane == 0) w.dist2[i] = acc;
+  }
+}
+
+// step statistics, stage 1: every workgroup reduces 4096 walkers to one row of partial sums
+// (likelihood evaluations, walkers moved on, successes, far-enough moves, sum of log relative distances)
+constexpr int kStatsChunk = 4096;
+__global__ __launch_bounds__(256) void k_walk_stats(WalkState w, double r2, const StepParams *sp, double *partials) {
+  __shared__ double part[256][5];
+  if (sp) r2 = sp->r2;
+  const double ref = sqrt(r2);
+  double nc = 0, nmov = 0, nsucc = 0, nfar = 0, slog = 0;
+  const int i0 = blockIdx.x * kStatsChunk;
+  for (int j = threadIdx.x; j < kStatsChunk; j += 256) {
+    const int i = i0 + j;
+    if (i >= w.P || !w.movable[i]) continue;
+    nmov += 1;
+    nc += w.acceptable[i] ? 1 : 0;
+    if (w.success[i]) {
+      nsucc += 1;
+      const double d2 = w.dist2[i];
+      if (!isnan(d2)) {
+        nfar += (d2 > r2) ? 1 : 0;
+        slog += log(sqrt(d2) / ref + 1e-10);
+      }
+    }
+  }
+  part[threadIdx.x][0] = nc;
+  part[threadIdx.x][1] = nmov;
+  part[threadIdx.x][2] = nsucc;
+  part[threadIdx.x][3] = nfar;
+  part[threadIdx.x][4] = slog;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+      for (int c = 0; c < 5; ++c) part[threadIdx.x][c] += part[threadIdx.x + off][c];
+    __syncthreads();
+  }
+  if (threadIdx.x < 5) partials[blockIdx.x * 5 + threadIdx.x] = part[0][threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_walk_harvest(WalkState w, long long ring_host, long long *ring_dev, double r2,
-                                                      double *rec, const StepParams *sp, const uint8_t *was_starting) {
+                                                      double *rec, const StepParams *sp, const uint8_t *was_starting,
+                                                      const double *partials) {
   __shared__ double part[256][5];
   __shared__ long long s_ring;
   if (sp) r2 = sp->r2;
@@ -412,19 +500,13 @@ __global__ __launch_bounds__(256) void k_walk_harvest(WalkState w, long long rin
   __syncthreads();
   const long long ring = s_ring;
   double nc = 0, nmov = 0, nsucc = 0, nfar = 0, slog = 0;
-  const double ref = sqrt(r2);
-  for (int i = threadIdx.x; i < w.P; i += 256) {
-    if (!w.movable[i]) continue;
-    nmov += 1;
-    nc += w.acceptable[i] ? 1 : 0;
-    if (w.success[i]) {
-      nsucc += 1;
-      const double d2 = w.dist2[i];
-      if (!isnan(d2)) {
-        nfar += (d2 > r2) ? 1 : 0;
-        slog += log(sqrt(d2) / ref + 1e-10);
-      }
-    }
+  const int nrows = (w.P + kStatsChunk - 1) / kStatsChunk;   // stage 2 of the statistics: rows of k_walk_stats
+  for (int b = threadIdx.x; b < nrows; b += 256) {
+    nc += partials[b * 5 + 0];
+    nmov += partials[b * 5 + 1];
+    nsucc += partials[b * 5 + 2];
+    nfar += partials[b * 5 + 3];
+    slog += partials[b * 5 + 4];
   }
   part[threadIdx.x][0] = nc;
   part[threadIdx.x][1] = nmov;
@@ -487,10 +569,10 @@ __global__ __launch_bounds__(256) void k_walk_ring_shift(WalkState w, long long 
   }
 }
 
-__device__ void d_restart_philox(const WalkState &w, int i, const double *live, const double *Ls, int nlive, double Lmin,
-                                 unsigned long long seed, unsigned long long offset) {
-  if (w.generation[i] >= 0) return;
-  int pick = -1;
+__device__ void dw_restart_philox(const WalkState &w, int i, int lane, const double *live, const double *Ls, int nlive,
+                                  double Lmin, unsigned long long seed, unsigned long long offset, long long &gen) {
+  if (gen >= 0) return;   // wave-uniform
+  int pick = -1;          // every lane runs the same draws
   for (int attempt = 0; attempt < 64 && pick < 0; ++attempt) {
     unsigned r4[4];
     philox_block(seed, 4u, offset + (unsigned long long)i * 64ull + attempt, r4);
@@ -503,21 +585,26 @@ __device__ void d_restart_philox(const WalkState &w, int i, const double *live, 
   for (int j = 0; j < nlive && pick < 0; ++j)
     if (Ls[j] > Lmin) pick = j;
   if (pick < 0) return;   // no live point above the threshold: the walker stays unstarted
-  for (int k = 0; k < w.d; ++k) w.allu[((size_t)i * w.G) * w.d + k] = live[(size_t)pick * w.d + k];
-  w.allL[(size_t)i * w.G] = Ls[pick];
-  w.generation[i] = 0;
+  for (int k = lane; k < w.d; k += 64) w.allu[((size_t)i * w.G) * w.d + k] = live[(size_t)pick * w.d + k];
+  gen = 0;
+  if (lane == 0) {
+    w.allL[(size_t)i * w.G] = Ls[pick];
+    w.generation[i] = 0;
+  }
 }
 
-__global__ void k_walk_restart_philox(WalkState w, const double *live, const double *Ls, int nlive, double Lmin,
-                                      unsigned long long seed, unsigned long long offset, const StepParams *sp) {
+__global__ __launch_bounds__(64) void k_walk_restart_philox(WalkState w, const double *live, const double *Ls, int nlive,
+                                                            double Lmin, unsigned long long seed,
+                                                            unsigned long long offset, const StepParams *sp) {
   if (sp) {
     Lmin = sp->Lmin;
     seed = sp->seed;
     offset = sp->offset;
   }
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= w.P) return;
-  d_restart_philox(w, i, live, Ls, nlive, Lmin, seed, offset);
+  for (int i = blockIdx.x; i < w.P; i += gridDim.x) {
+    long long gen = w.generation[i];
+    dw_restart_philox(w, i, threadIdx.x, live, Ls, nlive, Lmin, seed, offset, gen);
+  }
 }
 
 // The per-walker front half of a whole step in ONE kernel (each dependent launch costs ~5 us of dispatch
@@ -525,36 +612,31 @@ __global__ void k_walk_restart_philox(WalkState w, const double *live, const dou
 // proposal, prior transform.  was_starting feeds the ring-index shift in the harvest kernel.  step_back
 // looks at all G chain slots: slots past a walker's generation hold NaN, so this equals the reference's
 // window of max(generation) + 1 slots.
-__global__ void k_walk_prologue(WalkState w, const double *live, const double *Ls, int nlive, int dirkind, WalkDirData dd,
-                                int tkind, double ta, double tb, uint8_t *was_starting, StepParams p,
-                                const StepParams *sp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= w.P) return;
+__global__ __launch_bounds__(64) void k_walk_prologue(WalkState w, const double *live, const double *Ls, int nlive,
+                                                      int dirkind, WalkDirData dd, int tkind, double ta, double tb,
+                                                      uint8_t *was_starting, StepParams p, const StepParams *sp) {
+  const int lane = threadIdx.x;
   if (sp) p = *sp;
+  for (int i = blockIdx.x; i < w.P; i += gridDim.x) {
   long long gen = w.generation[i];
   double t = w.currentt[i];
-  step_back_walker(p.Lmin, w.allL + (size_t)i * w.G, w.G, w.G, gen, t);
-  w.generation[i] = gen;
-  w.currentt[i] = t;
-  was_starting[i] = gen < 0 ? 1 : 0;
-  d_restart_philox(w, i, live, Ls, nlive, p.Lmin, p.seed, p.offset);
-  d_brackets_philox(w, i, p.scale, dirkind, p.dirscale, dd, p.seed, p.offset);
-  d_propose(w, i, nullptr, p.seed, p.offset);
-  if (w.movable[i]) {
-    const double *un = w.unew + (size_t)i * w.d;
-    double *pn = w.pnew + (size_t)i * w.nparams;
-    for (int k = 0; k < w.d; ++k) {
-      const double x = un[k];
-      double v = x;
-      if (tkind == 1) {
-        const double m = x * ta;
-        v = m + tb;
-      } else if (tkind == 2) {
-        const double m = x * ta;
-        v = m * tb;
-      }
-      pn[k] = v;
-    }
+  if (lane == 0) {   // the chain unwinding is scalar work on this walker's likelihood history
+    step_back_walker(p.Lmin, w.allL + (size_t)i * w.G, w.G, w.G, gen, t);
+    w.generation[i] = gen;
+    w.currentt[i] = t;
+    was_starting[i] = gen < 0 ? 1 : 0;
+  }
+  gen = __shfl(gen, 0, 64);
+  t = __shfl(t, 0, 64);
+  dw_restart_philox(w, i, lane, live, Ls, nlive, p.Lmin, p.seed, p.offset, gen);
+  double left = w.left[i], right = w.right[i];
+  bool sl = w.sl[i] != 0, sr = w.sr[i] != 0;
+  dw_brackets_philox(w, i, lane, p.scale, dirkind, p.dirscale, dd, p.seed, p.offset, t, left, right, sl, sr);
+  // the rows written above (restart point, direction) are read back by other lanes of this wave
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  dw_propose(w, i, lane, nullptr, p.seed, p.offset, gen, t, left, right, sl, sr, tkind, ta, tb);
   }
 }
 
@@ -723,6 +805,9 @@ __global__ void k_row_dist2(const double *a, const double *b, int n, int d, doub
 
 // ------------------------------------------------------------------ launchers -------------------
 static inline dim3 grid_for(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+// wave-per-walker kernels: one one-wave workgroup per walker (fewer, looping waves measured slower: 0.88 vs 0.71 ms
+// per step at 10^5 walkers); the loop in the kernels only matters beyond 4 M walkers
+static inline dim3 walker_grid(int P) { return dim3((unsigned)(P < (1 << 22) ? P : (1 << 22))); }
 
 void launch_walk_reset(const WalkState &w, hipStream_t s) {
   const long long n = (long long)w.P * w.G * w.d;
@@ -740,13 +825,13 @@ void launch_walk_restart_philox(const WalkState &w, const double *live, const do
                                 unsigned long long seed, unsigned long long offset, long long *ring, hipStream_t s,
                                 const StepParams *sp) {
   hipLaunchKernelGGL(k_walk_ring_shift, dim3(1), dim3(256), 0, s, w, ring);
-  hipLaunchKernelGGL(k_walk_restart_philox, grid_for(w.P, 64), dim3(64), 0, s, w, live, Ls, nlive, Lmin, seed, offset, sp);
+  hipLaunchKernelGGL(k_walk_restart_philox, walker_grid(w.P), dim3(64), 0, s, w, live, Ls, nlive, Lmin, seed, offset, sp);
 }
 
 void launch_walk_prologue(const WalkState &w, const double *live, const double *Ls, int nlive, int dirkind, WalkDirData dd,
                           int tkind, double ta, double tb, uint8_t *was_starting, const StepParams &p, const StepParams *sp,
                           hipStream_t s) {
-  hipLaunchKernelGGL(k_walk_prologue, grid_for(w.P, 64), dim3(64), 0, s, w, live, Ls, nlive, dirkind, dd, tkind, ta, tb,
+  hipLaunchKernelGGL(k_walk_prologue, walker_grid(w.P), dim3(64), 0, s, w, live, Ls, nlive, dirkind, dd, tkind, ta, tb,
                      was_starting, p, sp);
 }
 
@@ -769,13 +854,13 @@ void launch_walk_brackets(const WalkState &w, const long long *idx, int n, doubl
 
 void launch_walk_brackets_philox(const WalkState &w, double scale, int kind, double dirscale, WalkDirData dd,
                                  unsigned long long seed, unsigned long long offset, hipStream_t s, const StepParams *sp) {
-  hipLaunchKernelGGL(k_walk_brackets_philox, grid_for(w.P, 64), dim3(64), 0, s, w, scale, kind, dirscale, dd, seed,
+  hipLaunchKernelGGL(k_walk_brackets_philox, walker_grid(w.P), dim3(64), 0, s, w, scale, kind, dirscale, dd, seed,
                      offset, sp);
 }
 
 void launch_walk_propose(const WalkState &w, const double *unif, unsigned long long seed, unsigned long long offset,
                          hipStream_t s, const StepParams *sp) {
-  hipLaunchKernelGGL(k_walk_propose, grid_for(w.P, 64), dim3(64), 0, s, w, unif, seed, offset, sp);
+  hipLaunchKernelGGL(k_walk_propose, walker_grid(w.P), dim3(64), 0, s, w, unif, seed, offset, sp);
 }
 
 void launch_walk_transform(const WalkState &w, int tkind, double a, double b, hipStream_t s) {
@@ -787,13 +872,15 @@ void launch_walk_expand(const WalkState &w, const unsigned *blk, const double *p
 }
 
 void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStream_t s, const StepParams *sp) {
-  hipLaunchKernelGGL(k_walk_update, grid_for(w.P, 64), dim3(64), 0, s, w, Lmin, sp);
-  if (layer.kind >= 0) hipLaunchKernelGGL(k_walk_diag, dim3(w.P), dim3(64), 0, s, w, layer);
+  hipLaunchKernelGGL(k_walk_update, walker_grid(w.P), dim3(64), 0, s, w, Lmin, sp);
+  if (layer.kind >= 0) hipLaunchKernelGGL(k_walk_diag, walker_grid(w.P), dim3(64), 0, s, w, layer);
 }
 
-void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, hipStream_t s,
-                         const StepParams *sp, const uint8_t *was_starting) {
-  hipLaunchKernelGGL(k_walk_harvest, dim3(1), dim3(256), 0, s, w, ring, ring_dev, r2, rec, sp, was_starting);
+void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, double *partials,
+                         hipStream_t s, const StepParams *sp, const uint8_t *was_starting) {
+  const int nrows = (w.P + kStatsChunk - 1) / kStatsChunk;
+  hipLaunchKernelGGL(k_walk_stats, dim3(nrows), dim3(256), 0, s, w, r2, sp, partials);
+  hipLaunchKernelGGL(k_walk_harvest, dim3(1), dim3(256), 0, s, w, ring, ring_dev, r2, rec, sp, was_starting, partials);
 }
 
 void launch_within_unit_cube(const double *u, int n, int d, uint8_t *out, hipStream_t s) {

@@ -26,7 +26,7 @@ struct mlf_walkers {
   DevBuf allu, allL, generation, currentt, currentv, left, right, sl, sr, currentp;
   DevBuf unew, movable, acceptable, success, pnew, Lnew, dist2;
   DevBuf gmax, flags, snap, idx, rows, vals, vidx, vrows, unif, blk, compact, pc, Lc, rec, aux;
-  DevBuf axes, live, std, lay_ctr, lay_mat, lay_wrap, liveL, ring;
+  DevBuf axes, live, std, lay_ctr, lay_mat, lay_wrap, liveL, ring, partials;
   bool have_liveL = false;
   int nlive = 0;
   bool have_axes = false, have_live = false, have_std = false;
@@ -123,7 +123,7 @@ int finish_common(mlf_walkers *w, double Lmin, int64_t ringindex, double *rec) {
   CK(w->rec.reserve(nrec * sizeof(double)));
   const WalkState st = state_of(w);
   launch_walk_update(st, Lmin, layer_of(w), s);
-  launch_walk_harvest(st, ringindex, nullptr, w->r2, w->rec.as<double>(), s);
+  launch_walk_harvest(st, ringindex, nullptr, w->r2, w->rec.as<double>(), w->partials.as<double>(), s);
   CK(hipGetLastError());
   if (int rc = download(rec, w->rec, nrec * sizeof(double), s)) return rc;
   CK(hipStreamSynchronize(s));
@@ -155,7 +155,7 @@ int mlf_walkers_create(mlf_walkers **out, size_t popsize, size_t nsteps, size_t 
               {&w->sr, P},               {&w->unew, P * d * 8}, {&w->movable, P},        {&w->acceptable, P},
               {&w->success, P},          {&w->Lnew, P * 8},     {&w->dist2, P * 8},      {&w->gmax, 8},
               {&w->flags, P},            {&w->unif, P * 8},     {&w->blk, ((P + 255) / 256 + 1) * 4},
-              {&w->compact, P * d * 8}};
+              {&w->compact, P * d * 8}, {&w->partials, ((P + 4095) / 4096) * 5 * 8}};
   for (auto &e : plan) {
     hipError_t err = e.b->reserve(e.bytes);
     if (err != hipSuccess) {
@@ -179,7 +179,7 @@ int mlf_walkers_destroy(mlf_walkers *w) {
                    &w->sr, &w->currentp, &w->unew, &w->movable, &w->acceptable, &w->success, &w->pnew, &w->Lnew,
                    &w->dist2, &w->gmax, &w->flags, &w->snap, &w->idx, &w->rows, &w->vals, &w->vidx, &w->vrows, &w->unif, &w->blk, &w->compact,
                    &w->pc, &w->Lc, &w->rec, &w->aux, &w->axes, &w->live, &w->std, &w->lay_ctr, &w->lay_mat,
-                   &w->lay_wrap, &w->liveL, &w->ring};
+                   &w->lay_wrap, &w->liveL, &w->ring, &w->partials};
   for (DevBuf *b : all) b->release();
   w->d_sp.release();
   if (w->gexec) (void)hipGraphExecDestroy(w->gexec);
@@ -440,7 +440,8 @@ int mlf_walkers_step_dev(mlf_walkers *w, double Lmin, double scale, int dirkind,
                        w->flags.as<uint8_t>(), p, nullptr, s);
   launch_loglike(lkind, st.pnew, w->d, w->P, w->aux.as<double>(), sigma, st.Lnew, s);
   launch_walk_update(st, Lmin, layer_of(w), s);
-  launch_walk_harvest(st, 0, w->ring.as<long long>(), w->r2, w->rec.as<double>(), s, nullptr, w->flags.as<uint8_t>());
+  launch_walk_harvest(st, 0, w->ring.as<long long>(), w->r2, w->rec.as<double>(), w->partials.as<double>(), s, nullptr,
+                      w->flags.as<uint8_t>());
   CK(hipGetLastError());
   if (int rc = download(rec, w->rec, nrec * sizeof(double), s)) return rc;
   CK(hipStreamSynchronize(s));
@@ -507,7 +508,8 @@ int mlf_walkers_step_graph(mlf_walkers *w, double Lmin, double scale, int dirkin
                          w->flags.as<uint8_t>(), StepParams{}, sp, s);
     launch_loglike(lkind, st.pnew, w->d, w->P, w->aux.as<double>(), sigma, st.Lnew, s);
     launch_walk_update(st, 0.0, layer_of(w), s, sp);
-    launch_walk_harvest(st, 0, w->ring.as<long long>(), 0.0, w->rec.as<double>(), s, sp, w->flags.as<uint8_t>());
+    launch_walk_harvest(st, 0, w->ring.as<long long>(), 0.0, w->rec.as<double>(), w->partials.as<double>(), s, sp,
+                        w->flags.as<uint8_t>());
     (void)hipMemcpyAsync(w->h_rec, w->rec.p, nrec * sizeof(double), hipMemcpyDeviceToHost, s);
     hipGraph_t graph = nullptr;
     CK(hipStreamEndCapture(s, &graph));
