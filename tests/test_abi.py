@@ -67,3 +67,32 @@ def test_argument_validation_is_host_side():
         kernels.find_nearby(np.zeros((3, 2)), np.zeros((2, 2)), 1.0, np.empty(2, dtype=np.int32))
     with pytest.raises(ValueError):
         kernels.maxradiussq_bootstrap(np.zeros((4, 2)), np.ones((1, 5), dtype=bool))
+
+
+def test_step_sampler_path_fails_loudly_without_device():
+    from ultranest_amd import _lib
+    import ultranest_amd.popstepsampler as pop
+    import ultranest_amd.stepfuncs as sf
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.HipLibraryError):
+        sf.within_unit_cube(np.zeros((3, 2)))
+    with pytest.raises(_lib.HipLibraryError):
+        sf.step_back(0.0, np.zeros((2, 3)), np.zeros(2, dtype=np.int64), np.zeros(2))
+    with pytest.raises(_lib.HipLibraryError):
+        pop._Walkers(4, 3, 2)
+
+
+def test_host_helpers_need_no_device():
+    """changed_rows (lazy device mirror) and the compiled MultiCounter are host code."""
+    from ultranest_amd import _lib
+    a = np.random.RandomState(1).uniform(size=(50, 7))
+    b = a.copy()
+    rows, n = _lib.changed_rows(a, b)
+    assert n == 0 and len(rows) == 0
+    b[[3, 17, 49]] += 1e-16 * (1 + b[[3, 17, 49]])       # one-ulp changes are seen
+    b[5, 2] = -0.0 if b[5, 2] == 0 else b[5, 2]
+    rows, n = _lib.changed_rows(a, b)
+    assert n == 3 and list(rows) == [3, 17, 49]
+    rows, n = _lib.changed_rows(a, b, capacity=2)          # more changes than capacity: count is still exact
+    assert n == 3 and list(rows) == [3, 17]
