@@ -251,3 +251,38 @@ def test_full_size_properties_c5(K):
             diff = a[:, k] - b[j, k]
             acc = acc + diff * diff
         assert np.flatnonzero(acc <= r2)[0] == idx[j]
+
+
+# ------------------------------------------------------------------ INTEGRATION.md stub -------
+def test_integration_md_ctypes_stub_runs_verbatim(K):
+    """The ctypes stub INTEGRATION.md section B shows a maintainer is executed as printed (only the
+    library name is made absolute) and checked against the oracle."""
+    import os
+    import re
+    from ultranest_amd import _lib
+    import oracle.oracle as orc
+    text = open(os.path.join(os.path.dirname(__file__), "..", "INTEGRATION.md")).read()
+    section = text[text.index("## B. ctypes stub"):]
+    code = re.search(r"```python\n(.*?)```", section, re.S).group(1)
+    assert '"libmlfriends_hip.so"' in code
+    ns = {}
+    exec(compile(code.replace('"libmlfriends_hip.so"', repr(_lib.LIB_PATH)), "INTEGRATION.md", "exec"), ns)
+    rng = np.random.RandomState(5)
+    a = rng.uniform(size=(300, 7))
+    b = rng.uniform(size=(1000, 7))
+    near = np.empty(len(b), dtype=np.int64)
+    ns["find_nearby"](a, b, 0.3, near)
+    np.testing.assert_array_equal(near, orc.find_nearby(a, b, 0.3))
+    sel = rng.randint(0, len(a), size=(6, len(a)))
+    masks = np.zeros((6, len(a)), dtype=bool)
+    for i in range(6):
+        masks[i, sel[i]] = True
+    r2, skipped = ns["maxradiussq_rounds"](a, masks)
+    o_r2, o_sk = orc.maxradiussq_bootstrap(a, masks)
+    np.testing.assert_array_equal(skipped, o_sk)
+    np.testing.assert_array_equal(r2, o_r2)
+    z = rng.uniform(0, 10 * np.pi, size=(500, 4))
+    np.testing.assert_allclose(ns["loglike"](z), orc.loglike_eggbox(z), rtol=1e-12, atol=0)
+    wide = rng.uniform(size=(4, 129))     # above MLF_MAX_DIM: the stub surfaces mlf_last_error()
+    with pytest.raises(RuntimeError, match="MLF_MAX_DIM"):
+        ns["find_nearby"](wide, wide, 0.3, near[:4].copy())
