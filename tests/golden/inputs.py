@@ -217,3 +217,16 @@ def build_nodes(cls, values, children, nroots):
     for node, kids in zip(nodes, children):
         node.children = [nodes[j] for j in kids]
     return nodes[:nroots]
+
+
+def tree_points(seed, nnodes, udim=3):
+    """Coordinates for the nodes of `random_tree(seed, ...)`: unit-cube points and a 'transformed' copy
+    with one derived column (pdim = udim + 1)."""
+    rs = np.random.RandomState(seed + 77)
+    u = rs.uniform(size=(nnodes, udim))
+    p = np.hstack((10. * u - 5., (u ** 2).sum(axis=1, keepdims=True)))
+    return u, p
+
+
+RESULT_TREES = [(1201, 20, 160, 6), (1202, 8, 90, 3)]      # (seed, nroots, nnodes, nbootstraps of the run counter)
+RESULT_PARAMNAMES = (["a", "b", "c"], ["r2"])

@@ -519,7 +519,91 @@ def g11(ref):
     print("  wrote g11_pointstore.tsv", os.path.getsize(path), "bytes;", len(pops), "pops")
 
 
-GROUPS = dict(g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
+# ------------------------------------------------------------------ G12 -----
+
+def run_and_write(netiter, update_results, make_run_dir, seed, nroots, nnodes, nboot, log_dir):
+    """The tail of a run as the reference's driver performs it (integrator.py:2650-2832, :2933-2995):
+    explore the tree with the run's counter, then `_update_results` (combine_results + logz_sequence +
+    result files).  `update_results(state, counter, saved_logl, saved_nodeids)` is the driver method."""
+    import types
+    values, children = inputs.random_tree(seed, nroots, nnodes)
+    us, ps = inputs.tree_points(seed, len(values))
+    pile = netiter.PointPile(us.shape[1], ps.shape[1])
+    for urow, prow in zip(us, ps):
+        pile.add(urow, prow)
+    roots = inputs.build_nodes(netiter.TreeNode, values, children, nroots)
+    root = netiter.TreeNode(id=-1, value=-np.inf, children=roots)
+    np.random.seed(seed)
+    explorer = netiter.BreadthFirstIterator(roots)
+    counter = netiter.MultiCounter(nroots=nroots, nbootstraps=nboot, random=False, check_insertion_order=False)
+    saved_logl, saved_nodeids = [], []
+    while True:
+        nxt = explorer.next_node()
+        if nxt is None:
+            break
+        rootid, node, (_, active_rootids, active_values, _) = nxt
+        saved_logl.append(node.value)
+        saved_nodeids.append(node.id)
+        counter.passing_node(rootid, node, active_rootids, active_values)
+        explorer.expand_children_of(rootid, node)
+    names, derived = inputs.RESULT_PARAMNAMES
+    state = types.SimpleNamespace(
+        log=False, logger=None, pointpile=pile, use_mpi=False, comm=None, ncall=7 * len(values), paramnames=list(names),
+        derivedparamnames=list(derived), min_num_live_points=nroots, root=root, log_to_disk=True,
+        logs=make_run_dir(log_dir, run_num=1), num_params=len(names) + len(derived))
+    update_results(state, counter, saved_logl, saved_nodeids)
+    return state, np.float64(np.random.uniform())
+
+
+def g12(ref):
+    """Run summaries and result files: the reference's `_update_results` on seeded
+    trees; inputs of the file writer, sha256 of every file it wrote, results.json verbatim."""
+    import hashlib
+    import shutil
+    import ultranest.netiter as netiter
+    from ultranest.integrator import ReactiveNestedSampler
+    from ultranest.utils import make_run_dir, resample_equal
+    out = {}
+    for seed, nroots, nnodes, nboot in inputs.RESULT_TREES:
+        tmp = tempfile.mkdtemp()
+        with np.errstate(all="ignore"):
+            state, next_random = run_and_write(netiter, ReactiveNestedSampler._update_results, make_run_dir, seed, nroots,
+                                               nnodes, nboot, tmp)
+        res, seq = state.results, state.run_sequence
+        k = "t%d_" % seed
+        out[k + "next_random"] = next_random
+        for name in ("upoints", "points", "weights", "logw", "bootstrapped_weights", "logl"):
+            out[k + "ws_" + name] = np.asarray(res["weighted_samples"][name])
+        out[k + "samples"] = np.asarray(res["samples"])
+        for name in ("logz", "logzerr", "logvol", "nlive", "insert_order", "logwt", "logl", "weights"):
+            out[k + "seq_" + name] = np.asarray(seq[name])
+        out[k + "results_json"] = np.array(open(os.path.join(state.logs["info"], "results.json")).read())
+        for sub, fn in (("chains", "equal_weighted_post.txt"), ("chains", "weighted_post.txt"),
+                        ("chains", "weighted_post_untransformed.txt"), ("chains", "run.txt"),
+                        ("info", "results.json"), ("info", "post_summary.csv")):
+            data = open(os.path.join(state.logs[sub], fn), "rb").read()
+            out[k + "sha256_" + fn] = np.array(hashlib.sha256(data).hexdigest())
+            out[k + "head_" + fn] = np.array(data[:400].decode())
+        vals = np.sort([n.value for n in state.root.children])
+        lo, hi = float(vals[len(vals) // 2]), float(vals[-1] + 1.0)
+        out[k + "count_tree"] = np.array(netiter.count_tree(state.root.children))
+        out[k + "count_between"] = np.array([lo, hi] + list(netiter.count_tree_between(state.root.children, lo, hi)))
+        for tag, thresh in (("mid", lo), ("high", hi), ("first", float(vals[0]))):
+            parents, weights = netiter.find_nodes_before(state.root, thresh)
+            out[k + "before_%s" % tag] = np.array([[thresh, n.id, w] for n, w in zip(parents, weights)], dtype=float).reshape(-1, 3)
+        print("  tree", seed, "niter", res["niter"], "logz", res["logz"], "+-", res["logzerr"], "ess", res["ess"])
+        shutil.rmtree(tmp)
+    # systematic resampling alone, incl. a weight vector whose cumulative sum stays below the last position
+    rs = np.random.RandomState(12)
+    w = rs.uniform(size=500) ** 6
+    w /= w.sum()
+    x = rs.normal(size=(500, 2))
+    out["resample_x"], out["resample_w"] = x, w
+    out["resample_out"] = resample_equal(x, w, rstate=np.random.RandomState(99))
+    save("g12_results", **out)
+
+
+GROUPS = dict(g12=g12, g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

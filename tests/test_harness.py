@@ -91,3 +91,38 @@ def test_static_nested_sampler_eggbox_d2_known_answer():
     res = s.run(dlogz=0.1)
     assert abs(res["logz"] - 235.9) < 0.6, res
     assert res["nclusters"] > 5, res
+
+
+def test_static_nested_sampler_writes_reference_result_files(backend, tmp_path):
+    """With `log_dir` the run keeps the point tree, replays it through the bootstrapped counters
+    (netiter.logz_sequence) and writes the reference's chains/ + info/ files (integrator.py:2933-2995)."""
+    import json
+    import os
+    from ultranest_amd.harness import StaticNestedSampler
+    sigma, centers = 0.05, np.array([0.5, 0.5])
+
+    def loglike(theta):
+        return -0.5 * (((theta - centers) / sigma) ** 2).sum(axis=1) - 0.5 * np.log(2 * np.pi * sigma ** 2) * 2
+
+    s = StaticNestedSampler(2, loglike, num_live_points=100, ndraw=1024, seed=5, log_dir=str(tmp_path / "out"),
+                            paramnames=["x", "y"])
+    res = s.run(dlogz=0.5)
+    assert res["run_dir"].endswith("run1")
+    # tree replay and the running sum describe the same run
+    assert abs(res["logz_tree"] - res["logz"]) < 0.05, res
+    assert abs(res["logz_tree"]) < 4 * res["logzerr_tree"] + 0.2, res
+    assert s.results["niter"] == res["niter"] + 100 == len(s.run_sequence["logz"])     # dead + final live points
+    assert s.results["ncall"] == res["ncall"] and s.results["paramnames"] == ["x", "y"]
+    chains, info = os.path.join(res["run_dir"], "chains"), os.path.join(res["run_dir"], "info")
+    post = np.loadtxt(os.path.join(chains, "equal_weighted_post.txt"), skiprows=1)
+    assert post.shape == (s.results["niter"], 2)
+    assert np.allclose(post.mean(axis=0), centers, atol=0.02) and np.allclose(post.std(axis=0), sigma, atol=0.015)
+    weighted = np.loadtxt(os.path.join(chains, "weighted_post_untransformed.txt"), skiprows=1)
+    assert weighted.shape == (s.results["niter"], 4) and abs(weighted[:, 0].sum() - 1) < 1e-9
+    assert np.all(np.diff(weighted[:, 1]) >= 0)                       # dead points in likelihood order
+    run = np.loadtxt(os.path.join(chains, "run.txt"), skiprows=1)
+    assert run.shape == (s.results["niter"], 7) and run[0, 3] == 100
+    summary = json.load(open(os.path.join(info, "results.json")))
+    assert summary["niter"] == s.results["niter"] and abs(summary["logz"] - res["logz_tree"]) < 1e-12
+    assert "insertion_order_MWW_test" in summary and "weighted_samples" not in summary
+    assert open(os.path.join(info, "post_summary.csv")).readline().startswith('"x_mean","x_stdev"')

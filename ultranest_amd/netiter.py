@@ -246,3 +246,233 @@ class MultiCounter(object):
         self._cache = None
         self.logweights.append(logwidth)
         self.istail.append(nchildren == 0)
+
+
+# ---- tree statistics, point pile and run summaries (what the result files hold) ----
+
+def _walk(roots):
+    """Yield (explorer, rootid, node, active_rootids) in the driver's breadth-first order; the consumer
+    decides whether to expand, drop or stop."""
+    explorer = BreadthFirstIterator(roots)
+    while True:
+        nxt = explorer.next_node()
+        if nxt is None:
+            return
+        rootid, node, (_, active_rootids, _, _) = nxt
+        yield explorer, rootid, node, active_rootids
+
+
+def count_tree(roots):
+    """(number of nodes, largest number of parallel edges) of a tree (reference netiter.py:259-285)."""
+    nnodes = maxwidth = 0
+    for explorer, rootid, node, active_rootids in _walk(roots):
+        nnodes += 1
+        maxwidth = max(maxwidth, len(active_rootids))
+        explorer.expand_children_of(rootid, node)
+    return nnodes, maxwidth
+
+
+def count_tree_between(roots, lo, hi):
+    """As :func:`count_tree`, restricted to nodes with lo <= value <= hi (reference :288-330)."""
+    nnodes = maxwidth = 0
+    for explorer, rootid, node, active_rootids in _walk(roots):
+        if node.value > hi:
+            break
+        if node.value >= lo:
+            nnodes += 1
+            maxwidth = max(maxwidth, len(active_rootids))
+        explorer.expand_children_of(rootid, node)
+    return nnodes, maxwidth
+
+
+def find_nodes_before(root, value):
+    """Nodes that have a child at or above `value`, and for each the product of the fork counts on its
+    path from the root's children (reference :333-383).  If a root child itself is at or above `value`
+    the answer ends with `root` (weight 1)."""
+    parents, parent_weights = [], []
+    nforks = dict((n.id, 1.) for n in root.children)
+    for explorer, rootid, node, _ in _walk(root.children):
+        mine = nforks.pop(node.id)
+        if node.value >= value:
+            parents.append(root)
+            parent_weights.append(1)
+            break
+        if any(child.value >= value for child in node.children):
+            parents.append(node)
+            parent_weights.append(mine)
+            explorer.drop_next_node()
+            continue
+        explorer.expand_children_of(rootid, node)
+        for child in node.children:
+            nforks[child.id] = mine * len(node.children)
+    return parents, parent_weights
+
+
+class PointPile(object):
+    """Growing table of the coordinates of every tree node: row ``node.id`` holds the unit-cube point and
+    the transformed point (reference netiter.py:386-465; same attribute names ``us``, ``ps``, ``nrows``)."""
+
+    def __init__(self, udim, pdim, chunksize=1000):
+        self.nrows = 0
+        self.chunksize = chunksize
+        self.udim = udim
+        self.pdim = pdim
+        self.us = np.zeros((chunksize, udim))
+        self.ps = np.zeros((chunksize, pdim))
+
+    def add(self, newpointu, newpointp):
+        """Append one point; returns its row index."""
+        assert len(newpointu) == self.udim, (newpointu, self.us.shape)
+        assert len(newpointp) == self.pdim, (newpointp, self.ps.shape)
+        if self.nrows == len(self.us):
+            self.us = np.concatenate((self.us, np.zeros((self.chunksize, self.udim))))
+            self.ps = np.concatenate((self.ps, np.zeros((self.chunksize, self.pdim))))
+        row = self.nrows
+        self.us[row] = newpointu
+        self.ps[row] = newpointp
+        self.nrows = row + 1
+        return row
+
+    def getu(self, i):
+        return self.us[i]
+
+    def getp(self, i):
+        return self.ps[i]
+
+    def make_node(self, value, u, p):
+        """Store the point and return the tree node that refers to it."""
+        return TreeNode(value=value, id=self.add(u, p))
+
+
+def combine_results(saved_logl, saved_nodeids, pointpile, main_iterator, mpi_comm=None):
+    """Summary dictionary of a finished exploration (reference netiter.py:858-972): evidence with its
+    bootstrap and tail uncertainties, effective sample size, information, weighted and equally weighted
+    posterior samples, posterior summaries, best fit.  Keys and value types follow the reference, which is
+    what ``info/results.json`` and the ``chains/`` files are written from.  `mpi_comm` is accepted for
+    signature compatibility; this build shards over torch.distributed, not MPI (must be None)."""
+    assert mpi_comm is None, "MPI exchange is not part of this build"
+    from .utils import resample_equal
+    saved_logl = np.array(saved_logl)
+    logwt = np.array(main_iterator.logweights)
+    all_logZ = np.asarray(main_iterator.all_logZ)
+    assert logwt.shape == (len(saved_logl), len(all_logZ)), (logwt.shape, saved_logl.shape, all_logZ.shape)
+    saved_u = pointpile.getu(saved_nodeids)
+    saved_v = pointpile.getp(saved_nodeids)
+    logwt0, logwt_bs = logwt[:, 0], logwt[:, 1:]
+    logZ_bs = all_logZ[1:]
+    logZ = main_iterator.logZ
+
+    wt_bs = np.exp(logwt_bs + saved_logl.reshape((-1, 1)) - logZ_bs)
+    wt0 = np.exp(logwt0 + saved_logl - all_logZ[0])
+    w = wt0 / wt0.sum()
+    assert np.isclose(w.sum() - 1, 0), w.sum()
+    n = len(w)
+    ess = n / (1.0 + ((n * w - 1)**2).sum() / n)
+    tail_fraction = w[np.asarray(main_iterator.istail)].sum()
+    logzerr_tail = 0
+    if tail_fraction != 0:
+        logzerr_tail = np.logaddexp(np.log(tail_fraction) + logZ, logZ) - logZ
+    logzerr_bs = (logZ_bs - logZ).max()
+    samples = resample_equal(saved_v, w)
+
+    # per-axis information gain from a 39-bin weighted histogram of the cube coordinates
+    edges = np.linspace(0, 1, 40)
+    information_gain_bits = []
+    for column in saved_u.T:
+        density, _ = np.histogram(column, weights=wt0, density=True, bins=edges)
+        information_gain_bits.append(float((np.log2(1 / ((density + 0.001) * 40)) / 40).sum()))
+
+    best = saved_logl.argmax()
+    all_H = np.asarray(main_iterator.all_H)
+    results = dict(
+        niter=len(saved_logl),
+        logz=logZ, logzerr=(logzerr_tail**2 + logzerr_bs**2)**0.5,
+        logz_bs=logZ_bs.mean(),
+        logz_single=logZ,
+        logzerr_tail=logzerr_tail,
+        logzerr_bs=logzerr_bs,
+        ess=ess,
+        H=all_H[0], Herr=all_H.std(),
+        posterior=dict(
+            mean=samples.mean(axis=0).tolist(),
+            stdev=samples.std(axis=0).tolist(),
+            median=np.percentile(samples, 50, axis=0).tolist(),
+            errlo=np.percentile(samples, 15.8655, axis=0).tolist(),
+            errup=np.percentile(samples, 84.1345, axis=0).tolist(),
+            information_gain_bits=information_gain_bits,
+        ),
+        weighted_samples=dict(
+            upoints=saved_u, points=saved_v, weights=wt0, logw=logwt0,
+            bootstrapped_weights=wt_bs, logl=saved_logl),
+        samples=samples,
+        maximum_likelihood=dict(
+            logl=saved_logl[best],
+            point=saved_v[best, :].tolist(),
+            point_untransformed=saved_u[best, :].tolist(),
+        ),
+    )
+    if getattr(main_iterator, 'check_insertion_order', False):
+        results['insertion_order_MWW_test'] = dict(
+            independent_iterations=main_iterator.insertion_order_runlength,
+            converged=main_iterator.insertion_order_converged,
+        )
+    return results
+
+
+def logz_sequence(root, pointpile, nbootstraps=12, random=True, onNode=None, verbose=False,
+                  check_insertion_order=True):
+    """Replay the whole tree under `root` through a fresh :class:`MultiCounter` and record, per
+    iteration, evidence, its bootstrap scatter, remaining volume, live count and the insertion rank
+    of the replacement (reference netiter.py:975-1095).  Returns ``(sequence, results)`` like the
+    reference (its docstring states the opposite order)."""
+    import sys
+    roots = root.children
+    explorer = BreadthFirstIterator(roots)
+    counter = MultiCounter(nroots=len(roots), nbootstraps=max(1, nbootstraps), random=random,
+                           check_insertion_order=check_insertion_order)
+    counter.Lmax = max(-np.inf, max(n.value for n in roots))
+    logz, logzerr, nlive, logvol, insert_order = [], [], [], [], []
+    saved_nodeids, saved_logl = [], []
+    while True:
+        nxt = explorer.next_node()
+        if nxt is None:
+            break
+        rootid, node, (_, active_rootids, active_values, _) = nxt
+        if onNode:
+            onNode(node, counter)
+        logz.append(counter.logZ)
+        with np.errstate(invalid='ignore'):
+            logzerr.append(counter.logZerr_bs)
+        nactive = len(active_values)
+        # rank of the first child among the live values, only defined without ties
+        if node.children and len(np.unique(active_values)) == nactive:
+            rank = (active_values > node.children[0].value).sum()
+            insert_order.append(2 * (rank + 1.) / nactive)
+        else:
+            insert_order.append(np.nan)
+        nlive.append(nactive)
+        logvol.append(counter.logVolremaining)
+        if verbose:
+            sys.stderr.write("%d...\r" % (len(saved_logl) + 1))
+        saved_logl.append(node.value)
+        saved_nodeids.append(node.id)
+        counter.passing_node(rootid, node, active_rootids, active_values)
+        explorer.expand_children_of(rootid, node)
+
+    logwt = np.asarray(saved_logl) + np.asarray(counter.logweights)[:, 0]
+    logvol[-1] = logvol[-2]
+    results = combine_results(saved_logl, saved_nodeids, pointpile, counter)
+    sequence = dict(
+        logz=np.asarray(logz),
+        logzerr=np.asarray(logzerr),
+        logvol=np.asarray(logvol),
+        samples_n=np.asarray(nlive),
+        nlive=np.asarray(nlive),
+        insert_order=np.asarray(insert_order),
+        logwt=logwt,
+        niter=len(saved_logl),
+        logl=saved_logl,
+        weights=results['weighted_samples']['weights'],
+        samples=results['weighted_samples']['points'],
+    )
+    return sequence, results
