@@ -121,3 +121,52 @@ def test_compiled_counter_under_the_stock_driver(monkeypatch):
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g8_c1_run.json")))
     assert int(res["ncall"]) == gold["ncall"] and int(res["niter"]) == gold["niter"]
     assert abs(res["logz"] - gold["logz"]) < 1e-9 and abs(res["logzerr"] - gold["logzerr"]) < 1e-9
+
+
+def test_run_summaries_and_stores_under_the_stock_driver(monkeypatch, tmp_path):
+    """Every name integrator.py takes from .netiter / .utils / .store that this package provides (SURVEY.md 8f
+    rows f3, f4) replaced at once, with `log_dir` set and the text point store: the C1 run keeps its trajectory
+    and its summary and writes the reference's result files and point log."""
+    sys.path.insert(0, SCRATCH)
+    try:
+        import ultranest
+        import ultranest.integrator as integ
+    finally:
+        sys.path.remove(SCRATCH)
+    import ultranest_amd.netiter as mynet
+    import ultranest_amd.store as mystore
+    import ultranest_amd.utils as myutils
+    for name in ("BreadthFirstIterator", "MultiCounter", "PointPile", "TreeNode", "combine_results",
+                 "count_tree_between", "find_nodes_before", "logz_sequence"):
+        assert hasattr(integ, name)
+        monkeypatch.setattr(integ, name, getattr(mynet, name))
+    for name in ("make_run_dir", "resample_equal", "vectorize", "distributed_work_chunk_size"):
+        assert hasattr(integ, name)
+        monkeypatch.setattr(integ, name, getattr(myutils, name))
+    for name in ("NullPointStore", "TextPointStore"):
+        monkeypatch.setattr(integ, name, getattr(mystore, name))
+    ndim, sigma = 5, 0.01
+    centers = np.ones(ndim) * 0.5
+
+    def loglike(theta):
+        return -0.5 * (((theta - centers) / sigma) ** 2).sum(axis=1) - 0.5 * np.log(2 * np.pi * sigma ** 2) * ndim
+
+    names = ["p%d" % i for i in range(ndim)]
+    np.random.seed(1)
+    sampler = ultranest.ReactiveNestedSampler(names, loglike, transform=lambda x: x, vectorized=True,
+                                              log_dir=str(tmp_path), resume="overwrite", storage_backend="tsv")
+    assert isinstance(sampler.pointstore, mystore.TextPointStore)
+    res = sampler.run(min_num_live_points=400, viz_callback=None, show_status=False)
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g8_c1_run.json")))
+    assert int(res["ncall"]) == gold["ncall"] and int(res["niter"]) == gold["niter"]
+    assert abs(res["logz"] - gold["logz"]) < 1e-9 and abs(res["logzerr"] - gold["logzerr"]) < 1e-9
+    for sub, fn in (("chains", "equal_weighted_post.txt"), ("chains", "weighted_post.txt"), ("chains", "run.txt"),
+                    ("info", "results.json"), ("info", "post_summary.csv"), ("results", "points.tsv")):
+        assert os.path.getsize(os.path.join(str(tmp_path), sub, fn)) > 0, fn
+    stored = json.load(open(os.path.join(str(tmp_path), "info", "results.json")))
+    assert stored["niter"] == int(res["niter"]) and stored["paramnames"] == names
+    sampler.pointstore.close()
+    # the driver switches the text store to one value per line (integrator.py:1191): records of 3 + 2 ndim values
+    with open(os.path.join(str(tmp_path), "results", "points.tsv")) as f:
+        nvalues = sum(1 for _ in f)
+    assert nvalues % (3 + 2 * ndim) == 0 and nvalues // (3 + 2 * ndim) == sampler.pointstore.nrows > int(res["niter"])
