@@ -96,3 +96,20 @@ def test_host_helpers_need_no_device():
     assert n == 3 and list(rows) == [3, 17, 49]
     rows, n = _lib.changed_rows(a, b, capacity=2)          # more changes than capacity: count is still exact
     assert n == 3 and list(rows) == [3, 17]
+
+
+def test_every_documented_option_is_accepted_without_a_device():
+    """mlf_set_option only stores a switch: every name the header documents is accepted (and restored)
+    without a GPU; an unknown name is an error."""
+    import re
+    from ultranest_amd import _lib
+    header = open(os.path.join(os.path.dirname(__file__), "..", "include", "mlfriends_hip.h")).read()
+    block = header[header.index("tuning switches"):header.index("int mlf_set_option")]
+    names = re.findall(r'"([a-z_]+)"', block)
+    assert {"filter", "filter_min_queries", "filter_phases", "filter_phase_min_queries", "filter_fused_compact",
+            "fused_prep", "prep_matrix"} <= set(names)
+    defaults = {"filter_min_queries": 2048, "filter_phase_min_queries": 32768}
+    for name in names:
+        _lib.set_option(name, defaults.get(name, 1))
+    with pytest.raises(ValueError, match="unknown option"):
+        _lib.set_option("no_such_switch", 1)

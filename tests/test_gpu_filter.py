@@ -8,17 +8,20 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["phased", "single-sweep"])
+@pytest.fixture(scope="module", params=["phased", "phased-separate-compaction", "single-sweep"])
 def K(request):
-    """Every test runs twice: with the phased sweep (undecided queries compacted between live-point
-    ranges) forced on for small batches, and with the single sweep."""
+    """Every test runs three times: with the phased sweep (undecided queries compacted between live-point
+    ranges, inside the matrix kernel's epilogue or by separate kernels) forced on for small batches, and
+    with the single sweep."""
     from ultranest_amd import _lib, kernels
     assert _lib.device_count() >= 1
     _lib.set_option("filter", 1)
     _lib.set_option("filter_min_queries", 64)      # let small test batches take the filter path
-    _lib.set_option("filter_phases", 1 if request.param == "phased" else 0)
+    _lib.set_option("filter_phases", 0 if request.param == "single-sweep" else 1)
+    _lib.set_option("filter_fused_compact", 1 if request.param == "phased" else 0)
     _lib.set_option("filter_phase_min_queries", 64)
     yield kernels
+    _lib.set_option("filter_fused_compact", 1)
     _lib.set_option("filter_min_queries", 2048)
     _lib.set_option("filter_phase_min_queries", 32768)
     _lib.set_option("filter_phases", 1)

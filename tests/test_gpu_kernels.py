@@ -286,3 +286,35 @@ def test_integration_md_ctypes_stub_runs_verbatim(K):
     wide = rng.uniform(size=(4, 129))     # above MLF_MAX_DIM: the stub surfaces mlf_last_error()
     with pytest.raises(RuntimeError, match="MLF_MAX_DIM"):
         ns["find_nearby"](wide, wide, 0.3, near[:4].copy())
+
+
+def test_library_and_torch_share_one_hip_runtime_in_either_import_order():
+    """ultranest_amd first, torch second (and the reverse) in fresh processes: both see the device and a
+    torch tensor's memory is usable through the device-pointer ABI."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.join(os.path.dirname(__file__), "..")
+    body = """
+import numpy as np
+{first}
+{second}
+from ultranest_amd import _lib, kernels
+import torch
+assert _lib.device_count() >= 1 and torch.cuda.is_available()
+a = np.random.RandomState(1).uniform(size=(200, 5)); b = np.random.RandomState(2).uniform(size=(300, 5))
+out = np.empty(300, dtype=np.int64)
+kernels.find_nearby(a, b, 0.2, out)
+t = torch.arange(6, dtype=torch.float64, device="cuda").reshape(3, 2)
+assert float((t * 2).sum().item()) == 30.0
+kernels.find_nearby(a, b, 0.2, out)
+print("ok", int((out >= 0).sum()))
+"""
+    outs = []
+    for first, second in (("from ultranest_amd import _lib, kernels; _lib.device_name()", "import torch; torch.zeros(1, device='cuda')"),
+                          ("import torch; torch.zeros(1, device='cuda')", "from ultranest_amd import _lib, kernels; _lib.device_name()")):
+        r = subprocess.run([sys.executable, "-c", body.format(first=first, second=second)], cwd=root, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and outs[0].startswith("ok ")

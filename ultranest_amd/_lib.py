@@ -106,6 +106,27 @@ class HipLibraryError(RuntimeError):
     """The HIP library is missing or a HIP call failed (never silently replaced by CPU code)."""
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 and load them by path.  If this
+    library pulled in the system copy first and torch were imported later, the process would hold two HIP
+    runtimes and the second one finds no device.  Loading torch's copy first (without importing torch) makes
+    both orders end up on one runtime: the dynamic loader satisfies this library's libamdhip64.so.N dependency
+    from the already loaded object, and torch's later load of the same file is a no-op."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass    # fall back to the system runtime; a conflict then shows up as a loud "no device" error
+
+
 def lib():
     """Load (once) and return the ctypes handle.  Loading needs no GPU; calling kernels does."""
     global _lib
@@ -114,6 +135,7 @@ def lib():
             raise HipLibraryError(
                 "%s not found: build it with `python ultranest_amd/csrc/build.py` "
                 "(ultranest_amd has no CPU fallback)" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if a symbol is missing

@@ -64,6 +64,7 @@ struct FilterCtx {
 constexpr unsigned kFilterSegCap = 2048;
 bool g_filter_enabled = true;         // mlf_set_option("filter", 0/1)
 bool g_fused_prep = true;             // mlf_set_option("fused_prep", 0/1)
+bool g_filter_fused_compact = true;   // mlf_set_option("filter_fused_compact", 0/1): compaction inside the matrix kernel's epilogue
 bool g_filter_phases = true;          // mlf_set_option("filter_phases", 0/1): phased sweep with query compaction
 long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
 bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
@@ -235,15 +236,36 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       CK(f.pthi[i].reserve((size_t)nqpad * sizeof(float)));
       CK(f.pmap[i].reserve((size_t)nqpad * sizeof(int)));
     }
-    CK(f.png.reserve(2 * sizeof(unsigned)));
+    CK(f.png.reserve(4 * sizeof(unsigned)));
     CK(f.pflags.reserve((size_t)nqpad));
     CK(f.pblk.reserve(((size_t)nqpad / 256 + 2) * sizeof(unsigned)));
   }
+  const bool fused = nphase > 1 && g_filter_fused_compact;
+  if (fused) CK(hipMemsetAsync(f.png.as<unsigned>() + 2, 0, sizeof(unsigned), s));   // slot counter of the fused compaction
   for (int ph = 0; ph < nphase; ++ph) {
     fa.tile0 = (int)((long long)f.ntiles32 * ph / nphase);
     fa.tile1 = (int)((long long)f.ntiles32 * (ph + 1) / nphase);
     fa.append = ph > 0;
-    if (ph > 0) {   // compact the undecided queries of the previous set into set (ph - 1) & 1
+    fa.cq = nullptr;
+    if (fused && ph > 0) {   // the previous launch compacted its undecided queries into set (ph - 1) & 1
+      const int src = (ph - 1) & 1;
+      fa.qF = f.pqF[src].p;
+      fa.tlo = f.ptlo[src].as<float>();
+      fa.thi = f.pthi[src].as<float>();
+      fa.qmap = f.pmap[src].as<int>();
+      fa.ngroups_dev = f.png.as<unsigned>() + src;
+    }
+    if (fused && ph + 1 < nphase) {   // ... and this one compacts into set ph & 1
+      const int dst = ph & 1;
+      fa.cq = f.pqF[dst].p;
+      fa.ctlo = f.ptlo[dst].as<float>();
+      fa.cthi = f.pthi[dst].as<float>();
+      fa.cmap = f.pmap[dst].as<int>();
+      fa.ccount = f.png.as<unsigned>() + 2;
+      fa.ccap = (unsigned)nqpad;
+      fa.route = f.route.as<uint8_t>();
+    }
+    if (!fused && ph > 0) {   // compact the undecided queries of the previous set into set (ph - 1) & 1
       const int dst = (ph - 1) & 1, src = ph & 1;
       PhaseArgs pa{};
       pa.qF_src = ph == 1 ? f.qF.p : f.pqF[src].p;
@@ -283,6 +305,11 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     if (ev_after_filter) {
       CK(hipEventRecord(f.kev[f.kev_used + 1], s));
       f.kev_used += 2;
+    }
+    if (fa.cq) {
+      const int dst = ph & 1;
+      launch_phase_finish(fa.cq, fa.ctlo, fa.cthi, fa.cmap, fa.ccount, f.png.as<unsigned>() + dst, f.ks, s);
+      CK(hipGetLastError());
     }
   }
   if (ev_after_filter) CK(hipEventRecord(ev_after_filter, s));
@@ -655,6 +682,10 @@ int mlf_set_option(const char *name, long long value) {
   }
   if (!strcmp(name, "filter_phases")) {
     g_filter_phases = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "filter_fused_compact")) {
+    g_filter_fused_compact = value != 0;
     return 0;
   }
   if (!strcmp(name, "prep_matrix")) {

@@ -213,7 +213,7 @@ __device__ __forceinline__ int min3i(int a, int b, int c) {
 // ---------------------------------------------------------------- the MFMA filter ------------
 // One wave owns QW groups of 32 queries (B fragments resident in registers) and sweeps ALL
 // live-point tiles; a workgroup is 4 independent waves.
-template <int KS, int QW, bool FIRST>
+template <int KS, int QW, bool FIRST, bool COMPACT>
 __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -348,8 +348,12 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
     for (int s = 0; s < KS; ++s) af[s] = an[s];
   }
 
+  unsigned keepm[QW];   // COMPACT: queries of each group that stay in the sweep (bit = query row)
+  int qid[QW];
 #pragma unroll
   for (int g = 0; g < QW; ++g) {
+    keepm[g] = 0u;
+    qid[g] = -1;
     if (g0 + g >= ngroups) continue;
     const long long slot_q = (g0 + g) * 32 + (lane & 31);
     const long long qi = a.qmap ? (long long)a.qmap[slot_q] : slot_q;
@@ -362,6 +366,45 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
       res = ((m >> (lane & 31)) & 1ull) ? 0 : kNone;
     }
     if (lane < 32 && qi >= 0 && qi < a.nq && res != kNone) a.best[qi] = res;
+    if (COMPACT) {
+      const bool keep = qi >= 0 && qi < a.nq && res == kNone && a.route[qi] == 1;
+      keepm[g] = (unsigned)__ballot(keep);   // low half; lanes l and l + 32 agree
+      qid[g] = (int)qi;
+    }
+  }
+  if (COMPACT) {
+    unsigned total = 0;
+#pragma unroll
+    for (int g = 0; g < QW; ++g) total += (unsigned)__popc(keepm[g]);
+    unsigned base = 0;
+    if (total != 0u) {   // wave-uniform
+      if (lane == 0) base = atomicAdd(a.ccount, total);
+      base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+      uint4 *dst = reinterpret_cast<uint4 *>(a.cq);
+      const unsigned row = (unsigned)(lane & 31);
+#pragma unroll
+      for (int g = 0; g < QW; ++g) {
+        if ((keepm[g] >> row) & 1u) {
+          const unsigned rank = base + (unsigned)__popc(keepm[g] & ((1u << row) - 1u));
+          const size_t gd = rank >> 5;
+          const unsigned rd = (rank & 31u) + (unsigned)(lane & 32);
+          if (rank < a.ccap) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+              union { half8 h; uint4 u; } cv;
+              cv.h = bq[g][s];
+              dst[(gd * KS + s) * 64 + rd] = cv.u;
+            }
+          }
+          if (lane < 32 && rank < a.ccap) {
+            a.ctlo[rank] = tlo[g];
+            a.cthi[rank] = thi[g];
+            a.cmap[rank] = qid[g];
+          }
+        }
+        base += (unsigned)__popc(keepm[g]);
+      }
+    }
   }
   if (lane == 0) {
     a.seg_count[wave] = cursor < a.seg_cap ? cursor : a.seg_cap;
@@ -433,6 +476,36 @@ __global__ __launch_bounds__(256) void k_phase_gather(PhaseArgs a) {
       a.qmap_dst[slot] = -1;
     }
   }
+}
+
+// One wave after a compacting k_filter launch: group count, padding of the last group, counter reset.
+__global__ __launch_bounds__(64) void k_phase_finish(uint4 *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount,
+                                                     unsigned *ngroups_dst, int ks) {
+  const unsigned total = *ccount;   // never above the capacity: one slot per undecided query of the source set
+  const unsigned ngroups = (total + 31u) / 32u;
+  const unsigned slot = total + threadIdx.x;
+  if (threadIdx.x < 32 && slot < 32u * ngroups) {
+    const size_t gd = slot >> 5;
+    const unsigned rd = slot & 31u;
+    for (int s = 0; s < ks; ++s) {
+      cq[(gd * ks + s) * 64 + rd] = make_uint4(0u, 0u, 0u, 0u);
+      cq[(gd * ks + s) * 64 + rd + 32] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    ctlo[slot] = -1.0f;
+    cthi[slot] = -1.0f;
+    cmap[slot] = -1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *ngroups_dst = ngroups;
+    *ccount = 0u;
+  }
+}
+
+void launch_phase_finish(void *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount, unsigned *ngroups_dst,
+                         int ks, hipStream_t s) {
+  hipLaunchKernelGGL(k_phase_finish, dim3(1), dim3(64), 0, s, reinterpret_cast<uint4 *>(cq), ctlo, cthi, cmap, ccount,
+                     ngroups_dst, ks);
 }
 
 void launch_phase_compact(const PhaseArgs &a, hipStream_t s) {
@@ -518,10 +591,16 @@ template <int KS, int QW>
 static hipError_t launch_filter_t(const FilterArgs &a, bool first, hipStream_t s) {
   const long long waves = (a.ngroups + QW - 1) / QW;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  if (first)
-    hipLaunchKernelGGL((k_filter<KS, QW, true>), dim3(grid), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((k_filter<KS, QW, false>), dim3(grid), dim3(256), 0, s, a);
+  if (a.cq) {
+    if (first)
+      hipLaunchKernelGGL((k_filter<KS, QW, true, true>), dim3(grid), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_filter<KS, QW, false, true>), dim3(grid), dim3(256), 0, s, a);
+  } else if (first) {
+    hipLaunchKernelGGL((k_filter<KS, QW, true, false>), dim3(grid), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((k_filter<KS, QW, false, false>), dim3(grid), dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
 

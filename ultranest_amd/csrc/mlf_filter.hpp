@@ -24,7 +24,19 @@ struct FilterArgs {
   const int *qmap;
   const unsigned *ngroups_dev;
   int append;                 // 1: keep the list entries of the earlier phases (cursor starts at seg_count)
+  // fused compaction (non-final phase): every wave appends its still undecided queries (route 1, no certain
+  // hit) to a fresh fragment set straight from its registers; slots come from one atomic per wave on *ccount,
+  // so the slot order varies from run to run (results do not: every slot carries its query id in cmap)
+  void *cq;                   // [ngroups][KS][64][8] f16 fragments of the compacted set, nullptr = off
+  float *ctlo, *cthi;
+  int *cmap;
+  unsigned *ccount;
+  unsigned ccap;              // slots the compacted set can hold
+  const uint8_t *route;
 };
+// after a compacting launch: group count of the compacted set, padding of its last group, counter reset
+void launch_phase_finish(void *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount, unsigned *ngroups_dst,
+                         int ks, hipStream_t s);
 
 // compaction of the queries that are still undecided after a phase
 struct PhaseArgs {
