@@ -43,7 +43,8 @@ int mlf_device_name(char *buf, size_t buflen);
 int mlf_synchronize(void);
 /* tuning switches: "filter" (1/0: MFMA pre-filter in front of the exact neighbour scan; results are
  * identical either way), "filter_min_queries" (batches below this size use the exact scan only),
- * "filter_phases" (1/0: sweep the live points in two ranges and drop the decided proposals in between),
+ * "filter_phases" (0: one sweep; 1: sweep the live points in two ranges and drop the decided proposals in
+ * between; n >= 2: n ranges),
  * "filter_phase_min_queries", "filter_fused_compact" (1/0: that compaction inside the matrix kernel or as
  * separate kernels), "fused_prep", "prep_matrix" (1/0: which preparation kernel).  Results never depend on them. */
 int mlf_set_option(const char *name, long long value);

@@ -65,7 +65,7 @@ constexpr unsigned kFilterSegCap = 2048;
 bool g_filter_enabled = true;         // mlf_set_option("filter", 0/1)
 bool g_fused_prep = true;             // mlf_set_option("fused_prep", 0/1)
 bool g_filter_fused_compact = true;   // mlf_set_option("filter_fused_compact", 0/1): compaction inside the matrix kernel's epilogue
-bool g_filter_phases = true;          // mlf_set_option("filter_phases", 0/1): phased sweep with query compaction
+int g_filter_phases = 1;              // mlf_set_option("filter_phases", n): 0 single sweep, 1 default phase count, n >= 2 exactly n phases
 long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
 bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
 long long g_filter_min_queries = 2048;  // smaller batches go straight to the exact scan
@@ -228,7 +228,8 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   int nphase = 1;
   // worth it when the sweep is long compared with one compaction (~25 us + 40 us per 10^6 queries)
   if (g_filter_phases && nq >= g_filter_phase_min_queries && (g_filter_phase_min_queries < 32768 || nq * f.ntiles32 >= 30000000ll))
-    nphase = f.ntiles32 >= 16 ? 2 : 1;
+    nphase = g_filter_phases >= 2 ? (g_filter_phases <= f.ntiles32 / 4 ? g_filter_phases : (f.ntiles32 >= 16 ? 2 : 1))
+                                  : (f.ntiles32 >= 16 ? 2 : 1);
   if (nphase > 1) {
     for (int i = 0; i < 2; ++i) {
       CK(f.pqF[i].reserve((size_t)nqpad * f.ks * 16 * 2));
@@ -681,7 +682,7 @@ int mlf_set_option(const char *name, long long value) {
     return 0;
   }
   if (!strcmp(name, "filter_phases")) {
-    g_filter_phases = value != 0;
+    g_filter_phases = value < 0 ? 0 : (value > 64 ? 64 : (int)value);
     return 0;
   }
   if (!strcmp(name, "filter_fused_compact")) {
