@@ -168,12 +168,15 @@ def main():
     from ultranest_amd import _lib, kernels
     _lib.set_device(local_rank)
     group = None
-    if world > 1:
+    # under torch.distributed.run the process group is RCCL, also for a single rank (so that the 1-GPU
+    # box exercises the same init / barrier / all-reduce calls the N > 1 runs make)
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -196,7 +199,7 @@ def main():
             handle.inside_dev_timed(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -235,7 +238,7 @@ def main():
     first_ms, rebuild_ms = time_rebuild(u, group)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()          # rank 0 reaches this after assembling the JSON line
             dist.destroy_process_group()
@@ -334,7 +337,7 @@ def main():
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
