@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=150000, help="proposals timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline path (no single-sweep / filter-off comparison passes): used for the "
+                         "rocprofv3 runs, so that the per-kernel averages of the summary are those of the timed steps")
     args = ap.parse_args()
 
     import torch
@@ -204,36 +207,42 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        timed_steps.launch_ms = handle.timing_filter_launch_ms()
         timed_steps.filter_launches = handle.timing_filter_launches()
         return dt, handle.timing_collect()
 
     # single-sweep variant of the pre-filter (no compaction between live-point ranges), for the record
-    lib_mod.set_option("filter_phases", 0)
-    _, (ncalls_single, _, ms_scan_single, _) = timed_steps(max(3, args.steps // 4))
-    ms_scan_single /= max(ncalls_single, 1)
-    lib_mod.set_option("filter_phases", 1)
+    ms_scan_single = None
+    if not args.headline_only:
+        lib_mod.set_option("filter_phases", 0)
+        _, (ncalls_single, _, ms_scan_single, _) = timed_steps(max(3, args.steps // 4))
+        ms_scan_single /= max(ncalls_single, 1)
+        lib_mod.set_option("filter_phases", 1)
     elapsed, (ncalls, ms_prep, ms_scan, ms_rest) = timed_steps(args.steps)
     filter_launches = timed_steps.filter_launches
+    launch_ms_list = timed_steps.launch_ms
     accept = float(mask.float().mean().item())
     filter_on, kdim, ntiles32 = handle.filter_info(NPROPOSALS)
     mask_filter = mask.clone()
     # reference point: the exact FP64 scan kernel alone (MFMA pre-filter switched off), same batch
     nsteps_x = max(3, args.steps // 4)
-    lib_mod.set_option("filter", 0)
-    exact_elapsed, (ncalls_x, ms_prep_x, ms_scan_x, ms_rest_x) = timed_steps(nsteps_x)
-    lib_mod.set_option("filter", 1)
-    assert bool((mask == mask_filter).all().item()), "filter and exact scan disagree"
+    exact_elapsed = ncalls_x = ms_scan_x = scan_flops = ell_pass = None
+    if not args.headline_only:
+        lib_mod.set_option("filter", 0)
+        exact_elapsed, (ncalls_x, ms_prep_x, ms_scan_x, ms_rest_x) = timed_steps(nsteps_x)
+        lib_mod.set_option("filter", 1)
+        assert bool((mask == mask_filter).all().item()), "filter and exact scan disagree"
 
-    # algorithmic work of the neighbour scan on this batch: the reference's loop stops at the first
-    # hit, so a proposal costs 3*d flops per live point visited = (first index + 1), or N if none
-    idx = torch.empty(NPROPOSALS, dtype=torch.int64, device=dev)
-    handle.first_index_dev(pts.data_ptr(), NPROPOSALS, idx.data_ptr(), stream)
-    torch.cuda.synchronize()
-    visited = torch.where(idx >= 0, idx + 1, torch.full_like(idx, N_LIVE))
-    visited = torch.where(idx == -2, torch.zeros_like(idx), visited)
-    scan_flops = 3.0 * NDIM * float(visited.sum().item())
-    ell_pass = float((idx != -2).float().mean().item())
-    assert bool(((idx >= 0) == (mask != 0)).all().item()), "index and mask pipelines disagree"
+        # algorithmic work of the neighbour scan on this batch: the reference's loop stops at the first
+        # hit, so a proposal costs 3*d flops per live point visited = (first index + 1), or N if none
+        idx = torch.empty(NPROPOSALS, dtype=torch.int64, device=dev)
+        handle.first_index_dev(pts.data_ptr(), NPROPOSALS, idx.data_ptr(), stream)
+        torch.cuda.synchronize()
+        visited = torch.where(idx >= 0, idx + 1, torch.full_like(idx, N_LIVE))
+        visited = torch.where(idx == -2, torch.zeros_like(idx), visited)
+        scan_flops = 3.0 * NDIM * float(visited.sum().item())
+        ell_pass = float((idx != -2).float().mean().item())
+        assert bool(((idx >= 0) == (mask != 0)).all().item()), "index and mask pipelines disagree"
 
     first_ms, rebuild_ms = time_rebuild(u, group)
 
@@ -247,15 +256,17 @@ def main():
     scan_ms = ms_scan / max(ncalls, 1)
     prep_ms = ms_prep / max(ncalls, 1)
     rest_ms = ms_rest / max(ncalls, 1)
-    scan_x_ms = ms_scan_x / max(ncalls_x, 1)
     value = NPROPOSALS * world * args.steps / elapsed
     alg_bytes = NPROPOSALS * (8 * NDIM + 1) + 8 * N_LIVE * NDIM + 2 * 8 * NDIM * NDIM
-    exact_tflops = scan_flops / (scan_x_ms * 1e-3) / 1e12
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_scan_traffic.json")
     if os.path.exists(pmc_file):
         traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
-    exact_roof = {
+    exact_roof = scan_x_ms = None
+    if not args.headline_only:
+      scan_x_ms = ms_scan_x / max(ncalls_x, 1)
+      exact_tflops = scan_flops / (scan_x_ms * 1e-3) / 1e12
+      exact_roof = {
         "kernel": "k_scan<50> (exact FP64 neighbour scan; the whole scan when the pre-filter is off, "
                   "the re-check arithmetic when it is on)",
         "bound": "valu_fp64", "achieved": exact_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -278,11 +289,15 @@ def main():
         nlaunch, ms_kernels = filter_launches
         per_step = max(1, round(nlaunch / max(ncalls, 1)))
         launch_ms = ms_kernels / max(nlaunch, 1)
+        by_phase = [float(np.mean(launch_ms_list[i::per_step])) for i in range(per_step)] if len(launch_ms_list) else []
         ach = (mfma_flops / per_step) / (launch_ms * 1e-3) / 1e12
         roofline = {"kernel": "k_filter (v_mfma_f32_32x32x16_f16 bound on every pair distance)",
                     "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / F16_MFMA_PEAK_TFLOPS, "ms_per_launch": launch_ms,
                     "launches_per_step": per_step,
+                    "ms_per_launch_by_phase": by_phase,
+                    "kernel_names": ["k_filter<4, 4, false, true> (first live-point range, compacts the undecided proposals)",
+                                     "k_filter<4, 4, false, false> (second range)"] if per_step == 2 else None,
                     "algorithmic_flops_per_launch": mfma_flops / per_step,
                     "algorithmic_flops_per_step": mfma_flops, "executed_k_columns": kdim,
                     "measured_mfma_ceiling_TFLOPs": 1530.0,
@@ -291,7 +306,7 @@ def main():
                             "exit); ceiling measured with scripts/probes/mfma16_probe.hip in the same access pattern",
                     "traffic": traffic, "hbm": hbm}
     else:
-        roofline = dict(exact_roof)
+        roofline = dict(exact_roof or {})
         roofline["traffic"] = traffic
         roofline["hbm"] = hbm
     prep_bytes = NPROPOSALS * (8 * NDIM + 8 * NDIM + 2 * kdim + 9)      # row in, whitened f64 + f16 fragments + flags out

@@ -308,6 +308,9 @@ int mlf_region_timing_collect(mlf_region *r, int *ncalls, double *ms_prep, doubl
 /* k_filter launches of the timed calls since the last collect: their number and summed duration
  * (events bracket each launch on `stream`; the compaction kernels between phases are excluded) */
 int mlf_region_timing_filter_launches(mlf_region *r, int *nlaunches, double *ms_total);
+/* the same launches one by one, in launch order (a timed call with p phases contributes p consecutive
+ * entries); up to cap durations are written, *nlaunches is their full number.  Does not reset. */
+int mlf_region_timing_filter_launch_ms(mlf_region *r, double *ms, int cap, int *nlaunches);
 /* whether a batch of np proposals takes the MFMA pre-filter, and its GEMM shape (K columns per pair,
  * number of 32-row live-point tiles) */
 int mlf_region_filter_info(mlf_region *r, size_t np, int *active, int *kdim, int *ntiles32);

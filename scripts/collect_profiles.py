@@ -18,7 +18,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs(P, exist_ok=True)
 
 HEADLINE_GRID = {"k_scan": 15625 * 256, "k_prep<": 3907 * 256, "k_prep2": 3907 * 256, "k_prep3": 512 * 256,
-                 "k_filter<4, 4, false>": 1954 * 256, "k_recheck": 7813 * 64}     # 1e6 proposals / launch
+                 "k_filter<4, 4, false, true>": 1954 * 256, "k_filter<4, 4, false, false>": 1954 * 256,
+                 "k_recheck": 7813 * 64}     # 1e6 proposals / launch (the bench's --headline-only pass)
 
 
 def cp(src, dst):
@@ -75,17 +76,28 @@ for key in pmc:
         w_kb = sum(w) / max(1, len(w))
         summary[key]["hbm_traffic"] = dict(FETCH_SIZE_KiB=f_kb, WRITE_SIZE_KiB=w_kb, bytes_raw=(f_kb + w_kb) * 1024.0,
                                            bytes_gfx950_corrected=(2.0 * f_kb + w_kb) * 1024.0)
-mainkey = "k_filter<4, 4, false>" if "k_filter<4, 4, false>" in pmc else "k_scan"
-if mainkey in pmc and "FETCH_SIZE" in pmc[mainkey]:
-    fetch_kb = sum(pmc[mainkey]["FETCH_SIZE"]) / len(pmc[mainkey]["FETCH_SIZE"])
-    write_kb = sum(pmc[mainkey].get("WRITE_SIZE", [0])) / max(1, len(pmc[mainkey].get("WRITE_SIZE", [0])))
+# the roofline entry of bench.py is per k_filter launch, averaged over the two launches of a step
+mainkeys = [k for k in ("k_filter<4, 4, false, true>", "k_filter<4, 4, false, false>") if k in pmc and "FETCH_SIZE" in pmc[k]]
+if not mainkeys and "k_scan" in pmc and "FETCH_SIZE" in pmc["k_scan"]:
+    mainkeys = ["k_scan"]
+if mainkeys:
     # MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
-    # reports half the bytes of a wide coalesced read -> doubled as the guide prescribes (upper estimate:
-    # the calibration is for 16 B/lane loads, k_scan issues 8 B/lane loads)
-    traffic = (2.0 * fetch_kb + write_kb) * 1024.0
-    json.dump(dict(hbm_bytes_per_launch=traffic, source="%s_pmc_summary.json" % tag,
-                   kernel=mainkey, note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, launches of 1e6 "
-                        "proposals; (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md"),
+    # reports half the bytes of a wide coalesced read -> doubled as the guide prescribes
+    per_kernel = dict((k, summary[k]["hbm_traffic"]["bytes_gfx950_corrected"]) for k in mainkeys)
+    traffic = sum(per_kernel.values()) / len(per_kernel)
+    json.dump(dict(hbm_bytes_per_launch=traffic, per_kernel=per_kernel, source="%s_pmc_summary.json" % tag,
+                   kernel=" + ".join(mainkeys),
+                   note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --headline-only, "
+                        "launches of 1e6 proposals; (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md; "
+                        "mean over the launches of a step, like roofline.achieved"),
               open(os.path.join(P, "pmc_scan_traffic.json"), "w"), indent=1)
+    # the bench line copied above was produced before these counters existed on this box: give it the traffic
+    # of the same session (bench.py reads profiles/pmc_scan_traffic.json from now on)
+    bj = os.path.join(P, "%s_bench.json" % tag)
+    if os.path.exists(bj):
+        line = json.load(open(bj))
+        if isinstance(line.get("roofline"), dict) and "k_filter" in str(line["roofline"].get("kernel", "")):
+            line["roofline"]["traffic"] = traffic
+            json.dump(line, open(bj, "w"))
 json.dump(summary, open(os.path.join(P, "%s_pmc_summary.json" % tag), "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -18,15 +18,15 @@ echo "== config bench"; timeout 600 python scripts/config_bench.py > $O/config_b
 if [ "$1" != "noprof" ]; then
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprofv3 stats"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu > $O/prof_stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu --headline-only > $O/prof_stats.log 2>&1
 tail -2 $O/prof_stats.log
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "== rocprofv3 pmc $C"
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_$C -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu > $O/pmc_$C.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_$C -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu --headline-only > $O/pmc_$C.log 2>&1
   tail -1 $O/pmc_$C.log
 done
 echo "== rocprofv3 pmc SQ"
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_SQ -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu > $O/pmc_SQ.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_SQ -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu --headline-only > $O/pmc_SQ.log 2>&1
 tail -1 $O/pmc_SQ.log
 find $O -name "*.csv" | head -30
 # keep the merge-back small: drop anything big

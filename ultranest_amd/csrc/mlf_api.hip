@@ -1500,6 +1500,21 @@ int mlf_region_timing_filter_launches(mlf_region *r, int *nlaunches, double *ms_
   return 0;
 }
 
+int mlf_region_timing_filter_launch_ms(mlf_region *r, double *ms, int cap, int *nlaunches) {
+  if (!r || !nlaunches || (cap > 0 && !ms)) return fail_arg(MLF_E_BADARG, "null pointer");
+  FilterCtx &f = r->filter;
+  int n = 0;
+  for (size_t i = 0; i + 1 < f.kev_used; i += 2, ++n) {
+    if (n >= cap) continue;
+    CK(hipEventSynchronize(f.kev[i + 1]));
+    float t = 0.f;
+    CK(hipEventElapsedTime(&t, f.kev[i], f.kev[i + 1]));
+    ms[n] = t;
+  }
+  *nlaunches = n;
+  return 0;
+}
+
 int mlf_region_filter_info(mlf_region *r, size_t np, int *active, int *kdim, int *ntiles32) {
   if (!r || !active || !kdim || !ntiles32) return fail_arg(MLF_E_BADARG, "null pointer");
   *active = (r->ready && r->use_scan && filter_applies(r->filter, (long long)np, r->r2)) ? 1 : 0;

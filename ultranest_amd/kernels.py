@@ -261,6 +261,13 @@ class DeviceRegion(object):
         check(_lib.lib().mlf_region_timing_filter_launches(self._h, ctypes.byref(n), ctypes.byref(ms)))
         return n.value, ms.value
 
+    def timing_filter_launch_ms(self, cap=4096):
+        """durations (ms) of the k_filter launches of the timed calls since the last collect, in launch order"""
+        ms = np.empty(cap)
+        n = ctypes.c_int(0)
+        check(_lib.lib().mlf_region_timing_filter_launch_ms(self._h, ptr(ms), cap, ctypes.byref(n)))
+        return ms[:min(n.value, cap)].copy()
+
     def filter_info(self, npts):
         """(filter active for this batch size, K columns of the f16 GEMM, number of 32-row live tiles)"""
         act, k, t = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
