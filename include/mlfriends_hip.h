@@ -46,7 +46,8 @@ int mlf_synchronize(void);
  * "filter_phases" (0: one sweep; 1: sweep the live points in two ranges and drop the decided proposals in
  * between; n >= 2: n ranges),
  * "filter_phase_min_queries", "filter_fused_compact" (1/0: that compaction inside the matrix kernel or as
- * separate kernels), "fused_prep", "prep_matrix" (1/0: which preparation kernel).  Results never depend on them. */
+ * separate kernels), "fused_prep", "prep_matrix" (1/0: which preparation kernel), "tq_row_major" (1/0: layout of
+ * the whitened proposals handed from the preparation kernel to the exact re-check).  Results never depend on them. */
 int mlf_set_option(const char *name, long long value);
 
 /* ---- K1: find_nearby -- ultranest/mlfriends.pyx:143-183 -----------------------------------

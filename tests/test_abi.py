@@ -107,7 +107,7 @@ def test_every_documented_option_is_accepted_without_a_device():
     block = header[header.index("tuning switches"):header.index("int mlf_set_option")]
     names = re.findall(r'"([a-z_]+)"', block)
     assert {"filter", "filter_min_queries", "filter_phases", "filter_phase_min_queries", "filter_fused_compact",
-            "fused_prep", "prep_matrix"} <= set(names)
+            "fused_prep", "prep_matrix", "tq_row_major"} <= set(names)
     defaults = {"filter_min_queries": 2048, "filter_phase_min_queries": 32768}
     for name in names:
         _lib.set_option(name, defaults.get(name, 1))

@@ -64,6 +64,7 @@ struct FilterCtx {
 constexpr unsigned kFilterSegCap = 2048;
 bool g_filter_enabled = true;         // mlf_set_option("filter", 0/1)
 bool g_fused_prep = true;             // mlf_set_option("fused_prep", 0/1)
+bool g_tq_row_major = true;           // mlf_set_option("tq_row_major", 0/1): layout of the whitened proposals next to the filter
 bool g_filter_fused_compact = true;   // mlf_set_option("filter_fused_compact", 0/1): compaction inside the matrix kernel's epilogue
 int g_filter_phases = 1;              // mlf_set_option("filter_phases", n): 0 single sweep, 1 default phase count, n >= 2 exactly n phases
 long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
@@ -496,6 +497,10 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
       pa.t_ldk = (long long)np;
       ldq = 1;
       ldk = (long long)np;
+      if (use_filter && g_tq_row_major) {   // the exact re-check gathers single proposals: rows of d contiguous doubles
+        pa.t_ldq = ldq = (long long)r->d;
+        pa.t_ldk = ldk = 1;
+      }
       if (use_filter) {
         unsigned cap = 0;
         FilterCtx &f = r->filter;
@@ -683,6 +688,10 @@ int mlf_set_option(const char *name, long long value) {
   }
   if (!strcmp(name, "filter_phases")) {
     g_filter_phases = value < 0 ? 0 : (value > 64 ? 64 : (int)value);
+    return 0;
+  }
+  if (!strcmp(name, "tq_row_major")) {
+    g_tq_row_major = value != 0;
     return 0;
   }
   if (!strcmp(name, "filter_fused_compact")) {
