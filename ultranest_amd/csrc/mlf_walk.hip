@@ -50,14 +50,9 @@ __device__ __forceinline__ bool update_walker(bool hit, double &t, double &left,
   return success;
 }
 
-// step_back for one walker (stepfuncs.pyx:285-334).  `width` = max generation + 1 over the
-// population.  Exact for generation >= 0; a walker that unwinds below generation 0 with
-// below-threshold entries left (a state the sampler never produces) stops at -1.
-__device__ __forceinline__ void step_back_walker(double Lmin, double *L, int G, long long width, long long &gen,
+// second half of step_back: drop chain slots from the end until no below-threshold entry is left
+__device__ __forceinline__ void step_back_unwind(double Lmin, double *L, long long width, int nbelow, long long &gen,
                                                  double &t) {
-  if (width > G) width = G;
-  int nbelow = 0;
-  for (long long k = 0; k < width; ++k) nbelow += (L[k] < Lmin) ? 1 : 0;
   while (nbelow > 0) {
     const long long g = gen;
     if (g < 0 || g >= width) break;
@@ -66,6 +61,17 @@ __device__ __forceinline__ void step_back_walker(double Lmin, double *L, int G, 
     if (L[g] < Lmin) --nbelow;
     L[g] = qnan();
   }
+}
+
+// step_back for one walker (stepfuncs.pyx:285-334).  `width` = max generation + 1 over the
+// population.  Exact for generation >= 0; a walker that unwinds below generation 0 with
+// below-threshold entries left (a state the sampler never produces) stops at -1.
+__device__ __forceinline__ void step_back_walker(double Lmin, double *L, int G, long long width, long long &gen,
+                                                 double &t) {
+  if (width > G) width = G;
+  int nbelow = 0;
+  for (long long k = 0; k < width; ++k) nbelow += (L[k] < Lmin) ? 1 : 0;
+  step_back_unwind(Lmin, L, width, nbelow, gen, t);
 }
 
 // whitened coordinates of one point (T1: fmod wrap, centre, k-ascending FMA chain like BLAS)
@@ -423,30 +429,61 @@ __global__ __launch_bounds__(64) void k_walk_diag(WalkState w, WalkLayer ly) {
   const double *uo = w.allu + ((size_t)i * w.G + (g - 1)) * w.d;
   const double *un = w.unew + (size_t)i * w.d;
   double acc = 0.0;
-  for (int c = lane; c < w.d; c += 64) {
-    double ta, tb;
-    whiten_point(ly, uo, w.d, c, ta);
-    whiten_point(ly, un, w.d, c, tb);
-    const double diff = ta - tb;
-    acc += diff * diff;
+  if (ly.kind == 0 && w.d <= 64) {
+    // both points share every matrix element: lane k keeps the centred coordinate k of the two points, the
+    // chains read them by lane broadcast (same values and order as whiten_point: results are identical)
+    double vo = 0.0, vn = 0.0;
+    if (lane < w.d) {
+      vo = uo[lane];
+      vn = un[lane];
+      if (ly.wrap && !isnan(ly.wrap[lane])) {
+        vo = fmod(vo + ly.wrap[lane], 1.0);
+        vn = fmod(vn + ly.wrap[lane], 1.0);
+      }
+      vo -= ly.ctr[lane];
+      vn -= ly.ctr[lane];
+    }
+    double ta = 0.0, tb = 0.0;
+    const int c = lane < w.d ? lane : 0;
+    for (int k = 0; k < w.d; ++k) {
+      const double m = ly.mat[(size_t)k * w.d + c];
+      ta = __builtin_fma(__shfl(vo, k, 64), m, ta);
+      tb = __builtin_fma(__shfl(vn, k, 64), m, tb);
+    }
+    if (lane < w.d) {
+      const double diff = ta - tb;
+      acc = diff * diff;
+    }
+  } else {
+    for (int c = lane; c < w.d; c += 64) {
+      double ta, tb;
+      whiten_point(ly, uo, w.d, c, ta);
+      whiten_point(ly, un, w.d, c, tb);
+      const double diff = ta - tb;
+      acc += diff * diff;
+    }
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (lane == 0) w.dist2[i] = acc;
   }
 }
 
-// step statistics, stage 1: every workgroup reduces 4096 walkers to one row of partial sums
+// step statistics, stage 1: every workgroup reduces 1024 walkers to one row of partial sums
 // (likelihood evaluations, walkers moved on, successes, far-enough moves, sum of log relative distances)
-constexpr int kStatsChunk = 4096;
-__global__ __launch_bounds__(256) void k_walk_stats(WalkState w, double r2, const StepParams *sp, double *partials) {
-  __shared__ double part[256][5];
+constexpr int kStatsChunk = 1024;
+constexpr int kStatsCols = 6;   // + number of walkers (re)started in this call (setup_start's ring shift needs it)
+__global__ __launch_bounds__(256) void k_walk_stats(WalkState w, double r2, const StepParams *sp, double *partials,
+                                                    const uint8_t *was_starting) {
+  __shared__ double part[256][kStatsCols];
   if (sp) r2 = sp->r2;
   const double ref = sqrt(r2);
-  double nc = 0, nmov = 0, nsucc = 0, nfar = 0, slog = 0;
+  double nc = 0, nmov = 0, nsucc = 0, nfar = 0, slog = 0, nstart = 0;
   const int i0 = blockIdx.x * kStatsChunk;
   for (int j = threadIdx.x; j < kStatsChunk; j += 256) {
     const int i = i0 + j;
-    if (i >= w.P || !w.movable[i]) continue;
+    if (i >= w.P) continue;
+    if (was_starting && was_starting[i]) nstart += 1;
+    if (!w.movable[i]) continue;
     nmov += 1;
     nc += w.acceptable[i] ? 1 : 0;
     if (w.success[i]) {
@@ -463,62 +500,56 @@ __global__ __launch_bounds__(256) void k_walk_stats(WalkState w, double r2, cons
   part[threadIdx.x][2] = nsucc;
   part[threadIdx.x][3] = nfar;
   part[threadIdx.x][4] = slog;
+  part[threadIdx.x][5] = nstart;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off)
-      for (int c = 0; c < 5; ++c) part[threadIdx.x][c] += part[threadIdx.x + off][c];
+      for (int c = 0; c < kStatsCols; ++c) part[threadIdx.x][c] += part[threadIdx.x + off][c];
     __syncthreads();
   }
-  if (threadIdx.x < 5) partials[blockIdx.x * 5 + threadIdx.x] = part[0][threadIdx.x];
+  if (threadIdx.x < kStatsCols) partials[blockIdx.x * kStatsCols + threadIdx.x] = part[0][threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_walk_harvest(WalkState w, long long ring_host, long long *ring_dev, double r2,
                                                       double *rec, const StepParams *sp, const uint8_t *was_starting,
                                                       const double *partials) {
-  __shared__ double part[256][5];
+  __shared__ double part[256][kStatsCols];
   __shared__ long long s_ring;
   if (sp) r2 = sp->r2;
-  if (was_starting) {   // setup_start's ring shift (:456-462), deferred from the prologue kernel
-    __shared__ int nstart[256];
-    int n = 0;
-    for (int i = threadIdx.x; i < w.P; i += 256) n += was_starting[i] ? 1 : 0;
-    nstart[threadIdx.x] = n;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if ((int)threadIdx.x < off) nstart[threadIdx.x] += nstart[threadIdx.x + off];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      long long r = *ring_dev;
-      if (nstart[0] > 0 && nstart[0] < w.P)
-        for (int guard = 0; guard < w.P && was_starting[r]; ++guard) r = (r + 1) % w.P;
-      *ring_dev = r;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) s_ring = ring_dev ? *ring_dev : ring_host;
-  __syncthreads();
-  const long long ring = s_ring;
-  double nc = 0, nmov = 0, nsucc = 0, nfar = 0, slog = 0;
+  double nc = 0, nmov = 0, nsucc = 0, nfar = 0, slog = 0, nstart = 0;
   const int nrows = (w.P + kStatsChunk - 1) / kStatsChunk;   // stage 2 of the statistics: rows of k_walk_stats
   for (int b = threadIdx.x; b < nrows; b += 256) {
-    nc += partials[b * 5 + 0];
-    nmov += partials[b * 5 + 1];
-    nsucc += partials[b * 5 + 2];
-    nfar += partials[b * 5 + 3];
-    slog += partials[b * 5 + 4];
+    nc += partials[b * kStatsCols + 0];
+    nmov += partials[b * kStatsCols + 1];
+    nsucc += partials[b * kStatsCols + 2];
+    nfar += partials[b * kStatsCols + 3];
+    slog += partials[b * kStatsCols + 4];
+    nstart += partials[b * kStatsCols + 5];
   }
   part[threadIdx.x][0] = nc;
   part[threadIdx.x][1] = nmov;
   part[threadIdx.x][2] = nsucc;
   part[threadIdx.x][3] = nfar;
   part[threadIdx.x][4] = slog;
+  part[threadIdx.x][5] = nstart;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off)
-      for (int c = 0; c < 5; ++c) part[threadIdx.x][c] += part[threadIdx.x + off][c];
+      for (int c = 0; c < kStatsCols; ++c) part[threadIdx.x][c] += part[threadIdx.x + off][c];
     __syncthreads();
   }
+  if (threadIdx.x == 0) {
+    long long r = ring_dev ? *ring_dev : ring_host;
+    if (was_starting && ring_dev) {   // setup_start's ring shift (:456-462), deferred from the prologue kernel
+      const double ns = part[0][5];
+      if (ns > 0 && ns < (double)w.P)
+        for (int guard = 0; guard < w.P && was_starting[r]; ++guard) r = (r + 1) % w.P;
+      *ring_dev = r;
+    }
+    s_ring = r;
+  }
+  __syncthreads();
+  const long long ring = s_ring;
   const bool found = w.generation[ring] == (long long)(w.G - 1);
   const size_t row = ((size_t)ring * w.G + (w.G - 1)) * w.d;
   if (threadIdx.x == 0) {
@@ -620,8 +651,20 @@ __global__ __launch_bounds__(64) void k_walk_prologue(WalkState w, const double 
   for (int i = blockIdx.x; i < w.P; i += gridDim.x) {
   long long gen = w.generation[i];
   double t = w.currentt[i];
-  if (lane == 0) {   // the chain unwinding is scalar work on this walker's likelihood history
-    step_back_walker(p.Lmin, w.allL + (size_t)i * w.G, w.G, w.G, gen, t);
+  // all per-walker scalars are requested up front: one memory round trip instead of one per stage
+  double left = w.left[i], right = w.right[i];
+  bool sl = w.sl[i] != 0, sr = w.sr[i] != 0;
+  // step_back: the likelihood history is read by the whole wave at once (one thread walking the G slots paid
+  // G dependent load latencies per walker: 0.15 ms of this kernel at 10^5 walkers); the rare unwinding stays scalar
+  double *Lrow = w.allL + (size_t)i * w.G;
+  int nbelow = 0;
+  for (int k0 = 0; k0 < w.G; k0 += 64) {
+    const int k = k0 + lane;
+    const bool below_thr = k < w.G && Lrow[k] < p.Lmin;
+    nbelow += (int)__popcll(__ballot(below_thr));
+  }
+  if (lane == 0) {
+    if (nbelow > 0) step_back_unwind(p.Lmin, Lrow, w.G, nbelow, gen, t);
     w.generation[i] = gen;
     w.currentt[i] = t;
     was_starting[i] = gen < 0 ? 1 : 0;
@@ -629,8 +672,6 @@ __global__ __launch_bounds__(64) void k_walk_prologue(WalkState w, const double 
   gen = __shfl(gen, 0, 64);
   t = __shfl(t, 0, 64);
   dw_restart_philox(w, i, lane, live, Ls, nlive, p.Lmin, p.seed, p.offset, gen);
-  double left = w.left[i], right = w.right[i];
-  bool sl = w.sl[i] != 0, sr = w.sr[i] != 0;
   dw_brackets_philox(w, i, lane, p.scale, dirkind, p.dirscale, dd, p.seed, p.offset, t, left, right, sl, sr);
   // the rows written above (restart point, direction) are read back by other lanes of this wave
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -879,7 +920,7 @@ void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStr
 void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, double *partials,
                          hipStream_t s, const StepParams *sp, const uint8_t *was_starting) {
   const int nrows = (w.P + kStatsChunk - 1) / kStatsChunk;
-  hipLaunchKernelGGL(k_walk_stats, dim3(nrows), dim3(256), 0, s, w, r2, sp, partials);
+  hipLaunchKernelGGL(k_walk_stats, dim3(nrows), dim3(256), 0, s, w, r2, sp, partials, was_starting);
   hipLaunchKernelGGL(k_walk_harvest, dim3(1), dim3(256), 0, s, w, ring, ring_dev, r2, rec, sp, was_starting, partials);
 }
 

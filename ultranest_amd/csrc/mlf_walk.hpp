@@ -91,7 +91,7 @@ void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStr
 //      [8] sum log(dist/ref + 1e-10), [9 ..] u (d) then p (nparams)
 // ring_dev != nullptr: the ring index lives on the device (read, advanced when a walker was harvested, and
 // reported in rec[9 + d + nparams])
-// partials: scratch of 5 * ceil(P / 4096) doubles (two-stage reduction of the step statistics)
+// partials: scratch of 6 * ceil(P / 1024) doubles (two-stage reduction of the step statistics)
 void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, double *partials,
                          hipStream_t s, const StepParams *sp = nullptr, const uint8_t *was_starting = nullptr);
 // front half of a whole step in one kernel: step_back, restart, new slice, proposal, prior transform

@@ -155,7 +155,7 @@ int mlf_walkers_create(mlf_walkers **out, size_t popsize, size_t nsteps, size_t 
               {&w->sr, P},               {&w->unew, P * d * 8}, {&w->movable, P},        {&w->acceptable, P},
               {&w->success, P},          {&w->Lnew, P * 8},     {&w->dist2, P * 8},      {&w->gmax, 8},
               {&w->flags, P},            {&w->unif, P * 8},     {&w->blk, ((P + 255) / 256 + 1) * 4},
-              {&w->compact, P * d * 8}, {&w->partials, ((P + 4095) / 4096) * 5 * 8}};
+              {&w->compact, P * d * 8}, {&w->partials, ((P + 1023) / 1024) * 6 * 8}};
   for (auto &e : plan) {
     hipError_t err = e.b->reserve(e.bytes);
     if (err != hipSuccess) {
