@@ -903,8 +903,9 @@ int mlf_bootstrap_moments(const double *u, size_t n, size_t d, const uint8_t *se
   CK(c.small0.reserve(B * d * sizeof(double)));
   CK(c.small1.reserve(B * sizeof(int)));
   CK(c.out.reserve(B * d * d * sizeof(double)));
+  CK(c.small2.reserve(B * n * sizeof(int)));
   launch_boot_moments(c.src.as<double>(), (int)n, (int)d, c.selbytes.as<uint8_t>(), (int)B,
-                      c.small0.as<double>(), c.small1.as<int>(), c.out.as<double>(), c.stream);
+                      c.small0.as<double>(), c.small1.as<int>(), c.out.as<double>(), c.small2.as<int>(), c.stream);
   CK(hipGetLastError());
   CK(hipMemcpyAsync(mean_out, c.small0.p, B * d * sizeof(double), hipMemcpyDeviceToHost, c.stream));
   CK(hipMemcpyAsync(cov_out, c.out.p, B * d * d * sizeof(double), hipMemcpyDeviceToHost, c.stream));

@@ -117,60 +117,74 @@ void launch_boot_final(const unsigned long long *M, const unsigned *sel, int n, 
 }
 
 // ------------------------------------------------------- K3 pass 2 -----------------------
-// One wave per point j, lane = coordinate.  Neighbours are visited in ascending i from the hit
-// ballots, so the sum has the reference's order (:100-109); then pts[j] - sum / (double)nn.
-__global__ __launch_bounds__(kWave) void k_subtract_accum(const double *pts, int n, int d,
-                                                           const unsigned long long *flags,
-                                                           int ntiles, double *out) {
-  const int j = blockIdx.x;
-  const int lane = threadIdx.x;
-  for (int k = lane; k < d; k += kWave) {
-    double sum = 0.0;
-    long long nn = 0;
-    for (int t = 0; t < ntiles; ++t) {
-      unsigned long long m = flags[(long long)j * ntiles + t];
-      if (m == ~0ull) {   // whole tile: 64 consecutive rows, no bit scanning; 32 loads in flight per batch
-        const double *col = pts + (long long)t * kWave * d + k;
+// One wave per point j, lane = coordinate (two per lane up to d = 128).  Neighbours are visited in ascending i
+// from the hit ballots, so the sum has the reference's order (:100-109); then pts[j] - sum / (double)nn.
+// A workgroup holds 16 points and stages every 64-row tile of pts in LDS once for all of them: with the
+// LocalAffineLayer radius quirk every point is a neighbour of every point, and one wave per workgroup re-read
+// the whole array from L2 for each point (6.4 GB at N = 4000: 0.48 ms).
+constexpr int kAccumWaves = 16;
+__global__ __launch_bounds__(64 * kAccumWaves) void k_subtract_accum(const double *pts, int n, int d,
+                                                                    const unsigned long long *flags, int ntiles,
+                                                                    double *out) {
+  extern __shared__ double tile[];   // [64][d]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * kAccumWaves + wave;
+  const bool live = j < n;
+  const bool has0 = lane < d, has1 = lane + 64 < d;
+  double sum0 = 0.0, sum1 = 0.0;
+  long long nn = 0;
+  // the next tile travels in registers while this one is consumed (64 x 128 doubles over 1024 threads: 8 each)
+  constexpr int kPer = (kWave * 128 + 64 * kAccumWaves - 1) / (64 * kAccumWaves);   // d <= 128 (MLF_MAX_DIM)
+  double nxt[kPer];
+  auto fetch = [&](int t) {
+    const int rows = (n - t * kWave) < kWave ? (n - t * kWave) : kWave;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          double v[32];
-#pragma unroll
-          for (int q = 0; q < 32; ++q) v[q] = col[(long long)(32 * h + q) * d];
-#pragma unroll
-          for (int q = 0; q < 32; ++q) sum += v[q];
-        }
-        nn += 64;
-        continue;
-      }
-      // the additions must stay in ascending-i order, the LOADS need not wait for them: fetch up
-      // to eight neighbours at once (with the LocalAffineLayer radius quirk every point is a
-      // neighbour of every point, so this loop runs N times per output value)
-      while (m) {
-        double v[8];
-        int cnt = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          v[q] = 0.0;
-          if (m) {
-            const int i = t * kWave + __ffsll((long long)m) - 1;
-            m &= m - 1;
-            v[q] = pts[(long long)i * d + k];
-            cnt = q + 1;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (q < cnt) sum += v[q];
-        nn += cnt;
-      }
+    for (int q = 0; q < kPer; ++q) {
+      const int e = threadIdx.x + q * 64 * kAccumWaves;
+      nxt[q] = e < rows * d ? pts[(long long)t * kWave * d + e] : 0.0;
     }
-    out[(long long)j * d + k] = pts[(long long)j * d + k] - sum / (double)nn;
+  };
+  fetch(0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int rows = (n - t * kWave) < kWave ? (n - t * kWave) : kWave;
+    __syncthreads();   // the previous tile is consumed
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int e = threadIdx.x + q * 64 * kAccumWaves;
+      if (e < rows * d) tile[e] = nxt[q];
+    }
+    if (t + 1 < ntiles) fetch(t + 1);
+    __syncthreads();
+    if (!live) continue;
+    unsigned long long m = flags[(long long)j * ntiles + t];
+    if (m == ~0ull) {   // whole tile: no bit scanning
+#pragma unroll 16
+      for (int q = 0; q < kWave; ++q) {
+        if (has0) sum0 += tile[q * d + lane];
+        if (has1) sum1 += tile[q * d + lane + 64];
+      }
+      nn += kWave;
+      continue;
+    }
+    while (m) {
+      const int q = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      if (has0) sum0 += tile[q * d + lane];
+      if (has1) sum1 += tile[q * d + lane + 64];
+      ++nn;
+    }
+  }
+  if (live) {
+    if (has0) out[(long long)j * d + lane] = pts[(long long)j * d + lane] - sum0 / (double)nn;
+    if (has1) out[(long long)j * d + lane + 64] = pts[(long long)j * d + lane + 64] - sum1 / (double)nn;
   }
 }
 
 void launch_subtract_accum(const double *pts, int n, int d, const unsigned long long *flags,
                            int ntiles, double *out, hipStream_t s) {
-  hipLaunchKernelGGL(k_subtract_accum, dim3(n), dim3(kWave), 0, s, pts, n, d, flags, ntiles, out);
+  const unsigned grid = (unsigned)((n + kAccumWaves - 1) / kAccumWaves);
+  hipLaunchKernelGGL(k_subtract_accum, dim3(grid), dim3(64 * kAccumWaves), (size_t)kWave * d * sizeof(double), s, pts, n, d,
+                     flags, ntiles, out);
 }
 
 // ------------------------------------------------------- K5 ------------------------------
@@ -244,69 +258,148 @@ void launch_masked_max(const double *q, const uint8_t *selected, int n, double *
 }
 
 // ------------------------------------------------------- bootstrap moments ---------------
-// mean[b][k] over selected rows (block = bootstrap b; 4 row groups x 64 coordinate lanes)
-__global__ __launch_bounds__(256) void k_boot_mean(const double *u, int n, int d,
-                                                   const uint8_t *selected, double *mean,
-                                                   int *count) {
-  __shared__ double part[4][128];
-  __shared__ int cpart[4];
+// The selection masks are first turned into ascending index lists (one workgroup per bootstrap round):
+// looping over the mask itself made every row a load -> branch -> load chain (0.34 ms per kernel at
+// N = 4000, B = 30, for 6 Mflop of work); over a list the row loads are independent and unrolled.
+__global__ __launch_bounds__(256) void k_boot_index(const uint8_t *selected, int n, int *idx, int *count) {
+  __shared__ int wsum[4];
+  __shared__ int base;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint8_t *sel = selected + (long long)b * n;
+  int *out = idx + (long long)b * n;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    const bool on = i < n && sel[i] != 0;
+    const unsigned long long m = __ballot(on);
+    if (lane == 0) wsum[wave] = (int)__popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (on) out[off + (int)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) count[b] = base;
+}
+
+// mean[b][k] over the selected rows: workgroup = bootstrap b, 16 waves take the list entries j = g (mod 16)
+// in ascending order, lane = coordinate (two per lane up to d = 128); the 16 partial sums are added in a
+// fixed order
+__global__ __launch_bounds__(1024) void k_boot_mean(const double *u, int d, const int *idx, int n, const int *count,
+                                                    double *mean) {
+  __shared__ double part[16][128];
   const int b = blockIdx.x;
   const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint8_t *sel = selected + (long long)b * n;
+  const int *list = idx + (long long)b * n;
+  const int cnt = count[b];
+  const bool has0 = lane < d, has1 = lane + 64 < d;
   double s0 = 0.0, s1 = 0.0;
-  int c = 0;
-  for (int i = g; i < n; i += 4) {
-    if (!sel[i]) continue;
-    ++c;
-    if (lane < d) s0 += u[(long long)i * d + lane];
-    if (lane + 64 < d) s1 += u[(long long)i * d + lane + 64];
+  int j = g;
+  for (; j + 48 < cnt; j += 64) {   // four rows in flight
+    const long long r0 = list[j], r1 = list[j + 16], r2 = list[j + 32], r3 = list[j + 48];
+    if (has0) {
+      const double a0 = u[r0 * d + lane], a1 = u[r1 * d + lane], a2 = u[r2 * d + lane], a3 = u[r3 * d + lane];
+      s0 += a0;
+      s0 += a1;
+      s0 += a2;
+      s0 += a3;
+    }
+    if (has1) {
+      const double a0 = u[r0 * d + lane + 64], a1 = u[r1 * d + lane + 64], a2 = u[r2 * d + lane + 64],
+                   a3 = u[r3 * d + lane + 64];
+      s1 += a0;
+      s1 += a1;
+      s1 += a2;
+      s1 += a3;
+    }
+  }
+  for (; j < cnt; j += 16) {
+    const long long r = list[j];
+    if (has0) s0 += u[r * d + lane];
+    if (has1) s1 += u[r * d + lane + 64];
   }
   part[g][lane] = s0;
   part[g][lane + 64] = s1;
-  if (lane == 0) cpart[g] = c;
   __syncthreads();
   if (threadIdx.x < 128 && threadIdx.x < d) {
     const int k = threadIdx.x;
-    const int cnt = cpart[0] + cpart[1] + cpart[2] + cpart[3];
-    mean[(long long)b * d + k] = (part[0][k] + part[1][k] + part[2][k] + part[3][k]) / (double)cnt;
-    if (k == 0) count[b] = cnt;
+    double tot = 0.0;
+    for (int w = 0; w < 16; ++w) tot += part[w][k];
+    mean[(long long)b * d + k] = tot / (double)cnt;
   }
 }
 
 // cov[b][k][l] = sum_sel (u_ik - m_k)(u_il - m_l) / (cnt - 1); workgroup = (bootstrap b, row k),
-// thread = (row group g of 4, column l): coalesced reads of u[i][:], 4-way split of the rows
-__global__ __launch_bounds__(256) void k_boot_cov(const double *u, int n, int d,
-                                                  const uint8_t *selected, const double *mean,
-                                                  const int *count, double *cov) {
-  __shared__ double part[4][128];
+// thread = (list entries j = g (mod 16), column l): coalesced reads of u[i][:], four rows in flight, the 16
+// partial sums added in a fixed order
+__global__ __launch_bounds__(1024) void k_boot_cov(const double *u, int d, const int *idx, int n, const double *mean,
+                                                   const int *count, double *cov) {
+  __shared__ double part[16][128];
   const int b = blockIdx.y, k = blockIdx.x;
   const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint8_t *sel = selected + (long long)b * n;
+  const int *list = idx + (long long)b * n;
+  const int cnt = count[b];
   const double mk = mean[(long long)b * d + k];
-  const double ml0 = lane < d ? mean[(long long)b * d + lane] : 0.0;
-  const double ml1 = lane + 64 < d ? mean[(long long)b * d + lane + 64] : 0.0;
+  const bool has0 = lane < d, has1 = lane + 64 < d;
+  const double ml0 = has0 ? mean[(long long)b * d + lane] : 0.0;
+  const double ml1 = has1 ? mean[(long long)b * d + lane + 64] : 0.0;
   double a0 = 0.0, a1 = 0.0;
-  for (int i = g; i < n; i += 4) {
-    if (!sel[i]) continue;
-    const double dk = u[(long long)i * d + k] - mk;
-    if (lane < d) a0 = __builtin_fma(dk, u[(long long)i * d + lane] - ml0, a0);
-    if (lane + 64 < d) a1 = __builtin_fma(dk, u[(long long)i * d + lane + 64] - ml1, a1);
+  // this wave's list entries j = g + 16 t: lane t fetches entry t of each block of 64, the rows are then named by
+  // lane broadcasts (a load of the index in front of every row load doubled the dependent round trips)
+  for (int t0 = 0; g + 16 * t0 < cnt; t0 += 64) {
+    const int jt = g + 16 * (t0 + lane);
+    const int mine = jt < cnt ? list[jt] : -1;
+    int left = (cnt - g - 16 * t0 + 15) / 16;
+    if (left > 64) left = 64;
+    int t = 0;
+    for (; t + 3 < left; t += 4) {   // four rows in flight
+      const long long r0 = __shfl(mine, t, 64), r1 = __shfl(mine, t + 1, 64), r2 = __shfl(mine, t + 2, 64),
+                      r3 = __shfl(mine, t + 3, 64);
+      const double k0 = u[r0 * d + k] - mk, k1 = u[r1 * d + k] - mk, k2 = u[r2 * d + k] - mk, k3 = u[r3 * d + k] - mk;
+      if (has0) {
+        const double x0 = u[r0 * d + lane], x1 = u[r1 * d + lane], x2 = u[r2 * d + lane], x3 = u[r3 * d + lane];
+        a0 = __builtin_fma(k0, x0 - ml0, a0);
+        a0 = __builtin_fma(k1, x1 - ml0, a0);
+        a0 = __builtin_fma(k2, x2 - ml0, a0);
+        a0 = __builtin_fma(k3, x3 - ml0, a0);
+      }
+      if (has1) {
+        const double x0 = u[r0 * d + lane + 64], x1 = u[r1 * d + lane + 64], x2 = u[r2 * d + lane + 64],
+                     x3 = u[r3 * d + lane + 64];
+        a1 = __builtin_fma(k0, x0 - ml1, a1);
+        a1 = __builtin_fma(k1, x1 - ml1, a1);
+        a1 = __builtin_fma(k2, x2 - ml1, a1);
+        a1 = __builtin_fma(k3, x3 - ml1, a1);
+      }
+    }
+    for (; t < left; ++t) {
+      const long long r = __shfl(mine, t, 64);
+      const double dk = u[r * d + k] - mk;
+      if (has0) a0 = __builtin_fma(dk, u[r * d + lane] - ml0, a0);
+      if (has1) a1 = __builtin_fma(dk, u[r * d + lane + 64] - ml1, a1);
+    }
   }
   part[g][lane] = a0;
   part[g][lane + 64] = a1;
   __syncthreads();
   if (threadIdx.x < 128 && threadIdx.x < d) {
     const int l = threadIdx.x;
-    cov[((long long)b * d + k) * d + l] =
-        ((part[0][l] + part[1][l]) + (part[2][l] + part[3][l])) / (double)(count[b] - 1);
+    double tot = 0.0;
+    for (int w = 0; w < 16; ++w) tot += part[w][l];
+    cov[((long long)b * d + k) * d + l] = tot / (double)(cnt - 1);
   }
 }
 
+// idx: scratch of B * n ints
 void launch_boot_moments(const double *u, int n, int d, const uint8_t *selected, int B, double *mean,
-                         int *count, double *cov, hipStream_t s) {
-  hipLaunchKernelGGL(k_boot_mean, dim3(B), dim3(256), 0, s, u, n, d, selected, mean, count);
-  hipLaunchKernelGGL(k_boot_cov, dim3((unsigned)d, (unsigned)B), dim3(256), 0, s, u, n, d, selected, mean,
-                     count, cov);
+                         int *count, double *cov, int *idx, hipStream_t s) {
+  hipLaunchKernelGGL(k_boot_index, dim3(B), dim3(256), 0, s, selected, n, idx, count);
+  hipLaunchKernelGGL(k_boot_mean, dim3(B), dim3(1024), 0, s, u, d, idx, n, count, mean);
+  hipLaunchKernelGGL(k_boot_cov, dim3((unsigned)d, (unsigned)B), dim3(1024), 0, s, u, d, idx, n, mean, count, cov);
 }
 
 // ------------------------------------------------------- likelihoods (V1, L1-L3) ---------

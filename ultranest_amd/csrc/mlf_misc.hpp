@@ -21,7 +21,7 @@ void launch_scaling_transform(const double *pts, long long np, int d, const doub
                               double *out, long long ldt, hipStream_t s);
 void launch_masked_max(const double *q, const uint8_t *selected, int n, double *out, hipStream_t s);
 void launch_boot_moments(const double *u, int n, int d, const uint8_t *selected, int B, double *mean,
-                         int *count, double *cov, hipStream_t s);
+                         int *count, double *cov, int *idx_scratch, hipStream_t s);
 void launch_loglike(int kind, const double *params, int d, long long n, const double *aux,
                     double sigma, double *like, hipStream_t s);
 
