@@ -49,47 +49,78 @@ typedef __attribute__((ext_vector_type(16))) float float16v;
 // One workgroup of 16 waves; a wave takes the rows i = wave (mod 16) with lane = coordinate (two per lane up to
 // d = 128), so every row is one coalesced read.  (A thread-per-column / thread-per-row version of the same three
 // passes walked the rows with a DP-element stride and took 0.23 ms at N = 4000.)
+template <int H>   // H = number of 64-column halves (d <= 64 H); lanes past d work on column 0 and are masked at the end
 __global__ __launch_bounds__(1024) void k_ref_stats(const double *__restrict__ refR, int n, int d, int dp,
                                                     double *__restrict__ stats) {
-  __shared__ double part[16][MLF_FILTER_MAXD];
-  __shared__ double cc[MLF_FILTER_MAXD];
+  __shared__ double part[16][64 * H];
+  __shared__ double cc[64 * H];
   __shared__ double red[16];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const bool has0 = lane < d, has1 = lane + 64 < d;
-  // pass 1: centre of the live points
-  double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-  for (int i = wave; i < n; i += 16) {   // unrolled: eight rows in flight (one load at a time is pure latency)
-    if (has0) s0 += refR[(size_t)i * dp + lane];
-    if (has1) s1 += refR[(size_t)i * dp + lane + 64];
+  int col[H];
+  bool has[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    has[h] = lane + 64 * h < d;
+    col[h] = has[h] ? lane + 64 * h : 0;
   }
-  part[wave][lane] = s0;
-  part[wave][lane + 64] = s1;
+  // pass 1: centre of the live points
+  double sum[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) sum[h] = 0.0;
+  constexpr int kFly = 16;   // rows in flight per wave: this single-workgroup kernel is a chain of memory round trips
+  int i = wave;
+  for (; i + 16 * (kFly - 1) < n; i += 16 * kFly) {
+    double v[kFly][H];
+#pragma unroll
+    for (int q = 0; q < kFly; ++q)
+#pragma unroll
+      for (int h = 0; h < H; ++h) v[q][h] = refR[(size_t)(i + 16 * q) * dp + col[h]];
+#pragma unroll
+    for (int q = 0; q < kFly; ++q)
+#pragma unroll
+      for (int h = 0; h < H; ++h) sum[h] += v[q][h];
+  }
+  for (; i < n; i += 16)
+#pragma unroll
+    for (int h = 0; h < H; ++h) sum[h] += refR[(size_t)i * dp + col[h]];
+#pragma unroll
+  for (int h = 0; h < H; ++h) part[wave][lane + 64 * h] = sum[h];
   __syncthreads();
-  if (tid < d) {
+  if (tid < 64 * H) {
     double tot = 0.0;
     for (int w = 0; w < 16; ++w) tot += part[w][tid];
     cc[tid] = tot / (double)n;
   }
   __syncthreads();
-  const double c0 = has0 ? cc[lane] : 0.0, c1 = has1 ? cc[lane + 64] : 0.0;
+  double c[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) c[h] = cc[col[h]];
   // pass 2: largest centred coordinate (and whether everything is finite)
   double amax = 0.0;
   bool finite = true;
-#pragma unroll 8
-  for (int i = wave; i < n; i += 16) {
-    if (has0) {
-      const double v = fabs(refR[(size_t)i * dp + lane] - c0);
-      if (!(v <= 1.7e308)) finite = false;
-      amax = fmax(amax, v);
-    }
-    if (has1) {
-      const double v = fabs(refR[(size_t)i * dp + lane + 64] - c1);
-      if (!(v <= 1.7e308)) finite = false;
-      amax = fmax(amax, v);
-    }
+  i = wave;
+  for (; i + 16 * (kFly - 1) < n; i += 16 * kFly) {
+    double v[kFly][H];
+#pragma unroll
+    for (int q = 0; q < kFly; ++q)
+#pragma unroll
+      for (int h = 0; h < H; ++h) v[q][h] = fabs(refR[(size_t)(i + 16 * q) * dp + col[h]] - c[h]);
+#pragma unroll
+    for (int q = 0; q < kFly; ++q)
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        if (!(v[q][h] <= 1.7e308)) finite = false;
+        amax = fmax(amax, v[q][h]);
+      }
   }
+  for (; i < n; i += 16)
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const double v = fabs(refR[(size_t)i * dp + col[h]] - c[h]);
+      if (!(v <= 1.7e308)) finite = false;
+      amax = fmax(amax, v);
+    }
   amax = finite ? amax : INFINITY;
   for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
   if (lane == 0) red[wave] = amax;
@@ -105,25 +136,20 @@ __global__ __launch_bounds__(1024) void k_ref_stats(const double *__restrict__ r
   }
   // pass 3: largest scaled norm (an upper bound after the 1e-12 inflation below, whatever the summation order)
   double nmax = 0.0;
-  for (int i = wave; i < n; i += 64) {   // four rows in flight
-    double sq[4];
+  for (i = wave; i < n; i += 16 * kFly) {
+    double sq[kFly];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = i + 16 * q;
+    for (int q = 0; q < kFly; ++q) {
+      const int row = i + 16 * q < n ? i + 16 * q : i;
       sq[q] = 0.0;
-      if (row < n) {
-        if (has0) {
-          const double v = sigma * (refR[(size_t)row * dp + lane] - c0);
-          sq[q] = v * v;
-        }
-        if (has1) {
-          const double v = sigma * (refR[(size_t)row * dp + lane + 64] - c1);
-          sq[q] += v * v;
-        }
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const double v = has[h] ? sigma * (refR[(size_t)row * dp + col[h]] - c[h]) : 0.0;
+        sq[q] += v * v;
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kFly; ++q) {
       double r = sq[q];
       for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
       nmax = fmax(nmax, sqrt(r));
@@ -603,7 +629,10 @@ __global__ void k_route_gate(const uint8_t *route, const unsigned *counters, lon
 
 // ---------------------------------------------------------------- launchers -------------------
 void launch_ref_stats(const double *refR, int n, int d, int dp, double *stats, hipStream_t s) {
-  hipLaunchKernelGGL(k_ref_stats, dim3(1), dim3(1024), 0, s, refR, n, d, dp, stats);
+  if (d <= 64)
+    hipLaunchKernelGGL(k_ref_stats<1>, dim3(1), dim3(1024), 0, s, refR, n, d, dp, stats);
+  else
+    hipLaunchKernelGGL(k_ref_stats<2>, dim3(1), dim3(1024), 0, s, refR, n, d, dp, stats);
 }
 
 void launch_quant_refs(const double *refR, int n, int npad32, int d, int dp, int ks,

@@ -119,29 +119,38 @@ void launch_boot_final(const unsigned long long *M, const unsigned *sel, int n, 
 // ------------------------------------------------------- K3 pass 2 -----------------------
 // One wave per point j, lane = coordinate (two per lane up to d = 128).  Neighbours are visited in ascending i
 // from the hit ballots, so the sum has the reference's order (:100-109); then pts[j] - sum / (double)nn.
-// A workgroup holds 16 points and stages every 64-row tile of pts in LDS once for all of them: with the
+// A workgroup holds 16 points (8 waves x 2) and stages every 64-row tile of pts in LDS once for all of them: with the
 // LocalAffineLayer radius quirk every point is a neighbour of every point, and one wave per workgroup re-read
 // the whole array from L2 for each point (6.4 GB at N = 4000: 0.48 ms).
-constexpr int kAccumWaves = 16;
-__global__ __launch_bounds__(64 * kAccumWaves) void k_subtract_accum(const double *pts, int n, int d,
-                                                                    const unsigned long long *flags, int ntiles,
-                                                                    double *out) {
+constexpr int kAccumWaves = 8;
+constexpr int kAccumPer = 2;   // points per wave: one LDS read feeds both sums
+template <int H>               // 64-column halves (d <= 64 H); lanes past d work on column 0, their sums are not stored
+__global__ __launch_bounds__(64 * kAccumWaves) void k_subtract_accum(const double *__restrict__ pts, int n, int d,
+                                                                    const unsigned long long *__restrict__ flags,
+                                                                    int ntiles, double *__restrict__ out) {
   extern __shared__ double tile[];   // [64][d]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j = blockIdx.x * kAccumWaves + wave;
-  const bool live = j < n;
-  const bool has0 = lane < d, has1 = lane + 64 < d;
-  double sum0 = 0.0, sum1 = 0.0;
-  long long nn = 0;
-  // the next tile travels in registers while this one is consumed (64 x 128 doubles over 1024 threads: 8 each)
-  constexpr int kPer = (kWave * 128 + 64 * kAccumWaves - 1) / (64 * kAccumWaves);   // d <= 128 (MLF_MAX_DIM)
+  const int j0 = (blockIdx.x * kAccumWaves + wave) * kAccumPer;
+  int col[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) col[h] = lane + 64 * h < d ? lane + 64 * h : 0;
+  double sum[kAccumPer][H];
+  long long nn[kAccumPer];
+#pragma unroll
+  for (int p = 0; p < kAccumPer; ++p) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) sum[p][h] = 0.0;
+    nn[p] = 0;
+  }
+  // the next tile travels in registers while this one is consumed
+  constexpr int kPer = (kWave * 64 * H + 64 * kAccumWaves - 1) / (64 * kAccumWaves);
   double nxt[kPer];
   auto fetch = [&](int t) {
     const int rows = (n - t * kWave) < kWave ? (n - t * kWave) : kWave;
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
       const int e = threadIdx.x + q * 64 * kAccumWaves;
-      nxt[q] = e < rows * d ? pts[(long long)t * kWave * d + e] : 0.0;
+      nxt[q] = pts[(long long)t * kWave * d + (e < rows * d ? e : 0)];
     }
   };
   fetch(0);
@@ -155,36 +164,63 @@ __global__ __launch_bounds__(64 * kAccumWaves) void k_subtract_accum(const doubl
     }
     if (t + 1 < ntiles) fetch(t + 1);
     __syncthreads();
-    if (!live) continue;
-    unsigned long long m = flags[(long long)j * ntiles + t];
-    if (m == ~0ull) {   // whole tile: no bit scanning
+    unsigned long long m[kAccumPer];
+    unsigned long long any = 0ull, all = ~0ull;
+#pragma unroll
+    for (int p = 0; p < kAccumPer; ++p) {
+      m[p] = (j0 + p < n) ? flags[(long long)(j0 + p) * ntiles + t] : 0ull;
+      any |= m[p];
+      all &= m[p];
+    }
+    if (all == ~0ull) {   // whole tile for every point of this wave: no bit scanning
 #pragma unroll 16
       for (int q = 0; q < kWave; ++q) {
-        if (has0) sum0 += tile[q * d + lane];
-        if (has1) sum1 += tile[q * d + lane + 64];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const double v = tile[q * d + col[h]];
+#pragma unroll
+          for (int p = 0; p < kAccumPer; ++p) sum[p][h] += v;
+        }
       }
-      nn += kWave;
+#pragma unroll
+      for (int p = 0; p < kAccumPer; ++p) nn[p] += kWave;
       continue;
     }
-    while (m) {
-      const int q = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      if (has0) sum0 += tile[q * d + lane];
-      if (has1) sum1 += tile[q * d + lane + 64];
-      ++nn;
+    while (any) {   // ascending row order over the union; each point adds only its own neighbours
+      const int q = __ffsll((long long)any) - 1;
+      any &= any - 1;
+      double v[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) v[h] = tile[q * d + col[h]];
+#pragma unroll
+      for (int p = 0; p < kAccumPer; ++p)
+        if ((m[p] >> q) & 1ull) {   // wave-uniform
+#pragma unroll
+          for (int h = 0; h < H; ++h) sum[p][h] += v[h];
+          ++nn[p];
+        }
     }
   }
-  if (live) {
-    if (has0) out[(long long)j * d + lane] = pts[(long long)j * d + lane] - sum0 / (double)nn;
-    if (has1) out[(long long)j * d + lane + 64] = pts[(long long)j * d + lane + 64] - sum1 / (double)nn;
+#pragma unroll
+  for (int p = 0; p < kAccumPer; ++p) {
+    const int j = j0 + p;
+    if (j >= n) continue;
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+      if (lane + 64 * h < d)
+        out[(long long)j * d + lane + 64 * h] = pts[(long long)j * d + lane + 64 * h] - sum[p][h] / (double)nn[p];
   }
 }
 
 void launch_subtract_accum(const double *pts, int n, int d, const unsigned long long *flags,
                            int ntiles, double *out, hipStream_t s) {
-  const unsigned grid = (unsigned)((n + kAccumWaves - 1) / kAccumWaves);
-  hipLaunchKernelGGL(k_subtract_accum, dim3(grid), dim3(64 * kAccumWaves), (size_t)kWave * d * sizeof(double), s, pts, n, d,
-                     flags, ntiles, out);
+  const int per_block = kAccumWaves * kAccumPer;
+  const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
+  const size_t lds = (size_t)kWave * d * sizeof(double);
+  if (d <= 64)
+    hipLaunchKernelGGL(k_subtract_accum<1>, dim3(grid), dim3(64 * kAccumWaves), lds, s, pts, n, d, flags, ntiles, out);
+  else
+    hipLaunchKernelGGL(k_subtract_accum<2>, dim3(grid), dim3(64 * kAccumWaves), lds, s, pts, n, d, flags, ntiles, out);
 }
 
 // ------------------------------------------------------- K5 ------------------------------
@@ -289,43 +325,51 @@ __global__ __launch_bounds__(256) void k_boot_index(const uint8_t *selected, int
 // mean[b][k] over the selected rows: workgroup = bootstrap b, 16 waves take the list entries j = g (mod 16)
 // in ascending order, lane = coordinate (two per lane up to d = 128); the 16 partial sums are added in a
 // fixed order
-__global__ __launch_bounds__(1024) void k_boot_mean(const double *u, int d, const int *idx, int n, const int *count,
-                                                    double *mean) {
-  __shared__ double part[16][128];
+template <int H>   // 64-column halves (d <= 64 H); lanes past d work on column 0 and are not stored
+__global__ __launch_bounds__(1024) void k_boot_mean(const double *__restrict__ u, int d, const int *__restrict__ idx, int n,
+                                                    const int *__restrict__ count, double *__restrict__ mean) {
+  __shared__ double part[16][64 * H];
   const int b = blockIdx.x;
   const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int *list = idx + (long long)b * n;
   const int cnt = count[b];
-  const bool has0 = lane < d, has1 = lane + 64 < d;
-  double s0 = 0.0, s1 = 0.0;
-  int j = g;
-  for (; j + 48 < cnt; j += 64) {   // four rows in flight
-    const long long r0 = list[j], r1 = list[j + 16], r2 = list[j + 32], r3 = list[j + 48];
-    if (has0) {
-      const double a0 = u[r0 * d + lane], a1 = u[r1 * d + lane], a2 = u[r2 * d + lane], a3 = u[r3 * d + lane];
-      s0 += a0;
-      s0 += a1;
-      s0 += a2;
-      s0 += a3;
+  int col[H];
+  double sum[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    col[h] = lane + 64 * h < d ? lane + 64 * h : 0;
+    sum[h] = 0.0;
+  }
+  constexpr int kFly = 8;   // rows in flight
+  for (int t0 = 0; g + 16 * t0 < cnt; t0 += 64) {
+    const int jt = g + 16 * (t0 + lane);
+    const int mine = jt < cnt ? list[jt] : 0;   // this wave's next 64 list entries (j = g mod 16), one per lane
+    int left = (cnt - g - 16 * t0 + 15) / 16;
+    if (left > 64) left = 64;
+    int t = 0;
+    for (; t + kFly <= left; t += kFly) {
+      double v[kFly][H];
+#pragma unroll
+      for (int q = 0; q < kFly; ++q) {
+        const long long r = __builtin_amdgcn_readlane(mine, t + q);
+#pragma unroll
+        for (int h = 0; h < H; ++h) v[q][h] = u[r * d + col[h]];
+      }
+#pragma unroll
+      for (int q = 0; q < kFly; ++q)
+#pragma unroll
+        for (int h = 0; h < H; ++h) sum[h] += v[q][h];
     }
-    if (has1) {
-      const double a0 = u[r0 * d + lane + 64], a1 = u[r1 * d + lane + 64], a2 = u[r2 * d + lane + 64],
-                   a3 = u[r3 * d + lane + 64];
-      s1 += a0;
-      s1 += a1;
-      s1 += a2;
-      s1 += a3;
+    for (; t < left; ++t) {
+      const long long r = __builtin_amdgcn_readlane(mine, t);
+#pragma unroll
+      for (int h = 0; h < H; ++h) sum[h] += u[r * d + col[h]];
     }
   }
-  for (; j < cnt; j += 16) {
-    const long long r = list[j];
-    if (has0) s0 += u[r * d + lane];
-    if (has1) s1 += u[r * d + lane + 64];
-  }
-  part[g][lane] = s0;
-  part[g][lane + 64] = s1;
+#pragma unroll
+  for (int h = 0; h < H; ++h) part[g][lane + 64 * h] = sum[h];
   __syncthreads();
-  if (threadIdx.x < 128 && threadIdx.x < d) {
+  if (threadIdx.x < d) {
     const int k = threadIdx.x;
     double tot = 0.0;
     for (int w = 0; w < 16; ++w) tot += part[w][k];
@@ -333,64 +377,101 @@ __global__ __launch_bounds__(1024) void k_boot_mean(const double *u, int d, cons
   }
 }
 
-// cov[b][k][l] = sum_sel (u_ik - m_k)(u_il - m_l) / (cnt - 1); workgroup = (bootstrap b, row k),
-// thread = (list entries j = g (mod 16), column l): coalesced reads of u[i][:], four rows in flight, the 16
-// partial sums added in a fixed order
-__global__ __launch_bounds__(1024) void k_boot_cov(const double *u, int d, const int *idx, int n, const double *mean,
-                                                   const int *count, double *cov) {
-  __shared__ double part[16][128];
-  const int b = blockIdx.y, k = blockIdx.x;
+// cov[b][k][l] = sum_sel (u_ik - m_k)(u_il - m_l) / (cnt - 1).  Workgroup = (bootstrap b, kCovRows matrix rows k),
+// 8 waves over the list entries j = g (mod 8), lane = column l (two per lane up to d = 128).  A selected row is
+// read once per workgroup and serves all kCovRows values of k (its u_ik come from the same registers by lane
+// broadcast): one workgroup per single k re-read the selected rows from L2 d times per round (1.8 GB, 0.24 ms at
+// N = 4000, d = 50, B = 30).  Per (k, l) the products are accumulated in ascending list order within a wave and the
+// 8 partial sums are added in a fixed order.
+constexpr int kCovRows = 8;
+constexpr int kCovWaves = 8;   // 8 x 8 x 128 partial sums = 64 KB of LDS
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {   // l wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// H = number of 64-column halves (d <= 64 H).  Lanes past d work on column 0 (their sums are never stored): the
+// row loads and the accumulation carry no per-lane conditions.
+template <int H>
+__global__ __launch_bounds__(64 * kCovWaves) void k_boot_cov(const double *__restrict__ u, int d, const int *__restrict__ idx,
+                                                             int n, const double *__restrict__ mean,
+                                                             const int *__restrict__ count, double *__restrict__ cov) {
+  __shared__ double part[kCovWaves][kCovRows][64 * H];
+  const int b = blockIdx.y, k0 = blockIdx.x * kCovRows;
   const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int *list = idx + (long long)b * n;
   const int cnt = count[b];
-  const double mk = mean[(long long)b * d + k];
-  const bool has0 = lane < d, has1 = lane + 64 < d;
-  const double ml0 = has0 ? mean[(long long)b * d + lane] : 0.0;
-  const double ml1 = has1 ? mean[(long long)b * d + lane + 64] : 0.0;
-  double a0 = 0.0, a1 = 0.0;
-  // this wave's list entries j = g + 16 t: lane t fetches entry t of each block of 64, the rows are then named by
-  // lane broadcasts (a load of the index in front of every row load doubled the dependent round trips)
-  for (int t0 = 0; g + 16 * t0 < cnt; t0 += 64) {
-    const int jt = g + 16 * (t0 + lane);
-    const int mine = jt < cnt ? list[jt] : -1;
-    int left = (cnt - g - 16 * t0 + 15) / 16;
+  int col[H];
+  double ml[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    col[h] = lane + 64 * h < d ? lane + 64 * h : 0;
+    ml[h] = mean[(long long)b * d + col[h]];
+  }
+  double acc[kCovRows][H];
+#pragma unroll
+  for (int q = 0; q < kCovRows; ++q)
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc[q][h] = 0.0;
+  for (int t0 = 0; g + kCovWaves * t0 < cnt; t0 += 64) {
+    const int jt = g + kCovWaves * (t0 + lane);
+    const int mine = jt < cnt ? list[jt] : 0;   // this wave's next 64 list entries, one per lane
+    int left = (cnt - g - kCovWaves * t0 + kCovWaves - 1) / kCovWaves;
     if (left > 64) left = 64;
     int t = 0;
-    for (; t + 3 < left; t += 4) {   // four rows in flight
-      const long long r0 = __shfl(mine, t, 64), r1 = __shfl(mine, t + 1, 64), r2 = __shfl(mine, t + 2, 64),
-                      r3 = __shfl(mine, t + 3, 64);
-      const double k0 = u[r0 * d + k] - mk, k1 = u[r1 * d + k] - mk, k2 = u[r2 * d + k] - mk, k3 = u[r3 * d + k] - mk;
-      if (has0) {
-        const double x0 = u[r0 * d + lane], x1 = u[r1 * d + lane], x2 = u[r2 * d + lane], x3 = u[r3 * d + lane];
-        a0 = __builtin_fma(k0, x0 - ml0, a0);
-        a0 = __builtin_fma(k1, x1 - ml0, a0);
-        a0 = __builtin_fma(k2, x2 - ml0, a0);
-        a0 = __builtin_fma(k3, x3 - ml0, a0);
+    for (; t + 1 < left; t += 2) {              // two rows in flight
+      const long long r0 = __builtin_amdgcn_readlane(mine, t), r1 = __builtin_amdgcn_readlane(mine, t + 1);
+      double x0[H], x1[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        x0[h] = u[r0 * d + col[h]];
+        x1[h] = u[r1 * d + col[h]];
       }
-      if (has1) {
-        const double x0 = u[r0 * d + lane + 64], x1 = u[r1 * d + lane + 64], x2 = u[r2 * d + lane + 64],
-                     x3 = u[r3 * d + lane + 64];
-        a1 = __builtin_fma(k0, x0 - ml1, a1);
-        a1 = __builtin_fma(k1, x1 - ml1, a1);
-        a1 = __builtin_fma(k2, x2 - ml1, a1);
-        a1 = __builtin_fma(k3, x3 - ml1, a1);
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        x0[h] -= ml[h];
+        x1[h] -= ml[h];
+      }
+#pragma unroll
+      for (int q = 0; q < kCovRows; ++q) {
+        const int k = k0 + q < d ? k0 + q : 0;    // wave-uniform; the centred u_ik sits in lane k & 63 of half k >> 6
+        const double dk0 = (H == 1 || k < 64) ? readlane_f64(x0[0], k & 63) : readlane_f64(x0[H - 1], k & 63);
+        const double dk1 = (H == 1 || k < 64) ? readlane_f64(x1[0], k & 63) : readlane_f64(x1[H - 1], k & 63);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          acc[q][h] = __builtin_fma(dk0, x0[h], acc[q][h]);
+          acc[q][h] = __builtin_fma(dk1, x1[h], acc[q][h]);
+        }
       }
     }
-    for (; t < left; ++t) {
-      const long long r = __shfl(mine, t, 64);
-      const double dk = u[r * d + k] - mk;
-      if (has0) a0 = __builtin_fma(dk, u[r * d + lane] - ml0, a0);
-      if (has1) a1 = __builtin_fma(dk, u[r * d + lane + 64] - ml1, a1);
+    if (t < left) {
+      const long long r0 = __builtin_amdgcn_readlane(mine, t);
+      double x0[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) x0[h] = u[r0 * d + col[h]] - ml[h];
+#pragma unroll
+      for (int q = 0; q < kCovRows; ++q) {
+        const int k = k0 + q < d ? k0 + q : 0;
+        const double dk0 = (H == 1 || k < 64) ? readlane_f64(x0[0], k & 63) : readlane_f64(x0[H - 1], k & 63);
+#pragma unroll
+        for (int h = 0; h < H; ++h) acc[q][h] = __builtin_fma(dk0, x0[h], acc[q][h]);
+      }
     }
   }
-  part[g][lane] = a0;
-  part[g][lane + 64] = a1;
+#pragma unroll
+  for (int q = 0; q < kCovRows; ++q)
+#pragma unroll
+    for (int h = 0; h < H; ++h) part[g][q][lane + 64 * h] = acc[q][h];
   __syncthreads();
-  if (threadIdx.x < 128 && threadIdx.x < d) {
-    const int l = threadIdx.x;
-    double tot = 0.0;
-    for (int w = 0; w < 16; ++w) tot += part[w][l];
-    cov[((long long)b * d + k) * d + l] = tot / (double)(cnt - 1);
+  for (int e = threadIdx.x; e < kCovRows * 64 * H; e += 64 * kCovWaves) {
+    const int q = e / (64 * H), l = e % (64 * H);
+    if (k0 + q < d && l < d) {
+      double tot = 0.0;
+      for (int w = 0; w < kCovWaves; ++w) tot += part[w][q][l];
+      cov[((long long)b * d + k0 + q) * d + l] = tot / (double)(cnt - 1);
+    }
   }
 }
 
@@ -398,8 +479,15 @@ __global__ __launch_bounds__(1024) void k_boot_cov(const double *u, int d, const
 void launch_boot_moments(const double *u, int n, int d, const uint8_t *selected, int B, double *mean,
                          int *count, double *cov, int *idx, hipStream_t s) {
   hipLaunchKernelGGL(k_boot_index, dim3(B), dim3(256), 0, s, selected, n, idx, count);
-  hipLaunchKernelGGL(k_boot_mean, dim3(B), dim3(1024), 0, s, u, d, idx, n, count, mean);
-  hipLaunchKernelGGL(k_boot_cov, dim3((unsigned)d, (unsigned)B), dim3(1024), 0, s, u, d, idx, n, mean, count, cov);
+  if (d <= 64)
+    hipLaunchKernelGGL(k_boot_mean<1>, dim3(B), dim3(1024), 0, s, u, d, idx, n, count, mean);
+  else
+    hipLaunchKernelGGL(k_boot_mean<2>, dim3(B), dim3(1024), 0, s, u, d, idx, n, count, mean);
+  const dim3 cgrid((unsigned)((d + kCovRows - 1) / kCovRows), (unsigned)B);
+  if (d <= 64)
+    hipLaunchKernelGGL(k_boot_cov<1>, cgrid, dim3(64 * kCovWaves), 0, s, u, d, idx, n, mean, count, cov);
+  else
+    hipLaunchKernelGGL(k_boot_cov<2>, cgrid, dim3(64 * kCovWaves), 0, s, u, d, idx, n, mean, count, cov);
 }
 
 // ------------------------------------------------------- likelihoods (V1, L1-L3) ---------

@@ -17,8 +17,11 @@
 
 namespace mlf {
 
-template <int DP>
+// QB = queries per workgroup: 64 for large batches; 16 when the batch is so small that 64-query workgroups would
+// leave most CUs idle (the rebuild scans its 4000 live points against themselves: 63 workgroups for 256 CUs)
+template <int DP, int QB>
 __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
+  constexpr int kScanQB = QB;   // shadows the global default inside this kernel
   __shared__ __attribute__((aligned(16))) double qs[kScanQB * DP];
   __shared__ int state[kScanQB];  // SCAN_FIRST/MASK: first-hit index or kNone; -1 = inactive
   __shared__ int cnt[kScanQB];
@@ -116,11 +119,16 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
 
 hipError_t launch_scan(int dp, const ScanArgs &a, hipStream_t s) {
   if (a.nq <= 0) return hipSuccess;
-  const unsigned grid = (unsigned)((a.nq + kScanQB - 1) / kScanQB);
+  const bool small = a.nq <= 16384;
+  const int qb = small ? 16 : kScanQB;
+  const unsigned grid = (unsigned)((a.nq + qb - 1) / qb);
   switch (dp) {
-#define X(D)                                                       \
-  case D:                                                          \
-    hipLaunchKernelGGL(k_scan<D>, dim3(grid), dim3(kScanThreads), 0, s, a); \
+#define X(D)                                                                          \
+  case D:                                                                             \
+    if (small)                                                                        \
+      hipLaunchKernelGGL((k_scan<D, 16>), dim3(grid), dim3(kScanThreads), 0, s, a);    \
+    else                                                                              \
+      hipLaunchKernelGGL((k_scan<D, kScanQB>), dim3(grid), dim3(kScanThreads), 0, s, a); \
     break;
     MLF_FOR_EACH_DP(X)
 #undef X
