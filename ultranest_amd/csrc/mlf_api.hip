@@ -47,14 +47,14 @@ struct FilterCtx {
   bool usable = false;       // statistics are finite and the dimensionality is covered
   int ks = 0, ntiles32 = 0;
   double sigma = 1.0, amax = 0.0;
-  DevBuf stats, refF, qF, tlo, thi, route, best, counters, list, segcnt, gate2;
+  DevBuf stats, statscratch, refF, qF, tlo, thi, route, best, counters, list, segcnt, gate2;
   // phased sweep: two compacted query sets (ping-pong)
   DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png, pflags, pblk;
   // (start, stop) event pairs around every k_filter launch of the timed calls
   std::vector<hipEvent_t> kev;
   size_t kev_used = 0;
   void release() {
-    DevBuf *b[] = {&stats, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2,
+    DevBuf *b[] = {&stats, &statscratch, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2,
                    &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png, &pflags, &pblk};
     for (DevBuf *x : b) x->release();
     refs_ready = usable = false;
@@ -154,7 +154,13 @@ int filter_prepare_refs(FilterCtx &f, const double *refR, int n, int d, int dp, 
   CK(f.stats.reserve((8 + MLF_FILTER_MAXD) * sizeof(double)));
   CK(f.refF.reserve((size_t)npad32 * ks * 16 * 2));
   (void)d;
-  launch_ref_stats(refR, n, dp, dp, f.stats.as<double>(), s);
+  {
+    const void *before = f.statscratch.p;
+    const size_t bytes = ((size_t)64 * 128 + 2) * sizeof(double);
+    CK(f.statscratch.reserve(bytes));
+    if (f.statscratch.p != before) CK(hipMemsetAsync(f.statscratch.p, 0, bytes, s));   // running maxima start at zero
+  }
+  launch_ref_stats(refR, n, dp, dp, f.stats.as<double>(), f.statscratch.as<double>(), s);
   launch_quant_refs(refR, n, npad32, dp, dp, ks, f.stats.as<double>(), f.refF.p, s);
   CK(hipGetLastError());
   if (host_sync) {

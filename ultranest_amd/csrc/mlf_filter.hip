@@ -44,128 +44,85 @@ typedef __attribute__((ext_vector_type(8))) _Float16 half8;
 typedef __attribute__((ext_vector_type(16))) float float16v;
 
 // ---------------------------------------------------------------- live-point statistics -----
-// single workgroup: centre c[k] = mean_i a_ik, amax = max |a_ik - c_k|, sigma = 2^-ceil(log2 amax),
-// namax = max_i |sigma (a_i - c)|.  stats: [0]=sigma [1]=namax [2]=amax [3]=finite flag; c follows at [8..]
-// One workgroup of 16 waves; a wave takes the rows i = wave (mod 16) with lane = coordinate (two per lane up to
-// d = 128), so every row is one coalesced read.  (A thread-per-column / thread-per-row version of the same three
-// passes walked the rows with a DP-element stride and took 0.23 ms at N = 4000.)
-template <int H>   // H = number of 64-column halves (d <= 64 H); lanes past d work on column 0 and are masked at the end
-__global__ __launch_bounds__(1024) void k_ref_stats(const double *__restrict__ refR, int n, int d, int dp,
-                                                    double *__restrict__ stats) {
-  __shared__ double part[16][64 * H];
-  __shared__ double cc[64 * H];
-  __shared__ double red[16];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  int col[H];
-  bool has[H];
-#pragma unroll
-  for (int h = 0; h < H; ++h) {
-    has[h] = lane + 64 * h < d;
-    col[h] = has[h] ? lane + 64 * h : 0;
+// centre c[k] = mean_i a_ik, amax = max |a_ik - c_k|, sigma = 2^-ceil(log2 amax), namax = max_i |sigma (a_i - c)|.
+// stats: [0]=sigma [1]=namax [2]=amax [3]=finite flag; c follows at [8..].
+// Three short launches over many workgroups (a single-workgroup version of the same passes took 0.2 ms: one CU,
+// whatever its inner loops looked like).  Everything is deterministic: partial sums are added in a fixed order by
+// every consumer, maxima are order independent.  scratch: kStatBlocks * 128 doubles + 2 u64.
+constexpr int kStatBlocks = 64;
+
+// rows i = block (mod kStatBlocks) x wave (mod 4): column sums of this workgroup -> scratch[block][128]
+__global__ __launch_bounds__(256) void k_ref_colsum(const double *__restrict__ refR, int n, int d, int dp,
+                                                    double *__restrict__ scratch) {
+  __shared__ double part[4][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = lane < d ? lane : 0, c1 = lane + 64 < d ? lane + 64 : 0;
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = blockIdx.x * 4 + wave; i < n; i += 4 * kStatBlocks) {
+    s0 += refR[(size_t)i * dp + c0];
+    s1 += refR[(size_t)i * dp + c1];
   }
-  // pass 1: centre of the live points
-  double sum[H];
-#pragma unroll
-  for (int h = 0; h < H; ++h) sum[h] = 0.0;
-  constexpr int kFly = 16;   // rows in flight per wave: this single-workgroup kernel is a chain of memory round trips
-  int i = wave;
-  for (; i + 16 * (kFly - 1) < n; i += 16 * kFly) {
-    double v[kFly][H];
-#pragma unroll
-    for (int q = 0; q < kFly; ++q)
-#pragma unroll
-      for (int h = 0; h < H; ++h) v[q][h] = refR[(size_t)(i + 16 * q) * dp + col[h]];
-#pragma unroll
-    for (int q = 0; q < kFly; ++q)
-#pragma unroll
-      for (int h = 0; h < H; ++h) sum[h] += v[q][h];
-  }
-  for (; i < n; i += 16)
-#pragma unroll
-    for (int h = 0; h < H; ++h) sum[h] += refR[(size_t)i * dp + col[h]];
-#pragma unroll
-  for (int h = 0; h < H; ++h) part[wave][lane + 64 * h] = sum[h];
+  part[wave][lane] = s0;
+  part[wave][lane + 64] = s1;
   __syncthreads();
-  if (tid < 64 * H) {
+  if (threadIdx.x < 128)
+    scratch[blockIdx.x * 128 + threadIdx.x] =
+        (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// centre from the partial sums (fixed order), then this workgroup's rows: largest |a_ik - c_k| and largest
+// |a_i - c|^2 as bit patterns (non-negative doubles order like their bit patterns; NaN / inf -> all ones)
+__global__ __launch_bounds__(256) void k_ref_extent(const double *__restrict__ refR, int n, int d, int dp,
+                                                    const double *__restrict__ scratch,
+                                                    unsigned long long *__restrict__ maxima, double *__restrict__ stats) {
+  __shared__ double cc[128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 128) {
     double tot = 0.0;
-    for (int w = 0; w < 16; ++w) tot += part[w][tid];
-    cc[tid] = tot / (double)n;
+    for (int b = 0; b < kStatBlocks; ++b) tot += scratch[b * 128 + threadIdx.x];
+    cc[threadIdx.x] = tot / (double)n;
+    if (blockIdx.x == 0 && threadIdx.x < d) stats[8 + threadIdx.x] = cc[threadIdx.x];
   }
   __syncthreads();
-  double c[H];
-#pragma unroll
-  for (int h = 0; h < H; ++h) c[h] = cc[col[h]];
-  // pass 2: largest centred coordinate (and whether everything is finite)
-  double amax = 0.0;
+  const bool h0 = lane < d, h1 = lane + 64 < d;
+  const int c0 = h0 ? lane : 0, c1 = h1 ? lane + 64 : 0;
+  const double m0 = cc[c0], m1 = cc[c1];
+  double amax = 0.0, n2max = 0.0;
   bool finite = true;
-  i = wave;
-  for (; i + 16 * (kFly - 1) < n; i += 16 * kFly) {
-    double v[kFly][H];
-#pragma unroll
-    for (int q = 0; q < kFly; ++q)
-#pragma unroll
-      for (int h = 0; h < H; ++h) v[q][h] = fabs(refR[(size_t)(i + 16 * q) * dp + col[h]] - c[h]);
-#pragma unroll
-    for (int q = 0; q < kFly; ++q)
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        if (!(v[q][h] <= 1.7e308)) finite = false;
-        amax = fmax(amax, v[q][h]);
-      }
+  for (int i = blockIdx.x * 4 + wave; i < n; i += 4 * kStatBlocks) {
+    const double v0 = h0 ? refR[(size_t)i * dp + c0] - m0 : 0.0;
+    const double v1 = h1 ? refR[(size_t)i * dp + c1] - m1 : 0.0;
+    if (!(fabs(v0) <= 1.7e308) || !(fabs(v1) <= 1.7e308)) finite = false;
+    amax = fmax(amax, fmax(fabs(v0), fabs(v1)));
+    double sq = v0 * v0 + v1 * v1;
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    n2max = fmax(n2max, sq);
   }
-  for (; i < n; i += 16)
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const double v = fabs(refR[(size_t)i * dp + col[h]] - c[h]);
-      if (!(v <= 1.7e308)) finite = false;
-      amax = fmax(amax, v);
-    }
-  amax = finite ? amax : INFINITY;
   for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
-  if (lane == 0) red[wave] = amax;
-  __syncthreads();
-  double amax_all = red[0];
-  for (int w = 1; w < 16; ++w) amax_all = fmax(amax_all, red[w]);
-  __syncthreads();
+  const bool all_finite = __all(finite) && amax <= 1.7e308 && n2max <= 1.7e308;
+  if (lane == 0) {
+    atomicMax(&maxima[0], all_finite ? (unsigned long long)__double_as_longlong(amax) : ~0ull);
+    atomicMax(&maxima[1], all_finite ? (unsigned long long)__double_as_longlong(n2max) : ~0ull);
+  }
+}
+
+__global__ void k_ref_finish(unsigned long long *maxima, double *stats) {
+  const unsigned long long a = maxima[0], q = maxima[1];
+  maxima[0] = maxima[1] = 0ull;   // ready for the next set of live points
+  const bool finite = a != ~0ull && q != ~0ull;
+  const double amax_all = finite ? __longlong_as_double((long long)a) : INFINITY;
   double sigma = 1.0;
   if (amax_all > 0.0 && amax_all < 1e300) {
     int e;
     frexp(amax_all, &e);  // amax = m * 2^e, m in [0.5, 1)  ->  sigma*amax in [0.5, 1)
     sigma = ldexp(1.0, -e);
   }
-  // pass 3: largest scaled norm (an upper bound after the 1e-12 inflation below, whatever the summation order)
-  double nmax = 0.0;
-  for (i = wave; i < n; i += 16 * kFly) {
-    double sq[kFly];
-#pragma unroll
-    for (int q = 0; q < kFly; ++q) {
-      const int row = i + 16 * q < n ? i + 16 * q : i;
-      sq[q] = 0.0;
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const double v = has[h] ? sigma * (refR[(size_t)row * dp + col[h]] - c[h]) : 0.0;
-        sq[q] += v * v;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < kFly; ++q) {
-      double r = sq[q];
-      for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
-      nmax = fmax(nmax, sqrt(r));
-    }
-  }
-  if (lane == 0) red[wave] = nmax;
-  __syncthreads();
-  if (tid == 0) {
-    double nm = red[0];
-    for (int w = 1; w < 16; ++w) nm = fmax(nm, red[w]);
-    stats[0] = sigma;
-    stats[1] = nm * (1.0 + 1e-12);
-    stats[2] = amax_all;
-    stats[3] = (amax_all < 1e300) ? 1.0 : 0.0;
-  }
-  for (int k = tid; k < d; k += 1024) stats[8 + k] = cc[k];
+  // sigma is a power of two: |sigma (a_i - c)| = sigma |a_i - c| exactly; 1e-12 covers the rounding of the row sums
+  const double nmax = finite ? sigma * sqrt(__longlong_as_double((long long)q)) : INFINITY;
+  stats[0] = sigma;
+  stats[1] = nmax * (1.0 + 1e-12);
+  stats[2] = amax_all;
+  stats[3] = (amax_all < 1e300) ? 1.0 : 0.0;
 }
 
 // ---------------------------------------------------------------- live points -> f16 fragments
@@ -628,11 +585,11 @@ __global__ void k_route_gate(const uint8_t *route, const unsigned *counters, lon
 }
 
 // ---------------------------------------------------------------- launchers -------------------
-void launch_ref_stats(const double *refR, int n, int d, int dp, double *stats, hipStream_t s) {
-  if (d <= 64)
-    hipLaunchKernelGGL(k_ref_stats<1>, dim3(1), dim3(1024), 0, s, refR, n, d, dp, stats);
-  else
-    hipLaunchKernelGGL(k_ref_stats<2>, dim3(1), dim3(1024), 0, s, refR, n, d, dp, stats);
+void launch_ref_stats(const double *refR, int n, int d, int dp, double *stats, double *scratch, hipStream_t s) {
+  unsigned long long *maxima = reinterpret_cast<unsigned long long *>(scratch + (size_t)kStatBlocks * 128);
+  hipLaunchKernelGGL(k_ref_colsum, dim3(kStatBlocks), dim3(256), 0, s, refR, n, d, dp, scratch);
+  hipLaunchKernelGGL(k_ref_extent, dim3(kStatBlocks), dim3(256), 0, s, refR, n, d, dp, scratch, maxima, stats);
+  hipLaunchKernelGGL(k_ref_finish, dim3(1), dim3(1), 0, s, maxima, stats);
 }
 
 void launch_quant_refs(const double *refR, int n, int npad32, int d, int dp, int ks,

@@ -70,7 +70,8 @@ struct RecheckArgs {
   int *best;
 };
 
-void launch_ref_stats(const double *refR, int n, int d, int dp, double *stats, hipStream_t s);
+// scratch: (64 * 128 + 2) doubles, zero-initialised once (the last two words are running maxima, reset by the launch)
+void launch_ref_stats(const double *refR, int n, int d, int dp, double *stats, double *scratch, hipStream_t s);
 void launch_quant_refs(const double *refR, int n, int npad32, int d, int dp, int ks,
                        const double *stats, void *refF, hipStream_t s);
 void launch_quant_queries(const double *q, long long ldq, long long nq, long long nqpad, int d_src, int d, int ks,

@@ -346,24 +346,20 @@ __global__ __launch_bounds__(1024) void k_boot_mean(const double *__restrict__ u
     const int mine = jt < cnt ? list[jt] : 0;   // this wave's next 64 list entries (j = g mod 16), one per lane
     int left = (cnt - g - 16 * t0 + 15) / 16;
     if (left > 64) left = 64;
-    int t = 0;
-    for (; t + kFly <= left; t += kFly) {
+    for (int t = 0; t < left; t += kFly) {   // entries past `left` repeat entry t and are left out of the sum
       double v[kFly][H];
 #pragma unroll
       for (int q = 0; q < kFly; ++q) {
-        const long long r = __builtin_amdgcn_readlane(mine, t + q);
+        const long long r = __builtin_amdgcn_readlane(mine, t + q < left ? t + q : t);
 #pragma unroll
         for (int h = 0; h < H; ++h) v[q][h] = u[r * d + col[h]];
       }
 #pragma unroll
       for (int q = 0; q < kFly; ++q)
+        if (t + q < left) {   // wave-uniform
 #pragma unroll
-        for (int h = 0; h < H; ++h) sum[h] += v[q][h];
-    }
-    for (; t < left; ++t) {
-      const long long r = __builtin_amdgcn_readlane(mine, t);
-#pragma unroll
-      for (int h = 0; h < H; ++h) sum[h] += u[r * d + col[h]];
+          for (int h = 0; h < H; ++h) sum[h] += v[q][h];
+        }
     }
   }
 #pragma unroll
