@@ -96,6 +96,15 @@ int mlf_affine_transform(const double *pts, size_t np, size_t d, const double *c
  * the selected rows of u.  Two-pass (centred) accumulation. */
 int mlf_bootstrap_moments(const double *u, size_t n, size_t d, const uint8_t *selected, size_t B,
                           double *mean_out /* B*d */, double *cov_out /* B*d*d */);
+/* Both steps above and the matrix inversion between them in one call, without leaving the device (d <= 64, the
+ * reference's minvol = 0 case): f_out[b] = max over the rows NOT selected in round b of
+ * (u_i - m_b)^T (scale cov_b)^-1 (u_i - m_b), with m_b / cov_b the mean and sample covariance of the selected rows
+ * (reference mlfriends.pyx:1056-1066 passes scale = d + 2).  The form is evaluated through a Cholesky factor, so the
+ * values agree with inv + einsum to rounding (tolerance class).  A round whose matrix is not positive definite or
+ * not finite gives NaN (the reference raises LinAlgError there). */
+int mlf_bootstrap_factor(const double *u, size_t n, size_t d, const uint8_t *selected, size_t B, double scale,
+                         double *f_out);
+
 /* f_out[b] = max over UNselected rows of (u-ctr_b)^T invcov_b (u-ctr_b). */
 int mlf_bootstrap_quadform_max(const double *u, size_t n, size_t d, const uint8_t *selected,
                                size_t B, const double *ctr /* B*d */,

@@ -60,6 +60,13 @@ def bootstrap_quadform_max(u, selected, ctr, invcov):
     return out
 
 
+def bootstrap_factor(u, selected, scale):
+    """The reference's own sequence for one round (mlfriends.pyx:1056-1066 with minvol = 0): covariance of the
+    selected rows, LAPACK inverse, einsum over the left-out rows."""
+    mean, cov = bootstrap_moments(u, selected)
+    return bootstrap_quadform_max(u, selected, mean, np.linalg.inv(cov * scale))
+
+
 class DeviceRegion(object):
     """Mimics the mlf_region handle semantics (set / update_point / thresholds / inside)."""
     n_full_sets = 0
@@ -117,7 +124,8 @@ class DeviceRegion(object):
 
 
 PATCHED = ["find_nearby", "count_nearby", "subtract_nearby", "maxradiussq_bootstrap", "compute_mean_pair_distance",
-           "inside_ellipsoid", "affine_transform", "bootstrap_moments", "bootstrap_quadform_max", "DeviceRegion"]
+           "inside_ellipsoid", "affine_transform", "bootstrap_moments", "bootstrap_quadform_max", "bootstrap_factor",
+           "DeviceRegion"]
 
 
 def install(monkeypatch):

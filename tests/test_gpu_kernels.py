@@ -203,6 +203,27 @@ def test_bootstrap_enlargement_f(golden, K, oracle):
     np.testing.assert_allclose(f, g[name + "_f"], rtol=1e-10)
 
 
+@pytest.mark.parametrize("case", range(len(inputs.BOOTSTRAP_CASES)))
+def test_bootstrap_factor_on_device(case, golden, K, oracle):
+    """Moments + Cholesky + quadratic form in one device call (mlf_bootstrap_factor) against the reference's
+    per-round enlargement f (fixture G3; tolerance class: 1e-10 relative), and the failure path."""
+    g = golden("g3_bootstrap")
+    name, n, d, B = inputs.BOOTSTRAP_CASES[case]
+    u = inputs.live_points(300 + case, n, d)
+    masks = oracle.draw_bootstrap_masks(np.random.RandomState(900 + case), n, B)
+    if d > 64:
+        with pytest.raises(ValueError):
+            K.bootstrap_factor(u, masks, d + 2)
+        return
+    f = K.bootstrap_factor(u, masks, d + 2)
+    np.testing.assert_allclose(f, g[name + "_f"], rtol=1e-10)
+    # a round whose selected rows span no volume: NaN for that round only
+    flat = u.copy()
+    flat[:, 0] = 0.25
+    bad = K.bootstrap_factor(flat, masks[:2], d + 2)
+    assert np.isnan(bad).all()
+
+
 # ------------------------------------------------------------------ likelihoods ---------------
 def test_likelihoods_golden(golden):
     from ultranest_amd import likelihoods as L

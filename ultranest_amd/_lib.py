@@ -36,6 +36,7 @@ SIGNATURES = {
     "mlf_inside_ellipsoid": [_vp, _sz, _sz, _vp, _vp, _dbl, _vp, _vp],
     "mlf_affine_transform": [_vp, _sz, _sz, _vp, _vp, _vp, _vp],
     "mlf_bootstrap_moments": [_vp, _sz, _sz, _vp, _sz, _vp, _vp],
+    "mlf_bootstrap_factor": [_vp, _sz, _sz, _vp, _sz, _dbl, _vp],
     "mlf_bootstrap_quadform_max": [_vp, _sz, _sz, _vp, _sz, _vp, _vp, _vp],
     "mlf_region_create": [_vp],
     "mlf_region_destroy": [_vp],

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "../../include/mlfriends_hip.h"
@@ -920,6 +921,42 @@ int mlf_bootstrap_moments(const double *u, size_t n, size_t d, const uint8_t *se
   CK(hipMemcpyAsync(mean_out, c.small0.p, B * d * sizeof(double), hipMemcpyDeviceToHost, c.stream));
   CK(hipMemcpyAsync(cov_out, c.out.p, B * d * d * sizeof(double), hipMemcpyDeviceToHost, c.stream));
   CK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+int mlf_bootstrap_factor(const double *u, size_t n, size_t d, const uint8_t *selected, size_t B, double scale,
+                         double *f_out) {
+  if (int rc = check_dims(d)) return rc;
+  if (B == 0) return 0;
+  if (!u || !selected || !f_out || n == 0) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (d > 64) return fail_arg(MLF_E_DIM, "mlf_bootstrap_factor covers d <= 64 (use the moments + quadratic-form calls above that)");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  if (int rc = upload(c.src, u, n * d * sizeof(double), c.stream)) return rc;
+  if (int rc = upload(c.selbytes, selected, B * n, c.stream)) return rc;
+  CK(c.small0.reserve(B * d * sizeof(double)));
+  CK(c.small1.reserve(B * sizeof(int)));
+  CK(c.out.reserve(B * d * d * sizeof(double)));
+  CK(c.small2.reserve(B * n * sizeof(int)));
+  CK(c.small3.reserve(B * sizeof(unsigned long long)));
+  launch_boot_moments(c.src.as<double>(), (int)n, (int)d, c.selbytes.as<uint8_t>(), (int)B, c.small0.as<double>(),
+                      c.small1.as<int>(), c.out.as<double>(), c.small2.as<int>(), c.stream);
+  CK(hipGetLastError());
+  CK(hipMemsetAsync(c.small3.p, 0, B * sizeof(unsigned long long), c.stream));
+  CK(launch_boot_cholmax(c.src.as<double>(), (int)n, (int)d, c.selbytes.as<uint8_t>(), (int)B, c.small0.as<double>(),
+                         c.out.as<double>(), scale, c.small3.as<unsigned long long>(), c.stream));
+  std::vector<unsigned long long> bits(B);
+  CK(hipMemcpyAsync(bits.data(), c.small3.p, B * sizeof(unsigned long long), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+  for (size_t b = 0; b < B; ++b) {
+    double v;
+    if (bits[b] == ~0ull) {
+      v = std::numeric_limits<double>::quiet_NaN();
+    } else {
+      memcpy(&v, &bits[b], sizeof v);
+    }
+    f_out[b] = v;
+  }
   return 0;
 }
 

@@ -130,6 +130,17 @@ def bootstrap_moments(u, selected):
     return mean, cov
 
 
+def bootstrap_factor(u, selected, scale):
+    """f[B]: per round the largest quadratic form of the left-out rows with the (scale x) covariance of
+    the selected rows, all on the device (d <= 64); NaN marks a round with a singular matrix."""
+    u = f64(u)
+    sel = np.ascontiguousarray(selected, dtype=np.uint8)
+    B, n = sel.shape
+    f = np.empty(B)
+    check(_lib.lib().mlf_bootstrap_factor(ptr(u), n, u.shape[1], ptr(sel), B, float(scale), ptr(f)))
+    return f
+
+
 def bootstrap_quadform_max(u, selected, ctr, invcov):
     """f[b] = max over rows NOT selected in bootstrap b of (u-ctr_b)^T invcov_b (u-ctr_b);
     reference mlfriends.pyx:1060-1062."""

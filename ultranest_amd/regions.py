@@ -105,6 +105,12 @@ def _bootstrap_enlargement(u, masks, minvol):
         covs = np.empty((nrounds, ndim, ndim))
         for b, m in enumerate(masks):
             ctrs[b], covs[b] = bounding_ellipsoid(u[m], minvol=minvol)
+    elif minvol == 0 and ndim <= 64:
+        # moments, factorisation and the quadratic form in one device call (no LAPACK inverse on the host)
+        f = kernels.bootstrap_factor(u, masks, ndim + 2)
+        if not np.isfinite(f).all():
+            raise np.linalg.LinAlgError("Singular matrix")     # what np.linalg.inv raises in the reference
+        return f
     else:
         ctrs, covs = kernels.bootstrap_moments(u, masks)
         assert np.isfinite(covs).all(), (covs, u)
