@@ -86,6 +86,33 @@ def test_subtract_nearby_vs_oracle_dense(K, oracle):
         assert np.array_equal(K.subtract_nearby(u, r2), oracle.subtract_nearby(u, r2)), r2
 
 
+@pytest.mark.parametrize("n,d", [(333, 11), (130, 64), (257, 65), (500, 100), (64, 128), (1, 3), (17, 1)])
+def test_subtract_nearby_dimensions_and_ragged_tiles(n, d, K, oracle):
+    """Both column-half variants of the accumulate kernel (d <= 64, d <= 128), tile counts that are not a multiple
+    of the points per workgroup, and mixed neighbourhoods (some points see a whole 64-row tile, others do not)."""
+    rs = np.random.RandomState(100 + n + d)
+    u = rs.uniform(size=(n, d))
+    u[: n // 3] = 0.5 + 1e-3 * rs.normal(size=(n // 3, d))      # a tight clump: dense neighbourhoods
+    typical = d / 6.0                                            # mean squared distance of uniform points
+    for r2 in (0.0, 0.25 * typical, typical, 1e300):
+        assert np.array_equal(K.subtract_nearby(u, r2), oracle.subtract_nearby(u, r2)), (n, d, r2)
+
+
+@pytest.mark.parametrize("n,d,B", [(300, 70, 5), (1000, 128, 3), (100, 64, 33), (65, 1, 2), (2000, 50, 30)])
+def test_bootstrap_moments_dimensions(n, d, B, K, oracle):
+    """Index-list moment kernels in both column-half variants against numpy (tolerance class)."""
+    rs = np.random.RandomState(7 + n + d)
+    u = rs.uniform(size=(n, d))
+    masks = oracle.draw_bootstrap_masks(rs, n, B)
+    masks[0, :] = False
+    masks[0, : d + 5] = True                                     # a short list (fewer rows than one batch)
+    mean, cov = K.bootstrap_moments(u, masks)
+    for b in range(B):
+        sel = u[masks[b]]
+        np.testing.assert_allclose(mean[b], sel.mean(axis=0), rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(cov[b], np.atleast_2d(np.cov(sel, rowvar=0)), rtol=1e-9, atol=1e-15)
+
+
 # ------------------------------------------------------------------ K4 ------------------------
 @pytest.mark.parametrize("case", range(len(inputs.BOOTSTRAP_CASES)))
 def test_bootstrap_radius_golden(case, golden, K, oracle):
