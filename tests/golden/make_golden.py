@@ -603,7 +603,91 @@ def g12(ref):
     save("g12_results", **out)
 
 
-GROUPS = dict(g12=g12, g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
+# ------------------------------------------------------------------ G13 -----
+
+OVERCLUSTERED_TXT = [20, 23, 24, 27, 49]
+OVERCLUSTERED_NPZ = [20, 23, 24, 27, 42]
+
+
+def g13(ref):
+    """The reference's over-clustering regression fixtures (tests/overclustered_u_*.txt, tests/overclustered_*.npz)
+    run through the reference's own recipes (tests/test_clustering.py:116-225), with every intermediate value
+    recorded: the range checks of those tests become exact known answers."""
+    import types
+    from ultranest import ReactiveNestedSampler
+    from ultranest.utils import create_logger
+    tests_dir = os.path.join(REF, "tests")
+    out = {}
+    # recipe 1 (test_overclustering_eggbox_txt): ScalingLayer + MLFriends.compute_maxradiussq (global np.random) +
+    # update_clusters called with the u-space points as transformed points, as the reference's test does
+    np.random.seed(1)
+    for i in OVERCLUSTERED_TXT:
+        points = np.loadtxt(os.path.join(tests_dir, "overclustered_u_%d.txt" % i))
+        out["txt%d_u" % i] = points
+        radii, counts = [], []
+        for k in range(3):
+            layer = ref.ScalingLayer(wrapped_dims=[])
+            layer.optimize(points, points)
+            region = ref.MLFriends(points, layer)
+            maxr = region.compute_maxradiussq(nbootstraps=30)
+            region.maxradiussq = maxr
+            nclusters, clusteridxs, overlapped = ref.update_clusters(points, points, maxr)
+            radii.append(maxr)
+            counts.append(nclusters)
+        for j in range(3):
+            nclusters, clusteridxs, overlapped = ref.update_clusters(points, points, maxr)
+            counts.append(nclusters)
+        assert 14 < nclusters < 20
+        out["txt%d_radii" % i] = np.array(radii)
+        out["txt%d_nclusters" % i] = np.array(counts)
+        out["txt%d_ids" % i] = np.asarray(clusteridxs)
+        print("  txt", i, len(points), "points; r2", radii, "nclusters", counts)
+
+    # recipe 2 (test_overclustering_eggbox_update): the driver's _update_region on u0, then on u after invalidating
+    # the radius; AffineLayer, 30 bootstraps
+    class MockIntegrator(ReactiveNestedSampler):
+        def __init__(self):
+            self.use_mpi = False
+            self.mpi_size = 1
+            self.mpi_rank = 0
+            self.region = None
+            self.transformLayer = None
+            self.wrapped_axes = []
+            self.log = False
+            self.logger = create_logger("mock")
+            self.region_class = ref.MLFriends
+            self.transform_layer_class = ref.AffineLayer
+
+    def state(mock):
+        return np.array([mock.region.maxradiussq, mock.region.enlarge, mock.transformLayer.nclusters], dtype=float)
+
+    np.random.seed(1)
+    for i in OVERCLUSTERED_NPZ:
+        data = np.load(os.path.join(tests_dir, "overclustered_%d.npz" % i))
+        u0, u1 = data["u0"], data["u"]
+        out["npz%d_u0" % i], out["npz%d_u" % i] = u0, u1
+        mock = MockIntegrator()
+        mock.x_dim = u0.shape[1]
+        mock._update_region(u0, u0)
+        out["npz%d_first" % i] = state(mock)
+        out["npz%d_first_ids" % i] = np.asarray(mock.transformLayer.clusterids)
+        same = mock.transformLayer.create_new(u0, mock.region.maxradiussq)
+        out["npz%d_same_ids" % i] = np.asarray(same.clusterids)
+        new = mock.transformLayer.create_new(u1, mock.region.maxradiussq)
+        out["npz%d_new_ids" % i] = np.asarray(new.clusterids)
+        mock.region.maxradiussq = None
+        updated = mock._update_region(u1, u1)
+        out["npz%d_second" % i] = state(mock)
+        out["npz%d_second_ids" % i] = np.asarray(mock.transformLayer.clusterids)
+        out["npz%d_updated" % i] = np.array(bool(updated))
+        out["npz%d_next_random" % i] = np.float64(np.random.uniform())
+        _, sizes = np.unique(mock.transformLayer.clusterids, return_counts=True)
+        assert 14 < mock.transformLayer.nclusters < 20 and sizes.min() > 1
+        print("  npz", i, u0.shape, "->", u1.shape, "first", out["npz%d_first" % i], "second", out["npz%d_second" % i], updated)
+    save("g13_overclustered", **out)
+
+
+GROUPS = dict(g13=g13, g12=g12, g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)
