@@ -254,3 +254,66 @@ def test_graph_replay_equals_kernel_by_kernel_launches(direction):
             nfound += 1
             assert np.array_equal(ua, ub) and np.array_equal(pa, pb) and La == Lb
     assert nfound > 30
+
+
+# ---- the reference's own small tests of this module (tests/test_popstepsampling.py), same recipes -------------
+def _make_region(m, ndim, nlive=400):
+    us = np.random.uniform(size=(nlive, ndim))
+    layer = m.AffineLayer() if ndim > 1 else m.ScalingLayer()
+    layer.optimize(us, us)
+    region = m.MLFriends(us, layer)
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=30)
+    region.create_ellipsoid(minvol=1.0)
+    return region
+
+
+# reference tests/test_popstepsampling.py:116-138
+def test_direction_proposals_for_every_layer_and_region_class(backend):
+    import ultranest_amd.mlfriends as m
+    import ultranest_amd.popstepsampler as pop
+    proposals = [pop.generate_cube_oriented_direction, pop.generate_random_direction,
+                 pop.generate_region_oriented_direction, pop.generate_region_random_direction]
+    np.random.seed(2)
+    points = np.random.uniform(size=(100, 10))
+    for layer_class in m.AffineLayer, m.ScalingLayer:
+        layer = layer_class()
+        layer.optimize(points, points)
+        for region_class in m.MLFriends, m.RobustEllipsoidRegion, m.SimpleRegion:
+            region = region_class(points, layer)
+            r, f = region.compute_enlargement(minvol=1.0, nbootstraps=30)
+            region.maxradiussq, region.enlarge = r, f
+            region.create_ellipsoid(minvol=1.0)
+            for prop in proposals:
+                directions = prop(points, region, scale=1.)
+                assert directions.shape == points.shape, (prop, region_class, layer_class)
+                assert np.isfinite(directions).all()
+
+
+# reference tests/test_popstepsampling.py:141-158
+def test_slice_limit_functions():
+    import ultranest_amd.popstepsampler as pop
+    fake_tleft, fake_tright = [-0.5, -0.2, -1.5], [0.2, 2.4, 0.2]
+    expected = [(fake_tleft, fake_tright), ([-0.5, -0.2, -1.], [0.2, 1.0, 0.2])]
+    for func, (want_left, want_right) in zip((pop.slice_limit_to_unitcube, pop.slice_limit_to_scale), expected):
+        tleft, tright = func(fake_tleft, fake_tright)
+        assert np.allclose(tleft, want_left) and np.allclose(tright, want_right), func
+
+
+# reference tests/test_popstepsampling.py:269-292
+def test_direction_proposal_values(backend):
+    import ultranest_amd.mlfriends as m
+    import ultranest_amd.popstepsampler as pop
+    np.random.seed(12)
+    region = _make_region(m, 10, nlive=400)
+    ui = region.u[::2]
+    scale = np.random.uniform()
+    vcube = pop.generate_cube_oriented_direction(ui, region, scale)
+    assert vcube.shape == ui.shape
+    assert ((vcube != 0).sum(axis=1) == 1).all(), vcube
+    assert np.allclose(np.linalg.norm(vcube, axis=1), scale)
+    assert (pop.generate_random_direction(ui, region, scale) != 0).all()
+    assert (pop.generate_region_oriented_direction(ui, region, scale) != 0).all()
+    assert (pop.generate_region_random_direction(ui, region, scale) != 0).all()
+    vcubestd = pop.generate_cube_oriented_direction_scaled(ui, region, scale)
+    assert vcubestd.shape == ui.shape
+    assert ((vcubestd != 0).sum(axis=1) == 1).all(), vcubestd

@@ -321,3 +321,42 @@ def test_inplace_live_point_replacement(backend):
     region.maxradiussq = None                       # driver invalidates the radius (:2827)
     with pytest.raises(TypeError):
         region.inside(pts)
+
+
+# reference tests/test_regionsampling.py:145-192
+def test_ellipsoids_contain_their_points(backend):
+    """Every region class contains its own live points after compute_enlargement + create_ellipsoid, including a
+    WrappingEllipsoid with a constant (zero-variance) coordinate and a 1-d one."""
+    import ultranest_amd.mlfriends as m
+    np.random.seed(4)
+    tpoints = np.random.uniform(0.4, 0.6, size=(1000, 1))
+    tregion = m.WrappingEllipsoid(tpoints)
+    tregion.enlarge = tregion.compute_enlargement(nbootstraps=30)
+    tregion.create_ellipsoid()
+    assert tregion.inside(tpoints).all()
+    for umax in 0.6, 0.5:
+        points = np.random.uniform(0.4, 0.6, size=(1000, 3))
+        points = points[points[:, 0] < umax]
+        tpoints = points * 10
+        tpoints[:, 0] = np.floor(tpoints[:, 0])      # umax = 0.5: this coordinate is constant
+        layer = m.AffineLayer(wrapped_dims=[])
+        layer.optimize(points, points)
+        for cls in (m.MLFriends, m.RobustEllipsoidRegion, m.SimpleRegion):
+            region = cls(points, layer)
+            region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=30)
+            region.create_ellipsoid()
+            inside = region.inside(points)
+            assert inside.shape == (len(points),), (cls, inside.shape, points.shape)
+            assert inside.all(), cls
+        tregion = m.WrappingEllipsoid(tpoints)
+        if umax == 0.5:
+            assert list(tregion.variable_dims) == [False, True, True]
+        tregion.enlarge = tregion.compute_enlargement(nbootstraps=30)
+        tregion.create_ellipsoid()
+        inside = tregion.inside(tpoints)
+        assert inside.shape == (len(tpoints),), (inside.shape, tpoints.shape)
+        assert inside.all()
+        moved = tpoints.copy()
+        moved[:, 0] += 1                             # off the constant coordinate: outside
+        if umax == 0.5:
+            assert not tregion.inside(moved).any()

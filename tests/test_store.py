@@ -90,3 +90,100 @@ def test_harness_resumes_from_store(backend, tmp_path):
     store.close()
     assert abs(again["logz"] - first["logz"]) < 0.5
     assert calls[0] < 0.2 * ncalls_first, (calls[0], ncalls_first)
+
+
+# reference tests/test_store.py:8-75
+def test_text_store_lifecycle_like_the_reference_test(tmp_path):
+    """Open / add / close / reopen sequence of the reference's own test: what a fresh, an empty and a refilled
+    store serve, the wrong-width error, and the warnings when the column count does not match the file."""
+    from ultranest_amd.store import TextPointStore as PointStore
+    filepath = str(tmp_path / "store.txt")
+    ptst = PointStore(filepath, 4)
+    assert ptst.stack_empty
+    assert ptst.pop(-np.inf)[1] is None and ptst.pop(100)[1] is None          # new store serves nothing
+    ptst.close()
+    ptst = PointStore(filepath, 4)
+    assert ptst.pop(-np.inf)[1] is None and ptst.pop(100)[1] is None          # empty file serves nothing
+    ptst.close()
+    ptst = PointStore(filepath, 4)
+    with pytest.raises(ValueError):
+        ptst.add([-np.inf, 123, 4], 1)                                       # wrong length
+    ptst.close()
+    ptst = PointStore(filepath, 4)
+    assert ptst.stack_empty
+    ptst.add([-np.inf, 123, 413, 213], 2)
+    assert ptst.stack_empty                                                  # additions are not served back in the same session
+    ptst.close()
+    ptst = PointStore(filepath, 4)
+    assert not ptst.stack_empty
+    entry = ptst.pop(-np.inf)[1]
+    assert entry is not None and entry[1] == 123
+    assert ptst.pop(100)[1] is None
+    assert ptst.stack_empty
+    ptst.add([101, 155, 413, 213], 3)
+    assert ptst.stack_empty
+    ptst.close()
+    ptst = PointStore(filepath, 4)
+    assert ptst.pop(-np.inf)[1] is not None
+    assert ptst.pop(-np.inf)[1] is None and ptst.pop(100)[1] is None
+    ptst.add([99, 156, 413, 213], 4)
+    ptst.close()
+    ptst = PointStore(filepath, 4)
+    assert ptst.pop(-np.inf)[1] is not None
+    assert ptst.pop(-np.inf)[1] is None
+    entry = ptst.pop(100)[1]
+    assert entry is not None and entry[1] == 156
+    ptst.close()
+    for wrong in (3, 5):
+        with pytest.warns(UserWarning):
+            ptst = PointStore(filepath, wrong)
+        assert ptst.stack_empty
+        ptst.close()
+
+
+# reference tests/test_store.py:153-179
+def test_null_store_accepts_anything():
+    from ultranest_amd.store import NullPointStore
+    ptst = NullPointStore(4)
+    assert ptst.stack_empty and ptst.pop(-np.inf)[1] is None and ptst.pop(100)[1] is None
+    for row, ncalls in (([-np.inf, 123, 413, 213], 1), ([10, 123, 413, 213], 2), ([10, 123, 413, 213, 123], 3),
+                        ([99, 123, 413], 4)):
+        ptst.add(row, ncalls)                                                # no errors even for rubbish input
+    assert ptst.stack_empty and ptst.pop(-np.inf)[1] is None
+    ptst.close()
+
+
+# reference tests/test_store.py:182-243 (text flavour; the HDF5 flavour needs h5py)
+@pytest.mark.parametrize("N", [1, 2, 10, 100])
+def test_store_many_rows_pop_order(tmp_path, N):
+    from ultranest_amd.store import TextPointStore as PointStore
+    filepath = str(tmp_path / "many.txt")
+    ptst = PointStore(filepath, 3)
+    for i in range(N):
+        ptst.add([-np.inf, i - 0.1, i - 0.1], i)
+    for i in range(N):
+        ptst.add([i, i + 1, i + 1], i + N)
+    for i in range(N):
+        ptst.add([-np.inf, i - 0.1, i - 0.1], i + 2 * N)
+    for i in range(N - 1, -1, -1):
+        ptst.add([N - i, N - i + .5, N - i + .5], (N - i) + 3 * N)
+    ptst.close()
+    ptst = PointStore(filepath, 3)
+    assert ptst.ncalls == 4 * N and len(ptst.stack) == 4 * N
+    for i in range(N):
+        assert ptst.pop(-np.inf)[1] is not None
+    assert len(ptst.stack) == 3 * N
+    for i in range(N):
+        idx, row = ptst.pop(i)
+        assert row is not None and row[0] == i and row[1] >= i + .1
+    ptst.reset()
+    assert len(ptst.stack) == 2 * N
+    for i in range(N):
+        assert ptst.pop(-np.inf)[1] is not None
+    assert len(ptst.stack) == N
+    for i in range(N - 1, -1, -1):
+        ptst.reset()
+        idx, row = ptst.pop(N - i)
+        assert row is not None and row[0] == N - i and row[1] >= N - i + .1
+    assert len(ptst.stack) == 0 and ptst.stack_empty
+    ptst.close()
