@@ -145,6 +145,8 @@ def test_run_summaries_and_stores_under_the_stock_driver(monkeypatch, tmp_path):
         monkeypatch.setattr(integ, name, getattr(myutils, name))
     for name in ("NullPointStore", "TextPointStore"):
         monkeypatch.setattr(integ, name, getattr(mystore, name))
+    import ultranest_amd.ordertest as myorder
+    monkeypatch.setattr(integ, "UniformOrderAccumulator", myorder.UniformOrderAccumulator)      # integrator.py:35, :2609
     ndim, sigma = 5, 0.01
     centers = np.ones(ndim) * 0.5
 
