@@ -381,53 +381,11 @@ __global__ __launch_bounds__(256) void k_walk_expand(WalkState w, const unsigned
   for (int k = 0; k < w.nparams; ++k) w.pnew[(size_t)i * w.nparams + k] = pc[(size_t)rank * w.nparams + k];
 }
 
-// evolve, second half (evolve_update) + PopulationSliceSampler.advance bookkeeping
-// (popstepsampler.py:585-603) + move diagnostics (diagnose_move_distances :64-94)
-__global__ __launch_bounds__(64) void k_walk_update(WalkState w, double Lmin, const StepParams *sp) {
-  const int lane = threadIdx.x;
-  if (sp) Lmin = sp->Lmin;
-  for (int i = blockIdx.x; i < w.P; i += gridDim.x) {
-  // every lane reads the walker's scalars and derives the same decision; lane 0 writes them back
-  const bool movable = w.movable[i] != 0;
-  const bool hit = w.acceptable[i] != 0 && w.Lnew[i] > Lmin;
-  double t = w.currentt[i], left = w.left[i], right = w.right[i];
-  uint8_t sl = w.sl[i], sr = w.sr[i];
-  const long long g0 = w.generation[i];
-  const double Lnew = w.Lnew[i];
-  bool success = false;
-  if (movable) success = update_walker(hit, t, left, right, sl, sr);
-  if (lane == 0) {
-    w.dist2[i] = qnan();
-    w.success[i] = success ? 1 : 0;
-    if (movable) {
-      w.currentt[i] = t;
-      w.left[i] = left;
-      w.right[i] = right;
-      w.sl[i] = sl;
-      w.sr[i] = sr;
-    }
-    if (success) {
-      w.generation[i] = g0 + 1;
-      w.allL[(size_t)i * w.G + g0 + 1] = Lnew;
-    }
-  }
-  if (!success) continue;
-  const double *un = w.unew + (size_t)i * w.d;
-  double *dst = w.allu + ((size_t)i * w.G + g0 + 1) * w.d;
-  for (int k = lane; k < w.d; k += 64) dst[k] = un[k];
-  for (int k = lane; k < w.nparams; k += 64) w.currentp[(size_t)i * w.nparams + k] = w.pnew[(size_t)i * w.nparams + k];
-  }
-}
-
-// diagnose_move_distances for the walkers that moved: one wave per walker, lane = whitened
-// coordinate (T rows are read coalesced), squared differences summed by a fixed shuffle tree
-__global__ __launch_bounds__(64) void k_walk_diag(WalkState w, WalkLayer ly) {
-  const int lane = threadIdx.x;
-  for (int i = blockIdx.x; i < w.P; i += gridDim.x) {
-  if (!w.success[i]) continue;
-  const long long g = w.generation[i];          // already advanced by k_walk_update
-  const double *uo = w.allu + ((size_t)i * w.G + (g - 1)) * w.d;
-  const double *un = w.unew + (size_t)i * w.d;
+// diagnose_move_distances for one walker that moved (wave-wide, lane = whitened coordinate; T rows are read
+// coalesced, squared differences summed by a fixed shuffle tree): uo = the point the step started from, un = the
+// accepted point
+__device__ __forceinline__ void dw_move_distance(const WalkState &w, const WalkLayer &ly, int i, int lane, const double *uo,
+                                                 const double *un) {
   double acc = 0.0;
   if (ly.kind == 0 && w.d <= 64) {
     // both points share every matrix element: lane k keeps the centred coordinate k of the two points, the
@@ -465,6 +423,45 @@ __global__ __launch_bounds__(64) void k_walk_diag(WalkState w, WalkLayer ly) {
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (lane == 0) w.dist2[i] = acc;
+}
+
+// evolve, second half (evolve_update) + PopulationSliceSampler.advance bookkeeping
+// (popstepsampler.py:585-603) + move diagnostics (diagnose_move_distances :64-94)
+__global__ __launch_bounds__(64) void k_walk_update(WalkState w, double Lmin, const StepParams *sp, WalkLayer ly) {
+  const int lane = threadIdx.x;
+  if (sp) Lmin = sp->Lmin;
+  for (int i = blockIdx.x; i < w.P; i += gridDim.x) {
+  // every lane reads the walker's scalars and derives the same decision; lane 0 writes them back
+  const bool movable = w.movable[i] != 0;
+  const bool hit = w.acceptable[i] != 0 && w.Lnew[i] > Lmin;
+  double t = w.currentt[i], left = w.left[i], right = w.right[i];
+  uint8_t sl = w.sl[i], sr = w.sr[i];
+  const long long g0 = w.generation[i];
+  const double Lnew = w.Lnew[i];
+  bool success = false;
+  if (movable) success = update_walker(hit, t, left, right, sl, sr);
+  if (lane == 0) {
+    w.dist2[i] = qnan();
+    w.success[i] = success ? 1 : 0;
+    if (movable) {
+      w.currentt[i] = t;
+      w.left[i] = left;
+      w.right[i] = right;
+      w.sl[i] = sl;
+      w.sr[i] = sr;
+    }
+    if (success) {
+      w.generation[i] = g0 + 1;
+      w.allL[(size_t)i * w.G + g0 + 1] = Lnew;
+    }
+  }
+  if (!success) continue;
+  const double *un = w.unew + (size_t)i * w.d;
+  double *dst = w.allu + ((size_t)i * w.G + g0 + 1) * w.d;
+  for (int k = lane; k < w.d; k += 64) dst[k] = un[k];
+  for (int k = lane; k < w.nparams; k += 64) w.currentp[(size_t)i * w.nparams + k] = w.pnew[(size_t)i * w.nparams + k];
+  // move diagnostics of this step while the wave still owns the walker (a second launch re-read all of this)
+  if (ly.kind >= 0) dw_move_distance(w, ly, i, lane, w.allu + ((size_t)i * w.G + g0) * w.d, un);
   }
 }
 
@@ -913,8 +910,7 @@ void launch_walk_expand(const WalkState &w, const unsigned *blk, const double *p
 }
 
 void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStream_t s, const StepParams *sp) {
-  hipLaunchKernelGGL(k_walk_update, walker_grid(w.P), dim3(64), 0, s, w, Lmin, sp);
-  if (layer.kind >= 0) hipLaunchKernelGGL(k_walk_diag, walker_grid(w.P), dim3(64), 0, s, w, layer);
+  hipLaunchKernelGGL(k_walk_update, walker_grid(w.P), dim3(64), 0, s, w, Lmin, sp, layer);
 }
 
 void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, double *partials,
