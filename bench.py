@@ -166,17 +166,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1 and args.gpus == 1, "launch one process per GPU (torch.distributed.run)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hooks (a 1-GPU box can run the N > 1 control flow as N processes on one device with gloo collectives):
+    # MLF_BENCH_DEVICE pins every rank to one device, MLF_BENCH_BACKEND replaces "nccl"
+    device_index = int(os.environ.get("MLF_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("MLF_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     from ultranest_amd import _lib, kernels
-    _lib.set_device(local_rank)
+    _lib.set_device(device_index)
     group = None
     # under torch.distributed.run the process group is RCCL, also for a single rank (so that the 1-GPU
     # box exercises the same init / barrier / all-reduce calls the N > 1 runs make)
     use_dist = world > 1 or "RANK" in os.environ
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if use_dist:
@@ -204,7 +211,7 @@ def main():
         dt = time.perf_counter() - t0
         if use_dist:
             import torch.distributed as dist
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         timed_steps.launch_ms = handle.timing_filter_launch_ms()

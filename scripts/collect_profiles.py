@@ -39,6 +39,7 @@ cp("sample_bench.json", "%s_sample_bench.json" % tag)
 cp("big_batch.json", "%s_big_batch.json" % tag)
 cp("e2e_run.json", "%s_e2e_run.json" % tag)
 cp("bench_torchrun.json", "%s_bench_torchrun.json" % tag)
+cp("bench_2rank_gloo.json", "%s_bench_2rank_gloo.json" % tag)
 
 # kernel-trace: average duration of the headline launches only (the stats CSV mixes them with the
 # small scans of the region rebuild)

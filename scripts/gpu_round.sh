@@ -12,6 +12,7 @@ echo "== bench"; timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench.js
 echo "== step sampler bench (row f1)"; timeout 600 python scripts/walk_bench.py device > $O/walk_bench.log 2>&1; tail -3 $O/walk_bench.log
 echo "== device sampling bench (row f2)"; timeout 300 python scripts/sample_bench.py > $O/sample_bench.json 2> $O/sample_bench.err; tail -3 $O/sample_bench.err
 echo "== bench via torchrun (1 rank, RCCL init)"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu > $O/bench_torchrun.json 2> $O/bench_torchrun.err; echo "torchrun rc=$?"
+echo "== N = 2 control flow on this one GPU (2 processes, gloo collectives, both pinned to device 0)"; MLF_BENCH_DEVICE=0 MLF_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err; echo "2-rank rc=$?"
 echo "== size check (P = 8e6, N = 2e5)"; timeout 600 python scripts/big_batch_check.py > $O/big_batch.json 2> $O/big_batch.err; tail -4 $O/big_batch.json
 echo "== end-to-end run (eggbox d=2, N=1000, device-resident batches)"; timeout 300 python scripts/e2e_run.py > $O/e2e_run.log 2>&1; tail -1 $O/e2e_run.log | cut -c1-300
 echo "== config bench"; timeout 600 python scripts/config_bench.py > $O/config_bench.json 2> $O/config_bench.err; tail -2 $O/config_bench.err
