@@ -137,3 +137,44 @@ def test_sharded_bootstrap_with_hip_kernels():
     out = mgr.dict()
     mp.spawn(_gpu_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert out[0] == out[1] == (r1, f1), (dict(out), (r1, f1))
+
+
+def _rccl_worker(rank, world_size, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import torch
+    import torch.distributed as dist
+    import ultranest_amd.mlfriends as M
+    from ultranest_amd import distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MLF_FORCE_COLLECTIVES"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", 0))
+    try:
+        u = inputs.live_points(31, 1500, 12)
+        layer = M.AffineLayer()
+        layer.optimize(u, u)
+        region = M.MLFriends(u, layer)
+        out["pair"] = distributed.update_region_bootstrap(region, 30, minvol=0., rng=np.random.RandomState(1234))
+        out["backend"] = dist.get_backend()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_collectives_on_rccl_with_one_rank():
+    """The broadcast of the masks and the MAX all-reduce as RCCL calls on device tensors (one rank: all a 1-GPU box
+    can do), same result as the plain call."""
+    import torch.multiprocessing as mp
+    import ultranest_amd.mlfriends as M
+    u = inputs.live_points(31, 1500, 12)
+    layer = M.AffineLayer()
+    layer.optimize(u, u)
+    region = M.MLFriends(u, layer)
+    want = region.compute_enlargement(nbootstraps=30, rng=np.random.RandomState(1234))
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert out["backend"] == "nccl"
+    assert tuple(out["pair"]) == tuple(want), (dict(out), want)

@@ -30,6 +30,21 @@ def _dist():
     return dist
 
 
+def _forced():
+    """MLF_FORCE_COLLECTIVES=1: issue the broadcast / all-reduce also in a one-rank group (lets a single GPU
+    exercise the RCCL code path; the results are unchanged)."""
+    import os
+    return os.environ.get("MLF_FORCE_COLLECTIVES", "") not in ("", "0")
+
+
+def _initialised():
+    try:
+        dist = _dist()
+    except ImportError:
+        return False
+    return dist.is_available() and dist.is_initialized()
+
+
 def world(group=None):
     """(rank, world_size) of the default/group process group; (0, 1) when not initialised."""
     try:
@@ -61,7 +76,7 @@ def _tensor_device(group=None):
 def broadcast_masks(masks, npoints, nbootstraps, group=None, src=0):
     """Rank `src` provides the (B, N) bool masks; every rank returns the same array."""
     rank, size = world(group)
-    if size == 1:
+    if size == 1 and not (_forced() and _initialised()):
         return masks
     import torch
     dist = _dist()
@@ -78,7 +93,7 @@ def allreduce_max(values, group=None):
     """Element-wise MAX of a small float64 vector over all ranks (RCCL ncclMax on the GPU box)."""
     rank, size = world(group)
     values = np.asarray(values, dtype=np.float64)
-    if size == 1:
+    if size == 1 and not (_forced() and _initialised()):
         return values
     import torch
     dist = _dist()
