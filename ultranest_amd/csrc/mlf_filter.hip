@@ -319,6 +319,14 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
         const unsigned long long hit = anyhit[g] | (anyhit[g] >> 32);
         cm &= ~((hit & 0xffffffffull) | (hit << 32));
       }
+      if (FIRST && cm != 0ull) {   // wave-uniform
+        // a query with a certain hit below this tile cannot get a lower first index here, and its uncertain
+        // pairs in this tile cannot matter either (without this every later tile of an accepted proposal went
+        // through the detail path: first-index batches with many hits ran slower than the exact scan)
+        const int other = __shfl_xor(first[g], 32);
+        const int fb = first[g] < other ? first[g] : other;
+        cm &= ~__ballot(fb < t * 32);
+      }
       candm[g] = cm;
       need |= cm;
     }
