@@ -1,5 +1,9 @@
-"""Latency of MLFriends.inside through the host-pointer API at the batch sizes the stock driver uses."""
+"""Latency of MLFriends.inside through the reference's own API (host numpy in, host mask out) at the batch sizes
+the stock driver and the scalar step samplers use (reference stepsampler.py:296-330, 1060-1071, 1124: 1-10 points
+per call; integrator.py:1854-1855: all N live points every iteration).  Writes profiles/r02_small_batch.json
+when called with --save (run on the MI355X box)."""
 import json
+import os
 import sys
 import time
 
@@ -9,7 +13,7 @@ sys.path.insert(0, ".")
 import ultranest_amd.mlfriends as M  # noqa: E402
 
 out = []
-for (n, d) in [(400, 5), (400, 20), (4000, 50)]:
+for label, (n, d) in [("C1", (400, 5)), ("C2", (2000, 20)), ("C5", (4000, 50))]:
     rs = np.random.RandomState(1)
     u = 0.5 + 0.05 * rs.normal(size=(n, d))
     layer = M.AffineLayer()
@@ -17,13 +21,24 @@ for (n, d) in [(400, 5), (400, 20), (4000, 50)]:
     region = M.MLFriends(u, layer)
     region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=10, rng=rs)
     region.create_ellipsoid()
-    for p in (128, 4096, 65536):
-        pts = rs.uniform(0.3, 0.7, size=(p, d))
+    for p in (1, 10, 128, n, 65536):
+        pts = u[rs.randint(n, size=p)] + 0.01 * rs.normal(size=(p, d))
         region.inside(pts)
+        reps = 200 if p <= 4096 else 30
         t0 = time.perf_counter()
-        reps = 50
         for _ in range(reps):
             m = region.inside(pts)
         dt = (time.perf_counter() - t0) / reps
-        out.append(dict(n=n, d=d, p=p, us_per_call=dt * 1e6, accept=float(m.mean())))
+        # the driver's pattern: one live point replaced in place between calls (integrator.py:2749-2765)
+        t0 = time.perf_counter()
+        for i in range(reps):
+            region.u[i % n] = np.clip(region.u[i % n] + 1e-9, 1e-6, 1 - 1e-6)
+            region.unormed[i % n] = region.transformLayer.transform(region.u[i % n])
+            m = region.inside(pts)
+        dt_upd = (time.perf_counter() - t0) / reps
+        out.append(dict(config=label, n_live=n, d=d, batch=p, us_per_call=dt * 1e6,
+                        us_per_call_with_one_row_replaced=dt_upd * 1e6, accept=float(m.mean())))
         print(json.dumps(out[-1]), flush=True)
+if "--save" in sys.argv:
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(out, open("gpurun_out/r02_small_batch.json", "w"), indent=1)

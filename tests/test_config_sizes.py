@@ -1,0 +1,159 @@
+"""BASELINE.json configurations at their OWN sizes on the MI355X (`-m gpu`), each checked against the CPU
+oracle or against the exact FP64 scan:
+
+  C3  eggbox d = 10 (reference examples/testeggbox.py:9-26), N = 1000 live points, the HIP eggbox kernel as the
+      vectorized likelihood, through the nested-sampling harness with a fixed iteration budget: the run on the
+      HIP region path and the run on the oracle stand-in (same numpy stream) must be the same run
+      (equal-budget comparison, not convergence).
+  C5  sampler leg: 50-d Rosenbrock (examples/testrosenbrock.py:10-16) with PopulationSliceSampler wired as
+      in examples/test_PopSliceSampler.py:103-123, N = 4000 live points: resident device walkers against the
+      oracle's restatement of stepfuncs.pyx, call by call.
+  C5  membership leg: full-size (P = 10^6, N = 4000, d = 50) batches with varied scale / offset / cluster
+      structure and r^2 at the routing edges of the MFMA pre-filter: filtered masks == exact-scan masks.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c3_eggbox_d10_n1000_equal_budget(monkeypatch):
+    from ultranest_amd.harness import StaticNestedSampler
+    from ultranest_amd.likelihoods import eggbox_loglike, eggbox_transform
+    import oracle_backend
+
+    def run():
+        s = StaticNestedSampler(10, eggbox_loglike, transform=eggbox_transform, num_live_points=1000, ndraw=8192, seed=1)
+        res = s.run(dlogz=0.5, max_iters=2500)
+        return res, s.updater.region
+
+    got, region = run()
+    assert got["niter"] == 2500 and got["ncall"] > 3000, got
+    assert region.u.shape == (1000, 10)
+    oracle_backend.install(monkeypatch)      # region kernels -> CPU oracle; the likelihood stays the HIP kernel
+    want, region_o = run()
+    assert got["niter"] == want["niter"] and got["ncall"] == want["ncall"], (got, want)
+    assert got["ncall_region"] == want["ncall_region"] and got["nclusters"] == want["nclusters"], (got, want)
+    assert abs(got["logz"] - want["logz"]) < 1e-9 and abs(got["logzerr"] - want["logzerr"]) < 1e-9, (got, want)
+    assert np.array_equal(region.u, region_o.u)
+    assert region.maxradiussq == region_o.maxradiussq
+    assert abs(region.enlarge - region_o.enlarge) <= 1e-10 * region_o.enlarge
+
+
+def _c5_region(u, nboot=10, seed=2):
+    import ultranest_amd.mlfriends as m
+    layer = m.AffineLayer()
+    layer.optimize(u, u)
+    region = m.MLFriends(u, layer)
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=nboot, rng=np.random.RandomState(seed))
+    region.create_ellipsoid()
+    return region
+
+
+def test_c5_rosenbrock_d50_population_slice_sampler_vs_oracle(monkeypatch):
+    import ultranest_amd.popstepsampler as pop
+    from ultranest_amd import likelihoods
+    import oracle_backend
+    d, nlive, ncalls = 50, 4000, 240
+    rs = np.random.RandomState(31)
+    u = 0.5 + 0.02 * rs.normal(size=(nlive, d))            # around the Rosenbrock ridge after x*20-10: |theta| < ~2
+    region = _c5_region(u)
+    # the vectorized-likelihood callbacks are the HIP kernels behind plain callables (numpy in / numpy out, the
+    # reference's callback surface); without a `device_spec` the sampler fetches the proposals like the reference does
+    def transform(x):
+        return likelihoods.rosenbrock_transform(x)
+
+    def loglike(theta):
+        return likelihoods.rosenbrock_loglike(theta)
+
+    Ls = loglike(transform(u))
+    thresholds = np.sort(Ls)
+
+    def run():
+        np.random.seed(77)
+        sampler = pop.PopulationSliceSampler(popsize=64, nsteps=10, generate_direction=pop.generate_mixture_random_direction,
+                                             scale=1.0)
+        out, nfound = [], 0
+        for _ in range(ncalls):
+            Lmin = thresholds[min(nfound // 2, nlive // 2)]
+            res = sampler.__next__(region, Lmin, u, Ls, transform, loglike)
+            nfound += res[0] is not None
+            out.append(res)
+        return out, sampler.scale, sampler.state(), np.random.uniform()
+
+    got, scale_g, state_g, next_g = run()
+    oracle_backend.install(monkeypatch)
+    want, scale_w, state_w, next_w = run()
+    nfound = 0
+    for it, ((ua, pa, La, nca), (ub, pb, Lb, ncb)) in enumerate(zip(got, want)):
+        assert nca == ncb, it
+        assert (ua is None) == (ub is None), it
+        if ua is not None:
+            nfound += 1
+            assert np.array_equal(ua, ub) and np.array_equal(pa, pb) and La == Lb, it
+    assert nfound >= 20, nfound
+    assert scale_g == scale_w and next_g == next_w
+    assert np.array_equal(state_g["generation"], state_w["generation"])
+    assert np.array_equal(state_g["allL"], state_w["allL"], equal_nan=True)
+    assert np.array_equal(state_g["allu"], state_w["allu"], equal_nan=True)
+
+
+def _ellipsoid_draws(region, z, rad):
+    """set E of SURVEY.md 8d from pre-drawn normals `z` and radial uniforms `rad`"""
+    zz = z / np.linalg.norm(z, axis=1, keepdims=True)
+    zz *= region.enlarge ** 0.5 * rad ** (1.0 / z.shape[1])
+    return region.ellipsoid_center + zz @ region.ellipsoid_axes_T
+
+
+@pytest.fixture(scope="module")
+def fuzz_draws():
+    rs = np.random.RandomState(2024)
+    P, d = 1000000, 50
+    return rs.normal(size=(P, d)), rs.uniform(size=(P, 1))
+
+
+FUZZ_CASES = ["baseline", "tiny-scale", "offset-mixed", "two-clusters", "r2-edge-hi", "r2-edge-lo"]
+
+
+@pytest.mark.parametrize("case", FUZZ_CASES)
+def test_c5_full_size_filter_equals_exact_scan(case, fuzz_draws):
+    from ultranest_amd import _lib
+    z, rad = fuzz_draws
+    P, d = z.shape
+    N = 4000
+    rs = np.random.RandomState(FUZZ_CASES.index(case) + 5)
+    if case == "tiny-scale":
+        u = 0.5 + 1e-4 * rs.normal(size=(N, d)) * np.linspace(0.2, 3.0, d)
+    elif case == "offset-mixed":
+        u = 0.9 + 0.01 * rs.normal(size=(N, d))
+    elif case == "two-clusters":
+        u = np.where(rs.uniform(size=(N, 1)) < 0.5, 0.3, 0.7) + 0.02 * rs.normal(size=(N, d))
+    else:
+        u = 0.5 + 0.05 * rs.normal(size=(N, d))
+    assert np.logical_and(u > 0, u < 1).all()
+    region = _c5_region(u)
+    pts = _ellipsoid_draws(region, z, rad)
+    if case == "offset-mixed":            # a third of the batch are uniform-cube draws: gated out by the ellipsoid
+        pts[::3] = rs.uniform(size=pts[::3].shape)
+    pts[5::1000] = u[rs.randint(N, size=len(pts[5::1000]))]       # exact copies of live points: distance 0
+    amax = np.abs(region.unormed - region.unormed.mean(axis=0)).max()
+    sigma = 2.0 ** -np.ceil(np.log2(amax))
+    r2_list = [region.maxradiussq]
+    if case == "r2-edge-hi":              # sigma^2 r^2 around 4096: the host-side switch between filter and exact scan
+        r2_list = [3600.0 / sigma**2, 4090.0 / sigma**2, 4100.0 / sigma**2]
+    if case == "r2-edge-lo":              # ... and around 1e-30; only the exact copies can hit
+        r2_list = [3e-30 / sigma**2, 0.5e-30 / sigma**2, 1e-26 / sigma**2]
+    for r2 in r2_list:
+        region.maxradiussq = float(r2)
+        got = region.inside(pts)
+        _lib.set_option("filter", 0)
+        try:
+            want = region.inside(pts)
+        finally:
+            _lib.set_option("filter", 1)
+        assert np.array_equal(got, want), (case, r2, int((got != want).sum()))
+        assert got[5::1000].mean() > 0.9, got[5::1000].mean()      # copies of live points: distance exactly 0
+        if case == "two-clusters":
+            assert 0.0 < got.mean() < 1.0, got.mean()
+        if case == "r2-edge-lo":
+            assert got.sum() <= len(pts[5::1000]) + 5, got.sum()
