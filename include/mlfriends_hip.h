@@ -324,6 +324,11 @@ int mlf_region_timing_filter_launch_ms(mlf_region *r, double *ms, int cap, int *
 /* whether a batch of np proposals takes the MFMA pre-filter, and its GEMM shape (K columns per pair,
  * number of 32-row live-point tiles) */
 int mlf_region_filter_info(mlf_region *r, size_t np, int *active, int *kdim, int *ntiles32);
+/* Diagnostic counters of the LAST filtered batch of this region (synchronises the device): out[0] proposals the
+ * binary32 ellipsoid form could not decide (k_ell_exact), out[1] queries whitened in the reference arithmetic for the
+ * exact re-check / exact scan, out[2] uncertain pairs listed by the pre-filter, out[3] largest list segment, out[4]
+ * list segments, out[5] 32-query groups left for the second live-point range.  cap >= 6. */
+int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap);
 /* Measured issue rate of independent v_add_f64/v_mul_f64 (the non-fused FP64 vector rate that
  * bounds the distance kernels), in Tera-instructions*lanes per second (= TFLOP/s, 1 flop each). */
 int mlf_bench_fp64_valu(double *tflops);

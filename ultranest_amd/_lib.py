@@ -99,6 +99,7 @@ SIGNATURES = {
     "mlf_region_timing_filter_launch_ms": [_vp, _vp, ctypes.c_int, _vp],
     "mlf_region_filter_info": [_vp, _sz, _vp, _vp, _vp],
     "mlf_bench_fp64_valu": [_vp],
+    "mlf_region_debug_stats": [_vp, _vp, _int],
 }
 
 _lib = None

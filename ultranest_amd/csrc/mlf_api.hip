@@ -15,6 +15,7 @@
 #include "mlf_misc.hpp"
 #include "mlf_prep2.hpp"
 #include "mlf_prep3.hpp"
+#include "mlf_prep4.hpp"
 #include "mlf_sample.hpp"
 
 namespace {
@@ -51,12 +52,21 @@ struct FilterCtx {
   DevBuf stats, statscratch, refF, qF, tlo, thi, route, best, counters, list, segcnt, gate2;
   // phased sweep: two compacted query sets (ping-pong)
   DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png, pflags, pblk;
+  // bounded per-proposal stage (mlf_prep4.hip): ellipsoid band list, exact-coordinate slots, per-call counters
+  // misc: [0] band proposals, [1] k_ell_exact workgroups done, [2] queries routed to the exact scan, [3] "the exact scan
+  // has work" -- all return to zero by themselves (no memset per batch), zeroed once when the buffer is allocated;
+  // [4] band proposals and [5] exact-coordinate slots of the last batch (mlf_region_debug_stats)
+  DevBuf ell_list, slot, slotq, tqc, misc, uq, ucount;
+  size_t last_nsegs = 0;      // list segments of the last filtered batch
+  bool ell_pending = false;   // band list of the running call not decided yet (the k_mark_exact launch takes it along)
+  EllExactArgs ell_args{};
   // (start, stop) event pairs around every k_filter launch of the timed calls
   std::vector<hipEvent_t> kev;
   size_t kev_used = 0;
   void release() {
     DevBuf *b[] = {&stats, &statscratch, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2,
-                   &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png, &pflags, &pblk};
+                   &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png, &pflags, &pblk,
+                   &ell_list, &slot, &slotq, &tqc, &misc, &uq, &ucount};
     for (DevBuf *x : b) x->release();
     refs_ready = usable = false;
   }
@@ -70,6 +80,7 @@ bool g_filter_fused_compact = true;   // mlf_set_option("filter_fused_compact", 
 int g_filter_phases = 1;              // mlf_set_option("filter_phases", n): 0 single sweep, 1 default phase count, n >= 2 exactly n phases
 long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
 bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
+bool g_prep_bounded = true;           // mlf_set_option("prep_bounded", 0/1): FP32 matrix-core bounded stage (mlf_prep4.hip)
 long long g_filter_min_queries = 2048;  // smaller batches go straight to the exact scan
 
 struct Ctx {
@@ -184,6 +195,14 @@ bool filter_applies(const FilterCtx &f, long long nq, double r2) {
   return sr2 < 4096.0 && sr2 > 1e-30;
 }
 
+// self-resetting counters of the bounded stage: zeroed once, when allocated
+int misc_reserve(FilterCtx &f) {
+  if (f.misc.p) return 0;
+  CK(f.misc.reserve(8 * sizeof(unsigned)));
+  CK(hipMemset(f.misc.p, 0, 8 * sizeof(unsigned)));
+  return 0;
+}
+
 // Device buffers of one filtered batch.
 int filter_reserve(FilterCtx &f, long long nq, unsigned *cap_out) {
   const long long nqpad = (nq + 31) / 32 * 32;
@@ -198,6 +217,8 @@ int filter_reserve(FilterCtx &f, long long nq, unsigned *cap_out) {
   CK(f.list.reserve((size_t)nwaves * cap * sizeof(unsigned long long)));
   CK(f.segcnt.reserve((size_t)nwaves * sizeof(unsigned)));
   CK(f.gate2.reserve((size_t)nq));
+  CK(f.slot.reserve((size_t)nq * sizeof(int)));
+  if (int rc = misc_reserve(f)) return rc;
   *cap_out = cap;
   return 0;
 }
@@ -205,10 +226,18 @@ int filter_reserve(FilterCtx &f, long long nq, unsigned *cap_out) {
 // Filter pipeline on device data: answers for all nq queries in out_mask (bytes) and/or out_idx.
 // Query element (j, k) is q[j*ldq + k*ldk].  quantised = true: the fused k_prep2 has already
 // produced the binary16 fragments, thresholds and routes of this batch.
+// Where the exact whitened coordinates come from when the per-proposal stage did not store them (k_prep4): the
+// proposals themselves and the layer; the queries that need coordinates are whitened after the sweeps.
+struct ExactSrc {
+  const double *pts;
+  const double *lay_ctr;
+  const double *TtF;
+};
+
 int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int npad, int d, int dp,
                const double *q, long long ldq, long long ldk, long long nq, double r2, const uint8_t *gate,
                uint8_t *out_mask, long long *out_idx, hipStream_t s, bool quantised,
-               hipEvent_t ev_after_filter = nullptr) {
+               hipEvent_t ev_after_filter = nullptr, const ExactSrc *xs = nullptr) {
   const long long ngroups = (nq + 31) / 32;
   const long long nqpad = ngroups * 32;
   unsigned cap = 0;
@@ -322,6 +351,59 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     }
   }
   if (ev_after_filter) CK(hipEventRecord(ev_after_filter, s));
+  const int *slot = nullptr;
+  if (xs) {   // exact coordinates of the queries that still need them: uncertain pairs + everything routed to the exact scan
+    const long long nsegs = filter_wave_count(f.ks, ngroups);
+    const unsigned unit_cap = (unsigned)(nphase * (f.ks <= 4 ? 4 : (f.ks <= 8 ? 2 : 1)) * 32);   // queries per filter wave, all phases
+    CK(f.slot.reserve((size_t)nq * sizeof(int)));
+    CK(f.slotq.reserve((size_t)nq * sizeof(int)));
+    CK(f.uq.reserve((size_t)nsegs * unit_cap * sizeof(int)));
+    CK(f.ucount.reserve((size_t)(nsegs + 1) * sizeof(unsigned)));
+    CK(f.tqc.reserve((size_t)nq * d * sizeof(double)));
+    MarkArgs ma{};
+    ma.list = f.list.as<unsigned long long>();
+    ma.seg_cap = cap;
+    ma.seg_count = f.segcnt.as<unsigned>();
+    ma.nsegs = nsegs;
+    ma.nq = nq;
+    ma.nlive = n;
+    ma.route = f.route.as<uint8_t>();
+    ma.best = f.best.as<int>();
+    ma.counters = f.counters.as<unsigned>();
+    ma.slot = f.slot.as<int>();
+    ma.unit_cap = unit_cap;
+    ma.uq = f.uq.as<int>();
+    ma.ucount = f.ucount.as<unsigned>();
+    ma.xq = f.slotq.as<int>();
+    ma.nx = f.misc.as<unsigned>() + 2;
+    ma.scan_flag = f.misc.as<unsigned>() + 3;
+    if (f.ell_pending) {
+      ma.ell = f.ell_args;
+      f.ell_pending = false;
+    }
+    launch_mark_exact(ma, s);
+    CK(hipGetLastError());
+    launch_scan_counts(f.ucount.as<unsigned>(), (int)nsegs, s);
+    WhitenSlotsArgs wa{};
+    wa.pts = xs->pts;
+    wa.d = d;
+    wa.xq = f.slotq.as<int>();
+    wa.nx = f.misc.as<unsigned>() + 2;
+    wa.uq = f.uq.as<int>();
+    wa.ubase = f.ucount.as<unsigned>();
+    wa.nsegs = nsegs;
+    wa.unit_cap = unit_cap;
+    wa.slot = f.slot.as<int>();
+    wa.lay_ctr = xs->lay_ctr;
+    wa.TtF = xs->TtF;
+    wa.out = f.tqc.as<double>();
+    wa.stats_out = f.misc.as<unsigned>() + 5;
+    CK(launch_whiten_slots(wa, nq, s));
+    q = f.tqc.as<double>();
+    ldq = d;
+    ldk = 1;
+    slot = f.slot.as<int>();
+  }
   RecheckArgs ra{};
   ra.list = f.list.as<unsigned long long>();
   ra.seg_cap = cap;
@@ -336,12 +418,14 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   ra.nq = nq;
   ra.r2 = r2;
   ra.best = f.best.as<int>();
+  ra.slot = slot;
+  f.last_nsegs = (size_t)filter_wave_count(f.ks, ngroups);
   launch_recheck(ra, filter_wave_count(f.ks, ngroups), s);
   CK(hipGetLastError());
   // answers of the filtered queries + the gate of the exact scan that follows: (a) queries that do not
   // fit binary16 and (b) every filtered query if the uncertain-pair list overflowed
   launch_filter_finalize(f.route.as<uint8_t>(), f.best.as<int>(), f.counters.as<unsigned>(), nq, out_mask,
-                         out_idx, f.gate2.as<uint8_t>(), s);
+                         out_idx, f.gate2.as<uint8_t>(), s, xs ? f.misc.as<unsigned>() + 2 : nullptr);
   {
     ScanArgs a{};
     a.refT = refT;
@@ -359,6 +443,8 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     a.out_idx = out_idx;
     a.out_mask = out_mask;
     a.only_gated = 1;   // leave the outputs of ungated queries alone
+    a.slot = slot;
+    a.any_flag = xs ? f.misc.as<unsigned>() + 3 : nullptr;
     CK(launch_scan(dp, a, s));
   }
   CK(hipGetLastError());
@@ -437,6 +523,11 @@ struct mlf_region {
   bool chol_ready = false, chol_ok = false;
   double ell_eps_scale = 0.0;
   DevBuf tq, gate, pts, mask, row;
+  // bounded per-proposal stage (mlf_prep4.hip): binary32 fragments, chain start values, error constants
+  DevBuf p4_LtF, p4_TtF, p4_y0;
+  Prep4Consts p4c{};
+  bool p4_ready = false;
+  std::vector<double> h_L, h_lay_ctr, h_ell_ctr;   // host copies: y0 = L^T (c_lay - c_ell) follows the ellipsoid centre
   FilterCtx filter;
   DevBuf gen, gen2, cube, smask, blk, sout, ax_zero, ax_mat;   // device-side sampling
   DevBuf s_invT, s_lo, s_hi, s_thin, s_count, rf_p, rf_L, rf_out, rf_aux;
@@ -446,6 +537,106 @@ struct mlf_region {
 };
 
 namespace {
+
+float f32_up(double x) {
+  float f = (float)x;
+  if ((double)f < x) f = nextafterf(f, INFINITY);
+  return f;
+}
+
+float f32_dn(double x) {
+  float f = (float)x;
+  if ((double)f > x) f = nextafterf(f, -INFINITY);
+  return f;
+}
+
+// k_prep4 subtracts the LAYER centre from every proposal; the ellipsoid form then starts its chain at
+// y0 = L^T (c_lay - c_ell).  Recomputed whenever one of the two centres changes.
+int region_prep4_centres(mlf_region *r, hipStream_t s) {
+  const int d = r->d;
+  const std::vector<double> &L = r->h_L;
+  std::vector<double> s0((size_t)d);
+  double s0n2 = 0.0, y0n2 = 0.0;
+  for (int k = 0; k < d; ++k) {
+    s0[k] = r->h_lay_ctr[k] - r->h_ell_ctr[k];
+    s0n2 += s0[k] * s0[k];
+  }
+  std::vector<float> y0f((size_t)32 * ((r->dp + 31) / 32), 0.0f);
+  for (int i = 0; i < d; ++i) {
+    double y = 0.0;
+    for (int k = i; k < d; ++k) y += L[(size_t)k * d + i] * s0[k];
+    y0n2 += y * y;
+    y0f[i] = (float)y;
+  }
+  if (!std::isfinite(s0n2) || !std::isfinite(y0n2) || std::sqrt(y0n2) > 1e30) {
+    r->p4_ready = false;
+    return 0;
+  }
+  r->p4c.s0n = f32_up(std::sqrt(s0n2) * (1.0 + 1e-12));
+  r->p4c.y0n = f32_up(std::sqrt(y0n2) * (1.0 + 1e-12));
+  if (int rc = upload(r->p4_y0, y0f.data(), y0f.size() * sizeof(float), s)) return rc;
+  CK(hipStreamSynchronize(s));
+  return 0;
+}
+
+// Fragments and error constants of the bounded per-proposal stage.  L: lower Cholesky factor of the ellipsoid matrix,
+// fro2 = |A|_F^2; layer_T / layer_ctr may be null for regions without a neighbour scan.
+int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2, const double *ell_center,
+                       const double *layer_ctr, const double *layer_T, hipStream_t s) {
+  r->p4_ready = false;
+  const int d = r->d, dp = r->dp;
+  if (!prep4_usable(d) || (dp & 1) || dp > 64 || !r->chol_ok || r->has_wrap) return 0;
+  if (r->use_scan && (r->layer_kind != 0 || !layer_T || !layer_ctr)) return 0;
+  double lf2 = 0.0, lmax = 0.0, dmin = INFINITY;
+  for (int i = 0; i < d; ++i)
+    for (int k = 0; k <= i; ++k) {
+      const double v = L[(size_t)i * d + k];
+      lf2 += v * v;
+      lmax = std::fmax(lmax, std::fabs(v));
+      if (k == i) dmin = std::fmin(dmin, v);
+    }
+  if (!std::isfinite(lf2) || !(lmax < 1e30) || !(dmin > 0.0)) return 0;
+  const double g = (dp + 4) * std::ldexp(1.0, -24) * (1.0 + std::ldexp(1.0, -10)) + std::ldexp(1.0, -40);
+  const double lf = std::sqrt(lf2);
+  // share of the proposals near the boundary that the binary32 form cannot decide ~ d g |L|_F / sigma_min(L):
+  // beyond a few per cent the exact kernel behind it would dominate, the binary64 stage (k_prep3) is used instead
+  if (d * g * lf / dmin > 0.02) return 0;
+  r->p4c.g_chain = f32_up(g);
+  r->p4c.lf = f32_up(lf * (1.0 + 1e-12));
+  r->p4c.eps_scale = f32_up(std::ldexp(1.0, -34) * std::sqrt(fro2) * (1.0 + 1e-12));
+  r->p4c.tf = 0.0f;
+  r->h_L = L;
+  r->h_ell_ctr.assign(ell_center, ell_center + d);
+  r->h_lay_ctr.assign(r->use_scan ? layer_ctr : ell_center, (r->use_scan ? layer_ctr : ell_center) + d);
+  std::vector<float> ltf(prep4_ltf_count(dp));
+  prep4_lt_fragments(L.data(), d, dp, ltf.data());
+  if (int rc = upload(r->p4_LtF, ltf.data(), ltf.size() * sizeof(float), s)) return rc;
+  if (r->use_scan) {
+    double tf2 = 0.0, tmax = 0.0, cmin = INFINITY, cmax = 0.0;
+    for (int c = 0; c < d; ++c) {
+      double cn = 0.0;
+      for (int k = 0; k < d; ++k) {
+        const double v = layer_T[(size_t)k * d + c];
+        cn += v * v;
+        tmax = std::fmax(tmax, std::fabs(v));
+      }
+      tf2 += cn;
+      cmin = std::fmin(cmin, cn);
+      cmax = std::fmax(cmax, cn);
+    }
+    if (!std::isfinite(tf2) || !(tmax < 1e30) || !(cmin > 0.0)) return 0;
+    // zeta against the binary16 term of Delta: g sqrt(d) cond(T) < 2^-11, or the uncertainty band of the filter more than
+    // doubles (T = eigenvectors x diag: the column norms are its singular values)
+    if (g * std::sqrt((double)d) * std::sqrt(cmax / cmin) * 2048.0 > 1.0) return 0;
+    r->p4c.tf = f32_up(std::sqrt(tf2) * (1.0 + 1e-12));
+    std::vector<float> ttf(prep4_ttf_count(dp));
+    prep4_t_fragments(layer_T, d, dp, ttf.data());
+    if (int rc = upload(r->p4_TtF, ttf.data(), ttf.size() * sizeof(float), s)) return rc;
+  }
+  CK(hipStreamSynchronize(s));
+  r->p4_ready = true;
+  return region_prep4_centres(r, s);
+}
 
 // whiten `n` cube-space rows already on the device with the region's own layer (same kernels and
 // arithmetic as for proposals, so a live point is at distance exactly 0 from itself)
@@ -481,9 +672,77 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
   // fused stage (coalesced staging, coordinate-major output, optional quantisation) for affine layers
   const bool fused = r->layer_kind == 0 && g_fused_prep && prep2_usable(r->dp) && r->chol_ready;
   long long ldq = r->d, ldk = 1;
-  if (r->use_scan) CK(r->tq.reserve(np * (size_t)r->d * sizeof(double)));
+  const bool bounded = fused && g_prep_bounded && r->p4_ready && !r->has_wrap && (use_filter || !r->use_scan) &&
+                       np < (size_t)0x7fffffff && (reinterpret_cast<uintptr_t>(d_pts) & 15) == 0;   // 16-byte pieces
+  ExactSrc xsrc{};
+  if (r->use_scan && !bounded) CK(r->tq.reserve(np * (size_t)r->d * sizeof(double)));
   if (ev) CK(hipEventRecord(ev[0], s));
-  if (fused && g_prep_matrix && prep3_usable(r->d)) {   // FP64 matrix-core version of the fused stage
+  if (bounded) {   // FP32 matrix cores: bounded ellipsoid test + approximate whitening straight into the filter operand
+    FilterCtx &f = r->filter;
+    if (int rc = misc_reserve(f)) return rc;
+    CK(f.ell_list.reserve(np * sizeof(int)));
+    Prep4Args pa{};
+    pa.pts = d_pts;
+    pa.np = (long long)np;
+    pa.d = r->d;
+    pa.dp = r->dp;
+    pa.LtF = r->p4_LtF.as<float>();
+    pa.y0 = r->p4_y0.as<float>();
+    pa.TtF = r->p4_TtF.as<float>();
+    pa.lay_ctr = r->use_scan ? r->lay_ctr.as<double>() : r->ell_ctr.as<double>();
+    pa.c = r->p4c;
+    pa.c.enl_lo = f32_dn(r->enlarge);
+    pa.c.enl_hi = f32_up(r->enlarge);
+    pa.gate = gate;
+    pa.do_tr = r->use_scan ? 1 : 0;
+    pa.ell_count = f.misc.as<unsigned>();
+    pa.ell_list = f.ell_list.as<int>();
+    pa.ell_cap = (unsigned)np;
+    if (r->use_scan) {
+      unsigned cap = 0;
+      if (int rc = filter_reserve(f, (long long)np, &cap)) return rc;
+      pa.stats = f.stats.as<double>();
+      pa.r2 = r->r2;
+      pa.qF = f.qF.p;
+      pa.tlo = f.tlo.as<float>();
+      pa.thi = f.thi.as<float>();
+      pa.route = f.route.as<uint8_t>();
+      pa.best = f.best.as<int>();
+      pa.slot = f.slot.as<int>();
+      pa.counters = f.counters.as<unsigned>();
+      pa.scan_flag = f.misc.as<unsigned>() + 3;
+      pa.ks = f.ks;
+      pa.nqpad = ((long long)np + 31) / 32 * 32;
+      xsrc.pts = d_pts;
+      xsrc.lay_ctr = r->lay_ctr.as<double>();
+      xsrc.TtF = r->lay_TtF.as<double>();
+    }
+    CK(launch_prep4(pa, s));
+    EllExactArgs ea{};
+    ea.count = f.misc.as<unsigned>();
+    ea.done = f.misc.as<unsigned>() + 1;
+    ea.last = f.misc.as<unsigned>() + 4;
+    ea.list = f.ell_list.as<int>();
+    ea.cap = (unsigned)np;
+    ea.pts = d_pts;
+    ea.d = r->d;
+    ea.dp = r->dp;
+    ea.ell_ctr = r->ell_ctr.as<double>();
+    ea.ell_Lt = r->ell_Lt.as<double>();
+    ea.ell_A = r->ell_A.as<double>();
+    ea.eps_scale = r->ell_eps_scale;
+    ea.enlarge = r->enlarge;
+    ea.chol_ok = r->chol_ok ? 1 : 0;
+    ea.gate = gate;
+    ea.route = r->use_scan ? f.route.as<uint8_t>() : nullptr;
+    if (r->use_scan && !pregate) {   // decided by the tail of the k_mark_exact launch, next to the marking work
+      f.ell_args = ea;
+      f.ell_pending = true;
+    } else {
+      launch_ell_exact(ea, s);
+      CK(hipGetLastError());
+    }
+  } else if (fused && g_prep_matrix && prep3_usable(r->d)) {   // FP64 matrix-core version of the fused stage
     Prep3Args pa{};
     pa.pts = d_pts;
     pa.np = (long long)np;
@@ -607,7 +866,7 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
   if (use_filter) {
     if (int rc = filter_run(r->filter, r->refT.as<double>(), r->refR.as<double>(), r->n, r->npad, r->d, r->dp,
                             r->tq.as<double>(), ldq, ldk, (long long)np, r->r2, gate, d_idx ? nullptr : d_mask,
-                            d_idx, s, fused, ev ? ev[2] : nullptr))
+                            d_idx, s, fused, ev ? ev[2] : nullptr, bounded ? &xsrc : nullptr))
       return rc;
   } else if (r->use_scan) {
     ScanArgs a{};
@@ -711,6 +970,10 @@ int mlf_set_option(const char *name, long long value) {
   }
   if (!strcmp(name, "prep_matrix")) {
     g_prep_matrix = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "prep_bounded")) {
+    g_prep_bounded = value != 0;
     return 0;
   }
   if (!strcmp(name, "filter_min_queries")) {
@@ -1015,7 +1278,7 @@ int mlf_region_create(mlf_region **out) {
 int mlf_region_destroy(mlf_region *r) {
   if (!r) return 0;
   DevBuf *bufs[] = {&r->refT, &r->refR, &r->lay_ctr, &r->lay_mat, &r->lay_T8, &r->ell_Lt, &r->ell_LtF, &r->lay_TtF, &r->wrap, &r->ell_ctr,
-                    &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row,
+                    &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row, &r->p4_LtF, &r->p4_TtF, &r->p4_y0,
                     &r->gen, &r->gen2, &r->cube, &r->smask, &r->blk, &r->sout, &r->ax_zero, &r->ax_mat,
                     &r->s_invT, &r->s_lo, &r->s_hi, &r->s_thin, &r->s_count, &r->rf_p, &r->rf_L, &r->rf_out, &r->rf_aux};
   for (DevBuf *b : bufs) b->release();
@@ -1051,8 +1314,10 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
   const int dp = r->dp;
   if (int rc = prep_consts(r->ell_ctr, r->ell_A, ell_center, ell_invcov, (int)d, dp, false, c.stream))
     return rc;
+  std::vector<double> L((size_t)d * d, 0.0);
+  double fro_sq = 0.0;
   {  // Cholesky factor + Frobenius norm of the ellipsoid matrix for the bounded H3 evaluation (k_prep2)
-    std::vector<double> L((size_t)d * d, 0.0), Lt((size_t)dp * dp, 0.0);
+    std::vector<double> Lt((size_t)dp * dp, 0.0);
     bool ok = true;
     double fro = 0.0;
     for (size_t e = 0; e < d * d; ++e) fro += ell_invcov[e] * ell_invcov[e];
@@ -1080,6 +1345,7 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
     if (ok)
       for (size_t k = 0; k < d; ++k)
         for (size_t j = 0; j < d; ++j) Lt[k * dp + j] = L[j * d + k];
+    fro_sq = fro;
     r->chol_ok = ok && std::isfinite(fro);
     r->ell_eps_scale = std::ldexp(1.0, -34) * std::sqrt(fro);
     if (int rc = upload(r->ell_Lt, Lt.data(), Lt.size() * sizeof(double), c.stream)) return rc;
@@ -1130,6 +1396,7 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
     if (int rc = filter_prepare_refs(r->filter, r->refR.as<double>(), (int)n, (int)d, dp, c.stream, true))
       return rc;
   }
+  if (int rc = region_prep4_setup(r, L, fro_sq, ell_center, layer_ctr, layer_T, c.stream)) return rc;
   CK(hipStreamSynchronize(c.stream));
   r->ready = true;
   return 0;
@@ -1172,6 +1439,11 @@ int mlf_region_set_ellipsoid_center(mlf_region *r, const double *ell_center) {
   std::vector<double> pc = pad_vector(ell_center, r->d, r->dp);
   if (int rc = upload(r->ell_ctr, pc.data(), pc.size() * sizeof(double), c.stream)) return rc;
   CK(hipStreamSynchronize(c.stream));
+  if (r->p4_ready) {
+    r->h_ell_ctr.assign(ell_center, ell_center + r->d);
+    if (!r->use_scan) r->h_lay_ctr = r->h_ell_ctr;   // no layer: the proposals are centred on the ellipsoid itself
+    if (int rc = region_prep4_centres(r, c.stream)) return rc;
+  }
   return 0;
 }
 
@@ -1577,6 +1849,41 @@ int mlf_region_filter_info(mlf_region *r, size_t np, int *active, int *kdim, int
   *active = (r->ready && r->use_scan && filter_applies(r->filter, (long long)np, r->r2)) ? 1 : 0;
   *kdim = r->filter.ks * 16;
   *ntiles32 = r->filter.ntiles32;
+  return 0;
+}
+
+int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap) {
+  // counters of the LAST filtered batch of this region (after a synchronisation): [0] proposals in the binary32
+  // ellipsoid band, [1] queries whitened in the reference arithmetic, [2] uncertain pairs listed, [3] largest list
+  // segment, [4] list segments, [5] 32-query groups left for the second live-point range
+  if (!r || !out || cap < 6) return fail_arg(MLF_E_BADARG, "bad argument");
+  FilterCtx &f = r->filter;
+  for (int i = 0; i < cap; ++i) out[i] = 0;
+  CK(hipDeviceSynchronize());
+  if (f.misc.p) {
+    unsigned m[8];
+    CK(hipMemcpy(m, f.misc.p, sizeof m, hipMemcpyDeviceToHost));
+    out[0] = m[4];
+    out[1] = m[5];
+  }
+  if (f.segcnt.p && f.segcnt.cap >= sizeof(unsigned)) {
+    const size_t n = f.last_nsegs;
+    std::vector<unsigned> c(n);
+    if (n) CK(hipMemcpy(c.data(), f.segcnt.p, n * sizeof(unsigned), hipMemcpyDeviceToHost));
+    unsigned long long sum = 0, mx = 0;
+    for (unsigned v : c) {
+      sum += v;
+      mx = v > mx ? v : mx;
+    }
+    out[2] = sum;
+    out[3] = mx;
+    out[4] = n;
+  }
+  if (f.png.p) {
+    unsigned g[2];
+    CK(hipMemcpy(g, f.png.p, sizeof g, hipMemcpyDeviceToHost));
+    out[5] = g[0];
+  }
   return 0;
 }
 

@@ -40,6 +40,8 @@ struct ScanArgs {
   int mode;
   const uint8_t *gate;            // optional, per query: 0 = do not scan (result: none)
   int only_gated;                 // 1: write outputs only for gated-in queries; idle workgroups exit early
+  const int *slot;                // optional: query j reads row slot[j] of q (negative: no coordinates, never scanned)
+  const unsigned *any_flag;       // optional (device): 0 = no query is gated in, every workgroup returns at once
   long long *out_idx;             // SCAN_FIRST / SCAN_COUNT
   unsigned long long *out_flags;  // SCAN_FLAGS  [nq][ntiles]
   uint8_t *out_mask;              // SCAN_MASK

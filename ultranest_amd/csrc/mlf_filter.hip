@@ -543,17 +543,22 @@ void launch_phase_compact(const PhaseArgs &a, hipStream_t s) {
 // ---------------------------------------------------------------- exact re-check --------------
 // list entry = (query << 32) | live index.  The reference's arithmetic: acc = 0; k ascending:
 // diff = a[k] - b[k]; acc += diff*diff (this file is compiled with -ffp-contract=off).
-__global__ __launch_bounds__(64) void k_recheck(RecheckArgs a) {
+__global__ __launch_bounds__(256) void k_recheck(RecheckArgs a) {
   const unsigned count = a.seg_count[blockIdx.x];
   const unsigned long long *seg = a.list + (size_t)blockIdx.x * a.seg_cap;
-  for (unsigned e = threadIdx.x; e < count; e += 64) {
+  for (unsigned e = threadIdx.x; e < count; e += 256) {
     const unsigned long long ent = seg[e];
     const long long qi = (long long)(ent >> 32);
     const int i = (int)(ent & 0xffffffffu);
     if (i >= a.n || qi >= a.nq) continue;
     if (a.best[qi] <= i) continue;   // a certain hit at a lower (mask mode: any) index settles this query
     const double *ar = a.refR + (size_t)i * a.dp;
-    const double *br = a.q + qi * a.ldq;
+    long long rowq = qi;
+    if (a.slot) {
+      rowq = a.slot[qi];
+      if (rowq < 0) continue;   // cannot happen for a pair that passes the test above (k_mark_exact applies the same one)
+    }
+    const double *br = a.q + rowq * a.ldq;
     const long long ldk = a.ldk > 1 ? a.ldk : 1;
     double acc = 0.0;
 #pragma unroll 10
@@ -569,8 +574,10 @@ __global__ __launch_bounds__(64) void k_recheck(RecheckArgs a) {
 // exact scan kernel.  If the uncertain-pair list overflowed, route 1 answers also come from the
 // exact scan (second launch, gate = overflow), so nothing is written here.
 __global__ void k_filter_finalize(const uint8_t *route, const int *best, const unsigned *counters,
-                                  long long nq, uint8_t *out_mask, long long *out_idx, uint8_t *exact_gate) {
+                                  long long nq, uint8_t *out_mask, long long *out_idx, uint8_t *exact_gate,
+                                  unsigned *reset_word) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p == 0 && reset_word) *reset_word = 0u;   // slot counter of the batch: its readers ran before this launch
   if (p >= nq) return;
   const int rt = route[p];
   const bool to_scan = rt == 2 || (rt == 1 && counters[1] != 0u);
@@ -649,7 +656,7 @@ hipError_t launch_filter(int ks, const FilterArgs &a, bool first, hipStream_t s)
 
 void launch_recheck(const RecheckArgs &a, long long nwaves, hipStream_t s) {
   if (nwaves <= 0) return;
-  hipLaunchKernelGGL(k_recheck, dim3((unsigned)nwaves), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_recheck, dim3((unsigned)nwaves), dim3(256), 0, s, a);
 }
 
 long long filter_wave_count(int ks, long long ngroups) {
@@ -658,10 +665,11 @@ long long filter_wave_count(int ks, long long ngroups) {
 }
 
 void launch_filter_finalize(const uint8_t *route, const int *best, const unsigned *counters, long long nq,
-                            uint8_t *out_mask, long long *out_idx, uint8_t *exact_gate, hipStream_t s) {
+                            uint8_t *out_mask, long long *out_idx, uint8_t *exact_gate, hipStream_t s,
+                            unsigned *reset_word) {
   if (nq <= 0) return;
   hipLaunchKernelGGL(k_filter_finalize, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, route, best,
-                     counters, nq, out_mask, out_idx, exact_gate);
+                     counters, nq, out_mask, out_idx, exact_gate, reset_word);
 }
 
 void launch_route_gate(const uint8_t *route, const unsigned *counters, long long nq, int which,

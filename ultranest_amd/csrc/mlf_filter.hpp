@@ -68,6 +68,7 @@ struct RecheckArgs {
   long long ldq, ldk, nq;   // query element (j, k) at q[j*ldq + k*ldk]
   double r2;
   int *best;
+  const int *slot;       // optional: query qi reads row slot[qi] of q (compact exact coordinates, mlf_prep4.hip)
 };
 
 // scratch: (64 * 128 + 2) doubles, zero-initialised once (the last two words are running maxima, reset by the launch)
@@ -81,7 +82,8 @@ hipError_t launch_filter(int ks, const FilterArgs &a, bool first, hipStream_t s)
 void launch_recheck(const RecheckArgs &a, long long nwaves, hipStream_t s);
 long long filter_wave_count(int ks, long long ngroups);  // waves (= list segments) of a k_filter launch
 void launch_filter_finalize(const uint8_t *route, const int *best, const unsigned *counters, long long nq,
-                            uint8_t *out_mask, long long *out_idx, uint8_t *exact_gate, hipStream_t s);
+                            uint8_t *out_mask, long long *out_idx, uint8_t *exact_gate, hipStream_t s,
+                            unsigned *reset_word = nullptr);
 void launch_route_gate(const uint8_t *route, const unsigned *counters, long long nq, int which,
                        uint8_t *gate, hipStream_t s);
 

@@ -40,7 +40,8 @@ __device__ __forceinline__ bool filter_thresholds(double sigma, double namax, do
   const double sr = sigma * sqrt(r2);
   const double lo = sr * (1.0 - 0x1p-30) - delta;
   const double hi = sr * (1.0 + 0x1p-30) + delta;
-  const double t_lo = lo > 0.0 ? lo * lo - eacc : -1.0;
+  // lo <= 0: no pair may count as a certain hit; -inf and not -1, because a computed Dt can be as low as -eacc
+  const double t_lo = lo > 0.0 ? lo * lo - eacc : -INFINITY;
   const double t_hi = hi * hi + eacc;
   float l = (float)t_lo;
   if ((double)l > t_lo) l = nextafterf(l, -INFINITY);
@@ -49,6 +50,34 @@ __device__ __forceinline__ bool filter_thresholds(double sigma, double namax, do
   *lo_f = l;
   *hi_f = h;
   return t_hi < 30000.0;
+}
+
+// The same thresholds for k_prep4 (mlf_prep4.hip), where the query operand is the binary16 rounding of an APPROXIMATE
+// whitened point bq (binary32 FMA chain) instead of the exact one: |bq - sigma b'| <= zeta.  Everything is evaluated in
+// binary32; every intermediate that must be an upper (lower) bound is multiplied by up = 1 + 2^-18 (dn = 1 - 2^-18),
+// which covers the < 16 roundings of 2^-24 each in front of it (all sums are sums of non-negative terms).
+//   nb    computed |bh|^2 (relative error <= nu = 2^-18, added to Eacc)
+//   zeta  >= |bq - sigma b'|
+//   sr_lo <= sigma sqrt(r2) (1 - 2^-30),  sr_hi >= sigma sqrt(r2) (1 + 2^-30)
+// |bh - sigma b'| <= |bh - bq| + zeta with |bh - bq| <= 2^-11 |bq| + sqrt(K) 2^-25 (binary16 rounding incl. subnormals) and
+// |bq| <= |sigma b'| + zeta, so Delta = 2^-11 (1 + 2^-9)(namax + nbn) + 2 sqrt(K) 2^-24 + 2^-40 (namax + nbn) + (1 + 2^-10) zeta
+// with nbn >= |sigma b'| obtained from |bh|: |sigma b'| <= |bq| + zeta, |bq| <= (|bh| + sqrt(K) 2^-25) / (1 - 2^-11).
+__device__ __forceinline__ bool filter_thresholds4(float namax, float nb, float zeta, float sqrt_k, float sr_lo,
+                                                   float sr_hi, float *lo_f, float *hi_f) {
+  const float up = 1.0f + 0x1p-18f, dn = 1.0f - 0x1p-18f;
+  const float nbh = __builtin_sqrtf(nb) * up;
+  const float nbn = ((nbh + sqrt_k * 0x1p-25f) * (1.0f + 0x1p-10f) + zeta) * up;
+  const float w0 = namax + nbn;
+  const float delta = (0x1p-11f * (1.0f + 0x1p-9f) * w0 + 2.0f * sqrt_k * 0x1p-24f + 0x1p-40f * w0 +
+                       (1.0f + 0x1p-10f) * zeta) * up;
+  const float w = w0 + 0x1p-8f;
+  const float eacc = (0x1p-15f * w * w + 0x1p-22f + 0x1p-18f * nb) * up;
+  const float lo = (sr_lo * dn - delta) * dn;
+  const float hi = (sr_hi * up + delta) * up;
+  *lo_f = lo > 0.0f ? (lo * lo) * dn - eacc * up : -INFINITY;
+  const float t_hi = ((hi * hi) * up + eacc) * up;
+  *hi_f = t_hi;
+  return t_hi < 30000.0f;   // false for NaN
 }
 
 }  // namespace mlf

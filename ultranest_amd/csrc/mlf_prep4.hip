@@ -1,0 +1,692 @@
+// mlf_prep4.hip -- per-proposal stage of MLFriends.inside for AffineLayer-family regions, bounded form:
+//   H3 ellipsoid test (reference mlfriends.pyx:882-912)
+//   T1 whitening      (:737-743)              -- only as accurate as the binary16 pre-filter needs it
+//   + binary16 quantisation and thresholds for the MFMA pre-filter (mlf_filter.hip)
+//
+// k_prep3 whitens every proposal in the reference's binary64 arithmetic and stores the result (400 MB per 10^6 x 50
+// batch) although only the ~10^-4 of the pairs that the pre-filter cannot decide ever read it.  Here both d x d
+// products run on the FP32 matrix cores (v_mfma_f32_32x32x2_f32: bit for bit a k-ascending binary32 FMA chain, one
+// rounding per term), the whitened point goes straight into the filter's binary16 operand fragments, and nothing
+// else is written.  What keeps the results identical to the reference's:
+//   * ellipsoid: q^ = |y^|^2 with y^ ~ L^T (x - c_e) carries a proven error eta (below); proposals with
+//     |sqrt q^ - sqrt enlarge| inside that band go to a list and k_ell_exact decides them in binary64;
+//   * whitening: |bq - sigma (b - c)| <= zeta enters the pre-filter's Delta (filter_thresholds4), so a pair is
+//     "certain" only if it is certain for every point within zeta; the queries of the uncertain pairs are whitened
+//     afterwards in the reference arithmetic (k_mark_exact / k_whiten_slots) for the exact re-check.
+//
+// Error model.  delta_k = fl64(x_k - c_k), dt_k = fl32(delta_k).  A chain s = fma(a_n, b_n, ... fma(a_1, b_1, s_0))
+// of n binary32 terms satisfies |s - (s_0 + sum a_k b_k)| <= gamma_n (|s_0| + sum |a_k b_k|), gamma_n = n u / (1 - n u),
+// u = 2^-24; the operands are roundings of the binary64 matrix entries and of delta (each (1 + e), |e| <= u), the start
+// value is a rounding of a binary64 number.  Together: |y^_i - y_i| <= g (|y0_i| + sum_k |L_ki| |delta_k|) with
+// g = (n + 4) u (1 + 2^-10) + 2^-40 (the last term covers the binary64 roundings on the host), hence in the 2-norm
+//      eta  = g (|y0| + |L|_F |delta|)                      (Cauchy-Schwarz per row)
+//      zeta = g (|sigma c_s| + sigma |T|_F |delta|)
+// |delta| comes from the same dt_k (binary32 sum of squares, relative error <= (n + 2) u).  The reference's own
+// rounding of the quadratic form and the factorisation A = L L^T are covered by eps = 2^-34 |A|_F |x - c_e|^2 exactly
+// as in k_prep3.  The proposal is inside for certain if (sqrt q^ + eta)^2 + eps < enlarge, outside for certain if
+// (sqrt q^ - eta)^2 - eps > enlarge, everything else (NaN / inf included) is decided by k_ell_exact.
+//
+// Layout.  One wave owns a group of 32 proposals = one 32-query group of the filter.  B operand (k x 32 proposals):
+// lane (p = l & 31, h = l >> 5) holds coordinate k = 2 s + h at k-step s.  A operand = 32 matrix rows x 2 k from LDS.
+// C (32 rows x 32 proposals): lane (p, h) holds rows i = (r & 3) + 8 (r >> 2) + 4 h, r = 0..15.  The host orders the
+// rows of T so that row i of tile t is filter column 32 t + 16 (r >> 3) + 8 h + (r & 7): a lane then holds, for
+// filter k-step 2 t + (r >> 3), exactly the 8 consecutive columns of its own fragment piece -- the f16 operand is
+// packed in registers and stored with one contiguous 1 KiB wave store per k-step, no transpose.
+// Rows arrive with coalesced 16-byte loads and are redistributed through a wave-private LDS buffer (odd row stride:
+// conflict-free ds_read_b64).  -ffp-contract=off; FMAs only where written.
+#include "mlf_prep4.hpp"
+
+#include <math.h>
+
+#include <vector>
+
+#include "mlf_filter_dev.hpp"
+#include "mlf_prep3.hpp"
+
+namespace mlf {
+
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef double double4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+namespace {
+
+template <int DP>
+struct P4 {
+  static constexpr int NKS = DP / 2;                    // k-steps of 2 coordinates
+  static constexpr int KS = (DP + 6 + 15) / 16;         // filter k-steps of 16 binary16 columns
+  static constexpr int NT = (KS + 1) / 2;               // 32-row output tiles of the whitening
+  static constexpr int NE = (DP + 31) / 32;             // 32-row output tiles of L^T delta
+  static constexpr int KMIN = DP <= 32 ? DP - 1 : (DP == 50 ? 49 : DP - 3);   // every d served by this instance exceeds KMIN - 1
+  static constexpr int NLT = NKS + (NE > 1 ? NKS - 16 : 0);   // stored k-steps of the L^T fragments
+  static constexpr int NPC = (DP + 3) / 4;              // 1 KiB pieces (64 lanes x 16 bytes) that cover a group of 32 rows
+  static constexpr int WAVE_DOUBLES = NPC * 128 + 64;   // staging buffer per wave: the group's rows as they lie in HBM,
+                                                        // then zeros for the operand columns past d
+  static constexpr size_t lds_bytes() {
+    return (size_t)(NT * NKS * 64 + NLT * 64 + 32 * NE + 32 * NT) * sizeof(float) + (size_t)DP * sizeof(double) +
+           (size_t)4 * WAVE_DOUBLES * sizeof(double);
+  }
+};
+
+// filter column of row i of tile t of the whitening product
+__host__ __device__ inline int p4_column(int t, int i) {
+  return 32 * t + 16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3);
+}
+
+__device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+}  // namespace
+
+template <int DP>
+__global__ __launch_bounds__(256, 2) void k_prep4(Prep4Args a) {
+  using C = P4<DP>;
+  constexpr int NKS = C::NKS, NT = C::NT, NE = C::NE, KS = C::KS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds4[];
+  float *TtF = reinterpret_cast<float *>(lds4);
+  float *LtF = TtF + NT * NKS * 64;
+  float *y0l = LtF + C::NLT * 64;
+  float *csl = y0l + 32 * NE;
+  double *ctrl = reinterpret_cast<double *>(csl + 32 * NT);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int p32 = lane & 31, h = lane >> 5;
+  double *xs = ctrl + DP + wv * C::WAVE_DOUBLES;
+  const int d = a.d;
+  const bool quant = a.do_tr != 0;
+  constexpr float up = 1.0f + 0x1p-18f, dn = 1.0f - 0x1p-18f;
+
+  const double sigma = quant ? a.stats[0] : 1.0;
+  const bool sig_ok = sigma >= 0x1p-60 && sigma <= 0x1p60;   // binary32 scaling of T stays exact
+  const float sig_f = sig_ok ? (float)sigma : 1.0f;
+  if (blockIdx.x == 0 && tid == 0 && a.counters) {
+    a.counters[0] = 0;
+    a.counters[1] = 0;
+    *a.scan_flag = 0u;   // set by k_mark_exact if a query of this batch is routed to the exact scan
+  }
+  if (quant)
+    for (int e = tid; e < NT * NKS * 64; e += 256) TtF[e] = a.TtF[e] * (-2.0f * sig_f);   // power of two: exact
+  for (int e = tid; e < C::NLT * 64; e += 256) LtF[e] = a.LtF[e];
+  if (tid < 32 * NE) y0l[tid] = a.y0[tid];
+  if (tid < 32 * NT) {
+    const int col = p4_column(tid >> 5, tid & 31);
+    csl[tid] = (quant && col < DP) ? 2.0f * (float)(sigma * a.stats[8 + col]) : 0.0f;   // chain = -2 (sigma t - sigma c_s)
+  }
+  if (tid < DP) ctrl[tid] = tid < d ? a.lay_ctr[tid] : 0.0;
+  for (int e = lane; e < C::WAVE_DOUBLES; e += 64) xs[e] = 0.0;   // the padding columns stay zero for good
+  __syncthreads();
+
+  // uniform per-kernel quantities of the thresholds (binary32, rounded outward)
+  float namax = 0.0f, zeta_scale = 0.0f, zeta0 = 0.0f, sr_lo = 0.0f, sr_hi = 0.0f;
+  const float sqrt_k = __builtin_sqrtf((float)(16 * KS));
+  if (quant) {
+    namax = (float)a.stats[1] * up;
+    float cs2 = 0.0f;
+    for (int e = 0; e < 32 * NT; ++e) cs2 = __builtin_fmaf(csl[e], csl[e], cs2);
+    const float csn = 0.5f * __builtin_sqrtf(cs2) * up;
+    zeta_scale = a.c.g_chain * (sig_f * a.c.tf) * up;
+    zeta0 = a.c.g_chain * csn * up + 0x1p-100f;
+    const double sr = sigma * sqrt(a.r2);
+    sr_lo = (float)(sr * (1.0 - 0x1p-30)) * dn;
+    sr_hi = (float)(sr * (1.0 + 0x1p-30)) * up;
+  }
+
+  const long long ngroups = quant ? a.nqpad / 32 : (a.np + 31) / 32;
+  const long long wave_id = (long long)blockIdx.x * 4 + wv;
+  const long long nwaves = (long long)gridDim.x * 4;
+  const long long total = a.np * (long long)d;
+
+  // A group of 32 rows is 32 d contiguous doubles; it is copied as it lies, in 16-byte pieces, straight into the
+  // wave's LDS buffer (global_load_lds: no staging registers).  Lanes past the group / past the batch stay out; what
+  // they would have written keeps its old contents (finite or not, those rows are never live).
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+  auto fetch_group = [&](long long grp) {
+    const long long base = grp * 32 * (long long)d;
+    if (base + 128 * C::NPC <= total) {   // wave-uniform: the whole 1 KiB-granular window lies inside the batch
+#pragma unroll
+      for (int i = 0; i < C::NPC; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t *)(a.pts + base + 2 * (lane + 64 * i)),
+                                         (lptr_t *)(reinterpret_cast<char *>(xs) + i * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::NPC; ++i) {
+        const int e = lane + 64 * i;
+        const long long g = base + 2 * e;
+        if (e < 16 * d && g + 1 < total)
+          __builtin_amdgcn_global_load_lds((gptr_t *)(a.pts + g), (lptr_t *)(reinterpret_cast<char *>(xs) + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // operands of the staged group: lane (p, h) takes coordinates 2 s + h of row p, centred and rounded to binary32;
+  // returns the lane's part of |dt|^2.  Coordinates past d: the centre table holds NaN there -> 0.
+  auto operands = [&](float *dt) {
+    float dn2 = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      const int k = 2 * s + h;
+      const double xv = xs[p32 * d + k] - ctrl[k];
+      const double dl = (2 * s + 1 < C::KMIN || k < d) ? xv : 0.0;
+      dt[s] = (float)dl;
+      dn2 = __builtin_fmaf(dt[s], dt[s], dn2);
+    }
+    return dn2;
+  };
+
+  // Software pipeline over the wave's groups: while the matrix cores work on group g (operands dta, in registers), the
+  // same basic block converts group g + 1 and packs the binary16 operand of group g, so that the vector work sits in
+  // the shadow of the 64-cycle MFMAs; the rows of group g + 2 are in flight towards LDS meanwhile.
+  float dta[NKS];
+  float dn2a = 0.0f;
+  if (wave_id < ngroups) {
+    fetch_group(wave_id);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    dn2a = operands(dta);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next group overwrites the rows
+    __builtin_amdgcn_wave_barrier();
+    fetch_group(wave_id + nwaves);
+  }
+  uint4 *qdst = reinterpret_cast<uint4 *>(a.qF);
+  for (long long grp = wave_id; grp < ngroups; grp += nwaves) {
+    const long long p = grp * 32 + p32;
+    const bool live = p < a.np;
+
+    // ---- section 1: y^ = y0 + L^T delta (group g) on the matrix cores || operands of group g + 1 on the vector unit
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows of group g + 1 have landed
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    float dtb[NKS];
+    float dn2b = 0.0f;
+    float16v ye[NE];
+#pragma unroll
+    for (int t = 0; t < NE; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ye[t][r] = y0l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+#pragma unroll
+      for (int t = 0; t < NE; ++t)
+        if (s >= 16 * t)   // L^T is upper triangular: rows 32 t.. have no entries left of column 32 t
+          ye[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(LtF[((t ? NKS : 0) + s - 16 * t) * 64 + lane], dta[s], ye[t], 0, 0, 0);
+      const int k = 2 * s + h;
+      const double xv = xs[p32 * d + k] - ctrl[k];   // unconditional read (a conditional one becomes a branch)
+      const double dl = (2 * s + 1 < C::KMIN || k < d) ? xv : 0.0;
+      dtb[s] = (float)dl;
+      dn2b = __builtin_fmaf(dtb[s], dtb[s], dn2b);
+    }
+    // issue order: per k-step the matrix instruction(s), the LDS reads of a later step, three vector instructions
+#pragma unroll
+    for (int s = 0; s < (NE > 1 ? 16 : NKS); ++s) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+    }
+    if constexpr (NE > 1) {
+#pragma unroll
+      for (int s = 16; s < NKS; ++s) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operands(g + 1) have left the LDS buffer ...
+    __builtin_amdgcn_wave_barrier();
+    fetch_group(grp + 2 * nwaves);                       // ... group g + 2 goes into flight
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- section 2: -2 bq = -2 (sigma T^T delta - sigma c_s), tile by tile || the ellipsoid decision, then the
+    // binary16 packing of the tile before
+    float16v tt[NT];
+    unsigned pk[NT * 8];
+    float nbq = 0.0f;
+    auto pack_tile = [&](int t) {   // columns -2 bh of one tile, and its share of 4 |bh|^2
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const float2v v = {tt[t][2 * m], tt[t][2 * m + 1]};
+        union { half2v v; unsigned u; } cv;
+        cv.v = __builtin_convertvector(v, half2v);
+        const float f0 = (float)cv.v[0], f1 = (float)cv.v[1];
+        nbq = __builtin_fmaf(f0, f0, nbq);
+        nbq = __builtin_fmaf(f1, f1, nbq);
+        pk[t * 8 + m] = cv.u;
+      }
+    };
+    if (quant) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tt[0][r] = csl[(r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) tt[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(TtF[s * 64 + lane], dta[s], tt[0], 0, 0, 0);
+    }
+    float qs = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NE; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qs = __builtin_fmaf(ye[t][r], ye[t][r], qs);
+    qs = half_sum(qs);
+    const float dn2 = half_sum(dn2a);
+
+    bool sure_in = false, sure_out = false;
+    float dnorm = 0.0f;
+    {
+      const bool finite = qs < 3.0e38f && dn2 < 3.0e38f;   // false for NaN
+      const float sq = __builtin_sqrtf(qs);
+      dnorm = __builtin_sqrtf(dn2) * up + 0x1p-100f;
+      const float eta = a.c.g_chain * (a.c.y0n + a.c.lf * dnorm) * up;
+      const float de = dnorm + a.c.s0n;
+      const float eps = a.c.eps_scale * (de * de) * up;
+      const float hi = sq * up + eta;
+      const float qhi = ((hi * hi) * up + eps) * up;
+      const float lo = (sq * dn - eta) * dn;
+      const float qlo = ((lo * lo) * dn - eps * up) * dn;
+      sure_in = finite && qhi < a.c.enl_lo;
+      sure_out = finite && lo > 0.0f && qlo > a.c.enl_hi;
+    }
+    if (quant) {
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {   // one matrix instruction, then up to four vector instructions of the decision
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 1; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tt[t][r] = csl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+        for (int s = 0; s < NKS; ++s)
+          tt[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(TtF[(t * NKS + s) * 64 + lane], dta[s], tt[t], 0, 0, 0);
+        pack_tile(t - 1);
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      pack_tile(NT - 1);
+    }
+    const bool band = live && !sure_in && !sure_out;
+    const bool ins_any = live && !sure_out;   // band proposals: provisionally inside, k_ell_exact has the last word
+    {
+      const unsigned long long bm = __ballot(band && h == 0);
+      if (bm != 0ull) {   // wave-uniform, rare
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(a.ell_count, (unsigned)__popcll(bm));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (band && h == 0) {
+          const unsigned slot = base + (unsigned)__popcll(bm & ((1ull << lane) - 1ull));
+          if (slot < a.ell_cap) a.ell_list[slot] = (int)p;
+        }
+      }
+    }
+    if (live && h == 0) a.gate[p] = ins_any ? 1 : 0;
+
+    if (quant) {
+      const float nb = 0.25f * half_sum(nbq);   // |bh|^2
+      int rt = ins_any ? 1 : 0;
+      if (rt == 1 && (!sig_ok || !(nb <= 29000.0f))) rt = 2;   // NaN / inf / does not fit binary16: exact scan
+      float lo_f = -1.0f, hi_f = -1.0f;
+      if (rt == 1) {
+        const float zeta = (zeta_scale * dnorm + zeta0) * up;
+        if (!filter_thresholds4(namax, nb, zeta, sqrt_k, sr_lo, sr_hi, &lo_f, &hi_f)) {
+          rt = 2;
+          lo_f = hi_f = -1.0f;
+        }
+      }
+      // three pieces of |bh|^2 (x ones column of the live point) behind three ones (x its |ah|^2 pieces)
+      const _Float16 p1 = (_Float16)nb;
+      const float r1 = nb - (float)p1;
+      const _Float16 p2 = (_Float16)r1;
+      const float r2 = r1 - (float)p2;
+      const _Float16 p3 = (_Float16)r2;
+      const _Float16 one = (_Float16)1.0f;
+      union { half2v v; unsigned u; } sp[3];
+      sp[0].v = (half2v){one, one};
+      sp[1].v = (half2v){one, p1};
+      sp[2].v = (half2v){p2, p3};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int c = DP + 2 * q;   // compile-time after unrolling
+        if (h == ((c >> 3) & 1)) pk[4 * (c >> 4) + ((c & 7) >> 1)] = sp[q].u;
+      }
+      const bool keep = rt == 1;   // otherwise every operand column of this query is zero
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        qdst[((size_t)grp * KS + s) * 64 + lane] = make_uint4(keep ? pk[4 * s] : 0u, keep ? pk[4 * s + 1] : 0u,
+                                                              keep ? pk[4 * s + 2] : 0u, keep ? pk[4 * s + 3] : 0u);
+      if (h == 0) {
+        a.tlo[p] = lo_f;
+        a.thi[p] = hi_f;
+        if (live) {
+          a.route[p] = (uint8_t)rt;
+          a.best[p] = kNone;
+          a.slot[p] = -1;
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) dta[s] = dtb[s];
+    dn2a = dn2b;
+  }
+}
+
+// ---------------------------------------------------------------- host helpers -----------------
+bool prep4_usable(int d) { return d >= 1 && d <= 64; }
+
+static int p4_nt(int dp) { return (((dp + 6 + 15) / 16) + 1) / 2; }
+static int p4_ne(int dp) { return (dp + 31) / 32; }
+
+size_t prep4_ltf_count(int dp) {
+  const int nks = dp / 2;
+  return (size_t)(nks + (p4_ne(dp) > 1 ? nks - 16 : 0)) * 64;
+}
+
+size_t prep4_ttf_count(int dp) { return (size_t)p4_nt(dp) * (dp / 2) * 64; }
+
+void prep4_lt_fragments(const double *L, int d, int dp, float *out) {
+  const int nks = dp / 2, ne = p4_ne(dp);
+  size_t f = 0;
+  for (int t = 0; t < ne; ++t)
+    for (int s = 16 * t; s < nks; ++s, ++f)
+      for (int l = 0; l < 64; ++l) {
+        const int row = 32 * t + (l & 31), k = 2 * s + (l >> 5);
+        out[f * 64 + l] = (row < d && k < d) ? (float)L[(size_t)k * d + row] : 0.0f;   // (L^T)[row][k]
+      }
+}
+
+void prep4_t_fragments(const double *T, int d, int dp, float *out) {
+  const int nks = dp / 2, nt = p4_nt(dp);
+  for (int t = 0; t < nt; ++t)
+    for (int s = 0; s < nks; ++s)
+      for (int l = 0; l < 64; ++l) {
+        const int col = p4_column(t, l & 31), k = 2 * s + (l >> 5);
+        out[((size_t)t * nks + s) * 64 + l] = (col < d && k < d) ? (float)T[(size_t)k * d + col] : 0.0f;
+      }
+}
+
+hipError_t launch_prep4(const Prep4Args &a, hipStream_t s) {
+  if (a.np <= 0) return hipSuccess;
+  if (!prep4_usable(a.d) || a.dp < a.d || (a.dp & 1)) return hipErrorInvalidValue;
+  const long long groups = a.do_tr ? a.nqpad / 32 : (a.np + 31) / 32;
+  switch (a.dp) {
+#define X(D)                                                                                                     \
+  case D: {                                                                                                      \
+    constexpr size_t lds = P4<D>::lds_bytes();                                                                   \
+    static bool attr_set = false;                                                                                \
+    if (!attr_set) {                                                                                             \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep4<D>),                            \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+      if (e != hipSuccess) return e;                                                                             \
+      attr_set = true;                                                                                           \
+    }                                                                                                            \
+    if (a.do_tr && a.ks != P4<D>::KS) return hipErrorInvalidValue;                                               \
+    const long long per_cu = (160 * 1024) / (long long)lds >= 2 ? 2 : 1;                                         \
+    long long grid = (groups + 3) / 4;                                                                           \
+    if (grid > 256 * per_cu) grid = 256 * per_cu;                                                                \
+    hipLaunchKernelGGL((k_prep4<D>), dim3((unsigned)grid), dim3(256), lds, s, a);                                \
+    break;                                                                                                       \
+  }
+    MLF_FOR_EACH_DP_PREP4(X)
+#undef X
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- exact ellipsoid test ----------
+// One wave per listed proposal.  Tier 1: qt = |L^T delta|^2 in binary64 with the band eps = 2^-34 |A|_F |delta|^2 of
+// k_prep3 (the factor and the wave's delta sit in LDS); tier 2 (inside that band, practically never): the reference's
+// arithmetic -- one accumulator, j outer, (d_j * A_jk) * d_k, no FMA.  The last workgroup to finish resets the list
+// counter for the next batch (every workgroup has read it by then).  `blk` / `nblk`: this workgroup's index within
+// the workgroups that run this body (it is also a tail of the k_mark_exact launch).
+__device__ __forceinline__ void ell_exact_body(const EllExactArgs &a, double *ltl, unsigned blk, unsigned nblk) {
+  const unsigned count = *a.count < a.cap ? *a.count : a.cap;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned wave = blk * 4 + wv, nwaves = nblk * 4;
+  const int d = a.d;
+  const int ls = d | 1;
+  double *dls = ltl + (size_t)d * ls + wv * 64;   // this wave's delta
+  if (count != 0u) {   // uniform over the workgroups
+    for (int e = threadIdx.x; e < d * d; e += 256) {
+      const int k = e / d, j = e - k * d;
+      ltl[k * ls + j] = a.ell_Lt[(size_t)k * a.dp + j];
+    }
+    __syncthreads();
+  }
+  for (unsigned e = wave; e < count; e += nwaves) {
+    const long long p = a.list[e];
+    const double *row = a.pts + p * (long long)d;
+    const bool own = lane < d;
+    const double dl = own ? row[lane] - a.ell_ctr[lane] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    dls[lane] = dl;
+    __builtin_amdgcn_wave_barrier();
+    const double *lrow = ltl + (own ? lane : 0) * ls;
+    double y = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < d; ++j) y = __builtin_fma((own && j >= lane) ? lrow[j] : 0.0, dls[j], y);
+    double qt = y * y, nrm2 = dl * dl;
+    for (int o = 32; o > 0; o >>= 1) {
+      qt += __shfl_xor(qt, o, 64);
+      nrm2 += __shfl_xor(nrm2, o, 64);
+    }
+    const double eps = a.eps_scale * nrm2;
+    bool inside;
+    if (a.chol_ok && qt + eps < a.enlarge) {
+      inside = true;
+    } else if (a.chol_ok && qt - eps > a.enlarge) {
+      inside = false;
+    } else {
+      double acc = 0.0;
+      if (lane == 0) {
+        for (int j = 0; j < d; ++j) {
+          const double dj = row[j] - a.ell_ctr[j];
+          const double *arow = a.ell_A + (size_t)j * a.dp;
+          for (int k = 0; k < d; ++k) acc += (dj * arow[k]) * (row[k] - a.ell_ctr[k]);
+        }
+      }
+      acc = __shfl(acc, 0, 64);
+      inside = acc <= a.enlarge;
+    }
+    if (!inside && lane == 0) {
+      a.gate[p] = 0;
+      if (a.route) a.route[p] = 0;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(a.done, 1u);
+    if (t == nblk - 1u) {
+      if (a.last) *a.last = *a.count;   // kept for mlf_region_debug_stats
+      *a.count = 0u;
+      *a.done = 0u;
+    }
+  }
+}
+
+static size_t ell_exact_lds(int d) { return ((size_t)d * (d | 1) + 4 * 64) * sizeof(double); }
+constexpr unsigned kEllBlocks = 128;
+
+__global__ __launch_bounds__(256) void k_ell_exact(EllExactArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double ltl[];
+  ell_exact_body(a, ltl, blockIdx.x, gridDim.x);
+}
+
+void launch_ell_exact(const EllExactArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(k_ell_exact, dim3(kEllBlocks), dim3(256), ell_exact_lds(a.d), s, a);
+}
+
+// ---------------------------------------------------------------- which queries need exact coordinates
+// Queries of uncertain pairs: one wave per list segment.  A segment holds the pairs of at most unit_cap distinct
+// queries (the filter waves that wrote it own QW x 32 queries per phase), so the claimed queries of a segment get
+// ranks 0.. in the segment's own window of `uq` -- no shared counter (one counter for all waves serialises at ~90 M
+// atomics/s: 80 us per batch in the first version of this kernel).  First claimant of a query wins (CAS on its slot
+// word; a query can sit in the segments of two phases).  An exclusive scan over the per-segment counts then gives the
+// dense numbering (k_whiten_slots).  Four entries per lane are in flight per step.
+__device__ __forceinline__ void mark_segment(const MarkArgs &a, long long seg, int lane) {
+  const unsigned count = a.seg_count[seg];
+  const unsigned long long *sg = a.list + (size_t)seg * a.seg_cap;
+  int *win = a.uq + (size_t)seg * a.unit_cap;
+  unsigned nwin = 0;
+  for (unsigned e0 = 0; e0 < count; e0 += 256) {   // wave-uniform trip count
+    unsigned long long ent[4];
+    bool want[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned e = e0 + 64 * j + (unsigned)lane;
+      want[j] = e < count;
+      ent[j] = want[j] ? sg[e] : 0ull;
+    }
+    int bst[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long qi = (long long)(ent[j] >> 32);
+      const int i = (int)(ent[j] & 0xffffffffu);
+      want[j] = want[j] && i < a.nlive && qi < a.nq;
+      bst[j] = want[j] ? a.best[qi] : 0;
+    }
+    bool won[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long qi = (long long)(ent[j] >> 32);
+      const int i = (int)(ent[j] & 0xffffffffu);
+      // a certain hit at or below i settles the pair (k_recheck skips it for the same reason)
+      won[j] = want[j] && bst[j] > i && atomicCAS(&a.slot[qi], -1, -2) == -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned long long wm = __ballot(won[j]);
+      if (won[j]) {
+        const unsigned r = nwin + (unsigned)__popcll(wm & ((1ull << lane) - 1ull));
+        if (r < a.unit_cap) win[r] = (int)(ent[j] >> 32);
+      }
+      nwin += (unsigned)__popcll(wm);
+    }
+  }
+  if (lane == 0) a.ucount[seg] = nwin < a.unit_cap ? nwin : a.unit_cap;
+}
+
+// blocks [0, segblocks): the list segments; [segblocks, segblocks + qblocks): one thread per query -- everything routed
+// to the exact scan (rare: these take slots from a shared counter, and raise the flag that wakes the scan launch up);
+// the last kEllBlocks blocks (if a.ell.count): the exact ellipsoid test of the band proposals, which only has to be
+// complete before the finalise kernel
+__global__ __launch_bounds__(256) void k_mark_exact(MarkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double ltl[];
+  const long long segblocks = (a.nsegs + 3) / 4, qblocks = (a.nq + 255) / 256;
+  const int lane = threadIdx.x & 63;
+  const long long b = blockIdx.x;
+  if (b < segblocks) {
+    const long long seg = b * 4 + (threadIdx.x >> 6);
+    if (seg < a.nsegs) mark_segment(a, seg, lane);
+  } else if (b < segblocks + qblocks) {
+    const long long p = (b - segblocks) * 256 + threadIdx.x;
+    bool want = false;
+    if (p < a.nq) {
+      const int rt = a.route[p];
+      want = rt == 2 || (rt == 1 && a.counters[1] != 0u);
+    }
+    const bool won = want && atomicCAS(&a.slot[p], -1, -2) == -1;
+    const unsigned long long wm = __ballot(won);
+    if (wm != 0ull) {   // rare
+      unsigned base = 0;
+      if (lane == 0) {
+        *a.scan_flag = 1u;
+        base = atomicAdd(a.nx, (unsigned)__popcll(wm));
+      }
+      base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+      if (won) a.xq[base + (unsigned)__popcll(wm & ((1ull << lane) - 1ull))] = (int)p;
+    } else if (__any(want) && lane == 0) {
+      *a.scan_flag = 1u;
+    }
+  } else {
+    ell_exact_body(a.ell, ltl, (unsigned)(b - segblocks - qblocks), kEllBlocks);
+  }
+}
+
+void launch_mark_exact(const MarkArgs &a, hipStream_t s) {
+  const long long blocks = (a.nsegs + 3) / 4 + (a.nq + 255) / 256 + (a.ell.count ? kEllBlocks : 0);
+  if (blocks <= 0) return;
+  hipLaunchKernelGGL(k_mark_exact, dim3((unsigned)blocks), dim3(256), a.ell.count ? ell_exact_lds(a.ell.d) : 0, s, a);
+}
+
+// ---------------------------------------------------------------- exact whitening of the slots --
+// Dense numbering of the claimed queries: [0, nx) the exact-scan queries (xq), then the segments' winners in segment
+// order (ubase = exclusive scan of ucount, total at ubase[nsegs]).  The arithmetic is k_prep3's whitening (and
+// k_prep's, which whitens the live points): delta_k = x_k - c_k, then a k-ascending FMA chain per output on
+// v_mfma_f64_16x16x4_f64.  Tile = 16 slots; lane (pl = l & 15, kq = l >> 4) holds coordinate 4 ks + kq of slot pl;
+// results: rows kq + 4 r of every 16-row block.  The lane that resolves a slot also publishes slot[q].
+template <int NK>
+__global__ __launch_bounds__(256) void k_whiten_slots(WhitenSlotsArgs a) {
+  constexpr int NC = (NK + 3) / 4;
+  const unsigned nx = *a.nx;
+  const unsigned n = nx + a.ubase[a.nsegs];
+  const unsigned tiles = (n + 15u) / 16u;
+  const int lane = threadIdx.x & 63, pl = lane & 15, kq = lane >> 4;
+  const int d = a.d;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.stats_out[0] = n;   // kept for mlf_region_debug_stats
+  for (unsigned tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < tiles; tile += gridDim.x * 4) {
+    const unsigned sl = tile * 16 + pl;
+    const bool valid = sl < n;
+    long long q = 0;
+    if (valid) {
+      if (sl < nx) {
+        q = a.xq[sl];
+      } else {   // largest segment u with ubase[u] <= j
+        const unsigned j = sl - nx;
+        long long lo = 0, hi = a.nsegs - 1;
+        while (lo < hi) {
+          const long long mid = (lo + hi + 1) >> 1;
+          if (a.ubase[mid] <= j) lo = mid; else hi = mid - 1;
+        }
+        q = a.uq[(size_t)lo * a.unit_cap + (j - a.ubase[lo])];
+      }
+      if (kq == 0) a.slot[q] = (int)sl;
+    }
+    const double *row = a.pts + q * (long long)d;
+    double dw[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const int k = 4 * ks + kq;
+      dw[ks] = k < d ? row[k] - a.lay_ctr[k] : 0.0;
+    }
+    double4v t[NC];
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) t[ct] = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct)
+        t[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.TtF[((size_t)ct * NK + ks) * 64 + lane], dw[ks], t[ct], 0, 0, 0);
+    if (valid) {
+      double *o = a.out + (size_t)sl * d;
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * ct + kq + 4 * r;
+          if (c < d) o[c] = t[ct][r];
+        }
+    }
+  }
+}
+
+hipError_t launch_whiten_slots(const WhitenSlotsArgs &a, long long max_slots, hipStream_t s) {
+  if (max_slots <= 0) return hipSuccess;
+  long long grid = (max_slots + 63) / 64;
+  if (grid > 1024) grid = 1024;
+  switch (prep3_ksteps(a.d)) {
+#define W(NKV)                                                                              \
+  case NKV:                                                                                 \
+    hipLaunchKernelGGL((k_whiten_slots<NKV>), dim3((unsigned)grid), dim3(256), 0, s, a);    \
+    break;
+    W(1) W(2) W(3) W(4) W(5) W(6) W(8) W(10) W(13) W(16)
+#undef W
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace mlf

@@ -29,17 +29,22 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const long long q0 = (long long)blockIdx.x * kScanQB;
+  __shared__ int any_active;
+  if (a.any_flag && *a.any_flag == 0u) return;   // device-side "nothing was routed to the exact scan"
+  const long long nqblk = (a.nq + kScanQB - 1) / kScanQB;
+  // one workgroup per query block; the gated second-stage launch is a bounded grid that strides over the blocks
+  for (long long qblk = blockIdx.x; qblk < nqblk; qblk += gridDim.x) {
+  const long long q0 = qblk * kScanQB;
   const long long left = a.nq - q0;
   const int nqb = left < kScanQB ? (int)left : kScanQB;
 
   if (a.only_gated) {  // second-stage use behind the MFMA filter: usually nothing to do
-    __shared__ int any_active;
+    __syncthreads();
     if (tid == 0) any_active = 0;
     __syncthreads();
     if (tid < nqb && a.gate[q0 + tid] != 0) any_active = 1;
     __syncthreads();
-    if (!any_active) return;
+    if (!any_active) continue;
   }
 
   // stage this workgroup's queries, zero padded to DP
@@ -48,7 +53,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
       const int qq = e / DP;
       const int k = e - qq * DP;
       double v = 0.0;
-      if (qq < nqb && k < a.d) v = a.q[(q0 + qq) * a.ldq + k];
+      if (qq < nqb && k < a.d) {
+        const long long row = a.slot ? (long long)a.slot[q0 + qq] : q0 + qq;
+        if (row >= 0) v = a.q[row * a.ldq + k];
+      }
       qs[e] = v;
     }
   } else {  // coordinate-major source: consecutive threads read consecutive queries
@@ -56,12 +64,16 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
       const int k = e / kScanQB;
       const int qq = e - k * kScanQB;
       double v = 0.0;
-      if (qq < nqb && k < a.d) v = a.q[(q0 + qq) * a.ldq + (long long)k * a.ldk];
+      if (qq < nqb && k < a.d) {
+        const long long row = a.slot ? (long long)a.slot[q0 + qq] : q0 + qq;
+        if (row >= 0) v = a.q[row * a.ldq + (long long)k * a.ldk];
+      }
       qs[qq * DP + k] = v;
     }
   }
   if (tid < kScanQB) {
-    const bool active = tid < nqb && (a.gate == nullptr || a.gate[q0 + tid] != 0);
+    const bool active = tid < nqb && (a.gate == nullptr || a.gate[q0 + tid] != 0) &&
+                        (a.slot == nullptr || a.slot[q0 + tid] >= 0);
     state[tid] = active ? kNone : -1;
     cnt[tid] = 0;
   }
@@ -115,13 +127,16 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     else if (mode == SCAN_MASK)
       a.out_mask[q0 + tid] = found ? 1 : 0;
   }
+  __syncthreads();   // the staged queries / states are reused by the next block of this workgroup
+  }
 }
 
 hipError_t launch_scan(int dp, const ScanArgs &a, hipStream_t s) {
   if (a.nq <= 0) return hipSuccess;
   const bool small = a.nq <= 16384;
   const int qb = small ? 16 : kScanQB;
-  const unsigned grid = (unsigned)((a.nq + qb - 1) / qb);
+  unsigned grid = (unsigned)((a.nq + qb - 1) / qb);
+  if (a.only_gated && grid > 2048u) grid = 2048u;   // mostly idle: keep the dispatch short
   switch (dp) {
 #define X(D)                                                                          \
   case D:                                                                             \

@@ -285,6 +285,13 @@ class DeviceRegion(object):
         check(_lib.lib().mlf_region_filter_info(self._h, int(npts), ctypes.byref(act), ctypes.byref(k), ctypes.byref(t)))
         return bool(act.value), k.value, t.value
 
+    def debug_stats(self):
+        """Counters of the last filtered batch (see mlf_region_debug_stats in include/mlfriends_hip.h)."""
+        out = np.zeros(8, dtype=np.uint64)
+        check(_lib.lib().mlf_region_debug_stats(self._h, ptr(out), 8))
+        keys = ("ellipsoid_band", "exact_whitened_queries", "uncertain_pairs", "largest_segment", "segments", "second_range_groups")
+        return dict(zip(keys, (int(v) for v in out[:6])))
+
     def time_inside_dev(self, d_pts, npts, d_mask, stream=0, reps=3):
         tot, scan = ctypes.c_float(0), ctypes.c_float(0)
         check(_lib.lib().mlf_region_time_inside_dev(self._h, ctypes.c_void_p(d_pts), npts, ctypes.c_void_p(d_mask),
