@@ -7,6 +7,10 @@ points, d=50.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Launched plainly with --gpus N > 1 the script starts its N ranks itself (torch.distributed.run on
+127.0.0.1); on a box with fewer than N devices the ranks share the devices and use gloo collectives,
+so that the N-rank control flow can be exercised anywhere.
+
 One "step" = one pass of MLFriends.inside (wrapping-ellipsoid test -> whitening -> neighbour
 scan) over one batch of P = 10^6 synthetic proposals that is already resident in HBM when the
 timed region starts.  Weak scaling: every rank (one process per GPU) filters its own batch of P
@@ -22,6 +26,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,8 +38,9 @@ sys.path.insert(0, ROOT)
 N_LIVE, NDIM, NPROPOSALS, NBOOT = 4000, 50, 1000000, 30
 FP64_VALU_PEAK_TFLOPS = 39.3     # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz, one flop per non-fused v_*_f64
 F16_MFMA_PEAK_TFLOPS = 2500.0    # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
-FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix = vector FMA peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+F32_MFMA_PEAK_TFLOPS = 157.3     # f32-in MFMA = the FP32 vector rate (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F16_FLOPS = 2 * 32 * 32 * 16   # one v_mfma_f32_32x32x16_f16
 
 
 def build_region(group):
@@ -86,6 +92,33 @@ def time_rebuild(u, group):
     return first_ms, float(np.median(steady))
 
 
+def host_api(region, pts_dev):
+    """The path the reference itself calls (mlfriends.pyx:1186-1211 from integrator.py:1776-1804): host numpy in,
+    host bool mask out, P = 10^6; pageable source buffer.  Bound: 8 d bytes per proposal over PCIe."""
+    import torch
+    pts = pts_dev.cpu().numpy()
+    region.inside(pts[:1000])
+    ts = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        m = region.inside(pts)
+        ts.append(time.perf_counter() - t0)
+    dst = torch.empty_like(pts_dev)
+    src = torch.from_numpy(pts)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    h2d = (time.perf_counter() - t0) / 3
+    med = float(np.median(ts))
+    return {"call": "MLFriends.inside(host numpy (P, d) float64) -> host bool mask, pageable memory",
+            "ms_per_batch": med * 1e3, "proposals_per_s": len(pts) / med, "accept_fraction": float(m.mean()),
+            "h2d_GBps_same_buffer": pts.nbytes / h2d / 1e9, "pcie_bound_proposals_per_s": len(pts) / h2d,
+            "fraction_of_pcie_bound": h2d / med}
+
+
 def cpu_baseline(region, pts_host, u):
     """The CPU oracle (single-threaded C restatement of the reference's Cython loops,
     oracle/mlfriends_oracle.c) on a bounded sample of the same proposals, on this box's host."""
@@ -124,7 +157,6 @@ def cpu_baseline_parallel(region, sample, nproc):
     """The same oracle pass in `nproc` independent processes at once (the reference's `mpiexec -np k`
     mode, docs/performance.rst:355-371, has no shared state in this path): host throughput when all
     of them run concurrently, each on the same sample."""
-    import subprocess
     import tempfile
     if nproc <= 1:
         return None
@@ -149,6 +181,23 @@ def cpu_baseline_parallel(region, sample, nproc):
                        % (nproc, len(sample), max(inner), wall))
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks under torch.distributed.run ourselves."""
+    import socket
+    import torch
+    ndev = torch.cuda.device_count()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    if ndev < args.gpus:      # fewer devices than ranks (a 1-GPU box): ranks share devices, collectives over gloo
+        env["MLF_BENCH_BACKEND"] = "gloo"
+        env["MLF_BENCH_NDEV"] = str(max(ndev, 1))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,18 +206,24 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=150000, help="proposals timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
-                    help="only the headline path (no single-sweep / filter-off comparison passes): used for the "
-                         "rocprofv3 runs, so that the per-kernel averages of the summary are those of the timed steps")
+                    help="only the headline path (no single-sweep / filter-off / host-API comparison passes): used for "
+                         "the rocprofv3 runs, so that the per-kernel averages of the summary are those of the timed steps")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1 and args.gpus == 1, "launch one process per GPU (torch.distributed.run)"
-    # test hooks (a 1-GPU box can run the N > 1 control flow as N processes on one device with gloo collectives):
-    # MLF_BENCH_DEVICE pins every rank to one device, MLF_BENCH_BACKEND replaces "nccl"
-    device_index = int(os.environ.get("MLF_BENCH_DEVICE", local_rank))
+    # hooks for boxes with fewer devices than ranks: MLF_BENCH_DEVICE pins every rank to one device, MLF_BENCH_NDEV
+    # wraps the local rank around the devices present, MLF_BENCH_BACKEND replaces "nccl"
+    if "MLF_BENCH_DEVICE" in os.environ:
+        device_index = int(os.environ["MLF_BENCH_DEVICE"])
+    else:
+        device_index = local_rank % int(os.environ.get("MLF_BENCH_NDEV", str(max(world, 1))))
     backend = os.environ.get("MLF_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
@@ -199,46 +254,69 @@ def main():
 
     from ultranest_amd import _lib as lib_mod
 
-    def timed_steps(nsteps):
+    def run_steps(nsteps, stage_events):
+        """nsteps passes between two barriers; returns (max-over-ranks seconds, this rank's seconds).
+        stage_events: also record the per-stage hipEvents (only outside the headline loop: six extra events per pass
+        cost ~7 % of a 0.6 ms step).  The k_filter launches are bracketed by events in both modes."""
+        call = handle.inside_dev_timed if stage_events else handle.inside_dev
         for _ in range(args.warmup):
             handle.inside_dev(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
         handle.timing_collect()
+        handle.timing_filter_launches()
         barrier()
         t0 = time.perf_counter()
         for _ in range(nsteps):
-            handle.inside_dev_timed(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
+            call(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
         barrier()
-        dt = time.perf_counter() - t0
+        mine = time.perf_counter() - t0
+        dt = mine
         if use_dist:
             import torch.distributed as dist
             t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        timed_steps.launch_ms = handle.timing_filter_launch_ms()
-        timed_steps.filter_launches = handle.timing_filter_launches()
-        return dt, handle.timing_collect()
+        run_steps.launch_ms = handle.timing_filter_launch_ms()
+        run_steps.filter_launches = handle.timing_filter_launches()
+        return dt, mine
 
-    # single-sweep variant of the pre-filter (no compaction between live-point ranges), for the record
-    ms_scan_single = None
-    if not args.headline_only:
-        lib_mod.set_option("filter_phases", 0)
-        _, (ncalls_single, _, ms_scan_single, _) = timed_steps(max(3, args.steps // 4))
-        ms_scan_single /= max(ncalls_single, 1)
-        lib_mod.set_option("filter_phases", 1)
-    elapsed, (ncalls, ms_prep, ms_scan, ms_rest) = timed_steps(args.steps)
-    filter_launches = timed_steps.filter_launches
-    launch_ms_list = timed_steps.launch_ms
+    lib_mod.set_option("time_filter_launches", 1)
+    # ---- the headline: exactly K steps, hipEvents only around the dominant kernel's launches -----------------
+    elapsed, elapsed_mine = run_steps(args.steps, False)
+    filter_launches = run_steps.filter_launches
+    launch_ms_list = run_steps.launch_ms
+    stats = handle.debug_stats()
     accept = float(mask.float().mean().item())
     filter_on, kdim, ntiles32 = handle.filter_info(NPROPOSALS)
     mask_filter = mask.clone()
-    # reference point: the exact FP64 scan kernel alone (MFMA pre-filter switched off), same batch
-    nsteps_x = max(3, args.steps // 4)
+    # ---- per-stage breakdown (separate pass with stage events) ---------------------------------------------
+    nsteps_b = max(3, args.steps // 2)
+    run_steps(nsteps_b, True)
+    ncalls, ms_prep, ms_scan, ms_rest = handle.timing_collect()
+    assert bool((mask == mask_filter).all().item())
+
+    # single-sweep variant of the pre-filter (no compaction between live-point ranges), for the record
+    ms_scan_single = None
     exact_elapsed = ncalls_x = ms_scan_x = scan_flops = ell_pass = None
+    nsteps_x = max(3, args.steps // 4)
+    hostapi = None
     if not args.headline_only:
+        lib_mod.set_option("filter_phases", 0)
+        run_steps(nsteps_x, True)
+        ncalls_single, _, ms_scan_single, _ = handle.timing_collect()
+        ms_scan_single /= max(ncalls_single, 1)
+        lib_mod.set_option("filter_phases", 1)
+        # reference point: the exact FP64 scan kernel alone (MFMA pre-filter switched off), same batch
         lib_mod.set_option("filter", 0)
-        exact_elapsed, (ncalls_x, ms_prep_x, ms_scan_x, ms_rest_x) = timed_steps(nsteps_x)
+        exact_elapsed, _ = run_steps(nsteps_x, True)
+        ncalls_x, ms_prep_x, ms_scan_x, ms_rest_x = handle.timing_collect()
         lib_mod.set_option("filter", 1)
         assert bool((mask == mask_filter).all().item()), "filter and exact scan disagree"
+        # ... and the FP64 per-proposal stage (k_prep3) in front of the filter instead of the bounded FP32 one
+        lib_mod.set_option("prep_bounded", 0)
+        run_steps(nsteps_x, True)
+        ncalls_p3, ms_prep_p3, _, ms_rest_p3 = handle.timing_collect()
+        lib_mod.set_option("prep_bounded", 1)
+        assert bool((mask == mask_filter).all().item()), "bounded and exact per-proposal stage disagree"
 
         # algorithmic work of the neighbour scan on this batch: the reference's loop stops at the first
         # hit, so a proposal costs 3*d flops per live point visited = (first index + 1), or N if none
@@ -250,9 +328,18 @@ def main():
         scan_flops = 3.0 * NDIM * float(visited.sum().item())
         ell_pass = float((idx != -2).float().mean().item())
         assert bool(((idx >= 0) == (mask != 0)).all().item()), "index and mask pipelines disagree"
+        if rank == 0:
+            hostapi = host_api(region, pts)
+    lib_mod.set_option("time_filter_launches", 0)
 
     first_ms, rebuild_ms = time_rebuild(u, group)
 
+    per_rank = [elapsed_mine]
+    if use_dist:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, elapsed_mine)
+        per_rank = gathered
     if rank != 0:
         if use_dist:
             import torch.distributed as dist
@@ -271,53 +358,62 @@ def main():
         traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
     exact_roof = scan_x_ms = None
     if not args.headline_only:
-      scan_x_ms = ms_scan_x / max(ncalls_x, 1)
-      exact_tflops = scan_flops / (scan_x_ms * 1e-3) / 1e12
-      exact_roof = {
-        "kernel": "k_scan<50> (exact FP64 neighbour scan; the whole scan when the pre-filter is off, "
-                  "the re-check arithmetic when it is on)",
-        "bound": "valu_fp64", "achieved": exact_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": exact_tflops / FP64_VALU_PEAK_TFLOPS, "ms_per_launch": scan_x_ms,
-        "algorithmic_flops_per_launch": scan_flops,
-        "measured_valu_probe_tflops": kernels.bench_fp64_valu(),
-        "proposals_per_s_filter_off": NPROPOSALS * world * nsteps_x / exact_elapsed,
-        "note": "bit-exactness forbids FMA/MFMA in the distance itself: peak = non-fused FP64 vector issue rate"}
+        scan_x_ms = ms_scan_x / max(ncalls_x, 1)
+        exact_tflops = scan_flops / (scan_x_ms * 1e-3) / 1e12
+        exact_roof = {
+            "kernel": "k_scan<50> (exact FP64 neighbour scan; the whole scan when the pre-filter is off, "
+                      "the re-check arithmetic when it is on)",
+            "bound": "valu_fp64", "achieved": exact_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": exact_tflops / FP64_VALU_PEAK_TFLOPS, "ms_per_launch": scan_x_ms,
+            "algorithmic_flops_per_launch": scan_flops,
+            "measured_valu_probe_tflops": kernels.bench_fp64_valu(),
+            "proposals_per_s_filter_off": NPROPOSALS * world * nsteps_x / exact_elapsed,
+            "note": "bit-exactness forbids FMA/MFMA in the distance itself: peak = non-fused FP64 vector issue rate"}
     stage_ms = prep_ms + scan_ms + rest_ms
-    hbm = {"algorithmic_bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / (stage_ms * 1e-3) / 1e9,
+    hbm = {"algorithmic_bytes_per_step": alg_bytes, "achieved_GBps": alg_bytes / (stage_ms * 1e-3) / 1e9,
            "peak_GBps": HBM_PEAK_GBPS, "frac": alg_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     if filter_on:
-        # f16 GEMM of the pre-filter: every (live point, proposal) pair costs 2*(d+6) flops
-        # (d coordinates + 6 norm columns ride the matrix core); the executed K is padded to kdim
-        # One step = the pair work of the whole batch, swept in `launches_per_step` k_filter launches
-        # (two phases; the second one only sees the queries that are still undecided).  Per launch: half
-        # of the algorithmic pair flops over the average launch duration -- the quantity rocprofv3's
-        # per-kernel average must reproduce (profiles/*_rocprofv3_kernel_stats.csv).
-        mfma_flops = 2.0 * N_LIVE * NPROPOSALS * (NDIM + 6)
+        # f16 GEMM of the pre-filter on v_mfma_f32_32x32x16_f16 (32768 flop each).  EXECUTED work per step: the first
+        # live-point range sweeps every 32-query group, the second only the groups left after the device-side
+        # compaction (group count read back from the device); per (group, 32-row live tile): KS = kdim / 16 matrix
+        # instructions.  This is the number SQ_INSTS_MFMA x 32768 / average ns of the rocprofv3 summaries in profiles/
+        # reproduces; the all-pairs figure of round 1 is kept as `equivalent_*`.
+        ks = kdim // 16
         nlaunch, ms_kernels = filter_launches
-        per_step = max(1, round(nlaunch / max(ncalls, 1)))
+        per_step = max(1, round(nlaunch / max(args.steps, 1)))
+        ngroups1 = (NPROPOSALS + 31) // 32
+        tiles = [ntiles32 * (i + 1) // per_step - ntiles32 * i // per_step for i in range(per_step)]
+        groups = [ngroups1] + [stats["second_range_groups"]] * (per_step - 1)
+        mfma_per_launch = [g * t * ks for g, t in zip(groups, tiles)]
+        exec_flops = float(sum(mfma_per_launch)) * MFMA_F16_FLOPS
         launch_ms = ms_kernels / max(nlaunch, 1)
         by_phase = [float(np.mean(launch_ms_list[i::per_step])) for i in range(per_step)] if len(launch_ms_list) else []
-        ach = (mfma_flops / per_step) / (launch_ms * 1e-3) / 1e12
-        roofline = {"kernel": "k_filter (v_mfma_f32_32x32x16_f16 bound on every pair distance)",
+        ach = (exec_flops / per_step) / (launch_ms * 1e-3) / 1e12
+        allpairs = 2.0 * N_LIVE * NPROPOSALS * (NDIM + 6)
+        roofline = {"kernel": "k_filter (v_mfma_f32_32x32x16_f16 bound on the pair distances; two launches per step)",
                     "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / F16_MFMA_PEAK_TFLOPS, "ms_per_launch": launch_ms,
                     "launches_per_step": per_step,
                     "ms_per_launch_by_phase": by_phase,
+                    "executed_mfma_per_launch_by_phase": mfma_per_launch,
+                    "executed_flops_per_launch": exec_flops / per_step,
+                    "achieved_by_phase": [m * MFMA_F16_FLOPS / (t * 1e-3) / 1e12 for m, t in zip(mfma_per_launch, by_phase)],
                     "kernel_names": ["k_filter<4, 4, false, true> (first live-point range, compacts the undecided proposals)",
                                      "k_filter<4, 4, false, false> (second range)"] if per_step == 2 else None,
-                    "algorithmic_flops_per_launch": mfma_flops / per_step,
-                    "algorithmic_flops_per_step": mfma_flops, "executed_k_columns": kdim,
-                    "measured_mfma_ceiling_TFLOPs": 1530.0,
-                    "note": "achieved counts every (live point, proposal) pair of the batch although the second "
-                            "phase skips the decided proposals (an algorithmic saving, like the reference's early "
-                            "exit); ceiling measured with scripts/probes/mfma16_probe.hip in the same access pattern",
+                    "equivalent_allpairs_flops_per_step": allpairs,
+                    "equivalent_allpairs_TFLOPs": allpairs / (launch_ms * per_step * 1e-3) / 1e12,
+                    "executed_k_columns": kdim, "second_range_groups": stats["second_range_groups"],
+                    "note": "achieved = executed matrix-instruction flops of one launch (average of the launches of a step) "
+                            "over the average launch duration from hipEvents inside the timed region; pairs skipped by the "
+                            "second range are not counted (they are an algorithmic saving)",
                     "traffic": traffic, "hbm": hbm}
     else:
         roofline = dict(exact_roof or {})
         roofline["traffic"] = traffic
         roofline["hbm"] = hbm
-    prep_bytes = NPROPOSALS * (8 * NDIM + 8 * NDIM + 2 * kdim + 9)      # row in, whitened f64 + f16 fragments + flags out
-    prep_flops = NPROPOSALS * 2.0 * (NDIM * NDIM + NDIM * (NDIM + 1) / 2)
+    # per-proposal stage: row in (8 d), binary16 operand + thresholds + route / slot / best words out
+    prep_bytes = NPROPOSALS * (8 * NDIM + 2 * kdim + 8 + 1 + 4 + 4 + 1)
+    prep_mfma_flops = NPROPOSALS / 32 * 84 * 2.0 * 32 * 32 * 2     # 84 v_mfma_f32_32x32x2_f32 per 32 proposals (d = 50)
     out = {
         "metric": "proposal-points filtered/sec (MLFriends.inside) + region-rebuild ms, N=4000 d=50",
         "value": value, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -328,26 +424,38 @@ def main():
                                "on a batch resident in HBM",
                    "n_live": N_LIVE, "d": NDIM, "proposals_per_step_per_gpu": NPROPOSALS, "bootstraps": NBOOT,
                    "parallelism": "proposal rows sharded over " + str(world) + " GPU(s), region replicated",
-                   "mfma_prefilter": bool(filter_on)},
+                   "mfma_prefilter": bool(filter_on),
+                   "arithmetic": "inputs, thresholds and every decision that depends on the reference's rounding: binary64 "
+                                 "(non-fused); deciding bounds for the other 99.99 % of the pairs: binary16 operands / "
+                                 "binary32 accumulate on the matrix cores, binary32 bounded whitening; masks bit-identical "
+                                 "to the exact FP64 scan (asserted in this run)"},
+        "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
         "rebuild_ms": rebuild_ms, "rebuild_first_ms": first_ms,
         "accept_fraction": accept, "ellipsoid_pass_fraction": ell_pass,
-        "kernel_ms": {"per-proposal stage (k_prep3: ellipsoid + whitening on the FP64 matrix cores + f16 quantisation)": prep_ms,
+        "kernel_ms": {"per-proposal stage (k_prep4: bounded ellipsoid test + whitening on the FP32 matrix cores -> f16 "
+                      "operand; k_ell_exact rides in the k_mark_exact launch)": prep_ms,
                       ("scan kernel (k_filter)" if filter_on else "scan kernel (k_scan)"): scan_ms,
-                      "rest of scan stage (exact re-check of uncertain pairs, routing, finalise)": rest_ms,
-                      "scan kernel as a single sweep over all live points (phases off)": ms_scan_single},
+                      "rest of scan stage (exact-coordinate slots, exact whitening + re-check of uncertain pairs, "
+                      "routing, finalise)": rest_ms,
+                      "scan kernel as a single sweep over all live points (phases off)": ms_scan_single,
+                      "per-proposal stage with the FP64 kernel instead (k_prep3, prep_bounded=0)":
+                          (ms_prep_p3 / max(ncalls_p3, 1)) if not args.headline_only else None,
+                      "measured_in": "a separate pass of %d steps with stage events (the headline loop carries events only "
+                                     "around the k_filter launches)" % nsteps_b},
+        "batch_counters": stats,
         "roofline": roofline,
         "roofline_exact_scan": exact_roof,
-        "roofline_prep": {"kernel": "k_prep3<13> (v_mfma_f64_16x16x4_f64)", "bound": "mfma_fp64", "unit": "TFLOP/s",
-                          "achieved": prep_flops / (prep_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
-                          "frac": prep_flops / (prep_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                          "algorithmic_flops_per_launch": prep_flops,
-                          "hbm": {"algorithmic_bytes_per_launch": prep_bytes,
-                                  "achieved_GBps": prep_bytes / (prep_ms * 1e-3) / 1e9,
-                                  "frac": prep_bytes / (prep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-                          "note": "algorithmic flops = 2*(d^2 + d(d+1)/2) per proposal (whitening + triangular "
-                                  "factor of the ellipsoid form); the kernel executes 80 of 104 16x16x4 tiles per "
-                                  "16 proposals (d = 50 padded to 52 x 64); measured v_mfma_f64 issue rate on this "
-                                  "part: 68-76 TFLOP/s (scripts/probes/mfma64_probe.hip)"},
+        "roofline_prep": {"kernel": "k_prep4<50> (v_mfma_f32_32x32x2_f32 + global_load_lds staging)", "bound": "hbm",
+                          "unit": "GB/s", "achieved": prep_bytes / (prep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                          "frac": prep_bytes / (prep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                          "algorithmic_bytes_per_launch": prep_bytes,
+                          "mfma_f32": {"executed_flops_per_launch": prep_mfma_flops,
+                                       "achieved_TFLOPs": prep_mfma_flops / (prep_ms * 1e-3) / 1e12,
+                                       "peak_TFLOPs": F32_MFMA_PEAK_TFLOPS},
+                          "note": "the stage time includes the launch gap in front of the filter; on gfx950 the FP32 matrix "
+                                  "instructions and the vector ALU do not co-execute (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in "
+                                  "profiles/), so matrix and vector time add up: DESIGN.md section 4c"},
+        "host_api": hostapi,
     }
     if world == 1 and not args.no_cpu:
         sample = pts[:args.cpu_sample].cpu().numpy()

@@ -80,6 +80,7 @@ bool g_filter_fused_compact = true;   // mlf_set_option("filter_fused_compact", 
 int g_filter_phases = 1;              // mlf_set_option("filter_phases", n): 0 single sweep, 1 default phase count, n >= 2 exactly n phases
 long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
 bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
+bool g_time_filter_launches = false;  // mlf_set_option("time_filter_launches", 0/1): event pairs around every k_filter launch of every call
 bool g_prep_bounded = true;           // mlf_set_option("prep_bounded", 0/1): FP32 matrix-core bounded stage (mlf_prep4.hip)
 long long g_filter_min_queries = 2048;  // smaller batches go straight to the exact scan
 
@@ -331,7 +332,8 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       fa.qmap = f.pmap[dst].as<int>();
       fa.ngroups_dev = f.png.as<unsigned>() + dst;
     }
-    if (ev_after_filter) {   // timed call: bracket the matrix kernel itself (the compaction kernels stay outside)
+    const bool time_launch = ev_after_filter || g_time_filter_launches;
+    if (time_launch) {   // timed call: bracket the matrix kernel itself (the compaction kernels stay outside)
       while (f.kev.size() < f.kev_used + 2) {
         hipEvent_t e;
         CK(hipEventCreate(&e));
@@ -340,7 +342,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       CK(hipEventRecord(f.kev[f.kev_used], s));
     }
     CK(launch_filter(f.ks, fa, out_idx != nullptr, s));
-    if (ev_after_filter) {
+    if (time_launch) {
       CK(hipEventRecord(f.kev[f.kev_used + 1], s));
       f.kev_used += 2;
     }
@@ -970,6 +972,10 @@ int mlf_set_option(const char *name, long long value) {
   }
   if (!strcmp(name, "prep_matrix")) {
     g_prep_matrix = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "time_filter_launches")) {
+    g_time_filter_launches = value != 0;
     return 0;
   }
   if (!strcmp(name, "prep_bounded")) {
