@@ -66,7 +66,8 @@ int mlf_subtract_nearby(const double *pts, size_t n, size_t d, double radiussq, 
 
 /* ---- K4: compute_maxradiussq over bootstrap rounds -- mlfriends.pyx:188-224 called from
  * MLFriends.compute_enlargement :1044-1054 and MLFriends.compute_maxradiussq :1004-1012.
- * selected is (B, n) bytes (non-zero = selected).  maxd_out[b] = max over unselected j of the
+ * selected is (B, n) bytes (non-zero = selected); here and in mlf_bootstrap_factor it may be a HOST or a DEVICE
+ * pointer (the multi-GPU rebuild broadcasts the masks between devices).  maxd_out[b] = max over unselected j of the
  * min over selected i of dist2(i,j), narrowed to binary32 and widened back exactly as the
  * reference's `cdef float` return does.  skipped_out[b] = 1 when bootstrap b selects all or
  * no points (reference :1048 `continue`); maxd_out[b] = 0 then.  skipped_out may be NULL. */
@@ -324,6 +325,19 @@ int mlf_region_timing_filter_launch_ms(mlf_region *r, double *ms, int cap, int *
 /* whether a batch of np proposals takes the MFMA pre-filter, and its GEMM shape (K columns per pair,
  * number of 32-row live-point tiles) */
 int mlf_region_filter_info(mlf_region *r, size_t np, int *active, int *kdim, int *ntiles32);
+/* ---- multi-GPU exchange step (reference integrator.py:395-404: gather + bcast + np.max) --------
+ * MAX all-reduce of a few doubles over RCCL for callers without torch.distributed.  librccl is dlopen()ed at the
+ * first call.  One process per GPU: rank 0 obtains 128 bytes with mlf_comm_unique_id and distributes them (MPI, file,
+ * socket ...), every rank calls mlf_comm_init_rank after mlf_set_device; mlf_allreduce_max(v, count) then leaves the
+ * element-wise maximum over the ranks in v.  One process driving ndev devices: mlf_comm_init(ndev), and
+ * mlf_allreduce_max takes ndev rows of `count` doubles.  NaN must travel as an explicit flag element, not through MAX
+ * (the Python layer does that: ultranest_amd.distributed). */
+int mlf_comm_unique_id(char *id_out, size_t len /* >= 128 */);
+int mlf_comm_init_rank(const char *id, size_t len, int nranks, int rank);
+int mlf_comm_init(int ndev);
+int mlf_allreduce_max(double *values, size_t count);
+int mlf_comm_destroy(void);
+
 /* Diagnostic counters of the LAST filtered batch of this region (synchronises the device): out[0] proposals the
  * binary32 ellipsoid form could not decide (k_ell_exact), out[1] queries whitened in the reference arithmetic for the
  * exact re-check / exact scan, out[2] uncertain pairs listed by the pre-filter, out[3] largest list segment, out[4]

@@ -178,3 +178,174 @@ def test_collectives_on_rccl_with_one_rank():
     mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
     assert out["backend"] == "nccl"
     assert tuple(out["pair"]) == tuple(want), (dict(out), want)
+
+
+def _one_rank_fails_worker(rank, world_size, port, out):
+    """rank 1's shard raises a FloatingPointError (what np.errstate(all='raise') turns a numpy warning into under the
+    driver, integrator.py:2066); rank 0's shard is fine.  Every rank must still reach the all-reduce and leave with the
+    same exception type (a rank that skips the collective leaves the others blocked in it)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import torch.distributed as dist
+    import oracle_backend
+    import ultranest_amd.kernels as K
+    import ultranest_amd.mlfriends as M
+    for name in oracle_backend.PATCHED:
+        setattr(K, name, getattr(oracle_backend, name))
+        if hasattr(M, name):
+            setattr(M, name, getattr(oracle_backend, name))
+    from ultranest_amd import distributed
+    from ultranest_amd.harness import RegionUpdater
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        u = inputs.live_points(31, 300, 4)
+        layer = M.AffineLayer()
+        layer.optimize(u, u)
+        region = M.MLFriends(u, layer)
+        good = region.enlargement_from_masks
+
+        def shard(masks, minvol=0.):
+            if rank == 1:
+                raise FloatingPointError("invalid value encountered in this rank's shard")
+            return good(masks, minvol=minvol)
+        region.enlargement_from_masks = shard
+        try:
+            distributed.update_region_bootstrap(region, 30, minvol=0., rng=np.random.RandomState(3))
+            out[rank] = "no error"
+        except np.linalg.LinAlgError:
+            out[rank] = "LinAlgError"
+        # the wrapping ellipsoid of the harness: same hazard, same cure
+        upd = RegionUpdater(4)
+        np.random.seed(5)
+        real = M.WrappingEllipsoid.enlargement_from_masks
+
+        def tshard(self, masks):
+            if rank == 1:
+                raise FloatingPointError("shard")
+            return real(self, masks)
+        import ultranest_amd.harness as H
+        H.WrappingEllipsoid.enlargement_from_masks = tshard
+        upd.update(u, nbootstraps=10, active_p=u * 3.0)
+        out[10 + rank] = upd.tregion is None
+        t = distributed.allreduce_max([float(rank)])       # the group is still in step
+        out[20 + rank] = float(t[0])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_failure_on_one_rank_only_keeps_the_group_in_step():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_one_rank_fails_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] == "LinAlgError" and out[1] == "LinAlgError", dict(out)
+    assert out[10] is True and out[11] is True, dict(out)
+    assert out[20] == 1.0 and out[21] == 1.0, dict(out)
+
+
+# ---- the C-ABI exchange step (mlf_comm_* / mlf_allreduce_max over librccl; include/mlfriends_hip.h) ------------------
+def _abi_comm_worker(rank, world_size, idpath, out):
+    sys.path.insert(0, ROOT)
+    import ctypes
+    import time
+    from ultranest_amd import _lib
+    L = _lib.lib()
+    _lib.set_device(rank)
+    buf = ctypes.create_string_buffer(128)
+    if rank == 0:
+        _lib.check(L.mlf_comm_unique_id(buf, 128))
+        with open(idpath + ".tmp", "wb") as fh:
+            fh.write(buf.raw)
+        os.replace(idpath + ".tmp", idpath)
+    else:
+        for _ in range(600):
+            if os.path.exists(idpath):
+                break
+            time.sleep(0.05)
+        buf = ctypes.create_string_buffer(open(idpath, "rb").read(), 128)
+    _lib.check(L.mlf_comm_init_rank(buf, 128, world_size, rank))
+    v = np.array([1.0 + rank, -float(rank), 0.5], dtype=np.float64)
+    _lib.check(L.mlf_allreduce_max(v.ctypes.data, 3))
+    out[rank] = list(v)
+    _lib.check(L.mlf_comm_destroy())
+
+
+@pytest.mark.gpu
+def test_abi_allreduce_max_one_rank_and_one_process(tmp_path):
+    import ctypes
+    from ultranest_amd import _lib
+    L = _lib.lib()
+    buf = ctypes.create_string_buffer(128)
+    _lib.check(L.mlf_comm_unique_id(buf, 128))
+    _lib.check(L.mlf_comm_init_rank(buf, 128, 1, 0))
+    v = np.array([3.0, -2.0, np.inf], dtype=np.float64)
+    _lib.check(L.mlf_allreduce_max(v.ctypes.data, 3))
+    assert list(v) == [3.0, -2.0, np.inf]
+    # one process driving all visible devices: ndev rows, the maximum lands in every row
+    ndev = _lib.device_count()
+    _lib.check(L.mlf_comm_init(ndev))
+    rows = np.arange(ndev * 4, dtype=np.float64).reshape(ndev, 4) * np.array([1.0, -1.0, 1.0, -1.0])
+    want = rows.max(axis=0)
+    _lib.check(L.mlf_allreduce_max(rows.ctypes.data, 4))
+    assert np.array_equal(rows, np.broadcast_to(want, rows.shape))
+    _lib.check(L.mlf_comm_destroy())
+    with pytest.raises(ValueError):
+        _lib.check(L.mlf_allreduce_max(v.ctypes.data, 3))      # no communicator
+
+
+@pytest.mark.gpu
+def test_abi_allreduce_max_two_ranks_over_rccl(tmp_path):
+    """one process per GPU, the 128-byte id handed over through a file (what an MPI_Bcast would do)"""
+    from ultranest_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_abi_comm_worker, args=(2, str(tmp_path / "id.bin"), out), nprocs=2, join=True)
+    assert out[0] == out[1] == [2.0, 0.0, 0.5], dict(out)
+
+
+def _rccl_two_rank_worker(rank, world_size, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import torch
+    import torch.distributed as dist
+    import ultranest_amd.mlfriends as M
+    from ultranest_amd import _lib, distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    _lib.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", rank))
+    try:
+        u = inputs.live_points(31, 1500, 12)
+        layer = M.AffineLayer()
+        layer.optimize(u, u)
+        region = M.MLFriends(u, layer)
+        rng = np.random.RandomState(1234 if rank == 0 else 77)
+        out[rank] = distributed.update_region_bootstrap(region, 30, minvol=0., rng=rng)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_bootstrap_two_ranks_over_rccl():
+    """the rebuild's exchange step on two GPUs: device-side mask broadcast + MAX all-reduce over RCCL"""
+    from ultranest_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    import ultranest_amd.mlfriends as M
+    u = inputs.live_points(31, 1500, 12)
+    layer = M.AffineLayer()
+    layer.optimize(u, u)
+    region = M.MLFriends(u, layer)
+    want = region.compute_enlargement(nbootstraps=30, rng=np.random.RandomState(1234))
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_two_rank_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert tuple(out[0]) == tuple(out[1]) == tuple(want), (dict(out), want)

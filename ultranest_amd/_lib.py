@@ -100,6 +100,11 @@ SIGNATURES = {
     "mlf_region_filter_info": [_vp, _sz, _vp, _vp, _vp],
     "mlf_bench_fp64_valu": [_vp],
     "mlf_region_debug_stats": [_vp, _vp, _int],
+    "mlf_comm_unique_id": [_vp, _sz],
+    "mlf_comm_init_rank": [_vp, _sz, _int, _int],
+    "mlf_comm_init": [_int],
+    "mlf_allreduce_max": [_vp, _sz],
+    "mlf_comm_destroy": [],
 }
 
 _lib = None

@@ -131,6 +131,14 @@ int upload(DevBuf &b, const void *host, size_t bytes, hipStream_t s) {
   return 0;
 }
 
+// like upload(), but `src` may be a host OR a device pointer (unified addressing picks the direction): the bootstrap
+// selection masks arrive from a device-side broadcast in the multi-GPU rebuild
+int upload_any(DevBuf &b, const void *src, size_t bytes, hipStream_t s) {
+  CK(b.reserve(bytes ? bytes : 1));
+  if (bytes) CK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyDefault, s));
+  return 0;
+}
+
 int check_dims(size_t d) {
   if (d == 0) return fail_arg(MLF_E_BADARG, "dimensionality must be positive");
   if (d > MLF_MAX_DIM) return fail_arg(MLF_E_DIM, "dimensionality above MLF_MAX_DIM (128) is not supported");
@@ -1051,7 +1059,7 @@ int mlf_maxradiussq_bootstrap(const double *pts, size_t n, size_t d, const uint8
   const int dp = pick_dp((int)d);
   const int npad = round_up((int)n, kWave);
   if (int rc = stage_live_points(pts, n, d, dp, npad, true)) return rc;
-  if (int rc = upload(c.selbytes, selected, B * n, c.stream)) return rc;
+  if (int rc = upload_any(c.selbytes, selected, B * n, c.stream)) return rc;
   CK(c.sel.reserve((size_t)npad * sizeof(unsigned)));
   CK(c.M.reserve((size_t)kBootGroup * npad * sizeof(unsigned long long)));
   CK(c.small0.reserve(B * sizeof(double)));
@@ -1202,7 +1210,7 @@ int mlf_bootstrap_factor(const double *u, size_t n, size_t d, const uint8_t *sel
   if (int rc = ensure_ctx()) return rc;
   Ctx &c = g_ctx;
   if (int rc = upload(c.src, u, n * d * sizeof(double), c.stream)) return rc;
-  if (int rc = upload(c.selbytes, selected, B * n, c.stream)) return rc;
+  if (int rc = upload_any(c.selbytes, selected, B * n, c.stream)) return rc;
   CK(c.small0.reserve(B * d * sizeof(double)));
   CK(c.small1.reserve(B * sizeof(int)));
   CK(c.out.reserve(B * d * d * sizeof(double)));

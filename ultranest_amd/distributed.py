@@ -25,6 +25,11 @@ import numpy as np
 from . import regions
 
 
+# what a shard of bootstrap rounds can raise (the driver runs the rebuild under np.errstate(all='raise'),
+# integrator.py:2066): caught per rank, exchanged as a flag, re-raised on every rank after the all-reduce
+SHARD_ERRORS = (np.linalg.LinAlgError, FloatingPointError, AssertionError, Warning)
+
+
 def _dist():
     import torch.distributed as dist
     return dist
@@ -73,8 +78,10 @@ def _tensor_device(group=None):
     return torch.device("cpu")
 
 
-def broadcast_masks(masks, npoints, nbootstraps, group=None, src=0):
-    """Rank `src` provides the (B, N) bool masks; every rank returns the same array."""
+def broadcast_masks(masks, npoints, nbootstraps, group=None, src=0, keep_on_device=False):
+    """Rank `src` provides the (B, N) bool masks; every rank returns the same matrix.  With `keep_on_device` and a
+    device backend (RCCL) the result is the uint8 device tensor of the broadcast itself -- the bootstrap kernels take
+    device pointers for the masks, so nothing travels device -> host -> device; otherwise a numpy bool array."""
     rank, size = world(group)
     if size == 1 and not (_forced() and _initialised()):
         return masks
@@ -86,6 +93,8 @@ def broadcast_masks(masks, npoints, nbootstraps, group=None, src=0):
     else:
         buf = torch.empty((nbootstraps, npoints), dtype=torch.uint8, device=dev)
     dist.broadcast(buf, src=src, group=group)
+    if keep_on_device and dev.type == "cuda":
+        return buf
     return buf.cpu().numpy().astype(bool)
 
 
@@ -107,19 +116,25 @@ def sharded_enlargement(region, nbootstraps, minvol=0., rng=np.random, group=Non
     Single process: identical to ``region.compute_enlargement`` (same draws, same bits)."""
     rank, size = world(group)
     npoints = len(region.u)
-    masks = regions._draw_selection(rng, npoints, nbootstraps) if rank == 0 else None
-    masks = broadcast_masks(masks, npoints, nbootstraps, group=group)
+    # every rank draws (so that rank-replicated host logic that uses the same stream afterwards stays in step across
+    # the ranks when they are seeded alike); rank 0's draw is the one that counts
+    masks = regions._draw_selection(rng, npoints, nbootstraps)
+    masks = broadcast_masks(masks, npoints, nbootstraps, group=group, keep_on_device=True)
     lo, hi = shard_bounds(nbootstraps, rank, size)
     error = None
     r = f = 0.0
     try:
         out = region.enlargement_from_masks(masks[lo:hi], minvol=minvol) if hi > lo else (0.0, 0.0)
         r, f = out if isinstance(out, tuple) else (0.0, out)
-    except np.linalg.LinAlgError as e:
+    except SHARD_ERRORS as e:     # whatever happens in this rank's shard, the rank still takes part in the collective
         error = e
     r, f, flag = allreduce_max([r, f, 0.0 if error is None else 1.0], group=group)
     if flag > 0:
-        raise error if error is not None else np.linalg.LinAlgError("compute_enlargement failed on another rank")
+        # the same exception type on every rank (the ranks must take the same branch in the caller); a failure in a
+        # single-process run keeps its own type
+        if size == 1 and error is not None:
+            raise error
+        raise np.linalg.LinAlgError("compute_enlargement failed on rank(s) of the group") from error
     return float(r), float(f)
 
 

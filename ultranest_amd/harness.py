@@ -93,15 +93,22 @@ class RegionUpdater(object):
                 with np.errstate(invalid='raise'):
                     tregion = WrappingEllipsoid(active_p)
                     rank, size = distributed.world(self.group)
-                    masks = distributed.broadcast_masks(
-                        None if rank else _draw(len(active_p), nbootstraps), len(active_p), nbootstraps, group=self.group)
+                    masks = distributed.broadcast_masks(       # every rank draws (streams stay in step), rank 0's counts
+                        _draw(len(active_p), nbootstraps), len(active_p), nbootstraps, group=self.group)
                     lo, hi = distributed.shard_bounds(nbootstraps, rank, size)
-                    f = tregion.enlargement_from_masks(masks[lo:hi]) if hi > lo else 0.0
-                    tregion.enlarge = float(distributed.allreduce_max([f], group=self.group)[0])
+                    f, failed = 0.0, 0.0
+                    try:      # the shard may fail on ONE rank only: every rank still joins the all-reduce
+                        f = tregion.enlargement_from_masks(masks[lo:hi]) if hi > lo else 0.0
+                    except distributed.SHARD_ERRORS:
+                        failed = 1.0
+                    f, failed = distributed.allreduce_max([f, failed], group=self.group)
+                    if failed > 0:
+                        raise np.linalg.LinAlgError("tregion bootstrap failed on a rank")
+                    tregion.enlarge = float(f)
                     tregion.create_ellipsoid()
                     self.tregion = tregion
             except (FloatingPointError, np.linalg.LinAlgError):
-                self.tregion = None
+                self.tregion = None       # on every rank alike
         return updated
 
 

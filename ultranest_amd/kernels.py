@@ -57,16 +57,28 @@ def maxradiussq_bootstrap(unormed, selected):
 
     Returns (r2[B] -- already float32-rounded like the reference's ``cdef float`` --, skipped[B])."""
     pts = f64(unormed)
-    sel = np.ascontiguousarray(selected, dtype=np.uint8)
-    if sel.ndim == 1:
-        sel = sel[None, :]
-    B, n = sel.shape
+    sel_ptr, B, n, _keep = _mask_arg(selected)
     if n != pts.shape[0]:
         raise ValueError("selection mask length != number of points")
     r2 = np.empty(B, dtype=np.float64)
     skipped = np.empty(B, dtype=np.uint8)
-    check(_lib.lib().mlf_maxradiussq_bootstrap(ptr(pts), n, pts.shape[1], ptr(sel), B, ptr(r2), ptr(skipped)))
+    check(_lib.lib().mlf_maxradiussq_bootstrap(ptr(pts), n, pts.shape[1], sel_ptr, B, ptr(r2), ptr(skipped)))
     return r2, skipped.astype(bool)
+
+
+def _mask_arg(selected):
+    """(pointer, B, n, keep-alive) of a (B, n) selection matrix: numpy bool / uint8 on the host, or a uint8 torch
+    tensor on the device (the masks of a device-side broadcast stay where they are)."""
+    if hasattr(selected, "data_ptr"):          # torch tensor
+        t = selected if selected.dim() == 2 else selected[None, :]
+        if not t.is_contiguous():
+            t = t.contiguous()
+        assert t.element_size() == 1, t.dtype
+        return ctypes.c_void_p(t.data_ptr()), int(t.shape[0]), int(t.shape[1]), t
+    sel = np.ascontiguousarray(selected, dtype=np.uint8)
+    if sel.ndim == 1:
+        sel = sel[None, :]
+    return ptr(sel), sel.shape[0], sel.shape[1], sel
 
 
 def compute_mean_pair_distance(pts, clusterids):
@@ -134,10 +146,9 @@ def bootstrap_factor(u, selected, scale):
     """f[B]: per round the largest quadratic form of the left-out rows with the (scale x) covariance of
     the selected rows, all on the device (d <= 64); NaN marks a round with a singular matrix."""
     u = f64(u)
-    sel = np.ascontiguousarray(selected, dtype=np.uint8)
-    B, n = sel.shape
+    sel_ptr, B, n, _keep = _mask_arg(selected)
     f = np.empty(B)
-    check(_lib.lib().mlf_bootstrap_factor(ptr(u), n, u.shape[1], ptr(sel), B, float(scale), ptr(f)))
+    check(_lib.lib().mlf_bootstrap_factor(ptr(u), n, u.shape[1], sel_ptr, B, float(scale), ptr(f)))
     return f
 
 

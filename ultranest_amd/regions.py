@@ -96,10 +96,23 @@ def _draw_selection(rng, npoints, nbootstraps):
     return masks
 
 
+def _select_rounds(masks, use):
+    """rows `use` of the (B, N) selection matrix (numpy on the host or a torch tensor on the device)"""
+    if use.all():
+        return masks
+    if hasattr(masks, "data_ptr"):
+        import torch
+        return masks[torch.from_numpy(np.flatnonzero(use)).to(masks.device)]
+    return masks[use]
+
+
 def _bootstrap_enlargement(u, masks, minvol):
     """Per-round wrapping-ellipsoid enlargement f_b (reference mlfriends.pyx:1056-1066):
     ellipsoid of the selected points, largest Mahalanobis distance of the left-out ones."""
     nrounds, ndim = len(masks), u.shape[1]
+    on_device = hasattr(masks, "data_ptr")        # uint8 torch tensor from a device-side broadcast
+    if on_device and (STRICT_HOST_MOMENTS or not (minvol == 0 and ndim <= 64)):
+        masks, on_device = masks.cpu().numpy().astype(bool), False
     if STRICT_HOST_MOMENTS:
         ctrs = np.empty((nrounds, ndim))
         covs = np.empty((nrounds, ndim, ndim))
@@ -318,7 +331,7 @@ class MLFriends(object):
         use = ~skipped
         if use.any():
             maxd = float(r2[use].max())
-            f = _bootstrap_enlargement(self.u, masks[use], minvol)
+            f = _bootstrap_enlargement(self.u, _select_rounds(masks, use), minvol)
             assert np.isfinite(f).all(), (f, self.unormed)
             if not (f > 0).all():
                 raise np.linalg.LinAlgError("Distances are not positive")
