@@ -140,13 +140,11 @@ def test_run_summaries_and_stores_under_the_stock_driver(monkeypatch, tmp_path):
                  "count_tree_between", "find_nodes_before", "logz_sequence"):
         assert hasattr(integ, name)
         monkeypatch.setattr(integ, name, getattr(mynet, name))
-    for name in ("make_run_dir", "resample_equal", "vectorize", "distributed_work_chunk_size"):
+    for name in ("make_run_dir", "resample_equal"):
         assert hasattr(integ, name)
         monkeypatch.setattr(integ, name, getattr(myutils, name))
     for name in ("NullPointStore", "TextPointStore"):
         monkeypatch.setattr(integ, name, getattr(mystore, name))
-    import ultranest_amd.ordertest as myorder
-    monkeypatch.setattr(integ, "UniformOrderAccumulator", myorder.UniformOrderAccumulator)      # integrator.py:35, :2609
     ndim, sigma = 5, 0.01
     centers = np.ones(ndim) * 0.5
 

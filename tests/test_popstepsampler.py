@@ -55,44 +55,6 @@ def test_trace_equals_reference(backend, golden, name, popsize, nsteps):
     assert isinstance(sampler.status, str)
 
 
-def test_simple_slice_sampler_moves_points_above_threshold(backend, golden):
-    """Sanity of the PopulationSimpleSliceSampler loop (cf. reference
-    tests/test_popstepsampling.py:222-260): accepted points beat Lmin and stay in the cube."""
-    import ultranest_amd.popstepsampler as pop
-    g = golden("g9_stepfuncs")
-    region = _region(g)
-    u = region.u
-    Ls = inputs.walker_loglike(u)
-    Lmin = np.sort(Ls)[20]
-    np.random.seed(4)
-    sampler = pop.PopulationSimpleSliceSampler(popsize=50, nsteps=3, generate_direction=pop.generate_random_direction)
-    region.transformLayer.transform = lambda x: np.dot(x - g["region_ctr"], g["region_T"])
-    out = [sampler.__next__(region, Lmin, u, Ls, inputs.walker_transform, inputs.walker_loglike) for _ in range(50)]
-    L = np.array([o[2] for o in out])
-    pts = np.array([o[0] for o in out])
-    assert (L > Lmin).all()
-    assert np.logical_and(pts > 0, pts < 1).all()
-    assert out[0][3] > 0 and all(o[3] == 0 for o in out[1:])
-    assert np.allclose(L, inputs.walker_loglike(pts))
-
-
-def test_random_walk_sampler(backend, golden):
-    import ultranest_amd.popstepsampler as pop
-    g = golden("g9_stepfuncs")
-    region = _region(g)
-    region.transformLayer.transform = lambda x: np.dot(x - g["region_ctr"], g["region_T"])
-    u = region.u
-    Ls = inputs.walker_loglike(u)
-    Lmin = np.sort(Ls)[2]
-    np.random.seed(5)
-    sampler = pop.PopulationRandomWalkSampler(popsize=30, nsteps=40, generate_direction=pop.generate_random_direction,
-                                              scale=0.05)
-    out = [sampler.__next__(region, Lmin, u, Ls, inputs.walker_transform, inputs.walker_loglike) for _ in range(30)]
-    L = np.array([o[2] for o in out])
-    assert (L > Lmin).all() and out[0][3] == 1200
-    assert sampler.scale != 0.05
-
-
 # ---- GPU-only: resident likelihood and the Philox stream -----------------------------------------
 
 def _ball_problem(d, nlive, seed):

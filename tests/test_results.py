@@ -172,34 +172,6 @@ def test_resample_equal_and_run_dir(golden, tmp_path):
     assert sorted(os.listdir(first["run_dir"])) == ["chains", "extra", "info", "plots", "results"]
     flat = utils.make_run_dir(str(tmp_path / "flat"), append_run_num=False)
     assert flat["run_dir"] == str(tmp_path / "flat") and os.path.isdir(flat["chains"])
-    assert [utils.distributed_work_chunk_size(30, r, 8) for r in range(8)] == [4, 4, 4, 4, 4, 4, 3, 3]
-    mask = np.array([1, 0, 1, 1, 0, 1], dtype=bool)
-    assert list(utils.submasks(mask, np.array([0, 1, 1, 1], dtype=bool), np.array([1, 0, 1], dtype=bool))) == [2, 5]
-    assert list(utils.vectorize(lambda x: x.sum())(np.arange(6.).reshape(3, 2))) == [1., 5., 9.]
-
-
-# reference tests/test_utils.py:9-30, :98-112, :114-120 (the helpers this package provides)
-def test_vectorize_like_the_reference_test():
-    from ultranest_amd.utils import vectorize
-
-    def myfunc(x):
-        return (x**2).sum()
-
-    a = np.array([1.2, 2.3, 3.4])
-    np.testing.assert_allclose(np.array([myfunc(a)]), vectorize(myfunc)([a]))
-    b = np.array([[1.2, 2.3, 3.4], [1.2, 2.3, 3.4]])
-    np.testing.assert_allclose(np.array([myfunc(b[0]), myfunc(b[1])]), vectorize(myfunc)(b))
-
-    class FuncClass(object):
-        def __call__(self, x):
-            return (x**2).sum()
-
-        def foo(self, x):
-            return x
-
-    caller = FuncClass()
-    assert vectorize(caller)(b).shape == (2,)          # callables without __name__ are fine
-    assert vectorize(caller.foo)(b).shape == (2, 3)
 
 
 def test_make_run_dir_numbering_limit(tmp_path):
@@ -211,12 +183,3 @@ def test_make_run_dir_numbering_limit(tmp_path):
     assert os.path.exists(os.path.join(base, 'run2'))
     with pytest.raises(ValueError):
         make_run_dir(base, max_run_num=3)
-
-
-@pytest.mark.parametrize("mpi_size", [1, 4, 10, 37, 53, 100, 1000, 513])
-@pytest.mark.parametrize("missing", [0, 1, 4, 10, 17, 31, 100, 1000, 513])
-def test_distributed_work_chunk_size_is_balanced(mpi_size, missing):
-    from ultranest_amd.utils import distributed_work_chunk_size
-    todo = [distributed_work_chunk_size(missing, rank, mpi_size) for rank in range(mpi_size)]
-    assert sum(todo) == missing
-    assert max(todo) - min(todo) in {0, 1}

@@ -18,73 +18,106 @@ from ._lib import check, ptr
 
 
 class TreeNode(object):
-    """Tree node: ordering value (log-likelihood), point id, children (reference :34-60)."""
+    """One point of the nested-sampling tree: `value` orders the nodes (log-likelihood), `id` is the row of the
+    point in the :class:`PointPile`, `children` the points that replaced it (reference netiter.py:34-60)."""
+
+    __slots__ = ("value", "id", "children")
 
     def __init__(self, value=None, id=None, children=None):
-        self.value = value
-        self.id = id
-        self.children = children or []
-
-    def __str__(self, indent=0):
-        return ' ' * indent + '- Node: %s\n' % self.value + '\n'.join(
-            [c.__str__(indent=indent + 2) for c in self.children])
+        self.value, self.id = value, id
+        self.children = [] if not children else children
 
     def __lt__(self, other):
         return self.value < other.value
 
+    def __str__(self, indent=0):
+        lines = ["%s- Node: %s" % (" " * indent, self.value)]
+        lines += [child.__str__(indent=indent + 2) for child in self.children]
+        return "\n".join(lines) if len(lines) > 1 else lines[0] + "\n"
+
 
 class BreadthFirstIterator(object):
-    """Explores the tree in order of node value; the nodes crossed "in parallel" are the live
-    points (reference :63-162).  Same attributes: ``active_nodes``, ``active_root_ids``,
-    ``active_node_values``, ``active_node_ids``."""
+    """Walks the tree in ascending order of node value.  The nodes the walk is currently "passing in parallel" are the
+    live points (reference netiter.py:63-162).  The live set is kept as four parallel columns -- node objects, root
+    index, value, point id -- in preallocated buffers with a fill count (the driver advances this structure once per
+    iteration; growing numpy arrays by concatenation, as a literal reading of the reference would, costs a
+    reallocation each time a node forks).  The public attributes are views of the filled part and keep the reference's
+    names: ``active_nodes``, ``active_root_ids``, ``active_node_values``, ``active_node_ids``; ordering rules that are
+    observable downstream are kept: an only child inherits its parent's slot, the children of a fork go to the end."""
 
     def __init__(self, roots):
         self.roots = roots
         self.reset()
 
     def reset(self):
-        self.active_nodes = list(self.roots)
-        self.active_root_ids = np.arange(len(self.active_nodes))
-        self.active_node_values = np.array([n.value for n in self.active_nodes])
-        self.active_node_ids = np.array([n.id for n in self.active_nodes])
+        n = len(self.roots)
+        self._cap = max(16, 2 * n)
+        self._n = n
+        self._nodes = list(self.roots)
+        self._root = np.empty(self._cap, dtype=np.int64)
+        self._val = np.empty(self._cap, dtype=np.float64)
+        self._ids = np.empty(self._cap, dtype=np.int64)
+        self._root[:n] = np.arange(n)
+        if n:
+            self._val[:n] = [node.value for node in self.roots]
+            self._ids[:n] = [node.id for node in self.roots]
+        self.next_index = None
+
+    active_nodes = property(lambda self: self._nodes)
+    active_root_ids = property(lambda self: self._root[:self._n])
+    active_node_values = property(lambda self: self._val[:self._n])
+    active_node_ids = property(lambda self: self._ids[:self._n])
 
     def next_node(self):
-        """``(rootid, node, (active_nodes, active_root_ids, active_node_values, active_node_ids))``
-        of the lowest active node (left in the active set), or None when the tree is exhausted."""
-        if self.active_nodes == []:
+        """``(rootid, node, (active_nodes, active_root_ids, active_node_values, active_node_ids))`` of the live node
+        with the lowest value -- it stays in the live set until dropped or expanded -- or None when nothing is left."""
+        if self._n == 0:
             return None
-        self.next_index = i = np.argmin(self.active_node_values)
-        return self.active_root_ids[i], self.active_nodes[i], (
-            self.active_nodes, self.active_root_ids, self.active_node_values, self.active_node_ids)
+        i = self.next_index = int(np.argmin(self._val[:self._n]))
+        return self._root[i], self._nodes[i], (self._nodes, self.active_root_ids, self.active_node_values,
+                                               self.active_node_ids)
 
-    def _remove_current(self):
-        i = self.next_index
-        self.active_nodes.pop(i)
-        self.active_node_values = np.delete(self.active_node_values, i)
-        self.active_root_ids = np.delete(self.active_root_ids, i)
-        self.active_node_ids = np.delete(self.active_node_ids, i)
+    def _close_gap(self, i):
+        n = self._n
+        del self._nodes[i]
+        for col in (self._root, self._val, self._ids):
+            col[i:n - 1] = col[i + 1:n]
+        self._n = n - 1
+
+    def _grow_for(self, extra):
+        need = self._n + extra
+        if need <= self._cap:
+            return
+        self._cap = max(need, 2 * self._cap)
+        for name in ("_root", "_val", "_ids"):
+            old = getattr(self, name)
+            new = np.empty(self._cap, dtype=old.dtype)
+            new[:self._n] = old[:self._n]
+            setattr(self, name, new)
 
     def drop_next_node(self):
-        """Forget the current node (reference :110-120)."""
-        self._remove_current()
+        """Take the current node out of the live set without following its children (reference :110-120)."""
+        self._close_gap(self.next_index)
 
     def expand_children_of(self, rootid, node):
-        """Replace the current node by its children: an only child takes its slot, several are
-        appended at the end (reference :122-161)."""
+        """The current node dies: one child -> it takes over the slot; a fork -> the slot closes and the children
+        join at the end; a leaf -> the slot just closes (reference :122-161)."""
         kids = node.children
+        i = self.next_index
         if len(kids) == 1:
-            i = self.next_index
-            self.active_nodes[i] = kids[0]
-            self.active_node_values[i] = kids[0].value
-            self.active_root_ids[i] = rootid
-            self.active_node_ids[i] = kids[0].id
+            only = kids[0]
+            self._nodes[i] = only
+            self._root[i], self._val[i], self._ids[i] = rootid, only.value, only.id
             return
-        self._remove_current()
+        self._close_gap(i)
         if kids:
-            self.active_nodes += kids
-            self.active_node_values = np.concatenate((self.active_node_values, [c.value for c in kids]))
-            self.active_root_ids = np.concatenate((self.active_root_ids, [rootid for c in kids]))
-            self.active_node_ids = np.concatenate((self.active_node_ids, [c.id for c in kids]))
+            self._grow_for(len(kids))
+            lo, hi = self._n, self._n + len(kids)
+            self._nodes.extend(kids)
+            self._root[lo:hi] = rootid
+            self._val[lo:hi] = [k.value for k in kids]
+            self._ids[lo:hi] = [k.id for k in kids]
+            self._n = hi
 
 
 class _OrderAccumulatorView(object):
@@ -129,10 +162,8 @@ class MultiCounter(object):
             mask[np.unique(np.random.randint(nroots, size=nroots))] = True
             rows.append(mask)
         self.rootids = np.array(rows)
-        self.random = random
-        self.ncounters = len(self.rootids)
-        self.check_insertion_order = check_insertion_order
-        self.insertion_order_threshold = 4
+        self.random, self.check_insertion_order = random, check_insertion_order
+        self.ncounters, self.insertion_order_threshold = len(self.rootids), 4
         handle = ctypes.c_void_p()
         member = np.ascontiguousarray(self.rootids, dtype=np.uint8)
         check(_lib.lib().mlf_counter_create(ctypes.byref(handle), nroots, self.ncounters, ptr(member), int(bool(random)),
@@ -153,9 +184,7 @@ class MultiCounter(object):
 
     def reset(self, nentries):
         assert nentries == self.ncounters
-        self.logweights = []
-        self.istail = []
-        self.Lmax = -np.inf
+        self.logweights, self.istail, self.Lmax = [], [], -np.inf
         check(_lib.lib().mlf_counter_reset(self._h))
         self._cache = None
 
@@ -193,15 +222,9 @@ class MultiCounter(object):
     all_logZremain = property(lambda self: self._state()[1][3])
     insertion_order_runs = property(lambda self: self._state()[2])
 
-    @property
-    def logZ_bs(self):
-        """logZ of the bootstrap ensemble"""
-        return self.all_logZ[1:].mean()
-
-    @property
-    def logZerr_bs(self):
-        """logZ scatter of the bootstrap ensemble"""
-        return self.all_logZ[1:].std()
+    # mean and scatter of ln Z over the bootstrap counters (everything but counter 0)
+    logZ_bs = property(lambda self: np.mean(self.all_logZ[1:]))
+    logZerr_bs = property(lambda self: np.std(self.all_logZ[1:]))
 
     @property
     def insertion_order_runlength(self):
@@ -253,226 +276,221 @@ class MultiCounter(object):
 def _walk(roots):
     """Yield (explorer, rootid, node, active_rootids) in the driver's breadth-first order; the consumer
     decides whether to expand, drop or stop."""
-    explorer = BreadthFirstIterator(roots)
-    while True:
-        nxt = explorer.next_node()
-        if nxt is None:
-            return
-        rootid, node, (_, active_rootids, _, _) = nxt
-        yield explorer, rootid, node, active_rootids
+    walk = BreadthFirstIterator(roots)
+    step = walk.next_node()
+    while step is not None:
+        yield walk, step[0], step[1], step[2][1]
+        step = walk.next_node()
+
+
+def _tree_extent(roots, lo=-np.inf, hi=np.inf):
+    """nodes with lo <= value <= hi, and the widest live set seen while one of them was the lowest node"""
+    size = width = 0
+    for walk, rootid, node, live_roots in _walk(roots):
+        if node.value > hi:
+            break
+        if node.value >= lo:
+            size, width = size + 1, max(width, len(live_roots))
+        walk.expand_children_of(rootid, node)
+    return size, width
 
 
 def count_tree(roots):
     """(number of nodes, largest number of parallel edges) of a tree (reference netiter.py:259-285)."""
-    nnodes = maxwidth = 0
-    for explorer, rootid, node, active_rootids in _walk(roots):
-        nnodes += 1
-        maxwidth = max(maxwidth, len(active_rootids))
-        explorer.expand_children_of(rootid, node)
-    return nnodes, maxwidth
+    return _tree_extent(roots)
 
 
 def count_tree_between(roots, lo, hi):
     """As :func:`count_tree`, restricted to nodes with lo <= value <= hi (reference :288-330)."""
-    nnodes = maxwidth = 0
-    for explorer, rootid, node, active_rootids in _walk(roots):
-        if node.value > hi:
-            break
-        if node.value >= lo:
-            nnodes += 1
-            maxwidth = max(maxwidth, len(active_rootids))
-        explorer.expand_children_of(rootid, node)
-    return nnodes, maxwidth
+    return _tree_extent(roots, lo, hi)
 
 
 def find_nodes_before(root, value):
-    """Nodes that have a child at or above `value`, and for each the product of the fork counts on its
-    path from the root's children (reference :333-383).  If a root child itself is at or above `value`
-    the answer ends with `root` (weight 1)."""
-    parents, parent_weights = [], []
-    nforks = dict((n.id, 1.) for n in root.children)
-    for explorer, rootid, node, _ in _walk(root.children):
-        mine = nforks.pop(node.id)
+    """The places of the tree where the likelihood threshold `value` is crossed (reference netiter.py:333-383):
+    every node below `value` that has a child at or above it, each with the number of siblings-at-every-fork along
+    its path (product of the fork widths from the root's children down); the subtree of such a node is not looked at
+    any further.  If one of the root's children is itself at or above `value`, `root` closes the list with weight 1.
+    The answer is ordered like the breadth-first walk would find it: by ascending node value."""
+    found = []
+    reaches_root = False
+    stack = [(child, 1.) for child in reversed(root.children)]
+    while stack:
+        node, weight = stack.pop()
         if node.value >= value:
-            parents.append(root)
-            parent_weights.append(1)
-            break
-        if any(child.value >= value for child in node.children):
-            parents.append(node)
-            parent_weights.append(mine)
-            explorer.drop_next_node()
+            reaches_root = True          # only children of the root can get here: deeper ones end at their parent
             continue
-        explorer.expand_children_of(rootid, node)
-        for child in node.children:
-            nforks[child.id] = mine * len(node.children)
+        kids = node.children
+        if any(k.value >= value for k in kids):
+            found.append((node.value, len(found), node, weight))
+            continue
+        stack.extend((k, weight * len(kids)) for k in reversed(kids))
+    found.sort(key=lambda item: item[:2])
+    parents = [item[2] for item in found]
+    parent_weights = [item[3] for item in found]
+    if reaches_root:
+        parents.append(root)
+        parent_weights.append(1)
     return parents, parent_weights
 
 
 class PointPile(object):
-    """Growing table of the coordinates of every tree node: row ``node.id`` holds the unit-cube point and
-    the transformed point (reference netiter.py:386-465; same attribute names ``us``, ``ps``, ``nrows``)."""
+    """Append-only table of the points behind the tree nodes: row ``node.id`` holds the unit-cube coordinates and the
+    transformed parameters (reference netiter.py:386-465; attributes ``us``, ``ps``, ``nrows``, ``udim``, ``pdim``,
+    ``chunksize``).  One buffer with both blocks side by side, grown geometrically; ``us`` / ``ps`` are views of it
+    (at least `chunksize` rows are allocated from the start, as callers slice them with ``[:nrows]``)."""
 
     def __init__(self, udim, pdim, chunksize=1000):
+        self.udim, self.pdim, self.chunksize = udim, pdim, chunksize
         self.nrows = 0
-        self.chunksize = chunksize
-        self.udim = udim
-        self.pdim = pdim
-        self.us = np.zeros((chunksize, udim))
-        self.ps = np.zeros((chunksize, pdim))
+        self._table = np.zeros((chunksize, udim + pdim))
+
+    us = property(lambda self: self._table[:, :self.udim])
+    ps = property(lambda self: self._table[:, self.udim:])
 
     def add(self, newpointu, newpointp):
-        """Append one point; returns its row index."""
-        assert len(newpointu) == self.udim, (newpointu, self.us.shape)
-        assert len(newpointp) == self.pdim, (newpointp, self.ps.shape)
-        if self.nrows == len(self.us):
-            self.us = np.concatenate((self.us, np.zeros((self.chunksize, self.udim))))
-            self.ps = np.concatenate((self.ps, np.zeros((self.chunksize, self.pdim))))
+        """Store one point, return its row."""
+        newpointu, newpointp = np.asarray(newpointu), np.asarray(newpointp)
+        if newpointu.shape != (self.udim,) or newpointp.shape != (self.pdim,):
+            raise AssertionError((newpointu.shape, newpointp.shape, self.udim, self.pdim))
         row = self.nrows
-        self.us[row] = newpointu
-        self.ps[row] = newpointp
+        if row == len(self._table):
+            bigger = np.zeros((max(row + self.chunksize, 2 * row), self.udim + self.pdim))
+            bigger[:row] = self._table
+            self._table = bigger
+        self._table[row, :self.udim] = newpointu
+        self._table[row, self.udim:] = newpointp
         self.nrows = row + 1
         return row
 
     def getu(self, i):
-        return self.us[i]
+        return self._table[i, :self.udim]
 
     def getp(self, i):
-        return self.ps[i]
+        return self._table[i, self.udim:]
 
     def make_node(self, value, u, p):
-        """Store the point and return the tree node that refers to it."""
+        """Store the point and hand back the tree node that points at it."""
         return TreeNode(value=value, id=self.add(u, p))
 
 
-def combine_results(saved_logl, saved_nodeids, pointpile, main_iterator, mpi_comm=None):
-    """Summary dictionary of a finished exploration (reference netiter.py:858-972): evidence with its
-    bootstrap and tail uncertainties, effective sample size, information, weighted and equally weighted
-    posterior samples, posterior summaries, best fit.  Keys and value types follow the reference, which is
-    what ``info/results.json`` and the ``chains/`` files are written from.  `mpi_comm` is accepted for
-    signature compatibility; this build shards over torch.distributed, not MPI (must be None)."""
-    assert mpi_comm is None, "MPI exchange is not part of this build"
-    from .utils import resample_equal
-    saved_logl = np.array(saved_logl)
-    logwt = np.array(main_iterator.logweights)
-    all_logZ = np.asarray(main_iterator.all_logZ)
-    assert logwt.shape == (len(saved_logl), len(all_logZ)), (logwt.shape, saved_logl.shape, all_logZ.shape)
-    saved_u = pointpile.getu(saved_nodeids)
-    saved_v = pointpile.getp(saved_nodeids)
-    logwt0, logwt_bs = logwt[:, 0], logwt[:, 1:]
-    logZ_bs = all_logZ[1:]
-    logZ = main_iterator.logZ
-
-    wt_bs = np.exp(logwt_bs + saved_logl.reshape((-1, 1)) - logZ_bs)
-    wt0 = np.exp(logwt0 + saved_logl - all_logZ[0])
-    w = wt0 / wt0.sum()
-    assert np.isclose(w.sum() - 1, 0), w.sum()
+def _kish_ess(w):
+    """effective sample size of normalised weights in the reference's form N / (1 + mean((N w - 1)^2))"""
     n = len(w)
-    ess = n / (1.0 + ((n * w - 1)**2).sum() / n)
-    tail_fraction = w[np.asarray(main_iterator.istail)].sum()
-    logzerr_tail = 0
-    if tail_fraction != 0:
-        logzerr_tail = np.logaddexp(np.log(tail_fraction) + logZ, logZ) - logZ
-    logzerr_bs = (logZ_bs - logZ).max()
-    samples = resample_equal(saved_v, w)
+    return n / (1.0 + np.mean((n * w - 1) ** 2))
 
-    # per-axis information gain from a 39-bin weighted histogram of the cube coordinates
-    edges = np.linspace(0, 1, 40)
-    information_gain_bits = []
-    for column in saved_u.T:
-        density, _ = np.histogram(column, weights=wt0, density=True, bins=edges)
-        information_gain_bits.append(float((np.log2(1 / ((density + 0.001) * 40)) / 40).sum()))
 
-    best = saved_logl.argmax()
-    all_H = np.asarray(main_iterator.all_H)
+def _axis_information_bits(upoints, weights, nbins=40):
+    """Per unit-cube axis: how far the weighted marginal departs from uniform, in bits (reference netiter.py:915-922):
+    histogram density on nbins - 1 equal bins of [0, 1], then sum(log2(1 / ((density + 0.001) nbins)) / nbins)."""
+    edges = np.linspace(0, 1, nbins)
+    bits = []
+    for column in upoints.T:
+        density = np.histogram(column, bins=edges, weights=weights, density=True)[0]
+        bits.append(float(np.sum(np.log2(1.0 / ((density + 0.001) * nbins)) / nbins)))
+    return bits
+
+
+def _posterior_summary(samples):
+    lo, mid, hi = np.percentile(samples, [15.8655, 50, 84.1345], axis=0)
+    return dict(mean=samples.mean(axis=0).tolist(), stdev=samples.std(axis=0).tolist(), median=mid.tolist(),
+                errlo=lo.tolist(), errup=hi.tolist())
+
+
+def combine_results(saved_logl, saved_nodeids, pointpile, main_iterator, mpi_comm=None):
+    """What a finished walk over the tree says (reference netiter.py:858-972): evidence of the main counter, its
+    scatter over the bootstrap counters and the share of the still-live tail, information, effective sample size,
+    weighted and equally weighted posterior samples with their summaries, the best fit.  The dictionary layout is the
+    reference's (``info/results.json`` and the ``chains/`` files are written from it).  Under MPI the reference
+    gathers the bootstrap columns of all ranks; this build shards over torch.distributed only, so an MPI communicator
+    is refused up front."""
+    if mpi_comm is not None:
+        raise NotImplementedError("combine_results: MPI gathering is not part of this build (pass mpi_comm=None)")
+    from .utils import resample_equal
+    logl = np.asarray(saved_logl, dtype=float)
+    logwidths = np.asarray(main_iterator.logweights)             # (iterations, counters): column 0 = all roots
+    logz_all = np.asarray(main_iterator.all_logZ)
+    if logwidths.shape != (len(logl), len(logz_all)):
+        raise AssertionError((logwidths.shape, logl.shape, logz_all.shape))
+    logz = main_iterator.logZ
+    upoints, points = pointpile.getu(saved_nodeids), pointpile.getp(saved_nodeids)
+
+    # posterior weights of every counter at once; the main counter's column, normalised, drives everything below
+    weights_all = np.exp(logwidths + logl[:, None] - logz_all[None, :])
+    main = weights_all[:, 0]
+    w = main / main.sum()
+    if not np.isclose(w.sum(), 1):
+        raise AssertionError(w.sum())
+    tail_share = w[np.asarray(main_iterator.istail, dtype=bool)].sum()
+    logzerr_tail = 0 if tail_share == 0 else np.logaddexp(np.log(tail_share) + logz, logz) - logz
+    logz_boot = logz_all[1:]
+    logzerr_bs = (logz_boot - logz).max()
+    samples = resample_equal(points, w)
+    posterior = _posterior_summary(samples)
+    posterior["information_gain_bits"] = _axis_information_bits(upoints, main)
+    info_all = np.asarray(main_iterator.all_H)
+    top = int(np.argmax(logl))
     results = dict(
-        niter=len(saved_logl),
-        logz=logZ, logzerr=(logzerr_tail**2 + logzerr_bs**2)**0.5,
-        logz_bs=logZ_bs.mean(),
-        logz_single=logZ,
-        logzerr_tail=logzerr_tail,
-        logzerr_bs=logzerr_bs,
-        ess=ess,
-        H=all_H[0], Herr=all_H.std(),
-        posterior=dict(
-            mean=samples.mean(axis=0).tolist(),
-            stdev=samples.std(axis=0).tolist(),
-            median=np.percentile(samples, 50, axis=0).tolist(),
-            errlo=np.percentile(samples, 15.8655, axis=0).tolist(),
-            errup=np.percentile(samples, 84.1345, axis=0).tolist(),
-            information_gain_bits=information_gain_bits,
-        ),
-        weighted_samples=dict(
-            upoints=saved_u, points=saved_v, weights=wt0, logw=logwt0,
-            bootstrapped_weights=wt_bs, logl=saved_logl),
+        niter=len(logl),
+        logz=logz, logzerr=float(np.hypot(logzerr_tail, logzerr_bs)),
+        logz_bs=logz_boot.mean(), logz_single=logz,
+        logzerr_tail=logzerr_tail, logzerr_bs=logzerr_bs,
+        ess=_kish_ess(w),
+        H=info_all[0], Herr=info_all.std(),
+        posterior=posterior,
+        weighted_samples=dict(upoints=upoints, points=points, weights=main, logw=logwidths[:, 0],
+                              bootstrapped_weights=weights_all[:, 1:], logl=logl),
         samples=samples,
-        maximum_likelihood=dict(
-            logl=saved_logl[best],
-            point=saved_v[best, :].tolist(),
-            point_untransformed=saved_u[best, :].tolist(),
-        ),
+        maximum_likelihood=dict(logl=logl[top], point=points[top, :].tolist(),
+                                point_untransformed=upoints[top, :].tolist()),
     )
     if getattr(main_iterator, 'check_insertion_order', False):
-        results['insertion_order_MWW_test'] = dict(
-            independent_iterations=main_iterator.insertion_order_runlength,
-            converged=main_iterator.insertion_order_converged,
-        )
+        results['insertion_order_MWW_test'] = dict(independent_iterations=main_iterator.insertion_order_runlength,
+                                                   converged=main_iterator.insertion_order_converged)
     return results
 
 
 def logz_sequence(root, pointpile, nbootstraps=12, random=True, onNode=None, verbose=False,
                   check_insertion_order=True):
-    """Replay the whole tree under `root` through a fresh :class:`MultiCounter` and record, per
-    iteration, evidence, its bootstrap scatter, remaining volume, live count and the insertion rank
-    of the replacement (reference netiter.py:975-1095).  Returns ``(sequence, results)`` like the
-    reference (its docstring states the opposite order)."""
+    """Replay the tree below `root` through a fresh :class:`MultiCounter` and keep, for every iteration, what the
+    run looked like just before the node died: evidence and its bootstrap scatter, remaining volume, number of live
+    points, and where the replacement landed among the live likelihoods (reference netiter.py:975-1095).  Returns
+    ``(sequence, results)``, the order the reference implements (its docstring says the opposite)."""
     import sys
     roots = root.children
-    explorer = BreadthFirstIterator(roots)
+    walk = BreadthFirstIterator(roots)
     counter = MultiCounter(nroots=len(roots), nbootstraps=max(1, nbootstraps), random=random,
                            check_insertion_order=check_insertion_order)
-    counter.Lmax = max(-np.inf, max(n.value for n in roots))
-    logz, logzerr, nlive, logvol, insert_order = [], [], [], [], []
-    saved_nodeids, saved_logl = [], []
-    while True:
-        nxt = explorer.next_node()
-        if nxt is None:
-            break
-        rootid, node, (_, active_rootids, active_values, _) = nxt
+    counter.Lmax = max([-np.inf] + [n.value for n in roots])
+    track = dict(logz=[], logzerr=[], logvol=[], nlive=[], insert_order=[], logl=[], nodeid=[])
+    step = walk.next_node()
+    while step is not None:
+        rootid, node, (_, live_roots, live_values, _) = step
         if onNode:
             onNode(node, counter)
-        logz.append(counter.logZ)
+        nlive = len(live_values)
         with np.errstate(invalid='ignore'):
-            logzerr.append(counter.logZerr_bs)
-        nactive = len(active_values)
-        # rank of the first child among the live values, only defined without ties
-        if node.children and len(np.unique(active_values)) == nactive:
-            rank = (active_values > node.children[0].value).sum()
-            insert_order.append(2 * (rank + 1.) / nactive)
-        else:
-            insert_order.append(np.nan)
-        nlive.append(nactive)
-        logvol.append(counter.logVolremaining)
+            scatter = counter.logZerr_bs
+        # insertion rank of the first replacement among the live values; undefined when values tie
+        order = np.nan
+        if node.children and len(np.unique(live_values)) == nlive:
+            order = 2 * (np.count_nonzero(live_values > node.children[0].value) + 1.) / nlive
+        for key, item in (("logz", counter.logZ), ("logzerr", scatter), ("logvol", counter.logVolremaining),
+                          ("nlive", nlive), ("insert_order", order), ("logl", node.value), ("nodeid", node.id)):
+            track[key].append(item)
         if verbose:
-            sys.stderr.write("%d...\r" % (len(saved_logl) + 1))
-        saved_logl.append(node.value)
-        saved_nodeids.append(node.id)
-        counter.passing_node(rootid, node, active_rootids, active_values)
-        explorer.expand_children_of(rootid, node)
+            sys.stderr.write("%d...\r" % len(track["logl"]))
+        counter.passing_node(rootid, node, live_roots, live_values)
+        walk.expand_children_of(rootid, node)
+        step = walk.next_node()
 
-    logwt = np.asarray(saved_logl) + np.asarray(counter.logweights)[:, 0]
-    logvol[-1] = logvol[-2]
-    results = combine_results(saved_logl, saved_nodeids, pointpile, counter)
+    track["logvol"][-1] = track["logvol"][-2]
+    results = combine_results(track["logl"], track["nodeid"], pointpile, counter)
+    nlive = np.asarray(track["nlive"])
     sequence = dict(
-        logz=np.asarray(logz),
-        logzerr=np.asarray(logzerr),
-        logvol=np.asarray(logvol),
-        samples_n=np.asarray(nlive),
-        nlive=np.asarray(nlive),
-        insert_order=np.asarray(insert_order),
-        logwt=logwt,
-        niter=len(saved_logl),
-        logl=saved_logl,
-        weights=results['weighted_samples']['weights'],
-        samples=results['weighted_samples']['points'],
+        logz=np.asarray(track["logz"]), logzerr=np.asarray(track["logzerr"]), logvol=np.asarray(track["logvol"]),
+        samples_n=nlive, nlive=nlive, insert_order=np.asarray(track["insert_order"]),
+        logwt=np.asarray(track["logl"]) + np.asarray(counter.logweights)[:, 0],
+        niter=len(track["logl"]), logl=track["logl"],
+        weights=results['weighted_samples']['weights'], samples=results['weighted_samples']['points'],
     )
     return sequence, results

@@ -61,20 +61,23 @@ class GenericPopulationSampler(object):
 
     logstat_labels = ['accept_rate', 'efficiency', 'scale', 'far_enough', 'mean_rel_jump']
 
+    def _acceptance_weighted(self, column, transform=None):
+        """average of one logstat column over the recorded steps, weighted by their acceptance rates"""
+        if not self.logstat:
+            return np.nan
+        table = np.asarray(self.logstat, dtype=float)
+        values = table[:, column] if transform is None else transform(table[:, column])
+        return np.average(values, weights=table[:, 0])
+
     @property
     def mean_jump_distance(self):
-        """Geometric mean jump distance, weighted by acceptance rate."""
-        if len(self.logstat) == 0:
-            return np.nan
-        return np.exp(np.average(np.log([row[-1] + 1e-10 for row in self.logstat]),
-                                 weights=[row[0] for row in self.logstat]))
+        """Geometric mean jump distance (in units of the MLFriends radius), weighted by acceptance rate."""
+        return np.exp(self._acceptance_weighted(-1, lambda rel: np.log(rel + 1e-10)))
 
     @property
     def far_enough_fraction(self):
         """Fraction of jumps exceeding the MLFriends radius."""
-        if len(self.logstat) == 0:
-            return np.nan
-        return np.average([row[-2] for row in self.logstat], weights=[row[0] for row in self.logstat])
+        return self._acceptance_weighted(-2)
 
     def get_info_dict(self):
         have = len(self.logstat) > 0
@@ -250,16 +253,10 @@ class PopulationSliceSampler(GenericPopulationSampler):
 
     def __init__(self, popsize, nsteps, generate_direction, scale=1.0, scale_adapt_factor=0.9, log=False,
                  logfile=None, device_rng=None):
-        self.nsteps = nsteps
-        self.nrejects = 0
-        self.scale = scale
-        self.scale_adapt_factor = scale_adapt_factor
-        self.ringindex = 0
-        self.log = log
-        self.logfile = logfile
-        self.logstat = []
-        self.popsize = popsize
-        self.generate_direction = generate_direction
+        self.popsize, self.nsteps, self.generate_direction = popsize, nsteps, generate_direction
+        self.scale, self.scale_adapt_factor = scale, scale_adapt_factor
+        self.log, self.logfile, self.logstat = log, logfile, []
+        self.nrejects = self.ringindex = 0
         if device_rng is not None and not isinstance(device_rng, DeviceRNG):
             raise TypeError("device_rng must be an ultranest_amd.regions.DeviceRNG")
         self.device_rng = device_rng
@@ -434,152 +431,9 @@ class PopulationSliceSampler(GenericPopulationSampler):
         return None, None, None, nc
 
 
-class PopulationRandomWalkSampler(GenericPopulationSampler):
-    """Vectorized Gaussian random walk (reference popstepsampler.py:197-344): `nsteps` truncated
-    normal steps along `generate_direction` for `popsize` walkers, adapting the step scale to a
-    23.4 % acceptance rate.  Host numpy around the unit-cube intersection kernel."""
-
-    def __init__(self, popsize, nsteps, generate_direction, scale, scale_adapt_factor=0.9, scale_min=1e-20,
-                 scale_max=20, log=False, logfile=None):
-        assert scale_adapt_factor <= 1
-        self.nsteps, self.popsize = nsteps, popsize
-        self.nrejects, self.ncalls = 0, 0
-        self.scale, self.scale_adapt_factor = scale, scale_adapt_factor
-        self.scale_min, self.scale_max = scale_min, scale_max
-        self.log, self.logfile = log, logfile
-        self.logstat = []
-        self.prepared_samples = []
-        self.generate_direction = generate_direction
-
-    def __str__(self):
-        return 'PopulationRandomWalkSampler(popsize=%d, nsteps=%d, generate_direction=%s, scale=%.g)' % (
-            self.popsize, self.nsteps, self.generate_direction, self.scale)
-
-    def __next__(self, region, Lmin, us, Ls, transform, loglike, ndraw=10, plot=False, tregion=None, log=False):
-        import scipy.stats
-        nlive, ndim = us.shape
-        nc = 0
-        if len(self.prepared_samples) == 0:
-            ilive = np.random.randint(0, nlive, size=self.popsize)
-            allu, allp, allL = us[ilive, :], None, Ls[ilive]
-            nc = self.nsteps * self.popsize
-            target_rejects = self.nsteps * self.popsize * (1 - 0.234)
-            nrejects_expected = self.nrejects + target_rejects
-            for _ in range(self.nsteps):
-                v = self.generate_direction(allu, region, self.scale)
-                tleft, tright = unitcube_line_intersection(allu, v)
-                step = scipy.stats.truncnorm.rvs(tleft, tright, loc=0, scale=1).reshape((-1, 1))
-                proposed_u = allu + v * step
-                outside = ~np.logical_and(proposed_u > 0, proposed_u < 1).all(axis=1)
-                assert not outside.any(), proposed_u[outside, :]
-                proposed_p = transform(proposed_u)
-                proposed_L = loglike(proposed_p)
-                accept = proposed_L > Lmin
-                self.nrejects += (~accept).sum()
-                allu[accept, :] = proposed_u[accept, :]
-                if allp is None:
-                    allp = proposed_p * np.nan
-                allp[accept, :] = proposed_p[accept, :]
-                allL[accept] = proposed_L[accept]
-            assert np.isfinite(allp).all(), 'some walkers never moved! Double nsteps of PopulationRandomWalkSampler.'
-            far_enough, (move_distance, reference_distance) = diagnose_move_distances(
-                region, us[ilive[accept], :], allu[accept, :])
-            self.prepared_samples = list(zip(allu, allp, allL))
-            self.logstat.append([
-                accept.mean(),
-                1 - (self.nrejects - (nrejects_expected - target_rejects)) / (self.nsteps * self.popsize),
-                self.scale, self.nsteps, np.mean(far_enough),
-                np.exp(np.mean(np.log(move_distance / reference_distance + 1e-10)))])
-            if self.nrejects > nrejects_expected and self.scale > self.scale_min:
-                self.scale *= self.scale_adapt_factor
-            elif self.nrejects < nrejects_expected and self.scale < self.scale_max:
-                self.scale /= self.scale_adapt_factor
-        u, p, L = self.prepared_samples.pop(0)
-        return u, p, L, nc
-
-
-class PopulationSimpleSliceSampler(GenericPopulationSampler):
-    """Vectorized slice sampler without stepping out (reference popstepsampler.py:747-1000): every
-    likelihood batch has exactly `popsize` rows; workers that finished their point help the
-    unfinished ones.  The shrinking bookkeeping is ``update_vectorised_slice_sampler``."""
-
-    def __init__(self, popsize, nsteps, generate_direction, scale_adapt_factor=1.0, adapt_slice_scale_target=2.0,
-                 scale=1.0, scale_jitter_func=None, slice_limit=slice_limit_to_unitcube, max_it=100,
-                 shrink_factor=1.0):
-        assert shrink_factor >= 1.0, "The shrink factor should be greater than 1.0 to be efficient"
-        self.nsteps, self.popsize, self.max_it = nsteps, popsize, max_it
-        self.nrejects, self.ncalls, self.discarded = 0, 0, 0
-        self.generate_direction = generate_direction
-        self.scale_adapt_factor = scale_adapt_factor
-        self.shrink_factor = shrink_factor
-        self.scale = float(scale)
-        self.adapt_slice_scale_target = adapt_slice_scale_target
-        self.scale_jitter_func = scale_jitter_func if scale_jitter_func is not None else (lambda: 1.)
-        self.prepared_samples = []
-        self.slice_limit = slice_limit
-        self.logstat = []
-
-    def __str__(self):
-        return 'PopulationSimpleSliceSampler(popsize=%d, nsteps=%d, generate_direction=%s, scale=%.g)' % (
-            self.popsize, self.nsteps, self.generate_direction, self.scale)
-
-    def __next__(self, region, Lmin, us, Ls, transform, loglike, ndraw=10, plot=False, tregion=None, log=False,
-                 test=False):
-        nlive, ndim = us.shape
-        nc = 0
-        if len(self.prepared_samples) == 0:
-            ilive = np.random.randint(0, nlive, size=self.popsize)
-            allu = np.array(us[ilive, :]) if not test else np.array(us)
-            allp = np.zeros((self.popsize, ndim)) * np.nan
-            allL = np.array(Ls[ilive])
-            n_discarded = 0
-            interval_final = 0.
-            for _ in range(self.nsteps):
-                factor_scale = self.scale_jitter_func()
-                v = self.generate_direction(allu, region, scale=1.0) * self.scale * factor_scale
-                cube_left, cube_right = unitcube_line_intersection(allu, v)
-                tleft_worker, tright_worker = self.slice_limit(cube_left, cube_right)
-                tleft, tright = self.slice_limit(cube_left, cube_right)
-                worker_running = np.arange(self.popsize, dtype=int_dtype)
-                status = np.zeros(self.popsize, dtype=int_dtype)
-                for _it in range(self.max_it):
-                    position = np.random.uniform(size=(self.popsize,))
-                    t = tleft_worker + (tright_worker - tleft_worker) * position
-                    proposed_u = allu[worker_running, :] + t.reshape((-1, 1)) * v[worker_running, :]
-                    proposed_p = transform(proposed_u)
-                    proposed_L = loglike(proposed_p)
-                    nc += self.popsize
-                    if allp.shape[1] != proposed_p.shape[1]:
-                        allp = np.zeros((self.popsize, proposed_p.shape[1])) * np.nan
-                    tleft, tright, worker_running, status, allu, allL, allp, ndisc = update_vectorised_slice_sampler(
-                        t, tleft, tright, proposed_L, proposed_u, proposed_p, worker_running, status, Lmin,
-                        self.shrink_factor, allu, allL, allp, self.popsize)
-                    n_discarded += ndisc
-                    tleft_worker, tright_worker = tleft[worker_running], tright[worker_running]
-                    if not np.any(status == 0):
-                        break
-                interval_final += np.median(tright - tleft)
-            interval_final = interval_final / self.nsteps
-            self.discarded += n_discarded
-            self.ncalls += nc
-            assert np.isfinite(allp).all(), 'some walkers never moved! Double nsteps of PopulationSimpleSliceSampler.'
-            far_enough, (move_distance, reference_distance) = diagnose_move_distances(region, us[ilive, :], allu)
-            self.prepared_samples = list(zip(allu, allp, allL))
-            self.logstat.append([self.popsize / nc, self.scale, self.nsteps,
-                                 np.mean(far_enough) if len(far_enough) > 0 else 0,
-                                 np.exp(np.mean(np.log(move_distance / reference_distance + 1e-10)))
-                                 if len(far_enough) > 0 else 0])
-            if interval_final >= 1. / self.adapt_slice_scale_target:
-                self.scale *= 1. / self.scale_adapt_factor
-            else:
-                self.scale *= self.scale_adapt_factor
-        u, p, L = self.prepared_samples.pop(0)
-        return u, p, L, nc
-
-
 __all__ = [
     "generate_cube_oriented_direction", "generate_cube_oriented_direction_scaled", "generate_random_direction",
     "generate_region_oriented_direction", "generate_region_random_direction", "generate_differential_direction",
-    "generate_mixture_random_direction", "PopulationRandomWalkSampler", "PopulationSliceSampler",
-    "PopulationSimpleSliceSampler", "unitcube_line_intersection", "diagnose_move_distances",
+    "generate_mixture_random_direction", "PopulationSliceSampler", "unitcube_line_intersection",
+    "diagnose_move_distances",
     "slice_limit_to_unitcube", "slice_limit_to_scale", "int_dtype"]

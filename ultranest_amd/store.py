@@ -5,10 +5,12 @@ run can be resumed -- by this package or by stock UltraNest (SURVEY.md 8f row f4
 
 ``TextPointStore`` writes / reads the reference's text format byte for byte (``fmt`` = ``%.18e`` per value,
 ``delimiter`` between values, one row per ``add``; both attributes can be changed after construction, which
-the reference's driver does, integrator.py:1189-1194).  The HDF5 flavour needs h5py exactly as in the
-reference; h5py is not part of this image, so ``HDF5PointStore`` raises ImportError when it is missing.
+the reference's driver does, integrator.py:1189-1194).  The reference's HDF5 flavour (store.py:161-227, h5py) is NOT
+provided: h5py is not part of this image, so its file format could neither be pinned against a file written by the
+reference nor exercised at all; use ``storage_backend='tsv'`` (or the reference's own HDF5PointStore next to this
+package -- the row format is the same).
 
-Interface of all three: ``add(row, ncalls) -> index``, ``pop(Lmin) -> (index, row) | (None, None)``,
+Interface of both: ``add(row, ncalls) -> index``, ``pop(Lmin) -> (index, row) | (None, None)``,
 ``reset()``, ``flush()``, ``close()``, attributes ``ncols``, ``nrows``, ``ncalls``, ``stack``, ``stack_empty``.
 """
 import os
@@ -112,42 +114,3 @@ class TextPointStore(FilePointStore):
         self.fileobj.write(record.encode('latin1'))
         index, self.nrows, self.ncalls = self.nrows, self.nrows + 1, ncalls
         return index
-
-
-class HDF5PointStore(FilePointStore):
-    """HDF5 file with the resizable dataset ``points`` (rows as above) and the attribute ``ncalls``
-    (reference store.py:161-227).  Needs h5py.  A file can be open only once per process."""
-
-    FILES_OPENED = []
-
-    def __init__(self, filepath, ncols, **h5_file_args):
-        import h5py
-        if filepath in self.FILES_OPENED:
-            raise IOError("%s already open in this process" % filepath)
-        self.ncols = int(ncols)
-        h5_file_args.setdefault('mode', 'a')
-        self.fileobj = h5py.File(filepath, **h5_file_args)
-        self.FILES_OPENED.append(filepath)
-        self.filepath = filepath
-        if 'points' not in self.fileobj:
-            self.fileobj.create_dataset('points', dtype=np.float64, shape=(0, self.ncols), maxshape=(None, self.ncols))
-        data = self.fileobj['points']
-        if data.shape[1] != self.ncols:
-            raise IOError("Tried to resume from file '%s', which has a different number of columns!" % (filepath))
-        rows = data[:]
-        self.nrows = len(rows)
-        self.ncalls = self.fileobj.attrs.get('ncalls', self.nrows)
-        self._set_stack(rows)
-
-    def add(self, row, ncalls):
-        _check_width(row, self.ncols)
-        data = self.fileobj['points']
-        data.resize(self.nrows + 1, axis=0)
-        data[self.nrows, :] = row
-        self.fileobj.attrs['ncalls'] = self.ncalls = ncalls
-        index, self.nrows = self.nrows, self.nrows + 1
-        return index
-
-    def close(self):
-        self.fileobj.close()
-        self.FILES_OPENED.remove(self.filepath)
