@@ -433,9 +433,9 @@ def main():
         "rebuild_ms": rebuild_ms, "rebuild_first_ms": first_ms,
         "accept_fraction": accept, "ellipsoid_pass_fraction": ell_pass,
         "kernel_ms": {"per-proposal stage (k_prep4: bounded ellipsoid test + whitening on the FP32 matrix cores -> f16 "
-                      "operand; k_ell_exact rides in the k_mark_exact launch)": prep_ms,
+                      "operand; the ellipsoid band is decided by the tail of the re-check launch)": prep_ms,
                       ("scan kernel (k_filter)" if filter_on else "scan kernel (k_scan)"): scan_ms,
-                      "rest of scan stage (exact-coordinate slots, exact whitening + re-check of uncertain pairs, "
+                      "rest of scan stage (re-check of uncertain pairs incl. exact whitening of their queries, "
                       "routing, finalise)": rest_ms,
                       "scan kernel as a single sweep over all live points (phases off)": ms_scan_single,
                       "per-proposal stage with the FP64 kernel instead (k_prep3, prep_bounded=0)":

@@ -53,10 +53,12 @@ struct FilterCtx {
   // phased sweep: two compacted query sets (ping-pong)
   DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png, pflags, pblk;
   // bounded per-proposal stage (mlf_prep4.hip): ellipsoid band list, exact-coordinate slots, per-call counters
-  // misc: [0] band proposals, [1] k_ell_exact workgroups done, [2] queries routed to the exact scan, [3] "the exact scan
-  // has work" -- all return to zero by themselves (no memset per batch), zeroed once when the buffer is allocated;
-  // [4] band proposals and [5] exact-coordinate slots of the last batch (mlf_region_debug_stats)
-  DevBuf ell_list, slot, slotq, tqc, misc, uq, ucount;
+  // misc: [0] band proposals, [1] k_ell_exact workgroups done -- both return to zero by themselves (no memset per batch),
+  // zeroed once when the buffer is allocated; [2], [3] "a proposal is routed to the exact scan", used alternately by
+  // successive batches (the scan launch of a batch clears the word of the next one); [4] band proposals of the last
+  // batch (mlf_region_debug_stats)
+  DevBuf ell_list, misc;
+  unsigned batch_parity = 0;
   size_t last_nsegs = 0;      // list segments of the last filtered batch
   bool ell_pending = false;   // band list of the running call not decided yet (the k_mark_exact launch takes it along)
   EllExactArgs ell_args{};
@@ -66,7 +68,7 @@ struct FilterCtx {
   void release() {
     DevBuf *b[] = {&stats, &statscratch, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2,
                    &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png, &pflags, &pblk,
-                   &ell_list, &slot, &slotq, &tqc, &misc, &uq, &ucount};
+                   &ell_list, &misc};
     for (DevBuf *x : b) x->release();
     refs_ready = usable = false;
   }
@@ -226,7 +228,6 @@ int filter_reserve(FilterCtx &f, long long nq, unsigned *cap_out) {
   CK(f.list.reserve((size_t)nwaves * cap * sizeof(unsigned long long)));
   CK(f.segcnt.reserve((size_t)nwaves * sizeof(unsigned)));
   CK(f.gate2.reserve((size_t)nq));
-  CK(f.slot.reserve((size_t)nq * sizeof(int)));
   if (int rc = misc_reserve(f)) return rc;
   *cap_out = cap;
   return 0;
@@ -240,7 +241,9 @@ int filter_reserve(FilterCtx &f, long long nq, unsigned *cap_out) {
 struct ExactSrc {
   const double *pts;
   const double *lay_ctr;
-  const double *TtF;
+  const double *T8;   // row-major layer matrix, row stride ldt
+  int ldt;
+  const double *T64;  // the same as 64 x 64, zero padded (d <= 64)
 };
 
 int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int npad, int d, int dp,
@@ -283,12 +286,15 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       CK(f.pthi[i].reserve((size_t)nqpad * sizeof(float)));
       CK(f.pmap[i].reserve((size_t)nqpad * sizeof(int)));
     }
-    CK(f.png.reserve(4 * sizeof(unsigned)));
+    if (!f.png.p) {   // group counts + the slot counter of the fused compaction (returns to zero by itself: k_phase_finish)
+      CK(f.png.reserve(4 * sizeof(unsigned)));
+      CK(hipMemset(f.png.p, 0, 4 * sizeof(unsigned)));
+    }
     CK(f.pflags.reserve((size_t)nqpad));
     CK(f.pblk.reserve(((size_t)nqpad / 256 + 2) * sizeof(unsigned)));
   }
   const bool fused = nphase > 1 && g_filter_fused_compact;
-  if (fused) CK(hipMemsetAsync(f.png.as<unsigned>() + 2, 0, sizeof(unsigned), s));   // slot counter of the fused compaction
+
   for (int ph = 0; ph < nphase; ++ph) {
     fa.tile0 = (int)((long long)f.ntiles32 * ph / nphase);
     fa.tile1 = (int)((long long)f.ntiles32 * (ph + 1) / nphase);
@@ -361,81 +367,54 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     }
   }
   if (ev_after_filter) CK(hipEventRecord(ev_after_filter, s));
-  const int *slot = nullptr;
-  if (xs) {   // exact coordinates of the queries that still need them: uncertain pairs + everything routed to the exact scan
-    const long long nsegs = filter_wave_count(f.ks, ngroups);
-    const unsigned unit_cap = (unsigned)(nphase * (f.ks <= 4 ? 4 : (f.ks <= 8 ? 2 : 1)) * 32);   // queries per filter wave, all phases
-    CK(f.slot.reserve((size_t)nq * sizeof(int)));
-    CK(f.slotq.reserve((size_t)nq * sizeof(int)));
-    CK(f.uq.reserve((size_t)nsegs * unit_cap * sizeof(int)));
-    CK(f.ucount.reserve((size_t)(nsegs + 1) * sizeof(unsigned)));
-    CK(f.tqc.reserve((size_t)nq * d * sizeof(double)));
-    MarkArgs ma{};
-    ma.list = f.list.as<unsigned long long>();
-    ma.seg_cap = cap;
-    ma.seg_count = f.segcnt.as<unsigned>();
-    ma.nsegs = nsegs;
-    ma.nq = nq;
-    ma.nlive = n;
-    ma.route = f.route.as<uint8_t>();
-    ma.best = f.best.as<int>();
-    ma.counters = f.counters.as<unsigned>();
-    ma.slot = f.slot.as<int>();
-    ma.unit_cap = unit_cap;
-    ma.uq = f.uq.as<int>();
-    ma.ucount = f.ucount.as<unsigned>();
-    ma.xq = f.slotq.as<int>();
-    ma.nx = f.misc.as<unsigned>() + 2;
-    ma.scan_flag = f.misc.as<unsigned>() + 3;
-    if (f.ell_pending) {
-      ma.ell = f.ell_args;
+  const long long nsegs_all = filter_wave_count(f.ks, ngroups);
+  f.last_nsegs = (size_t)nsegs_all;
+  if (xs) {   // no whitened coordinates were stored: the re-check whitens the queries of its pairs itself
+    RecheckWArgs rw{};
+    rw.list = f.list.as<unsigned long long>();
+    rw.seg_cap = cap;
+    rw.seg_count = f.segcnt.as<unsigned>();
+    rw.nsegs = nsegs_all;
+    rw.unit_cap = (unsigned)(nphase * (f.ks <= 4 ? 4 : (f.ks <= 8 ? 2 : 1)) * 32);   // queries per filter wave, all phases
+    rw.refR = refR;
+    rw.n = n;
+    rw.d = d;
+    rw.dp = dp;
+    rw.pts = xs->pts;
+    rw.nq = nq;
+    rw.lay_ctr = xs->lay_ctr;
+    rw.T64 = xs->T64;
+    rw.r2 = r2;
+    rw.best = f.best.as<int>();
+    if (f.ell_pending) {   // the band proposals of k_prep4 are decided by the last waves of this launch (before the finalise)
+      rw.ell = f.ell_args;
       f.ell_pending = false;
     }
-    launch_mark_exact(ma, s);
+    launch_recheck_whiten(rw, s);
     CK(hipGetLastError());
-    launch_scan_counts(f.ucount.as<unsigned>(), (int)nsegs, s);
-    WhitenSlotsArgs wa{};
-    wa.pts = xs->pts;
-    wa.d = d;
-    wa.xq = f.slotq.as<int>();
-    wa.nx = f.misc.as<unsigned>() + 2;
-    wa.uq = f.uq.as<int>();
-    wa.ubase = f.ucount.as<unsigned>();
-    wa.nsegs = nsegs;
-    wa.unit_cap = unit_cap;
-    wa.slot = f.slot.as<int>();
-    wa.lay_ctr = xs->lay_ctr;
-    wa.TtF = xs->TtF;
-    wa.out = f.tqc.as<double>();
-    wa.stats_out = f.misc.as<unsigned>() + 5;
-    CK(launch_whiten_slots(wa, nq, s));
-    q = f.tqc.as<double>();
-    ldq = d;
-    ldk = 1;
-    slot = f.slot.as<int>();
+  } else {
+    RecheckArgs ra{};
+    ra.list = f.list.as<unsigned long long>();
+    ra.seg_cap = cap;
+    ra.seg_count = f.segcnt.as<unsigned>();
+    ra.refR = refR;
+    ra.n = n;
+    ra.d = d;
+    ra.dp = dp;
+    ra.q = q;
+    ra.ldq = ldq;
+    ra.ldk = ldk;
+    ra.nq = nq;
+    ra.r2 = r2;
+    ra.best = f.best.as<int>();
+    launch_recheck(ra, nsegs_all, s);
+    CK(hipGetLastError());
   }
-  RecheckArgs ra{};
-  ra.list = f.list.as<unsigned long long>();
-  ra.seg_cap = cap;
-  ra.seg_count = f.segcnt.as<unsigned>();
-  ra.refR = refR;
-  ra.n = n;
-  ra.d = d;
-  ra.dp = dp;
-  ra.q = q;
-  ra.ldq = ldq;
-  ra.ldk = ldk;
-  ra.nq = nq;
-  ra.r2 = r2;
-  ra.best = f.best.as<int>();
-  ra.slot = slot;
-  f.last_nsegs = (size_t)filter_wave_count(f.ks, ngroups);
-  launch_recheck(ra, filter_wave_count(f.ks, ngroups), s);
-  CK(hipGetLastError());
   // answers of the filtered queries + the gate of the exact scan that follows: (a) queries that do not
   // fit binary16 and (b) every filtered query if the uncertain-pair list overflowed
-  launch_filter_finalize(f.route.as<uint8_t>(), f.best.as<int>(), f.counters.as<unsigned>(), nq, out_mask,
-                         out_idx, f.gate2.as<uint8_t>(), s, xs ? f.misc.as<unsigned>() + 2 : nullptr);
+  if (!xs)
+    launch_filter_finalize(f.route.as<uint8_t>(), f.best.as<int>(), f.counters.as<unsigned>(), nq, out_mask,
+                           out_idx, f.gate2.as<uint8_t>(), s);
   {
     ScanArgs a{};
     a.refT = refT;
@@ -453,8 +432,20 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     a.out_idx = out_idx;
     a.out_mask = out_mask;
     a.only_gated = 1;   // leave the outputs of ungated queries alone
-    a.slot = slot;
-    a.any_flag = xs ? f.misc.as<unsigned>() + 3 : nullptr;
+    if (xs) {   // the finalise work rides in the scan launch; its gate is the routing itself; the (rare) workgroups
+                // that do scan whiten their own queries
+      a.q = xs->pts;
+      a.ldq = d;
+      a.ldk = 1;
+      a.raw_ctr = xs->lay_ctr;
+      a.raw_T8 = xs->T8;
+      a.raw_ldt = xs->ldt;
+      a.route = f.route.as<uint8_t>();
+      a.counters = f.counters.as<unsigned>();
+      a.fin_best = f.best.as<int>();
+      a.any_flag = f.misc.as<unsigned>() + 2 + f.batch_parity;
+      a.fin_reset = f.misc.as<unsigned>() + 2 + (f.batch_parity ^ 1u);
+    }
     CK(launch_scan(dp, a, s));
   }
   CK(hipGetLastError());
@@ -534,7 +525,7 @@ struct mlf_region {
   double ell_eps_scale = 0.0;
   DevBuf tq, gate, pts, mask, row;
   // bounded per-proposal stage (mlf_prep4.hip): binary32 fragments, chain start values, error constants
-  DevBuf p4_LtF, p4_TtF, p4_y0;
+  DevBuf p4_LtF, p4_TtF, p4_y0, lay_T64, ell_L;
   Prep4Consts p4c{};
   bool p4_ready = false;
   std::vector<double> h_L, h_lay_ctr, h_ell_ctr;   // host copies: y0 = L^T (c_lay - c_ell) follows the ellipsoid centre
@@ -618,6 +609,13 @@ int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2,
   r->h_L = L;
   r->h_ell_ctr.assign(ell_center, ell_center + d);
   r->h_lay_ctr.assign(r->use_scan ? layer_ctr : ell_center, (r->use_scan ? layer_ctr : ell_center) + d);
+  {   // the lower factor itself, row-major with stride dp (the wave-per-proposal exact test reads its columns)
+    std::vector<double> lrm((size_t)dp * dp, 0.0);
+    for (int j = 0; j < d; ++j)
+      for (int k = 0; k <= j; ++k) lrm[(size_t)j * dp + k] = L[(size_t)j * d + k];
+    if (int rc = upload(r->ell_L, lrm.data(), lrm.size() * sizeof(double), s)) return rc;
+    CK(hipStreamSynchronize(s));
+  }
   std::vector<float> ltf(prep4_ltf_count(dp));
   prep4_lt_fragments(L.data(), d, dp, ltf.data());
   if (int rc = upload(r->p4_LtF, ltf.data(), ltf.size() * sizeof(float), s)) return rc;
@@ -642,6 +640,10 @@ int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2,
     std::vector<float> ttf(prep4_ttf_count(dp));
     prep4_t_fragments(layer_T, d, dp, ttf.data());
     if (int rc = upload(r->p4_TtF, ttf.data(), ttf.size() * sizeof(float), s)) return rc;
+    std::vector<double> t64((size_t)64 * 64, 0.0);   // for the exact whitening inside the re-check
+    for (int k = 0; k < d; ++k)
+      for (int c2 = 0; c2 < d; ++c2) t64[(size_t)k * 64 + c2] = layer_T[(size_t)k * d + c2];
+    if (int rc = upload(r->lay_T64, t64.data(), t64.size() * sizeof(double), s)) return rc;
   }
   CK(hipStreamSynchronize(s));
   r->p4_ready = true;
@@ -718,14 +720,16 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
       pa.thi = f.thi.as<float>();
       pa.route = f.route.as<uint8_t>();
       pa.best = f.best.as<int>();
-      pa.slot = f.slot.as<int>();
       pa.counters = f.counters.as<unsigned>();
-      pa.scan_flag = f.misc.as<unsigned>() + 3;
+      f.batch_parity ^= 1u;
+      pa.scan_flag = f.misc.as<unsigned>() + 2 + f.batch_parity;
       pa.ks = f.ks;
       pa.nqpad = ((long long)np + 31) / 32 * 32;
       xsrc.pts = d_pts;
       xsrc.lay_ctr = r->lay_ctr.as<double>();
-      xsrc.TtF = r->lay_TtF.as<double>();
+      xsrc.T8 = r->lay_T8.as<double>();
+      xsrc.ldt = (r->dp + 7) / 8 * 8;
+      xsrc.T64 = r->lay_T64.as<double>();
     }
     CK(launch_prep4(pa, s));
     EllExactArgs ea{};
@@ -739,6 +743,7 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
     ea.dp = r->dp;
     ea.ell_ctr = r->ell_ctr.as<double>();
     ea.ell_Lt = r->ell_Lt.as<double>();
+    ea.ell_L = r->ell_L.as<double>();
     ea.ell_A = r->ell_A.as<double>();
     ea.eps_scale = r->ell_eps_scale;
     ea.enlarge = r->enlarge;
@@ -1292,7 +1297,7 @@ int mlf_region_create(mlf_region **out) {
 int mlf_region_destroy(mlf_region *r) {
   if (!r) return 0;
   DevBuf *bufs[] = {&r->refT, &r->refR, &r->lay_ctr, &r->lay_mat, &r->lay_T8, &r->ell_Lt, &r->ell_LtF, &r->lay_TtF, &r->wrap, &r->ell_ctr,
-                    &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row, &r->p4_LtF, &r->p4_TtF, &r->p4_y0,
+                    &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row, &r->p4_LtF, &r->p4_TtF, &r->p4_y0, &r->lay_T64, &r->ell_L,
                     &r->gen, &r->gen2, &r->cube, &r->smask, &r->blk, &r->sout, &r->ax_zero, &r->ax_mat,
                     &r->s_invT, &r->s_lo, &r->s_hi, &r->s_thin, &r->s_count, &r->rf_p, &r->rf_L, &r->rf_out, &r->rf_aux};
   for (DevBuf *b : bufs) b->release();
@@ -1878,7 +1883,6 @@ int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap) {
     unsigned m[8];
     CK(hipMemcpy(m, f.misc.p, sizeof m, hipMemcpyDeviceToHost));
     out[0] = m[4];
-    out[1] = m[5];
   }
   if (f.segcnt.p && f.segcnt.cap >= sizeof(unsigned)) {
     const size_t n = f.last_nsegs;

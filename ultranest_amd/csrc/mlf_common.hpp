@@ -28,6 +28,26 @@ enum ScanMode : int {
   SCAN_MASK = 3    // R3: byte mask "gate && any live point within r2"     (u8 out)
 };
 
+// exact ellipsoid test of the proposals k_prep4 could not decide (bounded binary64 form first, the reference's
+// summation order only inside that form's own band)
+struct EllExactArgs {
+  unsigned *count;         // reset to 0 by the last workgroup
+  unsigned *done;          // workgroups finished (returns to 0)
+  unsigned *last;          // optional: receives the count before it is reset
+  const int *list;
+  unsigned cap;
+  const double *pts;
+  int d, dp;
+  const double *ell_ctr;   // [dp]
+  const double *ell_Lt;    // [dp][dp]  Lt[k][j] = L[j][k]
+  const double *ell_L;     // [dp][dp]  L[j][k] row-major (the same factor, for the wave-per-proposal form)
+  const double *ell_A;     // [d][dp]
+  double eps_scale, enlarge;
+  int chol_ok;
+  uint8_t *gate;
+  uint8_t *route;          // may be null
+};
+
 struct ScanArgs {
   const double *refT;
   int n, npad, ntiles;
@@ -40,8 +60,23 @@ struct ScanArgs {
   int mode;
   const uint8_t *gate;            // optional, per query: 0 = do not scan (result: none)
   int only_gated;                 // 1: write outputs only for gated-in queries; idle workgroups exit early
-  const int *slot;                // optional: query j reads row slot[j] of q (negative: no coordinates, never scanned)
-  const unsigned *any_flag;       // optional (device): 0 = no query is gated in, every workgroup returns at once
+  // optional: q holds the proposals as handed over (not whitened); the workgroup whitens the rows it has staged in the
+  // arithmetic of k_prep (delta_k = x_k - c_k, k-ascending FMA chain) before scanning -- the second-stage launch
+  // behind k_prep4, which stores no whitened coordinates
+  const double *raw_ctr;          // [>= d] layer centre; nullptr = q is already whitened
+  const double *raw_T8;           // row-major layer matrix, element (k, c) at raw_T8[k * raw_ldt + c]
+  int raw_ldt;
+  const unsigned *any_flag;       // optional (device): 0 and no list overflow (counters[1]) = nothing to scan, the scanning
+                                  // workgroups return at once
+  // optional: the gate comes from the pre-filter's routing instead of a byte array -- a query is scanned if
+  // route == 2, or route == 1 and the uncertain-pair list overflowed (counters[1]); `gate` is ignored then
+  const uint8_t *route;
+  const unsigned *counters;
+  // optional tail of the launch (workgroups behind the scanning ones): answers of the FILTERED queries from best[]
+  // (k_filter_finalize's job, riding in this launch to save a kernel boundary)
+  const int *fin_best;            // nullptr = no tail
+  unsigned fin_grid0;             // first workgroup of the tail (filled in by the launcher)
+  unsigned *fin_reset;            // optional word zeroed by the tail
   long long *out_idx;             // SCAN_FIRST / SCAN_COUNT
   unsigned long long *out_flags;  // SCAN_FLAGS  [nq][ntiles]
   uint8_t *out_mask;              // SCAN_MASK

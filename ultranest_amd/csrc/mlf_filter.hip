@@ -553,12 +553,7 @@ __global__ __launch_bounds__(256) void k_recheck(RecheckArgs a) {
     if (i >= a.n || qi >= a.nq) continue;
     if (a.best[qi] <= i) continue;   // a certain hit at a lower (mask mode: any) index settles this query
     const double *ar = a.refR + (size_t)i * a.dp;
-    long long rowq = qi;
-    if (a.slot) {
-      rowq = a.slot[qi];
-      if (rowq < 0) continue;   // cannot happen for a pair that passes the test above (k_mark_exact applies the same one)
-    }
-    const double *br = a.q + rowq * a.ldq;
+    const double *br = a.q + qi * a.ldq;
     const long long ldk = a.ldk > 1 ? a.ldk : 1;
     double acc = 0.0;
 #pragma unroll 10

@@ -68,7 +68,6 @@ struct RecheckArgs {
   long long ldq, ldk, nq;   // query element (j, k) at q[j*ldq + k*ldk]
   double r2;
   int *best;
-  const int *slot;       // optional: query qi reads row slot[qi] of q (compact exact coordinates, mlf_prep4.hip)
 };
 
 // scratch: (64 * 128 + 2) doubles, zero-initialised once (the last two words are running maxima, reset by the launch)

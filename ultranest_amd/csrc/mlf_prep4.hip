@@ -42,6 +42,7 @@
 
 #include "mlf_filter_dev.hpp"
 #include "mlf_prep3.hpp"
+#include "mlf_ell_exact.hpp"
 
 namespace mlf {
 
@@ -101,7 +102,6 @@ __global__ __launch_bounds__(256, 2) void k_prep4(Prep4Args a) {
   if (blockIdx.x == 0 && tid == 0 && a.counters) {
     a.counters[0] = 0;
     a.counters[1] = 0;
-    *a.scan_flag = 0u;   // set by k_mark_exact if a query of this batch is routed to the exact scan
   }
   if (quant)
     for (int e = tid; e < NT * NKS * 64; e += 256) TtF[e] = a.TtF[e] * (-2.0f * sig_f);   // power of two: exact
@@ -355,13 +355,13 @@ __global__ __launch_bounds__(256, 2) void k_prep4(Prep4Args a) {
       for (int s = 0; s < KS; ++s)
         qdst[((size_t)grp * KS + s) * 64 + lane] = make_uint4(keep ? pk[4 * s] : 0u, keep ? pk[4 * s + 1] : 0u,
                                                               keep ? pk[4 * s + 2] : 0u, keep ? pk[4 * s + 3] : 0u);
+      if (__any(rt == 2) && lane == 0) *a.scan_flag = 1u;   // rare: wakes the exact-scan workgroups of this batch up
       if (h == 0) {
         a.tlo[p] = lo_f;
         a.thi[p] = hi_f;
         if (live) {
           a.route[p] = (uint8_t)rt;
           a.best[p] = kNone;
-          a.slot[p] = -1;
         }
       }
     }
@@ -436,37 +436,54 @@ hipError_t launch_prep4(const Prep4Args &a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------- exact ellipsoid test ----------
-// One wave per listed proposal.  Tier 1: qt = |L^T delta|^2 in binary64 with the band eps = 2^-34 |A|_F |delta|^2 of
-// k_prep3 (the factor and the wave's delta sit in LDS); tier 2 (inside that band, practically never): the reference's
-// arithmetic -- one accumulator, j outer, (d_j * A_jk) * d_k, no FMA.  The last workgroup to finish resets the list
-// counter for the next batch (every workgroup has read it by then).  `blk` / `nblk`: this workgroup's index within
-// the workgroups that run this body (it is also a tail of the k_mark_exact launch).
-__device__ __forceinline__ void ell_exact_body(const EllExactArgs &a, double *ltl, unsigned blk, unsigned nblk) {
+// (body: mlf_ell_exact.hpp -- it also runs as the tail of the second-stage scan launch)
+__global__ __launch_bounds__(256) void k_ell_exact(EllExactArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double ltl[];
+  ell_exact_body(a, ltl, blockIdx.x, gridDim.x);
+}
+
+void launch_ell_exact(const EllExactArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(k_ell_exact, dim3(kEllBlocks), dim3(256), ell_exact_lds(a.d), s, a);
+}
+
+// ---------------------------------------------------------------- exact re-check, whitening its own queries
+// The pairs the pre-filter could not decide are re-evaluated in the reference's arithmetic.  k_prep4 stores no
+// whitened coordinates, so the wave that owns a list segment whitens the few distinct queries of that segment itself,
+// in exactly the arithmetic that whitened the live points (k_prep: delta_k = x_k - c_k, k-ascending binary64 FMA chain
+// per output; also what k_prep3 / v_mfma_f64 compute), keeps them in LDS and then runs the reference's distance loop
+// (acc = 0; k ascending: diff = a_k - t_k; acc += diff * diff, no FMA) per listed pair.
+//   1. every live entry (query not yet settled by a certain hit at or below the pair's live index) inserts its query
+//      into an LDS hash table (open addressing; a segment holds pairs of at most `unit_cap` distinct queries),
+//   2. the occupied slots are numbered, 3. in rounds of kTQ queries: the wave whitens them one after the other (lane =
+//      output coordinate, the matrix row T[k][.] is one coalesced load), then evaluates the entries of these queries.
+// One wave = one workgroup, so that (almost) all segments of a batch are resident at once: the work per segment is a
+// chain of ~8 dependent memory round trips, and what matters is how many of those chains run concurrently.  A first
+// version numbered the queries of ALL segments globally (claim kernel, scan, whitening kernel, re-check kernel:
+// 24 + 10 + 21 + 21 us per 10^6-proposal batch, almost all of it launch and dependent-load latency), a second one
+// used 256-thread workgroups (74 us: a quarter of the segments resident).  The last waves of the launch decide the
+// ellipsoid band (ell_exact_wave).
+constexpr unsigned kEllWaves = 512;
+
+// the ellipsoid band, one wave per proposal, as light as the re-check waves it shares a launch with: row k of L^T
+// is read through the vector L1 (20 KB, resident), delta sits in 64 doubles of LDS
+__device__ __forceinline__ void ell_exact_wave(const EllExactArgs &a, double *dls, unsigned wave, unsigned nwaves) {
   const unsigned count = *a.count < a.cap ? *a.count : a.cap;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const unsigned wave = blk * 4 + wv, nwaves = nblk * 4;
+  const int lane = threadIdx.x & 63;
   const int d = a.d;
-  const int ls = d | 1;
-  double *dls = ltl + (size_t)d * ls + wv * 64;   // this wave's delta
-  if (count != 0u) {   // uniform over the workgroups
-    for (int e = threadIdx.x; e < d * d; e += 256) {
-      const int k = e / d, j = e - k * d;
-      ltl[k * ls + j] = a.ell_Lt[(size_t)k * a.dp + j];
-    }
-    __syncthreads();
-  }
+  const bool own = lane < d;
+  const double *lcol = a.ell_L + (own ? lane : 0);   // column `lane` of the lower factor: L[j][lane], coalesced over the lanes
+  const double myctr = own ? a.ell_ctr[lane] : 0.0;
   for (unsigned e = wave; e < count; e += nwaves) {
     const long long p = a.list[e];
     const double *row = a.pts + p * (long long)d;
-    const bool own = lane < d;
-    const double dl = own ? row[lane] - a.ell_ctr[lane] : 0.0;
+    const double dl = own ? row[lane] - myctr : 0.0;
     __builtin_amdgcn_wave_barrier();
     dls[lane] = dl;
     __builtin_amdgcn_wave_barrier();
-    const double *lrow = ltl + (own ? lane : 0) * ls;
     double y = 0.0;
-#pragma unroll 8
-    for (int j = 0; j < d; ++j) y = __builtin_fma((own && j >= lane) ? lrow[j] : 0.0, dls[j], y);
+#pragma unroll 10
+    for (int j = 0; j < d; ++j) y = __builtin_fma(lcol[(size_t)j * a.dp], dls[j], y);   // (L^T delta)_lane; L is stored with its zeros
+    if (!own) y = 0.0;
     double qt = y * y, nrm2 = dl * dl;
     for (int o = 32; o > 0; o >>= 1) {
       qt += __shfl_xor(qt, o, 64);
@@ -495,10 +512,9 @@ __device__ __forceinline__ void ell_exact_body(const EllExactArgs &a, double *lt
       if (a.route) a.route[p] = 0;
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     const unsigned t = atomicAdd(a.done, 1u);
-    if (t == nblk - 1u) {
+    if (t == nwaves - 1u) {
       if (a.last) *a.last = *a.count;   // kept for mlf_region_debug_stats
       *a.count = 0u;
       *a.done = 0u;
@@ -506,187 +522,136 @@ __device__ __forceinline__ void ell_exact_body(const EllExactArgs &a, double *lt
   }
 }
 
-static size_t ell_exact_lds(int d) { return ((size_t)d * (d | 1) + 4 * 64) * sizeof(double); }
-constexpr unsigned kEllBlocks = 128;
+constexpr int kTQ = 8;     // whitened queries held in LDS per round
+constexpr int kChunk = 32;  // entries handled together: at most 32 distinct queries, a 64-slot table
 
-__global__ __launch_bounds__(256) void k_ell_exact(EllExactArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double ltl[];
-  ell_exact_body(a, ltl, blockIdx.x, gridDim.x);
-}
-
-void launch_ell_exact(const EllExactArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(k_ell_exact, dim3(kEllBlocks), dim3(256), ell_exact_lds(a.d), s, a);
-}
-
-// ---------------------------------------------------------------- which queries need exact coordinates
-// Queries of uncertain pairs: one wave per list segment.  A segment holds the pairs of at most unit_cap distinct
-// queries (the filter waves that wrote it own QW x 32 queries per phase), so the claimed queries of a segment get
-// ranks 0.. in the segment's own window of `uq` -- no shared counter (one counter for all waves serialises at ~90 M
-// atomics/s: 80 us per batch in the first version of this kernel).  First claimant of a query wins (CAS on its slot
-// word; a query can sit in the segments of two phases).  An exclusive scan over the per-segment counts then gives the
-// dense numbering (k_whiten_slots).  Four entries per lane are in flight per step.
-__device__ __forceinline__ void mark_segment(const MarkArgs &a, long long seg, int lane) {
-  const unsigned count = a.seg_count[seg];
-  const unsigned long long *sg = a.list + (size_t)seg * a.seg_cap;
-  int *win = a.uq + (size_t)seg * a.unit_cap;
-  unsigned nwin = 0;
-  for (unsigned e0 = 0; e0 < count; e0 += 256) {   // wave-uniform trip count
-    unsigned long long ent[4];
-    bool want[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned e = e0 + 64 * j + (unsigned)lane;
-      want[j] = e < count;
-      ent[j] = want[j] ? sg[e] : 0ull;
-    }
-    int bst[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long long qi = (long long)(ent[j] >> 32);
-      const int i = (int)(ent[j] & 0xffffffffu);
-      want[j] = want[j] && i < a.nlive && qi < a.nq;
-      bst[j] = want[j] ? a.best[qi] : 0;
-    }
-    bool won[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long long qi = (long long)(ent[j] >> 32);
-      const int i = (int)(ent[j] & 0xffffffffu);
-      // a certain hit at or below i settles the pair (k_recheck skips it for the same reason)
-      won[j] = want[j] && bst[j] > i && atomicCAS(&a.slot[qi], -1, -2) == -1;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned long long wm = __ballot(won[j]);
-      if (won[j]) {
-        const unsigned r = nwin + (unsigned)__popcll(wm & ((1ull << lane) - 1ull));
-        if (r < a.unit_cap) win[r] = (int)(ent[j] >> 32);
-      }
-      nwin += (unsigned)__popcll(wm);
-    }
+__global__ __launch_bounds__(64) void k_recheck_whiten(RecheckWArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds_r[];
+  const int lane = threadIdx.x;
+  if (blockIdx.x >= a.nsegs) {   // tail: ellipsoid band
+    ell_exact_wave(a.ell, lds_r, blockIdx.x - (unsigned)a.nsegs, kEllWaves);
+    return;
   }
-  if (lane == 0) a.ucount[seg] = nwin < a.unit_cap ? nwin : a.unit_cap;
-}
-
-// blocks [0, segblocks): the list segments; [segblocks, segblocks + qblocks): one thread per query -- everything routed
-// to the exact scan (rare: these take slots from a shared counter, and raise the flag that wakes the scan launch up);
-// the last kEllBlocks blocks (if a.ell.count): the exact ellipsoid test of the band proposals, which only has to be
-// complete before the finalise kernel
-__global__ __launch_bounds__(256) void k_mark_exact(MarkArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double ltl[];
-  const long long segblocks = (a.nsegs + 3) / 4, qblocks = (a.nq + 255) / 256;
-  const int lane = threadIdx.x & 63;
-  const long long b = blockIdx.x;
-  if (b < segblocks) {
-    const long long seg = b * 4 + (threadIdx.x >> 6);
-    if (seg < a.nsegs) mark_segment(a, seg, lane);
-  } else if (b < segblocks + qblocks) {
-    const long long p = (b - segblocks) * 256 + threadIdx.x;
-    bool want = false;
-    if (p < a.nq) {
-      const int rt = a.route[p];
-      want = rt == 2 || (rt == 1 && a.counters[1] != 0u);
-    }
-    const bool won = want && atomicCAS(&a.slot[p], -1, -2) == -1;
-    const unsigned long long wm = __ballot(won);
-    if (wm != 0ull) {   // rare
-      unsigned base = 0;
-      if (lane == 0) {
-        *a.scan_flag = 1u;
-        base = atomicAdd(a.nx, (unsigned)__popcll(wm));
-      }
-      base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-      if (won) a.xq[base + (unsigned)__popcll(wm & ((1ull << lane) - 1ull))] = (int)p;
-    } else if (__any(want) && lane == 0) {
-      *a.scan_flag = 1u;
-    }
-  } else {
-    ell_exact_body(a.ell, ltl, (unsigned)(b - segblocks - qblocks), kEllBlocks);
-  }
-}
-
-void launch_mark_exact(const MarkArgs &a, hipStream_t s) {
-  const long long blocks = (a.nsegs + 3) / 4 + (a.nq + 255) / 256 + (a.ell.count ? kEllBlocks : 0);
-  if (blocks <= 0) return;
-  hipLaunchKernelGGL(k_mark_exact, dim3((unsigned)blocks), dim3(256), a.ell.count ? ell_exact_lds(a.ell.d) : 0, s, a);
-}
-
-// ---------------------------------------------------------------- exact whitening of the slots --
-// Dense numbering of the claimed queries: [0, nx) the exact-scan queries (xq), then the segments' winners in segment
-// order (ubase = exclusive scan of ucount, total at ubase[nsegs]).  The arithmetic is k_prep3's whitening (and
-// k_prep's, which whitens the live points): delta_k = x_k - c_k, then a k-ascending FMA chain per output on
-// v_mfma_f64_16x16x4_f64.  Tile = 16 slots; lane (pl = l & 15, kq = l >> 4) holds coordinate 4 ks + kq of slot pl;
-// results: rows kq + 4 r of every 16-row block.  The lane that resolves a slot also publishes slot[q].
-template <int NK>
-__global__ __launch_bounds__(256) void k_whiten_slots(WhitenSlotsArgs a) {
-  constexpr int NC = (NK + 3) / 4;
-  const unsigned nx = *a.nx;
-  const unsigned n = nx + a.ubase[a.nsegs];
-  const unsigned tiles = (n + 15u) / 16u;
-  const int lane = threadIdx.x & 63, pl = lane & 15, kq = lane >> 4;
+  const unsigned count = a.seg_count[blockIdx.x];
+  if (count == 0) return;
   const int d = a.d;
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.stats_out[0] = n;   // kept for mlf_region_debug_stats
-  for (unsigned tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < tiles; tile += gridDim.x * 4) {
-    const unsigned sl = tile * 16 + pl;
-    const bool valid = sl < n;
-    long long q = 0;
-    if (valid) {
-      if (sl < nx) {
-        q = a.xq[sl];
-      } else {   // largest segment u with ubase[u] <= j
-        const unsigned j = sl - nx;
-        long long lo = 0, hi = a.nsegs - 1;
-        while (lo < hi) {
-          const long long mid = (lo + hi + 1) >> 1;
-          if (a.ubase[mid] <= j) lo = mid; else hi = mid - 1;
-        }
-        q = a.uq[(size_t)lo * a.unit_cap + (j - a.ubase[lo])];
+  const int ds = (d + 1) | 1;                                  // row stride of the whitened queries in LDS
+  double *tq = lds_r;                                          // [kTQ][ds]
+  double *dlw = tq + kTQ * ds;                                 // [kTQ][64] the centred proposals being whitened
+  int *hkey = reinterpret_cast<int *>(dlw + kTQ * 64);         // [64] query or -1
+  int *hid = hkey + 64;                                        // [64] number of the slot's query
+  int *qlist = hid + 64;                                       // [64] number -> query
+  const unsigned long long *seg = a.list + (size_t)blockIdx.x * a.seg_cap;
+  // A segment rarely holds more than a few dozen pairs; longer ones are taken in chunks of kChunk entries (a query
+  // that appears in two chunks is whitened twice: same result).
+  for (unsigned e0 = 0; e0 < count; e0 += kChunk) {
+    __builtin_amdgcn_wave_barrier();
+    hkey[lane] = -1;
+    __builtin_amdgcn_wave_barrier();
+    // 1. distinct queries of the live entries of this chunk
+    const unsigned e = e0 + (unsigned)lane;
+    long long qi = -1;
+    int i = 0;
+    bool livee = false;
+    unsigned h = 0;
+    if (lane < kChunk && e < count) {
+      const unsigned long long ent = seg[e];
+      qi = (long long)(ent >> 32);
+      i = (int)(ent & 0xffffffffu);
+      livee = i < a.n && qi < a.nq && a.best[qi] > i;   // a certain hit at or below i settles the pair
+    }
+    if (livee) {
+      h = ((unsigned)qi * 2654435761u) & 63u;
+      while (true) {
+        const int old = atomicCAS(&hkey[h], -1, (int)qi);
+        if (old == -1 || old == (int)qi) break;
+        h = (h + 1u) & 63u;
       }
-      if (kq == 0) a.slot[q] = (int)sl;
     }
-    const double *row = a.pts + q * (long long)d;
-    double dw[NK];
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-      const int k = 4 * ks + kq;
-      dw[ks] = k < d ? row[k] - a.lay_ctr[k] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    // 2. number the occupied slots
+    const bool occ = hkey[lane] != -1;
+    const unsigned long long bm = __ballot(occ);
+    const unsigned nqb = (unsigned)__popcll(bm);
+    if (occ) {
+      const unsigned id = (unsigned)__popcll(bm & ((1ull << lane) - 1ull));
+      hid[lane] = (int)id;
+      qlist[id] = hkey[lane];
     }
-    double4v t[NC];
+    __builtin_amdgcn_wave_barrier();
+    const unsigned myid = livee ? (unsigned)hid[h] : 0xffffffffu;
+    // 3. rounds of kTQ queries.  The rows of a round's queries are requested together and whitened together: one
+    // coalesced load of the matrix row T[k][.] (64 x 64 doubles, zero padded: a.T64; resident in the vector L1) feeds
+    // the chains of all of them.
+    const bool inrow = lane < d;
+    const double myctr = inrow ? a.lay_ctr[lane] : 0.0;
+    const double *tp = a.T64 + lane;
+    for (unsigned r0 = 0; r0 < nqb; r0 += kTQ) {
+      const unsigned nr = nqb - r0 < (unsigned)kTQ ? nqb - r0 : (unsigned)kTQ;   // wave-uniform
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int ct = 0; ct < NC; ++ct) t[ct] = (double4v){0.0, 0.0, 0.0, 0.0};
+      for (int t = 0; t < kTQ; ++t)
+        if ((unsigned)t < nr) dlw[t * 64 + lane] = inrow ? a.pts[(long long)qlist[r0 + t] * d + lane] - myctr : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      double acc[kTQ];
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks)
-#pragma unroll
-      for (int ct = 0; ct < NC; ++ct)
-        t[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.TtF[((size_t)ct * NK + ks) * 64 + lane], dw[ks], t[ct], 0, 0, 0);
-    if (valid) {
-      double *o = a.out + (size_t)sl * d;
-#pragma unroll
-      for (int ct = 0; ct < NC; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = 16 * ct + kq + 4 * r;
-          if (c < d) o[c] = t[ct][r];
+      for (int t = 0; t < kTQ; ++t) acc[t] = 0.0;
+      if (nr <= 2u) {   // the common case: keep the chains short
+#pragma unroll 10
+        for (int k = 0; k < d; ++k) {
+          const double tk = tp[k * 64];
+          acc[0] = __builtin_fma(dlw[k], tk, acc[0]);
+          acc[1] = __builtin_fma(dlw[64 + k], tk, acc[1]);
         }
+      } else {
+#pragma unroll 5
+        for (int k = 0; k < d; ++k) {
+          const double tk = tp[k * 64];
+#pragma unroll
+          for (int t = 0; t < kTQ; ++t) acc[t] = __builtin_fma(dlw[t * 64 + k], tk, acc[t]);   // rows past nr: zeros or stale, unused
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < kTQ; ++t)
+        if ((unsigned)t < nr && inrow) tq[t * ds + lane] = acc[t];
+      __builtin_amdgcn_wave_barrier();
+      if (livee && myid >= r0 && myid < r0 + kTQ && a.best[qi] > i) {
+        const double2 *ar = reinterpret_cast<const double2 *>(a.refR + (size_t)i * a.dp);   // rows are 16-byte aligned (dp even)
+        const double *br = tq + (myid - r0) * ds;
+        double accd = 0.0;
+        const int d2 = d >> 1;
+#pragma unroll 5
+        for (int k2 = 0; k2 < d2; ++k2) {   // the reference's loop: sub, mul, add, each rounded, k ascending
+          const double2 av = ar[k2];
+          const double d0 = av.x - br[2 * k2];
+          accd += d0 * d0;
+          const double d1 = av.y - br[2 * k2 + 1];
+          accd += d1 * d1;
+        }
+        if (d & 1) {
+          const double d0 = a.refR[(size_t)i * a.dp + d - 1] - br[d - 1];
+          accd += d0 * d0;
+        }
+        if (accd <= a.r2) atomicMin(&a.best[qi], i);
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
 
-hipError_t launch_whiten_slots(const WhitenSlotsArgs &a, long long max_slots, hipStream_t s) {
-  if (max_slots <= 0) return hipSuccess;
-  long long grid = (max_slots + 63) / 64;
-  if (grid > 1024) grid = 1024;
-  switch (prep3_ksteps(a.d)) {
-#define W(NKV)                                                                              \
-  case NKV:                                                                                 \
-    hipLaunchKernelGGL((k_whiten_slots<NKV>), dim3((unsigned)grid), dim3(256), 0, s, a);    \
-    break;
-    W(1) W(2) W(3) W(4) W(5) W(6) W(8) W(10) W(13) W(16)
-#undef W
-    default:
-      return hipErrorInvalidValue;
+static size_t recheck_w_lds(int d) { return ((size_t)kTQ * ((d + 1) | 1) + kTQ * 64) * sizeof(double) + (size_t)3 * 64 * sizeof(int); }
+
+void launch_recheck_whiten(const RecheckWArgs &a_in, hipStream_t s) {
+  if (a_in.nsegs <= 0) return;
+  RecheckWArgs a = a_in;
+  const size_t lds = recheck_w_lds(a.d);
+  static size_t attr_bytes = 0;
+  if (lds > 48 * 1024 && lds > attr_bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_recheck_whiten), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_bytes = lds;
   }
-  return hipGetLastError();
+  const unsigned grid = (unsigned)a.nsegs + (a.ell.count ? kEllWaves : 0u);
+  hipLaunchKernelGGL(k_recheck_whiten, dim3(grid), dim3(64), lds, s, a);
 }
 
 }  // namespace mlf

@@ -38,9 +38,8 @@ struct Prep4Args {
   float *tlo, *thi;
   uint8_t *route;
   int *best;
-  int *slot;              // out: -1 per proposal (exact-whitening slots are claimed later)
   unsigned *counters;
-  unsigned *scan_flag;
+  unsigned *scan_flag;    // set to 1 if a proposal of this batch is routed to the exact scan (reset by the scan launch of the NEXT batch's predecessor: two words alternate)
   int ks;
   long long nqpad;
 };
@@ -58,65 +57,25 @@ void prep4_lt_fragments(const double *L, int d, int dp, float *out);
 void prep4_t_fragments(const double *T, int d, int dp, float *out);
 hipError_t launch_prep4(const Prep4Args &a, hipStream_t s);
 
-// exact ellipsoid test of the proposals k_prep4 could not decide (bounded binary64 form first, the reference's
-// summation order only inside that form's own band)
-struct EllExactArgs {
-  unsigned *count;         // reset to 0 by the last workgroup
-  unsigned *done;          // workgroups finished (returns to 0)
-  unsigned *last;          // optional: receives the count before it is reset
-  const int *list;
-  unsigned cap;
-  const double *pts;
-  int d, dp;
-  const double *ell_ctr;   // [dp]
-  const double *ell_Lt;    // [dp][dp]  Lt[k][j] = L[j][k]
-  const double *ell_A;     // [d][dp]
-  double eps_scale, enlarge;
-  int chol_ok;
-  uint8_t *gate;
-  uint8_t *route;          // may be null
-};
 void launch_ell_exact(const EllExactArgs &a, hipStream_t s);
 
-// after the filter sweeps: which queries need their whitened coordinates in the reference arithmetic
-struct MarkArgs {
+// exact re-check of the uncertain pairs with the whitening of their queries inside the launch (mlf_prep4.hip)
+struct RecheckWArgs {
   const unsigned long long *list;
   unsigned seg_cap;
   const unsigned *seg_count;
   long long nsegs;
+  unsigned unit_cap;       // distinct queries a segment can hold pairs of
+  const double *refR;      // [npad][dp] whitened live points
+  int n, d, dp;
+  const double *pts;       // (nq, d) proposals as handed over
   long long nq;
-  int nlive;
-  const uint8_t *route;
-  const int *best;
-  const unsigned *counters;   // [1] = list overflow
-  int *slot;                  // [nq] -1 / claimed (-2) / dense slot (written by k_whiten_slots)
-  unsigned unit_cap;          // distinct queries a segment can hold pairs of
-  int *uq;                    // [nsegs][unit_cap] claimed queries per segment
-  unsigned *ucount;           // [nsegs + 1] claimed queries per segment (scanned in place afterwards)
-  int *xq;                    // [nq] queries routed to the exact scan
-  unsigned *nx;               // their number (shared counter: rare)
-  unsigned *scan_flag;        // set to 1 if any query takes the exact scan
-  EllExactArgs ell;           // ell.count != nullptr: the band proposals are decided by the tail of this launch
+  const double *lay_ctr;   // [>= d]
+  const double *T64;       // layer matrix as 64 x 64 row-major, zero padded: element (k, c) at T64[k * 64 + c]
+  double r2;
+  int *best;
+  EllExactArgs ell;        // ell.count != nullptr: the band proposals are decided by the last waves of this launch
 };
-void launch_mark_exact(const MarkArgs &a, hipStream_t s);
-
-// exact whitening (k-ascending binary64 FMA chain on v_mfma_f64_16x16x4_f64, identical to k_prep / k_prep3) of the
-// claimed queries into a compact buffer
-struct WhitenSlotsArgs {
-  const double *pts;
-  int d;
-  const int *xq;
-  const unsigned *nx;
-  const int *uq;
-  const unsigned *ubase;   // exclusive scan of the per-segment counts, total at [nsegs]
-  long long nsegs;
-  unsigned unit_cap;
-  int *slot;               // out: dense slot of every claimed query
-  const double *lay_ctr;
-  const double *TtF;       // k_prep3's fragments of T
-  double *out;             // [slot][d]
-  unsigned *stats_out;     // [0] = number of slots of this batch
-};
-hipError_t launch_whiten_slots(const WhitenSlotsArgs &a, long long max_slots, hipStream_t s);
+void launch_recheck_whiten(const RecheckWArgs &a, hipStream_t s);
 
 }  // namespace mlf

@@ -30,10 +30,31 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   __shared__ int any_active;
-  if (a.any_flag && *a.any_flag == 0u) return;   // device-side "nothing was routed to the exact scan"
+  if (a.fin_best && blockIdx.x >= a.fin_grid0) {   // tail: answers of the filtered queries
+    const long long p = ((long long)blockIdx.x - a.fin_grid0) * kScanThreads + tid;
+    if (p == 0 && a.fin_reset) *a.fin_reset = 0u;
+    if (p >= a.nq) return;
+    const int rt = a.route[p];
+    if (rt == 2 || (rt == 1 && a.counters[1] != 0u)) return;   // written by the scanning workgroups
+    const int b = a.fin_best[p];
+    const bool found = rt == 1 && b != kNone;
+    if (a.out_mask) a.out_mask[p] = found ? 1 : 0;
+    if (a.out_idx) a.out_idx[p] = rt == 0 ? -2ll : (found ? (long long)b : -1ll);
+    return;
+  }
+  const unsigned scan_blocks = a.fin_best ? a.fin_grid0 : gridDim.x;
+  const bool overflow = a.route && a.counters[1] != 0u;
+  if (a.any_flag && *a.any_flag == 0u && !overflow) return;   // nothing was routed to the exact scan
+  auto gated = [&](long long j) {
+    if (a.route) {
+      const int rt = a.route[j];
+      return rt == 2 || (rt == 1 && overflow);
+    }
+    return a.gate == nullptr || a.gate[j] != 0;
+  };
   const long long nqblk = (a.nq + kScanQB - 1) / kScanQB;
   // one workgroup per query block; the gated second-stage launch is a bounded grid that strides over the blocks
-  for (long long qblk = blockIdx.x; qblk < nqblk; qblk += gridDim.x) {
+  for (long long qblk = blockIdx.x; qblk < nqblk; qblk += scan_blocks) {
   const long long q0 = qblk * kScanQB;
   const long long left = a.nq - q0;
   const int nqb = left < kScanQB ? (int)left : kScanQB;
@@ -42,7 +63,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     __syncthreads();
     if (tid == 0) any_active = 0;
     __syncthreads();
-    if (tid < nqb && a.gate[q0 + tid] != 0) any_active = 1;
+    if (tid < nqb && gated(q0 + tid)) any_active = 1;
     __syncthreads();
     if (!any_active) continue;
   }
@@ -53,10 +74,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
       const int qq = e / DP;
       const int k = e - qq * DP;
       double v = 0.0;
-      if (qq < nqb && k < a.d) {
-        const long long row = a.slot ? (long long)a.slot[q0 + qq] : q0 + qq;
-        if (row >= 0) v = a.q[row * a.ldq + k];
-      }
+      if (qq < nqb && k < a.d) v = a.q[(q0 + qq) * a.ldq + k];
       qs[e] = v;
     }
   } else {  // coordinate-major source: consecutive threads read consecutive queries
@@ -64,16 +82,33 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
       const int k = e / kScanQB;
       const int qq = e - k * kScanQB;
       double v = 0.0;
-      if (qq < nqb && k < a.d) {
-        const long long row = a.slot ? (long long)a.slot[q0 + qq] : q0 + qq;
-        if (row >= 0) v = a.q[row * a.ldq + (long long)k * a.ldk];
-      }
+      if (qq < nqb && k < a.d) v = a.q[(q0 + qq) * a.ldq + (long long)k * a.ldk];
       qs[qq * DP + k] = v;
     }
   }
+  if (a.raw_ctr) {   // rows are proposals as handed over: whiten them in place (reference arithmetic, see ScanArgs)
+    constexpr int kPer = (kScanQB * DP + kScanThreads - 1) / kScanThreads;
+    double tv[kPer];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < kPer; ++m) {
+      const int idx = tid + m * kScanThreads;
+      const int qq = idx / a.d, c = idx - qq * a.d;
+      double acc = 0.0;
+      if (qq < kScanQB)
+        for (int k = 0; k < a.d; ++k) acc = __builtin_fma(qs[qq * DP + k] - a.raw_ctr[k], a.raw_T8[(size_t)k * a.raw_ldt + c], acc);
+      tv[m] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < kPer; ++m) {
+      const int idx = tid + m * kScanThreads;
+      const int qq = idx / a.d, c = idx - qq * a.d;
+      if (qq < kScanQB) qs[qq * DP + c] = tv[m];
+    }
+  }
   if (tid < kScanQB) {
-    const bool active = tid < nqb && (a.gate == nullptr || a.gate[q0 + tid] != 0) &&
-                        (a.slot == nullptr || a.slot[q0 + tid] >= 0);
+    const bool active = tid < nqb && gated(q0 + tid);
     state[tid] = active ? kNone : -1;
     cnt[tid] = 0;
   }
@@ -117,7 +152,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
   }
   __syncthreads();
 
-  if (tid < nqb && !(a.only_gated && a.gate[q0 + tid] == 0)) {
+  if (tid < nqb && !(a.only_gated && !gated(q0 + tid))) {
     const int st = state[tid];
     const bool found = st >= 0 && st != kNone;
     if (mode == SCAN_FIRST)
@@ -131,12 +166,18 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
   }
 }
 
-hipError_t launch_scan(int dp, const ScanArgs &a, hipStream_t s) {
-  if (a.nq <= 0) return hipSuccess;
+hipError_t launch_scan(int dp, const ScanArgs &a_in, hipStream_t s) {
+  if (a_in.nq <= 0) return hipSuccess;
+  ScanArgs a = a_in;
   const bool small = a.nq <= 16384;
   const int qb = small ? 16 : kScanQB;
   unsigned grid = (unsigned)((a.nq + qb - 1) / qb);
   if (a.only_gated && grid > 2048u) grid = 2048u;   // mostly idle: keep the dispatch short
+  if (a.fin_best) {
+    a.fin_grid0 = grid;
+    grid += (unsigned)((a.nq + kScanThreads - 1) / kScanThreads);
+  }
+
   switch (dp) {
 #define X(D)                                                                          \
   case D:                                                                             \
