@@ -38,7 +38,6 @@ sys.path.insert(0, ROOT)
 N_LIVE, NDIM, NPROPOSALS, NBOOT = 4000, 50, 1000000, 30
 FP64_VALU_PEAK_TFLOPS = 39.3     # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz, one flop per non-fused v_*_f64
 F16_MFMA_PEAK_TFLOPS = 2500.0    # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
-F32_MFMA_PEAK_TFLOPS = 157.3     # f32-in MFMA = the FP32 vector rate (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F16_FLOPS = 2 * 32 * 32 * 16   # one v_mfma_f32_32x32x16_f16
 
@@ -413,7 +412,8 @@ def main():
         roofline["hbm"] = hbm
     # per-proposal stage: row in (8 d), binary16 operand + thresholds + route / slot / best words out
     prep_bytes = NPROPOSALS * (8 * NDIM + 2 * kdim + 8 + 1 + 4 + 4 + 1)
-    prep_mfma_flops = NPROPOSALS / 32 * 84 * 2.0 * 32 * 32 * 2     # 84 v_mfma_f32_32x32x2_f32 per 32 proposals (d = 50)
+    prep_mfma_flops = NPROPOSALS / 32 * 42 * 2.0 * 32 * 32 * 16    # 42 v_mfma_f32_32x32x16_f16 per 32 proposals (d = 50):
+    # 3 partial products (hi hi, hi lo, lo hi) x [6 k-steps of the triangular L^T + 8 of T^T]
     out = {
         "metric": "proposal-points filtered/sec (MLFriends.inside) + region-rebuild ms, N=4000 d=50",
         "value": value, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -445,16 +445,16 @@ def main():
         "batch_counters": stats,
         "roofline": roofline,
         "roofline_exact_scan": exact_roof,
-        "roofline_prep": {"kernel": "k_prep4<50> (v_mfma_f32_32x32x2_f32 + global_load_lds staging)", "bound": "hbm",
+        "roofline_prep": {"kernel": "k_prep4<50> (split-binary16 v_mfma_f32_32x32x16_f16 + global_load_lds staging)", "bound": "hbm",
                           "unit": "GB/s", "achieved": prep_bytes / (prep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                           "frac": prep_bytes / (prep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                           "algorithmic_bytes_per_launch": prep_bytes,
-                          "mfma_f32": {"executed_flops_per_launch": prep_mfma_flops,
+                          "mfma_f16": {"executed_flops_per_launch": prep_mfma_flops,
                                        "achieved_TFLOPs": prep_mfma_flops / (prep_ms * 1e-3) / 1e12,
-                                       "peak_TFLOPs": F32_MFMA_PEAK_TFLOPS},
-                          "note": "the stage time includes the launch gap in front of the filter; on gfx950 the FP32 matrix "
-                                  "instructions and the vector ALU do not co-execute (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in "
-                                  "profiles/), so matrix and vector time add up: DESIGN.md section 4c"},
+                                       "peak_TFLOPs": F16_MFMA_PEAK_TFLOPS},
+                          "note": "the stage time includes the launch gap in front of the filter; the matrix work is 13 % "
+                                  "of the SIMD time (profiles/), the kernel is bound by getting 400 MB of proposals "
+                                  "through 2 waves per SIMD: DESIGN.md section 4c"},
         "host_api": hostapi,
     }
     if world == 1 and not args.no_cpu:

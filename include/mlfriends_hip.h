@@ -339,8 +339,8 @@ int mlf_allreduce_max(double *values, size_t count);
 int mlf_comm_destroy(void);
 
 /* Diagnostic counters of the LAST filtered batch of this region (synchronises the device): out[0] proposals the
- * binary32 ellipsoid form could not decide (k_ell_exact), out[1] queries whitened in the reference arithmetic for the
- * exact re-check / exact scan, out[2] uncertain pairs listed by the pre-filter, out[3] largest list segment, out[4]
+ * bounded ellipsoid form could not decide (decided in binary64 by the tail of the re-check launch), out[1] reserved
+ * (0), out[2] uncertain pairs listed by the pre-filter, out[3] largest list segment, out[4]
  * list segments, out[5] 32-query groups left for the second live-point range.  cap >= 6. */
 int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap);
 /* Measured issue rate of independent v_add_f64/v_mul_f64 (the non-fused FP64 vector rate that

@@ -1,10 +1,12 @@
 """Soundness of the bounded per-proposal stage (csrc/mlf_prep4.hip) on the CPU: a numpy restatement of the device
-arithmetic -- binary32 FMA chains (what v_mfma_f32_32x32x2_f32 computes, bit for bit a k-ascending fmaf chain), the
-binary32 decision with its outward factors, filter_thresholds4 -- checked against the reference's binary64 results.
+arithmetic -- split-binary16 matrix chains with binary32 accumulation (v_mfma_f32_32x32x16_f16 as probed on gfx950:
+two groups of 8 exact products per instruction, each added with one rounding; a rounded tree inside the groups is
+covered as well), the binary32 decision with its outward factors, filter_thresholds4 -- checked against the
+reference's binary64 results.
 
 Properties:
   ellipsoid   sure_in  => einsum-order q <= enlarge ;  sure_out => q > enlarge   (mlfriends.pyx:882-912)
-  chain       |y^ - y|_2 <= g (|y0| + |L|_F |delta|)                             (the eta / zeta of the kernel header)
+  chain       |y^ - y|_2 <= eta,  |bq - sigma (T^T delta - c_s)|_2 <= zeta        (the eta / zeta of the kernel header)
   filter      with a query operand built from ANY point within zeta of the exact whitened point:
               Dt <= T_lo => s <= r2 ;  Dt > T_hi => s > r2                       (s = the reference's sequential distance)
 """
@@ -16,16 +18,58 @@ UP = f32(1.0) + f32(2.0**-18)
 DN = f32(1.0) - f32(2.0**-18)
 
 
-def fma32_chain(start, a, b):
-    """fl32(a_n b_n + ... fl32(a_1 b_1 + start)) for rows: start (m,), a (m, n), b (n,) all float32"""
+def pow2_scale(v, e):
+    """power of two s with s v in [2^(e-1), 2^e)"""
+    return 2.0 ** (e - np.frexp(v)[1])
+
+
+def split16(x):
+    """two binary16 pieces of binary32 values: hi = fl16(x), lo = fl16(x - hi) (the subtraction is exact)"""
+    x = np.asarray(x, dtype=np.float32)
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo
+
+
+def split16_matrix(m, scale):
+    """host side: pieces of scale * m computed in binary64, and the representation error"""
+    x = m * scale
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float64)).astype(np.float16)
+    return hi, lo, x - hi.astype(np.float64) - lo.astype(np.float64)
+
+
+def _group_sum(prod, tree):
+    """sum of 8 exact products per row: exact (one rounding when added to C), or a depth-3 tree of binary32 additions"""
+    if not tree:
+        return prod.sum(axis=1)
+    v = prod
+    while v.shape[1] > 1:
+        v = (v[:, 0::2] + v[:, 1::2]).astype(np.float32).astype(np.float64)
+    return v[:, 0]
+
+
+def mfma16_chain(start, mh, ml, hi, lo, tree=False, k_from=None):
+    """v_mfma_f32_32x32x16_f16 chain as probed on gfx950 (scripts/probes/mfma16_acc_probe.hip): per instruction two
+    groups of 8 exact products, added to C one after the other with a binary32 rounding each; per k-step the three
+    partial products Mh hi, Mh lo, Ml hi.  start (m,) float32; mh, ml (m, K) float16; hi, lo (K,) float16."""
     acc = start.astype(np.float64)
-    for k in range(a.shape[1]):
-        acc = (a[:, k].astype(np.float64) * np.float64(b[k]) + acc).astype(np.float32).astype(np.float64)
+    K = mh.shape[1]
+    mh = mh.astype(np.float64)
+    ml = ml.astype(np.float64)
+    hi = hi.astype(np.float64)
+    lo = lo.astype(np.float64)
+    for s in range(0, K, 16):
+        for a, b in ((mh, hi), (mh, lo), (ml, hi)):
+            for g0 in (s, s + 8):
+                part = _group_sum(a[:, g0:g0 + 8] * b[g0:g0 + 8], tree)
+                acc = (acc + part).astype(np.float32).astype(np.float64)
     return acc.astype(np.float32)
 
 
 def g_chain(dp):
-    g = (dp + 4) * 2.0**-24 * (1 + 2.0**-10) + 2.0**-40
+    nsteps = 3 * ((dp + 15) // 16)
+    g = (4.0 * nsteps + 8.0) * 2.0**-24 * (1 + 2.0**-8) + 2.0**-21.6 + 2.0**-21.9
     return np.nextafter(f32(g), f32(np.inf))
 
 
@@ -48,36 +92,73 @@ def einsum_order_q(delta, A):
     return acc
 
 
-def ellipsoid_decision(x, c_lay, L, y0_f32, consts, enlarge):
-    """restatement of the H3 part of k_prep4 for one proposal; returns (sure_in, sure_out)"""
-    d = len(x)
-    dt = (x - c_lay).astype(np.float32)
-    Lt32 = L.T.astype(np.float32)                     # (L^T)[i][k] = L[k][i]
-    y = fma32_chain(y0_f32, Lt32, dt)
+def pad16(v, K):
+    out = np.zeros(v.shape[:-1] + (K,), dtype=v.dtype)
+    out[..., :v.shape[-1]] = v
+    return out
+
+
+class EllSetup:
+    """host constants of region_prep4_setup / region_prep4_centres (csrc/mlf_api.hip) for the ellipsoid chain"""
+
+    def __init__(self, L, A, c_ell, c_lay, amax):
+        d = L.shape[0]
+        dp = d + (d & 1)
+        self.K = K = 16 * ((dp + 15) // 16)
+        self.sx = pow2_scale(amax, 5)
+        self.sl = pow2_scale(np.abs(L).max(), 8)
+        lh, ll, err = split16_matrix(L.T, self.sl)
+        self.lh, self.ll = pad16(lh, K), pad16(ll, K)
+        s0 = c_lay - c_ell
+        y0 = L.T @ s0
+        self.y0 = y0
+        self.y0f = (y0 * self.sl * self.sx).astype(np.float32)
+        lf = np.linalg.norm(L)
+        self.g = g_chain(dp)
+        self.consts = dict(g=self.g, y0n=up32(np.linalg.norm(y0) * (1 + 1e-12)), lf=up32(lf * (1 + 1e-12)),
+                           el=up32(np.linalg.norm(err) / self.sl * (1 + 1e-12)),
+                           l_abs=up32(lf * np.sqrt(K) * 2.0**-25 / self.sx * (1 + 1e-12)),
+                           s0n=up32(np.linalg.norm(s0) * (1 + 1e-12)),
+                           eps_scale=up32(2.0**-34 * np.linalg.norm(A) * (1 + 1e-12)))
+        self.c_lay = c_lay
+
+    def operands(self, x):
+        xp = x * self.sx - self.sx * self.c_lay          # binary64, one rounding (the scalings are exact)
+        x32 = pad16(xp.astype(np.float32), self.K)
+        hi, lo = split16(x32)
+        dn2 = f32(0)
+        for v in x32:
+            dn2 = f32(np.float64(v) * np.float64(v) + np.float64(dn2))
+        return hi, lo, f32(dn2 * f32(1.0 / self.sx**2))
+
+
+def ellipsoid_decision(x, es, enlarge, tree):
+    """restatement of the H3 part of k_prep4 for one proposal; returns (sure_in, sure_out, y^)"""
+    c = es.consts
+    hi, lo, dn2 = es.operands(x)
+    y = mfma16_chain(es.y0f, es.lh, es.ll, hi, lo, tree)
     qs = f32(0)
     for v in y:                                       # the device sums per lane and adds two halves: any order of n + 1 roundings
         qs = f32(np.float64(v) * np.float64(v) + np.float64(qs))
-    dn2 = f32(0)
-    for v in dt:
-        dn2 = f32(np.float64(v) * np.float64(v) + np.float64(dn2))
+    qs = f32(qs * f32(1.0 / (es.sl * es.sx) ** 2))
     finite = bool(qs < f32(3e38) and dn2 < f32(3e38))
     sq = np.sqrt(qs)
     dnorm = np.sqrt(dn2) * UP + f32(2.0**-100)
-    eta = consts["g"] * (consts["y0n"] + consts["lf"] * dnorm) * UP
-    de = dnorm + consts["s0n"]
-    eps = consts["eps_scale"] * (de * de) * UP
-    hi = sq * UP + eta
-    qhi = ((hi * hi) * UP + eps) * UP
-    lo = (sq * DN - eta) * DN
-    qlo = ((lo * lo) * DN - eps * UP) * DN
-    return finite and bool(qhi < dn32(enlarge)), finite and bool(lo > 0) and bool(qlo > up32(enlarge))
+    eta = (c["g"] * (c["y0n"] + c["lf"] * dnorm) + c["el"] * dnorm + c["l_abs"]) * UP
+    de = dnorm + c["s0n"]
+    eps = c["eps_scale"] * (de * de) * UP
+    hi_ = sq * UP + eta
+    qhi = ((hi_ * hi_) * UP + eps) * UP
+    lo_ = (sq * DN - eta) * DN
+    qlo = ((lo_ * lo_) * DN - eps * UP) * DN
+    return (finite and bool(qhi < dn32(enlarge)), finite and bool(lo_ > 0) and bool(qlo > up32(enlarge)),
+            y.astype(np.float64) / (es.sl * es.sx), float(eta))
 
 
 @pytest.mark.parametrize("d,cond,shift", [(2, 1.0, 0.0), (5, 30.0, 1e-3), (20, 3.0, 0.0), (50, 1.5, 2e-3), (50, 40.0, 0.0),
                                           (64, 5.0, 1e-2)])
 def test_ellipsoid_decisions_are_sound_and_chain_error_is_bounded(d, cond, shift):
     rs = np.random.RandomState(d * 7 + int(cond))
-    dp = d + (d & 1)
     # a covariance with the requested condition number, its inverse as the ellipsoid matrix
     Q, _ = np.linalg.qr(rs.normal(size=(d, d)))
     ev = np.geomspace(1.0, cond**2, d) * 1e-3
@@ -86,24 +167,18 @@ def test_ellipsoid_decisions_are_sound_and_chain_error_is_bounded(d, cond, shift
     L = np.linalg.cholesky(A)
     c_ell = 0.5 + 0.01 * rs.normal(size=d)
     c_lay = c_ell + shift * rs.normal(size=d)
-    s0 = c_lay - c_ell
-    y0 = L.T @ s0
-    g = g_chain(dp)
-    consts = dict(g=g, y0n=up32(np.linalg.norm(y0) * (1 + 1e-12)), lf=up32(np.linalg.norm(L) * (1 + 1e-12)),
-                  s0n=up32(np.linalg.norm(s0) * (1 + 1e-12)),
-                  eps_scale=up32(2.0**-34 * np.linalg.norm(A) * (1 + 1e-12)))
     enlarge = float(d) * 1.3
     # proposals on and around the boundary q = enlarge (the only place where the decision is delicate)
-    z = rs.normal(size=(400, d))
+    z = rs.normal(size=(300, d))
     z /= np.linalg.norm(z, axis=1, keepdims=True)
-    radii = np.sqrt(enlarge) * np.concatenate((1 + 3e-6 * rs.normal(size=200), rs.uniform(0.3, 1.7, size=200)))
+    radii = np.sqrt(enlarge) * np.concatenate((1 + 3e-5 * rs.normal(size=150), rs.uniform(0.3, 1.7, size=150)))
     x = c_ell + (z * radii[:, None]) @ np.linalg.inv(L)            # |L^T (x - c_e)| = radius
+    es = EllSetup(L, A, c_ell, c_lay, np.abs(x - c_lay).max() * 0.7)
     nin = nout = nband = 0
-    y0_f32 = y0.astype(np.float32)
-    for row in x:
+    for i, row in enumerate(x):
         delta_e = row - c_ell
         q_ref = einsum_order_q(delta_e, A)
-        sure_in, sure_out = ellipsoid_decision(row, c_lay, L, y0_f32, consts, enlarge)
+        sure_in, sure_out, y_hat, eta = ellipsoid_decision(row, es, enlarge, tree=bool(i & 1))
         assert not (sure_in and sure_out)
         if sure_in:
             assert q_ref <= enlarge
@@ -114,14 +189,10 @@ def test_ellipsoid_decisions_are_sound_and_chain_error_is_bounded(d, cond, shift
         else:
             nband += 1
         # the error model itself, in the 2-norm
-        dlt = row - c_lay
-        y_hat = fma32_chain(y0_f32, L.T.astype(np.float32), dlt.astype(np.float32)).astype(np.float64)
-        y_true = L.T @ delta_e
-        bound = float(g) * (np.linalg.norm(y0) + np.linalg.norm(L) * np.linalg.norm(dlt))
-        assert np.linalg.norm(y_hat - y_true) <= bound
-    assert nin > 50 and nout > 50
-    # the band is what k_ell_exact has to decide: it must stay a small share away from the boundary cluster
-    assert nband < 260, (nin, nout, nband)
+        assert np.linalg.norm(y_hat - L.T @ delta_e) <= eta
+    assert nin > 40 and nout > 40
+    # the band is what the binary64 test has to decide: it must stay a small share away from the boundary cluster
+    assert nband < 200, (nin, nout, nband)
 
 
 def thresholds4(namax, nb, zeta, sqrt_k, sr_lo, sr_hi):
@@ -224,21 +295,38 @@ def _split3_f64(v):
 
 
 def test_whitening_chain_error_model():
-    """|bq - sigma (T^T delta - c_s)|_2 <= g (|sigma c_s| + sigma |T|_F |delta|) for the binary32 chain, also with the
-    -2 folded into the matrix (exact scaling)"""
+    """|bq - sigma (T^T delta - c_s)|_2 <= zeta = sigma [g (|c_s| + |T|_F |delta|) + |E_T|_F |delta| / s_T + |T|_F sqrt(K) 2^-25 / s_x]
+    for the split-binary16 chain; the epilogue v = fma(acc, -2 sigma / (s_T s_x), 2 sigma c_s) adds one rounding of a
+    value the binary16 conversion behind it rounds 2^13 times coarser (covered by Delta's binary16 term)"""
     rs = np.random.RandomState(11)
     for d, cond in ((6, 2.0), (50, 1.3), (50, 15.0), (64, 6.0)):
         dp = d + (d & 1)
+        K = 16 * ((dp + 15) // 16)
         Q, _ = np.linalg.qr(rs.normal(size=(d, d)))
         T = Q * np.geomspace(1.0, cond, d) * 20.0
         sigma = 2.0**-3
         cs = 0.01 * rs.normal(size=d)
         g = float(g_chain(dp))
-        M32 = (T.T.astype(np.float32) * f32(-2 * sigma))          # rows = outputs
-        start = (f32(2) * (sigma * cs).astype(np.float32))
-        for _ in range(30):
+        st = pow2_scale(np.abs(T).max(), 8)
+        sx = pow2_scale(0.12, 5)
+        th, tl, err = split16_matrix(T.T, st)              # rows = outputs
+        th, tl = pad16(th, K), pad16(tl, K)
+        tf = np.linalg.norm(T)
+        zt = g * tf + np.linalg.norm(err) / st
+        zt_abs = tf * np.sqrt(K) * 2.0**-25 / sx
+        c_lay = 0.5 + 0.01 * rs.normal(size=d)
+        for it in range(30):
             delta = 0.05 * rs.normal(size=d) * rs.uniform(0.1, 3)
-            out = fma32_chain(start, M32, delta.astype(np.float32)).astype(np.float64) / -2.0
-            exact = sigma * (T.T @ delta - cs)
-            bound = g * (np.linalg.norm(sigma * cs) + sigma * np.linalg.norm(T) * np.linalg.norm(delta))
-            assert np.linalg.norm(out - exact) <= bound
+            x = c_lay + delta
+            xp = x * sx - sx * c_lay
+            x32 = pad16(xp.astype(np.float32), K)
+            hi, lo = split16(x32)
+            acc = mfma16_chain(np.zeros(d, dtype=np.float32), th, tl, hi, lo, tree=bool(it & 1)).astype(np.float64)
+            kappa = -2.0 * sigma / (st * sx)
+            v = (acc * kappa + 2.0 * sigma * cs).astype(np.float32).astype(np.float64)
+            out = v / -2.0
+            dtrue = x - c_lay
+            exact = sigma * (T.T @ dtrue - cs)
+            dnorm = np.linalg.norm(x32.astype(np.float64)) / sx * (1 + 2.0**-18)
+            zeta = sigma * (zt * dnorm + g * np.linalg.norm(cs) + zt_abs)
+            assert np.linalg.norm(out - exact) <= zeta * (1 + 2.0**-20), (d, cond, it)

@@ -83,7 +83,7 @@ int g_filter_phases = 1;              // mlf_set_option("filter_phases", n): 0 s
 long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
 bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
 bool g_time_filter_launches = false;  // mlf_set_option("time_filter_launches", 0/1): event pairs around every k_filter launch of every call
-bool g_prep_bounded = true;           // mlf_set_option("prep_bounded", 0/1): FP32 matrix-core bounded stage (mlf_prep4.hip)
+bool g_prep_bounded = true;           // mlf_set_option("prep_bounded", 0/1): matrix-core bounded stage (mlf_prep4.hip)
 long long g_filter_min_queries = 2048;  // smaller batches go straight to the exact scan
 
 struct Ctx {
@@ -551,8 +551,15 @@ float f32_dn(double x) {
   return f;
 }
 
+// power of two s with s * amax in (2^(e-1), 2^e]
+double pow2_scale(double amax, int e) {
+  int ex = 0;
+  std::frexp(amax, &ex);   // amax = m 2^ex, m in [0.5, 1)
+  return std::ldexp(1.0, e - ex);
+}
+
 // k_prep4 subtracts the LAYER centre from every proposal; the ellipsoid form then starts its chain at
-// y0 = L^T (c_lay - c_ell).  Recomputed whenever one of the two centres changes.
+// y0 = L^T (c_lay - c_ell) (scaled like the accumulator: s_L s_x).  Recomputed whenever one of the two centres changes.
 int region_prep4_centres(mlf_region *r, hipStream_t s) {
   const int d = r->d;
   const std::vector<double> &L = r->h_L;
@@ -562,14 +569,15 @@ int region_prep4_centres(mlf_region *r, hipStream_t s) {
     s0[k] = r->h_lay_ctr[k] - r->h_ell_ctr[k];
     s0n2 += s0[k] * s0[k];
   }
+  const double acc_scale = 1.0 / (double)r->p4c.inv_sl_sx;
   std::vector<float> y0f((size_t)32 * ((r->dp + 31) / 32), 0.0f);
   for (int i = 0; i < d; ++i) {
     double y = 0.0;
     for (int k = i; k < d; ++k) y += L[(size_t)k * d + i] * s0[k];
     y0n2 += y * y;
-    y0f[i] = (float)y;
+    y0f[i] = (float)(y * acc_scale);
   }
-  if (!std::isfinite(s0n2) || !std::isfinite(y0n2) || std::sqrt(y0n2) > 1e30) {
+  if (!std::isfinite(s0n2) || !std::isfinite(y0n2) || std::sqrt(y0n2) * acc_scale > 1e30) {
     r->p4_ready = false;
     return 0;
   }
@@ -581,9 +589,10 @@ int region_prep4_centres(mlf_region *r, hipStream_t s) {
 }
 
 // Fragments and error constants of the bounded per-proposal stage.  L: lower Cholesky factor of the ellipsoid matrix,
-// fro2 = |A|_F^2; layer_T / layer_ctr may be null for regions without a neighbour scan.
+// fro2 = |A|_F^2; layer_T / layer_ctr may be null for regions without a neighbour scan; `live` = the cube-space live
+// points (n x d) or null: their spread around the layer centre fixes the scale of the binary16 proposal operand.
 int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2, const double *ell_center,
-                       const double *layer_ctr, const double *layer_T, hipStream_t s) {
+                       const double *layer_ctr, const double *layer_T, const double *live, size_t nlive, hipStream_t s) {
   r->p4_ready = false;
   const int d = r->d, dp = r->dp;
   if (!prep4_usable(d) || (dp & 1) || dp > 64 || !r->chol_ok || r->has_wrap) return 0;
@@ -596,19 +605,39 @@ int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2,
       lmax = std::fmax(lmax, std::fabs(v));
       if (k == i) dmin = std::fmin(dmin, v);
     }
-  if (!std::isfinite(lf2) || !(lmax < 1e30) || !(dmin > 0.0)) return 0;
-  const double g = (dp + 4) * std::ldexp(1.0, -24) * (1.0 + std::ldexp(1.0, -10)) + std::ldexp(1.0, -40);
+  if (!std::isfinite(lf2) || !(lmax > 0.0) || !(lmax < 1e100) || !(dmin > 0.0)) return 0;
+  const int nsteps = 3 * ((dp + 15) / 16);   // matrix instructions per output chain
+  const int kdim = 16 * ((dp + 15) / 16);
+  const double g = (4.0 * nsteps + 8.0) * std::ldexp(1.0, -24) * (1.0 + std::ldexp(1.0, -8)) + std::pow(2.0, -21.6) +
+                   std::pow(2.0, -21.9);
   const double lf = std::sqrt(lf2);
-  // share of the proposals near the boundary that the binary32 form cannot decide ~ d g |L|_F / sigma_min(L):
-  // beyond a few per cent the exact kernel behind it would dominate, the binary64 stage (k_prep3) is used instead
+  // share of the proposals near the boundary that the binary32 chain cannot decide ~ d g |L|_F / sigma_min(L):
+  // beyond a few per cent the binary64 test behind it would dominate, the binary64 stage (k_prep3) is used instead
   if (d * g * lf / dmin > 0.02) return 0;
-  r->p4c.g_chain = f32_up(g);
-  r->p4c.lf = f32_up(lf * (1.0 + 1e-12));
-  r->p4c.eps_scale = f32_up(std::ldexp(1.0, -34) * std::sqrt(fro2) * (1.0 + 1e-12));
-  r->p4c.tf = 0.0f;
+  // scale of the proposal operand: the live points' largest centred coordinate lands in (16, 32]; a region without
+  // live points uses the ellipsoid's extent, 1 / (smallest diagonal entry of L) being a bound on its semi-axes' scale
+  const double *ctr = r->use_scan ? layer_ctr : ell_center;
+  double amax = 0.0;
+  if (live)
+    for (size_t i = 0; i < nlive; ++i)
+      for (int k = 0; k < d; ++k) amax = std::fmax(amax, std::fabs(live[i * d + k] - ctr[k]));
+  if (!(amax > 0.0) || !std::isfinite(amax)) amax = 4.0 / dmin;
+  if (!(amax > 1e-60) || !(amax < 1e60)) return 0;
+  const double sx = pow2_scale(amax, 5);
+  const double sl = pow2_scale(lmax, 8);            // largest |s_L L| entry in (128, 256]
+  Prep4Consts &c = r->p4c;
+  c = Prep4Consts{};
+  c.g_chain = f32_up(g);
+  c.lf = f32_up(lf * (1.0 + 1e-12));
+  c.eps_scale = f32_up(std::ldexp(1.0, -34) * std::sqrt(fro2) * (1.0 + 1e-12));
+  c.s_x = (float)sx;
+  c.inv_sx = (float)(1.0 / sx);
+  c.inv_sl_sx = (float)(1.0 / (sl * sx));
+  c.l_abs = f32_up(lf * std::sqrt((double)kdim) * std::ldexp(1.0, -25) / sx * (1.0 + 1e-12));
+  if (!(c.inv_sl_sx > 0.0f) || !std::isfinite(1.0f / c.inv_sl_sx) || !(c.inv_sx > 0.0f)) return 0;
   r->h_L = L;
   r->h_ell_ctr.assign(ell_center, ell_center + d);
-  r->h_lay_ctr.assign(r->use_scan ? layer_ctr : ell_center, (r->use_scan ? layer_ctr : ell_center) + d);
+  r->h_lay_ctr.assign(ctr, ctr + d);
   {   // the lower factor itself, row-major with stride dp (the wave-per-proposal exact test reads its columns)
     std::vector<double> lrm((size_t)dp * dp, 0.0);
     for (int j = 0; j < d; ++j)
@@ -616,15 +645,16 @@ int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2,
     if (int rc = upload(r->ell_L, lrm.data(), lrm.size() * sizeof(double), s)) return rc;
     CK(hipStreamSynchronize(s));
   }
-  std::vector<float> ltf(prep4_ltf_count(dp));
-  prep4_lt_fragments(L.data(), d, dp, ltf.data());
-  if (int rc = upload(r->p4_LtF, ltf.data(), ltf.size() * sizeof(float), s)) return rc;
+  std::vector<uint16_t> ltf(prep4_ltf_count(dp));
+  const double el = prep4_lt_fragments(L.data(), d, dp, sl, ltf.data());
+  c.el = f32_up(el / sl * (1.0 + 1e-12));
+  if (int rc = upload(r->p4_LtF, ltf.data(), ltf.size() * sizeof(uint16_t), s)) return rc;
   if (r->use_scan) {
     double tf2 = 0.0, tmax = 0.0, cmin = INFINITY, cmax = 0.0;
-    for (int c = 0; c < d; ++c) {
+    for (int cc = 0; cc < d; ++cc) {
       double cn = 0.0;
       for (int k = 0; k < d; ++k) {
-        const double v = layer_T[(size_t)k * d + c];
+        const double v = layer_T[(size_t)k * d + cc];
         cn += v * v;
         tmax = std::fmax(tmax, std::fabs(v));
       }
@@ -632,14 +662,19 @@ int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2,
       cmin = std::fmin(cmin, cn);
       cmax = std::fmax(cmax, cn);
     }
-    if (!std::isfinite(tf2) || !(tmax < 1e30) || !(cmin > 0.0)) return 0;
+    if (!std::isfinite(tf2) || !(tmax > 0.0) || !(tmax < 1e100) || !(cmin > 0.0)) return 0;
     // zeta against the binary16 term of Delta: g sqrt(d) cond(T) < 2^-11, or the uncertainty band of the filter more than
     // doubles (T = eigenvectors x diag: the column norms are its singular values)
     if (g * std::sqrt((double)d) * std::sqrt(cmax / cmin) * 2048.0 > 1.0) return 0;
-    r->p4c.tf = f32_up(std::sqrt(tf2) * (1.0 + 1e-12));
-    std::vector<float> ttf(prep4_ttf_count(dp));
-    prep4_t_fragments(layer_T, d, dp, ttf.data());
-    if (int rc = upload(r->p4_TtF, ttf.data(), ttf.size() * sizeof(float), s)) return rc;
+    const double st = pow2_scale(tmax, 8);
+    const double tf = std::sqrt(tf2);
+    std::vector<uint16_t> ttf(prep4_ttf_count(dp));
+    const double et = prep4_t_fragments(layer_T, d, dp, st, ttf.data());
+    c.zt = f32_up((g * tf + et / st) * (1.0 + 1e-12));
+    c.zt_abs = f32_up(tf * std::sqrt((double)kdim) * std::ldexp(1.0, -25) / sx * (1.0 + 1e-12));
+    c.inv_st_sx = (float)(1.0 / (st * sx));
+    if (!(c.inv_st_sx > 0.0f) || !std::isfinite(1.0f / c.inv_st_sx)) return 0;
+    if (int rc = upload(r->p4_TtF, ttf.data(), ttf.size() * sizeof(uint16_t), s)) return rc;
     std::vector<double> t64((size_t)64 * 64, 0.0);   // for the exact whitening inside the re-check
     for (int k = 0; k < d; ++k)
       for (int c2 = 0; c2 < d; ++c2) t64[(size_t)k * 64 + c2] = layer_T[(size_t)k * d + c2];
@@ -689,7 +724,7 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
   ExactSrc xsrc{};
   if (r->use_scan && !bounded) CK(r->tq.reserve(np * (size_t)r->d * sizeof(double)));
   if (ev) CK(hipEventRecord(ev[0], s));
-  if (bounded) {   // FP32 matrix cores: bounded ellipsoid test + approximate whitening straight into the filter operand
+  if (bounded) {   // matrix cores (split binary16): bounded ellipsoid test + approximate whitening straight into the filter operand
     FilterCtx &f = r->filter;
     if (int rc = misc_reserve(f)) return rc;
     CK(f.ell_list.reserve(np * sizeof(int)));
@@ -698,9 +733,9 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
     pa.np = (long long)np;
     pa.d = r->d;
     pa.dp = r->dp;
-    pa.LtF = r->p4_LtF.as<float>();
+    pa.LtF = r->p4_LtF.p;
     pa.y0 = r->p4_y0.as<float>();
-    pa.TtF = r->p4_TtF.as<float>();
+    pa.TtF = r->p4_TtF.p;
     pa.lay_ctr = r->use_scan ? r->lay_ctr.as<double>() : r->ell_ctr.as<double>();
     pa.c = r->p4c;
     pa.c.enl_lo = f32_dn(r->enlarge);
@@ -1415,7 +1450,9 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
     if (int rc = filter_prepare_refs(r->filter, r->refR.as<double>(), (int)n, (int)d, dp, c.stream, true))
       return rc;
   }
-  if (int rc = region_prep4_setup(r, L, fro_sq, ell_center, layer_ctr, layer_T, c.stream)) return rc;
+  if (int rc = region_prep4_setup(r, L, fro_sq, ell_center, layer_ctr, layer_T, (use_scan && live_space) ? unormed : nullptr,
+                                  n, c.stream))
+    return rc;
   CK(hipStreamSynchronize(c.stream));
   r->ready = true;
   return 0;

@@ -5,35 +5,51 @@
 //
 // k_prep3 whitens every proposal in the reference's binary64 arithmetic and stores the result (400 MB per 10^6 x 50
 // batch) although only the ~10^-4 of the pairs that the pre-filter cannot decide ever read it.  Here both d x d
-// products run on the FP32 matrix cores (v_mfma_f32_32x32x2_f32: bit for bit a k-ascending binary32 FMA chain, one
-// rounding per term), the whitened point goes straight into the filter's binary16 operand fragments, and nothing
-// else is written.  What keeps the results identical to the reference's:
-//   * ellipsoid: q^ = |y^|^2 with y^ ~ L^T (x - c_e) carries a proven error eta (below); proposals with
-//     |sqrt q^ - sqrt enlarge| inside that band go to a list and k_ell_exact decides them in binary64;
+// products run on the matrix cores with SPLIT binary16 operands (v_mfma_f32_32x32x16_f16, binary32 accumulate), the
+// whitened point goes straight into the filter's binary16 operand fragments, and nothing else is written.  What
+// keeps the results identical to the reference's:
+//   * ellipsoid: q^ = |y^|^2 with y^ ~ L^T (x - c_e) carries an error bound eta (below); proposals with
+//     |sqrt q^ - sqrt enlarge| inside that band go to a list and are decided in binary64 (ell_exact_*);
 //   * whitening: |bq - sigma (b - c)| <= zeta enters the pre-filter's Delta (filter_thresholds4), so a pair is
-//     "certain" only if it is certain for every point within zeta; the queries of the uncertain pairs are whitened
-//     afterwards in the reference arithmetic (k_mark_exact / k_whiten_slots) for the exact re-check.
+//     "certain" only if it is certain for every point within zeta; the queries of the uncertain pairs are whitened in
+//     the reference arithmetic by the re-check itself (k_recheck_whiten).
 //
-// Error model.  delta_k = fl64(x_k - c_k), dt_k = fl32(delta_k).  A chain s = fma(a_n, b_n, ... fma(a_1, b_1, s_0))
-// of n binary32 terms satisfies |s - (s_0 + sum a_k b_k)| <= gamma_n (|s_0| + sum |a_k b_k|), gamma_n = n u / (1 - n u),
-// u = 2^-24; the operands are roundings of the binary64 matrix entries and of delta (each (1 + e), |e| <= u), the start
-// value is a rounding of a binary64 number.  Together: |y^_i - y_i| <= g (|y0_i| + sum_k |L_ki| |delta_k|) with
-// g = (n + 4) u (1 + 2^-10) + 2^-40 (the last term covers the binary64 roundings on the host), hence in the 2-norm
-//      eta  = g (|y0| + |L|_F |delta|)                      (Cauchy-Schwarz per row)
-//      zeta = g (|sigma c_s| + sigma |T|_F |delta|)
-// |delta| comes from the same dt_k (binary32 sum of squares, relative error <= (n + 2) u).  The reference's own
-// rounding of the quadratic form and the factorisation A = L L^T are covered by eps = 2^-34 |A|_F |x - c_e|^2 exactly
-// as in k_prep3.  The proposal is inside for certain if (sqrt q^ + eta)^2 + eps < enlarge, outside for certain if
-// (sqrt q^ - eta)^2 - eps > enlarge, everything else (NaN / inf included) is decided by k_ell_exact.
+// Why binary16 and not the FP32 matrix instructions (the first version of this kernel used v_mfma_f32_32x32x2_f32, a
+// bit-exact k-ascending fmaf chain): on gfx950 those execute on the vector ALU's own lanes -- SQ_VALU_MFMA_COEXEC_CYCLES
+// was 0, 78 us of matrix time and ~45 us of vector time simply added up (0.155 ms per 10^6 x 50 batch) -- while the
+// binary16 ones run beside the vector ALU and take a quarter of the time for the three partial products below.
 //
-// Layout.  One wave owns a group of 32 proposals = one 32-query group of the filter.  B operand (k x 32 proposals):
-// lane (p = l & 31, h = l >> 5) holds coordinate k = 2 s + h at k-step s.  A operand = 32 matrix rows x 2 k from LDS.
-// C (32 rows x 32 proposals): lane (p, h) holds rows i = (r & 3) + 8 (r >> 2) + 4 h, r = 0..15.  The host orders the
-// rows of T so that row i of tile t is filter column 32 t + 16 (r >> 3) + 8 h + (r & 7): a lane then holds, for
-// filter k-step 2 t + (r >> 3), exactly the 8 consecutive columns of its own fragment piece -- the f16 operand is
-// packed in registers and stored with one contiguous 1 KiB wave store per k-step, no transpose.
-// Rows arrive with coalesced 16-byte loads and are redistributed through a wave-private LDS buffer (odd row stride:
-// conflict-free ds_read_b64).  -ffp-contract=off; FMAs only where written.
+// Operands.  x' = s_x (x - c) (binary64 FMA: one rounding), x32 = fl32(x'), hi = fl16(x32), lo = fl16(x32 - hi); a matrix
+// entry m' = s_m m likewise Mh = fl16(m'), Ml = fl16(m' - Mh) (host, binary64; s_x, s_m powers of two that centre the
+// values in the binary16 range).  The chain adds, per output, the exact products Mh hi + Mh lo + Ml hi over all k
+// to the start value: 3 K / 16 matrix instructions.
+// Error model.  (1) operands: |x' - hi - lo| <= 2^-21.6 |x'| + 2^-25 per coordinate (fl32, then two binary16 roundings;
+// the absolute term covers binary16 subnormals); the dropped product |Ml lo| <= 2^-22 (1 + 2^-9) |m' x'|; the matrix's
+// own representation error E = m' - Mh - Ml is known exactly on the host.  (2) accumulation: one instruction sums its
+// two groups of 8 exact products and adds them to C one after the other, each step rounded to binary32
+// (scripts/probes/mfma16_acc_probe.hip: with C = -2^20, one product 2^20 and fifteen products 2^-8 the result is
+// 8 x 2^-8 or 0 depending on the group the large product sits in; random and cancelling inputs: error <= 4.3 u S for
+// one instruction, <= 6.8 u S for a chain of 12, u = 2^-24, S = |C| + sum |a b|).  The bound used is
+// nu = (4 n + 8) u for a chain of n instructions: twice the worst case of round-to-nearest steps (2 chain additions per
+// instruction + a depth-3 tree inside a group), which also covers truncating adders.  Together, per output row,
+//     |o^ - o| <= g (|start| + sum_k |m'_k x'_k|) + sum_k |E_k| |x'_k| + 2^-25 sum_k |m'_k|,   g = nu (1 + 2^-8) + 2^-21.6 + 2^-21.9
+// and in the 2-norm over the rows (Cauchy-Schwarz per row)
+//     eta  = g (|y0| + |L|_F |delta|) + |E_L|_F |delta| / s_L + |L|_F sqrt(K) 2^-25 / s_x
+//     zeta = sigma [ g (|c_s| + |T|_F |delta|) + |E_T|_F |delta| / s_T + |T|_F sqrt(K) 2^-25 / s_x ]
+// |delta| comes from the same x32 (binary32 sum of squares).  The reference's own rounding of the quadratic form and
+// the factorisation A = L L^T are covered by eps = 2^-34 |A|_F |x - c_e|^2 exactly as in k_prep3.  The proposal is inside
+// for certain if (sqrt q^ + eta)^2 + eps < enlarge, outside for certain if (sqrt q^ - eta)^2 - eps > enlarge,
+// everything else (NaN / inf included) is decided in binary64.
+//
+// Layout.  One wave owns a group of 32 proposals = one 32-query group of the filter.  B operand (16 k x 32 proposals):
+// lane (p = l & 31, h = l >> 5) holds coordinates 16 s + 8 h + j, j = 0..7, at k-step s.  A operand = 32 matrix rows x
+// 16 k from LDS (one ds_read_b128 per instruction).  C (32 rows x 32 proposals): lane (p, h) holds rows
+// i = (r & 3) + 8 (r >> 2) + 4 h, r = 0..15.  The host orders the rows of T so that row i of tile t is filter column
+// 32 t + 16 (r >> 3) + 8 h + (r & 7): a lane then holds, for filter k-step 2 t + (r >> 3), exactly the 8 consecutive
+// columns of its own fragment piece -- the f16 operand is packed in registers and stored with one contiguous 1 KiB wave
+// store per k-step, no transpose.  Rows arrive in LDS as they lie in HBM (global_load_lds, 16-byte pieces, no staging
+// registers); the next group's rows are in flight while the current one is processed.
+// -ffp-contract=off; FMAs only where written.
 #include "mlf_prep4.hpp"
 
 #include <math.h>
@@ -49,25 +65,29 @@ namespace mlf {
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef double double4v __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 namespace {
 
 template <int DP>
 struct P4 {
-  static constexpr int NKS = DP / 2;                    // k-steps of 2 coordinates
+  static constexpr int NS = (DP + 15) / 16;             // k-steps of 16 coordinates (K = 16 NS)
   static constexpr int KS = (DP + 6 + 15) / 16;         // filter k-steps of 16 binary16 columns
   static constexpr int NT = (KS + 1) / 2;               // 32-row output tiles of the whitening
   static constexpr int NE = (DP + 31) / 32;             // 32-row output tiles of L^T delta
   static constexpr int KMIN = DP <= 32 ? DP - 1 : (DP == 50 ? 49 : DP - 3);   // every d served by this instance exceeds KMIN - 1
-  static constexpr int NLT = NKS + (NE > 1 ? NKS - 16 : 0);   // stored k-steps of the L^T fragments
+  static constexpr int NLT = NS + (NE > 1 ? NS - 2 : 0);   // stored k-steps of the L^T fragments (tile 1: k >= 32)
   static constexpr int NPC = (DP + 3) / 4;              // 1 KiB pieces (64 lanes x 16 bytes) that cover a group of 32 rows
-  static constexpr int WAVE_DOUBLES = NPC * 128 + 64;   // staging buffer per wave: the group's rows as they lie in HBM,
-                                                        // then zeros for the operand columns past d
-  static constexpr size_t lds_bytes() {
-    return (size_t)(NT * NKS * 64 + NLT * 64 + 32 * NE + 32 * NT) * sizeof(float) + (size_t)DP * sizeof(double) +
-           (size_t)4 * WAVE_DOUBLES * sizeof(double);
+  static constexpr int WAVE_DOUBLES = NPC * 128 + 64;   // staging buffer per wave: the group's rows as they lie in HBM
+  static constexpr size_t lds_for(int waves) {
+    return (size_t)(2 * NT * NS + 2 * NLT) * 1024 + (size_t)(32 * NE + 32 * NT) * sizeof(float) +
+           (size_t)(16 * NS) * sizeof(double) + (size_t)waves * WAVE_DOUBLES * sizeof(double);
   }
+  // waves of a workgroup: one workgroup per CU with as many waves (up to two per SIMD, the register budget) as
+  // the 160 KiB of LDS hold staging buffers for -- the fragments are shared by the workgroup
+  static constexpr int NW = lds_for(8) <= 160 * 1024 ? 8 : (lds_for(6) <= 160 * 1024 ? 6 : 4);
+  static constexpr size_t lds_bytes() { return lds_for(NW); }
 };
 
 // filter column of row i of tile t of the whitening product
@@ -80,59 +100,68 @@ __device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32
 }  // namespace
 
 template <int DP>
-__global__ __launch_bounds__(256, 2) void k_prep4(Prep4Args a) {
+__global__ __launch_bounds__(64 * P4<DP>::NW, 1) void k_prep4(Prep4Args a) {
   using C = P4<DP>;
-  constexpr int NKS = C::NKS, NT = C::NT, NE = C::NE, KS = C::KS;
+  constexpr int NS = C::NS, NT = C::NT, NE = C::NE, KS = C::KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds4[];
-  float *TtF = reinterpret_cast<float *>(lds4);
-  float *LtF = TtF + NT * NKS * 64;
-  float *y0l = LtF + C::NLT * 64;
+  // A fragments, 1 KiB each (64 lanes x 8 binary16): T hi [NT][NS], T lo [NT][NS], L^T hi [NLT], L^T lo [NLT]
+  const uint4 *Th = reinterpret_cast<const uint4 *>(lds4);
+  const uint4 *Tl = Th + NT * NS * 64;
+  const uint4 *Lh = Tl + NT * NS * 64;
+  const uint4 *Ll = Lh + C::NLT * 64;
+  float *y0l = reinterpret_cast<float *>(const_cast<uint4 *>(Ll + C::NLT * 64));
   float *csl = y0l + 32 * NE;
-  double *ctrl = reinterpret_cast<double *>(csl + 32 * NT);
+  double *ctrl = reinterpret_cast<double *>(csl + 32 * NT);   // [16 NS] s_x c_k, zero past d
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int p32 = lane & 31, h = lane >> 5;
-  double *xs = ctrl + DP + wv * C::WAVE_DOUBLES;
+  double *xs = ctrl + 16 * NS + wv * C::WAVE_DOUBLES;
   const int d = a.d;
   const bool quant = a.do_tr != 0;
   constexpr float up = 1.0f + 0x1p-18f, dn = 1.0f - 0x1p-18f;
 
   const double sigma = quant ? a.stats[0] : 1.0;
-  const bool sig_ok = sigma >= 0x1p-60 && sigma <= 0x1p60;   // binary32 scaling of T stays exact
+  const bool sig_ok = sigma >= 0x1p-60 && sigma <= 0x1p60;
   const float sig_f = sig_ok ? (float)sigma : 1.0f;
   if (blockIdx.x == 0 && tid == 0 && a.counters) {
     a.counters[0] = 0;
     a.counters[1] = 0;
   }
-  if (quant)
-    for (int e = tid; e < NT * NKS * 64; e += 256) TtF[e] = a.TtF[e] * (-2.0f * sig_f);   // power of two: exact
-  for (int e = tid; e < C::NLT * 64; e += 256) LtF[e] = a.LtF[e];
-  if (tid < 32 * NE) y0l[tid] = a.y0[tid];
+  {
+    uint4 *dst = reinterpret_cast<uint4 *>(lds4);
+    const uint4 *srcT = reinterpret_cast<const uint4 *>(a.TtF);
+    const uint4 *srcL = reinterpret_cast<const uint4 *>(a.LtF);
+    if (quant)
+      for (int e = tid; e < 2 * NT * NS * 64; e += 64 * C::NW) dst[e] = srcT[e];
+    for (int e = tid; e < 2 * C::NLT * 64; e += 64 * C::NW) dst[2 * NT * NS * 64 + e] = srcL[e];
+  }
+  if (tid < 32 * NE) y0l[tid] = a.y0[tid];   // already scaled by s_L s_x
   if (tid < 32 * NT) {
     const int col = p4_column(tid >> 5, tid & 31);
-    csl[tid] = (quant && col < DP) ? 2.0f * (float)(sigma * a.stats[8 + col]) : 0.0f;   // chain = -2 (sigma t - sigma c_s)
+    csl[tid] = (quant && col < DP) ? 2.0f * (float)(sigma * a.stats[8 + col]) : 0.0f;   // + 2 sigma c_s: the operand is -2 (sigma t - sigma c_s)
   }
-  if (tid < DP) ctrl[tid] = tid < d ? a.lay_ctr[tid] : 0.0;
-  for (int e = lane; e < C::WAVE_DOUBLES; e += 64) xs[e] = 0.0;   // the padding columns stay zero for good
+  if (tid < 16 * NS) ctrl[tid] = tid < d ? (double)a.c.s_x * a.lay_ctr[tid] : 0.0;
   __syncthreads();
 
-  // uniform per-kernel quantities of the thresholds (binary32, rounded outward)
-  float namax = 0.0f, zeta_scale = 0.0f, zeta0 = 0.0f, sr_lo = 0.0f, sr_hi = 0.0f;
+  // uniform per-kernel quantities (binary32, rounded outward)
+  float namax = 0.0f, zeta_scale = 0.0f, zeta0 = 0.0f, sr_lo = 0.0f, sr_hi = 0.0f, kappa = 0.0f;
   const float sqrt_k = __builtin_sqrtf((float)(16 * KS));
   if (quant) {
     namax = (float)a.stats[1] * up;
     float cs2 = 0.0f;
     for (int e = 0; e < 32 * NT; ++e) cs2 = __builtin_fmaf(csl[e], csl[e], cs2);
     const float csn = 0.5f * __builtin_sqrtf(cs2) * up;
-    zeta_scale = a.c.g_chain * (sig_f * a.c.tf) * up;
-    zeta0 = a.c.g_chain * csn * up + 0x1p-100f;
+    zeta_scale = sig_f * a.c.zt * up;                                   // per unit |delta|
+    zeta0 = (a.c.g_chain * csn + sig_f * a.c.zt_abs) * up + 0x1p-100f;
+    kappa = -2.0f * sig_f * a.c.inv_st_sx;                              // accumulator -> -2 sigma t (powers of two: exact)
     const double sr = sigma * sqrt(a.r2);
     sr_lo = (float)(sr * (1.0 - 0x1p-30)) * dn;
     sr_hi = (float)(sr * (1.0 + 0x1p-30)) * up;
   }
+  const float inv_sx2 = a.c.inv_sx * a.c.inv_sx, inv_slsx2 = a.c.inv_sl_sx * a.c.inv_sl_sx;
 
   const long long ngroups = quant ? a.nqpad / 32 : (a.np + 31) / 32;
-  const long long wave_id = (long long)blockIdx.x * 4 + wv;
-  const long long nwaves = (long long)gridDim.x * 4;
+  const long long wave_id = (long long)blockIdx.x * C::NW + wv;
+  const long long nwaves = (long long)gridDim.x * C::NW;
   const long long total = a.np * (long long)d;
 
   // A group of 32 rows is 32 d contiguous doubles; it is copied as it lies, in 16-byte pieces, straight into the
@@ -157,31 +186,52 @@ __global__ __launch_bounds__(256, 2) void k_prep4(Prep4Args a) {
       }
     }
   };
-  // operands of the staged group: lane (p, h) takes coordinates 2 s + h of row p, centred and rounded to binary32;
-  // returns the lane's part of |dt|^2.  Coordinates past d: the centre table holds NaN there -> 0.
-  auto operands = [&](float *dt) {
+  // operands of the staged group: lane (p, h) takes coordinates 16 s + 8 h + j of row p, centred and scaled in binary64
+  // (one FMA), rounded to binary32 and split into two binary16 pieces; returns the lane's part of |x32|^2
+  const double sxd = (double)a.c.s_x;
+  auto operands = [&](half8v *hi, half8v *lo) {
     float dn2 = 0.0f;
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      const int k = 2 * s + h;
-      const double xv = xs[p32 * d + k] - ctrl[k];
-      const double dl = (2 * s + 1 < C::KMIN || k < d) ? xv : 0.0;
-      dt[s] = (float)dl;
-      dn2 = __builtin_fmaf(dt[s], dt[s], dn2);
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int j2 = 0; j2 < 4; ++j2) {
+        float x32[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int jj = 2 * j2 + e;
+          const int k = 16 * s + 8 * h + jj;
+          const bool ok = 16 * s + 8 + jj < C::KMIN || k < d;   // columns below KMIN exist for every d of this instance
+          const double xv = __builtin_fma(xs[p32 * d + k], sxd, -ctrl[k < 16 * NS ? k : 0]);   // unconditional read
+          x32[e] = ok ? (float)xv : 0.0f;
+          dn2 = __builtin_fmaf(x32[e], x32[e], dn2);
+        }
+        const half2v hp = __builtin_convertvector((float2v){x32[0], x32[1]}, half2v);
+        const float2v res = {x32[0] - (float)hp[0], x32[1] - (float)hp[1]};   // exact
+        const half2v lp = __builtin_convertvector(res, half2v);
+        hi[s][2 * j2] = hp[0];
+        hi[s][2 * j2 + 1] = hp[1];
+        lo[s][2 * j2] = lp[0];
+        lo[s][2 * j2 + 1] = lp[1];
+      }
     }
     return dn2;
   };
+  auto frag = [&](const uint4 *base, int idx) {
+    union { uint4 u; half8v h; } cv;
+    cv.u = base[idx * 64 + lane];
+    return cv.h;
+  };
 
-  // Software pipeline over the wave's groups: while the matrix cores work on group g (operands dta, in registers), the
-  // same basic block converts group g + 1 and packs the binary16 operand of group g, so that the vector work sits in
-  // the shadow of the 64-cycle MFMAs; the rows of group g + 2 are in flight towards LDS meanwhile.
-  float dta[NKS];
+  // Pipeline over the wave's groups: the rows of group g + 1 travel to LDS while group g is processed; at the end of
+  // the iteration they are turned into operands and the rows of group g + 2 set out.  Matrix and vector phases of the
+  // two waves of a SIMD overlap each other (the binary16 matrix instructions run beside the vector ALU).
+  half8v hia[NS], loa[NS];
   float dn2a = 0.0f;
   if (wave_id < ngroups) {
     fetch_group(wave_id);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    dn2a = operands(dta);
+    dn2a = operands(hia, loa);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next group overwrites the rows
     __builtin_amdgcn_wave_barrier();
     fetch_group(wave_id + nwaves);
@@ -191,80 +241,50 @@ __global__ __launch_bounds__(256, 2) void k_prep4(Prep4Args a) {
     const long long p = grp * 32 + p32;
     const bool live = p < a.np;
 
-    // ---- section 1: y^ = y0 + L^T delta (group g) on the matrix cores || operands of group g + 1 on the vector unit
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows of group g + 1 have landed
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    float dtb[NKS];
-    float dn2b = 0.0f;
+    // ---- y^ = y0 + L^T delta
+    float qs = 0.0f;
+    {
     float16v ye[NE];
 #pragma unroll
     for (int t = 0; t < NE; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ye[t][r] = y0l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
+    for (int t = 0; t < NE; ++t)
 #pragma unroll
-      for (int t = 0; t < NE; ++t)
-        if (s >= 16 * t)   // L^T is upper triangular: rows 32 t.. have no entries left of column 32 t
-          ye[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(LtF[((t ? NKS : 0) + s - 16 * t) * 64 + lane], dta[s], ye[t], 0, 0, 0);
-      const int k = 2 * s + h;
-      const double xv = xs[p32 * d + k] - ctrl[k];   // unconditional read (a conditional one becomes a branch)
-      const double dl = (2 * s + 1 < C::KMIN || k < d) ? xv : 0.0;
-      dtb[s] = (float)dl;
-      dn2b = __builtin_fmaf(dtb[s], dtb[s], dn2b);
-    }
-    // issue order: per k-step the matrix instruction(s), the LDS reads of a later step, three vector instructions
-#pragma unroll
-    for (int s = 0; s < (NE > 1 ? 16 : NKS); ++s) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-    }
-    if constexpr (NE > 1) {
-#pragma unroll
-      for (int s = 16; s < NKS; ++s) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      for (int s = 2 * t; s < NS; ++s) {   // L^T is upper triangular: rows 32 t.. have no entries left of column 32 t
+        const int f = (t ? NS : 0) + s - 2 * t;
+        const half8v lh = frag(Lh, f), ll = frag(Ll, f);
+        ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh, hia[s], ye[t], 0, 0, 0);
+        ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh, loa[s], ye[t], 0, 0, 0);
+        ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ll, hia[s], ye[t], 0, 0, 0);
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operands(g + 1) have left the LDS buffer ...
-    __builtin_amdgcn_wave_barrier();
-    fetch_group(grp + 2 * nwaves);                       // ... group g + 2 goes into flight
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- section 2: -2 bq = -2 (sigma T^T delta - sigma c_s), tile by tile || the ellipsoid decision, then the
-    // binary16 packing of the tile before
-    float16v tt[NT];
-    unsigned pk[NT * 8];
-    float nbq = 0.0f;
-    auto pack_tile = [&](int t) {   // columns -2 bh of one tile, and its share of 4 |bh|^2
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const float2v v = {tt[t][2 * m], tt[t][2 * m + 1]};
-        union { half2v v; unsigned u; } cv;
-        cv.v = __builtin_convertvector(v, half2v);
-        const float f0 = (float)cv.v[0], f1 = (float)cv.v[1];
-        nbq = __builtin_fmaf(f0, f0, nbq);
-        nbq = __builtin_fmaf(f1, f1, nbq);
-        pk[t * 8 + m] = cv.u;
-      }
-    };
-    if (quant) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tt[0][r] = csl[(r & 3) + 8 * (r >> 2) + 4 * h];
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) tt[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(TtF[s * 64 + lane], dta[s], tt[0], 0, 0, 0);
-    }
-    float qs = 0.0f;
 #pragma unroll
     for (int t = 0; t < NE; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) qs = __builtin_fmaf(ye[t][r], ye[t][r], qs);
-    qs = half_sum(qs);
-    const float dn2 = half_sum(dn2a);
+    }
+
+    // ---- -2 bq = -2 (sigma T^T delta - sigma c_s), straight into the filter operand
+    float16v tt[NT];
+    unsigned pk[NT * 8];
+    float nbq = 0.0f;
+    if (quant) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        tt[t] = (float16v){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const half8v th = frag(Th, t * NS + s), tl = frag(Tl, t * NS + s);
+          tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, hia[s], tt[t], 0, 0, 0);
+          tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, loa[s], tt[t], 0, 0, 0);
+          tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, hia[s], tt[t], 0, 0, 0);
+        }
+      }
+    }
+
+    qs = half_sum(qs) * inv_slsx2;          // powers of two: exact scalings
+    const float dn2 = half_sum(dn2a) * inv_sx2;
 
     bool sure_in = false, sure_out = false;
     float dnorm = 0.0f;
@@ -272,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void k_prep4(Prep4Args a) {
       const bool finite = qs < 3.0e38f && dn2 < 3.0e38f;   // false for NaN
       const float sq = __builtin_sqrtf(qs);
       dnorm = __builtin_sqrtf(dn2) * up + 0x1p-100f;
-      const float eta = a.c.g_chain * (a.c.y0n + a.c.lf * dnorm) * up;
+      const float eta = (a.c.g_chain * (a.c.y0n + a.c.lf * dnorm) + a.c.el * dnorm + a.c.l_abs) * up;
       const float de = dnorm + a.c.s0n;
       const float eps = a.c.eps_scale * (de * de) * up;
       const float hi = sq * up + eta;
@@ -282,32 +302,8 @@ __global__ __launch_bounds__(256, 2) void k_prep4(Prep4Args a) {
       sure_in = finite && qhi < a.c.enl_lo;
       sure_out = finite && lo > 0.0f && qlo > a.c.enl_hi;
     }
-    if (quant) {
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) {   // one matrix instruction, then up to four vector instructions of the decision
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 1; t < NT; ++t) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tt[t][r] = csl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
-#pragma unroll
-        for (int s = 0; s < NKS; ++s)
-          tt[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(TtF[(t * NKS + s) * 64 + lane], dta[s], tt[t], 0, 0, 0);
-        pack_tile(t - 1);
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      pack_tile(NT - 1);
-    }
     const bool band = live && !sure_in && !sure_out;
-    const bool ins_any = live && !sure_out;   // band proposals: provisionally inside, k_ell_exact has the last word
+    const bool ins_any = live && !sure_out;   // band proposals: provisionally inside, the binary64 test has the last word
     {
       const unsigned long long bm = __ballot(band && h == 0);
       if (bm != 0ull) {   // wave-uniform, rare
@@ -323,6 +319,20 @@ __global__ __launch_bounds__(256, 2) void k_prep4(Prep4Args a) {
     if (live && h == 0) a.gate[p] = ins_any ? 1 : 0;
 
     if (quant) {
+      // binary16 operand: columns -2 bh, and 4 |bh|^2
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const float v0 = __builtin_fmaf(tt[t][2 * m], kappa, csl[32 * t + ((2 * m) & 3) + 8 * ((2 * m) >> 2) + 4 * h]);
+          const float v1 = __builtin_fmaf(tt[t][2 * m + 1], kappa, csl[32 * t + ((2 * m + 1) & 3) + 8 * ((2 * m + 1) >> 2) + 4 * h]);
+          union { half2v v; unsigned u; } cv;
+          cv.v = __builtin_convertvector((float2v){v0, v1}, half2v);
+          const float f0 = (float)cv.v[0], f1 = (float)cv.v[1];
+          nbq = __builtin_fmaf(f0, f0, nbq);
+          nbq = __builtin_fmaf(f1, f1, nbq);
+          pk[t * 8 + m] = cv.u;
+        }
       const float nb = 0.25f * half_sum(nbq);   // |bh|^2
       int rt = ins_any ? 1 : 0;
       if (rt == 1 && (!sig_ok || !(nb <= 29000.0f))) rt = 2;   // NaN / inf / does not fit binary16: exact scan
@@ -365,44 +375,80 @@ __global__ __launch_bounds__(256, 2) void k_prep4(Prep4Args a) {
         }
       }
     }
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) dta[s] = dtb[s];
-    dn2a = dn2b;
+    // ---- operands of group g + 1 (its rows have been in LDS for a while); then group g + 2 sets out
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    dn2a = operands(hia, loa);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the rows are overwritten
+    __builtin_amdgcn_wave_barrier();
+    fetch_group(grp + 2 * nwaves);
   }
 }
 
 // ---------------------------------------------------------------- host helpers -----------------
 bool prep4_usable(int d) { return d >= 1 && d <= 64; }
 
+static int p4_ns(int dp) { return (dp + 15) / 16; }
 static int p4_nt(int dp) { return (((dp + 6 + 15) / 16) + 1) / 2; }
 static int p4_ne(int dp) { return (dp + 31) / 32; }
+static int p4_nlt(int dp) { return p4_ns(dp) + (p4_ne(dp) > 1 ? p4_ns(dp) - 2 : 0); }
 
-size_t prep4_ltf_count(int dp) {
-  const int nks = dp / 2;
-  return (size_t)(nks + (p4_ne(dp) > 1 ? nks - 16 : 0)) * 64;
+size_t prep4_ltf_count(int dp) { return (size_t)2 * p4_nlt(dp) * 512; }   // binary16 values: hi block then lo block
+size_t prep4_ttf_count(int dp) { return (size_t)2 * p4_nt(dp) * p4_ns(dp) * 512; }
+
+namespace {
+// split s * v into two binary16 pieces; returns the representation error s v - hi - lo
+double split16(double v, double s, _Float16 *hi, _Float16 *lo) {
+  const double x = v * s;
+  const _Float16 h = (_Float16)x;
+  const _Float16 l = (_Float16)(x - (double)h);
+  *hi = h;
+  *lo = l;
+  return x - (double)h - (double)l;
 }
+}  // namespace
 
-size_t prep4_ttf_count(int dp) { return (size_t)p4_nt(dp) * (dp / 2) * 64; }
-
-void prep4_lt_fragments(const double *L, int d, int dp, float *out) {
-  const int nks = dp / 2, ne = p4_ne(dp);
+// fragments of (s_L L)^T: tile t (rows 32 t ..), k-steps s >= 2 t; lane (i, hh) holds (L^T)[32 t + i][16 s + 8 hh + j].
+// Returns |E|_F (representation error of the scaled matrix).
+double prep4_lt_fragments(const double *L, int d, int dp, double scale, uint16_t *out_bits) {
+  _Float16 *out = reinterpret_cast<_Float16 *>(out_bits);
+  const int ns = p4_ns(dp), ne = p4_ne(dp), nlt = p4_nlt(dp);
+  double e2 = 0.0;
   size_t f = 0;
   for (int t = 0; t < ne; ++t)
-    for (int s = 16 * t; s < nks; ++s, ++f)
-      for (int l = 0; l < 64; ++l) {
-        const int row = 32 * t + (l & 31), k = 2 * s + (l >> 5);
-        out[f * 64 + l] = (row < d && k < d) ? (float)L[(size_t)k * d + row] : 0.0f;   // (L^T)[row][k]
-      }
+    for (int s = 2 * t; s < ns; ++s, ++f)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+          const int row = 32 * t + (l & 31), k = 16 * s + 8 * (l >> 5) + j;
+          const double v = (row < d && k < d) ? L[(size_t)k * d + row] : 0.0;   // (L^T)[row][k]
+          _Float16 hi, lo;
+          const double e = split16(v, scale, &hi, &lo);
+          e2 += e * e;
+          out[(f * 64 + l) * 8 + j] = hi;
+          out[((size_t)nlt * 64 + f * 64 + l) * 8 + j] = lo;
+        }
+  return std::sqrt(e2);
 }
 
-void prep4_t_fragments(const double *T, int d, int dp, float *out) {
-  const int nks = dp / 2, nt = p4_nt(dp);
+// fragments of (s_T T)^T with the rows in filter-column order: tile t, k-step s; lane (i, hh) holds T[16 s + 8 hh + j][col(t, i)]
+double prep4_t_fragments(const double *T, int d, int dp, double scale, uint16_t *out_bits) {
+  _Float16 *out = reinterpret_cast<_Float16 *>(out_bits);
+  const int ns = p4_ns(dp), nt = p4_nt(dp);
+  double e2 = 0.0;
   for (int t = 0; t < nt; ++t)
-    for (int s = 0; s < nks; ++s)
-      for (int l = 0; l < 64; ++l) {
-        const int col = p4_column(t, l & 31), k = 2 * s + (l >> 5);
-        out[((size_t)t * nks + s) * 64 + l] = (col < d && k < d) ? (float)T[(size_t)k * d + col] : 0.0f;
-      }
+    for (int s = 0; s < ns; ++s)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+          const int col = p4_column(t, l & 31), k = 16 * s + 8 * (l >> 5) + j;
+          const double v = (col < d && k < d) ? T[(size_t)k * d + col] : 0.0;
+          _Float16 hi, lo;
+          const double e = split16(v, scale, &hi, &lo);
+          e2 += e * e;
+          const size_t f = (size_t)t * ns + s;
+          out[(f * 64 + l) * 8 + j] = hi;
+          out[(((size_t)nt * ns + f) * 64 + l) * 8 + j] = lo;
+        }
+  return std::sqrt(e2);
 }
 
 hipError_t launch_prep4(const Prep4Args &a, hipStream_t s) {
@@ -421,10 +467,9 @@ hipError_t launch_prep4(const Prep4Args &a, hipStream_t s) {
       attr_set = true;                                                                                           \
     }                                                                                                            \
     if (a.do_tr && a.ks != P4<D>::KS) return hipErrorInvalidValue;                                               \
-    const long long per_cu = (160 * 1024) / (long long)lds >= 2 ? 2 : 1;                                         \
-    long long grid = (groups + 3) / 4;                                                                           \
-    if (grid > 256 * per_cu) grid = 256 * per_cu;                                                                \
-    hipLaunchKernelGGL((k_prep4<D>), dim3((unsigned)grid), dim3(256), lds, s, a);                                \
+    long long grid = (groups + P4<D>::NW - 1) / P4<D>::NW;                                                       \
+    if (grid > 256) grid = 256;                                                                                  \
+    hipLaunchKernelGGL((k_prep4<D>), dim3((unsigned)grid), dim3(64 * P4<D>::NW), lds, s, a);                     \
     break;                                                                                                       \
   }
     MLF_FOR_EACH_DP_PREP4(X)

@@ -1,28 +1,36 @@
-// mlf_prep4.hpp -- bounded per-proposal stage of MLFriends.inside on the FP32 matrix cores (mlf_prep4.hip) and the
+// mlf_prep4.hpp -- bounded per-proposal stage of MLFriends.inside on the matrix cores (split binary16 operands) (mlf_prep4.hip) and the
 // exact side kernels that go with it (ellipsoid band, exact whitening of the few queries that need it)
 #pragma once
 #include "mlf_common.hpp"
 
 namespace mlf {
 
-// Host-side constants of one region for k_prep4, all in binary32 and rounded in the safe direction.
+// Host-side constants of one region for k_prep4 (error model: header of mlf_prep4.hip), all in binary32 and rounded
+// in the safe direction; the scales are powers of two.
 struct Prep4Consts {
-  float g_chain;     // relative error of one binary32 FMA chain incl. operand rounding: (DP + 4) 2^-24 (1 + 2^-10) + 2^-40
+  float g_chain;     // g: relative error of one split-binary16 chain (accumulation + operand splitting + dropped product)
   float y0n;         // >= | L^T (c_lay - c_ell) |
   float lf;          // >= | L |_F                (A = L L^T, the ellipsoid matrix)
+  float el;          // >= | E_L |_F / s_L        (representation error of the two binary16 pieces of s_L L)
+  float l_abs;       // >= | L |_F sqrt(K) 2^-25 / s_x     (binary16 subnormals of the proposal operand)
   float s0n;         // >= | c_lay - c_ell |
   float eps_scale;   // >= 2^-34 | A |_F          (reference rounding + factorisation, as in k_prep3)
   float enl_lo, enl_hi;   // enlarge rounded down / up
-  float tf;          // >= | T |_F                (layer matrix, unscaled)
+  float zt;          // >= g | T |_F + | E_T |_F / s_T     (zeta per unit sigma |delta|)
+  float zt_abs;      // >= | T |_F sqrt(K) 2^-25 / s_x     (zeta's absolute term per unit sigma)
+  float s_x;         // scale of the centred proposal
+  float inv_sx;      // 1 / s_x
+  float inv_sl_sx;   // 1 / (s_L s_x): accumulator of the ellipsoid chain -> y
+  float inv_st_sx;   // 1 / (s_T s_x): accumulator of the whitening chain -> T^T delta
 };
 
 struct Prep4Args {
   const double *pts;      // (np, d) row-major proposals, 16-byte aligned
   long long np;
   int d, dp;
-  const float *LtF;       // A fragments of L^T: tile t (32 rows), k-steps s >= 16 t; lane (i, h) holds L[2s+h][32t+i]
-  const float *y0;        // [32 NE] start values of the ellipsoid chain
-  const float *TtF;       // A fragments of T (unscaled): [NT][DP/2][64], rows in filter-column order (see .hip)
+  const void *LtF;        // binary16 A fragments of s_L L^T, hi block then lo block (prep4_lt_fragments)
+  const float *y0;        // [32 NE] start values of the ellipsoid chain: s_L s_x L^T (c_lay - c_ell)
+  const void *TtF;        // binary16 A fragments of s_T T^T, rows in filter-column order, hi block then lo block
   const double *lay_ctr;  // [>= d]
   Prep4Consts c;
   uint8_t *gate;          // out: inside the wrapping ellipsoid (band proposals: provisionally 1)
@@ -50,11 +58,12 @@ struct Prep4Args {
   X(36) X(40) X(44) X(48) X(50) X(52) X(56) X(60) X(64)
 
 bool prep4_usable(int d);                       // d <= 64
-size_t prep4_ltf_count(int dp);                 // floats
+size_t prep4_ltf_count(int dp);                 // binary16 values
 size_t prep4_ttf_count(int dp);
-// host helpers: L = lower Cholesky factor (d x d row-major), T = layer matrix (d x d row-major)
-void prep4_lt_fragments(const double *L, int d, int dp, float *out);
-void prep4_t_fragments(const double *T, int d, int dp, float *out);
+// host helpers: L = lower Cholesky factor (d x d row-major), T = layer matrix (d x d row-major); `scale` = power of
+// two applied before the split; return |E|_F, the Frobenius norm of (scale M - hi - lo)
+double prep4_lt_fragments(const double *L, int d, int dp, double scale, uint16_t *out_bits);
+double prep4_t_fragments(const double *T, int d, int dp, double scale, uint16_t *out_bits);
 hipError_t launch_prep4(const Prep4Args &a, hipStream_t s);
 
 void launch_ell_exact(const EllExactArgs &a, hipStream_t s);

@@ -300,8 +300,8 @@ class DeviceRegion(object):
         """Counters of the last filtered batch (see mlf_region_debug_stats in include/mlfriends_hip.h)."""
         out = np.zeros(8, dtype=np.uint64)
         check(_lib.lib().mlf_region_debug_stats(self._h, ptr(out), 8))
-        keys = ("ellipsoid_band", "exact_whitened_queries", "uncertain_pairs", "largest_segment", "segments", "second_range_groups")
-        return dict(zip(keys, (int(v) for v in out[:6])))
+        keys = ("ellipsoid_band", None, "uncertain_pairs", "largest_segment", "segments", "second_range_groups")
+        return {k: int(v) for k, v in zip(keys, out[:6]) if k}
 
     def time_inside_dev(self, d_pts, npts, d_mask, stream=0, reps=3):
         tot, scan = ctypes.c_float(0), ctypes.c_float(0)
