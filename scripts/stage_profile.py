@@ -1,5 +1,5 @@
 """C5 membership pipeline only (no rebuilds, no comparison passes): counters of the batch and a clean kernel list for
-rocprofv3.  python scripts/stage_profile.py [steps]"""
+rocprofv3.  python scripts/stage_profile.py [steps] [option=value ...]"""
 import json
 import sys
 import time
@@ -12,6 +12,9 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+for opt in sys.argv[2:]:   # name=value pairs for mlf_set_option
+    from ultranest_amd import _lib as _k
+    _k.set_option(opt.split("=")[0], int(opt.split("=")[1]))
 dev = torch.device("cuda", 0)
 u, region = bench.build_region(None)
 handle = region._dev.sync(region, True)

@@ -293,13 +293,15 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
         acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bq[g][s], acc[g], 0, 0, 0);
 
     // All 16 values of a lane belong to ONE query (column = lane & 31) and 16 live points, so the
-    // lane-wise minimum decides the common case with 8 v_min3 + 2 compares per group:
+    // lane-wise minimum decides the common case with 8 v_min3 + 1 compare per group:
     //   vmin >  T_hi : nothing within reach in this block (certain misses)
-    //   vmin <= T_lo : the query has a certain hit (mask mode needs nothing more)
     // Operands are finite binary16 values of bounded size, so acc holds no NaN / inf.
-    // The per-group decisions are wave masks combined on the scalar unit; the common path has a
-    // single branch per tile (one branch per group kept the scheduler from overlapping the
-    // epilogue with the next matrix products).
+    // The common path is 4 x (8 v_min3 + v_cmp) + 3 s_or + one branch per tile (one branch per group kept the
+    // scheduler from overlapping the epilogue with the next matrix products; the first version also compared
+    // against T_lo and combined three wave masks per group on the scalar unit in every tile: 62 scalar
+    // instructions per tile, as many issue slots as the vector part).  Mask mode: a query with a certain hit has its
+    // T_hi lowered to -inf in BOTH of its lanes, so it never shows up here again.
+    float vmin[QW];
     unsigned long long candm[QW];
     unsigned long long need = 0ull;
 #pragma unroll
@@ -310,29 +312,30 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
       const int m2 = min3i(__float_as_int(c[6]), __float_as_int(c[7]), __float_as_int(c[8]));
       const int m3 = min3i(__float_as_int(c[9]), __float_as_int(c[10]), __float_as_int(c[11]));
       const int m4 = min3i(__float_as_int(c[12]), __float_as_int(c[13]), __float_as_int(c[14]));
-      const float vmin = __int_as_float(min3i(min3i(m0, m1, m2), min3i(m3, m4, __float_as_int(c[15])), m0));
-      unsigned long long cm = __ballot(vmin <= thi[g]);
-      if (!FIRST) {
-        anyhit[g] |= __ballot(vmin <= tlo[g]);
-        // a query that already has a certain hit (in any tile so far) needs no re-check entries;
-        // both lanes of a query (l, l + 32) see the union of their halves
-        const unsigned long long hit = anyhit[g] | (anyhit[g] >> 32);
-        cm &= ~((hit & 0xffffffffull) | (hit << 32));
-      }
-      if (FIRST && cm != 0ull) {   // wave-uniform
-        // a query with a certain hit below this tile cannot get a lower first index here, and its uncertain
-        // pairs in this tile cannot matter either (without this every later tile of an accepted proposal went
-        // through the detail path: first-index batches with many hits ran slower than the exact scan)
-        const int other = __shfl_xor(first[g], 32);
-        const int fb = first[g] < other ? first[g] : other;
-        cm &= ~__ballot(fb < t * 32);
-      }
-      candm[g] = cm;
-      need |= cm;
+      vmin[g] = __int_as_float(min3i(min3i(m0, m1, m2), min3i(m3, m4, __float_as_int(c[15])), m0));
+      candm[g] = __ballot(vmin[g] <= thi[g]);
+      need |= candm[g];
     }
-    if (need != 0ull) {   // wave-uniform; rare in mask mode
+    if (need != 0ull) {   // wave-uniform: a first certain hit of some query, or an uncertain pair
 #pragma unroll
       for (int g = 0; g < QW; ++g) {
+        if (candm[g] == 0ull) continue;
+        if (!FIRST) {
+          // certain hits of this tile (vmin <= T_lo < T_hi): the query leaves the candidate test for good
+          const unsigned long long hb = __ballot(vmin[g] <= tlo[g]);
+          const unsigned long long hq = (hb | (hb >> 32)) & 0xffffffffull;
+          const unsigned long long both = hq | (hq << 32);
+          anyhit[g] |= both;
+          if ((both >> lane) & 1ull) thi[g] = -INFINITY;
+          candm[g] &= ~both;
+        } else {
+          // a query with a certain hit below this tile cannot get a lower first index here, and its uncertain
+          // pairs in this tile cannot matter either (without this every later tile of an accepted proposal went
+          // through the detail path: first-index batches with many hits ran slower than the exact scan)
+          const int other = __shfl_xor(first[g], 32);
+          const int fb = first[g] < other ? first[g] : other;
+          candm[g] &= ~__ballot(fb < t * 32);
+        }
         if (candm[g] == 0ull) continue;
         const float16v &c = acc[g];
         const bool detail = (candm[g] >> lane) & 1ull;
@@ -386,8 +389,7 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
       const int other = __shfl_xor(first[g], 32);
       res = first[g] < other ? first[g] : other;
     } else {
-      const unsigned long long m = anyhit[g] | (anyhit[g] >> 32);
-      res = ((m >> (lane & 31)) & 1ull) ? 0 : kNone;
+      res = ((anyhit[g] >> (lane & 31)) & 1ull) ? 0 : kNone;   // both lanes of a query carry its bit
     }
     if (lane < 32 && qi >= 0 && qi < a.nq && res != kNone) a.best[qi] = res;
     if (COMPACT) {
