@@ -47,7 +47,10 @@ int mlf_synchronize(void);
  * between; n >= 2: n ranges),
  * "filter_phase_min_queries", "filter_fused_compact" (1/0: that compaction inside the matrix kernel or as
  * separate kernels), "fused_prep", "prep_matrix" (1/0: which preparation kernel), "tq_row_major" (1/0: layout of
- * the whitened proposals handed from the preparation kernel to the exact re-check).  Results never depend on them. */
+ * the whitened proposals handed from the preparation kernel to the exact re-check), "prep_bounded" (1/0: the
+ * bounded matrix-core per-proposal stage or the binary64 one), "small_path" (1/0: mlf_region_inside with up to 256
+ * proposals as ONE launch over pinned staging -- the calls of the scalar step samplers -- or through the batched
+ * pipeline), "time_filter_launches".  Results never depend on them. */
 int mlf_set_option(const char *name, long long value);
 
 /* ---- K1: find_nearby -- ultranest/mlfriends.pyx:143-183 -----------------------------------

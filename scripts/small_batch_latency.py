@@ -25,10 +25,13 @@ for label, (n, d) in [("C1", (400, 5)), ("C2", (2000, 20)), ("C5", (4000, 50))]:
         pts = u[rs.randint(n, size=p)] + 0.01 * rs.normal(size=(p, d))
         region.inside(pts)
         reps = 200 if p <= 4096 else 30
-        t0 = time.perf_counter()
+        each = []
         for _ in range(reps):
+            t0 = time.perf_counter()
             m = region.inside(pts)
-        dt = (time.perf_counter() - t0) / reps
+            each.append(time.perf_counter() - t0)
+        dt = float(np.mean(each))
+        med = float(np.median(each))
         # the driver's pattern: one live point replaced in place between calls (integrator.py:2749-2765)
         t0 = time.perf_counter()
         for i in range(reps):
@@ -36,7 +39,7 @@ for label, (n, d) in [("C1", (400, 5)), ("C2", (2000, 20)), ("C5", (4000, 50))]:
             region.unormed[i % n] = region.transformLayer.transform(region.u[i % n])
             m = region.inside(pts)
         dt_upd = (time.perf_counter() - t0) / reps
-        out.append(dict(config=label, n_live=n, d=d, batch=p, us_per_call=dt * 1e6,
+        out.append(dict(config=label, n_live=n, d=d, batch=p, us_per_call=dt * 1e6, us_per_call_median=med * 1e6,
                         us_per_call_with_one_row_replaced=dt_upd * 1e6, accept=float(m.mean())))
         print(json.dumps(out[-1]), flush=True)
 if "--save" in sys.argv:

@@ -13,6 +13,9 @@
 #include "mlf_ctx.hpp"
 #include "mlf_filter.hpp"
 #include "mlf_misc.hpp"
+#include <atomic>
+#include <chrono>
+#include "mlf_small.hpp"
 #include "mlf_prep2.hpp"
 #include "mlf_prep3.hpp"
 #include "mlf_prep4.hpp"
@@ -83,6 +86,7 @@ int g_filter_phases = 1;              // mlf_set_option("filter_phases", n): 0 s
 long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
 bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
 bool g_time_filter_launches = false;  // mlf_set_option("time_filter_launches", 0/1): event pairs around every k_filter launch of every call
+bool g_small_path = true;             // mlf_set_option("small_path", 0/1): one launch for up to 256 proposals handed over on the host
 bool g_prep_bounded = true;           // mlf_set_option("prep_bounded", 0/1): matrix-core bounded stage (mlf_prep4.hip)
 long long g_filter_min_queries = 2048;  // smaller batches go straight to the exact scan
 
@@ -93,6 +97,12 @@ struct Ctx {
   // scratch used by the stateless host-pointer entry points
   DevBuf src, refT, refR, q, out, flags, sel, selbytes, M, small0, small1, small2, small3, mask, tq;
   FilterCtx filter;
+  // single-launch path for a handful of proposals (mlf_small.hip): pinned, device-mapped staging + two scratch words
+  // per proposal
+  double *pin_pts = nullptr, *pin_pts_dev = nullptr;
+  uint8_t *pin_mask = nullptr, *pin_mask_dev = nullptr;   // mask bytes, then (at kSmallMaxPoints) the completion word
+  unsigned small_seq = 0;
+  DevBuf small_words;
 };
 
 Ctx g_ctx;
@@ -998,6 +1008,10 @@ int mlf_set_option(const char *name, long long value) {
     g_filter_enabled = value != 0;
     return 0;
   }
+  if (!strcmp(name, "small_path")) {
+    g_small_path = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "fused_prep")) {
     g_fused_prep = value != 0;
     return 0;
@@ -1503,11 +1517,108 @@ int mlf_region_set_ellipsoid_center(mlf_region *r, const double *ell_center) {
   return 0;
 }
 
+// One launch, no copies on the stream: the proposals go through a pinned staging buffer the kernel reads directly,
+// the mask comes back the same way.
+static int region_inside_small(mlf_region *r, const double *pts, size_t np, uint8_t *mask) {
+  Ctx &c = g_ctx;
+  if (!c.pin_pts) {
+    CK(hipHostMalloc(reinterpret_cast<void **>(&c.pin_pts), (size_t)kSmallMaxPoints * kSmallMaxDim * sizeof(double),
+                     hipHostMallocMapped));
+    CK(hipHostMalloc(reinterpret_cast<void **>(&c.pin_mask), (size_t)kSmallMaxPoints + 64, hipHostMallocMapped));
+    memset(c.pin_mask, 0, (size_t)kSmallMaxPoints + 64);
+    CK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c.pin_pts_dev), c.pin_pts, 0));
+    CK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c.pin_mask_dev), c.pin_mask, 0));
+    CK(c.small_words.reserve(2 * kSmallMaxPoints * sizeof(unsigned)));
+    CK(hipMemsetAsync(c.small_words.p, 0, 2 * kSmallMaxPoints * sizeof(unsigned), c.stream));
+  }
+  static const bool timing = getenv("MLF_SMALL_TIMING") != nullptr;
+  static double acc_t[4] = {0, 0, 0, 0};
+  static int acc_n = 0;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = timing ? now() : 0.0;
+  memcpy(c.pin_pts, pts, np * (size_t)r->d * sizeof(double));
+  SmallArgs a{};
+  a.pts = c.pin_pts_dev;
+  a.np = (int)np;
+  a.d = r->d;
+  a.dp = r->dp;
+  a.ell_ctr = r->ell_ctr.as<double>();
+  a.ell_A = r->ell_A.as<double>();
+  a.ell_Lt = r->ell_Lt.as<double>();
+  a.eps_scale = r->ell_eps_scale;
+  a.enlarge = r->enlarge;
+  a.chol_ok = (r->chol_ready && r->chol_ok) ? 1 : 0;
+  a.use_scan = r->use_scan;
+  a.layer_kind = r->layer_kind;
+  a.wpp = 1;
+  if (r->use_scan) {
+    a.lay_ctr = r->lay_ctr.as<double>();
+    if (r->layer_kind == 0) {
+      a.lay_T8 = r->lay_T8.as<double>();
+      a.ldt8 = (r->dp + 7) / 8 * 8;
+    } else {
+      a.lay_std = r->lay_mat.as<double>();
+    }
+    a.wrap = r->has_wrap ? r->wrap.as<double>() : nullptr;
+    a.refT = r->refT.as<double>();
+    a.n = r->n;
+    a.npad = r->npad;
+    a.r2 = r->r2;
+    // enough workgroups per proposal to spread its live points over the chip, but no more than ~512 in all
+    const int shares = (r->n + 255) / 256;
+    int wpp = 512 / (int)np;
+    if (wpp > shares) wpp = shares;
+    a.wpp = wpp < 1 ? 1 : wpp;
+  }
+  a.state = c.small_words.as<unsigned>();
+  a.finished = c.small_words.as<unsigned>() + kSmallMaxPoints;
+  a.mask = c.pin_mask_dev;
+  a.flag = reinterpret_cast<unsigned *>(c.pin_mask_dev + kSmallMaxPoints);
+  a.seq = ++c.small_seq;
+  if (a.seq == 0u) a.seq = ++c.small_seq;   // 0 is the initial content of the word
+  const double t1 = timing ? now() : 0.0;
+  launch_inside_small(a, c.stream);
+  CK(hipGetLastError());
+  const double t2 = timing ? now() : 0.0;
+  {   // spin on the completion word; a kernel that does not report within ~2 ms is left to the stream's own error path
+    volatile unsigned *flag = reinterpret_cast<volatile unsigned *>(c.pin_mask + kSmallMaxPoints);
+    bool seen = false;
+    for (long spin = 0; spin < 4000000; ++spin) {
+      if (*flag == a.seq) {
+        seen = true;
+        break;
+      }
+      __builtin_ia32_pause();
+    }
+    if (!seen) {
+      CK(hipStreamSynchronize(c.stream));
+      if (*flag != a.seq) return fail_arg(MLF_E_STATE, "single-launch membership kernel did not complete");
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  const double t3 = timing ? now() : 0.0;
+  memcpy(mask, c.pin_mask, np);
+  if (timing) {
+    acc_t[0] += t1 - t0;
+    acc_t[1] += t2 - t1;
+    acc_t[2] += t3 - t2;
+    acc_t[3] += now() - t3;
+    if (++acc_n == 300) {
+      fprintf(stderr, "small path, np=%zu: stage %.2f us, launch %.2f us, wait %.2f us, copy out %.2f us\n", np, acc_t[0] / 300,
+              acc_t[1] / 300, acc_t[2] / 300, acc_t[3] / 300);
+      acc_n = 0;
+      acc_t[0] = acc_t[1] = acc_t[2] = acc_t[3] = 0;
+    }
+  }
+  return 0;
+}
+
 int mlf_region_inside(mlf_region *r, const double *pts, size_t np, uint8_t *mask) {
   if (!r) return fail_arg(MLF_E_BADARG, "null region");
   if (!r->ready) return fail_arg(MLF_E_STATE, "region used before mlf_region_set");
   if (np == 0) return 0;
   if (!pts || !mask) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (g_small_path && np <= (size_t)kSmallMaxPoints && r->d <= kSmallMaxDim) return region_inside_small(r, pts, np, mask);
   Ctx &c = g_ctx;
   if (int rc = upload(r->pts, pts, np * (size_t)r->d * sizeof(double), c.stream)) return rc;
   CK(r->mask.reserve(np));

@@ -135,6 +135,119 @@ def _bootstrap_enlargement(u, masks, minvol):
     return kernels.bootstrap_quadform_max(u, masks, ctrs, precisions)
 
 
+# ---- write-tracked live points --------------------------------------------------------------------
+_IN_PLACE_FUNCTIONS = frozenset(f for f in (getattr(np, n, None) for n in (
+    "copyto", "put", "place", "putmask", "put_along_axis", "fill_diagonal")) if f is not None)
+
+
+class _LiveArray(np.ndarray):
+    """``region.u`` as an ndarray that COUNTS its in-place writes.
+
+    The driver replaces one live point per iteration with ``region.u[worst] = u`` (reference
+    integrator.py:2753) and the step samplers then call ``region.inside`` with 1-10 points many times
+    before the next write (stepsampler.py:296-330, 1060-1071).  Comparing 4000 x 50 doubles with the last
+    uploaded snapshot on every one of those calls cost 60 us of a 120 us call; with the counter an
+    untouched array is recognised in O(1), and a plain row assignment names the rows to re-send.
+
+    The array owns its memory (``region.u = x`` copies x), so the only ways to write into it are through
+    this object and its views, which all share one counter cell:  __setitem__, ufunc ``out=`` (hence
+    ``+=`` and friends), the in-place methods, and numpy's in-place functions (np.copyto ...).  What the
+    counter cannot see -- writes through ``np.asarray(region.u)`` / ``region.u.view(np.ndarray)``, raw
+    buffers -- needs ``region.invalidate_device_state()``; nothing in the reference does that."""
+
+    def __array_finalize__(self, obj):
+        self._cell = getattr(obj, "_cell", None)
+        self._root = False
+
+    def _touch(self, key=None):
+        cell = self._cell
+        if cell is None:
+            return
+        cell[0] += 1
+        rows = cell[1]
+        if rows is None:
+            return
+        if self._root:   # a plain row assignment: remember which rows
+            if isinstance(key, tuple) and key:
+                key = key[0]
+            if isinstance(key, (int, np.integer)):
+                rows.append(int(key))
+                return
+            if isinstance(key, np.ndarray) and key.ndim == 1 and key.dtype.kind in "iu" and key.size <= 16:
+                rows.extend(int(k) for k in key)
+                return
+        cell[1] = None   # anything else: the next device call diffs the whole array
+
+    def __setitem__(self, key, value):
+        self._touch(key)
+        np.ndarray.__setitem__(self, key, value)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
+        if out is not None:
+            for o in out:
+                if isinstance(o, _LiveArray):
+                    o._touch()
+            kwargs["out"] = tuple(o.view(np.ndarray) if isinstance(o, _LiveArray) else o for o in out)
+        args = tuple(x.view(np.ndarray) if isinstance(x, _LiveArray) else x for x in inputs)
+        return getattr(ufunc, method)(*args, **kwargs)   # plain ndarrays out: results are not live points
+
+    def __array_function__(self, func, types, args, kwargs):
+        if func in _IN_PLACE_FUNCTIONS and args and isinstance(args[0], _LiveArray):
+            args[0]._touch()
+        return super().__array_function__(func, types, args, kwargs)
+
+    def __reduce__(self):   # pickles as the plain array it holds; a region re-wraps it on assignment
+        return np.asarray(self).__reduce__()
+
+
+def _in_place_method(name):
+    base = getattr(np.ndarray, name)
+
+    def method(self, *args, **kwargs):
+        self._touch()
+        return base(self, *args, **kwargs)
+    method.__name__ = name
+    method.__doc__ = base.__doc__
+    return method
+
+
+for _name in ("fill", "sort", "partition", "put", "itemset", "setfield", "byteswap", "resize"):
+    if hasattr(np.ndarray, _name):
+        setattr(_LiveArray, _name, _in_place_method(_name))
+
+
+class _LivePoints(object):
+    """Mixin: the ``u`` attribute of a region is a private, write-tracked copy (see _LiveArray)."""
+
+    @property
+    def u(self):
+        return self._u
+
+    @u.setter
+    def u(self, value):
+        cell = self.__dict__.get("_u_cell")
+        if cell is None:
+            cell = self.__dict__["_u_cell"] = [0, None]
+        if isinstance(value, _LiveArray) and value._cell is cell and value._root:
+            self._u = value
+            return
+        arr = np.array(value, order="C", copy=True).view(_LiveArray)
+        arr._cell = cell
+        arr._root = True
+        cell[0] += 1
+        cell[1] = None
+        self._u = arr
+
+    def invalidate_device_state(self):
+        """Forget what the device holds: the next device call re-sends the region.  Only needed after
+        writing into ``region.u`` (or the ellipsoid / layer arrays) behind numpy's back."""
+        self._dev.fast_key = None
+        cell = self.__dict__.get("_u_cell")
+        if cell is not None:
+            cell[0] += 1
+            cell[1] = None
+
+
 class _DeviceState(object):
     """Lazy mirror of a region's host attributes on the GPU (see module docstring).
 
@@ -150,6 +263,30 @@ class _DeviceState(object):
         self.thresholds = None
         self.axes_T = None
         self.sampling_data = None
+        self.fast_key = None      # identities + write counter of everything the device state was built from
+
+    @staticmethod
+    def _key(region, use_scan):
+        """What the device state depends on, by IDENTITY (arrays) and value (scalars): equal keys mean nothing
+        was re-assigned and region.u was not written to since the last sync."""
+        layer = region.transformLayer if use_scan else None
+        ld = layer.__dict__ if layer is not None else {}
+        cell = region.__dict__.get("_u_cell")
+        return (use_scan, region.__dict__.get("_u"), cell[0] if cell is not None else -1, layer,
+                ld.get("T"), ld.get("ctr"), ld.get("mean"), ld.get("std"), ld.get("wrap_cuts"),
+                region.ellipsoid_center, region.ellipsoid_invcov, region.enlarge, region.maxradiussq if use_scan else None)
+
+    def _key_unchanged(self, key):
+        old = self.fast_key
+        if old is None or len(old) != len(key):
+            return False
+        for a, b in zip(old, key):
+            if a is b:
+                continue
+            if isinstance(a, (float, int)) and isinstance(b, (float, int)) and not isinstance(a, bool) and a == b:
+                continue
+            return False
+        return True
 
     def refill(self, region, use_scan, method, nsamples, Lmin, tspec, lspec):
         """Device-resident proposal batch (draw, region test, prior transform, likelihood, threshold)."""
@@ -194,6 +331,17 @@ class _DeviceState(object):
         return True
 
     def sync(self, region, use_scan):
+        key = self._key(region, use_scan)
+        if self.handle is not None and key[2] >= 0 and self._key_unchanged(key):
+            return self.handle
+        handle = self._sync_slow(region, use_scan, key)
+        cell = region.__dict__.get("_u_cell")
+        if cell is not None:
+            cell[1] = []      # from here on plain row assignments are remembered
+        self.fast_key = key
+        return handle
+
+    def _sync_slow(self, region, use_scan, key):
         ndim = region.u.shape[1]
         if use_scan:
             if region.maxradiussq is None:
@@ -210,8 +358,14 @@ class _DeviceState(object):
             self.handle = kernels.DeviceRegion()
         full = self.consts is None or not self._same(consts, self.consts)
         changed = ()
-        if not full and use_scan:
-            u_now = region.u
+        cell = region.__dict__.get("_u_cell")
+        rows = cell[1] if cell is not None else None
+        known = (not full and use_scan and rows is not None and self.fast_key is not None
+                 and self.fast_key[1] is key[1] and len(rows) <= max(8, nlive // 8))
+        if known:      # only plain row assignments since the last sync: no diff
+            changed = sorted(set(r % nlive for r in rows))
+        elif not full and use_scan:
+            u_now = np.asarray(region.u)
             if u_now.dtype == np.float64 and u_now.flags.c_contiguous and u_now.shape == self.live.shape:
                 limit = max(8, nlive // 8)
                 changed, nchanged = _lib.changed_rows(self.live, u_now, capacity=limit)
@@ -242,7 +396,7 @@ class _DeviceState(object):
         return self.handle
 
 
-class MLFriends(object):
+class MLFriends(_LivePoints):
     """MLFriends region: the union of balls of radius sqrt(maxradiussq) around the whitened
     live points, intersected with a wrapping ellipsoid (reference mlfriends.pyx:915-1257)."""
 
