@@ -15,7 +15,7 @@
 //     5. the last workgroup of a proposal writes its mask byte (straight into the caller's pinned buffer) and
 //        returns the two scratch words of the proposal to zero
 // Same arithmetic as the batched kernels => same masks (tests/test_small_path.py compares the two on the GPU and
-// both with the oracle).  -ffp-contract=off; FMAs only where written.
+// both with the CPU restatement of the reference).  -ffp-contract=off; FMAs only where written.
 #include "mlf_small.hpp"
 
 #include <math.h>
