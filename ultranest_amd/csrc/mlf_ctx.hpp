@@ -19,7 +19,9 @@ struct DevBuf {
       cap = 0;
       if (e != hipSuccess) return e;
     }
-    const size_t want = bytes + bytes / 8 + 256;
+    // grow by half and in 64 KiB steps: scratch buffers shared by calls of slightly different sizes would otherwise be
+    // freed and re-allocated (hipFree synchronises the device) every time a new maximum comes along
+    const size_t want = (bytes + bytes / 2 + 65535) / 65536 * 65536;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) return e;
     cap = want;

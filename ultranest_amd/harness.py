@@ -8,6 +8,7 @@ passing these classes through its plug points."""
 import numpy as np
 
 from . import distributed
+from .layers import single_blas_thread
 from .mlfriends import LocalAffineLayer, MLFriends, WrappingEllipsoid, find_nearby, int_dtype
 
 
@@ -52,6 +53,7 @@ class RegionUpdater(object):
         self.region.create_ellipsoid(minvol=minvol)
         return (labels == 0).any()
 
+    @single_blas_thread
     def update(self, active_u, nbootstraps=30, minvol=0., active_p=None):
         """Returns True if the region object was (re)built or replaced."""
         assert nbootstraps > 0

@@ -168,18 +168,38 @@ class DeviceRegion(object):
     """Device-resident state of one region (live points in both layouts, layer, wrapping
     ellipsoid, thresholds) behind the opaque ``mlf_region`` handle."""
 
+    # Handles of regions that went out of use, with their device buffers.  A rebuild makes a new region object
+    # every time and the old ones sit in reference cycles (region -> bound methods -> region) until the cyclic
+    # collector runs: five at once, ~50 hipFree calls each -- a 55 ms stall in every fifth rebuild.  A recycled
+    # handle keeps its allocations; mlf_region_set overwrites everything they hold.
+    _idle = []
+    _IDLE_MAX = 8
+
     def __init__(self):
-        self._h = ctypes.c_void_p()
-        check(_lib.lib().mlf_region_create(ctypes.byref(self._h)))
+        if DeviceRegion._idle:
+            self._h = DeviceRegion._idle.pop()
+        else:
+            self._h = ctypes.c_void_p()
+            check(_lib.lib().mlf_region_create(ctypes.byref(self._h)))
 
     def close(self):
+        """free the device buffers now"""
         if self._h:
             _lib.lib().mlf_region_destroy(self._h)
             self._h = ctypes.c_void_p()
 
+    def release(self):
+        """hand the handle (and its buffers) to the next region"""
+        if self._h:
+            if len(DeviceRegion._idle) < DeviceRegion._IDLE_MAX:
+                DeviceRegion._idle.append(self._h)
+                self._h = ctypes.c_void_p()
+            else:
+                self.close()
+
     def __del__(self):
         try:
-            self.close()
+            self.release()
         except Exception:
             pass
 

@@ -10,11 +10,42 @@ the MI355X through ``ultranest_amd.kernels``.  ``transform`` of the N live point
 ``dot`` so that ``region.unormed`` is bit-identical to the reference's; proposal batches are
 transformed on the device inside the region's ``inside`` pipeline.
 """
+import functools
+
 import numpy as np
 
 from . import kernels
 
 int_dtype = kernels.int_dtype
+
+# ---- host linear algebra of a rebuild runs on ONE BLAS thread ------------------------------------------
+# The d x d problems of a region rebuild (covariance of 4000 x 50 points, eigh / inv of 50 x 50) are a millisecond of
+# work.  OpenBLAS wakes its whole pool for the products among them; on a many-core host that pool, spinning, pushed
+# the calling thread off its core: every few rebuilds one took 60-70 ms instead of 7 (scripts/rebuild_breakdown.py).
+_blas = {"controller": None, "tried": False}
+
+
+def _blas_controller():
+    if not _blas["tried"]:
+        _blas["tried"] = True
+        try:
+            from threadpoolctl import ThreadpoolController
+            _blas["controller"] = ThreadpoolController()
+        except Exception:      # threadpoolctl missing or a BLAS it cannot drive: leave the pool alone
+            _blas["controller"] = None
+    return _blas["controller"]
+
+
+def single_blas_thread(fn):
+    """Decorator: run `fn` with the BLAS pool limited to one thread (a no-op without threadpoolctl)."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        ctl = _blas_controller()
+        if ctl is None:
+            return fn(*args, **kwargs)
+        with ctl.limit(limits=1, user_api="blas"):
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def update_clusters(upoints, tpoints, maxradiussq, clusterids=None):
@@ -187,6 +218,7 @@ class AffineLayer(ScalingLayer):
         self.invT = invT
         self._init_common(nclusters, wrapped_dims, clusterids)
 
+    @single_blas_thread
     def optimize(self, points, centered_points, clusterids=None, minvol=0.):
         """ctr = mean of the wrapped points; cov = sample covariance of `centered_points`
         inflated by (d+2); T = eigvec * eigval**-0.5 with eigenvalues floored at 1e-40 of the

@@ -19,7 +19,7 @@ What runs where:
 import numpy as np
 
 from . import _lib, kernels
-from .layers import int_dtype
+from .layers import int_dtype, single_blas_thread
 
 # When True, ``MLFriends.inside`` transforms ellipsoid-passing points on the host with the same
 # ``np.dot`` the reference uses (bit-identical t-space points on the same machine) and only the
@@ -66,6 +66,7 @@ def make_eigvals_positive(a, targetprod):
     return a
 
 
+@single_blas_thread
 def bounding_ellipsoid(x, minvol=0.):
     """Centre and (d+2)-inflated sample covariance of the points `x`
     (reference mlfriends.pyx:426-476)."""
@@ -106,6 +107,7 @@ def _select_rounds(masks, use):
     return masks[use]
 
 
+@single_blas_thread
 def _bootstrap_enlargement(u, masks, minvol):
     """Per-round wrapping-ellipsoid enlargement f_b (reference mlfriends.pyx:1056-1066):
     ellipsoid of the selected points, largest Mahalanobis distance of the left-out ones."""
@@ -237,6 +239,32 @@ class _LivePoints(object):
         cell[0] += 1
         cell[1] = None
         self._u = arr
+
+    # ``sampling_methods`` / ``current_sampling_method`` hold bound methods of the region itself in the reference
+    # (mlfriends.pyx:944-950): a reference cycle, so a replaced region -- and its device buffers -- lives until the
+    # cyclic collector happens to run.  Here the own methods are kept by NAME and bound on access; anything else a
+    # caller assigns is kept as it is.
+    def _unbind(self, method):
+        return method.__name__ if getattr(method, "__self__", None) is self else method
+
+    def _bind(self, item):
+        return getattr(self, item) if isinstance(item, str) else item
+
+    @property
+    def sampling_methods(self):
+        return [self._bind(m) for m in self._sampling_methods]
+
+    @sampling_methods.setter
+    def sampling_methods(self, methods):
+        self._sampling_methods = [self._unbind(m) for m in methods]
+
+    @property
+    def current_sampling_method(self):
+        return self._bind(self._current_sampling_method)
+
+    @current_sampling_method.setter
+    def current_sampling_method(self, method):
+        self._current_sampling_method = self._unbind(method)
 
     def invalidate_device_state(self):
         """Forget what the device holds: the next device call re-sends the region.  Only needed after
@@ -434,6 +462,7 @@ class MLFriends(_LivePoints):
         ndim = self.u.shape[1]
         return self.transformLayer.logvolscale + np.log(r) * ndim
 
+    @single_blas_thread
     def create_ellipsoid(self, minvol=0.0):
         """Wrapping ellipsoid of all live points and its principal axes (reference :1213-1237)."""
         assert self.enlarge is not None
