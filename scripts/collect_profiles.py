@@ -17,9 +17,18 @@ P = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs(P, exist_ok=True)
 
-HEADLINE_GRID = {"k_scan": 15625 * 256, "k_prep<": 3907 * 256, "k_prep2": 3907 * 256, "k_prep3": 512 * 256,
-                 "k_filter<4, 4, false, true>": 1954 * 256, "k_filter<4, 4, false, false>": 1954 * 256,
-                 "k_recheck": 7813 * 64}     # 1e6 proposals / launch (the bench's --headline-only pass)
+# kernels of the headline step (1e6 proposals per launch in the bench's --headline-only pass) and the smallest grid
+# (threads) such a launch has: the same kernels also run on the 4000 live points during the region build
+HEADLINE_GRID = {"k_prep4": 100000, "k_prep3": 100000, "k_filter<4, 4, false, true>": 400000,
+                 "k_filter<4, 4, false, false>": 400000, "k_recheck_whiten": 400000, "k_scan": 400000,
+                 "k_phase_finish": 64}
+
+
+def headline(name, grid):
+    for key, least in HEADLINE_GRID.items():
+        if key in name and grid >= least:
+            return key
+    return None
 
 
 def cp(src, dst):
@@ -40,6 +49,9 @@ cp("big_batch.json", "%s_big_batch.json" % tag)
 cp("e2e_run.json", "%s_e2e_run.json" % tag)
 cp("bench_torchrun.json", "%s_bench_torchrun.json" % tag)
 cp("bench_2rank_gloo.json", "%s_bench_2rank_gloo.json" % tag)
+cp("bench_2rank_selfspawn.json", "%s_bench_2rank_selfspawn_gloo.json" % tag)
+cp("r02_small_batch.json", "%s_small_batch.json" % tag)
+cp("r02_mfma16_power_probe.json", "%s_mfma16_power_probe.json" % tag)
 
 # kernel-trace: average duration of the headline launches only (the stats CSV mixes them with the
 # small scans of the region rebuild)
@@ -48,24 +60,23 @@ summary = {}
 if os.path.exists(trace):
     dur = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
-        name = r["Kernel_Name"]
-        for key, grid in HEADLINE_GRID.items():
-            if key in name and int(r["Grid_Size_X"]) == grid:
-                dur[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+        key = headline(r["Kernel_Name"], int(r["Grid_Size_X"]))
+        if key:
+            dur[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
     for key, v in dur.items():
         summary[key] = dict(headline_launches=len(v), avg_ms=sum(v) / len(v), min_ms=min(v), max_ms=max(v))
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ"):
+for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ", "pmc_SQ2", "pmc_SQ3"):
     f = os.path.join(G, sub, "bench_counter_collection.csv")
     if not os.path.exists(f):
         continue
     for r in csv.DictReader(open(f)):
-        for key, grid in HEADLINE_GRID.items():
-            if key in r["Kernel_Name"] and int(r["Grid_Size"]) == grid:
-                pmc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                pmc[key]["VGPR_Count"] = [float(r["VGPR_Count"])]
-                pmc[key]["LDS_Block_Size"] = [float(r["LDS_Block_Size"])]
+        key = headline(r["Kernel_Name"], int(r["Grid_Size"]))
+        if key:
+            pmc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            pmc[key]["VGPR_Count"] = [float(r["VGPR_Count"])]
+            pmc[key]["LDS_Block_Size"] = [float(r["LDS_Block_Size"])]
 for key in pmc:
     summary.setdefault(key, {})["pmc_avg_per_launch"] = {c: sum(v) / len(v) for c, v in pmc[key].items()}
 

@@ -49,6 +49,7 @@ int fail_arg(int code, const char *msg) {
 // Buffers and host-side state of the MFMA pre-filter (mlf_filter.hip) for one set of live points.
 struct FilterCtx {
   bool refs_ready = false;   // live points quantised
+  bool refs_dirty = false;   // a live point was replaced since: requantise before the next batch that uses the operands
   bool usable = false;       // statistics are finite and the dimensionality is covered
   int ks = 0, ntiles32 = 0;
   double sigma = 1.0, amax = 0.0;
@@ -205,6 +206,15 @@ int filter_prepare_refs(FilterCtx &f, const double *refR, int n, int d, int dp, 
     f.usable = h[3] == 1.0 && h[2] > 0.0 && h[2] < 1e150;
   }
   f.refs_ready = true;
+  f.refs_dirty = false;
+  return 0;
+}
+
+// requantise the live points if one was replaced since the operands were built (mlf_region_update_point)
+int filter_refresh_refs(FilterCtx &f, const double *refR, int n, int d, int dp, hipStream_t s) {
+  if (!f.refs_ready || !f.refs_dirty) return 0;
+  if (int rc = filter_prepare_refs(f, refR, n, d, dp, s, false)) return rc;
+  f.refs_dirty = false;
   return 0;
 }
 
@@ -723,6 +733,8 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
                           long long *d_idx = nullptr, const uint8_t *pregate = nullptr) {
   if (np == 0) return 0;
   if (d_idx && !r->use_scan) return fail_arg(MLF_E_STATE, "region has no live points set");
+  if (r->use_scan)
+    if (int rc = filter_refresh_refs(r->filter, r->refR.as<double>(), r->n, r->d, r->dp, s)) return rc;
   CK(r->gate.reserve(np));
   uint8_t *gate = r->use_scan ? r->gate.as<uint8_t>() : d_mask;
   const bool use_filter = r->use_scan && filter_applies(r->filter, (long long)np, r->r2);
@@ -1488,9 +1500,9 @@ int mlf_region_update_point(mlf_region *r, size_t row, const double *unormed_row
   launch_update_row(src, r->d, r->dp, r->npad, (int)row, r->refT.as<double>(),
                     r->refR.as<double>(), c.stream);
   CK(hipGetLastError());
-  if (r->filter.refs_ready)  // centre / scale / norms depend on every row: requantise (two small kernels)
-    if (int rc = filter_prepare_refs(r->filter, r->refR.as<double>(), r->n, r->d, r->dp, c.stream, false))
-      return rc;
+  // centre / scale / norms of the pre-filter operands depend on every row: requantised (four small kernels) by the next
+  // batch that uses them -- the 1-10 point calls between two replacements (mlf_small.hip) never do
+  if (r->filter.refs_ready) r->filter.refs_dirty = true;
   CK(hipStreamSynchronize(c.stream));
   return 0;
 }
@@ -1692,6 +1704,7 @@ namespace {
 
 // neighbour test of t-space points against the resident live points (MFMA pre-filter when it applies)
 int region_scan_mask(mlf_region *r, const double *d_t, long long np, uint8_t *d_mask, hipStream_t s) {
+  if (int rc = filter_refresh_refs(r->filter, r->refR.as<double>(), r->n, r->d, r->dp, s)) return rc;
   if (filter_applies(r->filter, np, r->r2))
     return filter_run(r->filter, r->refT.as<double>(), r->refR.as<double>(), r->n, r->npad, r->d, r->dp, d_t,
                       (long long)r->d, 1, np, r->r2, nullptr, d_mask, nullptr, s, false);
