@@ -1381,6 +1381,7 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
   if (int rc = ensure_ctx()) return rc;
   Ctx &c = g_ctx;
   r->ready = false;
+  r->axes_ready = r->sampling_ready = false;   // a handle may be set again for another region (kernels.DeviceRegion recycles them)
   r->n = (int)n;
   r->d = (int)d;
   r->dp = pick_dp((int)d);
