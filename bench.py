@@ -398,7 +398,7 @@ def main():
                     "executed_flops_per_launch": exec_flops / per_step,
                     "achieved_by_phase": [m * MFMA_F16_FLOPS / (t * 1e-3) / 1e12 for m, t in zip(mfma_per_launch, by_phase)],
                     "kernel_names": ["k_filter<4, 4, false, true> (first live-point range, compacts the undecided proposals)",
-                                     "k_filter<4, 4, false, false> (second range)"] if per_step == 2 else None,
+                                     "k_filter<4, 2, false, false> (second range: two query groups per wave)"] if per_step == 2 else None,
                     "equivalent_allpairs_flops_per_step": allpairs,
                     "equivalent_allpairs_TFLOPs": allpairs / (launch_ms * per_step * 1e-3) / 1e12,
                     "executed_k_columns": kdim, "second_range_groups": stats["second_range_groups"],

@@ -87,6 +87,7 @@ int g_filter_phases = 1;              // mlf_set_option("filter_phases", n): 0 s
 long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
 bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
 bool g_time_filter_launches = false;  // mlf_set_option("time_filter_launches", 0/1): event pairs around every k_filter launch of every call
+int g_filter_narrow_tail = 1;          // mlf_set_option("filter_narrow_tail", 0/1): later ranges of a phased sweep with 2 query groups per wave
 bool g_small_path = true;             // mlf_set_option("small_path", 0/1): one launch for up to 256 proposals handed over on the host
 bool g_prep_bounded = true;           // mlf_set_option("prep_bounded", 0/1): matrix-core bounded stage (mlf_prep4.hip)
 long long g_filter_min_queries = 2048;  // smaller batches go straight to the exact scan
@@ -237,7 +238,7 @@ int misc_reserve(FilterCtx &f) {
 // Device buffers of one filtered batch.
 int filter_reserve(FilterCtx &f, long long nq, unsigned *cap_out) {
   const long long nqpad = (nq + 31) / 32 * 32;
-  const long long nwaves = filter_wave_count(f.ks, nqpad / 32);
+  const long long nwaves = filter_wave_count(f.ks, nqpad / 32, f.ks == 4 ? 2 : (f.ks < 4 ? 1 : 0));   // room for a narrow later range
   const unsigned cap = kFilterSegCap;   // uncertain pairs per filter wave (expected: tens)
   CK(f.qF.reserve((size_t)nqpad * f.ks * 16 * 2));
   CK(f.tlo.reserve((size_t)nqpad * sizeof(float)));
@@ -319,6 +320,9 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     fa.tile0 = (int)((long long)f.ntiles32 * ph / nphase);
     fa.tile1 = (int)((long long)f.ntiles32 * (ph + 1) / nphase);
     fa.append = ph > 0;
+    fa.seg_first_extra = filter_wave_count(f.ks, ngroups);   // segments beyond the first launch's own: for a narrow later range
+    fa.seg_extra = (g_filter_narrow_tail && nphase > 1 && f.ks <= 4) ? filter_wave_count(f.ks, ngroups, g_filter_narrow_tail) - fa.seg_first_extra : 0;
+    if (fa.seg_extra < 0) fa.seg_extra = 0;
     fa.cq = nullptr;
     if (fused && ph > 0) {   // the previous launch compacted its undecided queries into set (ph - 1) & 1
       const int src = (ph - 1) & 1;
@@ -375,7 +379,8 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       }
       CK(hipEventRecord(f.kev[f.kev_used], s));
     }
-    CK(launch_filter(f.ks, fa, out_idx != nullptr, s));
+    const int narrow = (f.ks <= 4 && ph > 0) ? g_filter_narrow_tail : 0;
+    CK(launch_filter(f.ks, fa, out_idx != nullptr, s, narrow));
     if (time_launch) {
       CK(hipEventRecord(f.kev[f.kev_used + 1], s));
       f.kev_used += 2;
@@ -387,7 +392,9 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     }
   }
   if (ev_after_filter) CK(hipEventRecord(ev_after_filter, s));
-  const long long nsegs_all = filter_wave_count(f.ks, ngroups);
+  const int any_narrow = (f.ks <= 4 && nphase > 1) ? g_filter_narrow_tail : 0;
+  long long nsegs_all = filter_wave_count(f.ks, ngroups, any_narrow);
+  if (nsegs_all < filter_wave_count(f.ks, ngroups)) nsegs_all = filter_wave_count(f.ks, ngroups);
   f.last_nsegs = (size_t)nsegs_all;
   if (xs) {   // no whitened coordinates were stored: the re-check whitens the queries of its pairs itself
     RecheckWArgs rw{};
@@ -395,7 +402,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     rw.seg_cap = cap;
     rw.seg_count = f.segcnt.as<unsigned>();
     rw.nsegs = nsegs_all;
-    rw.unit_cap = (unsigned)(nphase * (f.ks <= 4 ? 4 : (f.ks <= 8 ? 2 : 1)) * 32);   // queries per filter wave, all phases
+    rw.unit_cap = (unsigned)(nphase * (f.ks <= 4 ? 4 : (f.ks <= 8 ? 2 : 1)) * 32);   // queries per filter wave, all phases (a narrow later range has fewer)
     rw.refR = refR;
     rw.n = n;
     rw.d = d;
@@ -1018,6 +1025,10 @@ int mlf_set_option(const char *name, long long value) {
   if (!name) return fail_arg(MLF_E_BADARG, "null pointer");
   if (!strcmp(name, "filter")) {
     g_filter_enabled = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "filter_narrow_tail")) {
+    g_filter_narrow_tail = value < 0 ? 0 : (value > 3 ? 3 : (int)value);   // later ranges with 2 (1), 1 (2) or 3 (3) query groups per wave
     return 0;
   }
   if (!strcmp(name, "small_path")) {

@@ -235,6 +235,8 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long g0 = wave * QW;  // first query group of this wave
   const long long ngroups = a.ngroups_dev ? (long long)*a.ngroups_dev : a.ngroups;
+  if (!a.append && a.seg_extra > 0 && lane == 0)   // segments only a later, narrower launch of this batch uses start empty
+    for (long long i = wave; i < a.seg_extra; i += (long long)gridDim.x * 4) a.seg_count[a.seg_first_extra + i] = 0u;
   if (g0 >= ngroups) {
     if (lane == 0 && !a.append) a.seg_count[wave] = 0;
     return;
@@ -635,8 +637,18 @@ static hipError_t launch_filter_t(const FilterArgs &a, bool first, hipStream_t s
   return hipGetLastError();
 }
 
-hipError_t launch_filter(int ks, const FilterArgs &a, bool first, hipStream_t s) {
+hipError_t launch_filter(int ks, const FilterArgs &a, bool first, hipStream_t s, int narrow) {
   if (a.ngroups <= 0) return hipSuccess;
+  if (narrow == 2 && ks == 4) return launch_filter_t<4, 1>(a, first, s);
+  if (narrow == 3 && ks == 4) return launch_filter_t<4, 3>(a, first, s);
+  if (narrow)   // two query groups per wave: twice the waves of half the length (later ranges of a phased sweep)
+    switch (ks) {
+      case 1: return launch_filter_t<1, 2>(a, first, s);
+      case 2: return launch_filter_t<2, 2>(a, first, s);
+      case 3: return launch_filter_t<3, 2>(a, first, s);
+      case 4: return launch_filter_t<4, 2>(a, first, s);
+      default: break;
+    }
   switch (ks) {
     case 1: return launch_filter_t<1, 4>(a, first, s);
     case 2: return launch_filter_t<2, 4>(a, first, s);
@@ -656,8 +668,8 @@ void launch_recheck(const RecheckArgs &a, long long nwaves, hipStream_t s) {
   hipLaunchKernelGGL(k_recheck, dim3((unsigned)nwaves), dim3(256), 0, s, a);
 }
 
-long long filter_wave_count(int ks, long long ngroups) {
-  const int qw = ks <= 4 ? 4 : (ks <= 8 ? 2 : 1);
+long long filter_wave_count(int ks, long long ngroups, int narrow) {
+  const int qw = ks <= 4 ? (narrow == 2 && ks == 4 ? 1 : (narrow == 3 && ks == 4 ? 3 : (narrow ? 2 : 4))) : (ks <= 8 ? 2 : 1);
   return (ngroups + qw - 1) / qw;
 }
 

@@ -33,6 +33,8 @@ struct FilterArgs {
   unsigned *ccount;
   unsigned ccap;              // slots the compacted set can hold
   const uint8_t *route;
+  // list segments [seg_first_extra, seg_first_extra + seg_extra) are zeroed by the first waves of a non-appending launch
+  long long seg_first_extra, seg_extra;
 };
 // after a compacting launch: group count of the compacted set, padding of its last group, counter reset
 void launch_phase_finish(void *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount, unsigned *ngroups_dst,
@@ -77,9 +79,9 @@ void launch_quant_refs(const double *refR, int n, int npad32, int d, int dp, int
 void launch_quant_queries(const double *q, long long ldq, long long nq, long long nqpad, int d_src, int d, int ks,
                           const double *stats, double r2, const uint8_t *gate, void *qF, float *tlo,
                           float *thi, uint8_t *route, int *best, unsigned *counters, hipStream_t s);
-hipError_t launch_filter(int ks, const FilterArgs &a, bool first, hipStream_t s);
+hipError_t launch_filter(int ks, const FilterArgs &a, bool first, hipStream_t s, int narrow = 0);
 void launch_recheck(const RecheckArgs &a, long long nwaves, hipStream_t s);
-long long filter_wave_count(int ks, long long ngroups);  // waves (= list segments) of a k_filter launch
+long long filter_wave_count(int ks, long long ngroups, int narrow = 0);  // waves (= list segments) of a k_filter launch
 void launch_filter_finalize(const uint8_t *route, const int *best, const unsigned *counters, long long nq,
                             uint8_t *out_mask, long long *out_idx, uint8_t *exact_gate, hipStream_t s,
                             unsigned *reset_word = nullptr);
