@@ -395,7 +395,9 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
     }
     if (lane < 32 && qi >= 0 && qi < a.nq && res != kNone) a.best[qi] = res;
     if (COMPACT) {
-      const bool keep = qi >= 0 && qi < a.nq && res == kNone && a.route[qi] == 1;
+      // route == 1 <=> the query has thresholds (T_hi > 0; the stages in front write -1 for every other route, and a
+      // certain hit lowered it to -inf): no dependent load of the route byte at the end of the wave's life
+      const bool keep = qi >= 0 && qi < a.nq && res == kNone && thi[g] > 0.0f;
       keepm[g] = (unsigned)__ballot(keep);   // low half; lanes l and l + 32 agree
       qid[g] = (int)qi;
     }
