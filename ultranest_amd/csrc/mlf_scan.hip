@@ -19,7 +19,10 @@ namespace mlf {
 
 // QB = queries per workgroup: 64 for large batches; 16 when the batch is so small that 64-query workgroups would
 // leave most CUs idle (the rebuild scans its 4000 live points against themselves: 63 workgroups for 256 CUs)
-template <int DP, int QB>
+// EXTRA: the second-stage uses behind the MFMA pre-filter (routing bytes, in-place whitening of the staged rows, the
+// finalise tail).  They are compiled into their own instance: with them in the one kernel, the plain scan needed 215
+// instead of 128 VGPRs and ran with two instead of four waves per SIMD (exact scan 30 -> 23 TFLOP/s).
+template <int DP, int QB, bool EXTRA>
 __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
   constexpr int kScanQB = QB;   // shadows the global default inside this kernel
   __shared__ __attribute__((aligned(16))) double qs[kScanQB * DP];
@@ -30,7 +33,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   __shared__ int any_active;
-  if (a.fin_best && blockIdx.x >= a.fin_grid0) {   // tail: answers of the filtered queries
+  if (EXTRA && a.fin_best && blockIdx.x >= a.fin_grid0) {   // tail: answers of the filtered queries
     const long long p = ((long long)blockIdx.x - a.fin_grid0) * kScanThreads + tid;
     if (p == 0 && a.fin_reset) *a.fin_reset = 0u;
     if (p >= a.nq) return;
@@ -42,11 +45,11 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     if (a.out_idx) a.out_idx[p] = rt == 0 ? -2ll : (found ? (long long)b : -1ll);
     return;
   }
-  const unsigned scan_blocks = a.fin_best ? a.fin_grid0 : gridDim.x;
-  const bool overflow = a.route && a.counters[1] != 0u;
-  if (a.any_flag && *a.any_flag == 0u && !overflow) return;   // nothing was routed to the exact scan
+  const unsigned scan_blocks = (EXTRA && a.fin_best) ? a.fin_grid0 : gridDim.x;
+  const bool overflow = EXTRA && a.route && a.counters[1] != 0u;
+  if (EXTRA && a.any_flag && *a.any_flag == 0u && !overflow) return;   // nothing was routed to the exact scan
   auto gated = [&](long long j) {
-    if (a.route) {
+    if (EXTRA && a.route) {
       const int rt = a.route[j];
       return rt == 2 || (rt == 1 && overflow);
     }
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
   };
   const long long nqblk = (a.nq + kScanQB - 1) / kScanQB;
   // one workgroup per query block; the gated second-stage launch is a bounded grid that strides over the blocks
-  for (long long qblk = blockIdx.x; qblk < nqblk; qblk += scan_blocks) {
+  auto scan_block = [&](const long long qblk) {
   const long long q0 = qblk * kScanQB;
   const long long left = a.nq - q0;
   const int nqb = left < kScanQB ? (int)left : kScanQB;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     __syncthreads();
     if (tid < nqb && gated(q0 + tid)) any_active = 1;
     __syncthreads();
-    if (!any_active) continue;
+    if (!any_active) return;
   }
 
   // stage this workgroup's queries, zero padded to DP
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
       qs[qq * DP + k] = v;
     }
   }
-  if (a.raw_ctr) {   // rows are proposals as handed over: whiten them in place (reference arithmetic, see ScanArgs)
+  if (EXTRA && a.raw_ctr) {   // rows are proposals as handed over: whiten them in place (reference arithmetic, see ScanArgs)
     constexpr int kPer = (kScanQB * DP + kScanThreads - 1) / kScanThreads;
     double tv[kPer];
     __syncthreads();
@@ -162,7 +165,14 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     else if (mode == SCAN_MASK)
       a.out_mask[q0 + tid] = found ? 1 : 0;
   }
-  __syncthreads();   // the staged queries / states are reused by the next block of this workgroup
+  };
+  if (EXTRA) {
+    for (long long qblk = blockIdx.x; qblk < nqblk; qblk += scan_blocks) {
+      scan_block(qblk);
+      __syncthreads();   // the staged queries / states are reused by the next block of this workgroup
+    }
+  } else if ((long long)blockIdx.x < nqblk) {
+    scan_block(blockIdx.x);   // plain scan: one workgroup per query block
   }
 }
 
@@ -177,14 +187,21 @@ hipError_t launch_scan(int dp, const ScanArgs &a_in, hipStream_t s) {
     a.fin_grid0 = grid;
     grid += (unsigned)((a.nq + kScanThreads - 1) / kScanThreads);
   }
+  const bool extra = a.fin_best || a.route || a.any_flag || a.raw_ctr;
 
   switch (dp) {
 #define X(D)                                                                          \
   case D:                                                                             \
-    if (small)                                                                        \
-      hipLaunchKernelGGL((k_scan<D, 16>), dim3(grid), dim3(kScanThreads), 0, s, a);    \
-    else                                                                              \
-      hipLaunchKernelGGL((k_scan<D, kScanQB>), dim3(grid), dim3(kScanThreads), 0, s, a); \
+    if (extra) {                                                                      \
+      if (small)                                                                      \
+        hipLaunchKernelGGL((k_scan<D, 16, true>), dim3(grid), dim3(kScanThreads), 0, s, a);      \
+      else                                                                            \
+        hipLaunchKernelGGL((k_scan<D, kScanQB, true>), dim3(grid), dim3(kScanThreads), 0, s, a); \
+    } else if (small) {                                                               \
+      hipLaunchKernelGGL((k_scan<D, 16, false>), dim3(grid), dim3(kScanThreads), 0, s, a);       \
+    } else {                                                                          \
+      hipLaunchKernelGGL((k_scan<D, kScanQB, false>), dim3(grid), dim3(kScanThreads), 0, s, a);  \
+    }                                                                                 \
     break;
     MLF_FOR_EACH_DP(X)
 #undef X
