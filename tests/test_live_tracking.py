@@ -129,3 +129,24 @@ def test_device_state_is_reused_only_while_nothing_moved(monkeypatch):
         assert len(calls) == n + 1
     st.sync(reg, False)                                              # the ellipsoid-only use is a different state
     assert len(calls) == n + 2
+
+
+def test_untracked_live_points_never_take_the_fast_path(monkeypatch):
+    """a region whose ``_u`` is a plain array (e.g. restored by pickle: _LiveArray pickles as the array it holds) must be
+    diffed on every call"""
+    reg = _FakeRegion(np.random.RandomState(6).uniform(size=(10, 3)))
+    st = reg._dev
+    calls = []
+    monkeypatch.setattr(st, "_sync_slow", lambda region, use_scan, key: calls.append(1) or "handle")
+    st.handle = "handle"
+    st.sync(reg, True)
+    st.sync(reg, True)
+    assert len(calls) == 1
+    reg.__dict__["_u"] = np.array(reg.u)          # what unpickling leaves behind
+    st.sync(reg, True)
+    st.sync(reg, True)
+    assert len(calls) == 3
+    reg.u = reg.__dict__["_u"]                    # assigning through the property tracks it again
+    st.sync(reg, True)
+    st.sync(reg, True)
+    assert len(calls) == 4

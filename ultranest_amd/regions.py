@@ -300,7 +300,9 @@ class _DeviceState(object):
         layer = region.transformLayer if use_scan else None
         ld = layer.__dict__ if layer is not None else {}
         cell = region.__dict__.get("_u_cell")
-        return (use_scan, region.__dict__.get("_u"), cell[0] if cell is not None else -1, layer,
+        live = region.__dict__.get("_u")
+        tracked = cell is not None and isinstance(live, _LiveArray) and live._cell is cell   # not e.g. after unpickling
+        return (use_scan, live, cell[0] if tracked else -1, layer,
                 ld.get("T"), ld.get("ctr"), ld.get("mean"), ld.get("std"), ld.get("wrap_cuts"),
                 region.ellipsoid_center, region.ellipsoid_invcov, region.enlarge, region.maxradiussq if use_scan else None)
 
@@ -388,7 +390,7 @@ class _DeviceState(object):
         changed = ()
         cell = region.__dict__.get("_u_cell")
         rows = cell[1] if cell is not None else None
-        known = (not full and use_scan and rows is not None and self.fast_key is not None
+        known = (not full and use_scan and rows is not None and key[2] >= 0 and self.fast_key is not None
                  and self.fast_key[1] is key[1] and len(rows) <= max(8, nlive // 8))
         if known:      # only plain row assignments since the last sync: no diff
             changed = sorted(set(r % nlive for r in rows))
