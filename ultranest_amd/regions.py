@@ -169,6 +169,9 @@ class _LiveArray(np.ndarray):
         rows = cell[1]
         if rows is None:
             return
+        if len(rows) > 4096:   # nobody asked the device for a long time: stop collecting, diff at the next call
+            cell[1] = None
+            return
         if self._root:   # a plain row assignment: remember which rows
             if isinstance(key, tuple) and key:
                 key = key[0]
