@@ -14,7 +14,6 @@
 #include "mlf_filter.hpp"
 #include "mlf_misc.hpp"
 #include <atomic>
-#include <chrono>
 #include "mlf_small.hpp"
 #include "mlf_prep2.hpp"
 #include "mlf_prep3.hpp"
@@ -1297,8 +1296,9 @@ int mlf_bootstrap_factor(const double *u, size_t n, size_t d, const uint8_t *sel
                       c.small1.as<int>(), c.out.as<double>(), c.small2.as<int>(), c.stream);
   CK(hipGetLastError());
   CK(hipMemsetAsync(c.small3.p, 0, B * sizeof(unsigned long long), c.stream));
+  CK(c.M.reserve(boot_cholmax_scratch_bytes((int)d, (int)B)));
   CK(launch_boot_cholmax(c.src.as<double>(), (int)n, (int)d, c.selbytes.as<uint8_t>(), (int)B, c.small0.as<double>(),
-                         c.out.as<double>(), scale, c.small3.as<unsigned long long>(), c.stream));
+                         c.out.as<double>(), scale, c.small3.as<unsigned long long>(), c.M.p, c.stream));
   std::vector<unsigned long long> bits(B);
   CK(hipMemcpyAsync(bits.data(), c.small3.p, B * sizeof(unsigned long long), hipMemcpyDeviceToHost, c.stream));
   CK(hipStreamSynchronize(c.stream));
@@ -1555,11 +1555,6 @@ static int region_inside_small(mlf_region *r, const double *pts, size_t np, uint
     CK(c.small_words.reserve(2 * kSmallMaxPoints * sizeof(unsigned)));
     CK(hipMemsetAsync(c.small_words.p, 0, 2 * kSmallMaxPoints * sizeof(unsigned), c.stream));
   }
-  static const bool timing = getenv("MLF_SMALL_TIMING") != nullptr;
-  static double acc_t[4] = {0, 0, 0, 0};
-  static int acc_n = 0;
-  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t0 = timing ? now() : 0.0;
   memcpy(c.pin_pts, pts, np * (size_t)r->d * sizeof(double));
   SmallArgs a{};
   a.pts = c.pin_pts_dev;
@@ -1600,11 +1595,9 @@ static int region_inside_small(mlf_region *r, const double *pts, size_t np, uint
   a.flag = reinterpret_cast<unsigned *>(c.pin_mask_dev + kSmallMaxPoints);
   a.seq = ++c.small_seq;
   if (a.seq == 0u) a.seq = ++c.small_seq;   // 0 is the initial content of the word
-  const double t1 = timing ? now() : 0.0;
   launch_inside_small(a, c.stream);
   CK(hipGetLastError());
-  const double t2 = timing ? now() : 0.0;
-  {   // spin on the completion word; a kernel that does not report within ~2 ms is left to the stream's own error path
+  {   // spin on the completion word; a kernel that does not report within ~40 ms is left to the stream and its error path
     volatile unsigned *flag = reinterpret_cast<volatile unsigned *>(c.pin_mask + kSmallMaxPoints);
     bool seen = false;
     for (long spin = 0; spin < 4000000; ++spin) {
@@ -1620,20 +1613,7 @@ static int region_inside_small(mlf_region *r, const double *pts, size_t np, uint
     }
     std::atomic_thread_fence(std::memory_order_acquire);
   }
-  const double t3 = timing ? now() : 0.0;
   memcpy(mask, c.pin_mask, np);
-  if (timing) {
-    acc_t[0] += t1 - t0;
-    acc_t[1] += t2 - t1;
-    acc_t[2] += t3 - t2;
-    acc_t[3] += now() - t3;
-    if (++acc_n == 300) {
-      fprintf(stderr, "small path, np=%zu: stage %.2f us, launch %.2f us, wait %.2f us, copy out %.2f us\n", np, acc_t[0] / 300,
-              acc_t[1] / 300, acc_t[2] / 300, acc_t[3] / 300);
-      acc_n = 0;
-      acc_t[0] = acc_t[1] = acc_t[2] = acc_t[3] = 0;
-    }
-  }
   return 0;
 }
 

@@ -472,98 +472,139 @@ __global__ __launch_bounds__(64 * kCovWaves) void k_boot_cov(const double *__res
 }
 
 // Bootstrap enlargement without leaving the device (reference mlfriends.pyx:1056-1066 with minvol = 0):
-// f_b = max over the left-out rows of (u_i - m_b)^T (scale cov_b)^-1 (u_i - m_b).  Workgroup = (round b, slice of
-// the rows); every workgroup factorises scale cov_b = L L^T in LDS (d <= 64: a few microseconds) and each thread
-// solves L y = u_i - m_b for its rows, f = |y|^2.  The host version inverted the B matrices with LAPACK (1.1 ms
-// at B = 30, d = 50) between two device calls.  Result class: like the reference's inv + einsum to rounding
-// (tolerance class of `f`); a round whose matrix is not positive definite or not finite returns NaN.
-constexpr int kCholSlices = 8;
+// f_b = max over the left-out rows of (u_i - m_b)^T (scale cov_b)^-1 (u_i - m_b).  Two launches:
+//   k_boot_chol      one WAVE per round: scale cov_b = L L^T, lane = matrix row held in registers, the pivot column
+//                    travels by v_readlane; no barriers, no LDS (the first version factorised in LDS with three
+//                    workgroup barriers per column, and once in each of 8 row slices: 0.75 ms for 30 rounds)
+//   k_boot_solvemax  one wave per (round, slice of the rows): solves L y = u_i - m_b row by row, f = |y|^2, per-round
+//                    maximum by atomicMax on the bit pattern
+// The host version inverted the B matrices with LAPACK (1.1 ms at B = 30, d = 50) between two device calls.  Result
+// class: like the reference's inv + einsum to rounding (tolerance class of `f`); a round whose matrix is not positive
+// definite or not finite returns NaN.  Same sequence of roundings as the LDS version (right-looking, column by column).
+constexpr int kCholSlices = 64;
+
+// value of `v` on lane `lane` (wave-uniform index) through the scalar unit: two v_readlane_b32 instead of the two
+// ds_bpermute round trips of __shfl (the substitution below is one dependent chain of 64 such broadcasts per row)
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Lout: [B][DPC][DPC + 1] (lower triangle incl. diagonal; column DPC holds 1 / L_rr); bad[b] != 0: not positive definite
 template <int DPC>
-__global__ __launch_bounds__(256) void k_boot_cholmax(const double *__restrict__ u, int n, int d,
+__global__ __launch_bounds__(64) void k_boot_chol(const double *__restrict__ cov, int d, double scale,
+                                                  double *__restrict__ Lout, int *__restrict__ bad_out) {
+  const int r = threadIdx.x, b = blockIdx.x;
+  double a[DPC];   // row r of the matrix; entries right of the diagonal are never used
+#pragma unroll
+  for (int c = 0; c < DPC; ++c)
+    a[c] = (r < d && c < d) ? cov[((size_t)b * d + (r < d ? r : 0)) * d + (c < d ? c : 0)] * scale : (r == c ? 1.0 : 0.0);
+  bool bad = false;
+  double invd = 1.0;
+#pragma unroll
+  for (int j = 0; j < DPC; ++j) {
+    const double p = lane_value(a[j], j);   // the pivot: element (j, j)
+    if (!(p > 0.0) || !(p < 1e300)) bad = true;
+    const double sp = sqrt(p > 0.0 ? p : 1.0);
+    const double ip = 1.0 / sp;
+    if (r == j) {
+      a[j] = sp;
+      invd = ip;
+    } else if (r > j) {
+      a[j] *= ip;
+    }
+#pragma unroll
+    for (int c = j + 1; c < DPC; ++c) {
+      const double lc = lane_value(a[j], c);               // L[c][j]
+      if (r >= c) a[c] = __builtin_fma(-a[j], lc, a[c]);   // element (r, c) of the trailing matrix
+    }
+  }
+  if (r < DPC) {
+    double *dst = Lout + ((size_t)b * DPC + r) * (DPC + 1);
+#pragma unroll
+    for (int c = 0; c < DPC; ++c) dst[c] = c <= r ? a[c] : 0.0;
+    dst[DPC] = invd;
+  }
+  if (r == 0) bad_out[b] = bad ? 1 : 0;
+}
+
+// One wave per (round, slice of the rows); lane r holds row r of the factor in registers.  A row of u is solved
+// right-looking: y_k = acc_k / L_kk on lane k, broadcast, acc_r -= L_rk y_k on the lanes below -- 64 short steps without a
+// single memory access.  (One THREAD per row with y[] in registers looked cheaper on paper; the compiler hoisted the
+// 2016 loads of the unrolled substitution and spilled 4108 registers: that was most of the old kernel's 0.75 ms.)
+template <int DPC>
+__global__ __launch_bounds__(64) void k_boot_solvemax(const double *__restrict__ u, int n, int d,
                                                       const uint8_t *__restrict__ selected,
-                                                      const double *__restrict__ mean, const double *__restrict__ cov,
-                                                      double scale, unsigned long long *__restrict__ out_bits) {
-  __shared__ double L[DPC][DPC + 1];
-  __shared__ double m[DPC], invd[DPC];
-  __shared__ double red[256];
-  __shared__ int bad;
-  const int tid = threadIdx.x, b = blockIdx.x;
-  for (int e = tid; e < DPC * DPC; e += 256) {
-    const int r = e / DPC, c = e - r * DPC;
-    L[r][c] = (r < d && c < d) ? cov[((size_t)b * d + r) * d + c] * scale : (r == c ? 1.0 : 0.0);
+                                                      const double *__restrict__ mean, const double *__restrict__ Lin,
+                                                      const int *__restrict__ bad_in,
+                                                      unsigned long long *__restrict__ out_bits) {
+  __shared__ double Ls[DPC][DPC + 1];
+  const int r = threadIdx.x, b = blockIdx.x;
+  const double *src = Lin + (size_t)b * DPC * (DPC + 1);
+  for (int e = r; e < DPC * (DPC + 1); e += 64) {   // coalesced; column DPC (1 / L_rr) rides along
+    const int rr = e / (DPC + 1), c = e - rr * (DPC + 1);
+    Ls[rr][c] = src[e];
   }
-  if (tid < DPC) m[tid] = tid < d ? mean[(size_t)b * d + tid] : 0.0;
-  if (tid == 0) bad = 0;
-  __syncthreads();
-  for (int j = 0; j < DPC; ++j) {   // right-looking Cholesky, lower triangle
-    if (tid == 0) {
-      const double p = L[j][j];
-      if (!(p > 0.0) || !(p < 1e300)) bad = 1;
-      const double sp = sqrt(p > 0.0 ? p : 1.0);
-      L[j][j] = sp;
-      invd[j] = 1.0 / sp;
-    }
-    __syncthreads();
-    const double ip = invd[j];
-    for (int r = j + 1 + tid; r < DPC; r += 256) L[r][j] *= ip;
-    __syncthreads();
-    const int w = DPC - j - 1;
-    for (int e = tid; e < w * w; e += 256) {
-      const int r = j + 1 + e / w, c = j + 1 + e % w;
-      if (c <= r) L[r][c] = __builtin_fma(-L[r][j], L[c][j], L[r][c]);
-    }
-    __syncthreads();
-  }
+  __builtin_amdgcn_wave_barrier();
+  double Lr[DPC];
+  const int rc = r < DPC ? r : 0;
+#pragma unroll
+  for (int c = 0; c < DPC; ++c) Lr[c] = Ls[rc][c];
+  const double invd = r < DPC ? Ls[rc][DPC] : 1.0;
+  const double mr = r < d ? mean[(size_t)b * d + r] : 0.0;
   double fbest = 0.0;
   bool nan_seen = false;
   const uint8_t *sel = selected + (size_t)b * n;
-  for (int i = blockIdx.y * 256 + tid; i < n; i += 256 * kCholSlices) {
+  for (int i = blockIdx.y; i < n; i += kCholSlices) {   // wave-uniform
     if (sel[i]) continue;
-    const double *row = u + (size_t)i * d;
-    double y[DPC];
+    double acc = r < d ? u[(size_t)i * d + r] - mr : 0.0;
     double ss = 0.0;
 #pragma unroll
     for (int k = 0; k < DPC; ++k) {
-      double acc = k < d ? row[k < d ? k : 0] - m[k] : 0.0;
-#pragma unroll
-      for (int j = 0; j < k; ++j) acc = __builtin_fma(-L[k][j], y[j], acc);
-      y[k] = acc * invd[k];
-      ss = __builtin_fma(y[k], y[k], ss);
+      const double yk = lane_value(acc * invd, k);
+      ss = __builtin_fma(yk, yk, ss);
+      if (r > k) acc = __builtin_fma(-Lr[k], yk, acc);
     }
     if (ss != ss) nan_seen = true;
     fbest = fmax(fbest, ss);
   }
-  red[tid] = nan_seen ? NAN : fbest;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (tid < w) {
-      const double o = red[tid + w], mm = red[tid];
-      red[tid] = (o > mm || o != o) ? o : mm;
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    const double r = red[0];
+  if (r == 0) {
     // non-negative doubles order like their bit patterns; NaN / failed factorisation -> all ones
-    atomicMax(&out_bits[b], (bad || r != r) ? ~0ull : (unsigned long long)__double_as_longlong(r));
+    atomicMax(&out_bits[b], (bad_in[b] || nan_seen) ? ~0ull : (unsigned long long)__double_as_longlong(fbest));
   }
 }
 
-// out_bits: B words, zeroed by the caller; afterwards the bit pattern of f_b, or all ones for a failed round
+size_t boot_cholmax_scratch_bytes(int d, int B) {
+  const int dpc = d <= 8 ? 8 : (d <= 16 ? 16 : (d <= 32 ? 32 : 64));
+  return (size_t)B * dpc * (dpc + 1) * sizeof(double) + (size_t)B * sizeof(int);
+}
+
+// out_bits: B words, zeroed by the caller; afterwards the bit pattern of f_b, or all ones for a failed round.
+// scratch: boot_cholmax_scratch_bytes(d, B)
 hipError_t launch_boot_cholmax(const double *u, int n, int d, const uint8_t *selected, int B, const double *mean,
-                               const double *cov, double scale, unsigned long long *out_bits, hipStream_t s) {
+                               const double *cov, double scale, unsigned long long *out_bits, void *scratch,
+                               hipStream_t s) {
   if (n <= 0 || B <= 0) return hipSuccess;
   const dim3 grid((unsigned)B, kCholSlices);
+#define MLF_CHOL(DPC)                                                                                               \
+  {                                                                                                                 \
+    double *Ls = static_cast<double *>(scratch);                                                                    \
+    int *bad = reinterpret_cast<int *>(Ls + (size_t)B * DPC * (DPC + 1));                                           \
+    hipLaunchKernelGGL(k_boot_chol<DPC>, dim3((unsigned)B), dim3(64), 0, s, cov, d, scale, Ls, bad);                \
+    hipLaunchKernelGGL(k_boot_solvemax<DPC>, grid, dim3(64), 0, s, u, n, d, selected, mean, Ls, bad, out_bits);     \
+  }
   if (d <= 8)
-    hipLaunchKernelGGL(k_boot_cholmax<8>, grid, dim3(256), 0, s, u, n, d, selected, mean, cov, scale, out_bits);
+    MLF_CHOL(8)
   else if (d <= 16)
-    hipLaunchKernelGGL(k_boot_cholmax<16>, grid, dim3(256), 0, s, u, n, d, selected, mean, cov, scale, out_bits);
+    MLF_CHOL(16)
   else if (d <= 32)
-    hipLaunchKernelGGL(k_boot_cholmax<32>, grid, dim3(256), 0, s, u, n, d, selected, mean, cov, scale, out_bits);
+    MLF_CHOL(32)
   else if (d <= 64)
-    hipLaunchKernelGGL(k_boot_cholmax<64>, grid, dim3(256), 0, s, u, n, d, selected, mean, cov, scale, out_bits);
+    MLF_CHOL(64)
   else
     return hipErrorInvalidValue;
+#undef MLF_CHOL
   return hipGetLastError();
 }
 

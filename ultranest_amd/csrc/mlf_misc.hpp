@@ -21,8 +21,10 @@ void launch_scaling_transform(const double *pts, long long np, int d, const doub
                               double *out, long long ldt, hipStream_t s);
 void launch_masked_max(const double *q, const uint8_t *selected, int n, double *out, hipStream_t s);
 // f_b = max over left-out rows of the quadratic form with (scale cov_b)^-1, by Cholesky on the device (d <= 64)
+size_t boot_cholmax_scratch_bytes(int d, int B);
 hipError_t launch_boot_cholmax(const double *u, int n, int d, const uint8_t *selected, int B, const double *mean,
-                               const double *cov, double scale, unsigned long long *out_bits, hipStream_t s);
+                               const double *cov, double scale, unsigned long long *out_bits, void *scratch,
+                               hipStream_t s);
 void launch_boot_moments(const double *u, int n, int d, const uint8_t *selected, int B, double *mean,
                          int *count, double *cov, int *idx_scratch, hipStream_t s);
 void launch_loglike(int kind, const double *params, int d, long long n, const double *aux,
