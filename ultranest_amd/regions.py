@@ -376,20 +376,27 @@ class _DeviceState(object):
 
     def _sync_slow(self, region, use_scan, key):
         ndim = region.u.shape[1]
-        if use_scan:
-            if region.maxradiussq is None:
-                raise TypeError("region.maxradiussq is None: bootstrap the radius before testing membership")
-            kind, lctr, lmat = region.transformLayer.device_params(ndim)
-            shift = region.transformLayer.wrap_shift_vector(ndim)
-            r2 = float(region.maxradiussq)
-            nlive = len(region.u)
-        else:
-            kind, lctr, lmat, shift, r2, nlive = 0, None, None, None, 1e300, 0
-        consts = (kind, lctr, lmat, shift, np.asarray(region.ellipsoid_invcov), int(use_scan), nlive)
+        if use_scan and region.maxradiussq is None:
+            raise TypeError("region.maxradiussq is None: bootstrap the radius before testing membership")
+        r2 = float(region.maxradiussq) if use_scan else 1e300
+        nlive = len(region.u) if use_scan else 0
         thresholds = (float(region.enlarge), r2)
         if self.handle is None:
             self.handle = kernels.DeviceRegion()
-        full = self.consts is None or not self._same(consts, self.consts)
+        # layer, ellipsoid matrix and live-point array are the objects of the last sync: their values need no comparing
+        old = self.fast_key
+        untouched = (old is not None and self.consts is not None and old[0] == key[0] and key[2] >= 0
+                     and all(old[i] is key[i] for i in (1, 3, 4, 5, 6, 7, 8, 10)))
+        def current_consts():
+            if use_scan:
+                kind, lctr, lmat = region.transformLayer.device_params(ndim)
+                shift = region.transformLayer.wrap_shift_vector(ndim)
+            else:
+                kind, lctr, lmat, shift = 0, None, None, None
+            return (kind, lctr, lmat, shift, np.asarray(region.ellipsoid_invcov), int(use_scan), nlive)
+
+        consts = None if untouched else current_consts()
+        full = not untouched and (self.consts is None or not self._same(consts, self.consts))
         changed = ()
         cell = region.__dict__.get("_u_cell")
         rows = cell[1] if cell is not None else None
@@ -407,6 +414,9 @@ class _DeviceState(object):
                 changed = np.flatnonzero((self.live != u_now).any(axis=1))
                 full = len(changed) > max(8, nlive // 8)
         if full:
+            if consts is None:
+                consts = current_consts()
+            kind, lctr, lmat, shift = consts[:4]
             # the device whitens region.u itself (live_space=1): live points and proposals then go
             # through the same arithmetic, so a live point is at distance exactly 0 from itself
             self.handle.set(region.u if use_scan else None, kind, lctr, lmat, shift,
