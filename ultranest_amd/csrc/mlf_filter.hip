@@ -248,7 +248,6 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
   half8 bq[QW][KS];
   float tlo[QW], thi[QW];
   int first[QW];
-  unsigned long long anyhit[QW];
 #pragma unroll
   for (int g = 0; g < QW; ++g) {
     const long long grp = (g0 + g < ngroups) ? g0 + g : ngroups - 1;  // clamp (results discarded)
@@ -258,7 +257,6 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
     tlo[g] = (g0 + g < ngroups) ? a.tlo[qi] : -1.0f;
     thi[g] = (g0 + g < ngroups) ? a.thi[qi] : -1.0f;
     first[g] = kNone;
-    anyhit[g] = 0ull;
   }
   const int rowbase = 4 * (lane >> 5);
   unsigned cursor = a.append ? a.seg_count[wave] : 0u;           // wave-uniform
@@ -315,22 +313,20 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
       const int m3 = min3i(__float_as_int(c[9]), __float_as_int(c[10]), __float_as_int(c[11]));
       const int m4 = min3i(__float_as_int(c[12]), __float_as_int(c[13]), __float_as_int(c[14]));
       vmin[g] = __int_as_float(min3i(min3i(m0, m1, m2), min3i(m3, m4, __float_as_int(c[15])), m0));
+      // mask mode: a certain hit (vmin <= T_lo < T_hi) lowers this lane's T_hi to -inf -- two vector instructions, no
+      // branch -- and so never counts as a candidate, now or later.  (With the hits handled behind the branch, nearly
+      // every tile of the first range took it: a million first hits over half a million wave-tiles.)  The other lane of
+      // the query learns of it only at the end; until then it may still list uncertain pairs of a decided query, which
+      // the re-check answers like any other.
+      if (!FIRST) thi[g] = vmin[g] <= tlo[g] ? -INFINITY : thi[g];
       candm[g] = __ballot(vmin[g] <= thi[g]);
       need |= candm[g];
     }
-    if (need != 0ull) {   // wave-uniform: a first certain hit of some query, or an uncertain pair
+    if (need != 0ull) {   // wave-uniform: an uncertain pair (first-index mode: or a certain hit)
 #pragma unroll
       for (int g = 0; g < QW; ++g) {
         if (candm[g] == 0ull) continue;
-        if (!FIRST) {
-          // certain hits of this tile (vmin <= T_lo < T_hi): the query leaves the candidate test for good
-          const unsigned long long hb = __ballot(vmin[g] <= tlo[g]);
-          const unsigned long long hq = (hb | (hb >> 32)) & 0xffffffffull;
-          const unsigned long long both = hq | (hq << 32);
-          anyhit[g] |= both;
-          if ((both >> lane) & 1ull) thi[g] = -INFINITY;
-          candm[g] &= ~both;
-        } else {
+        if (FIRST) {
           // a query with a certain hit below this tile cannot get a lower first index here, and its uncertain
           // pairs in this tile cannot matter either (without this every later tile of an accepted proposal went
           // through the detail path: first-index batches with many hits ran slower than the exact scan)
@@ -391,7 +387,8 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
       const int other = __shfl_xor(first[g], 32);
       res = first[g] < other ? first[g] : other;
     } else {
-      res = ((anyhit[g] >> (lane & 31)) & 1ull) ? 0 : kNone;   // both lanes of a query carry its bit
+      const int mine = thi[g] == -INFINITY ? 1 : 0;   // only a certain hit leaves -inf behind (no threshold: -1)
+      res = (mine | __shfl_xor(mine, 32)) ? 0 : kNone;
     }
     if (lane < 32 && qi >= 0 && qi < a.nq && res != kNone) a.best[qi] = res;
     if (COMPACT) {
