@@ -108,7 +108,7 @@ def test_every_documented_option_is_accepted_without_a_device():
     names = re.findall(r'"([a-z_]+)"', block)
     assert {"filter", "filter_min_queries", "filter_phases", "filter_phase_min_queries", "filter_fused_compact",
             "fused_prep", "prep_matrix", "tq_row_major"} <= set(names)
-    defaults = {"filter_min_queries": 2048, "filter_phase_min_queries": 32768}
+    defaults = {"filter_min_queries": 257, "filter_phase_min_queries": 32768}
     for name in names:
         _lib.set_option(name, defaults.get(name, 1))
     with pytest.raises(ValueError, match="unknown option"):

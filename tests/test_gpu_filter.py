@@ -22,7 +22,7 @@ def K(request):
     _lib.set_option("filter_phase_min_queries", 64)
     yield kernels
     _lib.set_option("filter_fused_compact", 1)
-    _lib.set_option("filter_min_queries", 2048)
+    _lib.set_option("filter_min_queries", 257)
     _lib.set_option("filter_phase_min_queries", 32768)
     _lib.set_option("filter_phases", 1)
     _lib.set_option("filter", 1)
@@ -178,3 +178,38 @@ def test_fused_prep_matches_unfused(n, d, p, K, oracle):
         assert np.array_equal(m, want), key
     assert 0.02 < want.mean() < 0.98
     reg.close()
+
+
+@pytest.mark.parametrize("n,d", [(400, 7), (300, 1), (500, 5), (350, 33), (600, 63)])
+def test_bounded_stage_with_odd_batch_lengths(n, d, K, oracle):
+    """np * d odd: the proposals end in the middle of one of the 16-byte pieces k_prep4 fetches them in (the last
+    coordinate of the last proposal was left out once); every ragged size through the filter path must give the exact
+    scan's mask"""
+    import inputs
+    from ultranest_amd import _lib
+    u = inputs.live_points(41 + d, n, d)
+    ctr = u.mean(axis=0)
+    cov = np.atleast_2d(np.cov(u, rowvar=0)) * (d + 2)
+    ev, evec = np.linalg.eigh(cov)
+    T = evec * ev ** -0.5
+    inv = np.linalg.inv(cov)
+    reg = K.DeviceRegion()
+    reg.set(u, 0, ctr, T, None, ctr, inv, 40.0, 1.2, live_space=1)
+    tl = oracle.affine_transform(u, ctr, T)
+    _lib.set_option("small_path", 0)
+    try:
+        for p in (257, 385, 1001, 2049, 4097, 33333):
+            pts = inputs.proposal_mix(50 + p, u, p, shell_q=2.0)
+            pts[-1] = u[p % n]                       # the last proposal: a live point itself, inside for certain
+            got = {}
+            for filt in (1, 0):
+                _lib.set_option("filter", filt)
+                got[filt] = reg.inside(pts)
+            _lib.set_option("filter", 1)
+            assert np.array_equal(got[1], got[0]), (p, np.flatnonzero(got[1] != got[0])[:5])
+            assert got[1][-1]
+            want = oracle.inside_ellipsoid(pts, ctr, inv, 40.0) & (oracle.find_nearby(tl, oracle.affine_transform(pts, ctr, T), 1.2) >= 0)
+            assert np.array_equal(got[1], want), p
+    finally:
+        _lib.set_option("small_path", 1)
+        reg.close()

@@ -89,7 +89,9 @@ bool g_time_filter_launches = false;  // mlf_set_option("time_filter_launches", 
 int g_filter_narrow_tail = 1;          // mlf_set_option("filter_narrow_tail", 0/1): later ranges of a phased sweep with 2 query groups per wave
 bool g_small_path = true;             // mlf_set_option("small_path", 0/1): one launch for up to 256 proposals handed over on the host
 bool g_prep_bounded = true;           // mlf_set_option("prep_bounded", 0/1): matrix-core bounded stage (mlf_prep4.hip)
-long long g_filter_min_queries = 2048;  // smaller batches go straight to the exact scan
+constexpr long long kFilterMinQueriesDefault = 257;   // = everything the single-launch path does not take
+long long g_filter_min_queries = kFilterMinQueriesDefault;  // smaller batches go straight to the exact scan (with the
+// tile ranges of filter_tile_split a 1024-query batch takes 50 us through the filter, 175 us through the exact scan)
 
 struct Ctx {
   bool ready = false;
@@ -237,7 +239,11 @@ int misc_reserve(FilterCtx &f) {
 // Device buffers of one filtered batch.
 int filter_reserve(FilterCtx &f, long long nq, unsigned *cap_out) {
   const long long nqpad = (nq + 31) / 32 * 32;
-  const long long nwaves = filter_wave_count(f.ks, nqpad / 32, f.ks == 4 ? 2 : (f.ks < 4 ? 1 : 0));   // room for a narrow later range
+  long long nwaves = filter_wave_count(f.ks, nqpad / 32, f.ks == 4 ? 2 : (f.ks < 4 ? 1 : 0));   // room for a narrow later range
+  {   // ... and for the tile ranges of a small batch (filter_tile_split): one segment per (wave, range)
+    const long long plain = (filter_wave_count(f.ks, nqpad / 32) + 3) / 4 * 4;
+    if (plain <= 4096 && 4 * plain > nwaves) nwaves = 4 * plain;
+  }
   const unsigned cap = kFilterSegCap;   // uncertain pairs per filter wave (expected: tens)
   CK(f.qF.reserve((size_t)nqpad * f.ks * 16 * 2));
   CK(f.tlo.reserve((size_t)nqpad * sizeof(float)));
@@ -314,6 +320,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     CK(f.pblk.reserve(((size_t)nqpad / 256 + 2) * sizeof(unsigned)));
   }
   const bool fused = nphase > 1 && g_filter_fused_compact;
+  fa.split = nphase == 1 ? filter_tile_split(f.ks, ngroups, f.ntiles32) : 1;
 
   for (int ph = 0; ph < nphase; ++ph) {
     fa.tile0 = (int)((long long)f.ntiles32 * ph / nphase);
@@ -394,6 +401,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   const int any_narrow = (f.ks <= 4 && nphase > 1) ? g_filter_narrow_tail : 0;
   long long nsegs_all = filter_wave_count(f.ks, ngroups, any_narrow);
   if (nsegs_all < filter_wave_count(f.ks, ngroups)) nsegs_all = filter_wave_count(f.ks, ngroups);
+  if (fa.split > 1) nsegs_all = (filter_wave_count(f.ks, ngroups) + 3) / 4 * 4 * fa.split;
   f.last_nsegs = (size_t)nsegs_all;
   if (xs) {   // no whitened coordinates were stored: the re-check whitens the queries of its pairs itself
     RecheckWArgs rw{};
@@ -510,7 +518,7 @@ int scan_host(const double *apts, size_t na, const double *bpts, size_t nb, size
   // The stateless call pays the filter's live-point preparation every time and first-index mode keeps sweeping after
   // a hit, so the pre-filter only pays for larger batches than in the resident mask path (measured at N = 4000,
   // d = 50: exact scan 0.23-0.35 ms against 0.45-1.05 ms at 4000 queries; break-even between 16000 and 50000)
-  const long long host_min = g_filter_min_queries > 2048 ? g_filter_min_queries : (g_filter_min_queries < 2048 ? g_filter_min_queries : 32768);
+  const long long host_min = g_filter_min_queries != kFilterMinQueriesDefault ? g_filter_min_queries : 32768;
   if (mode == SCAN_FIRST && g_filter_enabled && (long long)nb >= host_min && na >= 256) {
     if (int rc = filter_prepare_refs(c.filter, c.refR.as<double>(), (int)na, (int)d, dp, c.stream, true)) return rc;
     if (filter_applies(c.filter, (long long)nb, r2)) {

@@ -235,10 +235,14 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long g0 = wave * QW;  // first query group of this wave
   const long long ngroups = a.ngroups_dev ? (long long)*a.ngroups_dev : a.ngroups;
-  if (!a.append && a.seg_extra > 0 && lane == 0)   // segments only a later, narrower launch of this batch uses start empty
+  // gridDim.y > 1 (batches too small to fill the chip with one wave per 4 query groups; never a compacting launch): the
+  // live-point tiles are split into gridDim.y ranges, one wave per (query groups, range), each with its own list segment
+  const int sub = COMPACT ? 0 : (int)blockIdx.y, nsub = COMPACT ? 1 : (int)gridDim.y;
+  const long long seg = wave + (long long)sub * gridDim.x * 4;
+  if (!a.append && a.seg_extra > 0 && lane == 0 && sub == 0)   // segments only a later, narrower launch of this batch uses start empty
     for (long long i = wave; i < a.seg_extra; i += (long long)gridDim.x * 4) a.seg_count[a.seg_first_extra + i] = 0u;
   if (g0 >= ngroups) {
-    if (lane == 0 && !a.append) a.seg_count[wave] = 0;
+    if (lane == 0 && !a.append) a.seg_count[seg] = 0;
     return;
   }
 
@@ -259,22 +263,25 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
     first[g] = kNone;
   }
   const int rowbase = 4 * (lane >> 5);
-  unsigned cursor = a.append ? a.seg_count[wave] : 0u;           // wave-uniform
-  unsigned long long *seg = a.list + (size_t)wave * a.seg_cap;   // this wave's list segment
+  unsigned cursor = a.append ? a.seg_count[seg] : 0u;            // wave-uniform
+  unsigned long long *seglist = a.list + (size_t)seg * a.seg_cap;   // this wave's list segment
 
   half8 af[KS];
   // Waves start at different live-point tiles (results are order independent): all waves
   // sweeping the same 4 KB tile at the same moment would queue on one L2 channel.
-  const int ntl = a.tile1 - a.tile0;   // tiles of this phase
-  const int tstart = a.tile0 + (int)(((long long)blockIdx.x * 37) % ntl);   // one sweep order per workgroup: its 4 waves share L1 lines
+  const int ntl_all = a.tile1 - a.tile0;   // tiles of this phase
+  const int tile0 = a.tile0 + (int)((long long)ntl_all * sub / nsub);        // ... and of this wave's range of it
+  const int tile1 = a.tile0 + (int)((long long)ntl_all * (sub + 1) / nsub);
+  const int ntl = tile1 - tile0;
+  const int tstart = tile0 + (int)(((long long)blockIdx.x * 37) % ntl);   // one sweep order per workgroup: its 4 waves share L1 lines
 #pragma unroll
   for (int s = 0; s < KS; ++s) af[s] = refF[((size_t)tstart * KS + s) * 64 + lane];
 
   for (int it = 0; it < ntl; ++it) {
     int t = tstart + it;
-    if (t >= a.tile1) t -= ntl;
+    if (t >= tile1) t -= ntl;
     int tn = t + 1;
-    if (tn >= a.tile1) tn = a.tile0;
+    if (tn >= tile1) tn = tile0;
     half8 an[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) an[s] = refF[((size_t)tn * KS + s) * 64 + lane];  // prefetch
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
               const int idx = t * 32 + rowbase + (r & 3) + 8 * (r >> 2);
               const long long slot_q = (g0 + g) * 32 + (lane & 31);
               const long long qi = a.qmap ? (long long)a.qmap[slot_q] : slot_q;
-              seg[slot] = qi >= 0 ? (((unsigned long long)qi << 32) | (unsigned)idx) : ~0ull;
+              seglist[slot] = qi >= 0 ? (((unsigned long long)qi << 32) | (unsigned)idx) : ~0ull;
             }
             cursor += (unsigned)__popcll(bm);
           }
@@ -390,7 +397,12 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
       const int mine = thi[g] == -INFINITY ? 1 : 0;   // only a certain hit leaves -inf behind (no threshold: -1)
       res = (mine | __shfl_xor(mine, 32)) ? 0 : kNone;
     }
-    if (lane < 32 && qi >= 0 && qi < a.nq && res != kNone) a.best[qi] = res;
+    if (lane < 32 && qi >= 0 && qi < a.nq && res != kNone) {
+      if (FIRST && nsub > 1)
+        atomicMin(a.best + qi, res);   // the waves of the other tile ranges report too
+      else
+        a.best[qi] = res;
+    }
     if (COMPACT) {
       // route == 1 <=> the query has thresholds (T_hi > 0; the stages in front write -1 for every other route, and a
       // certain hit lowered it to -inf): no dependent load of the route byte at the end of the wave's life
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
     }
   }
   if (lane == 0) {
-    a.seg_count[wave] = cursor < a.seg_cap ? cursor : a.seg_cap;
+    a.seg_count[seg] = cursor < a.seg_cap ? cursor : a.seg_cap;
     if (cursor > a.seg_cap) a.counters[1] = 1u;   // overflow: the exact scan redoes the batch
   }
 }
@@ -622,18 +634,26 @@ void launch_quant_queries(const double *q, long long ldq, long long nq, long lon
 template <int KS, int QW>
 static hipError_t launch_filter_t(const FilterArgs &a, bool first, hipStream_t s) {
   const long long waves = (a.ngroups + QW - 1) / QW;
-  const unsigned grid = (unsigned)((waves + 3) / 4);
+  const dim3 grid((unsigned)((waves + 3) / 4), (unsigned)((a.cq || a.split < 1) ? 1 : a.split));
   if (a.cq) {
     if (first)
-      hipLaunchKernelGGL((k_filter<KS, QW, true, true>), dim3(grid), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_filter<KS, QW, true, true>), grid, dim3(256), 0, s, a);
     else
-      hipLaunchKernelGGL((k_filter<KS, QW, false, true>), dim3(grid), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_filter<KS, QW, false, true>), grid, dim3(256), 0, s, a);
   } else if (first) {
-    hipLaunchKernelGGL((k_filter<KS, QW, true, false>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_filter<KS, QW, true, false>), grid, dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL((k_filter<KS, QW, false, false>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_filter<KS, QW, false, false>), grid, dim3(256), 0, s, a);
   }
   return hipGetLastError();
+}
+
+int filter_tile_split(int ks, long long ngroups, int ntiles) {
+  const long long waves = filter_wave_count(ks, ngroups);
+  long long k = 4096 / (waves > 0 ? waves : 1);   // two rounds of the ~2048 resident waves are the aim
+  if (k > 4) k = 4;
+  if (k > ntiles / 8) k = ntiles / 8;
+  return k < 1 ? 1 : (int)k;
 }
 
 hipError_t launch_filter(int ks, const FilterArgs &a, bool first, hipStream_t s, int narrow) {

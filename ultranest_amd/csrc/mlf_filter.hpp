@@ -35,6 +35,8 @@ struct FilterArgs {
   const uint8_t *route;
   // list segments [seg_first_extra, seg_first_extra + seg_extra) are zeroed by the first waves of a non-appending launch
   long long seg_first_extra, seg_extra;
+  // tile ranges of a non-compacting launch (grid.y); list segment of (wave, range) = wave + range * 4 * grid.x
+  int split;
 };
 // after a compacting launch: group count of the compacted set, padding of its last group, counter reset
 void launch_phase_finish(void *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount, unsigned *ngroups_dst,
@@ -81,7 +83,9 @@ void launch_quant_queries(const double *q, long long ldq, long long nq, long lon
                           float *thi, uint8_t *route, int *best, unsigned *counters, hipStream_t s);
 hipError_t launch_filter(int ks, const FilterArgs &a, bool first, hipStream_t s, int narrow = 0);
 void launch_recheck(const RecheckArgs &a, long long nwaves, hipStream_t s);
-long long filter_wave_count(int ks, long long ngroups, int narrow = 0);  // waves (= list segments) of a k_filter launch
+long long filter_wave_count(int ks, long long ngroups, int narrow = 0);
+// tile ranges a single-sweep launch over `ntiles` tiles should use for a batch of `ngroups` query groups (1 ... 4)
+int filter_tile_split(int ks, long long ngroups, int ntiles);  // waves (= list segments) of a k_filter launch
 void launch_filter_finalize(const uint8_t *route, const int *best, const unsigned *counters, long long nq,
                             uint8_t *out_mask, long long *out_idx, uint8_t *exact_gate, hipStream_t s,
                             unsigned *reset_word = nullptr);

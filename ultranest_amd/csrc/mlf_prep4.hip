@@ -183,6 +183,8 @@ __global__ __launch_bounds__(64 * P4<DP>::NW, 1) void k_prep4(Prep4Args a) {
         const long long g = base + 2 * e;
         if (e < 16 * d && g + 1 < total)
           __builtin_amdgcn_global_load_lds((gptr_t *)(a.pts + g), (lptr_t *)(reinterpret_cast<char *>(xs) + i * 1024), 16, 0, 0);
+        else if (e < 16 * d && g + 1 == total)   // np * d odd: the batch ends in the middle of this 16-byte piece
+          xs[2 * e] = a.pts[g];
       }
     }
   };
