@@ -213,3 +213,42 @@ def test_bounded_stage_with_odd_batch_lengths(n, d, K, oracle):
     finally:
         _lib.set_option("small_path", 1)
         reg.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_region_inside_random_shapes_filter_equals_exact_scan(seed, K):
+    """random (live points, dimension, batch length, geometry): whatever kernels a call is routed through -- bounded or
+    binary64 per-proposal stage, pre-filter with one or several tile ranges, phases, exact scan -- the mask is the same"""
+    import inputs
+    from ultranest_amd import _lib
+    rs = np.random.RandomState(1000 + seed)
+    d = int(rs.choice([1, 2, 3, 5, 7, 10, 13, 20, 31, 50, 63, 64]))
+    n = int(rs.randint(max(d + 2, 40), 3000))
+    p = int(rs.choice([257, 300, 511, 1000, 2047, 2049, 4001, 9999, 40001]))
+    u = inputs.live_points(seed, n, d)
+    if seed % 3 == 0:                        # strongly anisotropic cloud
+        u = 0.5 + (u - 0.5) * np.geomspace(1.0, 0.02, d)
+    ctr = u.mean(axis=0)
+    cov = np.atleast_2d(np.cov(u, rowvar=0)) * (d + 2)
+    ev, evec = np.linalg.eigh(cov)
+    T = evec * ev ** -0.5
+    inv = np.linalg.inv(cov)
+    tl = (u - ctr) @ T
+    dd = ((tl[:200, None, :] - tl[None, :200, :]) ** 2).sum(axis=2)
+    np.fill_diagonal(dd, np.inf)
+    r2 = float(np.sort(dd.min(axis=1))[int(0.7 * min(n, 200))]) * float(rs.uniform(0.5, 2.0))
+    enlarge = float(d) * float(rs.uniform(1.0, 3.0))
+    pts = inputs.proposal_mix(seed + 7, u, p, shell_q=2.0)
+    reg = K.DeviceRegion()
+    reg.set(u, 0, ctr, T, None, ctr, inv, enlarge, r2, live_space=1)
+    got = {}
+    for name, opts in (("default", {}), ("exact", {"filter": 0}), ("binary64 stage", {"prep_bounded": 0}),
+                       ("single sweep", {"filter_phases": 0}), ("wide tail", {"filter_narrow_tail": 0})):
+        for k, v in opts.items():
+            _lib.set_option(k, v)
+        got[name] = reg.inside(pts)
+        for k, v in (("filter", 1), ("prep_bounded", 1), ("filter_phases", 1), ("filter_narrow_tail", 1)):
+            _lib.set_option(k, v)
+    reg.close()
+    for name, m in got.items():
+        assert np.array_equal(m, got["exact"]), (name, d, n, p, np.flatnonzero(m != got["exact"])[:5])

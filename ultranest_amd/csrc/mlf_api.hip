@@ -223,6 +223,9 @@ int filter_refresh_refs(FilterCtx &f, const double *refR, int n, int d, int dp, 
 // host-side eligibility of one batch (the kernels re-check per query and fall back on their own)
 bool filter_applies(const FilterCtx &f, long long nq, double r2) {
   if (!g_filter_enabled || !f.refs_ready || !f.usable || nq < g_filter_min_queries) return false;
+  // below ~2000 proposals the five launches of the filter path (~45 us) only pay when the exact scan has real work:
+  // 400 proposals against 400 x 5 live coordinates take 43 us through the exact scan, 51 us through the filter
+  if (g_filter_min_queries == kFilterMinQueriesDefault && nq < 2048 && (long long)f.ntiles32 * 32 * f.ks * 16 < 40000) return false;
   if (!(r2 > 0.0) || !(r2 < 1e150)) return false;
   const double sr2 = f.sigma * f.sigma * r2;
   return sr2 < 4096.0 && sr2 > 1e-30;
