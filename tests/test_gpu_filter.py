@@ -252,3 +252,21 @@ def test_region_inside_random_shapes_filter_equals_exact_scan(seed, K):
     reg.close()
     for name, m in got.items():
         assert np.array_equal(m, got["exact"]), (name, d, n, p, np.flatnonzero(m != got["exact"])[:5])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_find_nearby_random_shapes_vs_oracle(seed, K, oracle):
+    """first-hit indices (reference mlfriends.pyx:143-183) for random live sets / batches, pre-filter on and off: the
+    lowest index must survive tile ranges swept by different waves, phases and the re-check"""
+    rs = np.random.RandomState(500 + seed)
+    d = int(rs.choice([1, 2, 4, 9, 16, 27, 50, 64, 70]))
+    na = int(rs.randint(33, 5000))
+    nb = int(rs.choice([65, 300, 1025, 4099, 20001]))
+    a = rs.normal(size=(na, d))
+    b = rs.normal(size=(nb, d)) * rs.uniform(0.5, 1.2)
+    b[::7] = a[rs.randint(na, size=len(b[::7]))]                  # exact copies: distance 0
+    d2 = ((b[:200, None, :] - a[None, :500, :]) ** 2).sum(axis=2).min(axis=1)
+    r2 = float(np.quantile(d2, rs.uniform(0.2, 0.8))) + 1e-12
+    want = oracle.find_nearby(a, b, r2)
+    for filt in (True, False):
+        assert np.array_equal(_find(K, a, b, r2, filt), want), (filt, d, na, nb)
