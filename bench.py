@@ -453,8 +453,8 @@ def main():
                                        "achieved_TFLOPs": prep_mfma_flops / (prep_ms * 1e-3) / 1e12,
                                        "peak_TFLOPs": F16_MFMA_PEAK_TFLOPS},
                           "note": "the stage time includes the launch gap in front of the filter; the matrix work is 13 % "
-                                  "of the SIMD time (profiles/), the kernel is bound by getting 400 MB of proposals "
-                                  "through 2 waves per SIMD: DESIGN.md section 4c"},
+                                  "of the SIMD time (profiles/); a plain device copy of a 400 MB buffer reaches 4.8 TB/s on "
+                                  "this part (profiles/r02_hbm_copy_rate.json): DESIGN.md section 4c"},
         "host_api": hostapi,
     }
     if world == 1 and not args.no_cpu:
