@@ -50,7 +50,8 @@ int mlf_synchronize(void);
  * the whitened proposals handed from the preparation kernel to the exact re-check), "prep_bounded" (1/0: the
  * bounded matrix-core per-proposal stage or the binary64 one), "small_path" (1/0: mlf_region_inside with up to 256
  * proposals as ONE launch over pinned staging -- the calls of the scalar step samplers -- or through the batched
- * pipeline), "filter_narrow_tail" (0: every range with 4 query groups per wave; 1 (default): later ranges with 2; 2 / 3: with 1 / 3),
+ * pipeline), "filter_first_range_pct" (10 ... 90, default 50: share of the live-point tiles the first of two ranges takes;
+ * 35 ... 50 measure the same), "filter_narrow_tail" (0: every range with 4 query groups per wave; 1 (default): later ranges with 2; 2 / 3: with 1 / 3),
  * "time_filter_launches".  Results never depend on them. */
 int mlf_set_option(const char *name, long long value);
 

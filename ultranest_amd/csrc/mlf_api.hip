@@ -86,6 +86,7 @@ int g_filter_phases = 1;              // mlf_set_option("filter_phases", n): 0 s
 long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
 bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
 bool g_time_filter_launches = false;  // mlf_set_option("time_filter_launches", 0/1): event pairs around every k_filter launch of every call
+int g_filter_first_range_pct = 50;     // mlf_set_option("filter_first_range_pct", 10 ... 90): share of the live-point tiles in the first of two ranges
 int g_filter_narrow_tail = 1;          // mlf_set_option("filter_narrow_tail", 0/1): later ranges of a phased sweep with 2 query groups per wave
 bool g_small_path = true;             // mlf_set_option("small_path", 0/1): one launch for up to 256 proposals handed over on the host
 bool g_prep_bounded = true;           // mlf_set_option("prep_bounded", 0/1): matrix-core bounded stage (mlf_prep4.hip)
@@ -328,6 +329,12 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   for (int ph = 0; ph < nphase; ++ph) {
     fa.tile0 = (int)((long long)f.ntiles32 * ph / nphase);
     fa.tile1 = (int)((long long)f.ntiles32 * (ph + 1) / nphase);
+    if (nphase == 2) {   // two ranges: the first takes g_filter_first_range_pct per cent of the tiles
+      const int cut = (int)((long long)f.ntiles32 * g_filter_first_range_pct / 100);
+      const int c = cut < 4 ? 4 : (cut > f.ntiles32 - 4 ? f.ntiles32 - 4 : cut);
+      fa.tile0 = ph == 0 ? 0 : c;
+      fa.tile1 = ph == 0 ? c : f.ntiles32;
+    }
     fa.append = ph > 0;
     fa.seg_first_extra = filter_wave_count(f.ks, ngroups);   // segments beyond the first launch's own: for a narrow later range
     fa.seg_extra = (g_filter_narrow_tail && nphase > 1 && f.ks <= 4) ? filter_wave_count(f.ks, ngroups, g_filter_narrow_tail) - fa.seg_first_extra : 0;
@@ -1035,6 +1042,10 @@ int mlf_set_option(const char *name, long long value) {
   if (!name) return fail_arg(MLF_E_BADARG, "null pointer");
   if (!strcmp(name, "filter")) {
     g_filter_enabled = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "filter_first_range_pct")) {
+    g_filter_first_range_pct = value < 10 ? 10 : (value > 90 ? 90 : (int)value);
     return 0;
   }
   if (!strcmp(name, "filter_narrow_tail")) {
