@@ -55,7 +55,7 @@ struct FilterCtx {
   DevBuf stats, statscratch, refF, qF, tlo, thi, route, best, counters, list, segcnt, gate2;
   // phased sweep: two compacted query sets (ping-pong)
   DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png, pflags, pblk;
-  // bounded per-proposal stage (mlf_prep4.hip): ellipsoid band list, exact-coordinate slots, per-call counters
+  // bounded per-proposal stage (mlf_prep4.hip): ellipsoid band list, per-call counters
   // misc: [0] band proposals, [1] k_ell_exact workgroups done -- both return to zero by themselves (no memset per batch),
   // zeroed once when the buffer is allocated; [2], [3] "a proposal is routed to the exact scan", used alternately by
   // successive batches (the scan launch of a batch clears the word of the next one); [4] band proposals of the last
@@ -63,7 +63,7 @@ struct FilterCtx {
   DevBuf ell_list, misc;
   unsigned batch_parity = 0;
   size_t last_nsegs = 0;      // list segments of the last filtered batch
-  bool ell_pending = false;   // band list of the running call not decided yet (the k_mark_exact launch takes it along)
+  bool ell_pending = false;   // band list of the running call not decided yet (the tail of the re-check launch decides it)
   EllExactArgs ell_args{};
   // (start, stop) event pairs around every k_filter launch of the timed calls
   std::vector<hipEvent_t> kev;
@@ -655,7 +655,7 @@ int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2,
   const double g = (4.0 * nsteps + 8.0) * std::ldexp(1.0, -24) * (1.0 + std::ldexp(1.0, -8)) + std::pow(2.0, -21.6) +
                    std::pow(2.0, -21.9);
   const double lf = std::sqrt(lf2);
-  // share of the proposals near the boundary that the binary32 chain cannot decide ~ d g |L|_F / sigma_min(L):
+  // share of the proposals near the boundary that the split-binary16 chain cannot decide ~ d g |L|_F / sigma_min(L):
   // beyond a few per cent the binary64 test behind it would dominate, the binary64 stage (k_prep3) is used instead
   if (d * g * lf / dmin > 0.02) return 0;
   // scale of the proposal operand: the live points' largest centred coordinate lands in (16, 32]; a region without
@@ -831,7 +831,7 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
     ea.chol_ok = r->chol_ok ? 1 : 0;
     ea.gate = gate;
     ea.route = r->use_scan ? f.route.as<uint8_t>() : nullptr;
-    if (r->use_scan && !pregate) {   // decided by the tail of the k_mark_exact launch, next to the marking work
+    if (r->use_scan && !pregate) {   // decided by the tail of the re-check launch (k_recheck_whiten)
       f.ell_args = ea;
       f.ell_pending = true;
     } else {
