@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 N_LIVE, NDIM, NPROPOSALS, NBOOT = 4000, 50, 1000000, 30
 FP64_VALU_PEAK_TFLOPS = 39.3     # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz, one flop per non-fused v_*_f64
 F16_MFMA_PEAK_TFLOPS = 2500.0    # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
+PROBE_F16_MFMA_TFLOPS = 1400.0   # what k_filter's instruction pattern sustains in a probe without memory traffic
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F16_FLOPS = 2 * 32 * 32 * 16   # one v_mfma_f32_32x32x16_f16
 
@@ -399,6 +400,11 @@ def main():
                     "achieved_by_phase": [m * MFMA_F16_FLOPS / (t * 1e-3) / 1e12 for m, t in zip(mfma_per_launch, by_phase)],
                     "kernel_names": ["k_filter<4, 4, false, true> (first live-point range, compacts the undecided proposals)",
                                      "k_filter<4, 2, false, false> (second range: two query groups per wave)"] if per_step == 2 else None,
+                    "practical_ceiling": {"TFLOPs": PROBE_F16_MFMA_TFLOPS, "frac": ach / PROBE_F16_MFMA_TFLOPS,
+                                          "source": "scripts/probes/mfma16_power_probe.hip: the same instruction pattern (4 chains x 4 "
+                                                    "k-steps + min3 epilogue, 2 waves per SIMD) with operands in registers; the chip "
+                                                    "runs 1.8-1.9 GHz under it, the matrix pipe is 74 % busy "
+                                                    "(profiles/r02_mfma16_power_probe.json)"},
                     "equivalent_allpairs_flops_per_step": allpairs,
                     "equivalent_allpairs_TFLOPs": allpairs / (launch_ms * per_step * 1e-3) / 1e12,
                     "executed_k_columns": kdim, "second_range_groups": stats["second_range_groups"],
