@@ -224,3 +224,42 @@ def test_reference_api_follows_every_kind_of_write_to_region_u(K):
         assert np.array_equal(got, fresh()), "step %d" % step
     region.ellipsoid_center = np.asarray(region.u).mean(axis=0)
     assert np.array_equal(region.inside(pts), fresh())
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_interleaved_row_updates_and_calls_of_every_size(seed, K):
+    """live points replaced one at a time (mlf_region_update_point: the pre-filter operands are requantised lazily)
+    between membership calls of every size class -- single launch, exact scan, pre-filter with tile ranges, phased
+    pre-filter -- must always agree with a region set up from scratch on the same live points"""
+    rs = np.random.RandomState(900 + seed)
+    d = int(rs.choice([2, 5, 9, 16, 33, 50]))
+    n = int(rs.randint(300, 2500))
+    u = inputs.live_points(seed + 70, n, d)
+    ctr = u.mean(axis=0)
+    cov = np.atleast_2d(np.cov(u, rowvar=0)) * (d + 2)
+    ev, evec = np.linalg.eigh(cov)
+    T = evec * ev ** -0.5
+    inv = np.linalg.inv(cov)
+    tl = (u - ctr) @ T
+    dd = ((tl[:150, None, :] - tl[None, :150, :]) ** 2).sum(axis=2)
+    np.fill_diagonal(dd, np.inf)
+    r2 = float(np.sort(dd.min(axis=1))[100])
+    enlarge = float(d) * 1.5
+    reg = K.DeviceRegion()
+    reg.set(u, 0, ctr, T, None, ctr, inv, enlarge, r2, live_space=1)
+    cur = u.copy()
+    sizes = [1, 7, 200, 256, 257, 1000, 3000, 40000]
+    for step in range(8):
+        for _ in range(int(rs.randint(1, 4))):
+            row = int(rs.randint(n))
+            cur[row] = np.clip(cur[int(rs.randint(n))] + 0.02 * rs.normal(size=d), 1e-6, 1 - 1e-6)
+            reg.update_point(row, cur[row])
+        p = sizes[(step + seed) % len(sizes)]
+        pts = inputs.proposal_mix(seed * 31 + step, cur, p, shell_q=2.0)
+        got = reg.inside(pts)
+        fresh = K.DeviceRegion()
+        fresh.set(cur, 0, ctr, T, None, ctr, inv, enlarge, r2, live_space=1)
+        want = fresh.inside(pts)
+        fresh.close()
+        assert np.array_equal(got, want), (d, n, p, step, np.flatnonzero(got != want)[:5])
+    reg.close()
