@@ -33,16 +33,29 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   __shared__ int any_active;
-  if (EXTRA && a.fin_best && blockIdx.x >= a.fin_grid0) {   // tail: answers of the filtered queries
-    const long long p = ((long long)blockIdx.x - a.fin_grid0) * kScanThreads + tid;
-    if (p == 0 && a.fin_reset) *a.fin_reset = 0u;
-    if (p >= a.nq) return;
-    const int rt = a.route[p];
-    if (rt == 2 || (rt == 1 && a.counters[1] != 0u)) return;   // written by the scanning workgroups
-    const int b = a.fin_best[p];
-    const bool found = rt == 1 && b != kNone;
-    if (a.out_mask) a.out_mask[p] = found ? 1 : 0;
-    if (a.out_idx) a.out_idx[p] = rt == 0 ? -2ll : (found ? (long long)b : -1ll);
+  if (EXTRA && a.fin_best && blockIdx.x >= a.fin_grid0) {   // tail: answers of the filtered queries, 4 per thread
+    const long long p0 = (((long long)blockIdx.x - a.fin_grid0) * kScanThreads + tid) * 4;
+    if (p0 == 0 && a.fin_reset) *a.fin_reset = 0u;
+    if (p0 >= a.nq) return;
+    const bool overflowed = a.counters[1] != 0u;
+    int rt[4], b[4];
+    if (p0 + 3 < a.nq) {   // the arrays are allocation-aligned and p0 is a multiple of 4: one vector load each
+      const uchar4 r4 = *reinterpret_cast<const uchar4 *>(a.route + p0);
+      const int4 b4 = *reinterpret_cast<const int4 *>(a.fin_best + p0);
+      rt[0] = r4.x, rt[1] = r4.y, rt[2] = r4.z, rt[3] = r4.w;
+      b[0] = b4.x, b[1] = b4.y, b[2] = b4.z, b[3] = b4.w;
+    } else {
+      for (int j = 0; j < 4; ++j) {
+        rt[j] = p0 + j < a.nq ? a.route[p0 + j] : 2;   // past the end: "not mine"
+        b[j] = p0 + j < a.nq ? a.fin_best[p0 + j] : kNone;
+      }
+    }
+    for (int j = 0; j < 4; ++j) {
+      if (rt[j] == 2 || (rt[j] == 1 && overflowed)) continue;   // written by the scanning workgroups
+      const bool found = rt[j] == 1 && b[j] != kNone;
+      if (a.out_mask) a.out_mask[p0 + j] = found ? 1 : 0;
+      if (a.out_idx) a.out_idx[p0 + j] = rt[j] == 0 ? -2ll : (found ? (long long)b[j] : -1ll);
+    }
     return;
   }
   const unsigned scan_blocks = (EXTRA && a.fin_best) ? a.fin_grid0 : gridDim.x;
@@ -182,10 +195,10 @@ hipError_t launch_scan(int dp, const ScanArgs &a_in, hipStream_t s) {
   const bool small = a.nq <= 16384;
   const int qb = small ? 16 : kScanQB;
   unsigned grid = (unsigned)((a.nq + qb - 1) / qb);
-  if (a.only_gated && grid > 2048u) grid = 2048u;   // mostly idle: keep the dispatch short
+  if (a.only_gated && grid > 512u) grid = 512u;   // mostly idle: keep the dispatch short (the workgroups stride over the query blocks)
   if (a.fin_best) {
     a.fin_grid0 = grid;
-    grid += (unsigned)((a.nq + kScanThreads - 1) / kScanThreads);
+    grid += (unsigned)((a.nq + 4 * kScanThreads - 1) / (4 * kScanThreads));
   }
   const bool extra = a.fin_best || a.route || a.any_flag || a.raw_ctr;
 
