@@ -325,6 +325,9 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   }
   const bool fused = nphase > 1 && g_filter_fused_compact;
   fa.split = nphase == 1 ? filter_tile_split(f.ks, ngroups, f.ntiles32) : 1;
+  // two ranges, compaction inside the first, finalise tail in the scan launch: nobody pads the compacted set or publishes
+  // its group count (k_phase_finish: a 5 us launch) -- the second range reads the slot counter itself, the tail resets it
+  const bool fold_finish = fused && nphase == 2 && xs != nullptr;
 
   for (int ph = 0; ph < nphase; ++ph) {
     fa.tile0 = (int)((long long)f.ntiles32 * ph / nphase);
@@ -347,6 +350,10 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       fa.thi = f.pthi[src].as<float>();
       fa.qmap = f.pmap[src].as<int>();
       fa.ngroups_dev = f.png.as<unsigned>() + src;
+      if (fold_finish) {
+        fa.ngroups_dev = nullptr;
+        fa.nslots_dev = f.png.as<unsigned>() + 2;
+      }
     }
     if (fused && ph + 1 < nphase) {   // ... and this one compacts into set ph & 1
       const int dst = ph & 1;
@@ -401,7 +408,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       CK(hipEventRecord(f.kev[f.kev_used + 1], s));
       f.kev_used += 2;
     }
-    if (fa.cq) {
+    if (fa.cq && !fold_finish) {
       const int dst = ph & 1;
       launch_phase_finish(fa.cq, fa.ctlo, fa.cthi, fa.cmap, fa.ccount, f.png.as<unsigned>() + dst, f.ks, s);
       CK(hipGetLastError());
@@ -489,6 +496,10 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       a.fin_best = f.best.as<int>();
       a.any_flag = f.misc.as<unsigned>() + 2 + f.batch_parity;
       a.fin_reset = f.misc.as<unsigned>() + 2 + (f.batch_parity ^ 1u);
+      if (fold_finish) {
+        a.fin_slots = f.png.as<unsigned>() + 2;
+        a.fin_groups = f.png.as<unsigned>();   // where k_phase_finish would have left the group count (debug_stats)
+      }
     }
     CK(launch_scan(dp, a, s));
   }

@@ -77,6 +77,8 @@ struct ScanArgs {
   const int *fin_best;            // nullptr = no tail
   unsigned fin_grid0;             // first workgroup of the tail (filled in by the launcher)
   unsigned *fin_reset;            // optional word zeroed by the tail
+  unsigned *fin_slots;            // optional: slot counter of the fused compaction -- *fin_groups = ceil(it / 32), then zeroed
+  unsigned *fin_groups;
   long long *out_idx;             // SCAN_FIRST / SCAN_COUNT
   unsigned long long *out_flags;  // SCAN_FLAGS  [nq][ntiles]
   uint8_t *out_mask;              // SCAN_MASK

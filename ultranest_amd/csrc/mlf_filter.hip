@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long g0 = wave * QW;  // first query group of this wave
-  const long long ngroups = a.ngroups_dev ? (long long)*a.ngroups_dev : a.ngroups;
+  const long long nslots = a.nslots_dev ? (long long)*a.nslots_dev : -1;
+  const long long ngroups = nslots >= 0 ? (nslots + 31) / 32 : (a.ngroups_dev ? (long long)*a.ngroups_dev : a.ngroups);
   // gridDim.y > 1 (batches too small to fill the chip with one wave per 4 query groups; never a compacting launch): the
   // live-point tiles are split into gridDim.y ranges, one wave per (query groups, range), each with its own list segment
   const int sub = COMPACT ? 0 : (int)blockIdx.y, nsub = COMPACT ? 1 : (int)gridDim.y;
@@ -258,8 +259,9 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) bq[g][s] = qF[((size_t)grp * KS + s) * 64 + lane];
     const long long qi = grp * 32 + (lane & 31);
-    tlo[g] = (g0 + g < ngroups) ? a.tlo[qi] : -1.0f;
-    thi[g] = (g0 + g < ngroups) ? a.thi[qi] : -1.0f;
+    const bool have = g0 + g < ngroups && (nslots < 0 || qi < nslots);   // an unpadded last group: slots past the count are dead
+    tlo[g] = have ? a.tlo[qi] : -1.0f;
+    thi[g] = have ? a.thi[qi] : -1.0f;
     first[g] = kNone;
   }
   const int rowbase = 4 * (lane >> 5);

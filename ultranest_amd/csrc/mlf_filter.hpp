@@ -23,6 +23,9 @@ struct FilterArgs {
   int tile0, tile1;
   const int *qmap;
   const unsigned *ngroups_dev;
+  // or: nslots_dev = number of SLOTS of the compacted set, straight from the compacting launch's counter (the last group
+  // may be partly filled: slots past the count are ignored; nobody has padded it)
+  const unsigned *nslots_dev;
   int append;                 // 1: keep the list entries of the earlier phases (cursor starts at seg_count)
   // fused compaction (non-final phase): every wave appends its still undecided queries (route 1, no certain
   // hit) to a fresh fragment set straight from its registers; slots come from one atomic per wave on *ccount,

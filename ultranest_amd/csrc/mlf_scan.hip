@@ -36,6 +36,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
   if (EXTRA && a.fin_best && blockIdx.x >= a.fin_grid0) {   // tail: answers of the filtered queries, 4 per thread
     const long long p0 = (((long long)blockIdx.x - a.fin_grid0) * kScanThreads + tid) * 4;
     if (p0 == 0 && a.fin_reset) *a.fin_reset = 0u;
+    if (p0 == 0 && a.fin_slots) {   // every filter launch of the batch is over: the compaction counter goes back to zero
+      *a.fin_groups = (*a.fin_slots + 31u) / 32u;
+      *a.fin_slots = 0u;
+    }
     if (p0 >= a.nq) return;
     const bool overflowed = a.counters[1] != 0u;
     int rt[4], b[4];
