@@ -328,6 +328,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   // two ranges, compaction inside the first, finalise tail in the scan launch: nobody pads the compacted set or publishes
   // its group count (k_phase_finish: a 5 us launch) -- the second range reads the slot counter itself, the tail resets it
   const bool fold_finish = fused && nphase == 2 && xs != nullptr;
+  if (getenv("MLF_DEBUG_RESET") && fold_finish) CK(hipMemsetAsync(f.png.as<unsigned>() + 2, 0, sizeof(unsigned), s));
 
   for (int ph = 0; ph < nphase; ++ph) {
     fa.tile0 = (int)((long long)f.ntiles32 * ph / nphase);

@@ -259,9 +259,16 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) bq[g][s] = qF[((size_t)grp * KS + s) * 64 + lane];
     const long long qi = grp * 32 + (lane & 31);
-    const bool have = g0 + g < ngroups && (nslots < 0 || qi < nslots);   // an unpadded last group: slots past the count are dead
+    // an unpadded last group: the slots past the count hold whatever an earlier batch left there.  Thresholds -1 alone do
+    // not silence them (stale operands can give Dt <= -1, a "certain hit" reported to a stale query number): their
+    // operand is zeroed as well, so Dt = 0 exactly as in a padded group
+    const bool have = g0 + g < ngroups && (nslots < 0 || qi < nslots);
     tlo[g] = have ? a.tlo[qi] : -1.0f;
     thi[g] = have ? a.thi[qi] : -1.0f;
+    if (nslots >= 0 && !have) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) bq[g][s] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
     first[g] = kNone;
   }
   const int rowbase = 4 * (lane >> 5);
