@@ -32,11 +32,19 @@ def test_shard_bounds_cover_exactly():
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+    """rendezvous token for the spawned ranks: a fresh temporary FILE (file:// store) -- a port found free here could be
+    taken by the time the ranks bind it (seen once in a few hundred runs: EADDRINUSE)"""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="mlf_rdzv_")
+    os.close(fd)
+    os.unlink(path)          # the store creates it
+    return path
+
+
+def _init(dist, backend, token, rank, world_size, **kw):
+    if backend == "gloo":
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # the container's hostname may not resolve
+    dist.init_process_group(backend, init_method="file://" + token, rank=rank, world_size=world_size, **kw)
 
 
 def _worker(rank, world_size, port, singular, out):
@@ -52,9 +60,7 @@ def _worker(rank, world_size, port, singular, out):
         if hasattr(M, name):
             setattr(M, name, getattr(oracle_backend, name))
     from ultranest_amd import distributed
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    _init(dist, "gloo", port, rank, world_size)
     try:
         u = inputs.live_points(31, 300, 4)
         if singular:
@@ -109,9 +115,7 @@ def _gpu_worker(rank, world_size, port, out):
     import torch.distributed as dist
     import ultranest_amd.mlfriends as M
     from ultranest_amd import distributed
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    _init(dist, "gloo", port, rank, world_size)
     try:
         u = inputs.live_points(31, 1500, 12)
         layer = M.AffineLayer()
@@ -146,11 +150,9 @@ def _rccl_worker(rank, world_size, port, out):
     import torch.distributed as dist
     import ultranest_amd.mlfriends as M
     from ultranest_amd import distributed
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     os.environ["MLF_FORCE_COLLECTIVES"] = "1"
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", 0))
+    _init(dist, "nccl", port, rank, world_size, device_id=torch.device("cuda", 0))
     try:
         u = inputs.live_points(31, 1500, 12)
         layer = M.AffineLayer()
@@ -197,9 +199,7 @@ def _one_rank_fails_worker(rank, world_size, port, out):
             setattr(M, name, getattr(oracle_backend, name))
     from ultranest_amd import distributed
     from ultranest_amd.harness import RegionUpdater
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    _init(dist, "gloo", port, rank, world_size)
     try:
         u = inputs.live_points(31, 300, 4)
         layer = M.AffineLayer()
@@ -316,11 +316,9 @@ def _rccl_two_rank_worker(rank, world_size, port, out):
     import torch.distributed as dist
     import ultranest_amd.mlfriends as M
     from ultranest_amd import _lib, distributed
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(rank)
     _lib.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", rank))
+    _init(dist, "nccl", port, rank, world_size, device_id=torch.device("cuda", rank))
     try:
         u = inputs.live_points(31, 1500, 12)
         layer = M.AffineLayer()
