@@ -347,3 +347,36 @@ def test_sharded_bootstrap_two_ranks_over_rccl():
     out = mgr.dict()
     mp.spawn(_rccl_two_rank_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert tuple(out[0]) == tuple(out[1]) == tuple(want), (dict(out), want)
+
+
+def _gather_worker(rank, world_size, port, out):
+    sys.path.insert(0, os.path.dirname(__file__))
+    import torch.distributed as dist
+    from ultranest_amd import distributed
+    _init(dist, "gloo", port, rank, world_size)
+    rs = np.random.RandomState(10 + rank)
+    k = [3, 0, 5][rank]                                   # rank 1 accepted nothing in this round
+    u, v, logl = rs.uniform(size=(k, 4)), rs.normal(size=(k, 6)), rs.normal(size=k)
+    su, sv, sl, nc = distributed.allgather_samples(u, v, logl, 100 + rank)
+    out.put((rank, su, sv, sl, nc, u, v, logl))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allgather_samples_uneven_ranks():
+    """reference integrator.py:1916-1928: rank-ordered concatenation of what every rank accepted, summed call counts"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    mp.spawn(_gather_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    res = sorted((out.get() for _ in range(3)), key=lambda t: t[0])
+    want_u = np.concatenate([r[5] for r in res])
+    want_v = np.concatenate([r[6] for r in res])
+    want_l = np.concatenate([r[7] for r in res])
+    for rank, su, sv, sl, nc, *_ in res:
+        assert nc == 100 + 101 + 102
+        assert np.array_equal(su, want_u) and np.array_equal(sv, want_v) and np.array_equal(sl, want_l)
+    # one process: passthrough
+    from ultranest_amd import distributed
+    u, v, l_, nc = distributed.allgather_samples(np.ones((2, 3)), np.zeros((2, 1)), [1.0, 2.0], 7)
+    assert u.shape == (2, 3) and v.shape == (2, 1) and list(l_) == [1.0, 2.0] and nc == 7

@@ -148,3 +148,37 @@ def update_region_bootstrap(region, nbootstraps, minvol=0., group=None, rng=np.r
     region.maxradiussq = r
     region.enlarge = f
     return r, f
+
+
+def allgather_samples(u, v, logl, ncall, group=None):
+    """Every rank contributes the points it accepted in this round -- `u` (k, x_dim), `v` (k, num_params), `logl`
+    (k,), k may differ from rank to rank and may be 0 -- and its number of likelihood calls; every rank gets the
+    rank-ordered concatenation and the summed call count.  Counterpart of the reference's gather + bcast of pickled
+    arrays (integrator.py:1916-1928), as two collectives on one padded tensor: an all-gather of the row counts and
+    an all-gather of the rows."""
+    u = np.atleast_2d(np.asarray(u, dtype=np.float64))
+    v = np.atleast_2d(np.asarray(v, dtype=np.float64))
+    logl = np.asarray(logl, dtype=np.float64).reshape(-1)
+    if not (len(u) == len(v) == len(logl)):
+        raise ValueError("u, v and logl must have one row per accepted point")
+    rank, size = world(group)
+    if size == 1 and not (_forced() and _initialised()):
+        return u, v, logl, int(ncall)
+    import torch
+    dist = _dist()
+    dev = _tensor_device(group)
+    xdim, npar = u.shape[1], v.shape[1]
+    mine = torch.tensor([len(u), int(ncall)], dtype=torch.int64, device=dev)
+    heads = [torch.empty_like(mine) for _ in range(size)]
+    dist.all_gather(heads, mine, group=group)
+    counts = [int(h[0].item()) for h in heads]
+    total_calls = sum(int(h[1].item()) for h in heads)
+    width = xdim + npar + 1
+    rows = max(max(counts), 1)
+    pack = torch.zeros((rows, width), dtype=torch.float64, device=dev)
+    if len(u):
+        pack[:len(u)] = torch.from_numpy(np.concatenate((u, v, logl[:, None]), axis=1)).to(dev)
+    parts = [torch.empty_like(pack) for _ in range(size)]
+    dist.all_gather(parts, pack, group=group)
+    merged = torch.cat([p[:k] for p, k in zip(parts, counts)], dim=0).cpu().numpy()
+    return merged[:, :xdim], merged[:, xdim:xdim + npar], merged[:, -1], total_calls
