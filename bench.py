@@ -433,7 +433,7 @@ def main():
                    "mfma_prefilter": bool(filter_on),
                    "arithmetic": "inputs, thresholds and every decision that depends on the reference's rounding: binary64 "
                                  "(non-fused); deciding bounds for the other 99.99 % of the pairs: binary16 operands / "
-                                 "binary32 accumulate on the matrix cores, binary32 bounded whitening; masks bit-identical "
+                                 "binary32 accumulate on the matrix cores, bounded whitening with split binary16 operands; masks bit-identical "
                                  "to the exact FP64 scan (asserted in this run)"},
         "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
         "rebuild_ms": rebuild_ms, "rebuild_first_ms": first_ms, "rebuild_ms_each": rebuild_all,

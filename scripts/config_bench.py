@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Numbers for the BASELINE.json configurations other than the headline (GPU box): proposal sets
 E (inside the wrapping ellipsoid), U (uniform cube: ellipsoid test only), F (no neighbour within
-reach: full scan) through MLFriends.inside, region rebuild, bootstrap sharding unit, likelihood
+reach, radius below the pre-filter's range: exact full scan), N (radius / sqrt(5): almost no neighbour, pre-filter) through MLFriends.inside, region rebuild, bootstrap sharding unit, likelihood
 kernels.  One JSON object on stdout; scripts/collect_profiles.py stores it under profiles/."""
 import json
 import os
@@ -58,7 +58,10 @@ for name, n, d, p in (("C2", 2000, 20, 100000), ("C5", 4000, 50, 1000000), ("C1-
     E = (torch.as_tensor(region.ellipsoid_center, device=dev) + z @ torch.as_tensor(region.ellipsoid_axes_T.copy(), device=dev)).contiguous()
     U = torch.rand(p, d, dtype=torch.float64, device=dev, generator=g)
     res = {"bootstrap30_ms": boot_ms}
-    for label, pts, r2 in (("E", E, region.maxradiussq), ("U", U, region.maxradiussq), ("F", E, 1e-300)):
+    # N: (almost) no proposal has a neighbour, but the radius is in the pre-filter's range: every query sweeps all live
+    # points through the matrix cores and leaves undecided -- the realistic "full scan" (F falls back to the exact kernel)
+    for label, pts, r2 in (("E", E, region.maxradiussq), ("U", U, region.maxradiussq), ("F", E, 1e-300),
+                           ("N", E, region.maxradiussq * 0.2)):
         handle.set_thresholds(region.enlarge, r2)
         rate, acc = timed_inside(handle, pts)
         res[label] = {"proposals_per_s": rate, "accept": acc}
