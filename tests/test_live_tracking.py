@@ -56,6 +56,11 @@ def test_every_in_place_write_is_counted_and_reads_are_not():
         lambda: u.sort(axis=0),
         lambda: u.T.__setitem__(0, 0.2),
         lambda: u.reshape(-1).__setitem__(7, 0.9),
+        lambda: u.flat.__setitem__(11, 0.6),                 # the raw handles count when they are asked for
+        lambda: setattr(u, "flat", 0.35),
+        lambda: u[2:4].flat.__setitem__(0, 0.65),
+        lambda: u.ctypes.data,
+        lambda: u.data,
     ]
     for i, w in enumerate(writes):
         before = _gen(h)

@@ -154,8 +154,8 @@ class _LiveArray(np.ndarray):
     The array owns its memory (``region.u = x`` copies x), so the only ways to write into it are through
     this object and its views, which all share one counter cell:  __setitem__, ufunc ``out=`` (hence
     ``+=`` and friends), the in-place methods, and numpy's in-place functions (np.copyto ...).  What the
-    counter cannot see -- writes through ``np.asarray(region.u)`` / ``region.u.view(np.ndarray)``, raw
-    buffers -- needs ``region.invalidate_device_state()``; nothing in the reference does that."""
+    counter cannot see -- writes through ``np.asarray(region.u)`` / ``region.u.view(np.ndarray)`` or a
+    ``memoryview`` (``.flat``, ``.ctypes`` and ``.data`` count as a write when they are asked for) -- needs ``region.invalidate_device_state()``; nothing in the reference does that."""
 
     def __array_finalize__(self, obj):
         self._cell = getattr(obj, "_cell", None)
@@ -219,6 +219,25 @@ def _in_place_method(name):
 for _name in ("fill", "sort", "partition", "put", "itemset", "setfield", "byteswap", "resize"):
     if hasattr(np.ndarray, _name):
         setattr(_LiveArray, _name, _in_place_method(_name))
+
+
+def _raw_handle(name):
+    """``flat``, ``ctypes`` and ``data`` hand out something that writes without passing through the array
+    object: asking for one of them counts as a write (a whole-array diff at the next device call)."""
+    base = getattr(np.ndarray, name)
+
+    def getter(self):
+        self._touch()
+        return base.__get__(self, type(self))
+
+    def setter(self, value):   # only ``flat`` has one (a.flat = x assigns through it)
+        self._touch()
+        base.__set__(self, value)
+    return property(getter, setter, doc=base.__doc__)
+
+
+for _name in ("flat", "ctypes", "data"):
+    setattr(_LiveArray, _name, _raw_handle(_name))
 
 
 class _LivePoints(object):
