@@ -301,6 +301,11 @@ int mlf_counter_state(const mlf_counter *c, double *scalars, double *all_H, doub
 int mlf_host_changed_rows(const double *a, const double *b, size_t n, size_t d, int64_t *rows,
                           size_t capacity, size_t *count);
 
+/* host helper (no GPU): (nrounds, npoints) bootstrap selection masks from numpy's legacy MT19937 stream, the
+ * same draws as nrounds calls of np.random.randint(npoints, size=npoints) (reference mlfriends.pyx:1044-1047,
+ * :565-566); key[624] / pos = np.random.get_state()[1:3], advanced in place */
+int mlf_host_draw_selection(uint32_t *key, int32_t *pos, size_t npoints, size_t nrounds, uint8_t *masks);
+
 /* H3 -> T1 -> K1 with the index kept: d_idx[p] = first live point within radiussq (>= 0),
  * -1 = inside the ellipsoid but no neighbour, -2 = outside the wrapping ellipsoid. */
 int mlf_region_first_index_dev(mlf_region *r, const double *d_pts, size_t np, int64_t *d_idx,

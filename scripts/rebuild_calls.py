@@ -49,3 +49,29 @@ for name, a, b in log:
     prev = b
 print("%8.3f ms host (tail)" % ((t_end - prev) * 1e3))
 print("total %.3f ms, in C calls %.3f ms" % ((t_end - t_start) * 1e3, sum(b - a for _, a, b in log) * 1e3))
+
+# the same rebuild under cProfile, averaged over several rounds: which host functions the gaps consist of
+import cProfile  # noqa: E402
+import io  # noqa: E402
+import pstats  # noqa: E402
+
+_lib._lib = real
+ROUNDS = 20
+inputs = []
+for rep in range(ROUNDS):
+    v = u.copy()
+    v[:bench.N_LIVE // 10] = 0.5 + 0.045 * rs.normal(size=(bench.N_LIVE // 10, bench.NDIM))
+    inputs.append(v)
+pr = cProfile.Profile()
+t0 = time.perf_counter()
+pr.enable()
+for v in inputs:
+    upd.update(v, nbootstraps=bench.NBOOT, minvol=0.)
+pr.disable()
+print("under cProfile: %.3f ms per rebuild" % ((time.perf_counter() - t0) / ROUNDS * 1e3))
+out = io.StringIO()
+st = pstats.Stats(pr, stream=out)
+rows = sorted(st.stats.items(), key=lambda kv: -kv[1][2])[:32]
+for (fname, line, func), (cc, nc, tt, ct, _) in rows:
+    print("%7.3f ms self %7.3f ms cum %5.1f calls  %s:%d %s" % (tt / ROUNDS * 1e3, ct / ROUNDS * 1e3, nc / ROUNDS,
+                                                            os.path.basename(fname), line, func))

@@ -88,6 +88,7 @@ SIGNATURES = {
                                _vp, _vp],
     "mlf_walkers_export": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlf_host_changed_rows": [_vp, _vp, _sz, _sz, _vp, _sz, _vp],
+    "mlf_host_draw_selection": [_vp, _vp, _sz, _sz, _vp],
     "mlf_counter_create": [_vp, _sz, _sz, _vp, _int, _int],
     "mlf_counter_destroy": [_vp],
     "mlf_counter_reset": [_vp],
@@ -196,6 +197,24 @@ def set_device(i):
 def set_option(name, value):
     """Tuning switch of the library (e.g. set_option("filter", 0) forces the exact scan only)."""
     check(lib().mlf_set_option(name.encode(), int(value)))
+
+
+def draw_selection(rng, npoints, nbootstraps):
+    """(B, N) boolean selection masks from a legacy MT19937 stream (``np.random`` or a RandomState): what B
+    calls of ``rng.randint(N, size=N)`` select, with the generator left where those calls leave it.  None if
+    `rng` is not such a generator."""
+    try:
+        state = rng.get_state()
+    except (AttributeError, TypeError):
+        return None
+    if not isinstance(state, tuple) or state[0] != "MT19937" or not 0 < npoints <= 1 << 31:
+        return None
+    key = np.array(state[1], dtype=np.uint32)
+    pos = ctypes.c_int32(int(state[2]))
+    masks = np.empty((nbootstraps, npoints), dtype=bool)
+    check(lib().mlf_host_draw_selection(key.ctypes.data, ctypes.byref(pos), npoints, nbootstraps, masks.ctypes.data))
+    rng.set_state((state[0], key, pos.value) + tuple(state[3:]))
+    return masks
 
 
 def changed_rows(a, b, capacity=64):

@@ -244,6 +244,58 @@ int mlf_host_changed_rows(const double *a, const double *b, size_t n, size_t d, 
   return 0;
 }
 
+// Host helper of the bootstrap (regions._draw_selection): the selection masks of `nrounds` rounds, drawn from
+// numpy's legacy MT19937 stream exactly as `nrounds` calls of np.random.randint(npoints, size=npoints) draw them
+// (reference mlfriends.pyx:1044-1047): 32-bit words, masked with the smallest 2^k - 1 >= npoints - 1, values above
+// npoints - 1 rejected.  `key`/`pos` are the generator state (np.random.get_state()[1:3]) and are advanced in place.
+// 120000 draws cost numpy 1.2 ms of a 6 ms region rebuild.
+namespace {
+inline void mt19937_refill(uint32_t *key) {
+  constexpr int kN = 624, kM = 397;
+  auto twist = [](uint32_t hi, uint32_t lo) {
+    const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  };
+  int i = 0;
+  for (; i < kN - kM; ++i) key[i] = key[i + kM] ^ twist(key[i], key[i + 1]);
+  for (; i < kN - 1; ++i) key[i] = key[i + (kM - kN)] ^ twist(key[i], key[i + 1]);
+  key[kN - 1] = key[kM - 1] ^ twist(key[kN - 1], key[0]);
+}
+}  // namespace
+
+int mlf_host_draw_selection(uint32_t *key, int32_t *pos, size_t npoints, size_t nrounds, uint8_t *masks) {
+  if (!key || !pos || (npoints && nrounds && !masks)) return mlf::ctx_fail_arg(MLF_E_BADARG, "null pointer");
+  if (npoints == 0 || npoints > 0x80000000ull || *pos < 0 || *pos > 624)
+    return mlf::ctx_fail_arg(MLF_E_BADARG, "npoints or generator position out of range");
+  memset(masks, 0, npoints * nrounds);
+  if (npoints == 1) {   // numpy fills the zeros without drawing
+    memset(masks, 1, nrounds);
+    return 0;
+  }
+  const uint32_t top = (uint32_t)(npoints - 1);
+  uint32_t mask = top;
+  mask |= mask >> 1, mask |= mask >> 2, mask |= mask >> 4, mask |= mask >> 8, mask |= mask >> 16;
+  int p = *pos;
+  for (size_t b = 0; b < nrounds; ++b) {
+    uint8_t *row = masks + b * npoints;
+    for (size_t i = 0; i < npoints; ++i) {
+      uint32_t v;
+      do {
+        if (p == 624) mt19937_refill(key), p = 0;
+        uint32_t y = key[p++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        v = y & mask;
+      } while (v > top);
+      row[v] = 1;
+    }
+  }
+  *pos = p;
+  return 0;
+}
+
 int mlf_counter_state(const mlf_counter *c, double *scalars, double *all_H, double *all_logZ, double *all_logVolremaining,
                       double *all_logZremain, int64_t *runs, size_t runs_capacity, size_t *nruns) {
   if (!c || !scalars) return mlf::ctx_fail_arg(MLF_E_BADARG, "null pointer");

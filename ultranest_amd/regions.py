@@ -91,6 +91,9 @@ def _inside_ellipsoid(points, ellipsoid_center, ellipsoid_invcov, square_radius)
 def _draw_selection(rng, npoints, nbootstraps):
     """(B, N) bootstrap selection masks; ONE ``rng.randint(N, size=N)`` per round, drawn before
     any validity check, exactly like the reference (mlfriends.pyx:1044-1047)."""
+    masks = _lib.draw_selection(rng, npoints, nbootstraps)   # numpy's MT19937 stream, compiled
+    if masks is not None:
+        return masks
     masks = np.zeros((nbootstraps, npoints), dtype=bool)
     for b in range(nbootstraps):
         masks[b, rng.randint(npoints, size=npoints)] = True
