@@ -136,6 +136,10 @@ int mlf_region_set(mlf_region *r, const double *live, size_t n, size_t d, int li
 /* in-place live point replacement, integrator.py:2753-2754; the row is in the space given by
  * live_space at mlf_region_set */
 int mlf_region_update_point(mlf_region *r, size_t row, const double *live_row);
+/* the same for `count` DISTINCT rows in one call (the driver replaces one live point per iteration and tests
+ * membership once per refill, integrator.py:1776-1804: every replaced row since the last test goes in one upload
+ * and two launches); live_rows = (count, d) row-major, the new contents of the live points rows[0..count) */
+int mlf_region_update_points(mlf_region *r, size_t count, const int64_t *rows, const double *live_rows);
 int mlf_region_set_thresholds(mlf_region *r, double enlarge, double radiussq);
 int mlf_region_set_ellipsoid_center(mlf_region *r, const double *ell_center);
 int mlf_region_inside(mlf_region *r, const double *pts, size_t np, uint8_t *mask);

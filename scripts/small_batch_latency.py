@@ -32,15 +32,29 @@ for label, (n, d) in [("C1", (400, 5)), ("C2", (2000, 20)), ("C5", (4000, 50))]:
             each.append(time.perf_counter() - t0)
         dt = float(np.mean(each))
         med = float(np.median(each))
-        # the driver's pattern: one live point replaced in place between calls (integrator.py:2749-2765)
-        t0 = time.perf_counter()
+        # the driver's pattern: one live point replaced in place between calls (integrator.py:2749-2765); medians,
+        # write included (a generation-2 pass of the cyclic collector inside the loop costs 37 ms once)
+        each = []
         for i in range(reps):
+            t0 = time.perf_counter()
             region.u[i % n] = np.clip(region.u[i % n] + 1e-9, 1e-6, 1 - 1e-6)
             region.unormed[i % n] = region.transformLayer.transform(region.u[i % n])
             m = region.inside(pts)
-        dt_upd = (time.perf_counter() - t0) / reps
+            each.append(time.perf_counter() - t0)
+        dt_upd = float(np.median(each))
+        # a refill's worth of iterations between two calls: 20 rows replaced, then one call
+        each = []
+        for i in range(reps // 4):
+            t0 = time.perf_counter()
+            for k in range(20):
+                j = (i * 20 + k) % n
+                region.u[j] = np.clip(region.u[j] + 1e-9, 1e-6, 1 - 1e-6)
+            m = region.inside(pts)
+            each.append(time.perf_counter() - t0)
+        dt_upd20 = float(np.median(each))
         out.append(dict(config=label, n_live=n, d=d, batch=p, us_per_call=dt * 1e6, us_per_call_median=med * 1e6,
-                        us_per_call_with_one_row_replaced=dt_upd * 1e6, accept=float(m.mean())))
+                        us_per_call_with_one_row_replaced=dt_upd * 1e6,
+                        us_per_call_with_20_rows_replaced=dt_upd20 * 1e6, accept=float(m.mean())))
         print(json.dumps(out[-1]), flush=True)
 if "--save" in sys.argv:
     os.makedirs("gpurun_out", exist_ok=True)

@@ -112,6 +112,11 @@ class DeviceRegion(object):
         DeviceRegion.n_row_updates += 1
         self.s["unormed"][row] = self._whiten(unormed_row)[0] if self.live_space else unormed_row
 
+    def update_points(self, rows, live_rows):
+        assert len(set(int(r) for r in rows)) == len(rows)
+        for row, value in zip(rows, np.asarray(live_rows, dtype=float)):
+            self.update_point(int(row), value)
+
     def inside(self, pts):
         s = self.s
         pts = np.ascontiguousarray(pts, dtype=float)

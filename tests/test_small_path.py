@@ -226,6 +226,61 @@ def test_reference_api_follows_every_kind_of_write_to_region_u(K):
     assert np.array_equal(region.inside(pts), fresh())
 
 
+@pytest.mark.parametrize("nrep", [1, 2, 9, 37, 38, 120])
+def test_many_replaced_rows_between_two_calls_go_in_one_update(nrep, K):
+    """the driver replaces one live point per iteration and tests membership once per refill (integrator.py:2753,
+    1776-1804): all rows written since the last call are re-sent together (mlf_region_update_points), above
+    n / 8 rows the whole set; either way the answers are those of a region built from scratch"""
+    import ultranest_amd.mlfriends as M
+    from ultranest_amd import kernels
+    rs = np.random.RandomState(40 + nrep)
+    n, d = 300, 7
+    u = 0.5 + 0.08 * rs.normal(size=(n, d))
+    layer = M.AffineLayer()
+    layer.optimize(u, u)
+    region = M.MLFriends(u, layer)
+    t = region.unormed
+    dd = ((t[:, None, :] - t[None, :, :]) ** 2).sum(axis=2)
+    np.fill_diagonal(dd, np.inf)
+    region.maxradiussq = float(np.sort(dd.min(axis=1))[int(0.8 * n)])
+    region.enlarge = 2.6
+    region.create_ellipsoid()
+    calls = {"set": 0, "rows": []}
+    real_set, real_rows = kernels.DeviceRegion.set, kernels.DeviceRegion.update_points
+
+    def counted_set(self, *a, **kw):
+        calls["set"] += 1
+        return real_set(self, *a, **kw)
+
+    def counted_rows(self, rows, live_rows):
+        calls["rows"].append(len(rows))
+        return real_rows(self, rows, live_rows)
+    kernels.DeviceRegion.set, kernels.DeviceRegion.update_points = counted_set, counted_rows
+    try:
+        for batch in (40, 700):      # single-launch path and the batched path
+            pts = np.clip(u[rs.randint(n, size=batch)] + 0.1 * rs.normal(size=(batch, d)), 1e-6, 1 - 1e-6)
+            region.inside(pts)
+            calls["set"], calls["rows"] = 0, []
+            rows = rs.choice(n, size=nrep, replace=False)
+            for i in rows:
+                region.u[i] = np.clip(region.u[rs.randint(n)] + 0.05 * rs.normal(size=d), 1e-6, 1 - 1e-6)
+            region.u[rows[0]] = np.clip(region.u[rows[0]] + 0.01, 1e-6, 1 - 1e-6)     # one row written twice
+            got = region.inside(pts)
+            if nrep <= max(8, n // 8):
+                assert calls["set"] == 0 and calls["rows"] == [nrep]
+            else:
+                assert calls["set"] == 1 and calls["rows"] == []
+            other = M.MLFriends(np.array(region.u), region.transformLayer)
+            other.maxradiussq, other.enlarge = region.maxradiussq, region.enlarge
+            other.ellipsoid_center, other.ellipsoid_invcov = region.ellipsoid_center, region.ellipsoid_invcov
+            kernels.DeviceRegion.set, kernels.DeviceRegion.update_points = real_set, real_rows
+            want = other.inside(pts)
+            kernels.DeviceRegion.set, kernels.DeviceRegion.update_points = counted_set, counted_rows
+            assert np.array_equal(got, want) and 0.02 < want.mean() < 0.98
+    finally:
+        kernels.DeviceRegion.set, kernels.DeviceRegion.update_points = real_set, real_rows
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_interleaved_row_updates_and_calls_of_every_size(seed, K):
     """live points replaced one at a time (mlf_region_update_point: the pre-filter operands are requantised lazily)
@@ -250,10 +305,15 @@ def test_interleaved_row_updates_and_calls_of_every_size(seed, K):
     cur = u.copy()
     sizes = [1, 7, 200, 256, 257, 1000, 3000, 40000]
     for step in range(8):
-        for _ in range(int(rs.randint(1, 4))):
-            row = int(rs.randint(n))
-            cur[row] = np.clip(cur[int(rs.randint(n))] + 0.02 * rs.normal(size=d), 1e-6, 1 - 1e-6)
-            reg.update_point(row, cur[row])
+        if step % 3 == 2:      # several rows in one call (mlf_region_update_points), sometimes many
+            rows = rs.choice(n, size=int(rs.choice([1, 2, 17, min(n, 300)])), replace=False)
+            cur[rows] = np.clip(cur[rs.randint(n, size=len(rows))] + 0.02 * rs.normal(size=(len(rows), d)), 1e-6, 1 - 1e-6)
+            reg.update_points(rows, cur[rows])
+        else:
+            for _ in range(int(rs.randint(1, 4))):
+                row = int(rs.randint(n))
+                cur[row] = np.clip(cur[int(rs.randint(n))] + 0.02 * rs.normal(size=d), 1e-6, 1 - 1e-6)
+                reg.update_point(row, cur[row])
         p = sizes[(step + seed) % len(sizes)]
         pts = inputs.proposal_mix(seed * 31 + step, cur, p, shell_q=2.0)
         got = reg.inside(pts)

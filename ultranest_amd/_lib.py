@@ -42,6 +42,7 @@ SIGNATURES = {
     "mlf_region_destroy": [_vp],
     "mlf_region_set": [_vp, _vp, _sz, _sz, _int, _int, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int],
     "mlf_region_update_point": [_vp, _sz, _vp],
+    "mlf_region_update_points": [_vp, _sz, _vp, _vp],
     "mlf_region_set_thresholds": [_vp, _dbl, _dbl],
     "mlf_region_set_ellipsoid_center": [_vp, _vp],
     "mlf_region_inside": [_vp, _vp, _sz, _vp],

@@ -1530,27 +1530,65 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
   return 0;
 }
 
-int mlf_region_update_point(mlf_region *r, size_t row, const double *unormed_row) {
-  if (!r || !unormed_row) return fail_arg(MLF_E_BADARG, "null pointer");
+// Pinned, device-mapped staging of the single-launch membership call (proposals in, mask and completion word out) and
+// of the row replacements: created on first use.
+constexpr size_t kSmallStagingBytes = (size_t)kSmallMaxPoints * kSmallMaxDim * sizeof(double);
+static int small_staging(Ctx &c) {
+  if (c.pin_pts) return 0;
+  CK(hipHostMalloc(reinterpret_cast<void **>(&c.pin_pts), kSmallStagingBytes, hipHostMallocMapped));
+  CK(hipHostMalloc(reinterpret_cast<void **>(&c.pin_mask), (size_t)kSmallMaxPoints + 64, hipHostMallocMapped));
+  memset(c.pin_mask, 0, (size_t)kSmallMaxPoints + 64);
+  CK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c.pin_pts_dev), c.pin_pts, 0));
+  CK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c.pin_mask_dev), c.pin_mask, 0));
+  CK(c.small_words.reserve(2 * kSmallMaxPoints * sizeof(unsigned)));
+  CK(hipMemsetAsync(c.small_words.p, 0, 2 * kSmallMaxPoints * sizeof(unsigned), c.stream));
+  return 0;
+}
+
+int mlf_region_update_points(mlf_region *r, size_t count, const int64_t *rows, const double *live_rows) {
+  if (!r || (count && (!rows || !live_rows))) return fail_arg(MLF_E_BADARG, "null pointer");
   if (!r->ready || !r->use_scan) return fail_arg(MLF_E_STATE, "region has no live points set");
-  if (row >= (size_t)r->n) return fail_arg(MLF_E_BADARG, "row out of range");
+  for (size_t k = 0; k < count; ++k)
+    if (rows[k] < 0 || rows[k] >= (int64_t)r->n) return fail_arg(MLF_E_BADARG, "row out of range");
+  if (count == 0) return 0;
   Ctx &c = g_ctx;
-  CK(r->row.reserve(2 * (size_t)r->d * sizeof(double)));
-  if (int rc = upload(r->row, unormed_row, r->d * sizeof(double), c.stream)) return rc;
-  const double *src = r->row.as<double>();
-  if (r->live_space) {
-    double *dst = r->row.as<double>() + r->d;
-    if (int rc = region_whiten_rows(r, src, 1, dst, c.stream)) return rc;
-    src = dst;
+  // one buffer: [count x d new rows | count x d whitened rows | count indices]
+  const size_t block = count * (size_t)r->d;
+  CK(r->row.reserve((2 * block + count) * sizeof(double)));
+  double *raw = r->row.as<double>(), *white = raw + block;
+  long long *index = reinterpret_cast<long long *>(raw + 2 * block);
+  const double *src = raw;
+  const long long *index_src = index;
+  if (int rc = small_staging(c)) return rc;
+  if ((block + count) * sizeof(double) <= kSmallStagingBytes) {
+    // the usual few rows: no copy on the stream, the kernels read the pinned staging buffer (free: a single-launch
+    // membership call has its mask back before it returns, and this call ends with a synchronisation)
+    memcpy(c.pin_pts, live_rows, block * sizeof(double));
+    memcpy(c.pin_pts + block, rows, count * sizeof(int64_t));
+    src = c.pin_pts_dev;
+    index_src = reinterpret_cast<const long long *>(c.pin_pts_dev + block);
+  } else {
+    CK(hipMemcpyAsync(raw, live_rows, block * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    CK(hipMemcpyAsync(index, rows, count * sizeof(int64_t), hipMemcpyHostToDevice, c.stream));
   }
-  launch_update_row(src, r->d, r->dp, r->npad, (int)row, r->refT.as<double>(),
-                    r->refR.as<double>(), c.stream);
+  if (r->live_space) {
+    if (int rc = region_whiten_rows(r, src, count, white, c.stream)) return rc;
+    src = white;
+  }
+  launch_update_rows(src, (int)count, r->d, r->dp, r->npad, index_src, r->refT.as<double>(), r->refR.as<double>(), c.stream);
   CK(hipGetLastError());
   // centre / scale / norms of the pre-filter operands depend on every row: requantised (four small kernels) by the next
   // batch that uses them -- the 1-10 point calls between two replacements (mlf_small.hip) never do
   if (r->filter.refs_ready) r->filter.refs_dirty = true;
   CK(hipStreamSynchronize(c.stream));
   return 0;
+}
+
+int mlf_region_update_point(mlf_region *r, size_t row, const double *unormed_row) {
+  if (!unormed_row) return fail_arg(MLF_E_BADARG, "null pointer");
+  const int64_t index = (int64_t)row;
+  if (r && row >= (size_t)r->n && r->ready && r->use_scan) return fail_arg(MLF_E_BADARG, "row out of range");
+  return mlf_region_update_points(r, 1, &index, unormed_row);
 }
 
 int mlf_region_set_thresholds(mlf_region *r, double enlarge, double radiussq) {
@@ -1579,16 +1617,7 @@ int mlf_region_set_ellipsoid_center(mlf_region *r, const double *ell_center) {
 // the mask comes back the same way.
 static int region_inside_small(mlf_region *r, const double *pts, size_t np, uint8_t *mask) {
   Ctx &c = g_ctx;
-  if (!c.pin_pts) {
-    CK(hipHostMalloc(reinterpret_cast<void **>(&c.pin_pts), (size_t)kSmallMaxPoints * kSmallMaxDim * sizeof(double),
-                     hipHostMallocMapped));
-    CK(hipHostMalloc(reinterpret_cast<void **>(&c.pin_mask), (size_t)kSmallMaxPoints + 64, hipHostMallocMapped));
-    memset(c.pin_mask, 0, (size_t)kSmallMaxPoints + 64);
-    CK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c.pin_pts_dev), c.pin_pts, 0));
-    CK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c.pin_mask_dev), c.pin_mask, 0));
-    CK(c.small_words.reserve(2 * kSmallMaxPoints * sizeof(unsigned)));
-    CK(hipMemsetAsync(c.small_words.p, 0, 2 * kSmallMaxPoints * sizeof(unsigned), c.stream));
-  }
+  if (int rc = small_staging(c)) return rc;
   memcpy(c.pin_pts, pts, np * (size_t)r->d * sizeof(double));
   SmallArgs a{};
   a.pts = c.pin_pts_dev;

@@ -31,18 +31,20 @@ void launch_build_layouts(const double *src, int n, int d, int dp, int npad, dou
                      d, dp, npad, refT, refR);
 }
 
-__global__ void k_update_row(const double *row, int d, int dp, int npad, int i, double *refT,
+__global__ void k_update_row(const double *rows, int d, int dp, int npad, const long long *index, double *refT,
                              double *refR) {
   const int k = threadIdx.x;
   if (k >= dp) return;
-  const double v = k < d ? row[k] : 0.0;
-  refR[(long long)i * dp + k] = v;
+  const long long i = index[blockIdx.x];
+  const double v = k < d ? rows[(long long)blockIdx.x * d + k] : 0.0;
+  refR[i * dp + k] = v;
   refT[(long long)k * npad + i] = v;
 }
 
-void launch_update_row(const double *row, int d, int dp, int npad, int i, double *refT,
-                       double *refR, hipStream_t s) {
-  hipLaunchKernelGGL(k_update_row, dim3(1), dim3(128), 0, s, row, d, dp, npad, i, refT, refR);
+// `count` whitened rows (count x d, packed) replace the live points index[0..count) in both layouts
+void launch_update_rows(const double *rows, int count, int d, int dp, int npad, const long long *index, double *refT,
+                        double *refR, hipStream_t s) {
+  hipLaunchKernelGGL(k_update_row, dim3((unsigned)count), dim3(128), 0, s, rows, d, dp, npad, index, refT, refR);
 }
 
 __global__ void k_fill_u64(unsigned long long *p, long long n, unsigned long long v) {

@@ -6,8 +6,8 @@ namespace mlf {
 
 void launch_build_layouts(const double *src, int n, int d, int dp, int npad, double *refT,
                           double *refR, hipStream_t s);
-void launch_update_row(const double *row, int d, int dp, int npad, int i, double *refT,
-                       double *refR, hipStream_t s);
+void launch_update_rows(const double *rows, int count, int d, int dp, int npad, const long long *index, double *refT,
+                        double *refR, hipStream_t s);
 void launch_fill_u64(unsigned long long *p, long long n, unsigned long long v, hipStream_t s);
 void launch_pack_selection(const uint8_t *selected, int n, int npad, int b0, int nb, unsigned *sel,
                            hipStream_t s);

@@ -233,6 +233,13 @@ class DeviceRegion(object):
     def update_point(self, row, unormed_row):
         check(_lib.lib().mlf_region_update_point(self._h, int(row), ptr(f64(unormed_row))))
 
+    def update_points(self, rows, live_rows):
+        """Replace the DISTINCT live points `rows` by the rows of `live_rows` in one call."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        live_rows = f64(live_rows)
+        assert live_rows.shape[0] == rows.shape[0]
+        check(_lib.lib().mlf_region_update_points(self._h, rows.shape[0], ptr(rows), ptr(live_rows)))
+
     def inside(self, pts):
         pts = f64(pts)
         mask = np.empty(pts.shape[0], dtype=np.uint8)

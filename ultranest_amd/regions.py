@@ -449,9 +449,11 @@ class _DeviceState(object):
             self.ell_center = np.array(region.ellipsoid_center, dtype=float)
             self.thresholds = thresholds
             return self.handle
-        for row in changed:
-            self.handle.update_point(row, region.u[row])
-            self.live[row] = region.u[row]
+        if len(changed):
+            rows = np.asarray(changed, dtype=np.int64)
+            fresh = np.asarray(region.u)[rows]
+            self.handle.update_points(rows, fresh)
+            self.live[rows] = fresh
         if not np.array_equal(self.ell_center, region.ellipsoid_center):
             self.handle.set_ellipsoid_center(region.ellipsoid_center)
             self.ell_center = np.array(region.ellipsoid_center, dtype=float)
