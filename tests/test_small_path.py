@@ -281,6 +281,42 @@ def test_many_replaced_rows_between_two_calls_go_in_one_update(nrep, K):
         kernels.DeviceRegion.set, kernels.DeviceRegion.update_points = real_set, real_rows
 
 
+def test_row_update_larger_than_the_pinned_staging_buffer(K):
+    """700 rows x 50 doubles do not fit the 256 KB staging buffer: plain copies on the stream instead; an empty
+    update is accepted and changes nothing"""
+    rs = np.random.RandomState(77)
+    n, d = 6000, 50
+    u = inputs.live_points(5, n, d)
+    ctr = u.mean(axis=0)
+    cov = np.cov(u, rowvar=0) * (d + 2)
+    ev, evec = np.linalg.eigh(cov)
+    T = evec * ev ** -0.5
+    inv = np.linalg.inv(cov)
+    tl = (u[:200] - ctr) @ T
+    dd = ((tl[:, None, :] - tl[None, :, :]) ** 2).sum(axis=2)
+    np.fill_diagonal(dd, np.inf)
+    r2 = float(np.median(dd.min(axis=1))) * 0.5
+    reg = K.DeviceRegion()
+    reg.set(u, 0, ctr, T, None, ctr, inv, 1.5 * d, r2, live_space=1)
+    cur = u.copy()
+    rows = rs.choice(n, size=700, replace=False)
+    cur[rows] = np.clip(cur[rs.randint(n, size=700)] + 0.02 * rs.normal(size=(700, d)), 1e-6, 1 - 1e-6)
+    reg.update_points(rows, cur[rows])
+    reg.update_points(np.zeros(0, dtype=np.int64), np.zeros((0, d)))
+    fresh = K.DeviceRegion()
+    fresh.set(cur, 0, ctr, T, None, ctr, inv, 1.5 * d, r2, live_space=1)
+    for p in (64, 5000):
+        pts = inputs.proposal_mix(3 + p, cur, p, shell_q=2.0)
+        got, want = reg.inside(pts), fresh.inside(pts)
+        assert np.array_equal(got, want) and want.any() and not want.all()
+    # the replaced rows themselves are members (distance exactly 0 to their own new position)
+    assert reg.inside(cur[rows[:50]]).all()
+    with pytest.raises(Exception):
+        reg.update_points(np.array([n]), cur[:1])
+    reg.close()
+    fresh.close()
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_interleaved_row_updates_and_calls_of_every_size(seed, K):
     """live points replaced one at a time (mlf_region_update_point: the pre-filter operands are requantised lazily)
