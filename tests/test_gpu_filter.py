@@ -2,8 +2,13 @@
 change speed, never a result bit.  Adversarial cases: radii that coincide exactly with a pair
 distance (and one ulp below), badly scaled / offset data, queries outside the binary16 range,
 uncertain-pair list overflow."""
+import os
+
 import numpy as np
 import pytest
+
+# soak runs: MLF_FUZZ_OFFSET=k shifts the seeds of the random-shape tests (the default run is offset 0)
+FUZZ_OFFSET = int(os.environ.get("MLF_FUZZ_OFFSET", "0"))
 
 pytestmark = pytest.mark.gpu
 
@@ -221,6 +226,7 @@ def test_region_inside_random_shapes_filter_equals_exact_scan(seed, K):
     binary64 per-proposal stage, pre-filter with one or several tile ranges, phases, exact scan -- the mask is the same"""
     import inputs
     from ultranest_amd import _lib
+    seed += FUZZ_OFFSET
     rs = np.random.RandomState(1000 + seed)
     d = int(rs.choice([1, 2, 3, 5, 7, 10, 13, 20, 31, 50, 63, 64]))
     n = int(rs.randint(max(d + 2, 40), 3000))
@@ -259,7 +265,7 @@ def test_region_inside_random_shapes_filter_equals_exact_scan(seed, K):
 def test_find_nearby_random_shapes_vs_oracle(seed, K, oracle):
     """first-hit indices (reference mlfriends.pyx:143-183) for random live sets / batches, pre-filter on and off: the
     lowest index must survive tile ranges swept by different waves, phases and the re-check"""
-    rs = np.random.RandomState(500 + seed)
+    rs = np.random.RandomState(500 + seed + FUZZ_OFFSET)
     d = int(rs.choice([1, 2, 4, 9, 16, 27, 50, 64, 70]))
     na = int(rs.randint(33, 5000))
     nb = int(rs.choice([65, 300, 1025, 4099, 20001]))

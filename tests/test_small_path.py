@@ -1,8 +1,13 @@
 """Single-launch MLFriends.inside for 1 ... 256 proposals (csrc/mlf_small.hip) against the batched pipeline and the
 oracle: masks must be identical whatever path a call takes (reference mlfriends.pyx:1186-1211; callers with such
 batches: stepsampler.py:296-330, 1060-1071, integrator.py:1854-1855)."""
+import os
+
 import numpy as np
 import pytest
+
+# soak runs: MLF_FUZZ_OFFSET=k shifts the seeds of the random tests (the default run is offset 0)
+FUZZ_OFFSET = int(os.environ.get("MLF_FUZZ_OFFSET", "0"))
 
 import inputs
 
@@ -322,6 +327,7 @@ def test_interleaved_row_updates_and_calls_of_every_size(seed, K):
     """live points replaced one at a time (mlf_region_update_point: the pre-filter operands are requantised lazily)
     between membership calls of every size class -- single launch, exact scan, pre-filter with tile ranges, phased
     pre-filter -- must always agree with a region set up from scratch on the same live points"""
+    seed += FUZZ_OFFSET
     rs = np.random.RandomState(900 + seed)
     d = int(rs.choice([2, 5, 9, 16, 33, 50]))
     n = int(rs.randint(300, 2500))
