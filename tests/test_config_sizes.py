@@ -11,6 +11,8 @@ oracle or against the exact FP64 scan:
   C5  membership leg: full-size (P = 10^6, N = 4000, d = 50) batches with varied scale / offset / cluster
       structure and r^2 at the routing edges of the MFMA pre-filter: filtered masks == exact-scan masks.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -107,11 +109,13 @@ def _ellipsoid_draws(region, z, rad):
 
 @pytest.fixture(scope="module")
 def fuzz_draws():
-    rs = np.random.RandomState(2024)
+    rs = np.random.RandomState(2024 + FUZZ_OFFSET)
     P, d = 1000000, 50
     return rs.normal(size=(P, d)), rs.uniform(size=(P, 1))
 
 
+# soak runs: MLF_FUZZ_OFFSET=k shifts the seeds (the default run is offset 0)
+FUZZ_OFFSET = int(os.environ.get("MLF_FUZZ_OFFSET", "0"))
 FUZZ_CASES = ["baseline", "tiny-scale", "offset-mixed", "two-clusters", "r2-edge-hi", "r2-edge-lo"]
 
 
@@ -121,7 +125,7 @@ def test_c5_full_size_filter_equals_exact_scan(case, fuzz_draws):
     z, rad = fuzz_draws
     P, d = z.shape
     N = 4000
-    rs = np.random.RandomState(FUZZ_CASES.index(case) + 5)
+    rs = np.random.RandomState(FUZZ_CASES.index(case) + 5 + FUZZ_OFFSET)
     if case == "tiny-scale":
         u = 0.5 + 1e-4 * rs.normal(size=(N, d)) * np.linspace(0.2, 3.0, d)
     elif case == "offset-mixed":
