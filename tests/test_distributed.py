@@ -182,7 +182,7 @@ def test_collectives_on_rccl_with_one_rank():
     assert tuple(out["pair"]) == tuple(want), (dict(out), want)
 
 
-def _one_rank_fails_worker(rank, world_size, port, out):
+def _one_rank_fails_worker(rank, world_size, port, out, exc_name="FloatingPointError"):
     """rank 1's shard raises a FloatingPointError (what np.errstate(all='raise') turns a numpy warning into under the
     driver, integrator.py:2066); rank 0's shard is fine.  Every rank must still reach the all-reduce and leave with the
     same exception type (a rank that skips the collective leaves the others blocked in it)."""
@@ -199,6 +199,9 @@ def _one_rank_fails_worker(rank, world_size, port, out):
             setattr(M, name, getattr(oracle_backend, name))
     from ultranest_amd import distributed
     from ultranest_amd.harness import RegionUpdater
+    from ultranest_amd._lib import HipLibraryError
+    exc = {"FloatingPointError": FloatingPointError, "RuntimeError": RuntimeError, "HipLibraryError": HipLibraryError,
+           "MemoryError": MemoryError}[exc_name]
     _init(dist, "gloo", port, rank, world_size)
     try:
         u = inputs.live_points(31, 300, 4)
@@ -209,7 +212,7 @@ def _one_rank_fails_worker(rank, world_size, port, out):
 
         def shard(masks, minvol=0.):
             if rank == 1:
-                raise FloatingPointError("invalid value encountered in this rank's shard")
+                raise exc("invalid value encountered in this rank's shard")
             return good(masks, minvol=minvol)
         region.enlargement_from_masks = shard
         try:
@@ -224,7 +227,7 @@ def _one_rank_fails_worker(rank, world_size, port, out):
 
         def tshard(self, masks):
             if rank == 1:
-                raise FloatingPointError("shard")
+                raise exc("shard")
             return real(self, masks)
         import ultranest_amd.harness as H
         H.WrappingEllipsoid.enlargement_from_masks = tshard
@@ -236,11 +239,14 @@ def _one_rank_fails_worker(rank, world_size, port, out):
         dist.destroy_process_group()
 
 
-def test_failure_on_one_rank_only_keeps_the_group_in_step():
+@pytest.mark.parametrize("exc_name", ["FloatingPointError", "RuntimeError", "HipLibraryError", "MemoryError"])
+def test_failure_on_one_rank_only_keeps_the_group_in_step(exc_name):
+    """whatever a shard raises -- a numerical error, a device-layer RuntimeError (HipLibraryError was not in
+    the caught set, the failing rank skipped the all-reduce and the others hung), an allocation failure"""
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_one_rank_fails_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_one_rank_fails_worker, args=(2, _free_port(), out, exc_name), nprocs=2, join=True)
     assert out[0] == "LinAlgError" and out[1] == "LinAlgError", dict(out)
     assert out[10] is True and out[11] is True, dict(out)
     assert out[20] == 1.0 and out[21] == 1.0, dict(out)

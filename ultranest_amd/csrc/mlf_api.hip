@@ -86,6 +86,8 @@ int g_filter_phases = 1;              // mlf_set_option("filter_phases", n): 0 s
 long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
 bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
 bool g_time_filter_launches = false;  // mlf_set_option("time_filter_launches", 0/1): event pairs around every k_filter launch of every call
+int g_filter_sweep = 1;                // mlf_set_option("filter_sweep", 0/1): mask-mode sweep by k_sweep (mlf_sweep.hip) instead of k_filter
+int g_filter_debug = 0;                // timing builds only
 int g_filter_first_range_pct = 50;     // mlf_set_option("filter_first_range_pct", 10 ... 90): share of the live-point tiles in the first of two ranges
 int g_filter_narrow_tail = 1;          // mlf_set_option("filter_narrow_tail", 0/1): later ranges of a phased sweep with 2 query groups per wave
 bool g_small_path = true;             // mlf_set_option("small_path", 0/1): one launch for up to 256 proposals handed over on the host
@@ -301,6 +303,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   fa.seg_cap = cap;
   fa.seg_count = f.segcnt.as<unsigned>();
   fa.counters = f.counters.as<unsigned>();
+  fa.dbg = g_filter_debug;
   // Phased sweep: the live-point tiles are split into nphase ranges; after each range the queries that
   // are decided (certain hit) leave, the rest is compacted into fresh 32-query groups.  Every launch
   // is sized for the worst case and reads the actual group count from device memory: no host sync.
@@ -404,7 +407,13 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       CK(hipEventRecord(f.kev[f.kev_used], s));
     }
     const int narrow = (f.ks <= 4 && ph > 0) ? g_filter_narrow_tail : 0;
-    CK(launch_filter(f.ks, fa, out_idx != nullptr, s, narrow));
+    {
+      const int qw = filter_groups_per_wave(f.ks, narrow);
+      if (g_filter_sweep && out_idx == nullptr && narrow < 2 && sweep_available(f.ks, fa))
+        CK(launch_sweep(f.ks, qw, fa, s));
+      else
+        CK(launch_filter(f.ks, fa, out_idx != nullptr, s, narrow));
+    }
     if (time_launch) {
       CK(hipEventRecord(f.kev[f.kev_used + 1], s));
       f.kev_used += 2;
@@ -1054,6 +1063,14 @@ int mlf_set_option(const char *name, long long value) {
   if (!name) return fail_arg(MLF_E_BADARG, "null pointer");
   if (!strcmp(name, "filter")) {
     g_filter_enabled = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "filter_debug")) {
+    g_filter_debug = (int)value;
+    return 0;
+  }
+  if (!strcmp(name, "filter_sweep")) {
+    g_filter_sweep = (int)value;
     return 0;
   }
   if (!strcmp(name, "filter_first_range_pct")) {

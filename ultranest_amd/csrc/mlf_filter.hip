@@ -696,8 +696,12 @@ void launch_recheck(const RecheckArgs &a, long long nwaves, hipStream_t s) {
   hipLaunchKernelGGL(k_recheck, dim3((unsigned)nwaves), dim3(256), 0, s, a);
 }
 
+int filter_groups_per_wave(int ks, int narrow) {
+  return ks <= 4 ? (narrow == 2 && ks == 4 ? 1 : (narrow == 3 && ks == 4 ? 3 : (narrow ? 2 : 4))) : (ks <= 8 ? 2 : 1);
+}
+
 long long filter_wave_count(int ks, long long ngroups, int narrow) {
-  const int qw = ks <= 4 ? (narrow == 2 && ks == 4 ? 1 : (narrow == 3 && ks == 4 ? 3 : (narrow ? 2 : 4))) : (ks <= 8 ? 2 : 1);
+  const int qw = filter_groups_per_wave(ks, narrow);
   return (ngroups + qw - 1) / qw;
 }
 

@@ -40,6 +40,7 @@ struct FilterArgs {
   long long seg_first_extra, seg_extra;
   // tile ranges of a non-compacting launch (grid.y); list segment of (wave, range) = wave + range * 4 * grid.x
   int split;
+  int dbg;   // timing builds only (mlf_set_option("filter_debug")): 1 no compaction stores, 2 two tiles only, 4 no query operands
 };
 // after a compacting launch: group count of the compacted set, padding of its last group, counter reset
 void launch_phase_finish(void *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount, unsigned *ngroups_dst,
@@ -85,6 +86,10 @@ void launch_quant_queries(const double *q, long long ldq, long long nq, long lon
                           const double *stats, double r2, const uint8_t *gate, void *qF, float *tlo,
                           float *thi, uint8_t *route, int *best, unsigned *counters, hipStream_t s);
 hipError_t launch_filter(int ks, const FilterArgs &a, bool first, hipStream_t s, int narrow = 0);
+// mask-mode sweep (mlf_sweep.hip): qw query groups per wave
+bool sweep_available(int ks, const FilterArgs &a);
+hipError_t launch_sweep(int ks, int qw, const FilterArgs &a, hipStream_t s);
+int filter_groups_per_wave(int ks, int narrow);
 void launch_recheck(const RecheckArgs &a, long long nwaves, hipStream_t s);
 long long filter_wave_count(int ks, long long ngroups, int narrow = 0);
 // tile ranges a single-sweep launch over `ntiles` tiles should use for a batch of `ngroups` query groups (1 ... 4)

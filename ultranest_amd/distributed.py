@@ -25,9 +25,12 @@ import numpy as np
 from . import regions
 
 
-# what a shard of bootstrap rounds can raise (the driver runs the rebuild under np.errstate(all='raise'),
-# integrator.py:2066): caught per rank, exchanged as a flag, re-raised on every rank after the all-reduce
-SHARD_ERRORS = (np.linalg.LinAlgError, FloatingPointError, AssertionError, Warning)
+# A shard of bootstrap rounds can raise numerical errors (the driver runs the rebuild under np.errstate(all='raise'),
+# integrator.py:2066: LinAlgError, FloatingPointError, AssertionError, Warning) and anything the device layer reports
+# (HipLibraryError is a RuntimeError; an out-of-memory allocation a MemoryError).  EVERY exception of a shard is caught
+# per rank, exchanged as a flag and re-raised on every rank after the all-reduce: a rank that skipped the collective
+# would leave the other ranks blocked in it.
+SHARD_ERRORS = (Exception,)
 
 
 def _dist():
@@ -94,6 +97,9 @@ def broadcast_masks(masks, npoints, nbootstraps, group=None, src=0, keep_on_devi
         buf = torch.empty((nbootstraps, npoints), dtype=torch.uint8, device=dev)
     dist.broadcast(buf, src=src, group=group)
     if keep_on_device and dev.type == "cuda":
+        # stream contract: the consumers (mlf_* calls) copy from this tensor on the LIBRARY's stream, which knows nothing
+        # of torch's streams -- the broadcast (queued behind torch's current stream) has to be complete before they start
+        torch.cuda.current_stream(dev).synchronize()
         return buf
     return buf.cpu().numpy().astype(bool)
 

@@ -98,14 +98,16 @@ class RegionUpdater(object):
                     masks = distributed.broadcast_masks(       # every rank draws (streams stay in step), rank 0's counts
                         _draw(len(active_p), nbootstraps), len(active_p), nbootstraps, group=self.group)
                     lo, hi = distributed.shard_bounds(nbootstraps, rank, size)
-                    f, failed = 0.0, 0.0
+                    f, failed, err = 0.0, 0.0, None
                     try:      # the shard may fail on ONE rank only: every rank still joins the all-reduce
                         f = tregion.enlargement_from_masks(masks[lo:hi]) if hi > lo else 0.0
-                    except distributed.SHARD_ERRORS:
-                        failed = 1.0
+                    except distributed.SHARD_ERRORS as e:
+                        failed, err = 1.0, e
                     f, failed = distributed.allreduce_max([f, failed], group=self.group)
                     if failed > 0:
-                        raise np.linalg.LinAlgError("tregion bootstrap failed on a rank")
+                        if size == 1 and err is not None:
+                            raise err     # a single process keeps the exception's own type, as the reference does
+                        raise np.linalg.LinAlgError("tregion bootstrap failed on a rank") from err
                     tregion.enlarge = float(f)
                     tregion.create_ellipsoid()
                     self.tregion = tregion
