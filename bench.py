@@ -41,6 +41,7 @@ F16_MFMA_PEAK_TFLOPS = 2500.0    # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md
 PROBE_F16_MFMA_TFLOPS = 1400.0   # what k_filter's instruction pattern sustains in a probe without memory traffic
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F16_FLOPS = 2 * 32 * 32 * 16   # one v_mfma_f32_32x32x16_f16
+CLOCK_SETTLE_STEPS = 100         # untimed steps in front of the W warm-up steps of a timed loop (see run_steps)
 
 
 def build_region(group):
@@ -205,6 +206,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=150000, help="proposals timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="which leg is the headline `value`: weak = P proposals per rank and step (default), strong = ONE "
+                         "batch of P proposals per step sharded over the ranks; the other leg is reported beside it")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline path (no single-sweep / filter-off / host-API comparison passes): used for "
                          "the rocprofv3 runs, so that the per-kernel averages of the summary are those of the timed steps")
@@ -254,12 +258,15 @@ def main():
 
     from ultranest_amd import _lib as lib_mod
 
-    def run_steps(nsteps, stage_events):
+    def run_steps(nsteps, stage_events, settle=0):
         """nsteps passes between two barriers; returns (max-over-ranks seconds, this rank's seconds).
+        settle: untimed steps in front of the W warm-up steps (CLOCK_SETTLE_STEPS for the headline: the device's clock
+        management needs tens of milliseconds of load before the chip runs at its sustained clock; the first 10 ms
+        after an idle period -- such as the host-side region build in front of this loop -- run ~8 % slower).
         stage_events: also record the per-stage hipEvents (only outside the headline loop: six extra events per pass
         cost ~7 % of a 0.6 ms step).  The k_filter launches are bracketed by events in both modes."""
         call = handle.inside_dev_timed if stage_events else handle.inside_dev
-        for _ in range(args.warmup):
+        for _ in range(settle + args.warmup):
             handle.inside_dev(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
         handle.timing_collect()
         handle.timing_filter_launches()
@@ -280,14 +287,27 @@ def main():
         return dt, mine
 
     lib_mod.set_option("time_filter_launches", 1)
-    # ---- the headline: exactly K steps, hipEvents only around the dominant kernel's launches -----------------
-    elapsed, elapsed_mine = run_steps(args.steps, False)
+    exact_elapsed = ncalls_x = ms_scan_x = scan_flops = ell_pass = None
+    nsteps_x = max(3, args.steps // 4)
+    mask_exact = None
+    if not args.headline_only:
+        # ---- the reference answer first: the exact FP64 scan kernel alone (MFMA pre-filter switched off) on the same
+        # batch.  Its mask is what the timed path is compared with below; its time is `roofline_exact_scan`.
+        lib_mod.set_option("filter", 0)
+        exact_elapsed, _ = run_steps(nsteps_x, True)
+        ncalls_x, ms_prep_x, ms_scan_x, ms_rest_x = handle.timing_collect()
+        lib_mod.set_option("filter", 1)
+        mask_exact = mask.clone()
+    # ---- the headline: W warm-up steps, then exactly K steps, hipEvents only around the dominant kernel's launches ----
+    elapsed, elapsed_mine = run_steps(args.steps, False, settle=CLOCK_SETTLE_STEPS)
     filter_launches = run_steps.filter_launches
     launch_ms_list = run_steps.launch_ms
     stats = handle.debug_stats()
     accept = float(mask.float().mean().item())
     filter_on, kdim, ntiles32 = handle.filter_info(NPROPOSALS)
     mask_filter = mask.clone()
+    if mask_exact is not None:
+        assert bool((mask_exact == mask_filter).all().item()), "filter and exact scan disagree"
     # ---- per-stage breakdown (separate pass with stage events) ---------------------------------------------
     nsteps_b = max(3, args.steps // 2)
     run_steps(nsteps_b, True)
@@ -296,8 +316,6 @@ def main():
 
     # single-sweep variant of the pre-filter (no compaction between live-point ranges), for the record
     ms_scan_single = None
-    exact_elapsed = ncalls_x = ms_scan_x = scan_flops = ell_pass = None
-    nsteps_x = max(3, args.steps // 4)
     hostapi = None
     if not args.headline_only:
         lib_mod.set_option("filter_phases", 0)
@@ -305,12 +323,7 @@ def main():
         ncalls_single, _, ms_scan_single, _ = handle.timing_collect()
         ms_scan_single /= max(ncalls_single, 1)
         lib_mod.set_option("filter_phases", 1)
-        # reference point: the exact FP64 scan kernel alone (MFMA pre-filter switched off), same batch
-        lib_mod.set_option("filter", 0)
-        exact_elapsed, _ = run_steps(nsteps_x, True)
-        ncalls_x, ms_prep_x, ms_scan_x, ms_rest_x = handle.timing_collect()
-        lib_mod.set_option("filter", 1)
-        assert bool((mask == mask_filter).all().item()), "filter and exact scan disagree"
+        assert bool((mask == mask_filter).all().item()), "single sweep and phased sweep disagree"
         # ... and the FP64 per-proposal stage (k_prep3) in front of the filter instead of the bounded FP32 one
         lib_mod.set_option("prep_bounded", 0)
         run_steps(nsteps_x, True)
@@ -332,14 +345,79 @@ def main():
             hostapi = host_api(region, pts)
     lib_mod.set_option("time_filter_launches", 0)
 
+    # ---- strong scaling: ONE batch of P proposals per step, rows sharded over the ranks (distributed.shard_bounds; no
+    # collective in the data path, integrator.py:1916-1928 gathers only accepted rows), and the 30-round bootstrap of
+    # the rebuild sharded over the ranks INCLUDING its all-reduce (integrator.py:375-415) -------------------------
+    from ultranest_amd import distributed
+
+    def maxed(x):
+        if not use_dist:
+            return float(x)
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    lo, hi = distributed.shard_bounds(NPROPOSALS, rank, world)
+    if world > 1:
+        full = proposals_in_ellipsoid(region, NPROPOSALS, 1000, dev)     # the SAME batch on every rank; each takes its rows
+        shard = full[lo:hi].contiguous()
+        del full
+    else:
+        shard = pts
+    smask = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
+    for _ in range(CLOCK_SETTLE_STEPS + args.warmup):
+        handle.inside_dev(shard.data_ptr(), hi - lo, smask.data_ptr(), stream)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        handle.inside_dev(shard.data_ptr(), hi - lo, smask.data_ptr(), stream)
+    barrier()
+    strong_mine = time.perf_counter() - t0
+    strong_elapsed = maxed(strong_mine)
+    strong_accept = float(smask.float().mean().item())
+    # sharded bootstrap: masks drawn once, broadcast, 30 rounds over the ranks, ONE all-reduce(MAX) of 3 doubles
+    boot_reps = max(3, min(10, args.steps))
+    rs_b = np.random.RandomState(5)
+    distributed.update_region_bootstrap(region, NBOOT, minvol=0., group=group, rng=rs_b)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(boot_reps):
+        r_b, f_b = distributed.update_region_bootstrap(region, NBOOT, minvol=0., group=group, rng=rs_b)
+    barrier()
+    boot_mine = (time.perf_counter() - t0) / boot_reps
+    boot_elapsed = maxed(boot_mine)
+    ranks_seen = 1
+    if use_dist:
+        import torch.distributed as dist
+        ones = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones.item())))
+    strong = {
+        "what": "ONE batch of %d proposals per step, rows sharded over %d rank(s) by shard_bounds (region replicated, no "
+                "collective in the data path); value = P x steps / max-over-ranks seconds between two barriers" % (NPROPOSALS, world),
+        "value": NPROPOSALS * args.steps / strong_elapsed, "unit": "proposals/s", "ms_per_step": strong_elapsed / args.steps * 1e3,
+        "rows_this_rank": hi - lo, "accept_fraction_this_rank": strong_accept,
+        "bootstrap30_sharded_ms": boot_elapsed * 1e3,
+        "bootstrap30_sharded_what": "distributed.update_region_bootstrap: 30 selection masks drawn on every rank, rank 0's "
+                                    "broadcast, ceil(30 / ranks) rounds per rank on the device, ONE all-reduce(MAX) of (r2, f, "
+                                    "error flag), INCLUDED in the time; max over ranks",
+        "bootstrap_result": [r_b, f_b],
+        "collective_backend": (backend if use_dist else None), "ranks_seen_by_allreduce": ranks_seen,
+    }
+
     first_ms, rebuild_ms, rebuild_all = time_rebuild(u, group)
 
     per_rank = [elapsed_mine]
+    per_rank_strong = [(strong_mine, boot_mine)]
     if use_dist:
         import torch.distributed as dist
         gathered = [None] * world
         dist.all_gather_object(gathered, elapsed_mine)
         per_rank = gathered
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (strong_mine, boot_mine))
+        per_rank_strong = gathered
     if rank != 0:
         if use_dist:
             import torch.distributed as dist
@@ -351,6 +429,12 @@ def main():
     prep_ms = ms_prep / max(ncalls, 1)
     rest_ms = ms_rest / max(ncalls, 1)
     value = NPROPOSALS * world * args.steps / elapsed
+    strong["per_rank_ms_per_step"] = [a / args.steps * 1e3 for a, _ in per_rank_strong]
+    strong["per_rank_bootstrap30_ms"] = [b * 1e3 for _, b in per_rank_strong]
+    weak = {"what": "%d proposals per rank and step (the per-GPU work is fixed as ranks are added)" % NPROPOSALS,
+            "value": value, "unit": "proposals/s", "ms_per_step": elapsed / args.steps * 1e3,
+            "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank]}
+    headline = strong if args.scaling == "strong" else weak
     alg_bytes = NPROPOSALS * (8 * NDIM + 1) + 8 * N_LIVE * NDIM + 2 * 8 * NDIM * NDIM
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_scan_traffic.json")
@@ -422,8 +506,10 @@ def main():
     # 3 partial products (hi hi, hi lo, lo hi) x [6 k-steps of the triangular L^T + 8 of T^T]
     out = {
         "metric": "proposal-points filtered/sec (MLFriends.inside) + region-rebuild ms, N=4000 d=50",
-        "value": value, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "value": headline["value"], "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": headline["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
+        "clock_settle_steps": CLOCK_SETTLE_STEPS,
+        "weak_scaling": weak, "strong_scaling": strong,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "C5: N=4000 live points, d=50, P=1e6 proposals/step/GPU drawn uniformly inside the "
                                "wrapping ellipsoid (set E), AffineLayer, 30 bootstraps; one step = MLFriends.inside "

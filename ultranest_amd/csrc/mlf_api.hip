@@ -86,7 +86,6 @@ int g_filter_phases = 1;              // mlf_set_option("filter_phases", n): 0 s
 long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
 bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
 bool g_time_filter_launches = false;  // mlf_set_option("time_filter_launches", 0/1): event pairs around every k_filter launch of every call
-int g_filter_sweep = 1;                // mlf_set_option("filter_sweep", 0/1): mask-mode sweep by k_sweep (mlf_sweep.hip) instead of k_filter
 int g_filter_debug = 0;                // timing builds only
 int g_filter_first_range_pct = 50;     // mlf_set_option("filter_first_range_pct", 10 ... 90): share of the live-point tiles in the first of two ranges
 int g_filter_narrow_tail = 1;          // mlf_set_option("filter_narrow_tail", 0/1): later ranges of a phased sweep with 2 query groups per wave
@@ -183,7 +182,7 @@ int filter_prepare_refs(FilterCtx &f, const double *refR, int n, int d, int dp, 
                         bool host_sync) {
   f.refs_ready = false;
   const int ks = (dp + 6 + 15) / 16;   // filter dimensionality = padded DP (zero columns are harmless)
-  if (ks > 9 || n < 1) {
+  if (ks > 9 || n < 1 || (long long)round_up(n, 32) / 32 * ks * 1024 >= (1ll << 31)) {   // k_sweep addresses the tiles with 32-bit buffer offsets
     f.usable = false;
     return 0;
   }
@@ -407,13 +406,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       CK(hipEventRecord(f.kev[f.kev_used], s));
     }
     const int narrow = (f.ks <= 4 && ph > 0) ? g_filter_narrow_tail : 0;
-    {
-      const int qw = filter_groups_per_wave(f.ks, narrow);
-      if (g_filter_sweep && out_idx == nullptr && narrow < 2 && sweep_available(f.ks, fa))
-        CK(launch_sweep(f.ks, qw, fa, s));
-      else
-        CK(launch_filter(f.ks, fa, out_idx != nullptr, s, narrow));
-    }
+    CK(launch_filter(f.ks, fa, out_idx != nullptr, s, narrow));
     if (time_launch) {
       CK(hipEventRecord(f.kev[f.kev_used + 1], s));
       f.kev_used += 2;
@@ -1069,16 +1062,12 @@ int mlf_set_option(const char *name, long long value) {
     g_filter_debug = (int)value;
     return 0;
   }
-  if (!strcmp(name, "filter_sweep")) {
-    g_filter_sweep = (int)value;
-    return 0;
-  }
   if (!strcmp(name, "filter_first_range_pct")) {
     g_filter_first_range_pct = value < 10 ? 10 : (value > 90 ? 90 : (int)value);
     return 0;
   }
   if (!strcmp(name, "filter_narrow_tail")) {
-    g_filter_narrow_tail = value < 0 ? 0 : (value > 3 ? 3 : (int)value);   // later ranges with 2 (1), 1 (2) or 3 (3) query groups per wave
+    g_filter_narrow_tail = value != 0;
     return 0;
   }
   if (!strcmp(name, "small_path")) {

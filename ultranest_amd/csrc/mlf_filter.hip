@@ -227,9 +227,10 @@ __device__ __forceinline__ int min3i(int a, int b, int c) {
 }
 
 // ---------------------------------------------------------------- the MFMA filter ------------
-// One wave owns QW groups of 32 queries (B fragments resident in registers) and sweeps ALL
-// live-point tiles; a workgroup is 4 independent waves.
-template <int KS, int QW, bool FIRST, bool COMPACT>
+// FIRST-INDEX mode (find_nearby: the lowest live index within r2, mlfriends.pyx:176-183).  One wave owns QW groups of
+// 32 queries (B fragments resident in registers) and sweeps ALL live-point tiles; a workgroup is 4 independent waves.
+// The mask mode of the same sweep (MLFriends.inside, where any hit decides) is k_sweep in mlf_sweep.hip.
+template <int KS, int QW, bool COMPACT>
 __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -308,15 +309,9 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
       for (int g = 0; g < QW; ++g)
         acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bq[g][s], acc[g], 0, 0, 0);
 
-    // All 16 values of a lane belong to ONE query (column = lane & 31) and 16 live points, so the
-    // lane-wise minimum decides the common case with 8 v_min3 + 1 compare per group:
-    //   vmin >  T_hi : nothing within reach in this block (certain misses)
-    // Operands are finite binary16 values of bounded size, so acc holds no NaN / inf.
-    // The common path is 4 x (8 v_min3 + v_cmp) + 3 s_or + one branch per tile (one branch per group kept the
-    // scheduler from overlapping the epilogue with the next matrix products; the first version also compared
-    // against T_lo and combined three wave masks per group on the scalar unit in every tile: 62 scalar
-    // instructions per tile, as many issue slots as the vector part).  Mask mode: a query with a certain hit has its
-    // T_hi lowered to -inf in BOTH of its lanes, so it never shows up here again.
+    // All 16 values of a lane belong to ONE query (column = lane & 31) and 16 live points, so the lane-wise minimum
+    // decides the common case with 8 v_min3 + 1 compare per group: vmin > T_hi -- nothing within reach in this block
+    // (certain misses).  Operands are finite binary16 values of bounded size, so acc holds no NaN / inf.
     float vmin[QW];
     unsigned long long candm[QW];
     unsigned long long need = 0ull;
@@ -329,12 +324,6 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
       const int m3 = min3i(__float_as_int(c[9]), __float_as_int(c[10]), __float_as_int(c[11]));
       const int m4 = min3i(__float_as_int(c[12]), __float_as_int(c[13]), __float_as_int(c[14]));
       vmin[g] = __int_as_float(min3i(min3i(m0, m1, m2), min3i(m3, m4, __float_as_int(c[15])), m0));
-      // mask mode: a certain hit (vmin <= T_lo < T_hi) lowers this lane's T_hi to -inf -- two vector instructions, no
-      // branch -- and so never counts as a candidate, now or later.  (With the hits handled behind the branch, nearly
-      // every tile of the first range took it: a million first hits over half a million wave-tiles.)  The other lane of
-      // the query learns of it only at the end; until then it may still list uncertain pairs of a decided query, which
-      // the re-check answers like any other.
-      if (!FIRST) thi[g] = vmin[g] <= tlo[g] ? -INFINITY : thi[g];
       candm[g] = __ballot(vmin[g] <= thi[g]);
       need |= candm[g];
     }
@@ -342,7 +331,7 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
 #pragma unroll
       for (int g = 0; g < QW; ++g) {
         if (candm[g] == 0ull) continue;
-        if (FIRST) {
+        {
           // a query with a certain hit below this tile cannot get a lower first index here, and its uncertain
           // pairs in this tile cannot matter either (without this every later tile of an accepted proposal went
           // through the detail path: first-index batches with many hits ran slower than the exact scan)
@@ -358,9 +347,7 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
           for (int r = 0; r < 16; ++r) {
             const float v = c[r];
             const int idx = t * 32 + rowbase + (r & 3) + 8 * (r >> 2);
-            if (v <= tlo[g]) {
-              if (FIRST) first[g] = idx < first[g] ? idx : first[g];
-            }
+            if (v <= tlo[g]) first[g] = idx < first[g] ? idx : first[g];
           }
         }
         // uncertainty band: append (query, live point) to this wave's PRIVATE list segment for the
@@ -398,16 +385,10 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
     if (g0 + g >= ngroups) continue;
     const long long slot_q = (g0 + g) * 32 + (lane & 31);
     const long long qi = a.qmap ? (long long)a.qmap[slot_q] : slot_q;
-    int res;
-    if (FIRST) {
-      const int other = __shfl_xor(first[g], 32);
-      res = first[g] < other ? first[g] : other;
-    } else {
-      const int mine = thi[g] == -INFINITY ? 1 : 0;   // only a certain hit leaves -inf behind (no threshold: -1)
-      res = (mine | __shfl_xor(mine, 32)) ? 0 : kNone;
-    }
+    const int other = __shfl_xor(first[g], 32);
+    const int res = first[g] < other ? first[g] : other;
     if (lane < 32 && qi >= 0 && qi < a.nq && res != kNone) {
-      if (FIRST && nsub > 1)
+      if (nsub > 1)
         atomicMin(a.best + qi, res);   // the waves of the other tile ranges report too
       else
         a.best[qi] = res;
@@ -641,19 +622,13 @@ void launch_quant_queries(const double *q, long long ldq, long long nq, long lon
 }
 
 template <int KS, int QW>
-static hipError_t launch_filter_t(const FilterArgs &a, bool first, hipStream_t s) {
+static hipError_t launch_filter_t(const FilterArgs &a, hipStream_t s) {
   const long long waves = (a.ngroups + QW - 1) / QW;
   const dim3 grid((unsigned)((waves + 3) / 4), (unsigned)((a.cq || a.split < 1) ? 1 : a.split));
-  if (a.cq) {
-    if (first)
-      hipLaunchKernelGGL((k_filter<KS, QW, true, true>), grid, dim3(256), 0, s, a);
-    else
-      hipLaunchKernelGGL((k_filter<KS, QW, false, true>), grid, dim3(256), 0, s, a);
-  } else if (first) {
-    hipLaunchKernelGGL((k_filter<KS, QW, true, false>), grid, dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((k_filter<KS, QW, false, false>), grid, dim3(256), 0, s, a);
-  }
+  if (a.cq)
+    hipLaunchKernelGGL((k_filter<KS, QW, true>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_filter<KS, QW, false>), grid, dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -665,28 +640,26 @@ int filter_tile_split(int ks, long long ngroups, int ntiles) {
   return k < 1 ? 1 : (int)k;
 }
 
+// first = first-index mode (k_filter); otherwise the mask-mode sweep (k_sweep, mlf_sweep.hip).  narrow: two query
+// groups per wave instead of four (later ranges of a phased sweep: twice the waves of half the length).
 hipError_t launch_filter(int ks, const FilterArgs &a, bool first, hipStream_t s, int narrow) {
   if (a.ngroups <= 0) return hipSuccess;
-  if (narrow == 2 && ks == 4) return launch_filter_t<4, 1>(a, first, s);
-  if (narrow == 3 && ks == 4) return launch_filter_t<4, 3>(a, first, s);
-  if (narrow)   // two query groups per wave: twice the waves of half the length (later ranges of a phased sweep)
-    switch (ks) {
-      case 1: return launch_filter_t<1, 2>(a, first, s);
-      case 2: return launch_filter_t<2, 2>(a, first, s);
-      case 3: return launch_filter_t<3, 2>(a, first, s);
-      case 4: return launch_filter_t<4, 2>(a, first, s);
-      default: break;
-    }
-  switch (ks) {
-    case 1: return launch_filter_t<1, 4>(a, first, s);
-    case 2: return launch_filter_t<2, 4>(a, first, s);
-    case 3: return launch_filter_t<3, 4>(a, first, s);
-    case 4: return launch_filter_t<4, 4>(a, first, s);
-    case 5: return launch_filter_t<5, 2>(a, first, s);
-    case 6: return launch_filter_t<6, 2>(a, first, s);
-    case 7: return launch_filter_t<7, 2>(a, first, s);
-    case 8: return launch_filter_t<8, 2>(a, first, s);
-    case 9: return launch_filter_t<9, 1>(a, first, s);
+  const int qw = filter_groups_per_wave(ks, narrow);
+  if (!first) return launch_sweep(ks, qw, a, s);
+  switch (ks * 8 + qw) {
+    case 1 * 8 + 4: return launch_filter_t<1, 4>(a, s);
+    case 2 * 8 + 4: return launch_filter_t<2, 4>(a, s);
+    case 3 * 8 + 4: return launch_filter_t<3, 4>(a, s);
+    case 4 * 8 + 4: return launch_filter_t<4, 4>(a, s);
+    case 1 * 8 + 2: return launch_filter_t<1, 2>(a, s);
+    case 2 * 8 + 2: return launch_filter_t<2, 2>(a, s);
+    case 3 * 8 + 2: return launch_filter_t<3, 2>(a, s);
+    case 4 * 8 + 2: return launch_filter_t<4, 2>(a, s);
+    case 5 * 8 + 2: return launch_filter_t<5, 2>(a, s);
+    case 6 * 8 + 2: return launch_filter_t<6, 2>(a, s);
+    case 7 * 8 + 2: return launch_filter_t<7, 2>(a, s);
+    case 8 * 8 + 2: return launch_filter_t<8, 2>(a, s);
+    case 9 * 8 + 1: return launch_filter_t<9, 1>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -696,9 +669,7 @@ void launch_recheck(const RecheckArgs &a, long long nwaves, hipStream_t s) {
   hipLaunchKernelGGL(k_recheck, dim3((unsigned)nwaves), dim3(256), 0, s, a);
 }
 
-int filter_groups_per_wave(int ks, int narrow) {
-  return ks <= 4 ? (narrow == 2 && ks == 4 ? 1 : (narrow == 3 && ks == 4 ? 3 : (narrow ? 2 : 4))) : (ks <= 8 ? 2 : 1);
-}
+int filter_groups_per_wave(int ks, int narrow) { return ks <= 4 ? (narrow ? 2 : 4) : (ks <= 8 ? 2 : 1); }
 
 long long filter_wave_count(int ks, long long ngroups, int narrow) {
   const int qw = filter_groups_per_wave(ks, narrow);

@@ -87,7 +87,6 @@ void launch_quant_queries(const double *q, long long ldq, long long nq, long lon
                           float *thi, uint8_t *route, int *best, unsigned *counters, hipStream_t s);
 hipError_t launch_filter(int ks, const FilterArgs &a, bool first, hipStream_t s, int narrow = 0);
 // mask-mode sweep (mlf_sweep.hip): qw query groups per wave
-bool sweep_available(int ks, const FilterArgs &a);
 hipError_t launch_sweep(int ks, int qw, const FilterArgs &a, hipStream_t s);
 int filter_groups_per_wave(int ks, int narrow);
 void launch_recheck(const RecheckArgs &a, long long nwaves, hipStream_t s);

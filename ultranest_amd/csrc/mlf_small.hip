@@ -22,18 +22,24 @@
 
 namespace mlf {
 
-// The workgroup that completes the LAST proposal of the call raises the host-visible flag the caller spins on (the
-// mask bytes are in host memory before it: system-scope fence).  The caller does not wait for the kernel's own
-// completion signal, ~4 us later; the next launch is ordered behind this one by the stream.
+// The workgroup that completes the LAST proposal of the call raises the host-visible flag the caller spins on.  The
+// caller does not wait for the kernel's own completion signal (~4 us later; the next launch is ordered behind this one
+// by the stream), so the flag is the ONLY thing that orders the mask bytes -- written by many workgroups straight into
+// host memory -- before the caller's read: every workgroup releases its own mask byte at system scope BEFORE it counts
+// itself as finished, and the workgroup that sees the full count acquires those releases before it raises the flag
+// (fence - atomic - fence: the threadFenceReduction pattern).  Without the per-workgroup fence only the last
+// workgroup's own byte was ordered; the staging buffer is reused from call to call, so a byte still in flight would have
+// been a stale answer of the previous call.
 __device__ __forceinline__ void finish_point(const SmallArgs &a) {
   bool last = true;
   if (a.np > 1) {
-    const unsigned t = atomicAdd(a.finished, 1u);
+    __threadfence_system();   // release: this proposal's mask byte is in host memory before the count moves
+    const unsigned t = __hip_atomic_fetch_add(a.finished, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     last = t == (unsigned)a.np - 1u;
     if (last) *a.finished = 0u;
   }
   if (last) {
-    __threadfence_system();
+    __threadfence_system();   // acquire side of the other workgroups' releases + release of this one's byte
     __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }

@@ -331,10 +331,6 @@ static hipError_t launch_sweep_t(const FilterArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-bool sweep_available(int ks, const FilterArgs &a) {
-  return ks >= 1 && ks <= 9 && (long long)a.ntiles32 * ks * 1024 < (1ll << 31);   // buffer offsets are 32-bit
-}
-
 // query groups per wave as filter_groups_per_wave(ks, narrow) has them
 hipError_t launch_sweep(int ks, int qw, const FilterArgs &a, hipStream_t s) {
   if (a.ngroups <= 0) return hipSuccess;
