@@ -100,7 +100,7 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   // scratch used by the stateless host-pointer entry points
-  DevBuf src, refT, refR, q, out, flags, sel, selbytes, M, small0, small1, small2, small3, mask, tq;
+  DevBuf src, refT, refR, q, out, flags, sel, selmask, selbytes, M, small0, small1, small2, small3, mask, tq;
   FilterCtx filter;
   // single-launch path for a handful of proposals (mlf_small.hip): pinned, device-mapped staging + two scratch words
   // per proposal
@@ -168,7 +168,7 @@ int stage_live_points(const double *pts, size_t n, size_t d, int dp, int npad, b
   int rc = upload(c.src, pts, n * d * sizeof(double), c.stream);
   if (rc) return rc;
   CK(c.refT.reserve((size_t)npad * dp * sizeof(double)));
-  CK(c.refR.reserve((size_t)npad * dp * sizeof(double)));
+  CK(c.refR.reserve((size_t)(npad + 1) * dp * sizeof(double)));   // k_boot requests the first block of the row after its last
   (void)want_rows;
   launch_build_layouts(c.src.as<double>(), (int)n, (int)d, dp, npad, c.refT.as<double>(),
                        c.refR.as<double>(), c.stream);
@@ -1177,6 +1177,7 @@ int mlf_maxradiussq_bootstrap(const double *pts, size_t n, size_t d, const uint8
   if (int rc = stage_live_points(pts, n, d, dp, npad, true)) return rc;
   if (int rc = upload_any(c.selbytes, selected, B * n, c.stream)) return rc;
   CK(c.sel.reserve((size_t)npad * sizeof(unsigned)));
+  CK(c.selmask.reserve((size_t)(npad + 1) * kBootGroup * sizeof(unsigned)));   // k_boot requests one row past its last
   CK(c.M.reserve((size_t)kBootGroup * npad * sizeof(unsigned long long)));
   CK(c.small0.reserve(B * sizeof(double)));
   CK(c.small1.reserve(B));
@@ -1192,12 +1193,13 @@ int mlf_maxradiussq_bootstrap(const double *pts, size_t n, size_t d, const uint8
   for (size_t b0 = 0; b0 < B; b0 += kBootGroup) {
     const int nb = (int)((B - b0) < (size_t)kBootGroup ? (B - b0) : (size_t)kBootGroup);
     launch_pack_selection(c.selbytes.as<uint8_t>(), (int)n, npad, (int)b0, nb, c.sel.as<unsigned>(),
-                          c.stream);
+                          c.stream, c.selmask.as<unsigned>());
     launch_fill_u64(c.M.as<unsigned long long>(), (long long)kBootGroup * npad, init_bits, c.stream);
     BootArgs a{};
     a.refT = c.refT.as<double>();
     a.refR = c.refR.as<double>();
     a.sel = c.sel.as<unsigned>();
+    a.selmask = c.selmask.as<unsigned>();
     a.n = (int)n;
     a.npad = npad;
     a.chunk = chunk;

@@ -19,11 +19,40 @@
 
 namespace mlf {
 
+// Round 3.  The live point i a wave is working on is the same for all its lanes, so its coordinates and its 32
+// selection words travel through the SCALAR unit (s_load_dwordx16 from refR / selmask, issued one 8-coordinate block
+// ahead of their use) and enter the vector instructions as scalar operands: no LDS tile, no barrier, no ds_read latency
+// for the one or two waves a SIMD holds (round 2: 32-row LDS tiles, two barriers per tile, 40 % of the vector issue
+// slots used).  The masked minimum of round r is  mind[r] = min(mind[r], acc')  with the high word of acc' = high word
+// of acc OR selmask[i][r] (0 if i is selected in round r, 0xffffffff otherwise): an unselected i turns the candidate
+// into a quiet NaN, which v_min_f64 ignores -- 2 vector instructions per round where select + compare + select took
+// 4-5.  The non-NaN candidates are the same binary64 values as before and min is exact: results bit-identical.
+typedef int sgpr16 __attribute__((ext_vector_type(16)));
+typedef int sgpr8 __attribute__((ext_vector_type(8)));
+typedef int sgpr4 __attribute__((ext_vector_type(4)));
+
+// scalar loads are asynchronous: the value may be used only behind sload_wait on the same variable
+#define MLF_SLOAD(SUFFIX, dst, ptr, byteoff)                                                                \
+  do {                                                                                                      \
+    asm volatile("s_load_dword" SUFFIX " %0, %1, %2" : "=s"(dst) : "s"(ptr), "n"(byteoff) : "memory");      \
+    __builtin_amdgcn_sched_barrier(0); /* the request stays in front of the arithmetic it is meant to overlap */ \
+  } while (0)
+
+template <class V>
+__device__ __forceinline__ void sload_wait(V &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)); }
+template <class V, class W>
+__device__ __forceinline__ void sload_wait(V &v, W &w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+s"(w)); }
+template <class V, class W, class X>
+__device__ __forceinline__ void sload_wait(V &v, W &w, X &x) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+s"(w), "+s"(x)); }
+
+template <class V>
+__device__ __forceinline__ double sgpr_double(const V &v, int k) { return __hiloint2double(v[2 * k + 1], v[2 * k]); }
+
 template <int DP>
 __global__ __launch_bounds__(kWave) void k_boot(BootArgs a) {
-  __shared__ __attribute__((aligned(16))) double tile[kBootTI * DP];
-  __shared__ unsigned tsel[kBootTI];
-
+  static_assert(kBootGroup == 32, "two 16-word selection blocks per live point");
+  constexpr int NB = DP / 8;        // full blocks of 8 coordinates
+  constexpr int TAIL = DP - 8 * NB; // 0, 2, 4 or 6 coordinates (DP is even)
   const int lane = threadIdx.x;
   const int j = blockIdx.x * kWave + lane;  // < npad by construction of the grid
   double b[DP];
@@ -38,35 +67,99 @@ __global__ __launch_bounds__(kWave) void k_boot(BootArgs a) {
   const int i_begin = blockIdx.y * a.chunk;
   int i_end = i_begin + a.chunk;
   if (i_end > a.n) i_end = a.n;
+  if (i_begin >= i_end) return;
 
-  for (int i0 = i_begin; i0 < i_end; i0 += kBootTI) {
-    __syncthreads();
-    // rows i0 .. i0+TI-1 of refR are contiguous (npad >= i0+TI because chunk and npad are
-    // multiples of kBootTI)
-    const double *src = a.refR + (size_t)i0 * DP;
-    for (int e = lane; e < kBootTI * DP; e += kWave) tile[e] = src[e];
-    if (lane < kBootTI) tsel[lane] = a.sel[i0 + lane];
-    __syncthreads();
+  const double *row = a.refR + (size_t)i_begin * DP;             // wave-uniform
+  const unsigned *mk = a.selmask + (size_t)i_begin * kBootGroup;
+  sgpr16 blk[2];   // two coordinate blocks in flight / in use
+  sgpr8 t8;
+  sgpr4 t4;
+  sgpr16 mlo, mhi;
+  auto issue = [&](int t, const double *r) __attribute__((always_inline)) {   // block t of the row at r
+    if (t < NB) {
+      if (t & 1) MLF_SLOAD("x16", blk[1], r, 0); else MLF_SLOAD("x16", blk[0], r, 0);
+    }
+  };
+  (void)issue;
+  // prologue: block 0 and both selection blocks of the first row
+  MLF_SLOAD("x16", mlo, mk, 0);
+  MLF_SLOAD("x16", mhi, mk, 64);
+  if (NB > 0) MLF_SLOAD("x16", blk[0], row, 0);
+  if (NB > 0) sload_wait(blk[0], mlo, mhi); else sload_wait(mlo, mhi);
 
-    const int nt = (i_end - i0) < kBootTI ? (i_end - i0) : kBootTI;
-    for (int ii = 0; ii < nt; ++ii) {
-      const unsigned si = __builtin_amdgcn_readfirstlane(tsel[ii]);
-      const double2 *row = reinterpret_cast<const double2 *>(tile + ii * DP);
-      double acc = 0.0;
+  for (int i = i_begin; i < i_end; ++i) {
+    const double *nrow = row + DP;   // the rows past i_end - 1 exist (npad rows, or the next chunk's): loaded, never used
+    const unsigned *nmk = mk + kBootGroup;
+    double acc = 0.0;
+    if (NB == 0) {   // d < 8: the row is its own tail
+      if (TAIL >= 4) MLF_SLOAD("x8", t8, row, 0);
+      if (TAIL == 2) MLF_SLOAD("x4", t4, row, 0);
+      if (TAIL == 6) MLF_SLOAD("x4", t4, row, 32);
+      if (TAIL == 2) sload_wait(t4);
+      if (TAIL == 4) sload_wait(t8);
+      if (TAIL == 6) sload_wait(t8, t4);
+    }
+    // coordinate blocks: block t is in blk[t & 1] and ready; block t + 1 is requested before block t is consumed
 #pragma unroll
-      for (int k = 0; k < DP; k += 2) {
-        const double2 v = row[k >> 1];
-        const double d0 = v.x - b[k];
-        acc += d0 * d0;
-        const double d1 = v.y - b[k + 1];
-        acc += d1 * d1;
+    for (int t = 0; t < NB; ++t) {
+      if (t + 1 < NB) {
+        if ((t + 1) & 1) MLF_SLOAD("x16", blk[1], row, 64 * (t + 1)); else MLF_SLOAD("x16", blk[0], row, 64 * (t + 1));
+      } else {
+        if (TAIL >= 4) MLF_SLOAD("x8", t8, row, 64 * NB);
+        if (TAIL == 2) MLF_SLOAD("x4", t4, row, 64 * NB);
+        if (TAIL == 6) MLF_SLOAD("x4", t4, row, 64 * NB + 32);
       }
 #pragma unroll
-      for (int r = 0; r < kBootGroup; ++r) {
-        const double cand = ((si >> r) & 1u) ? acc : 1e300;
-        mind[r] = cand < mind[r] ? cand : mind[r];
+      for (int k = 0; k < 8; ++k) {
+        const double d0 = sgpr_double(blk[t & 1], k) - b[8 * t + k];
+        acc += d0 * d0;
+      }
+      if (t + 1 < NB) {
+        sload_wait(blk[(t + 1) & 1]);
+      } else {
+        if (TAIL == 2) sload_wait(t4);
+        if (TAIL == 4) sload_wait(t8);
+        if (TAIL == 6) sload_wait(t8, t4);
       }
     }
+    // next row's first block travels during the tail coordinates and the first half of the minima
+    if (NB > 0) MLF_SLOAD("x16", blk[0], nrow, 0);
+    if (TAIL >= 4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double d0 = sgpr_double(t8, k) - b[8 * NB + k];
+        acc += d0 * d0;
+      }
+    }
+    if (TAIL == 2 || TAIL == 6) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const double d0 = sgpr_double(t4, k) - b[8 * NB + (TAIL == 6 ? 4 : 0) + k];
+        acc += d0 * d0;
+      }
+    }
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const double cand = __longlong_as_double((long long)(bits | ((unsigned long long)(unsigned)mlo[r] << 32)));
+      double m = mind[r];
+      asm volatile("v_min_f64 %0, %0, %1" : "+v"(m) : "v"(cand));   // NaN candidate: m stays (no canonicalisation)
+      mind[r] = m;
+    }
+    if (NB > 0) sload_wait(blk[0]);
+    MLF_SLOAD("x16", mlo, nmk, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const double cand = __longlong_as_double((long long)(bits | ((unsigned long long)(unsigned)mhi[r] << 32)));
+      double m = mind[16 + r];
+      asm volatile("v_min_f64 %0, %0, %1" : "+v"(m) : "v"(cand));
+      mind[16 + r] = m;
+    }
+    sload_wait(mlo);
+    MLF_SLOAD("x16", mhi, nmk, 64);
+    sload_wait(mhi);
+    row = nrow;
+    mk = nmk;
   }
 
   if (j < a.n) {

@@ -88,6 +88,7 @@ struct BootArgs {
   const double *refT;   // [DP][npad]
   const double *refR;   // [npad][DP]
   const unsigned *sel;  // [npad] bit b set = live point selected in bootstrap round b of this group
+  const unsigned *selmask;  // [npad][kBootGroup] 0 if the live point is selected in the round, 0xffffffff otherwise
   int n, npad;
   int chunk;            // live points per blockIdx.y (multiple of kBootTI)
   unsigned long long *M;  // [kBootGroup][npad] running minima as ordered bit patterns

@@ -57,9 +57,11 @@ void launch_fill_u64(unsigned long long *p, long long n, unsigned long long v, h
   hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
 }
 
-// (B, n) byte masks -> one 32-bit word per live point, bit r = selected in round b0 + r
+// (B, n) byte masks -> one 32-bit word per live point, bit r = selected in round b0 + r; and, for k_boot, the same bits
+// expanded to one word per (live point, round): 0 = selected, 0xffffffff = not selected (OR-ed into the high word of a
+// candidate distance, the latter turns it into a NaN that the running minimum ignores)
 __global__ void k_pack_selection(const uint8_t *selected, int n, int npad, int b0, int nb,
-                                 unsigned *sel) {
+                                 unsigned *sel, unsigned *selmask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npad) return;
   unsigned w = 0;
@@ -67,12 +69,20 @@ __global__ void k_pack_selection(const uint8_t *selected, int n, int npad, int b
     for (int r = 0; r < nb; ++r)
       if (selected[(long long)(b0 + r) * n + i]) w |= 1u << r;
   sel[i] = w;
+  if (selmask) {
+    uint4 *dst = reinterpret_cast<uint4 *>(selmask + (size_t)i * kBootGroup);
+#pragma unroll
+    for (int q = 0; q < kBootGroup / 4; ++q) {
+      const unsigned nib = ~(w >> (4 * q));
+      dst[q] = make_uint4((nib & 1u) ? ~0u : 0u, (nib & 2u) ? ~0u : 0u, (nib & 4u) ? ~0u : 0u, (nib & 8u) ? ~0u : 0u);
+    }
+  }
 }
 
 void launch_pack_selection(const uint8_t *selected, int n, int npad, int b0, int nb, unsigned *sel,
-                           hipStream_t s) {
+                           hipStream_t s, unsigned *selmask) {
   hipLaunchKernelGGL(k_pack_selection, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s,
-                     selected, n, npad, b0, nb, sel);
+                     selected, n, npad, b0, nb, sel, selmask);
 }
 
 // ------------------------------------------------------- K4 epilogue ---------------------

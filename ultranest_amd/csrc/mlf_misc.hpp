@@ -10,7 +10,7 @@ void launch_update_rows(const double *rows, int count, int d, int dp, int npad, 
                         double *refR, hipStream_t s);
 void launch_fill_u64(unsigned long long *p, long long n, unsigned long long v, hipStream_t s);
 void launch_pack_selection(const uint8_t *selected, int n, int npad, int b0, int nb, unsigned *sel,
-                           hipStream_t s);
+                           hipStream_t s, unsigned *selmask = nullptr);
 void launch_boot_final(const unsigned long long *M, const unsigned *sel, int n, int npad, int nb,
                        double *maxd, uint8_t *skipped, hipStream_t s);
 void launch_subtract_accum(const double *pts, int n, int d, const unsigned long long *flags,
