@@ -702,9 +702,112 @@ __global__ __launch_bounds__(128) void k_loglike(int kind, const double *params,
   if (lane < nrows) like[j0 + lane] = loglike_row(kind, mine + lane * ds, d, aux, sigma);
 }
 
+// Even d <= 128: no staging at all.  A row is read by HW = 2 ... 64 lanes (the smallest power of two with 2 HW >= d), two
+// consecutive coordinates (one 16-byte non-temporal load) per lane, so a wave-wide load covers 64 / HW whole rows =
+// one contiguous piece of the batch; four such loads are in flight per lane before the first is consumed.  The terms
+// of a row are combined across its lanes (sum or product: tolerance class 1e-12, the reference's pairwise numpy sum
+// is not bit-reproduced either way); lane 0 of the row stores the result.  No LDS: 16 waves per SIMD can be resident
+// (the staged kernel above holds 52 KB of LDS per 2 waves: 6 waves per CU, 2.8 TB/s at 10^6 x 50).
+template <int KIND, int HW>
+__global__ __launch_bounds__(256) void k_loglike_rows(const double *__restrict__ params, int d, long long n,
+                                                      const double *__restrict__ aux, double sigma,
+                                                      double *__restrict__ like) {
+  constexpr int RPW = 64 / HW;   // rows per wave-wide load
+  constexpr int U = 4;           // loads in flight per lane
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & (HW - 1), half = lane / HW;
+  const int k0 = 2 * sub;
+  const bool active = k0 < d;
+  const long long nwaves = (long long)gridDim.x * 4;
+  const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  double c0 = 0.0, c1 = 0.0;
+  if (KIND == 0 && active) {
+    c0 = aux[k0];
+    c1 = aux[k0 + 1];
+  }
+  const double gconst = KIND == 0 ? -0.5 * log(2.0 * M_PI * sigma * sigma) * (double)d : 0.0;
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  for (long long base = gw * RPW; base < n; base += nwaves * RPW * U) {
+    dbl2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long r = base + (long long)u * nwaves * RPW + half;
+      v[u] = (dbl2){0.0, 0.0};
+      if (active && r < n) v[u] = __builtin_nontemporal_load(reinterpret_cast<const dbl2 *>(params + r * d) + sub);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long r = base + (long long)u * nwaves * RPW + half;
+      const double x0 = v[u].x, x1 = v[u].y;
+      double acc;
+      if (KIND == 0) {          // docs/gauss.py:25-27
+        const double z0 = (x0 - c0) / sigma, z1 = (x1 - c1) / sigma;
+        acc = active ? z0 * z0 + z1 * z1 : 0.0;
+      } else if (KIND == 1) {   // examples/testeggbox.py:9-11
+        acc = active ? cos(x0 / 2.0) * cos(x1 / 2.0) : 1.0;
+      } else if (KIND == 2) {   // examples/test_PopSliceSampler.py:69-71
+        acc = active ? cos(x0) * cos(x1) : 1.0;
+      } else {                  // examples/testrosenbrock.py:10-13: terms k = 2 sub and 2 sub + 1 (the latter needs x[k0 + 2])
+        const double nx = __shfl_down(x0, 1, HW);
+        const double t0 = x1 - x0 * x0, w0 = 1.0 - x0;
+        const double t1 = nx - x1 * x1, w1 = 1.0 - x1;
+        acc = (k0 + 1 < d) ? 100.0 * (t0 * t0) + w0 * w0 : 0.0;
+        if (k0 + 2 < d) acc += 100.0 * (t1 * t1) + w1 * w1;
+      }
+#pragma unroll
+      for (int o = HW / 2; o > 0; o >>= 1) {
+        const double other = __shfl_xor(acc, o, HW);
+        acc = (KIND == 1 || KIND == 2) ? acc * other : acc + other;
+      }
+      if (sub == 0 && r < n) {
+        double out;
+        if (KIND == 0) {
+          out = -0.5 * acc + gconst;
+        } else if (KIND == 1) {
+          const double b1 = 2.0 + acc, b2 = b1 * b1;
+          out = b2 * b2 * b1;
+        } else if (KIND == 2) {
+          out = acc * acc;
+        } else {
+          out = -2.0 * acc;
+        }
+        like[r] = out;
+      }
+    }
+  }
+}
+
+template <int KIND>
+static void launch_loglike_rows(const double *params, int d, long long n, const double *aux, double sigma, double *like,
+                                hipStream_t s) {
+  int hw = 2;   // lanes per row: the smallest power of two with 2 hw >= d
+  while (2 * hw < d) hw *= 2;
+  const int rpw = 64 / hw;
+  long long waves = (n + rpw * 4 - 1) / (rpw * 4);          // four loads per lane
+  if (waves > 256 * 4 * 8 * 4) waves = 256 * 4 * 8 * 4;      // grid-stride beyond 32 waves per SIMD
+  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  switch (hw) {
+#define MLF_LL(H)                                                                                              \
+  case H:                                                                                                      \
+    hipLaunchKernelGGL((k_loglike_rows<KIND, H>), grid, block, 0, s, params, d, n, aux, sigma, like);          \
+    break;
+    MLF_LL(2) MLF_LL(4) MLF_LL(8) MLF_LL(16) MLF_LL(32) MLF_LL(64)
+#undef MLF_LL
+    default: break;
+  }
+}
+
 void launch_loglike(int kind, const double *params, int d, long long n, const double *aux,
                     double sigma, double *like, hipStream_t s) {
   if (n <= 0) return;
+  if (d % 2 == 0 && d <= 128 && (reinterpret_cast<uintptr_t>(params) & 15u) == 0) {   // rows are 16-byte aligned
+    switch (kind) {
+      case 0: launch_loglike_rows<0>(params, d, n, aux, sigma, like, s); return;
+      case 1: launch_loglike_rows<1>(params, d, n, aux, sigma, like, s); return;
+      case 2: launch_loglike_rows<2>(params, d, n, aux, sigma, like, s); return;
+      default: launch_loglike_rows<3>(params, d, n, aux, sigma, like, s); return;
+    }
+  }
   const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
