@@ -71,14 +71,15 @@ def proposals_in_ellipsoid(region, p, seed, dev):
     return pts.contiguous()
 
 
-def time_rebuild(u, group):
+def time_rebuild(u, group, device_resident=False):
     """Steady-state region rebuild (harness counterpart of the driver's _update_region: LocalAffineLayer
     create_new incl. clustering + subtract_nearby, region ctor, 30 bootstrap rounds, create_ellipsoid,
     inside(live points), shrink test) on the SURVEY 8d rebuild input."""
     import ultranest_amd.mlfriends as M
     from ultranest_amd.harness import RegionUpdater
     rs = np.random.RandomState(7)
-    upd = RegionUpdater(NDIM, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer, group=group)
+    upd = RegionUpdater(NDIM, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer, group=group,
+                        device_resident=device_resident)
     np.random.seed(11)
     t0 = time.perf_counter()
     upd.update(u, nbootstraps=NBOOT, minvol=0.)
@@ -407,6 +408,7 @@ def main():
     }
 
     first_ms, rebuild_ms, rebuild_all = time_rebuild(u, group)
+    _, rebuild_dev_ms, rebuild_dev_all = time_rebuild(u, group, device_resident=True) if world == 1 else (None, None, None)
 
     per_rank = [elapsed_mine]
     per_rank_strong = [(strong_mine, boot_mine)]
@@ -523,6 +525,15 @@ def main():
                                  "to the exact FP64 scan (asserted in this run)"},
         "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
         "rebuild_ms": rebuild_ms, "rebuild_first_ms": first_ms, "rebuild_ms_each": rebuild_all,
+        "rebuild_what": "steady-state rebuild through harness.RegionUpdater (LocalAffineLayer create_new incl. clustering + "
+                        "subtract_nearby, region, 30 bootstrap rounds, wrapping ellipsoid, membership of the live points): "
+                        "DEFAULT path -- every numpy / LAPACK call of the reference kept on the host, T and unormed bit-identical "
+                        "to the reference's",
+        "rebuild_device_resident_ms": rebuild_dev_ms, "rebuild_device_resident_ms_each": rebuild_dev_all,
+        "rebuild_device_resident_what": "the same rebuild with RegionUpdater(device_resident=True) (ultranest_amd.device_rebuild, "
+                                        "opt-in): live points uploaded once, whitening / covariances / clustering / bootstrap on "
+                                        "the device, d x d LAPACK on the host; tolerance class 1e-10 on T, radius, enlargement "
+                                        "instead of bit parity (tests/test_device_rebuild.py); N = 1 only",
         "accept_fraction": accept, "ellipsoid_pass_fraction": ell_pass,
         "kernel_ms": {"per-proposal stage (k_prep4: bounded ellipsoid test + whitening on the matrix cores with split binary16 operands -> f16 "
                       "operand; the ellipsoid band is decided by the tail of the re-check launch)": prep_ms,

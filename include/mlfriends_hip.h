@@ -51,7 +51,7 @@ int mlf_synchronize(void);
  * bounded matrix-core per-proposal stage or the binary64 one), "small_path" (1/0: mlf_region_inside with up to 256
  * proposals as ONE launch over pinned staging -- the calls of the scalar step samplers -- or through the batched
  * pipeline), "filter_first_range_pct" (10 ... 90, default 50: share of the live-point tiles the first of two ranges takes;
- * 35 ... 50 measure the same), "filter_narrow_tail" (0: every range with 4 query groups per wave; 1 (default): later ranges with 2; 2 / 3: with 1 / 3),
+ * 35 ... 50 measure the same), "filter_narrow_tail" (0: every range with 4 query groups per wave; 1 (default): later ranges with 2),
  * "time_filter_launches".  Results never depend on them. */
 int mlf_set_option(const char *name, long long value);
 
@@ -66,8 +66,26 @@ int mlf_count_nearby(const double *apts, size_t na, const double *bpts, size_t n
                      double radiussq, int64_t *out);
 
 /* ---- K3: subtract_nearby -- ultranest/mlfriends.pyx:73-138 ----------------------------------
- * out[j,:] = pts[j,:] - mean of all pts[i,:] with dist2(i,j) <= radiussq (i ascending sum). */
+ * out[j,:] = pts[j,:] - mean of all pts[i,:] with dist2(i,j) <= radiussq (i ascending sum).
+ * Array arguments of the stateless entry points (here: pts, out; mlf_find_nearby: apts, bpts, out; the point arrays of
+ * the bootstrap calls, mlf_affine_transform, the live points of mlf_region_set) may be HOST or DEVICE pointers: a
+ * device-resident caller (ultranest_amd.device_rebuild) keeps them in HBM between calls. */
 int mlf_subtract_nearby(const double *pts, size_t n, size_t d, double radiussq, double *out);
+
+/* ---- H1: the labels of update_clusters -- ultranest/mlfriends.pyx:275-343 ----------------------
+ * Friends-of-friends clusters of tpts with linking length sqrt(radiussq): labels[i] in 1 ... (start at 1; `previous`,
+ * optional, seeds cluster c at the first point that carried label c before, exactly as the reference re-uses old ids
+ * :289-291, :317-320), *nclusters = number of distinct labels.  One all-pairs pass on the device (hit ballots), the
+ * reference's growth rounds replayed on the bit rows on the host.  tpts: host or device; previous / labels: host. */
+int mlf_cluster_labels(const double *tpts, size_t n, size_t d, double radiussq, const int64_t *previous,
+                       int64_t *labels, int64_t *nclusters);
+/* the two halves of mlf_cluster_labels: the adjacency bits (n rows of ceil(n / 64) 64-bit words; bit i of row j: points
+ * i and j are within the radius; *adj_out points into a pinned buffer of the library, valid until the next call of
+ * either function) and the host-only replay of the growth rounds, which touches no device and no library state -- a
+ * caller may run it on another thread next to its device calls (ultranest_amd.device_rebuild does). */
+int mlf_adjacency_bits(const double *pts, size_t n, size_t d, double radiussq, const unsigned long long **adj_out);
+int mlf_host_cluster_replay(const unsigned long long *adj, size_t n, const int64_t *previous, int64_t *labels,
+                            int64_t *nclusters);
 
 /* ---- K4: compute_maxradiussq over bootstrap rounds -- mlfriends.pyx:188-224 called from
  * MLFriends.compute_enlargement :1044-1054 and MLFriends.compute_maxradiussq :1004-1012.
@@ -133,6 +151,10 @@ int mlf_region_set(mlf_region *r, const double *live, size_t n, size_t d, int li
                    int layer_kind, const double *layer_ctr, const double *layer_T,
                    const double *wrap_shift, const double *ell_center, const double *ell_invcov,
                    double enlarge, double radiussq, int use_scan);
+/* optional, before mlf_region_set with `live` on the DEVICE: the largest |live[i][k] - layer_ctr[k]| (it fixes the scale
+ * of the binary16 proposal operand; without the hint the rows are fetched back once to find it).  Consumed by the next
+ * mlf_region_set of the handle. */
+int mlf_region_hint_live_extent(mlf_region *r, double amax);
 /* in-place live point replacement, integrator.py:2753-2754; the row is in the space given by
  * live_space at mlf_region_set */
 int mlf_region_update_point(mlf_region *r, size_t row, const double *live_row);

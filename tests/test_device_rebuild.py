@@ -1,0 +1,100 @@
+"""Opt-in device-resident rebuild (ultranest_amd.device_rebuild) against the default, reference-bit-preserving rebuild:
+same cluster labels, same `np.random` consumption, T / cov / unormed / radius / enlargement / ellipsoid within the
+tolerance class of the mode (1e-10), same accept decision, masks of a proposal batch equal for the region as built
+(checked against the CPU oracle).  Reference: integrator.py:2055-2122, mlfriends.pyx:666-710, 827-850, 1017-1070, 1213-1237."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(n, d, seed, layer_name, blobs=1):
+    import ultranest_amd.mlfriends as M
+    from ultranest_amd.harness import RegionUpdater
+    rs = np.random.RandomState(seed)
+    u = 0.5 + 0.05 * rs.normal(size=(n, d))
+    if blobs == 2:
+        u[: n // 2] += 0.2
+        u[n // 2:] -= 0.2
+    layer_class = getattr(M, layer_name)
+    out = []
+    for device_resident in (False, True):
+        upd = RegionUpdater(d, region_class=M.MLFriends, transform_layer_class=layer_class, device_resident=device_resident)
+        np.random.seed(11)
+        upd.update(u, nbootstraps=30, minvol=0.)
+        rs2 = np.random.RandomState(seed + 1)
+        u2 = u.copy()
+        u2[: n // 10] = u[: n // 10] * 0.9 + 0.05 + 0.002 * rs2.normal(size=(n // 10, d))
+        changed = upd.update(u2, nbootstraps=30, minvol=0.)
+        out.append((upd, changed, np.random.get_state()[2], np.random.uniform()))
+    return u2, out
+
+
+@pytest.mark.parametrize("n,d,layer_name,blobs", [(400, 5, "LocalAffineLayer", 1), (1000, 10, "AffineLayer", 1),
+                                                   (600, 4, "AffineLayer", 2), (2000, 20, "LocalAffineLayer", 1),
+                                                   (4000, 50, "LocalAffineLayer", 1)])
+def test_device_resident_rebuild_matches_default(n, d, layer_name, blobs):
+    from oracle import oracle as orc
+    u2, ((a, ch_a, pos_a, nxt_a), (b, ch_b, pos_b, nxt_b)) = _pair(n, d, 3, layer_name, blobs)
+    assert b._device_rebuild is not None, "the device path did not run"
+    assert ch_a == ch_b
+    assert (pos_a, nxt_a) == (pos_b, nxt_b), "np.random consumed differently"
+    la, lb = a.transformLayer, b.transformLayer
+    assert la.nclusters == lb.nclusters
+    assert np.array_equal(la.clusterids, lb.clusterids)
+    tol = dict(rtol=1e-10, atol=1e-12)
+    assert np.allclose(la.ctr, lb.ctr, **tol)
+    assert np.allclose(la.cov, lb.cov, **tol)
+    assert np.allclose(abs(la.logvolscale - lb.logvolscale), 0, atol=1e-9)
+    # eigenvectors are defined up to sign / order within the tolerance: compare what they generate
+    assert np.allclose(la.T @ la.T.T, lb.T @ lb.T.T, rtol=1e-8, atol=1e-10 * np.abs(la.T @ la.T.T).max())
+    assert np.allclose(lb.T @ lb.invT, np.eye(d), atol=1e-9)
+    ra, rb = a.region, b.region
+    assert np.allclose(np.asarray(ra.u), np.asarray(rb.u), rtol=0, atol=0)
+    assert np.allclose(rb.unormed, lb.transform(np.asarray(rb.u)), rtol=1e-9, atol=1e-11)
+    assert abs(ra.maxradiussq - rb.maxradiussq) <= 1e-6 * ra.maxradiussq      # binary32-rounded maxima of a 1e-10 class input
+    assert abs(ra.enlarge - rb.enlarge) <= 1e-8 * ra.enlarge
+    assert np.allclose(ra.ellipsoid_center, rb.ellipsoid_center, **tol)
+    assert np.allclose(ra.ellipsoid_cov, rb.ellipsoid_cov, **tol)
+    assert np.allclose(ra.ellipsoid_invcov, rb.ellipsoid_invcov, rtol=1e-8, atol=1e-8 * np.abs(ra.ellipsoid_invcov).max())
+    assert np.allclose(ra.estimate_volume(), rb.estimate_volume(), atol=1e-6)
+    assert np.allclose(rb.bbox_lo, rb.unormed.min(axis=0)) and np.allclose(rb.bbox_hi, rb.unormed.max(axis=0))
+    # the region as built answers exactly like the oracle on ITS OWN attributes
+    rs = np.random.RandomState(9)
+    pts = np.asarray(rb.u)[rs.randint(n, size=3000)] + 0.01 * rs.normal(size=(3000, d))
+    got = rb.inside(pts)
+    # live points whitened on the device (FMA chain): the oracle gets the same layer and whitens the same way
+    want = orc.region_inside(pts, orc.affine_transform(np.asarray(rb.u), lb.ctr, lb.T), lb.ctr, lb.T, rb.ellipsoid_center,
+                             rb.ellipsoid_invcov, rb.enlarge, rb.maxradiussq)
+    assert np.array_equal(got, want)
+    assert rb.inside(np.asarray(rb.u)).all() == ra.inside(np.asarray(ra.u)).all()
+    # in-place replacement of a live point afterwards is tracked like on any region
+    rb.u[3] = rb.u[5]
+    assert rb.inside(np.asarray(rb.u)[3:4])[0] == rb.inside(np.asarray(rb.u)[5:6])[0]
+
+
+def test_cluster_labels_equal_update_clusters():
+    """mlf_cluster_labels replays update_clusters' growth rounds: labels, numbering, carried-over seeds."""
+    import ctypes
+    from ultranest_amd import _lib
+    from ultranest_amd.layers import update_clusters
+    rs = np.random.RandomState(4)
+    for case in range(6):
+        n, d = 300 + 50 * case, 3
+        centres = rs.uniform(size=(4, d))
+        t = centres[rs.randint(4, size=n)] + 0.02 * rs.normal(size=(n, d))
+        r2 = 0.0015 * (1 + case)
+        prev = None if case % 2 == 0 else rs.randint(1, 6, size=n).astype(np.int64)
+        ncl, ids, _ = update_clusters(t, t, r2, prev)
+        labels = np.empty(n, dtype=np.int64)
+        k = ctypes.c_int64(0)
+        _lib.check(_lib.lib().mlf_cluster_labels(_lib.ptr(t), n, d, r2, _lib.ptr(prev), _lib.ptr(labels), ctypes.byref(k)))
+        assert np.array_equal(ids, labels), case
+        assert ncl == k.value

@@ -31,6 +31,10 @@ SIGNATURES = {
     "mlf_find_nearby": [_vp, _sz, _vp, _sz, _sz, _dbl, _vp],
     "mlf_count_nearby": [_vp, _sz, _vp, _sz, _sz, _dbl, _vp],
     "mlf_subtract_nearby": [_vp, _sz, _sz, _dbl, _vp],
+    "mlf_cluster_labels": [_vp, _sz, _sz, _dbl, _vp, _vp, _vp],
+    "mlf_adjacency_bits": [_vp, _sz, _sz, _dbl, _vp],
+    "mlf_host_cluster_replay": [_vp, _sz, _vp, _vp, _vp],
+    "mlf_region_hint_live_extent": [_vp, _dbl],
     "mlf_maxradiussq_bootstrap": [_vp, _sz, _sz, _vp, _sz, _vp, _vp],
     "mlf_pair_dist2_lower": [_vp, _sz, _sz, _vp],
     "mlf_inside_ellipsoid": [_vp, _sz, _sz, _vp, _vp, _dbl, _vp, _vp],

@@ -86,7 +86,6 @@ int g_filter_phases = 1;              // mlf_set_option("filter_phases", n): 0 s
 long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
 bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
 bool g_time_filter_launches = false;  // mlf_set_option("time_filter_launches", 0/1): event pairs around every k_filter launch of every call
-int g_filter_debug = 0;                // timing builds only
 int g_filter_first_range_pct = 50;     // mlf_set_option("filter_first_range_pct", 10 ... 90): share of the live-point tiles in the first of two ranges
 int g_filter_narrow_tail = 1;          // mlf_set_option("filter_narrow_tail", 0/1): later ranges of a phased sweep with 2 query groups per wave
 bool g_small_path = true;             // mlf_set_option("small_path", 0/1): one launch for up to 256 proposals handed over on the host
@@ -100,6 +99,8 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   // scratch used by the stateless host-pointer entry points
+  unsigned long long *pin_adj = nullptr;   // pinned host copy of the adjacency bits (mlf_cluster_labels)
+  size_t pin_adj_cap = 0;
   DevBuf src, refT, refR, q, out, flags, sel, selmask, selbytes, M, small0, small1, small2, small3, mask, tq;
   FilterCtx filter;
   // single-launch path for a handful of proposals (mlf_small.hip): pinned, device-mapped staging + two scratch words
@@ -142,10 +143,50 @@ std::vector<double> pad_vector(const double *v, int d, int dp, double fill = 0.0
   return o;
 }
 
-int upload(DevBuf &b, const void *host, size_t bytes, hipStream_t s) {
+// `src` may be a host or a device pointer (unified addressing picks the direction): the array arguments of the
+// stateless entry points can stay on the device between calls (device-resident rebuild, ultranest_amd.device_rebuild)
+// Pinned staging for the many small constant uploads of one call (mlf_region_set sends ~14 matrices and fragment sets):
+// while an arena is active, a small upload copies its source into the arena and leaves from there -- truly
+// asynchronous, so the caller needs no stream synchronisation before its host vectors go out of scope (round 2: nine
+// synchronisations and a dozen pageable copies, 0.2 of the call's 0.6 ms).  The arena is rewound by the caller once the
+// stream has been synchronised.
+struct HostArena {
+  unsigned char *p = nullptr;
+  size_t cap = 0, used = 0;
+  void *take(size_t bytes) {
+    const size_t at = (used + 63) / 64 * 64;
+    if (!p || at + bytes > cap) return nullptr;
+    used = at + bytes;
+    return p + at;
+  }
+};
+HostArena *g_arena = nullptr;
+constexpr size_t kArenaBytes = 1u << 20, kArenaMaxPiece = 128u << 10;
+
+bool arena_active() { return g_arena != nullptr; }
+
+int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t s) {
   CK(b.reserve(bytes ? bytes : 1));
-  if (bytes) CK(hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, s));
+  if (!bytes) return 0;
+  if (g_arena && bytes <= kArenaMaxPiece) {
+    if (void *stage = g_arena->take(bytes)) {
+      memcpy(stage, src, bytes);
+      CK(hipMemcpyAsync(b.p, stage, bytes, hipMemcpyHostToDevice, s));
+      return 0;
+    }
+  }
+  CK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyDefault, s));
+  if (g_arena) CK(hipStreamSynchronize(s));   // did not fit: the caller relies on the source being consumed
   return 0;
+}
+
+bool is_device_pointer(const void *p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();   // plain host memory the runtime has never seen
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice;
 }
 
 // like upload(), but `src` may be a host OR a device pointer (unified addressing picks the direction): the bootstrap
@@ -302,7 +343,6 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   fa.seg_cap = cap;
   fa.seg_count = f.segcnt.as<unsigned>();
   fa.counters = f.counters.as<unsigned>();
-  fa.dbg = g_filter_debug;
   // Phased sweep: the live-point tiles are split into nphase ranges; after each range the queries that
   // are decided (certain hit) leave, the rest is compacted into fresh 32-query groups.  Every launch
   // is sized for the worst case and reads the actual group count from device memory: no host sync.
@@ -330,7 +370,6 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   // two ranges, compaction inside the first, finalise tail in the scan launch: nobody pads the compacted set or publishes
   // its group count (k_phase_finish: a 5 us launch) -- the second range reads the slot counter itself, the tail resets it
   const bool fold_finish = fused && nphase == 2 && xs != nullptr;
-  if (getenv("MLF_DEBUG_RESET") && fold_finish) CK(hipMemsetAsync(f.png.as<unsigned>() + 2, 0, sizeof(unsigned), s));
 
   for (int ph = 0; ph < nphase; ++ph) {
     fa.tile0 = (int)((long long)f.ntiles32 * ph / nphase);
@@ -554,7 +593,7 @@ int scan_host(const double *apts, size_t na, const double *bpts, size_t nb, size
     }
   }
   if (!filtered) CK(launch_scan(dp, a, c.stream));
-  CK(hipMemcpyAsync(out, c.out.p, nb * sizeof(long long), hipMemcpyDeviceToHost, c.stream));
+  CK(hipMemcpyAsync(out, c.out.p, nb * sizeof(long long), hipMemcpyDefault, c.stream));   // host or device destination
   CK(hipStreamSynchronize(c.stream));
   return 0;
 }
@@ -565,7 +604,7 @@ int prep_consts(DevBuf &ctr_b, DevBuf &mat_b, const double *ctr, const double *m
   std::vector<double> pm = pad_matrix(mat, d, dp, transpose);
   if (int rc = upload(ctr_b, pc.data(), pc.size() * sizeof(double), s)) return rc;
   if (int rc = upload(mat_b, pm.data(), pm.size() * sizeof(double), s)) return rc;
-  CK(hipStreamSynchronize(s));  // host vectors go out of scope
+  if (!arena_active()) CK(hipStreamSynchronize(s));  // host vectors go out of scope
   return 0;
 }
 
@@ -578,6 +617,8 @@ struct mlf_region {
   int layer_kind = 0, use_scan = 1, live_space = 0;
   bool has_wrap = false;
   double enlarge = 0.0, r2 = 0.0;
+  double live_extent_hint = -1.0;   // mlf_region_hint_live_extent, consumed by the next mlf_region_set
+  HostArena arena;                  // pinned staging of the constants sent by mlf_region_set
   DevBuf refT, refR, lay_ctr, lay_mat, lay_T8, wrap, ell_ctr, ell_A, ell_Lt, ell_LtF, lay_TtF;
   bool chol_ready = false, chol_ok = false;
   double ell_eps_scale = 0.0;
@@ -642,7 +683,7 @@ int region_prep4_centres(mlf_region *r, hipStream_t s) {
   r->p4c.s0n = f32_up(std::sqrt(s0n2) * (1.0 + 1e-12));
   r->p4c.y0n = f32_up(std::sqrt(y0n2) * (1.0 + 1e-12));
   if (int rc = upload(r->p4_y0, y0f.data(), y0f.size() * sizeof(float), s)) return rc;
-  CK(hipStreamSynchronize(s));
+  if (!arena_active()) CK(hipStreamSynchronize(s));
   return 0;
 }
 
@@ -701,7 +742,7 @@ int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2,
     for (int j = 0; j < d; ++j)
       for (int k = 0; k <= j; ++k) lrm[(size_t)j * dp + k] = L[(size_t)j * d + k];
     if (int rc = upload(r->ell_L, lrm.data(), lrm.size() * sizeof(double), s)) return rc;
-    CK(hipStreamSynchronize(s));
+    if (!arena_active()) CK(hipStreamSynchronize(s));
   }
   std::vector<uint16_t> ltf(prep4_ltf_count(dp));
   const double el = prep4_lt_fragments(L.data(), d, dp, sl, ltf.data());
@@ -738,7 +779,7 @@ int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2,
       for (int c2 = 0; c2 < d; ++c2) t64[(size_t)k * 64 + c2] = layer_T[(size_t)k * d + c2];
     if (int rc = upload(r->lay_T64, t64.data(), t64.size() * sizeof(double), s)) return rc;
   }
-  CK(hipStreamSynchronize(s));
+  if (!arena_active()) CK(hipStreamSynchronize(s));
   r->p4_ready = true;
   return region_prep4_centres(r, s);
 }
@@ -1058,10 +1099,6 @@ int mlf_set_option(const char *name, long long value) {
     g_filter_enabled = value != 0;
     return 0;
   }
-  if (!strcmp(name, "filter_debug")) {
-    g_filter_debug = (int)value;
-    return 0;
-  }
   if (!strcmp(name, "filter_first_range_pct")) {
     g_filter_first_range_pct = value < 10 ? 10 : (value > 90 ? 90 : (int)value);
     return 0;
@@ -1159,9 +1196,133 @@ int mlf_subtract_nearby(const double *pts, size_t n, size_t d, double radiussq, 
   launch_subtract_accum(c.src.as<double>(), (int)n, (int)d, c.flags.as<unsigned long long>(), ntiles,
                         c.out.as<double>(), c.stream);
   CK(hipGetLastError());
-  CK(hipMemcpyAsync(out, c.out.p, n * d * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  CK(hipMemcpyAsync(out, c.out.p, n * d * sizeof(double), hipMemcpyDefault, c.stream));   // host or device destination
   CK(hipStreamSynchronize(c.stream));
   return 0;
+}
+
+// ------------------------------------------------------------------------------ H1 ---------
+// Friends-of-friends labels of update_clusters (mlfriends.pyx:275-343) from ONE all-pairs pass: the hit ballots of
+// every point against every point (k_scan, mode FLAGS: the adjacency matrix as n x ntiles 64-bit words) come back to
+// the host, where the reference's growth rounds -- members of the current cluster against the unlabelled points, a new
+// cluster seeded when nothing joins -- are replayed on the bit rows.  Distances are symmetric bit for bit, so a round
+// joins exactly the points the reference's find_nearby call reports; labels, their numbering and the carried-over
+// seeds (previous ids) are the reference's.
+int mlf_adjacency_bits(const double *pts, size_t n, size_t d, double radiussq, const unsigned long long **adj_out) {
+  if (int rc = check_dims(d)) return rc;
+  if (!pts || !adj_out || n == 0) return fail_arg(MLF_E_BADARG, "null pointer or no points");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  const int dp = pick_dp((int)d);
+  const int npad = round_up((int)n, kWave);
+  const int ntiles = npad / kWave;
+  if (int rc = stage_live_points(pts, n, d, dp, npad, false)) return rc;
+  CK(c.flags.reserve(n * (size_t)ntiles * sizeof(unsigned long long)));
+  ScanArgs a{};
+  a.refT = c.refT.as<double>();
+  a.n = (int)n;
+  a.npad = npad;
+  a.ntiles = ntiles;
+  a.q = c.src.as<double>();
+  a.ldq = (long long)d;
+  a.nq = (long long)n;
+  a.d = (int)d;
+  a.r2 = radiussq;
+  a.mode = SCAN_FLAGS;
+  a.out_flags = c.flags.as<unsigned long long>();
+  CK(launch_scan(dp, a, c.stream));
+  const size_t nwords = n * (size_t)ntiles;
+  if (c.pin_adj_cap < nwords) {   // pinned landing buffer for the bit matrix (2 MB at n = 4000), kept for the next call
+    if (c.pin_adj) (void)hipHostFree(c.pin_adj);
+    c.pin_adj = nullptr;
+    c.pin_adj_cap = 0;
+    CK(hipHostMalloc(reinterpret_cast<void **>(&c.pin_adj), nwords * sizeof(unsigned long long), hipHostMallocDefault));
+    c.pin_adj_cap = nwords;
+  }
+  CK(hipMemcpyAsync(c.pin_adj, c.flags.p, nwords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+  *adj_out = c.pin_adj;
+  return 0;
+}
+
+// Host only (no device, no library state: may run on another thread next to device calls).
+int mlf_host_cluster_replay(const unsigned long long *adj, size_t n, const int64_t *previous, int64_t *labels,
+                            int64_t *nclusters) {
+  if (!adj || !labels || !nclusters || n == 0) return fail_arg(MLF_E_BADARG, "null pointer or no points");
+  const int ntiles = (int)((n + 63) / 64);
+  // reach = union of the adjacency rows of all members of the current cluster (each member's row is OR-ed in once,
+  // when it joins): a growth round joins the unlabelled points inside `reach` -- the points the reference's
+  // find_nearby(members, unlabelled) call reports -- and then adds their rows
+  std::vector<unsigned long long> reach_v((size_t)ntiles, 0ull), unl((size_t)ntiles, 0ull);
+  unsigned long long *__restrict__ reach = reach_v.data();
+  std::vector<size_t> fresh;
+  for (size_t i = 0; i < n; ++i) {
+    labels[i] = 0;
+    unl[i >> 6] |= 1ull << (i & 63);
+  }
+  size_t nlabelled = 0;
+  auto seed_for = [&](int64_t cid, size_t fallback) {
+    if (previous)
+      for (size_t i = 0; i < n; ++i)
+        if (previous[i] == cid) return i;
+    return fallback;
+  };
+  auto add_member = [&](size_t i) {
+    const unsigned long long *__restrict__ row = adj + i * (size_t)ntiles;
+#pragma clang loop vectorize(enable)
+    for (int t = 0; t < ntiles; ++t) reach[t] |= row[t];
+  };
+  int64_t current = 1;
+  auto plant = [&](size_t i) {   // a carried-over seed may already wear an earlier label: it is re-labelled, as in the reference
+    if (labels[i] == 0) {
+      ++nlabelled;
+      unl[i >> 6] &= ~(1ull << (i & 63));
+    }
+    labels[i] = current;
+    for (int t = 0; t < ntiles; ++t) reach[t] = 0ull;
+    add_member(i);
+  };
+  plant(seed_for(current, 0));
+  while (nlabelled < n) {
+    fresh.clear();
+    for (int t = 0; t < ntiles; ++t) {
+      unsigned long long w = reach[t] & unl[t];
+      while (w) {
+        const int b = __builtin_ctzll(w);
+        w &= w - 1ull;
+        fresh.push_back((size_t)t * 64 + (size_t)b);
+      }
+    }
+    if (!fresh.empty()) {
+      for (size_t j : fresh) {
+        labels[j] = current;
+        unl[j >> 6] &= ~(1ull << (j & 63));
+      }
+      nlabelled += fresh.size();
+      for (size_t j : fresh) add_member(j);
+    } else {
+      ++current;
+      size_t first = 0;
+      while (first < n && labels[first] != 0) ++first;
+      plant(seed_for(current, first));
+    }
+  }
+  std::vector<char> seen((size_t)current + 1, 0);   // number of DISTINCT labels (a re-labelled seed can empty a cluster)
+  int64_t distinct = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (!seen[(size_t)labels[i]]) {
+      seen[(size_t)labels[i]] = 1;
+      ++distinct;
+    }
+  *nclusters = distinct;
+  return 0;
+}
+
+int mlf_cluster_labels(const double *tpts, size_t n, size_t d, double radiussq, const int64_t *previous, int64_t *labels,
+                       int64_t *nclusters) {
+  const unsigned long long *adj = nullptr;
+  if (int rc = mlf_adjacency_bits(tpts, n, d, radiussq, &adj)) return rc;
+  return mlf_host_cluster_replay(adj, n, previous, labels, nclusters);
 }
 
 // ------------------------------------------------------------------------------ K4 ---------
@@ -1291,7 +1452,7 @@ int mlf_affine_transform(const double *pts, size_t np, size_t d, const double *c
   a.t_out = c.out.as<double>();
   a.ldt = (long long)d;
   CK(launch_prep(dp, a, c.stream));
-  CK(hipMemcpyAsync(out, c.out.p, np * d * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  CK(hipMemcpyAsync(out, c.out.p, np * d * sizeof(double), hipMemcpyDefault, c.stream));
   CK(hipStreamSynchronize(c.stream));
   return 0;
 }
@@ -1417,6 +1578,7 @@ int mlf_region_destroy(mlf_region *r) {
   for (DevBuf *b : bufs) b->release();
   for (hipEvent_t e : r->events) (void)hipEventDestroy(e);
   r->filter.release();
+  if (r->arena.p) (void)hipHostFree(r->arena.p);
   delete r;
   return 0;
 }
@@ -1433,6 +1595,17 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
   if (layer_kind != 0 && layer_kind != 1) return fail_arg(MLF_E_BADARG, "layer_kind must be 0 or 1");
   if (int rc = ensure_ctx()) return rc;
   Ctx &c = g_ctx;
+  if (!r->arena.p) {   // pinned staging of the constants (kept with the handle; handles are recycled)
+    if (hipHostMalloc(reinterpret_cast<void **>(&r->arena.p), kArenaBytes, hipHostMallocDefault) == hipSuccess)
+      r->arena.cap = kArenaBytes;
+    else
+      (void)hipGetLastError();
+  }
+  r->arena.used = 0;
+  struct ArenaScope {   // every exit path of this call drops the arena
+    explicit ArenaScope(HostArena *a) { g_arena = a->p ? a : nullptr; }
+    ~ArenaScope() { g_arena = nullptr; }
+  } arena_scope(&r->arena);
   r->ready = false;
   r->axes_ready = r->sampling_ready = false;   // a handle may be set again for another region (kernels.DeviceRegion recycles them)
   r->n = (int)n;
@@ -1488,7 +1661,7 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
       prep3_fragments(L.data(), (int)d, true, true, frag.data());
       if (int rc = upload(r->ell_LtF, frag.data(), frag.size() * sizeof(double), c.stream)) return rc;
     }
-    CK(hipStreamSynchronize(c.stream));
+    if (!arena_active()) CK(hipStreamSynchronize(c.stream));
     r->chol_ready = true;
   }
   if (use_scan) {
@@ -1505,7 +1678,7 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
         prep3_fragments(layer_T, (int)d, true, false, frag.data());
         if (int rc = upload(r->lay_TtF, frag.data(), frag.size() * sizeof(double), c.stream)) return rc;
       }
-      CK(hipStreamSynchronize(c.stream));
+      if (!arena_active()) CK(hipStreamSynchronize(c.stream));
     } else {
       if (int rc = upload(r->lay_ctr, layer_ctr, d * sizeof(double), c.stream)) return rc;
       if (int rc = upload(r->lay_mat, layer_T, d * sizeof(double), c.stream)) return rc;
@@ -1513,7 +1686,7 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
     if (wrap_shift) {
       std::vector<double> w = pad_vector(wrap_shift, (int)d, dp, NAN);
       if (int rc = upload(r->wrap, w.data(), w.size() * sizeof(double), c.stream)) return rc;
-      CK(hipStreamSynchronize(c.stream));  // w goes out of scope
+      if (!arena_active()) CK(hipStreamSynchronize(c.stream));  // w goes out of scope
     }
     if (int rc = upload(c.src, unormed, n * d * sizeof(double), c.stream)) return rc;
     const double *rows = c.src.as<double>();
@@ -1530,9 +1703,26 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
     if (int rc = filter_prepare_refs(r->filter, r->refR.as<double>(), (int)n, (int)d, dp, c.stream, true))
       return rc;
   }
-  if (int rc = region_prep4_setup(r, L, fro_sq, ell_center, layer_ctr, layer_T, (use_scan && live_space) ? unormed : nullptr,
-                                  n, c.stream))
-    return rc;
+  {
+    size_t n_for_scale = n;
+    const double *live_host = (use_scan && live_space) ? unormed : nullptr;
+    std::vector<double> back;
+    const double hint = r->live_extent_hint;
+    r->live_extent_hint = -1.0;
+    if (live_host && hint > 0.0 && std::isfinite(hint)) {   // the caller knows the extent: one fictitious row carries it
+      back.assign(d, 0.0);
+      for (size_t k = 0; k < d; ++k) back[k] = layer_ctr[k];
+      back[0] = layer_ctr[0] + hint;
+      live_host = back.data();
+      n_for_scale = 1;
+    } else if (live_host && is_device_pointer(live_host)) {   // the operand scale is found on the host: fetch the rows once
+      back.resize(n * d);
+      CK(hipMemcpyAsync(back.data(), unormed, n * d * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+      CK(hipStreamSynchronize(c.stream));
+      live_host = back.data();
+    }
+    if (int rc = region_prep4_setup(r, L, fro_sq, ell_center, layer_ctr, layer_T, live_host, n_for_scale, c.stream)) return rc;
+  }
   CK(hipStreamSynchronize(c.stream));
   r->ready = true;
   return 0;
@@ -1550,6 +1740,12 @@ static int small_staging(Ctx &c) {
   CK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c.pin_mask_dev), c.pin_mask, 0));
   CK(c.small_words.reserve(2 * kSmallMaxPoints * sizeof(unsigned)));
   CK(hipMemsetAsync(c.small_words.p, 0, 2 * kSmallMaxPoints * sizeof(unsigned), c.stream));
+  return 0;
+}
+
+int mlf_region_hint_live_extent(mlf_region *r, double amax) {
+  if (!r) return fail_arg(MLF_E_BADARG, "null region");
+  r->live_extent_hint = amax;
   return 0;
 }
 

@@ -40,7 +40,6 @@ struct FilterArgs {
   long long seg_first_extra, seg_extra;
   // tile ranges of a non-compacting launch (grid.y); list segment of (wave, range) = wave + range * 4 * grid.x
   int split;
-  int dbg;   // timing builds only (mlf_set_option("filter_debug")): 1 no compaction stores, 2 two tiles only, 4 no query operands
 };
 // after a compacting launch: group count of the compacted set, padding of its last group, counter reset
 void launch_phase_finish(void *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount, unsigned *ngroups_dst,

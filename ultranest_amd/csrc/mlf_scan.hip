@@ -135,7 +135,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
   __syncthreads();
 
   const int mode = a.mode;
-  for (int t = wave; t < a.ntiles; t += kScanThreads / kWave) {
+  // FLAGS launches may split the live-point tiles over gridDim.y (every (query, tile) ballot is its own output word:
+  // no state crosses tiles): an all-pairs pass over a few thousand points is then 4 waves per SIMD instead of one
+  const int t_lo = (int)((long long)a.ntiles * blockIdx.y / gridDim.y), t_hi = (int)((long long)a.ntiles * (blockIdx.y + 1) / gridDim.y);
+  for (int t = t_lo + wave; t < t_hi; t += kScanThreads / kWave) {
     const int base = t * kWave;
     double r[DP];
 #pragma unroll
@@ -205,6 +208,13 @@ hipError_t launch_scan(int dp, const ScanArgs &a_in, hipStream_t s) {
     grid += (unsigned)((a.nq + 4 * kScanThreads - 1) / (4 * kScanThreads));
   }
   const bool extra = a.fin_best || a.route || a.any_flag || a.raw_ctr;
+  unsigned ny = 1;
+  if (a.mode == SCAN_FLAGS && !extra) {   // aim at ~4 waves per SIMD (4096 waves), at least 4 tiles per range
+    ny = 4096u / (grid * 4u > 0u ? grid * 4u : 1u);
+    if (ny > (unsigned)(a.ntiles / 4)) ny = (unsigned)(a.ntiles / 4);
+    if (ny < 1u) ny = 1u;
+    if (ny > 16u) ny = 16u;
+  }
 
   switch (dp) {
 #define X(D)                                                                          \
@@ -215,9 +225,9 @@ hipError_t launch_scan(int dp, const ScanArgs &a_in, hipStream_t s) {
       else                                                                            \
         hipLaunchKernelGGL((k_scan<D, kScanQB, true>), dim3(grid), dim3(kScanThreads), 0, s, a); \
     } else if (small) {                                                               \
-      hipLaunchKernelGGL((k_scan<D, 16, false>), dim3(grid), dim3(kScanThreads), 0, s, a);       \
+      hipLaunchKernelGGL((k_scan<D, 16, false>), dim3(grid, ny), dim3(kScanThreads), 0, s, a);       \
     } else {                                                                          \
-      hipLaunchKernelGGL((k_scan<D, kScanQB, false>), dim3(grid), dim3(kScanThreads), 0, s, a);  \
+      hipLaunchKernelGGL((k_scan<D, kScanQB, false>), dim3(grid, ny), dim3(kScanThreads), 0, s, a);  \
     }                                                                                 \
     break;
     MLF_FOR_EACH_DP(X)

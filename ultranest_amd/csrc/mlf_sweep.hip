@@ -102,13 +102,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sweep_waves
 #pragma unroll
   for (int g = 0; g < QW; ++g) {
     const long long grp = (g0 + g < ngroups) ? g0 + g : ngroups - 1;  // clamp (results discarded)
-    if (!(a.dbg & 4)) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) bq[g][s] = qF[((size_t)grp * KS + s) * 64 + lane];
-    }
+    for (int s = 0; s < KS; ++s) bq[g][s] = qF[((size_t)grp * KS + s) * 64 + lane];
     const long long qi = grp * 32 + (lane & 31);
     // slots past the count of an unpadded last group: thresholds -1 AND a zero operand (Dt = 0 exactly, as in a padded group)
-    const bool have = g0 + g < ngroups && (nslots < 0 || qi < nslots) && !(a.dbg & 4);
+    const bool have = g0 + g < ngroups && (nslots < 0 || qi < nslots);
     tlo[g] = have ? a.tlo[qi] : -1.0f;
     thi[g] = have ? a.thi[qi] : -1.0f;
     if (!have) {
@@ -126,8 +124,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sweep_waves
   const int ntl_all = a.tile1 - a.tile0;
   const int tile0 = a.tile0 + (int)((long long)ntl_all * sub / nsub);
   const int tile1 = a.tile0 + (int)((long long)ntl_all * (sub + 1) / nsub);
-  const int ntl = (a.dbg & 2) ? 2 : tile1 - tile0;
-  const int tstart = (a.dbg & 16) ? tile0 : tile0 + (int)(((long long)blockIdx.x * 37) % ntl);
+  const int ntl = tile1 - tile0;
+  const int tstart = tile0 + (int)(((long long)blockIdx.x * 37) % ntl);
   constexpr int kTileBytes = KS * 1024;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.refF), 0, a.ntiles32 * kTileBytes, 0x00020000);
@@ -247,14 +245,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sweep_waves
     } else {
       int off = tstart * kTileBytes;
       load_tile<KS>(A0, rsrc, voff, off);
-      if (a.dbg & 8) load_tile<KS>(A1, rsrc, voff, off);
       for (int it = 0; it < ntl; it += 2) {
         const int offn = next_off(off);
-        if (!(a.dbg & 8)) load_tile<KS>(A1, rsrc, voff, offn);   // in flight while this tile is multiplied
+        load_tile<KS>(A1, rsrc, voff, offn);   // in flight while this tile is multiplied
         tile(A0, off);
         if (it + 1 >= ntl) break;
         off = next_off(offn);
-        if (!(a.dbg & 8)) load_tile<KS>(A0, rsrc, voff, off);
+        load_tile<KS>(A0, rsrc, voff, off);
         tile(A1, offn);
       }
     }
@@ -279,7 +276,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sweep_waves
       qid[g] = (int)qi;
     }
   }
-  if (COMPACT && !(a.dbg & 1)) {
+  if (COMPACT) {
     unsigned total = 0;
 #pragma unroll
     for (int g = 0; g < QW; ++g) total += (unsigned)__popc(keepm[g]);

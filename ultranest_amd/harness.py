@@ -17,16 +17,31 @@ class RegionUpdater(object):
     current live points."""
 
     def __init__(self, x_dim, region_class=MLFriends, transform_layer_class=LocalAffineLayer,
-                 wrapped_axes=(), group=None, build_tregion=True):
+                 wrapped_axes=(), group=None, build_tregion=True, device_resident=False):
         self.x_dim = x_dim
         self.region_class = region_class
         self.transform_layer_class = transform_layer_class
         self.wrapped_axes = list(wrapped_axes)
         self.group = group
         self.build_tregion = build_tregion
+        # opt-in: the steady-state rebuild with the live points resident in HBM (ultranest_amd.device_rebuild: tolerance
+        # class 1e-10 on T / radius instead of the default path's bit parity with the reference's numpy calls)
+        self.device_resident = bool(device_resident)
+        self._device_rebuild = None
         self.region = None
         self.transformLayer = None
         self.tregion = None
+
+    def _use_device_rebuild(self, minvol):
+        if not self.device_resident:
+            return False
+        from . import device_rebuild
+        size = distributed.world(self.group)[1]
+        if not device_rebuild.supported(self.transformLayer, self.region_class, self.x_dim, minvol, size):
+            return False
+        if self._device_rebuild is None:
+            self._device_rebuild = device_rebuild.DeviceRebuild()
+        return True
 
     def _bootstrap(self, region, nbootstraps, minvol):
         return distributed.update_region_bootstrap(region, nbootstraps, minvol, group=self.group)
@@ -72,13 +87,19 @@ class RegionUpdater(object):
 
         with np.errstate(all='raise'):
             try:
-                nxt_layer = self.transformLayer.create_new(active_u, self.region.maxradiussq, minvol=minvol)
-                assert not (nxt_layer.clusterids == 0).any()
-                _, sizes = np.unique(nxt_layer.clusterids, return_counts=True)
-                nxt = self.region_class(active_u, nxt_layer)
-                self._bootstrap(nxt, nbootstraps, minvol)
-                nxt.create_ellipsoid(minvol=minvol)
-                contains_live = nxt.inside(active_u).all()
+                if self._use_device_rebuild(minvol):
+                    nxt_layer, nxt, contains_live = self._device_rebuild.next_region(
+                        active_u, self.transformLayer, self.region.maxradiussq, nbootstraps)
+                    assert not (nxt_layer.clusterids == 0).any()
+                    _, sizes = np.unique(nxt_layer.clusterids, return_counts=True)
+                else:
+                    nxt_layer = self.transformLayer.create_new(active_u, self.region.maxradiussq, minvol=minvol)
+                    assert not (nxt_layer.clusterids == 0).any()
+                    _, sizes = np.unique(nxt_layer.clusterids, return_counts=True)
+                    nxt = self.region_class(active_u, nxt_layer)
+                    self._bootstrap(nxt, nbootstraps, minvol)
+                    nxt.create_ellipsoid(minvol=minvol)
+                    contains_live = nxt.inside(active_u).all()
                 sensible = nxt_layer.nclusters < len(nxt.u) and sizes.max() >= nxt.u.shape[1]
                 shrinks = need_accept or nxt.estimate_volume() <= self.region.estimate_volume()
                 if contains_live and shrinks and sensible:

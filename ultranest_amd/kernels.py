@@ -224,6 +224,22 @@ class DeviceRegion(object):
                                         ptr(f64(ell_center)), ptr(f64(ell_invcov)), float(enlarge),
                                         float(radiussq), int(bool(use_scan))))
 
+    def set_from_device(self, live_dev, n, d, layer_kind, layer_ctr, layer_T, wrap_shift, ell_center, ell_invcov,
+                        enlarge, radiussq, use_scan=True, live_space=1, live_amax=None):
+        """`set` with the live points already on the device (`live_dev`: a C-contiguous float64 (n, d) torch tensor;
+        mlf_region_set takes host or device pointers for the point array).  `live_amax`: the largest |u - layer centre|
+        coordinate if the caller knows it (otherwise the rows are fetched back once to find it)."""
+        if live_amax is not None:
+            check(_lib.lib().mlf_region_hint_live_extent(self._h, float(live_amax)))
+        self._d = d
+        lc = f64(np.broadcast_to(layer_ctr, (d,)))
+        lt = f64(np.broadcast_to(layer_T, (d,))) if layer_kind == 1 else f64(layer_T)
+        ws = None if wrap_shift is None else f64(wrap_shift)
+        self._keep = (live_dev, lc, lt, ws)
+        check(_lib.lib().mlf_region_set(self._h, ctypes.c_void_p(live_dev.data_ptr()), n, d, int(live_space), int(layer_kind),
+                                        ptr(lc), ptr(lt), ptr(ws), ptr(f64(ell_center)), ptr(f64(ell_invcov)), float(enlarge),
+                                        float(radiussq), int(bool(use_scan))))
+
     def set_thresholds(self, enlarge, radiussq):
         check(_lib.lib().mlf_region_set_thresholds(self._h, float(enlarge), float(radiussq)))
 

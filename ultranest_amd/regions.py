@@ -385,6 +385,22 @@ class _DeviceState(object):
                 return False
         return True
 
+    def adopt(self, region, use_scan):
+        """The handle has just been set from data that never left the device (device_rebuild): record what a full
+        `_sync_slow` would have recorded, so that the next call finds the device state current."""
+        ndim = region.u.shape[1]
+        kind, lctr, lmat = region.transformLayer.device_params(ndim)
+        shift = region.transformLayer.wrap_shift_vector(ndim)
+        consts = (kind, lctr, lmat, shift, np.asarray(region.ellipsoid_invcov), int(use_scan), len(region.u))
+        self.consts = tuple(None if c is None else (c if np.isscalar(c) else np.array(c, dtype=float)) for c in consts)
+        self.live = np.array(region.u, dtype=float)
+        self.ell_center = np.array(region.ellipsoid_center, dtype=float)
+        self.thresholds = (float(region.enlarge), float(region.maxradiussq))
+        cell = region.__dict__.get("_u_cell")
+        if cell is not None:
+            cell[1] = []
+        self.fast_key = self._key(region, use_scan)
+
     def sync(self, region, use_scan):
         key = self._key(region, use_scan)
         if self.handle is not None and key[2] >= 0 and self._key_unchanged(key):
