@@ -61,12 +61,30 @@ def test_every_in_place_write_is_counted_and_reads_are_not():
         lambda: u[2:4].flat.__setitem__(0, 0.65),
         lambda: u.ctypes.data,
         lambda: u.data,
+        # writes that round 2 missed
+        lambda: np.copyto(dst=u, src=u * 1.0),               # the target as a keyword
+        lambda: np.put(a=u, ind=[0], v=[0.3]),
+        lambda: np.dot(u, np.eye(4), out=u[:, :]),           # out= of functions that are not ufuncs
+        lambda: np.cumsum(u, axis=0, out=u),
+        lambda: np.take(u, np.arange(30), axis=0, out=u),
     ]
     for i, w in enumerate(writes):
         before = _gen(h)
         w()
         assert _gen(h) > before, "write %d was not counted" % i
     assert np.asarray(u)[3, 0] != 123.0
+
+
+def test_boolean_scalar_key_is_not_a_row_number():
+    """u[True] = x writes EVERY row (numpy treats a scalar bool as a mask); it must not be remembered as 'row 1'."""
+    h = _Holder(np.random.RandomState(3).uniform(size=(10, 2)))
+    cell = h.__dict__["_u_cell"]
+    cell[1] = []                      # as after a device sync: row assignments are being remembered
+    h.u[3] = 0.5
+    assert cell[1] == [3]
+    h.u[True] = 0.25
+    assert cell[1] is None, "a whole-array write must force a diff"
+    assert (np.asarray(h.u) == 0.25).all()
 
 
 def test_results_of_arithmetic_are_plain_arrays():

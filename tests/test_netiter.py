@@ -88,3 +88,26 @@ def test_breadth_first_iterator_drop():
     it.expand_children_of(rootid, node)
     assert [n.id for n in it.active_nodes] == [0, 3, 4] and list(it.active_root_ids) == [0, 2, 2]
     assert list(it.active_node_values) == [3.0, 5.0, 6.0]
+
+
+def test_find_nodes_before_orders_ties_by_live_slot():
+    """likelihood plateau: equal-valued nodes are reported in the order of their slots in the breadth-first walk's live
+    set (reference netiter.py:356-383 walks with BreadthFirstIterator; np.argmin takes the first of equal values)"""
+    from ultranest_amd.netiter import TreeNode, find_nodes_before
+    root = TreeNode(id=-1, value=-np.inf)
+    kids = []
+    for i in range(4):
+        low = TreeNode(id=i, value=1.0)              # four roots on one plateau
+        low.children.append(TreeNode(id=10 + i, value=5.0))
+        root.children.append(low)
+        kids.append(low)
+    # a fork whose children tie with a later root: children of a fork go to the END of the live set
+    forked = TreeNode(id=4, value=0.5)
+    for j in range(2):
+        c = TreeNode(id=20 + j, value=1.0)
+        c.children.append(TreeNode(id=30 + j, value=7.0))
+        forked.children.append(c)
+    root.children.append(forked)
+    parents, weights = find_nodes_before(root, 3.0)
+    assert [p.id for p in parents] == [0, 1, 2, 3, 20, 21]
+    assert weights == [1., 1., 1., 1., 2., 2.]

@@ -98,6 +98,8 @@ struct Ctx {
   bool ready = false;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;   // host batches in chunks: copies here, kernels on `stream` (mlf_region_inside)
+  hipEvent_t copy_event = nullptr;
   // scratch used by the stateless host-pointer entry points
   unsigned long long *pin_adj = nullptr;   // pinned host copy of the adjacency bits (mlf_cluster_labels)
   size_t pin_adj_cap = 0;
@@ -1891,10 +1893,32 @@ int mlf_region_inside(mlf_region *r, const double *pts, size_t np, uint8_t *mask
   if (!pts || !mask) return fail_arg(MLF_E_BADARG, "null pointer");
   if (g_small_path && np <= (size_t)kSmallMaxPoints && r->d <= kSmallMaxDim) return region_inside_small(r, pts, np, mask);
   Ctx &c = g_ctx;
-  if (int rc = upload(r->pts, pts, np * (size_t)r->d * sizeof(double), c.stream)) return rc;
+  const size_t row_bytes = (size_t)r->d * sizeof(double);
   CK(r->mask.reserve(np));
-  if (int rc = region_inside_enqueue(r, r->pts.as<double>(), np, r->mask.as<uint8_t>(), c.stream, nullptr))
-    return rc;
+  // Large host batches (what integrator.py:1776-1804 hands over: 400 MB at 10^6 x 50) are sent in chunks on a copy
+  // stream; the kernels of chunk k run while chunk k + 1 crosses PCIe, so that only the last chunk's kernels and the
+  // mask's way back are not hidden behind the transfer (round 2: upload, then 0.55 ms of kernels, then the mask).
+  constexpr size_t kChunkRows = 131072;
+  if (np >= 3 * kChunkRows && !is_device_pointer(pts)) {
+    if (!c.copy_stream) {
+      CK(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+      CK(hipEventCreateWithFlags(&c.copy_event, hipEventDisableTiming));
+    }
+    CK(r->pts.reserve(np * row_bytes));
+    CK(hipStreamSynchronize(c.stream));   // the staging buffer may still be read by an earlier call's kernels
+    for (size_t row0 = 0; row0 < np; row0 += kChunkRows) {
+      const size_t rows = np - row0 < kChunkRows ? np - row0 : kChunkRows;
+      double *dst = r->pts.as<double>() + row0 * (size_t)r->d;
+      CK(hipMemcpyAsync(dst, pts + row0 * (size_t)r->d, rows * row_bytes, hipMemcpyHostToDevice, c.copy_stream));
+      CK(hipEventRecord(c.copy_event, c.copy_stream));
+      CK(hipStreamWaitEvent(c.stream, c.copy_event, 0));
+      if (int rc = region_inside_enqueue(r, dst, rows, r->mask.as<uint8_t>() + row0, c.stream, nullptr)) return rc;
+    }
+  } else {
+    if (int rc = upload(r->pts, pts, np * row_bytes, c.stream)) return rc;
+    if (int rc = region_inside_enqueue(r, r->pts.as<double>(), np, r->mask.as<uint8_t>(), c.stream, nullptr))
+      return rc;
+  }
   CK(hipMemcpyAsync(mask, r->mask.p, np, hipMemcpyDeviceToHost, c.stream));
   CK(hipStreamSynchronize(c.stream));
   return 0;

@@ -74,8 +74,11 @@ class BreadthFirstIterator(object):
         if self._n == 0:
             return None
         i = self.next_index = int(np.argmin(self._val[:self._n]))
-        return self._root[i], self._nodes[i], (self._nodes, self.active_root_ids, self.active_node_values,
-                                               self.active_node_ids)
+        # the caller gets arrays of its own: the buffers behind the public attributes are shifted in place when a slot
+        # closes, and a caller that keeps the tuple across expand_children_of / drop_next_node (the reference hands out
+        # fresh arrays on a fork or drop, netiter.py:110-161) must not see that
+        return self._root[i], self._nodes[i], (list(self._nodes), self.active_root_ids.copy(),
+                                               self.active_node_values.copy(), self.active_node_ids.copy())
 
     def _close_gap(self, i):
         n = self._n
@@ -310,26 +313,30 @@ def find_nodes_before(root, value):
     every node below `value` that has a child at or above it, each with the number of siblings-at-every-fork along
     its path (product of the fork widths from the root's children down); the subtree of such a node is not looked at
     any further.  If one of the root's children is itself at or above `value`, `root` closes the list with weight 1.
-    The answer is ordered like the breadth-first walk would find it: by ascending node value."""
-    found = []
-    reaches_root = False
-    stack = [(child, 1.) for child in reversed(root.children)]
-    while stack:
-        node, weight = stack.pop()
-        if node.value >= value:
-            reaches_root = True          # only children of the root can get here: deeper ones end at their parent
-            continue
+    The answer is in the order the breadth-first walk meets the nodes: ascending node value, equal values (likelihood
+    plateaus) in the order of their live-set slots."""
+    parents, parent_weights = [], []
+    weight_of = {child.id: 1. for child in root.children}
+    walk = BreadthFirstIterator(root.children)     # the live-set walk itself: equal values are met in ITS slot order
+    while True:
+        step = walk.next_node()
+        if step is None:
+            break
+        rootid, node, _ = step
+        if node.value >= value:          # only a child of the root can get here: everything still live lies above too
+            parents.append(root)
+            parent_weights.append(1)
+            break
         kids = node.children
         if any(k.value >= value for k in kids):
-            found.append((node.value, len(found), node, weight))
-            continue
-        stack.extend((k, weight * len(kids)) for k in reversed(kids))
-    found.sort(key=lambda item: item[:2])
-    parents = [item[2] for item in found]
-    parent_weights = [item[3] for item in found]
-    if reaches_root:
-        parents.append(root)
-        parent_weights.append(1)
+            parents.append(node)
+            parent_weights.append(weight_of[node.id])
+            walk.drop_next_node()
+        else:
+            for k in kids:
+                weight_of[k.id] = weight_of[node.id] * len(kids)
+            walk.expand_children_of(rootid, node)
+        del weight_of[node.id]
     return parents, parent_weights
 
 
@@ -431,7 +438,7 @@ def combine_results(saved_logl, saved_nodeids, pointpile, main_iterator, mpi_com
     top = int(np.argmax(logl))
     results = dict(
         niter=len(logl),
-        logz=logz, logzerr=float(np.hypot(logzerr_tail, logzerr_bs)),
+        logz=logz, logzerr=float((logzerr_tail**2 + logzerr_bs**2)**0.5),   # the reference's expression (netiter.py:927): hypot may differ in the last place
         logz_bs=logz_boot.mean(), logz_single=logz,
         logzerr_tail=logzerr_tail, logzerr_bs=logzerr_bs,
         ess=_kish_ess(w),

@@ -178,7 +178,7 @@ class _LiveArray(np.ndarray):
         if self._root:   # a plain row assignment: remember which rows
             if isinstance(key, tuple) and key:
                 key = key[0]
-            if isinstance(key, (int, np.integer)):
+            if isinstance(key, (int, np.integer)) and not isinstance(key, (bool, np.bool_)):   # u[True] = x writes everywhere
                 rows.append(int(key))
                 return
             if isinstance(key, np.ndarray) and key.ndim == 1 and key.dtype.kind in "iu" and key.size <= 16:
@@ -200,8 +200,18 @@ class _LiveArray(np.ndarray):
         return getattr(ufunc, method)(*args, **kwargs)   # plain ndarrays out: results are not live points
 
     def __array_function__(self, func, types, args, kwargs):
-        if func in _IN_PLACE_FUNCTIONS and args and isinstance(args[0], _LiveArray):
-            args[0]._touch()
+        # numpy functions that write into one of their arguments: the in-place family (first positional argument, or the
+        # keyword numpy gives it: dst / a / arr), and any function handed a live array as `out=` (np.dot, np.take,
+        # np.cumsum ... are not ufuncs and do not pass through __array_ufunc__)
+        if func in _IN_PLACE_FUNCTIONS:
+            target = args[0] if args else next((kwargs[k] for k in ("dst", "a", "arr") if k in kwargs), None)
+            if isinstance(target, _LiveArray):
+                target._touch()
+        out = kwargs.get("out") if kwargs else None
+        if out is not None:
+            for o in (out if isinstance(out, tuple) else (out,)):
+                if isinstance(o, _LiveArray):
+                    o._touch()
         return super().__array_function__(func, types, args, kwargs)
 
     def __reduce__(self):   # pickles as the plain array it holds; a region re-wraps it on assignment

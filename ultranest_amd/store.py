@@ -5,10 +5,11 @@ run can be resumed -- by this package or by stock UltraNest (SURVEY.md 8f row f4
 
 ``TextPointStore`` writes / reads the reference's text format byte for byte (``fmt`` = ``%.18e`` per value,
 ``delimiter`` between values, one row per ``add``; both attributes can be changed after construction, which
-the reference's driver does, integrator.py:1189-1194).  The reference's HDF5 flavour (store.py:161-227, h5py) is NOT
-provided: h5py is not part of this image, so its file format could neither be pinned against a file written by the
-reference nor exercised at all; use ``storage_backend='tsv'`` (or the reference's own HDF5PointStore next to this
-package -- the row format is the same).
+the reference's driver does, integrator.py:1189-1194).  ``HDF5PointStore`` keeps the reference's HDF5 layout
+(store.py:161-227: one growing float dataset ``points`` of shape (rows, ncols), file attribute ``ncalls``); it needs
+h5py, which is NOT part of this image: importing this module works without it, constructing the store raises the
+ImportError the reference raises, and its tests run against h5py when it is installed (a file written by the reference
+could not be produced here, so the layout is pinned by the reference's source, not by a golden file).
 
 Interface of both: ``add(row, ncalls) -> index``, ``pop(Lmin) -> (index, row) | (None, None)``,
 ``reset()``, ``flush()``, ``close()``, attributes ``ncols``, ``nrows``, ``ncalls``, ``stack``, ``stack_empty``.
@@ -114,3 +115,51 @@ class TextPointStore(FilePointStore):
         self.fileobj.write(record.encode('latin1'))
         index, self.nrows, self.ncalls = self.nrows, self.nrows + 1, ncalls
         return index
+
+
+class HDF5PointStore(FilePointStore):
+    """HDF5 file with the reference's layout (store.py:161-227): dataset ``points`` (float, shape (rows, ncols),
+    unlimited rows), file attribute ``ncalls``; every ``add`` grows the dataset by one row.  `h5_file_args` go to
+    ``h5py.File`` (default mode 'a').  A path that another instance of this process still holds open is closed first
+    (the reference does the same, :186-197: a forgotten store in an interactive session would otherwise make the
+    file impossible to reopen)."""
+
+    FILES_OPENED = []
+
+    def __init__(self, filepath, ncols, **h5_file_args):
+        import h5py
+        self.ncols = int(ncols)
+        h5_file_args.setdefault('mode', 'a')
+        still_open = []
+        for path, handle in HDF5PointStore.FILES_OPENED:
+            if path == filepath:
+                try:
+                    handle.close()
+                except Exception:     # already closed by its owner
+                    pass
+            else:
+                still_open.append((path, handle))
+        HDF5PointStore.FILES_OPENED[:] = still_open
+        self.fileobj = h5py.File(filepath, **h5_file_args)
+        HDF5PointStore.FILES_OPENED.append((filepath, self.fileobj))
+        if 'points' not in self.fileobj:
+            self.fileobj.create_dataset('points', dtype=float, shape=(0, self.ncols), maxshape=(None, self.ncols))
+        self.nrows, width = self.fileobj['points'].shape
+        if width != self.ncols:
+            raise IOError("Tried to resume from file '%s', which has a different number of columns!" % (self.fileobj))
+        self._set_stack(self.fileobj['points'][:])
+        self.ncalls = self.fileobj.attrs.get('ncalls', len(self.stack))
+
+    def add(self, row, ncalls):
+        _check_width(row, self.ncols)
+        points = self.fileobj['points']
+        points.resize(self.nrows + 1, axis=0)
+        points[self.nrows, :] = row
+        if self.ncalls != ncalls:
+            self.ncalls = self.fileobj.attrs['ncalls'] = ncalls
+        index, self.nrows = self.nrows, self.nrows + 1
+        return index
+
+    def close(self):
+        self.fileobj.close()
+        HDF5PointStore.FILES_OPENED[:] = [(p, h) for p, h in HDF5PointStore.FILES_OPENED if h is not self.fileobj]
