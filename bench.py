@@ -38,7 +38,8 @@ sys.path.insert(0, ROOT)
 N_LIVE, NDIM, NPROPOSALS, NBOOT = 4000, 50, 1000000, 30
 FP64_VALU_PEAK_TFLOPS = 39.3     # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz, one flop per non-fused v_*_f64
 F16_MFMA_PEAK_TFLOPS = 2500.0    # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
-PROBE_F16_MFMA_TFLOPS = 1400.0   # what k_filter's instruction pattern sustains in a probe without memory traffic
+PROBE_F16_MFMA_TFLOPS = 1580.0   # what v_mfma_f32_32x32x16_f16 sustains ALONE on this part (4 chains, operands in registers:
+# scripts/probes/mfma16_issue_probe.hip, profiles/r03_issue_probe.json): the clock under matrix load, not the issue slots, sets it
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F16_FLOPS = 2 * 32 * 32 * 16   # one v_mfma_f32_32x32x16_f16
 CLOCK_SETTLE_STEPS = 100         # untimed steps in front of the W warm-up steps of a timed loop (see run_steps)
@@ -438,10 +439,24 @@ def main():
             "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank]}
     headline = strong if args.scaling == "strong" else weak
     alg_bytes = NPROPOSALS * (8 * NDIM + 1) + 8 * N_LIVE * NDIM + 2 * 8 * NDIM * NDIM
+    # HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE need their own passes (they cannot be
+    # collected inside this run); the figures of the last profiled tree are IMPORTED from profiles/pmc_scan_traffic.json
+    # (scripts/collect_profiles.py) and labelled as such
     traffic = None
+    traffic_detail = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_scan_traffic.json")
     if os.path.exists(pmc_file):
-        traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+        pmc = json.load(open(pmc_file))
+        traffic = pmc.get("hbm_bytes_per_launch")
+        step_sum = pmc.get("hbm_bytes_per_step_all_kernels")
+        traffic_detail = {"source": "profiles/%s via profiles/pmc_scan_traffic.json: separate rocprofv3 --pmc passes "
+                                    "(FETCH_SIZE, WRITE_SIZE; gfx950 correction of MI355X_MICROARCH.md) over bench.py "
+                                    "--headline-only on the profiled tree -- imported, NOT measured in this run" % pmc.get("source"),
+                          "per_launch_average_of_the_sweep_launches": traffic,
+                          "per_kernel_bytes": pmc.get("per_kernel_all"),
+                          "per_step_sum_all_kernels": step_sum,
+                          "algorithmic_bytes_per_step": alg_bytes,
+                          "ratio_to_algorithmic": (step_sum / alg_bytes) if step_sum else None}
     exact_roof = scan_x_ms = None
     if not args.headline_only:
         scan_x_ms = ms_scan_x / max(ncalls_x, 1)
@@ -476,7 +491,7 @@ def main():
         by_phase = [float(np.mean(launch_ms_list[i::per_step])) for i in range(per_step)] if len(launch_ms_list) else []
         ach = (exec_flops / per_step) / (launch_ms * 1e-3) / 1e12
         allpairs = 2.0 * N_LIVE * NPROPOSALS * (NDIM + 6)
-        roofline = {"kernel": "k_filter (v_mfma_f32_32x32x16_f16 bound on the pair distances; two launches per step)",
+        roofline = {"kernel": "k_sweep (mlf_sweep.hip: v_mfma_f32_32x32x16_f16 bound on the pair distances, mask mode; two launches per step)",
                     "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / F16_MFMA_PEAK_TFLOPS, "ms_per_launch": launch_ms,
                     "launches_per_step": per_step,
@@ -484,23 +499,25 @@ def main():
                     "executed_mfma_per_launch_by_phase": mfma_per_launch,
                     "executed_flops_per_launch": exec_flops / per_step,
                     "achieved_by_phase": [m * MFMA_F16_FLOPS / (t * 1e-3) / 1e12 for m, t in zip(mfma_per_launch, by_phase)],
-                    "kernel_names": ["k_filter<4, 4, false, true> (first live-point range, compacts the undecided proposals)",
-                                     "k_filter<4, 2, false, false> (second range: two query groups per wave)"] if per_step == 2 else None,
+                    "kernel_names": ["k_sweep<4, 4, true, 2> (first live-point range, compacts the undecided proposals)",
+                                     "k_sweep<4, 2, false, 1> (second range: two query groups per wave)"] if per_step == 2 else None,
                     "practical_ceiling": {"TFLOPs": PROBE_F16_MFMA_TFLOPS, "frac": ach / PROBE_F16_MFMA_TFLOPS,
-                                          "source": "scripts/probes/mfma16_power_probe.hip: the same instruction pattern (4 chains x 4 "
-                                                    "k-steps + min3 epilogue, 2 waves per SIMD) with operands in registers; the chip "
-                                                    "runs 1.8-1.9 GHz under it, the matrix pipe is 74 % busy "
-                                                    "(profiles/r02_mfma16_power_probe.json)"},
+                                          "source": "scripts/probes/mfma16_issue_probe.hip: the matrix instruction ALONE (4 independent "
+                                                    "chains, operands in registers, 1 or 2 waves per SIMD) sustains 1.56-1.58 PFLOP/s on "
+                                                    "this part, 1.50-1.53 with three vector instructions pinned behind each (k_sweep has 2.5); "
+                                                    "a sweep over zero-valued query operands runs at 1.82 PFLOP/s: the chip's clock under "
+                                                    "matrix load depends on the data (profiles/r03_issue_probe.json, DESIGN.md 4b)"},
                     "equivalent_allpairs_flops_per_step": allpairs,
                     "equivalent_allpairs_TFLOPs": allpairs / (launch_ms * per_step * 1e-3) / 1e12,
                     "executed_k_columns": kdim, "second_range_groups": stats["second_range_groups"],
                     "note": "achieved = executed matrix-instruction flops of one launch (average of the launches of a step) "
                             "over the average launch duration from hipEvents inside the timed region; pairs skipped by the "
                             "second range are not counted (they are an algorithmic saving)",
-                    "traffic": traffic, "hbm": hbm}
+                    "traffic": traffic, "traffic_detail": traffic_detail, "hbm": hbm}
     else:
         roofline = dict(exact_roof or {})
         roofline["traffic"] = traffic
+        roofline["traffic_detail"] = traffic_detail
         roofline["hbm"] = hbm
     # per-proposal stage: row in (8 d), binary16 operand + thresholds + route / slot / best words out
     prep_bytes = NPROPOSALS * (8 * NDIM + 2 * kdim + 8 + 1 + 4 + 4 + 1)
@@ -537,7 +554,7 @@ def main():
         "accept_fraction": accept, "ellipsoid_pass_fraction": ell_pass,
         "kernel_ms": {"per-proposal stage (k_prep4: bounded ellipsoid test + whitening on the matrix cores with split binary16 operands -> f16 "
                       "operand; the ellipsoid band is decided by the tail of the re-check launch)": prep_ms,
-                      ("scan kernel (k_filter)" if filter_on else "scan kernel (k_scan)"): scan_ms,
+                      ("scan kernel (k_sweep, both launches)" if filter_on else "scan kernel (k_scan)"): scan_ms,
                       "rest of scan stage (re-check of uncertain pairs incl. exact whitening of their queries, "
                       "routing, finalise)": rest_ms,
                       "scan kernel as a single sweep over all live points (phases off)": ms_scan_single,

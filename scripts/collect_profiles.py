@@ -14,13 +14,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 os.makedirs(P, exist_ok=True)
 
 # kernels of the headline step (1e6 proposals per launch in the bench's --headline-only pass) and the smallest grid
 # (threads) such a launch has: the same kernels also run on the 4000 live points during the region build
-HEADLINE_GRID = {"k_prep4": 100000, "k_prep3": 100000, "k_filter<4, 4, false, true>": 400000,
-                 "k_filter<4, 2, false, false>": 400000, "k_filter<4, 4, false, false>": 400000, "k_recheck_whiten": 400000, "k_scan": 400000,
+HEADLINE_GRID = {"k_prep4": 100000, "k_prep3": 100000, "k_sweep<4, 4, true": 400000,
+                 "k_sweep<4, 2, false": 400000, "k_sweep<4, 4, false": 400000, "k_recheck_whiten": 400000, "k_scan": 400000,
                  "k_phase_finish": 64}
 
 
@@ -50,8 +50,11 @@ cp("e2e_run.json", "%s_e2e_run.json" % tag)
 cp("bench_torchrun.json", "%s_bench_torchrun.json" % tag)
 cp("bench_2rank_gloo.json", "%s_bench_2rank_gloo.json" % tag)
 cp("bench_2rank_selfspawn.json", "%s_bench_2rank_selfspawn_gloo.json" % tag)
-cp("r02_small_batch.json", "%s_small_batch.json" % tag)
-cp("r02_mfma16_power_probe.json", "%s_mfma16_power_probe.json" % tag)
+cp("small_batch.json", "%s_small_batch.json" % tag)
+cp("rebuild_modes.json", "%s_rebuild_modes.json" % tag)
+cp("midsize.json", "%s_midsize_batches.json" % tag)
+cp("host_api.json", "%s_host_api.json" % tag)
+cp("loglike_bench.json", "%s_loglike_bench.json" % tag)
 
 # kernel-trace: average duration of the headline launches only (the stats CSV mixes them with the
 # small scans of the region rebuild)
@@ -89,7 +92,7 @@ for key in pmc:
         summary[key]["hbm_traffic"] = dict(FETCH_SIZE_KiB=f_kb, WRITE_SIZE_KiB=w_kb, bytes_raw=(f_kb + w_kb) * 1024.0,
                                            bytes_gfx950_corrected=(2.0 * f_kb + w_kb) * 1024.0)
 # the roofline entry of bench.py is per k_filter launch, averaged over the two launches of a step
-mainkeys = [k for k in ("k_filter<4, 4, false, true>", "k_filter<4, 2, false, false>", "k_filter<4, 4, false, false>") if k in pmc and "FETCH_SIZE" in pmc[k]]
+mainkeys = [k for k in ("k_sweep<4, 4, true", "k_sweep<4, 2, false", "k_sweep<4, 4, false") if k in pmc and "FETCH_SIZE" in pmc[k]]
 if not mainkeys and "k_scan" in pmc and "FETCH_SIZE" in pmc["k_scan"]:
     mainkeys = ["k_scan"]
 if mainkeys:
@@ -97,7 +100,9 @@ if mainkeys:
     # reports half the bytes of a wide coalesced read -> doubled as the guide prescribes
     per_kernel = dict((k, summary[k]["hbm_traffic"]["bytes_gfx950_corrected"]) for k in mainkeys)
     traffic = sum(per_kernel.values()) / len(per_kernel)
-    json.dump(dict(hbm_bytes_per_launch=traffic, per_kernel=per_kernel, source="%s_pmc_summary.json" % tag,
+    per_kernel_all = dict((k, summary[k]["hbm_traffic"]["bytes_gfx950_corrected"]) for k in pmc if "hbm_traffic" in summary.get(k, {}))
+    json.dump(dict(hbm_bytes_per_launch=traffic, per_kernel=per_kernel, per_kernel_all=per_kernel_all,
+                   hbm_bytes_per_step_all_kernels=sum(per_kernel_all.values()), source="%s_pmc_summary.json" % tag,
                    kernel=" + ".join(mainkeys),
                    note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --headline-only, "
                         "launches of 1e6 proposals; (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md; "
@@ -108,7 +113,7 @@ if mainkeys:
     bj = os.path.join(P, "%s_bench.json" % tag)
     if os.path.exists(bj):
         line = json.load(open(bj))
-        if isinstance(line.get("roofline"), dict) and "k_filter" in str(line["roofline"].get("kernel", "")):
+        if isinstance(line.get("roofline"), dict) and "k_sweep" in str(line["roofline"].get("kernel", "")):
             line["roofline"]["traffic"] = traffic
             json.dump(line, open(bj, "w"))
 json.dump(summary, open(os.path.join(P, "%s_pmc_summary.json" % tag), "w"), indent=1)

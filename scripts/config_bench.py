@@ -27,9 +27,18 @@ def region_for(n, d):
     layer = M.AffineLayer()
     layer.optimize(u, u)
     region = M.MLFriends(u, layer)
-    t0 = time.perf_counter()
+    # the first call of a process pays context creation, code-object loading of the kernels of this dimensionality and
+    # the first allocations (round 2 reported 9.0 ms for C2 -- the first configuration of the loop -- against 1.7 ms at
+    # C5 for exactly that reason): one untimed call on another stream position, then the median of three
+    region.compute_enlargement(nbootstraps=30, rng=np.random.RandomState(99))
+    ts = []
+    for rep in range(3):
+        rs_t = np.random.RandomState(1000 + rep)
+        t0 = time.perf_counter()
+        region.compute_enlargement(nbootstraps=30, rng=rs_t)
+        ts.append((time.perf_counter() - t0) * 1e3)
     region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=30, rng=rs)
-    boot_ms = (time.perf_counter() - t0) * 1e3
+    boot_ms = float(np.median(ts))
     region.create_ellipsoid()
     return u, region, boot_ms
 

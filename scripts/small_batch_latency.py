@@ -58,4 +58,4 @@ for label, (n, d) in [("C1", (400, 5)), ("C2", (2000, 20)), ("C5", (4000, 50))]:
         print(json.dumps(out[-1]), flush=True)
 if "--save" in sys.argv:
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(out, open("gpurun_out/r02_small_batch.json", "w"), indent=1)
+    json.dump(out, open("gpurun_out/small_batch.json", "w"), indent=1)
