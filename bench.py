@@ -247,6 +247,10 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
+        # device work of THIS rank first (the untimed settle / warm-up steps are still queued when the host gets here; ranks
+        # that share a device -- the 1-GPU boxes of the pool -- would otherwise start their clocks while another rank's
+        # queue is still draining), then the ranks meet, then the device once more
+        torch.cuda.synchronize()
         if use_dist:
             import torch.distributed as dist
             dist.barrier()
@@ -266,7 +270,7 @@ def main():
         management needs tens of milliseconds of load before the chip runs at its sustained clock; the first 10 ms
         after an idle period -- such as the host-side region build in front of this loop -- run ~8 % slower).
         stage_events: also record the per-stage hipEvents (only outside the headline loop: six extra events per pass
-        cost ~7 % of a 0.6 ms step).  The k_filter launches are bracketed by events in both modes."""
+        cost ~7 % of a 0.6 ms step).  The k_sweep launches are bracketed by events in both modes."""
         call = handle.inside_dev_timed if stage_events else handle.inside_dev
         for _ in range(settle + args.warmup):
             handle.inside_dev(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
@@ -380,6 +384,7 @@ def main():
     strong_accept = float(smask.float().mean().item())
     # sharded bootstrap: masks drawn once, broadcast, 30 rounds over the ranks, ONE all-reduce(MAX) of 3 doubles
     boot_reps = max(3, min(10, args.steps))
+    r2_keep, f_keep = region.maxradiussq, region.enlarge
     rs_b = np.random.RandomState(5)
     distributed.update_region_bootstrap(region, NBOOT, minvol=0., group=group, rng=rs_b)
     barrier()
@@ -389,6 +394,7 @@ def main():
     barrier()
     boot_mine = (time.perf_counter() - t0) / boot_reps
     boot_elapsed = maxed(boot_mine)
+    region.maxradiussq, region.enlarge = r2_keep, f_keep     # the timed batches (and the CPU baseline below) belong to THIS region
     ranks_seen = 1
     if use_dist:
         import torch.distributed as dist
@@ -561,7 +567,7 @@ def main():
                       "per-proposal stage with the FP64 kernel instead (k_prep3, prep_bounded=0)":
                           (ms_prep_p3 / max(ncalls_p3, 1)) if not args.headline_only else None,
                       "measured_in": "a separate pass of %d steps with stage events (the headline loop carries events only "
-                                     "around the k_filter launches)" % nsteps_b},
+                                     "around the k_sweep launches)" % nsteps_b},
         "batch_counters": stats,
         "roofline": roofline,
         "roofline_exact_scan": exact_roof,

@@ -87,6 +87,7 @@ long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all til
 bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
 bool g_time_filter_launches = false;  // mlf_set_option("time_filter_launches", 0/1): event pairs around every k_filter launch of every call
 int g_filter_first_range_pct = 50;     // mlf_set_option("filter_first_range_pct", 10 ... 90): share of the live-point tiles in the first of two ranges
+int g_filter_split_waves = 2048;       // mlf_set_option("filter_split_waves", n): waves a single-sweep launch aims at when it splits the live-point tiles (1 ... 16 ranges; default: one round of the 2048 resident waves)
 int g_filter_narrow_tail = 1;          // mlf_set_option("filter_narrow_tail", 0/1): later ranges of a phased sweep with 2 query groups per wave
 bool g_small_path = true;             // mlf_set_option("small_path", 0/1): one launch for up to 256 proposals handed over on the host
 bool g_prep_bounded = true;           // mlf_set_option("prep_bounded", 0/1): matrix-core bounded stage (mlf_prep4.hip)
@@ -290,7 +291,8 @@ int filter_reserve(FilterCtx &f, long long nq, unsigned *cap_out) {
   long long nwaves = filter_wave_count(f.ks, nqpad / 32, f.ks == 4 ? 2 : (f.ks < 4 ? 1 : 0));   // room for a narrow later range
   {   // ... and for the tile ranges of a small batch (filter_tile_split): one segment per (wave, range)
     const long long plain = (filter_wave_count(f.ks, nqpad / 32) + 3) / 4 * 4;
-    if (plain <= 4096 && 4 * plain > nwaves) nwaves = 4 * plain;
+    const long long split = filter_tile_split(f.ks, nqpad / 32, f.ntiles32, g_filter_split_waves);
+    if (split * plain > nwaves) nwaves = split * plain;
   }
   const unsigned cap = kFilterSegCap;   // uncertain pairs per filter wave (expected: tens)
   CK(f.qF.reserve((size_t)nqpad * f.ks * 16 * 2));
@@ -368,7 +370,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     CK(f.pblk.reserve(((size_t)nqpad / 256 + 2) * sizeof(unsigned)));
   }
   const bool fused = nphase > 1 && g_filter_fused_compact;
-  fa.split = nphase == 1 ? filter_tile_split(f.ks, ngroups, f.ntiles32) : 1;
+  fa.split = nphase == 1 ? filter_tile_split(f.ks, ngroups, f.ntiles32, g_filter_split_waves) : 1;
   // two ranges, compaction inside the first, finalise tail in the scan launch: nobody pads the compacted set or publishes
   // its group count (k_phase_finish: a 5 us launch) -- the second range reads the slot counter itself, the tail resets it
   const bool fold_finish = fused && nphase == 2 && xs != nullptr;
@@ -1103,6 +1105,10 @@ int mlf_set_option(const char *name, long long value) {
   }
   if (!strcmp(name, "filter_first_range_pct")) {
     g_filter_first_range_pct = value < 10 ? 10 : (value > 90 ? 90 : (int)value);
+    return 0;
+  }
+  if (!strcmp(name, "filter_split_waves")) {
+    g_filter_split_waves = value < 256 ? 256 : (value > 16384 ? 16384 : (int)value);
     return 0;
   }
   if (!strcmp(name, "filter_narrow_tail")) {

@@ -632,11 +632,11 @@ static hipError_t launch_filter_t(const FilterArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-int filter_tile_split(int ks, long long ngroups, int ntiles) {
+int filter_tile_split(int ks, long long ngroups, int ntiles, int target_waves) {
   const long long waves = filter_wave_count(ks, ngroups);
-  long long k = 4096 / (waves > 0 ? waves : 1);   // two rounds of the ~2048 resident waves are the aim
-  if (k > 4) k = 4;
-  if (k > ntiles / 8) k = ntiles / 8;
+  long long k = target_waves / (waves > 0 ? waves : 1);   // default 2048: one round of the resident waves
+  if (k > kFilterMaxSplit) k = kFilterMaxSplit;
+  if (k > ntiles / 4) k = ntiles / 4;   // a wave of a few thousand proposals is latency bound: 4 tiles are 64 dependent matrix instructions
   return k < 1 ? 1 : (int)k;
 }
 

@@ -4,6 +4,8 @@
 
 #define MLF_FILTER_MAXD 128
 
+constexpr int kFilterMaxSplit = 16;   // tile ranges (grid.y) of a single-sweep launch over a small batch
+
 namespace mlf {
 
 struct FilterArgs {
@@ -91,7 +93,7 @@ int filter_groups_per_wave(int ks, int narrow);
 void launch_recheck(const RecheckArgs &a, long long nwaves, hipStream_t s);
 long long filter_wave_count(int ks, long long ngroups, int narrow = 0);
 // tile ranges a single-sweep launch over `ntiles` tiles should use for a batch of `ngroups` query groups (1 ... 4)
-int filter_tile_split(int ks, long long ngroups, int ntiles);  // waves (= list segments) of a k_filter launch
+int filter_tile_split(int ks, long long ngroups, int ntiles, int target_waves = 2048);  // waves (= list segments) of a k_filter launch
 void launch_filter_finalize(const uint8_t *route, const int *best, const unsigned *counters, long long nq,
                             uint8_t *out_mask, long long *out_idx, uint8_t *exact_gate, hipStream_t s,
                             unsigned *reset_word = nullptr);

@@ -22,26 +22,22 @@
 
 namespace mlf {
 
-// The workgroup that completes the LAST proposal of the call raises the host-visible flag the caller spins on.  The
-// caller does not wait for the kernel's own completion signal (~4 us later; the next launch is ordered behind this one
-// by the stream), so the flag is the ONLY thing that orders the mask bytes -- written by many workgroups straight into
-// host memory -- before the caller's read: every workgroup releases its own mask byte at system scope BEFORE it counts
-// itself as finished, and the workgroup that sees the full count acquires those releases before it raises the flag
-// (fence - atomic - fence: the threadFenceReduction pattern).  Without the per-workgroup fence only the last
-// workgroup's own byte was ordered; the staging buffer is reused from call to call, so a byte still in flight would have
-// been a stale answer of the previous call.
-__device__ __forceinline__ void finish_point(const SmallArgs &a) {
-  bool last = true;
-  if (a.np > 1) {
-    __threadfence_system();   // release: this proposal's mask byte is in host memory before the count moves
-    const unsigned t = __hip_atomic_fetch_add(a.finished, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    last = t == (unsigned)a.np - 1u;
-    if (last) *a.finished = 0u;
-  }
-  if (last) {
-    __threadfence_system();   // acquire side of the other workgroups' releases + release of this one's byte
-    __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+// Completion protocol.  The caller spins on a host-visible flag instead of waiting for the kernel's completion signal
+// (~4 us later; the next launch is ordered behind this one by the stream), so the flag is the ONLY thing that orders the
+// mask bytes before the caller's read.  Everything the workgroups tell each other travels in ATOMIC read-modify-write
+// words, which meet at the device's coherence point whatever XCD (and L2) a workgroup runs on:
+//   state[p]   += 1 per reporting workgroup, += 0x10000 if it found a neighbour (its return value tells the last one)
+//   finished   += 1 per completed proposal (its return value tells the last proposal's workgroup: the publisher)
+// A workgroup issues the second update only after the first has returned, so when the publisher's count comes back
+// every state word is final; its threads fetch (and zero) them with atomic exchanges, pack the answers 16 to a store
+// into the host buffer, fence at system scope and raise the flag.  No other workgroup writes to host memory, and nobody
+// needs a cache write-back.  (Round 2 let each finishing workgroup write its own byte into host memory, only the last
+// one fencing: bytes of other workgroups could still be in flight when the flag arrived -- a stale answer of the previous
+// call, ADVICE r2.  Fencing in every workgroup closes that, at +50 % latency for 128 proposals; so does staging the
+// answers in plain device memory, at the price of an L2 write-back per workgroup across the 8 XCDs.)
+__device__ __forceinline__ bool finish_point(const SmallArgs &a) {
+  if (a.np == 1) return true;
+  return __hip_atomic_fetch_add(a.finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.np - 1u;
 }
 
 // LDS: d x (d|1) doubles per matrix when STAGE (d <= 64): rows of L^T, then the layer matrix; all loads of a call --
@@ -52,7 +48,7 @@ __global__ __launch_bounds__(256) void k_inside_small(SmallArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mats[];
   __shared__ double xs[kSmallMaxDim], dl[kSmallMaxDim], dw[kSmallMaxDim], tq[kSmallMaxDim];
   __shared__ double red[2][4];
-  __shared__ int gate_s;
+  __shared__ int gate_s, last_s;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int p = blockIdx.x / a.wpp, part = blockIdx.x - p * a.wpp;
   const int d = a.d, ls = d | 1;
@@ -162,13 +158,13 @@ __global__ __launch_bounds__(256) void k_inside_small(SmallArgs a) {
     inside = gate_s != 0;
   }
 
+  bool publish = false;   // thread 0: this workgroup completed the last proposal of the call
   if (!a.use_scan) {
     if (part == 0 && tid == 0) {
-      a.mask[p] = inside ? 1 : 0;
-      finish_point(a);
+      (void)atomicAdd(a.state + p, (inside ? 0x10000u : 0u) + 1u);   // returned (waited for) before the count below moves
+      publish = finish_point(a);
     }
-    return;
-  }
+  } else {
 
   // ---- scan of this workgroup's live points
   int found = 0;
@@ -195,17 +191,28 @@ __global__ __launch_bounds__(256) void k_inside_small(SmallArgs a) {
   }
   found = __syncthreads_or(found);
   if (tid == 0) {
-    bool last_of_point = true;
-    int hits = found;
-    if (a.wpp > 1) {   // one word per proposal: workgroups that reported (low half) and hits (high half)
-      const unsigned old = atomicAdd(a.state + p, (found ? 0x10000u : 0u) + 1u);
-      last_of_point = (old & 0xffffu) == (unsigned)a.wpp - 1u;
-      hits += (int)(old >> 16);
-      if (last_of_point) a.state[p] = 0u;   // nobody else touches it in this launch
+    const unsigned old = atomicAdd(a.state + p, ((found && inside) ? 0x10000u : 0u) + 1u);
+    if ((old & 0xffffu) == (unsigned)a.wpp - 1u) publish = finish_point(a);   // the last workgroup of this proposal
+  }
+  }
+  if (tid == 0) last_s = publish ? 1 : 0;
+  __syncthreads();
+  if (last_s) {   // workgroup-uniform: fetch (and zero) every proposal's word, 16 answers per thread and host store
+    if (tid * 16 < a.np) {
+      unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int t = tid * 16 + q;
+        const unsigned word = t < a.np ? atomicExch(a.state + t, 0u) : 0u;
+        w[q >> 2] |= ((word >> 16) != 0u ? 1u : 0u) << (8 * (q & 3));
+      }
+      reinterpret_cast<uint4 *>(a.mask)[tid] = make_uint4(w[0], w[1], w[2], w[3]);   // the buffer is 16-byte aligned, kSmallMaxPoints long
     }
-    if (last_of_point) {
-      a.mask[p] = (inside && hits != 0) ? 1 : 0;
-      finish_point(a);
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+      if (a.np > 1) (void)atomicExch(a.finished, 0u);
+      __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

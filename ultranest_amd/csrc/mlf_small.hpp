@@ -28,7 +28,7 @@ struct SmallArgs {
   int n, npad;
   double r2;
   int wpp;                // workgroups per proposal
-  unsigned *state;        // [kSmallMaxPoints], zero between launches (the last workgroup of a proposal resets its word)
+  unsigned *state;        // [kSmallMaxPoints], zero between launches: workgroups reported (low half), hits (high half); fetched and zeroed by the publisher
   unsigned *finished;     // proposals completed in this launch; returns to zero
   uint8_t *mask;          // out (np); may be pinned host memory
   unsigned *flag;         // host-visible word that receives `seq` when every mask byte has been written
