@@ -41,19 +41,25 @@ int mlf_device_count(int *count);
 int mlf_set_device(int device);            /* device used by this process (default 0)      */
 int mlf_device_name(char *buf, size_t buflen);
 int mlf_synchronize(void);
-/* tuning switches: "filter" (1/0: MFMA pre-filter in front of the exact neighbour scan; results are
- * identical either way), "filter_min_queries" (batches below this size use the exact scan only),
- * "filter_phases" (0: one sweep; 1: sweep the live points in two ranges and drop the decided proposals in
- * between; n >= 2: n ranges),
- * "filter_phase_min_queries", "filter_fused_compact" (1/0: that compaction inside the matrix kernel or as
- * separate kernels), "fused_prep", "prep_matrix" (1/0: which preparation kernel), "tq_row_major" (1/0: layout of
- * the whitened proposals handed from the preparation kernel to the exact re-check), "prep_bounded" (1/0: the
- * bounded matrix-core per-proposal stage or the binary64 one), "small_path" (1/0: mlf_region_inside with up to 256
- * proposals as ONE launch over pinned staging -- the calls of the scalar step samplers -- or through the batched
- * pipeline), "filter_first_range_pct" (10 ... 90, default 50: share of the live-point tiles the first of two ranges takes;
- * 35 ... 50 measure the same), "filter_narrow_tail" (0: every range with 4 query groups per wave; 1 (default): later ranges with 2),
- * "time_filter_launches".  Results never depend on them. */
+/* Tuning options.  Every option has a PROCESS default (mlf_set_option) and can be overridden per region handle
+ * (mlf_region_set_option; inherit != 0 returns one option -- or, with name == NULL, all of them -- to the process
+ * default), so that two regions of one process can run different routings.  Results never depend on them.
+ *   "filter"                   1/0: matrix-core pre-filter in front of the exact neighbour scan
+ *   "filter_min_queries"       batches below this size use the exact scan only
+ *   "filter_phases"            0: one sweep; 1 (default): two live-point ranges, decided proposals dropped in between
+ *                              (the compaction rides in the first range's epilogue); n >= 2: n ranges
+ *   "filter_phase_min_queries" smaller batches sweep all tiles in one launch
+ *   "filter_first_range_pct"   10 ... 90, default 50: share of the live-point tiles the first of two ranges takes
+ *   "filter_narrow_tail"       0: every range with 4 query groups per wave; 1 (default): later ranges with 2
+ *   "filter_split_waves"       waves a single-sweep launch over a small batch aims at when it splits the tiles (1-16 ranges)
+ *   "fused_prep"               1/0: fused per-proposal stage, or k_prep followed by a separate quantisation
+ *   "prep_bounded"             1/0: the bounded matrix-core per-proposal stage (split binary16) or the binary64 one
+ *   "small_path"               1/0: mlf_region_inside with up to 256 proposals as ONE launch over pinned staging -- the calls
+ *                              of the scalar step samplers -- or through the batched pipeline
+ *   "time_filter_launches"     1/0: event pairs around every matrix-kernel launch (mlf_region_timing_filter_launch_ms)
+ * mlf_option_name enumerates the names (index 0, 1, ... until it fails). */
 int mlf_set_option(const char *name, long long value);
+int mlf_option_name(int index, char *buf, size_t buflen);
 
 /* ---- K1: find_nearby -- ultranest/mlfriends.pyx:143-183 -----------------------------------
  * out[j] = lowest i with sum_k (apts[i,k]-bpts[j,k])^2 <= radiussq (k ascending, no FMA),
@@ -155,6 +161,8 @@ int mlf_region_set(mlf_region *r, const double *live, size_t n, size_t d, int li
  * of the binary16 proposal operand; without the hint the rows are fetched back once to find it).  Consumed by the next
  * mlf_region_set of the handle. */
 int mlf_region_hint_live_extent(mlf_region *r, double amax);
+/* per-handle tuning option (see mlf_set_option) */
+int mlf_region_set_option(mlf_region *r, const char *name, long long value, int inherit);
 /* in-place live point replacement, integrator.py:2753-2754; the row is in the space given by
  * live_space at mlf_region_set */
 int mlf_region_update_point(mlf_region *r, size_t row, const double *live_row);

@@ -99,16 +99,21 @@ def test_host_helpers_need_no_device():
 
 
 def test_every_documented_option_is_accepted_without_a_device():
-    """mlf_set_option only stores a switch: every name the header documents is accepted (and restored)
-    without a GPU; an unknown name is an error."""
+    """mlf_set_option only stores a process default: every name the header documents is accepted (and restored)
+    without a GPU, the library enumerates exactly those names, an unknown name is an error."""
+    import ctypes
     import re
     from ultranest_amd import _lib
     header = open(os.path.join(os.path.dirname(__file__), "..", "include", "mlfriends_hip.h")).read()
-    block = header[header.index("tuning switches"):header.index("int mlf_set_option")]
-    names = re.findall(r'"([a-z_]+)"', block)
-    assert {"filter", "filter_min_queries", "filter_phases", "filter_phase_min_queries", "filter_fused_compact",
-            "fused_prep", "prep_matrix", "tq_row_major"} <= set(names)
-    defaults = {"filter_min_queries": 257, "filter_phase_min_queries": 32768}
+    block = header[header.index("Tuning options."):header.index("int mlf_set_option")]
+    names = re.findall(r'^ \*   "([a-z_]+)"', block, flags=re.M)
+    listed = []
+    buf = ctypes.create_string_buffer(64)
+    while _lib.lib().mlf_option_name(len(listed), buf, 64) == 0:
+        listed.append(buf.value.decode())
+    assert sorted(names) == sorted(listed) and len(listed) == 11
+    defaults = {"filter_min_queries": 257, "filter_phase_min_queries": 32768, "filter_first_range_pct": 50,
+                "filter_split_waves": 2048, "time_filter_launches": 0}
     for name in names:
         _lib.set_option(name, defaults.get(name, 1))
     with pytest.raises(ValueError, match="unknown option"):

@@ -13,20 +13,17 @@ FUZZ_OFFSET = int(os.environ.get("MLF_FUZZ_OFFSET", "0"))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["phased", "phased-separate-compaction", "single-sweep"])
+@pytest.fixture(scope="module", params=["phased", "single-sweep"])
 def K(request):
-    """Every test runs three times: with the phased sweep (undecided queries compacted between live-point
-    ranges, inside the matrix kernel's epilogue or by separate kernels) forced on for small batches, and
-    with the single sweep."""
+    """Every test runs twice: with the phased sweep (undecided queries compacted between live-point ranges, inside the
+    matrix kernel's epilogue) forced on for small batches, and with the single sweep."""
     from ultranest_amd import _lib, kernels
     assert _lib.device_count() >= 1
     _lib.set_option("filter", 1)
     _lib.set_option("filter_min_queries", 64)      # let small test batches take the filter path
     _lib.set_option("filter_phases", 0 if request.param == "single-sweep" else 1)
-    _lib.set_option("filter_fused_compact", 1 if request.param == "phased" else 0)
     _lib.set_option("filter_phase_min_queries", 64)
     yield kernels
-    _lib.set_option("filter_fused_compact", 1)
     _lib.set_option("filter_min_queries", 257)
     _lib.set_option("filter_phase_min_queries", 32768)
     _lib.set_option("filter_phases", 1)
@@ -163,16 +160,14 @@ def test_fused_prep_matches_unfused(n, d, p, K, oracle):
     reg = K.DeviceRegion()
     reg.set(u, 0, ctr, T, shift, ectr, einv, 60.0, 1.1, live_space=1)
     got = {}
-    # matrix = k_prep3 (FP64 matrix cores), vector = k_prep2, unfused = k_prep + separate quantisation
-    for mode, (fused, matrix) in dict(matrix=(1, 1), vector=(1, 0), unfused=(0, 0)).items():
+    # matrix = k_prep3 (FP64 matrix cores), unfused = k_prep + separate quantisation; set on THIS handle only
+    for mode, fused in dict(matrix=1, unfused=0).items():
         for filt in (1, 0):
-            _lib.set_option("fused_prep", fused)
-            _lib.set_option("prep_matrix", matrix)
-            _lib.set_option("filter", filt)
+            reg.set_option("fused_prep", fused)
+            reg.set_option("filter", filt)
             got[mode, filt] = reg.inside(pts)
-    _lib.set_option("fused_prep", 1)
-    _lib.set_option("prep_matrix", 1)
-    _lib.set_option("filter", 1)
+    reg.set_option("fused_prep")
+    reg.set_option("filter")
     wp = pts.copy()
     wp[:, 0] = np.fmod(wp[:, 0] + shift[0], 1)
     emask = oracle.inside_ellipsoid(pts, ectr, einv, 60.0)

@@ -35,6 +35,8 @@ SIGNATURES = {
     "mlf_adjacency_bits": [_vp, _sz, _sz, _dbl, _vp],
     "mlf_host_cluster_replay": [_vp, _sz, _vp, _vp, _vp],
     "mlf_region_hint_live_extent": [_vp, _dbl],
+    "mlf_region_set_option": [_vp, ctypes.c_char_p, ctypes.c_longlong, ctypes.c_int],
+    "mlf_option_name": [ctypes.c_int, _vp, _sz],
     "mlf_maxradiussq_bootstrap": [_vp, _sz, _sz, _vp, _sz, _vp, _vp],
     "mlf_pair_dist2_lower": [_vp, _sz, _sz, _vp],
     "mlf_inside_ellipsoid": [_vp, _sz, _sz, _vp, _vp, _dbl, _vp, _vp],

@@ -15,7 +15,6 @@
 #include "mlf_misc.hpp"
 #include <atomic>
 #include "mlf_small.hpp"
-#include "mlf_prep2.hpp"
 #include "mlf_prep3.hpp"
 #include "mlf_prep4.hpp"
 #include "mlf_sample.hpp"
@@ -46,6 +45,55 @@ int fail_arg(int code, const char *msg) {
   } while (0)
 
 // Buffers and host-side state of the MFMA pre-filter (mlf_filter.hip) for one set of live points.
+constexpr unsigned kFilterSegCap = 2048;
+constexpr long long kFilterMinQueriesDefault = 257;   // = everything the single-launch path does not take (with the tile
+// ranges of filter_tile_split a 1024-query batch takes 33 us through the filter, 175 us through the exact scan)
+
+// ---- tuning options -----------------------------------------------------------------------------------------------
+// Every option has a PROCESS default (mlf_set_option) and may be overridden per region handle
+// (mlf_region_set_option): two regions of one process can run different routings, and nothing a test or a benchmark
+// flips on one handle reaches another.  Results never depend on them.
+enum Opt : int {
+  OPT_FILTER,              // "filter" 0/1: matrix-core pre-filter in front of the exact scan
+  OPT_FIRST_RANGE_PCT,     // "filter_first_range_pct" 10 ... 90: share of the live-point tiles in the first of two ranges
+  OPT_SPLIT_WAVES,         // "filter_split_waves": waves a single-sweep launch aims at when it splits the tiles (1 ... 16 ranges)
+  OPT_NARROW_TAIL,         // "filter_narrow_tail" 0/1: later ranges of a phased sweep with 2 query groups per wave
+  OPT_SMALL_PATH,          // "small_path" 0/1: one launch for up to 256 proposals handed over on the host
+  OPT_FUSED_PREP,          // "fused_prep" 0/1: fused per-proposal stage (off: k_prep + separate quantisation)
+  OPT_PHASE_MIN_QUERIES,   // "filter_phase_min_queries": smaller batches sweep all tiles in one launch
+  OPT_PHASES,              // "filter_phases": 0 single sweep, 1 default phase count, n >= 2 exactly n phases
+  OPT_TIME_LAUNCHES,       // "time_filter_launches" 0/1: event pairs around every matrix-kernel launch of every call
+  OPT_PREP_BOUNDED,        // "prep_bounded" 0/1: bounded matrix-core per-proposal stage (mlf_prep4.hip) or the binary64 one
+  OPT_MIN_QUERIES,         // "filter_min_queries": smaller batches go straight to the exact scan
+  OPT_COUNT
+};
+const char *const kOptNames[OPT_COUNT] = {"filter", "filter_first_range_pct", "filter_split_waves", "filter_narrow_tail",
+                                          "small_path", "fused_prep", "filter_phase_min_queries", "filter_phases",
+                                          "time_filter_launches", "prep_bounded", "filter_min_queries"};
+long long g_opt[OPT_COUNT] = {1, 50, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault};
+
+struct OptOverrides {
+  long long v[OPT_COUNT] = {};
+  bool set[OPT_COUNT] = {};
+};
+
+int opt_id(const char *name) {
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (!strcmp(name, kOptNames[i])) return i;
+  return -1;
+}
+
+long long opt_clamp(int id, long long value) {
+  switch (id) {
+    case OPT_FIRST_RANGE_PCT: return value < 10 ? 10 : (value > 90 ? 90 : value);
+    case OPT_SPLIT_WAVES: return value < 256 ? 256 : (value > 16384 ? 16384 : value);
+    case OPT_PHASES: return value < 0 ? 0 : (value > 64 ? 64 : value);
+    case OPT_PHASE_MIN_QUERIES:
+    case OPT_MIN_QUERIES: return value;
+    default: return value != 0;
+  }
+}
+
 struct FilterCtx {
   bool refs_ready = false;   // live points quantised
   bool refs_dirty = false;   // a live point was replaced since: requantise before the next batch that uses the operands
@@ -54,7 +102,7 @@ struct FilterCtx {
   double sigma = 1.0, amax = 0.0;
   DevBuf stats, statscratch, refF, qF, tlo, thi, route, best, counters, list, segcnt, gate2;
   // phased sweep: two compacted query sets (ping-pong)
-  DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png, pflags, pblk;
+  DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png;
   // bounded per-proposal stage (mlf_prep4.hip): ellipsoid band list, per-call counters
   // misc: [0] band proposals, [1] k_ell_exact workgroups done -- both return to zero by themselves (no memset per batch),
   // zeroed once when the buffer is allocated; [2], [3] "a proposal is routed to the exact scan", used alternately by
@@ -68,32 +116,17 @@ struct FilterCtx {
   // (start, stop) event pairs around every k_filter launch of the timed calls
   std::vector<hipEvent_t> kev;
   size_t kev_used = 0;
+  OptOverrides ov;            // per-handle tuning (mlf_region_set_option); the stateless calls' context has none
   void release() {
     DevBuf *b[] = {&stats, &statscratch, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2,
-                   &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png, &pflags, &pblk,
+                   &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png,
                    &ell_list, &misc};
     for (DevBuf *x : b) x->release();
     refs_ready = usable = false;
   }
 };
 
-constexpr unsigned kFilterSegCap = 2048;
-bool g_filter_enabled = true;         // mlf_set_option("filter", 0/1)
-bool g_fused_prep = true;             // mlf_set_option("fused_prep", 0/1)
-bool g_tq_row_major = true;           // mlf_set_option("tq_row_major", 0/1): layout of the whitened proposals next to the filter
-bool g_filter_fused_compact = true;   // mlf_set_option("filter_fused_compact", 0/1): compaction inside the matrix kernel's epilogue
-int g_filter_phases = 1;              // mlf_set_option("filter_phases", n): 0 single sweep, 1 default phase count, n >= 2 exactly n phases
-long long g_filter_phase_min_queries = 32768;   // smaller batches sweep all tiles in one launch
-bool g_prep_matrix = true;            // mlf_set_option("prep_matrix", 0/1): FP64 matrix-core fused stage
-bool g_time_filter_launches = false;  // mlf_set_option("time_filter_launches", 0/1): event pairs around every k_filter launch of every call
-int g_filter_first_range_pct = 50;     // mlf_set_option("filter_first_range_pct", 10 ... 90): share of the live-point tiles in the first of two ranges
-int g_filter_split_waves = 2048;       // mlf_set_option("filter_split_waves", n): waves a single-sweep launch aims at when it splits the live-point tiles (1 ... 16 ranges; default: one round of the 2048 resident waves)
-int g_filter_narrow_tail = 1;          // mlf_set_option("filter_narrow_tail", 0/1): later ranges of a phased sweep with 2 query groups per wave
-bool g_small_path = true;             // mlf_set_option("small_path", 0/1): one launch for up to 256 proposals handed over on the host
-bool g_prep_bounded = true;           // mlf_set_option("prep_bounded", 0/1): matrix-core bounded stage (mlf_prep4.hip)
-constexpr long long kFilterMinQueriesDefault = 257;   // = everything the single-launch path does not take
-long long g_filter_min_queries = kFilterMinQueriesDefault;  // smaller batches go straight to the exact scan (with the
-// tile ranges of filter_tile_split a 1024-query batch takes 50 us through the filter, 175 us through the exact scan)
+inline long long opt(const FilterCtx &f, int id) { return f.ov.set[id] ? f.ov.v[id] : g_opt[id]; }
 
 struct Ctx {
   bool ready = false;
@@ -268,10 +301,10 @@ int filter_refresh_refs(FilterCtx &f, const double *refR, int n, int d, int dp, 
 
 // host-side eligibility of one batch (the kernels re-check per query and fall back on their own)
 bool filter_applies(const FilterCtx &f, long long nq, double r2) {
-  if (!g_filter_enabled || !f.refs_ready || !f.usable || nq < g_filter_min_queries) return false;
+  if (!opt(f, OPT_FILTER) || !f.refs_ready || !f.usable || nq < opt(f, OPT_MIN_QUERIES)) return false;
   // below ~2000 proposals the five launches of the filter path (~45 us) only pay when the exact scan has real work:
   // 400 proposals against 400 x 5 live coordinates take 43 us through the exact scan, 51 us through the filter
-  if (g_filter_min_queries == kFilterMinQueriesDefault && nq < 2048 && (long long)f.ntiles32 * 32 * f.ks * 16 < 40000) return false;
+  if (opt(f, OPT_MIN_QUERIES) == kFilterMinQueriesDefault && nq < 2048 && (long long)f.ntiles32 * 32 * f.ks * 16 < 40000) return false;
   if (!(r2 > 0.0) || !(r2 < 1e150)) return false;
   const double sr2 = f.sigma * f.sigma * r2;
   return sr2 < 4096.0 && sr2 > 1e-30;
@@ -291,7 +324,7 @@ int filter_reserve(FilterCtx &f, long long nq, unsigned *cap_out) {
   long long nwaves = filter_wave_count(f.ks, nqpad / 32, f.ks == 4 ? 2 : (f.ks < 4 ? 1 : 0));   // room for a narrow later range
   {   // ... and for the tile ranges of a small batch (filter_tile_split): one segment per (wave, range)
     const long long plain = (filter_wave_count(f.ks, nqpad / 32) + 3) / 4 * 4;
-    const long long split = filter_tile_split(f.ks, nqpad / 32, f.ntiles32, g_filter_split_waves);
+    const long long split = filter_tile_split(f.ks, nqpad / 32, f.ntiles32, (int)opt(f, OPT_SPLIT_WAVES));
     if (split * plain > nwaves) nwaves = split * plain;
   }
   const unsigned cap = kFilterSegCap;   // uncertain pairs per filter wave (expected: tens)
@@ -310,7 +343,7 @@ int filter_reserve(FilterCtx &f, long long nq, unsigned *cap_out) {
 }
 
 // Filter pipeline on device data: answers for all nq queries in out_mask (bytes) and/or out_idx.
-// Query element (j, k) is q[j*ldq + k*ldk].  quantised = true: the fused k_prep2 has already
+// Query element (j, k) is q[j*ldq + k*ldk].  quantised = true: the fused per-proposal stage has already
 // produced the binary16 fragments, thresholds and routes of this batch.
 // Where the exact whitened coordinates come from when the per-proposal stage did not store them (k_prep4): the
 // proposals themselves and the layer; the queries that need coordinates are whitened after the sweeps.
@@ -352,8 +385,11 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   // is sized for the worst case and reads the actual group count from device memory: no host sync.
   int nphase = 1;
   // worth it when the sweep is long compared with one compaction (~25 us + 40 us per 10^6 queries)
-  if (g_filter_phases && nq >= g_filter_phase_min_queries && (g_filter_phase_min_queries < 32768 || nq * f.ntiles32 >= 30000000ll))
-    nphase = g_filter_phases >= 2 ? (g_filter_phases <= f.ntiles32 / 4 ? g_filter_phases : (f.ntiles32 >= 16 ? 2 : 1))
+  const int want_phases = (int)opt(f, OPT_PHASES);
+  const long long phase_min = opt(f, OPT_PHASE_MIN_QUERIES);
+  const int narrow_tail = (int)opt(f, OPT_NARROW_TAIL);
+  if (want_phases && nq >= phase_min && (phase_min < 32768 || nq * f.ntiles32 >= 30000000ll))
+    nphase = want_phases >= 2 ? (want_phases <= f.ntiles32 / 4 ? want_phases : (f.ntiles32 >= 16 ? 2 : 1))
                                   : (f.ntiles32 >= 16 ? 2 : 1);
   if (nphase > 1) {
     for (int i = 0; i < 2; ++i) {
@@ -366,11 +402,9 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       CK(f.png.reserve(4 * sizeof(unsigned)));
       CK(hipMemset(f.png.p, 0, 4 * sizeof(unsigned)));
     }
-    CK(f.pflags.reserve((size_t)nqpad));
-    CK(f.pblk.reserve(((size_t)nqpad / 256 + 2) * sizeof(unsigned)));
   }
-  const bool fused = nphase > 1 && g_filter_fused_compact;
-  fa.split = nphase == 1 ? filter_tile_split(f.ks, ngroups, f.ntiles32, g_filter_split_waves) : 1;
+  const bool fused = nphase > 1;   // the compaction of the undecided queries rides in the matrix kernel's epilogue
+  fa.split = nphase == 1 ? filter_tile_split(f.ks, ngroups, f.ntiles32, (int)opt(f, OPT_SPLIT_WAVES)) : 1;
   // two ranges, compaction inside the first, finalise tail in the scan launch: nobody pads the compacted set or publishes
   // its group count (k_phase_finish: a 5 us launch) -- the second range reads the slot counter itself, the tail resets it
   const bool fold_finish = fused && nphase == 2 && xs != nullptr;
@@ -378,15 +412,15 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   for (int ph = 0; ph < nphase; ++ph) {
     fa.tile0 = (int)((long long)f.ntiles32 * ph / nphase);
     fa.tile1 = (int)((long long)f.ntiles32 * (ph + 1) / nphase);
-    if (nphase == 2) {   // two ranges: the first takes g_filter_first_range_pct per cent of the tiles
-      const int cut = (int)((long long)f.ntiles32 * g_filter_first_range_pct / 100);
+    if (nphase == 2) {   // two ranges: the first takes filter_first_range_pct per cent of the tiles
+      const int cut = (int)((long long)f.ntiles32 * opt(f, OPT_FIRST_RANGE_PCT) / 100);
       const int c = cut < 4 ? 4 : (cut > f.ntiles32 - 4 ? f.ntiles32 - 4 : cut);
       fa.tile0 = ph == 0 ? 0 : c;
       fa.tile1 = ph == 0 ? c : f.ntiles32;
     }
     fa.append = ph > 0;
     fa.seg_first_extra = filter_wave_count(f.ks, ngroups);   // segments beyond the first launch's own: for a narrow later range
-    fa.seg_extra = (g_filter_narrow_tail && nphase > 1 && f.ks <= 4) ? filter_wave_count(f.ks, ngroups, g_filter_narrow_tail) - fa.seg_first_extra : 0;
+    fa.seg_extra = (narrow_tail && nphase > 1 && f.ks <= 4) ? filter_wave_count(f.ks, ngroups, narrow_tail) - fa.seg_first_extra : 0;
     if (fa.seg_extra < 0) fa.seg_extra = 0;
     fa.cq = nullptr;
     if (fused && ph > 0) {   // the previous launch compacted its undecided queries into set (ph - 1) & 1
@@ -411,35 +445,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       fa.ccap = (unsigned)nqpad;
       fa.route = f.route.as<uint8_t>();
     }
-    if (!fused && ph > 0) {   // compact the undecided queries of the previous set into set (ph - 1) & 1
-      const int dst = (ph - 1) & 1, src = ph & 1;
-      PhaseArgs pa{};
-      pa.qF_src = ph == 1 ? f.qF.p : f.pqF[src].p;
-      pa.tlo_src = ph == 1 ? f.tlo.as<float>() : f.ptlo[src].as<float>();
-      pa.thi_src = ph == 1 ? f.thi.as<float>() : f.pthi[src].as<float>();
-      pa.qmap_src = ph == 1 ? nullptr : f.pmap[src].as<int>();
-      pa.ngroups_src = ph == 1 ? nullptr : f.png.as<unsigned>() + src;
-      pa.qF_dst = f.pqF[dst].p;
-      pa.tlo_dst = f.ptlo[dst].as<float>();
-      pa.thi_dst = f.pthi[dst].as<float>();
-      pa.qmap_dst = f.pmap[dst].as<int>();
-      pa.ngroups_dst = f.png.as<unsigned>() + dst;
-      pa.nslots_max = nqpad;
-      pa.nq = nq;
-      pa.route = f.route.as<uint8_t>();
-      pa.best = f.best.as<int>();
-      pa.ks = f.ks;
-      pa.flags = f.pflags.as<uint8_t>();
-      pa.blk = f.pblk.as<unsigned>();
-      launch_phase_compact(pa, s);
-      CK(hipGetLastError());
-      fa.qF = f.pqF[dst].p;
-      fa.tlo = f.ptlo[dst].as<float>();
-      fa.thi = f.pthi[dst].as<float>();
-      fa.qmap = f.pmap[dst].as<int>();
-      fa.ngroups_dev = f.png.as<unsigned>() + dst;
-    }
-    const bool time_launch = ev_after_filter || g_time_filter_launches;
+    const bool time_launch = ev_after_filter || opt(f, OPT_TIME_LAUNCHES);
     if (time_launch) {   // timed call: bracket the matrix kernel itself (the compaction kernels stay outside)
       while (f.kev.size() < f.kev_used + 2) {
         hipEvent_t e;
@@ -448,7 +454,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       }
       CK(hipEventRecord(f.kev[f.kev_used], s));
     }
-    const int narrow = (f.ks <= 4 && ph > 0) ? g_filter_narrow_tail : 0;
+    const int narrow = (f.ks <= 4 && ph > 0) ? narrow_tail : 0;
     CK(launch_filter(f.ks, fa, out_idx != nullptr, s, narrow));
     if (time_launch) {
       CK(hipEventRecord(f.kev[f.kev_used + 1], s));
@@ -461,7 +467,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     }
   }
   if (ev_after_filter) CK(hipEventRecord(ev_after_filter, s));
-  const int any_narrow = (f.ks <= 4 && nphase > 1) ? g_filter_narrow_tail : 0;
+  const int any_narrow = (f.ks <= 4 && nphase > 1) ? narrow_tail : 0;
   long long nsegs_all = filter_wave_count(f.ks, ngroups, any_narrow);
   if (nsegs_all < filter_wave_count(f.ks, ngroups)) nsegs_all = filter_wave_count(f.ks, ngroups);
   if (fa.split > 1) nsegs_all = (filter_wave_count(f.ks, ngroups) + 3) / 4 * 4 * fa.split;
@@ -585,8 +591,8 @@ int scan_host(const double *apts, size_t na, const double *bpts, size_t nb, size
   // The stateless call pays the filter's live-point preparation every time and first-index mode keeps sweeping after
   // a hit, so the pre-filter only pays for larger batches than in the resident mask path (measured at N = 4000,
   // d = 50: exact scan 0.23-0.35 ms against 0.45-1.05 ms at 4000 queries; break-even between 16000 and 50000)
-  const long long host_min = g_filter_min_queries != kFilterMinQueriesDefault ? g_filter_min_queries : 32768;
-  if (mode == SCAN_FIRST && g_filter_enabled && (long long)nb >= host_min && na >= 256) {
+  const long long host_min = opt(c.filter, OPT_MIN_QUERIES) != kFilterMinQueriesDefault ? opt(c.filter, OPT_MIN_QUERIES) : 32768;
+  if (mode == SCAN_FIRST && opt(c.filter, OPT_FILTER) && (long long)nb >= host_min && na >= 256) {
     if (int rc = filter_prepare_refs(c.filter, c.refR.as<double>(), (int)na, (int)d, dp, c.stream, true)) return rc;
     if (filter_applies(c.filter, (long long)nb, r2)) {
       if (int rc = filter_run(c.filter, c.refT.as<double>(), c.refR.as<double>(), (int)na, npad, (int)d, dp,
@@ -822,9 +828,9 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
   uint8_t *gate = r->use_scan ? r->gate.as<uint8_t>() : d_mask;
   const bool use_filter = r->use_scan && filter_applies(r->filter, (long long)np, r->r2);
   // fused stage (coalesced staging, coordinate-major output, optional quantisation) for affine layers
-  const bool fused = r->layer_kind == 0 && g_fused_prep && prep2_usable(r->dp) && r->chol_ready;
+  const bool fused = r->layer_kind == 0 && opt(r->filter, OPT_FUSED_PREP) && prep3_usable(r->d) && r->chol_ready;
   long long ldq = r->d, ldk = 1;
-  const bool bounded = fused && g_prep_bounded && r->p4_ready && !r->has_wrap && (use_filter || !r->use_scan) &&
+  const bool bounded = fused && opt(r->filter, OPT_PREP_BOUNDED) && r->p4_ready && !r->has_wrap && (use_filter || !r->use_scan) &&
                        np < (size_t)0x7fffffff && (reinterpret_cast<uintptr_t>(d_pts) & 15) == 0;   // 16-byte pieces
   ExactSrc xsrc{};
   if (r->use_scan && !bounded) CK(r->tq.reserve(np * (size_t)r->d * sizeof(double)));
@@ -897,7 +903,7 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
       launch_ell_exact(ea, s);
       CK(hipGetLastError());
     }
-  } else if (fused && g_prep_matrix && prep3_usable(r->d)) {   // FP64 matrix-core version of the fused stage
+  } else if (fused) {   // FP64 matrix-core version of the fused stage (v_mfma_f64_16x16x4_f64: the reference's FMA chain bit for bit)
     Prep3Args pa{};
     pa.pts = d_pts;
     pa.np = (long long)np;
@@ -922,7 +928,7 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
       pa.t_ldk = (long long)np;
       ldq = 1;
       ldk = (long long)np;
-      if (use_filter && g_tq_row_major) {   // the exact re-check gathers single proposals: rows of d contiguous doubles
+      if (use_filter) {   // the exact re-check gathers single proposals: rows of d contiguous doubles
         pa.t_ldq = ldq = (long long)r->d;
         pa.t_ldk = ldk = 1;
       }
@@ -943,45 +949,6 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
       }
     }
     CK(launch_prep3(pa, s));
-  } else if (fused) {
-    Prep2Args pa{};
-    pa.pts = d_pts;
-    pa.np = (long long)np;
-    pa.d = r->d;
-    pa.ell_ctr = r->ell_ctr.as<double>();
-    pa.ell_A = r->ell_A.as<double>();
-    pa.enlarge = r->enlarge;
-    pa.gate = gate;
-    pa.ell_Lt = r->ell_Lt.as<double>();
-    pa.ell_eps_scale = r->ell_eps_scale;
-    pa.chol_ok = r->chol_ok ? 1 : 0;
-    if (r->use_scan) {
-      pa.do_tr = 1;
-      pa.lay_ctr = r->lay_ctr.as<double>();
-      pa.lay_T8 = r->lay_T8.as<double>();
-      pa.wrap_shift = r->has_wrap ? r->wrap.as<double>() : nullptr;
-      pa.t_out = r->tq.as<double>();
-      pa.t_ldq = 1;
-      pa.t_ldk = (long long)np;
-      ldq = 1;
-      ldk = (long long)np;
-      if (use_filter) {
-        unsigned cap = 0;
-        FilterCtx &f = r->filter;
-        if (int rc = filter_reserve(f, (long long)np, &cap)) return rc;
-        pa.qF = f.qF.p;
-        pa.tlo = f.tlo.as<float>();
-        pa.thi = f.thi.as<float>();
-        pa.route = f.route.as<uint8_t>();
-        pa.best = f.best.as<int>();
-        pa.counters = f.counters.as<unsigned>();
-        pa.stats = f.stats.as<double>();
-        pa.r2 = r->r2;
-        pa.ks = f.ks;
-        pa.nqpad = ((long long)np + 31) / 32 * 32;
-      }
-    }
-    CK(launch_prep2(r->dp, pa, s));
   } else {
     PrepArgs pa{};
     pa.pts = d_pts;
@@ -1099,63 +1066,16 @@ int mlf_device_name(char *buf, size_t buflen) {
 
 int mlf_set_option(const char *name, long long value) {
   if (!name) return fail_arg(MLF_E_BADARG, "null pointer");
-  if (!strcmp(name, "filter")) {
-    g_filter_enabled = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "filter_first_range_pct")) {
-    g_filter_first_range_pct = value < 10 ? 10 : (value > 90 ? 90 : (int)value);
-    return 0;
-  }
-  if (!strcmp(name, "filter_split_waves")) {
-    g_filter_split_waves = value < 256 ? 256 : (value > 16384 ? 16384 : (int)value);
-    return 0;
-  }
-  if (!strcmp(name, "filter_narrow_tail")) {
-    g_filter_narrow_tail = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "small_path")) {
-    g_small_path = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "fused_prep")) {
-    g_fused_prep = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "filter_phase_min_queries")) {
-    g_filter_phase_min_queries = value;
-    return 0;
-  }
-  if (!strcmp(name, "filter_phases")) {
-    g_filter_phases = value < 0 ? 0 : (value > 64 ? 64 : (int)value);
-    return 0;
-  }
-  if (!strcmp(name, "tq_row_major")) {
-    g_tq_row_major = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "filter_fused_compact")) {
-    g_filter_fused_compact = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "prep_matrix")) {
-    g_prep_matrix = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "time_filter_launches")) {
-    g_time_filter_launches = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "prep_bounded")) {
-    g_prep_bounded = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "filter_min_queries")) {
-    g_filter_min_queries = value;
-    return 0;
-  }
-  return fail_arg(MLF_E_BADARG, "unknown option");
+  const int id = opt_id(name);
+  if (id < 0) return fail_arg(MLF_E_BADARG, "unknown option");
+  g_opt[id] = opt_clamp(id, value);
+  return 0;
+}
+
+int mlf_option_name(int index, char *buf, size_t buflen) {
+  if (!buf || !buflen || index < 0 || index >= OPT_COUNT) return fail_arg(MLF_E_BADARG, "no such option");
+  snprintf(buf, buflen, "%s", kOptNames[index]);
+  return 0;
 }
 
 int mlf_synchronize(void) {
@@ -1631,7 +1551,7 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
     return rc;
   std::vector<double> L((size_t)d * d, 0.0);
   double fro_sq = 0.0;
-  {  // Cholesky factor + Frobenius norm of the ellipsoid matrix for the bounded H3 evaluation (k_prep2)
+  {  // Cholesky factor + Frobenius norm of the ellipsoid matrix for the bounded H3 evaluation
     std::vector<double> Lt((size_t)dp * dp, 0.0);
     bool ok = true;
     double fro = 0.0;
@@ -1748,6 +1668,20 @@ static int small_staging(Ctx &c) {
   CK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c.pin_mask_dev), c.pin_mask, 0));
   CK(c.small_words.reserve(2 * kSmallMaxPoints * sizeof(unsigned)));
   CK(hipMemsetAsync(c.small_words.p, 0, 2 * kSmallMaxPoints * sizeof(unsigned), c.stream));
+  return 0;
+}
+
+int mlf_region_set_option(mlf_region *r, const char *name, long long value, int inherit) {
+  if (!r) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (!name) {   // every option of the handle back to the process defaults (a recycled handle starts clean)
+    if (!inherit) return fail_arg(MLF_E_BADARG, "null pointer");
+    r->filter.ov = OptOverrides{};
+    return 0;
+  }
+  const int id = opt_id(name);
+  if (id < 0) return fail_arg(MLF_E_BADARG, "unknown option");
+  r->filter.ov.set[id] = !inherit;
+  r->filter.ov.v[id] = inherit ? 0 : opt_clamp(id, value);
   return 0;
 }
 
@@ -1897,7 +1831,7 @@ int mlf_region_inside(mlf_region *r, const double *pts, size_t np, uint8_t *mask
   if (!r->ready) return fail_arg(MLF_E_STATE, "region used before mlf_region_set");
   if (np == 0) return 0;
   if (!pts || !mask) return fail_arg(MLF_E_BADARG, "null pointer");
-  if (g_small_path && np <= (size_t)kSmallMaxPoints && r->d <= kSmallMaxDim) return region_inside_small(r, pts, np, mask);
+  if (opt(r->filter, OPT_SMALL_PATH) && np <= (size_t)kSmallMaxPoints && r->d <= kSmallMaxDim) return region_inside_small(r, pts, np, mask);
   Ctx &c = g_ctx;
   const size_t row_bytes = (size_t)r->d * sizeof(double);
   CK(r->mask.reserve(np));

@@ -445,67 +445,8 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
 // In mask mode a query with a certain hit is decided, in first-index mode every later tile can only
 // give a larger index: either way it leaves the sweep.  With 1-3 neighbours per accepted proposal the
 // first hit sits anywhere in the live set, so splitting the sweep into phases and compacting the
-// undecided queries in between removes ~40 % of the matrix work at N = 4000.
-__global__ __launch_bounds__(256) void k_phase_select(PhaseArgs a) {   // flags + per-workgroup counts
-  __shared__ unsigned wsum[4];
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long nslots = a.ngroups_src ? 32ll * (long long)*a.ngroups_src : a.nslots_max;
-  bool keep = false;
-  if (i < nslots) {
-    const long long q = a.qmap_src ? (long long)a.qmap_src[i] : i;
-    keep = q >= 0 && q < a.nq && a.route[q] == 1 && a.best[q] == kNone;
-  }
-  if (i < a.nslots_max) a.flags[i] = keep ? 1 : 0;
-  const unsigned long long b = __ballot(keep);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (unsigned)__popcll(b);
-  __syncthreads();
-  if (threadIdx.x == 0) a.blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-__global__ __launch_bounds__(256) void k_phase_gather(PhaseArgs a) {
-  __shared__ unsigned wsum[4];
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool keep = i < a.nslots_max && a.flags[i] != 0;
-  const unsigned long long b = __ballot(keep);
-  if (lane == 0) wsum[wave] = (unsigned)__popcll(b);
-  __syncthreads();
-  unsigned base = a.blk[blockIdx.x];
-  for (int w = 0; w < wave; ++w) base += wsum[w];
-  const uint4 *src = reinterpret_cast<const uint4 *>(a.qF_src);
-  uint4 *dst = reinterpret_cast<uint4 *>(a.qF_dst);
-  const int KS = a.ks;
-  if (keep) {
-    const unsigned rank = base + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
-    const long long gs = i >> 5, gd = rank >> 5;
-    const int rs = (int)(i & 31), rd = (int)(rank & 31);
-    for (int s = 0; s < KS; ++s) {
-      dst[((size_t)gd * KS + s) * 64 + rd] = src[((size_t)gs * KS + s) * 64 + rs];
-      dst[((size_t)gd * KS + s) * 64 + rd + 32] = src[((size_t)gs * KS + s) * 64 + rs + 32];
-    }
-    a.tlo_dst[rank] = a.tlo_src[i];
-    a.thi_dst[rank] = a.thi_src[i];
-    a.qmap_dst[rank] = a.qmap_src ? a.qmap_src[i] : (int)i;
-  }
-  // padding of the last group + the group count (first workgroup)
-  if (blockIdx.x == 0) {
-    const unsigned total = a.blk[(a.nslots_max + 255) / 256];
-    const unsigned ngroups = (total + 31) / 32;
-    if (threadIdx.x == 0) *a.ngroups_dst = ngroups;
-    const unsigned slot = total + threadIdx.x;
-    if (threadIdx.x < 32 && slot < 32 * ngroups) {
-      const long long gd = slot >> 5;
-      const int rd = (int)(slot & 31);
-      for (int s = 0; s < KS; ++s) {
-        dst[((size_t)gd * KS + s) * 64 + rd] = make_uint4(0u, 0u, 0u, 0u);
-        dst[((size_t)gd * KS + s) * 64 + rd + 32] = make_uint4(0u, 0u, 0u, 0u);
-      }
-      a.tlo_dst[slot] = -1.0f;
-      a.thi_dst[slot] = -1.0f;
-      a.qmap_dst[slot] = -1;
-    }
-  }
-}
+// undecided queries in between removes ~40 % of the matrix work at N = 4000.  The compaction itself rides in the
+// epilogue of the matrix kernels (COMPACT instances of k_filter / k_sweep).
 
 // One wave after a compacting k_filter launch: group count, padding of the last group, counter reset.
 __global__ __launch_bounds__(64) void k_phase_finish(uint4 *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount,
@@ -535,14 +476,6 @@ void launch_phase_finish(void *cq, float *ctlo, float *cthi, int *cmap, unsigned
                          int ks, hipStream_t s) {
   hipLaunchKernelGGL(k_phase_finish, dim3(1), dim3(64), 0, s, reinterpret_cast<uint4 *>(cq), ctlo, cthi, cmap, ccount,
                      ngroups_dst, ks);
-}
-
-void launch_phase_compact(const PhaseArgs &a, hipStream_t s) {
-  if (a.nslots_max <= 0) return;
-  const unsigned grid = (unsigned)((a.nslots_max + 255) / 256);
-  hipLaunchKernelGGL(k_phase_select, dim3(grid), dim3(256), 0, s, a);
-  launch_scan_counts(a.blk, (int)grid, s);
-  hipLaunchKernelGGL(k_phase_gather, dim3(grid), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------- exact re-check --------------

@@ -47,26 +47,6 @@ struct FilterArgs {
 void launch_phase_finish(void *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount, unsigned *ngroups_dst,
                          int ks, hipStream_t s);
 
-// compaction of the queries that are still undecided after a phase
-struct PhaseArgs {
-  const void *qF_src;
-  void *qF_dst;
-  const float *tlo_src, *thi_src;
-  float *tlo_dst, *thi_dst;
-  const int *qmap_src;        // nullptr = identity (first compaction)
-  int *qmap_dst;
-  const unsigned *ngroups_src;   // nullptr: nslots_max / 32
-  unsigned *ngroups_dst;
-  long long nslots_max;       // worst-case number of source slots (multiple of 32)
-  long long nq;
-  const uint8_t *route;
-  const int *best;
-  int ks;
-  uint8_t *flags;             // [nslots_max]
-  unsigned *blk;              // [nslots_max / 256 + 2]
-};
-void launch_phase_compact(const PhaseArgs &a, hipStream_t s);
-
 struct RecheckArgs {
   const unsigned long long *list;
   unsigned seg_cap;

@@ -1,5 +1,5 @@
 // mlf_filter_dev.hpp -- device helpers shared by the query quantisation kernels
-// (k_quant_queries in mlf_filter.hip, the fused k_prep2 in mlf_prep2.hip)
+// (k_quant_queries in mlf_filter.hip, the fused stages k_prep3 / k_prep4)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>

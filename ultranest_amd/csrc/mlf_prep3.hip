@@ -1,6 +1,7 @@
 // mlf_prep3.hip -- fused per-proposal stage of MLFriends.inside for AffineLayer-family regions on
 // the FP64 matrix cores:
-//   H3 ellipsoid test (reference mlfriends.pyx:882-912), bounded form of mlf_prep2.hip
+//   H3 ellipsoid test (reference mlfriends.pyx:882-912) in the bounded |L^T delta|^2 form (the reference's einsum order
+//   only inside that form's own band)
 //   T1 whitening      (:737-743 incl. wraps :529-536)
 //   + binary16 quantisation and thresholds for the MFMA pre-filter (mlf_filter.hip)
 //
@@ -8,11 +9,11 @@
 // evaluated with v_mfma_f64_16x16x4_f64: A = a 16 x 4 matrix fragment (LDS, pre-arranged by the
 // host), B = 4 coordinates x 16 proposals straight from the proposal rows, C = 16 outputs x 16
 // proposals.  The instruction accumulates k-ascending with one rounding per FMA (measured: bit
-// identical to the scalar FMA chain, scripts/probes/mfma64_probe.hip), so T equals k_prep's /
-// k_prep2's whitening bit for bit -- live points whitened by k_prep and proposals whitened here
-// still meet at distance exactly 0.  The vector version (k_prep2) is bound by broadcasting every
-// matrix element to the lanes through LDS once per wave; here an operand register feeds 16 x 16 x 4
-// multiply-adds and the kernel runs at the FP64 issue rate (70+ TFLOP/s measured).
+// identical to the scalar FMA chain, scripts/probes/mfma64_probe.hip), so T equals k_prep's whitening bit for
+// bit -- live points whitened by k_prep and proposals whitened here still meet at distance exactly 0.  A vector
+// version of this stage (k_prep2, rounds 1-2: lane = proposal, both matrices broadcast from LDS; 0.57 against 0.31 ms,
+// removed in round 3) was bound by broadcasting every matrix element to the lanes once per wave; here an operand
+// register feeds 16 x 16 x 4 multiply-adds and the kernel runs at the FP64 issue rate (70+ TFLOP/s measured).
 //
 // Layout per 16-proposal tile: lane l holds proposal (l & 15); of every 16-row block of an output
 // it holds rows (l >> 4) + 4 r, r = 0..3.  Per-proposal scalars are therefore reduced over the four

@@ -188,9 +188,15 @@ class DeviceRegion(object):
             _lib.lib().mlf_region_destroy(self._h)
             self._h = ctypes.c_void_p()
 
+    def set_option(self, name, value=None):
+        """Tuning option of THIS region (mlf_region_set_option); value None = back to the process default
+        (_lib.set_option).  Results never depend on options."""
+        check(_lib.lib().mlf_region_set_option(self._h, name.encode(), 0 if value is None else int(value), int(value is None)))
+
     def release(self):
         """hand the handle (and its buffers) to the next region"""
         if self._h:
+            _lib.lib().mlf_region_set_option(self._h, None, 0, 1)     # the next owner starts from the process defaults
             if len(DeviceRegion._idle) < DeviceRegion._IDLE_MAX:
                 DeviceRegion._idle.append(self._h)
                 self._h = ctypes.c_void_p()
