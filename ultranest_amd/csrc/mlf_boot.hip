@@ -139,21 +139,35 @@ __global__ __launch_bounds__(kWave) void k_boot(BootArgs a) {
       }
     }
     const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
+    // four candidates are built before their minima are taken: a candidate's OR and its v_min_f64 are dependent, and with
+    // one temporary register pair per wave every second instruction waited for the one before it
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const double cand = __longlong_as_double((long long)(bits | ((unsigned long long)(unsigned)mlo[r] << 32)));
-      double m = mind[r];
-      asm volatile("v_min_f64 %0, %0, %1" : "+v"(m) : "v"(cand));   // NaN candidate: m stays (no canonicalisation)
-      mind[r] = m;
+    for (int r0 = 0; r0 < 16; r0 += 4) {
+      double cand[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        cand[q] = __longlong_as_double((long long)(bits | ((unsigned long long)(unsigned)mlo[r0 + q] << 32)));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        double m;
+        asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(mind[r0 + q]), "v"(cand[q]));   // NaN candidate: the minimum stays (no canonicalisation)
+        mind[r0 + q] = m;
+      }
     }
     if (NB > 0) sload_wait(blk[0]);
     MLF_SLOAD("x16", mlo, nmk, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const double cand = __longlong_as_double((long long)(bits | ((unsigned long long)(unsigned)mhi[r] << 32)));
-      double m = mind[16 + r];
-      asm volatile("v_min_f64 %0, %0, %1" : "+v"(m) : "v"(cand));
-      mind[16 + r] = m;
+    for (int r0 = 0; r0 < 16; r0 += 4) {
+      double cand[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        cand[q] = __longlong_as_double((long long)(bits | ((unsigned long long)(unsigned)mhi[r0 + q] << 32)));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        double m;
+        asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(mind[16 + r0 + q]), "v"(cand[q]));
+        mind[16 + r0 + q] = m;
+      }
     }
     sload_wait(mlo);
     MLF_SLOAD("x16", mhi, nmk, 64);
