@@ -12,7 +12,7 @@ import bench  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 dev = torch.device("cuda", 0)
-P = bench.NPROPOSALS
+P = int(os.environ.get("MLF_TS_P", bench.NPROPOSALS))
 u, region = bench.build_region(None)
 h0 = region._dev.sync(region, True)
 u2, region2 = bench.build_region(None)

@@ -204,6 +204,7 @@ class DeviceRebuild(object):
         if use.any():
             maxd = float(r2s[use].max())
             sel_d = masks_d if use.all() else masks_d[torch.from_numpy(np.flatnonzero(use)).to(dev)].contiguous()
+            # (the library's stream is a blocking stream and torch runs on the legacy default stream here: implicitly ordered)
             f = np.empty(int(use.sum()))
             _lib.check(L.mlf_bootstrap_factor(_p(U), n, d, _p(sel_d), len(f), float(d + 2), _lib.ptr(f)))
             if not np.isfinite(f).all():

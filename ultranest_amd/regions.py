@@ -106,7 +106,10 @@ def _select_rounds(masks, use):
         return masks
     if hasattr(masks, "data_ptr"):
         import torch
-        return masks[torch.from_numpy(np.flatnonzero(use)).to(masks.device)]
+        picked = masks[torch.from_numpy(np.flatnonzero(use)).to(masks.device)]
+        # the library copies from this tensor on ITS stream: the index kernel (torch's current stream) has to be done
+        torch.cuda.current_stream(masks.device).synchronize()
+        return picked
     return masks[use]
 
 
