@@ -404,6 +404,27 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     }
   }
   const bool fused = nphase > 1;   // the compaction of the undecided queries rides in the matrix kernel's epilogue
+  // mask mode behind the bounded per-proposal stage, single-sweep batches (below ~262144 proposals at N = 4000): the
+  // re-check (binary64 whitening of the queries of the uncertain pairs + the reference's distance loop) runs inside the
+  // sweep launch, each wave on the segment it has just written, and the ellipsoid band rides in the same launch: three
+  // launches per batch instead of four (131072 proposals: 104 -> 96 us).  Phased sweeps keep the separate re-check launch:
+  // there the waves' re-check tails cost more than the launch they save (10^6: 0.473 -> 0.51 ms)
+  const bool own_recheck = xs != nullptr && out_idx == nullptr && nphase == 1;
+  if (own_recheck) {
+    fa.rw.list = f.list.as<unsigned long long>();
+    fa.rw.seg_cap = cap;
+    fa.rw.seg_count = f.segcnt.as<unsigned>();
+    fa.rw.refR = refR;
+    fa.rw.n = n;
+    fa.rw.d = d;
+    fa.rw.dp = dp;
+    fa.rw.pts = xs->pts;
+    fa.rw.nq = nq;
+    fa.rw.lay_ctr = xs->lay_ctr;
+    fa.rw.T64 = xs->T64;
+    fa.rw.r2 = r2;
+    fa.rw.best = f.best.as<int>();
+  }
   fa.split = nphase == 1 ? filter_tile_split(f.ks, ngroups, f.ntiles32, (int)opt(f, OPT_SPLIT_WAVES)) : 1;
   // two ranges, compaction inside the first, finalise tail in the scan launch: nobody pads the compacted set or publishes
   // its group count (k_phase_finish: a 5 us launch) -- the second range reads the slot counter itself, the tail resets it
@@ -455,6 +476,15 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       CK(hipEventRecord(f.kev[f.kev_used], s));
     }
     const int narrow = (f.ks <= 4 && ph > 0) ? narrow_tail : 0;
+    if (own_recheck) {   // the sweeping waves re-check their own segments; the first launch carries the ellipsoid band
+      fa.append = 0;
+      fa.seg_extra = 0;
+      fa.rw.ell = EllExactArgs{};
+      if (ph == 0 && f.ell_pending) {
+        fa.rw.ell = f.ell_args;
+        f.ell_pending = false;
+      }
+    }
     CK(launch_filter(f.ks, fa, out_idx != nullptr, s, narrow));
     if (time_launch) {
       CK(hipEventRecord(f.kev[f.kev_used + 1], s));
@@ -472,7 +502,9 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   if (nsegs_all < filter_wave_count(f.ks, ngroups)) nsegs_all = filter_wave_count(f.ks, ngroups);
   if (fa.split > 1) nsegs_all = (filter_wave_count(f.ks, ngroups) + 3) / 4 * 4 * fa.split;
   f.last_nsegs = (size_t)nsegs_all;
-  if (xs) {   // no whitened coordinates were stored: the re-check whitens the queries of its pairs itself
+  if (own_recheck) {
+    // nothing left to do here: every sweeping wave has re-checked its own pairs
+  } else if (xs) {   // no whitened coordinates were stored: the re-check whitens the queries of its pairs itself
     RecheckWArgs rw{};
     rw.list = f.list.as<unsigned long long>();
     rw.seg_cap = cap;

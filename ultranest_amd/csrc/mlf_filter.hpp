@@ -1,6 +1,7 @@
 // mlf_filter.hpp -- MFMA pre-filter for the neighbour scan (see mlf_filter.hip)
 #pragma once
 #include "mlf_common.hpp"
+#include "mlf_prep4.hpp"
 
 #define MLF_FILTER_MAXD 128
 
@@ -42,6 +43,10 @@ struct FilterArgs {
   long long seg_first_extra, seg_extra;
   // tile ranges of a non-compacting launch (grid.y); list segment of (wave, range) = wave + range * 4 * grid.x
   int split;
+  // mask-mode sweep behind the bounded per-proposal stage (k_sweep): every wave re-checks the list segment it has just
+  // written itself (rw.pts != nullptr), and the first launch of a batch carries the ellipsoid band (rw.ell.count != nullptr)
+  // in kEllWaves leading waves -- no separate re-check launch
+  RecheckWArgs rw;
 };
 // after a compacting launch: group count of the compacted set, padding of its last group, counter reset
 void launch_phase_finish(void *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount, unsigned *ngroups_dst,

@@ -23,6 +23,7 @@
 // First-index mode (find_nearby proper) stays on k_filter.
 #include "mlf_filter.hpp"
 #include "mlf_filter_dev.hpp"
+#include "mlf_recheck_dev.hpp"
 
 #include <math.h>
 
@@ -81,15 +82,25 @@ constexpr int sweep_waves(int ks, int qw, int pf) {
 
 template <int KS, int QW, bool COMPACT, int PF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sweep_waves(KS, QW, PF)))) void k_sweep(FilterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds_sw[];   // re-check scratch, one slice per wave (own re-check only)
   const int lane = threadIdx.x & 63;
-  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // the first launch of a batch carries the ellipsoid band of the per-proposal stage in kEllWaves leading waves
+  // (the leading workgroups of every tile range of the grid: only those of range 0 have work)
+  const unsigned nellblk = (a.rw.pts && a.rw.ell.count) ? kEllWaves / 4 : 0u;
+  double *lds_wave = lds_sw + (size_t)(threadIdx.x >> 6) * (recheck_w_lds(a.rw.d) / sizeof(double));
+  if (blockIdx.x < nellblk) {
+    if (blockIdx.y == 0) ell_exact_wave(a.rw.ell, lds_wave, blockIdx.x * 4 + (threadIdx.x >> 6), kEllWaves);
+    return;
+  }
+  const unsigned bx = blockIdx.x - nellblk, gx = gridDim.x - nellblk;   // this workgroup among the sweeping ones
+  const long long wave = (long long)bx * 4 + (threadIdx.x >> 6);
   const long long g0 = wave * QW;  // first query group of this wave
   const long long nslots = a.nslots_dev ? (long long)*a.nslots_dev : -1;
   const long long ngroups = nslots >= 0 ? (nslots + 31) / 32 : (a.ngroups_dev ? (long long)*a.ngroups_dev : a.ngroups);
   const int sub = COMPACT ? 0 : (int)blockIdx.y, nsub = COMPACT ? 1 : (int)gridDim.y;
-  const long long seg = wave + (long long)sub * gridDim.x * 4;
+  const long long seg = wave + (long long)sub * gx * 4;
   if (!a.append && a.seg_extra > 0 && lane == 0 && sub == 0)
-    for (long long i = wave; i < a.seg_extra; i += (long long)gridDim.x * 4) a.seg_count[a.seg_first_extra + i] = 0u;
+    for (long long i = wave; i < a.seg_extra; i += (long long)gx * 4) a.seg_count[a.seg_first_extra + i] = 0u;
   if (g0 >= ngroups) {
     if (lane == 0 && !a.append) a.seg_count[seg] = 0;
     return;
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sweep_waves
   const int tile0 = a.tile0 + (int)((long long)ntl_all * sub / nsub);
   const int tile1 = a.tile0 + (int)((long long)ntl_all * (sub + 1) / nsub);
   const int ntl = tile1 - tile0;
-  const int tstart = tile0 + (int)(((long long)blockIdx.x * 37) % ntl);
+  const int tstart = tile0 + (int)(((long long)bx * 37) % ntl);
   constexpr int kTileBytes = KS * 1024;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.refF), 0, a.ntiles32 * kTileBytes, 0x00020000);
@@ -314,17 +325,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sweep_waves
     a.seg_count[seg] = cursor < a.seg_cap ? cursor : a.seg_cap;
     if (cursor > a.seg_cap) a.counters[1] = 1u;   // overflow: the exact scan redoes the batch
   }
+  if (a.rw.pts && cursor != 0u && cursor <= a.seg_cap) {   // wave-uniform: re-check the pairs this wave has just listed
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the entries were written by other lanes of this wave
+    recheck_segment(a.rw, seglist, cursor, lds_wave, lane);
+  }
 }
 
 template <int KS, int QW>
 static hipError_t launch_sweep_t(const FilterArgs &a, hipStream_t s) {
   const long long waves = (a.ngroups + QW - 1) / QW;
-  const dim3 grid((unsigned)((waves + 3) / 4), (unsigned)((a.cq || a.split < 1) ? 1 : a.split));
+  const unsigned nellblk = (a.rw.pts && a.rw.ell.count) ? kEllWaves / 4 : 0u;
+  const dim3 grid((unsigned)((waves + 3) / 4) + nellblk, (unsigned)((a.cq || a.split < 1) ? 1 : a.split));
+  const size_t lds = a.rw.pts ? 4 * recheck_w_lds(a.rw.d) : 0;   // <= 36 KiB (d <= 64)
   constexpr int PF = (KS * QW >= 12 && KS <= 4) ? 2 : 1;   // room for a third set of tile registers next to 2 waves per SIMD
   if (a.cq)
-    hipLaunchKernelGGL((k_sweep<KS, QW, true, PF>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_sweep<KS, QW, true, PF>), grid, dim3(256), lds, s, a);
   else
-    hipLaunchKernelGGL((k_sweep<KS, QW, false, PF>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_sweep<KS, QW, false, PF>), grid, dim3(256), lds, s, a);
   return hipGetLastError();
 }
 
