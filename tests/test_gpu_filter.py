@@ -304,3 +304,46 @@ def test_second_range_ignores_stale_slots_of_an_unpadded_last_group(K):
             _lib.set_option("filter", 1)
             assert np.array_equal(got, want), (rnd, d, n, p, np.flatnonzero(got != want)[:5])
     reg.close()
+
+
+def test_options_are_per_region_handle(K, oracle):
+    """mlf_region_set_option overrides the process default for ONE handle: two regions of a process run different
+    routings (the switches were process-global), give the same mask, and a released handle starts clean."""
+    import inputs
+    from ultranest_amd import _lib
+    n, d, p = 500, 6, 4000
+    u = inputs.live_points(77, n, d)
+    ctr = u.mean(axis=0)
+    cov = np.atleast_2d(np.cov(u, rowvar=0)) * (d + 2)
+    ev, evec = np.linalg.eigh(cov)
+    T = evec * ev ** -0.5
+    inv = np.linalg.inv(cov)
+    pts = inputs.proposal_mix(78, u, p, shell_q=2.0)
+    a, b = K.DeviceRegion(), K.DeviceRegion()
+    for reg in (a, b):
+        reg.set(u, 0, ctr, T, None, ctr, inv, 40.0, 1.2, live_space=1)
+    assert a.filter_info(p)[0] and b.filter_info(p)[0]
+    b.set_option("filter", 0)
+    assert a.filter_info(p)[0] and not b.filter_info(p)[0], "the override must reach one handle only"
+    ma, mb = a.inside(pts), b.inside(pts)
+    tl = oracle.affine_transform(u, ctr, T)
+    want = oracle.inside_ellipsoid(pts, ctr, inv, 40.0) & (oracle.find_nearby(tl, oracle.affine_transform(pts, ctr, T), 1.2) >= 0)
+    assert np.array_equal(ma, want) and np.array_equal(mb, want)
+    _lib.set_option("filter", 0)           # the process default moves: the handle without an override follows it
+    try:
+        assert not a.filter_info(p)[0]
+        b.set_option("filter", 1)
+        assert b.filter_info(p)[0]
+    finally:
+        _lib.set_option("filter", 1)
+    b.set_option("filter")                 # back to the default
+    assert b.filter_info(p)[0]
+    b.set_option("filter", 0)
+    b.release()
+    c = K.DeviceRegion()                   # recycles b's handle: no override left
+    c.set(u, 0, ctr, T, None, ctr, inv, 40.0, 1.2, live_space=1)
+    assert c.filter_info(p)[0]
+    with pytest.raises(ValueError, match="unknown option"):
+        c.set_option("no_such_switch", 1)
+    a.close()
+    c.close()
