@@ -20,7 +20,7 @@ os.makedirs(P, exist_ok=True)
 # kernels of the headline step (1e6 proposals per launch in the bench's --headline-only pass) and the smallest grid
 # (threads) such a launch has: the same kernels also run on the 4000 live points during the region build
 HEADLINE_GRID = {"k_prep4": 100000, "k_prep3": 100000, "k_sweep<4, 4, true": 400000,
-                 "k_sweep<4, 2, false": 400000, "k_sweep<4, 4, false": 400000, "k_recheck_whiten": 400000, "k_scan": 400000,
+                 "k_sweep<4, 2, false": 400000, "k_recheck_whiten": 400000, "k_scan": 400000,
                  "k_phase_finish": 64}
 
 
@@ -92,7 +92,7 @@ for key in pmc:
         summary[key]["hbm_traffic"] = dict(FETCH_SIZE_KiB=f_kb, WRITE_SIZE_KiB=w_kb, bytes_raw=(f_kb + w_kb) * 1024.0,
                                            bytes_gfx950_corrected=(2.0 * f_kb + w_kb) * 1024.0)
 # the roofline entry of bench.py is per k_filter launch, averaged over the two launches of a step
-mainkeys = [k for k in ("k_sweep<4, 4, true", "k_sweep<4, 2, false", "k_sweep<4, 4, false") if k in pmc and "FETCH_SIZE" in pmc[k]]
+mainkeys = [k for k in ("k_sweep<4, 4, true", "k_sweep<4, 2, false") if k in pmc and "FETCH_SIZE" in pmc[k]]
 if not mainkeys and "k_scan" in pmc and "FETCH_SIZE" in pmc["k_scan"]:
     mainkeys = ["k_scan"]
 if mainkeys:
