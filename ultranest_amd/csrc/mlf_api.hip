@@ -1302,11 +1302,13 @@ int mlf_maxradiussq_bootstrap(const double *pts, size_t n, size_t d, const uint8
   CK(c.M.reserve((size_t)kBootGroup * npad * sizeof(unsigned long long)));
   CK(c.small0.reserve(B * sizeof(double)));
   CK(c.small1.reserve(B));
-  // enough live-point chunks to put ~2 waves on every SIMD of the chip
+  // live-point chunks: one round of the 2048 waves the chip holds at two per SIMD (k_boot's register budget), equal shares
+  // (a wave pays ~1 us of set-up for its own 64 rows: no chunk below 8 live points)
   const int rowblocks = npad / kWave;
-  int want_chunks = (2048 + rowblocks - 1) / rowblocks;
+  int want_chunks = 2048 / rowblocks;
   if (want_chunks < 1) want_chunks = 1;
-  int chunk = round_up(((int)n + want_chunks - 1) / want_chunks, kBootTI);
+  int chunk = ((int)n + want_chunks - 1) / want_chunks;
+  if (chunk < 8) chunk = 8;
   const int nchunks = ((int)n + chunk - 1) / chunk;
   const double init = 1e300;
   unsigned long long init_bits;

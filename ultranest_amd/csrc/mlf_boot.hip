@@ -8,52 +8,66 @@
 //
 // Mapping: one LANE owns one row j (a potential "unselected" point b_j), coordinates in
 // registers, plus 32 running minima (one per bootstrap round).  The live points i are streamed
-// through an LDS sub-tile and broadcast to the wave; whether i is selected in round b is a
-// wave-uniform bit, so each masked min is a scalar select + one v_min_f64.  The live points are
+// past the wave; whether i is selected in round b is a wave-uniform bit.  The live points are
 // split over blockIdx.y chunks to fill the chip (N = 4000 rows are only 63 waves); the partial
 // minima meet in M[b][j] through 64-bit atomicMin on the bit patterns (order preserving for
 // non-negative doubles).
 //
 // Compiled with -ffp-contract=off: diff = a_i[k] - b_j[k]; acc += diff*diff, k ascending.
+#include <type_traits>
+
 #include "mlf_common.hpp"
 
 namespace mlf {
 
-// Round 3.  The live point i a wave is working on is the same for all its lanes, so its coordinates and its 32
-// selection words travel through the SCALAR unit (s_load_dwordx16 from refR / selmask, issued one 8-coordinate block
-// ahead of their use) and enter the vector instructions as scalar operands: no LDS tile, no barrier, no ds_read latency
-// for the one or two waves a SIMD holds (round 2: 32-row LDS tiles, two barriers per tile, 40 % of the vector issue
-// slots used).  The masked minimum of round r is  mind[r] = min(mind[r], acc')  with the high word of acc' = high word
-// of acc OR selmask[i][r] (0 if i is selected in round r, 0xffffffff otherwise): an unselected i turns the candidate
-// into a quiet NaN, which v_min_f64 ignores -- 2 vector instructions per round where select + compare + select took
-// 4-5.  The non-NaN candidates are the same binary64 values as before and min is exact: results bit-identical.
-typedef int sgpr16 __attribute__((ext_vector_type(16)));
-typedef int sgpr8 __attribute__((ext_vector_type(8)));
-typedef int sgpr4 __attribute__((ext_vector_type(4)));
+// How the live point i reaches all 64 lanes (it is the same for the whole wave).
+//   round 2: 32-row LDS tiles, two barriers per tile; 40 % of the vector issue slots used.
+//   round 3a: scalar loads (s_load_dwordx16 from refR / selmask, one 8-coordinate block ahead of its use), the values
+//     entering the vector instructions as scalar operands.  Counters (profiles/r03_rebuild_pmc_summary.json): 67 % of the
+//     wave-cycles in s_waitcnt -- scalar loads return out of order, so every wait is lgkmcnt(0), i.e. a wait for the
+//     request issued one block (96 cycles) earlier, and a request that misses the 16 KB scalar cache (the rows stream
+//     through it) takes ~430 cycles; a SIMD holds two of these waves (178 VGPRs), nine waits per live point.
+//   round 3b (this kernel): VECTOR loads, three live points ahead, and the DPP row broadcast.  Lane l loads coordinate
+//     16 c + (l mod 16) of the live point into register pair c: each row of 16 lanes holds the same 16 coordinates, and
+//     `v_mov_b64_dpp ... row_newbcast:k` hands coordinate 16 c + k to every lane (one extra vector instruction per
+//     coordinate, 4 instead of 3; no scalar or LDS traffic, vector loads return in order so that vmcnt waits only for
+//     what is needed).  The 32 selection words of the live point sit in two registers the same way and enter the
+//     candidate's OR through the DPP operand of `v_or_b32` itself.
+// The masked minimum of round r is  mind[r] = min(mind[r], acc')  with the high word of acc' = high word of acc OR
+// selmask[i][r] (0 if i is selected in round r, 0xffffffff otherwise): an unselected i turns the candidate into a quiet
+// NaN, which v_min_f64 ignores -- 2 vector instructions per round where select + compare + select took 4-5.  The
+// non-NaN candidates are the same binary64 values as before and min is exact: results bit-identical.
+constexpr int kDppRowNewBcast = 0x150;   // DPP control row_newbcast:0 (gfx90a+): lane k of each row of 16 to the whole row
 
-// scalar loads are asynchronous: the value may be used only behind sload_wait on the same variable
-#define MLF_SLOAD(SUFFIX, dst, ptr, byteoff)                                                                \
-  do {                                                                                                      \
-    asm volatile("s_load_dword" SUFFIX " %0, %1, %2" : "=s"(dst) : "s"(ptr), "n"(byteoff) : "memory");      \
-    __builtin_amdgcn_sched_barrier(0); /* the request stays in front of the arithmetic it is meant to overlap */ \
-  } while (0)
+template <int K>
+__device__ __forceinline__ double row_bcast(double x) {
+  return __builtin_amdgcn_update_dpp(0.0, x, kDppRowNewBcast + K, 0xf, 0xf, true);
+}
+template <int K>
+__device__ __forceinline__ unsigned row_bcast(unsigned x) {
+  return __builtin_amdgcn_update_dpp(0u, x, kDppRowNewBcast + K, 0xf, 0xf, true);
+}
 
-template <class V>
-__device__ __forceinline__ void sload_wait(V &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)); }
-template <class V, class W>
-__device__ __forceinline__ void sload_wait(V &v, W &w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+s"(w)); }
-template <class V, class W, class X>
-__device__ __forceinline__ void sload_wait(V &v, W &w, X &x) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+s"(w), "+s"(x)); }
+template <int K, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (K < N) {
+    f(std::integral_constant<int, K>{});
+    static_for<K + 1, N>(f);
+  }
+}
 
-template <class V>
-__device__ __forceinline__ double sgpr_double(const V &v, int k) { return __hiloint2double(v[2 * k + 1], v[2 * k]); }
+template <int NCH>
+struct BootRow {        // one live point as the wave holds it: 16 coordinates per register pair, 16 selection words per register
+  double x[NCH];
+  unsigned mlo, mhi;
+};
 
 template <int DP>
-__global__ __launch_bounds__(kWave) void k_boot(BootArgs a) {
-  static_assert(kBootGroup == 32, "two 16-word selection blocks per live point");
-  constexpr int NB = DP / 8;        // full blocks of 8 coordinates
-  constexpr int TAIL = DP - 8 * NB; // 0, 2, 4 or 6 coordinates (DP is even)
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(DP <= 64 ? 2 : 1, DP <= 64 ? 2 : 1))) void k_boot(BootArgs a) {
+  static_assert(kBootGroup == 32, "two registers of 16 selection words per live point");
+  constexpr int NCH = (DP + 15) / 16;
   const int lane = threadIdx.x;
+  const int sub = lane & 15;
   const int j = blockIdx.x * kWave + lane;  // < npad by construction of the grid
   double b[DP];
 #pragma unroll
@@ -69,111 +83,71 @@ __global__ __launch_bounds__(kWave) void k_boot(BootArgs a) {
   if (i_end > a.n) i_end = a.n;
   if (i_begin >= i_end) return;
 
-  const double *row = a.refR + (size_t)i_begin * DP;             // wave-uniform
-  const unsigned *mk = a.selmask + (size_t)i_begin * kBootGroup;
-  sgpr16 blk[2];   // two coordinate blocks in flight / in use
-  sgpr8 t8;
-  sgpr4 t4;
-  sgpr16 mlo, mhi;
-  auto issue = [&](int t, const double *r) __attribute__((always_inline)) {   // block t of the row at r
-    if (t < NB) {
-      if (t & 1) MLF_SLOAD("x16", blk[1], r, 0); else MLF_SLOAD("x16", blk[0], r, 0);
-    }
+  int off[NCH];   // this lane's coordinate in chunk c (the last chunk of a row repeats its last coordinate: never broadcast)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) off[c] = 16 * c + sub < DP ? 16 * c + sub : DP - 1;
+  const int last = a.n - 1;
+  auto fetch = [&](BootRow<NCH> &R, int i) __attribute__((always_inline)) {
+    const int ii = i < last ? i : last;   // requests past the chunk are harmless, past the array they are not
+    const double *r = a.refR + (size_t)ii * DP;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) R.x[c] = r[off[c]];
+    const unsigned *k = a.selmask + (size_t)ii * kBootGroup;
+    R.mlo = k[sub];
+    R.mhi = k[16 + sub];
+    // the requests stay HERE, two live points ahead of their use: without the barrier the compiler sinks these loads of
+    // read-only data down to their first use (and every live point then costs a full memory latency)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   };
-  (void)issue;
-  // prologue: block 0 and both selection blocks of the first row
-  MLF_SLOAD("x16", mlo, mk, 0);
-  MLF_SLOAD("x16", mhi, mk, 64);
-  if (NB > 0) MLF_SLOAD("x16", blk[0], row, 0);
-  if (NB > 0) sload_wait(blk[0], mlo, mhi); else sload_wait(mlo, mhi);
-
-  for (int i = i_begin; i < i_end; ++i) {
-    const double *nrow = row + DP;   // the rows past i_end - 1 exist (npad rows, or the next chunk's): loaded, never used
-    const unsigned *nmk = mk + kBootGroup;
-    double acc = 0.0;
-    if (NB == 0) {   // d < 8: the row is its own tail
-      if (TAIL >= 4) MLF_SLOAD("x8", t8, row, 0);
-      if (TAIL == 2) MLF_SLOAD("x4", t4, row, 0);
-      if (TAIL == 6) MLF_SLOAD("x4", t4, row, 32);
-      if (TAIL == 2) sload_wait(t4);
-      if (TAIL == 4) sload_wait(t8);
-      if (TAIL == 6) sload_wait(t8, t4);
-    }
-    // coordinate blocks: block t is in blk[t & 1] and ready; block t + 1 is requested before block t is consumed
-#pragma unroll
-    for (int t = 0; t < NB; ++t) {
-      if (t + 1 < NB) {
-        if ((t + 1) & 1) MLF_SLOAD("x16", blk[1], row, 64 * (t + 1)); else MLF_SLOAD("x16", blk[0], row, 64 * (t + 1));
-      } else {
-        if (TAIL >= 4) MLF_SLOAD("x8", t8, row, 64 * NB);
-        if (TAIL == 2) MLF_SLOAD("x4", t4, row, 64 * NB);
-        if (TAIL == 6) MLF_SLOAD("x4", t4, row, 64 * NB + 32);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const double d0 = sgpr_double(blk[t & 1], k) - b[8 * t + k];
-        acc += d0 * d0;
-      }
-      if (t + 1 < NB) {
-        sload_wait(blk[(t + 1) & 1]);
-      } else {
-        if (TAIL == 2) sload_wait(t4);
-        if (TAIL == 4) sload_wait(t8);
-        if (TAIL == 6) sload_wait(t8, t4);
-      }
-    }
-    // next row's first block travels during the tail coordinates and the first half of the minima
-    if (NB > 0) MLF_SLOAD("x16", blk[0], nrow, 0);
-    if (TAIL >= 4) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const double d0 = sgpr_double(t8, k) - b[8 * NB + k];
-        acc += d0 * d0;
-      }
-    }
-    if (TAIL == 2 || TAIL == 6) {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const double d0 = sgpr_double(t4, k) - b[8 * NB + (TAIL == 6 ? 4 : 0) + k];
-        acc += d0 * d0;
-      }
-    }
+  auto process = [&](const BootRow<NCH> &R) __attribute__((always_inline)) {
+    // the reference's loop (diff, diff * diff, acc +=, k ascending), written skewed: stage s broadcasts coordinate s,
+    // subtracts for s - 1, squares for s - 2 and accumulates s - 3, so that every instruction's operand was produced four
+    // instructions earlier (a dependent binary64 instruction issues 8 cycles after its producer, an independent one after
+    // 4; left to itself the scheduler kept the four instructions of a coordinate back to back in two of three sections)
+    double acc = 0.0, xb[4], dd[4], sq[4];
+    static_for<0, DP + 3>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s >= 3) acc += sq[(s - 3) & 3];
+      if constexpr (s >= 2 && s - 2 < DP) sq[(s - 2) & 3] = dd[(s - 2) & 3] * dd[(s - 2) & 3];
+      if constexpr (s >= 1 && s - 1 < DP) dd[(s - 1) & 3] = xb[(s - 1) & 3] - b[s - 1];
+      if constexpr (s < DP) xb[s & 3] = row_bcast<(s & 15)>(R.x[s >> 4]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
     const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
-    // four candidates are built before their minima are taken: a candidate's OR and its v_min_f64 are dependent, and with
-    // one temporary register pair per wave every second instruction waited for the one before it
-#pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += 4) {
+    const unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32);
+    // four candidates are built before their minima are taken: a candidate's OR and its v_min_f64 are dependent
+    static_for<0, kBootGroup / 4>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int r0 = 4 * decltype(gc)::value;
       double cand[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        cand[q] = __longlong_as_double((long long)(bits | ((unsigned long long)(unsigned)mlo[r0 + q] << 32)));
+      static_for<0, 4>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int r = r0 + decltype(qc)::value;
+        const unsigned h = row_bcast<(r & 15)>(r < 16 ? R.mlo : R.mhi) | hi;
+        cand[r - r0] = __hiloint2double((int)h, (int)lo);
+      });
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         double m;
         asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(mind[r0 + q]), "v"(cand[q]));   // NaN candidate: the minimum stays (no canonicalisation)
         mind[r0 + q] = m;
       }
-    }
-    if (NB > 0) sload_wait(blk[0]);
-    MLF_SLOAD("x16", mlo, nmk, 0);
-#pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += 4) {
-      double cand[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        cand[q] = __longlong_as_double((long long)(bits | ((unsigned long long)(unsigned)mhi[r0 + q] << 32)));
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        double m;
-        asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(mind[16 + r0 + q]), "v"(cand[q]));
-        mind[16 + r0 + q] = m;
-      }
-    }
-    sload_wait(mlo);
-    MLF_SLOAD("x16", mhi, nmk, 64);
-    sload_wait(mhi);
-    row = nrow;
-    mk = nmk;
+    });
+  };
+
+  // three register sets: live points i + 1 and i + 2 on their way while i is consumed (a fourth set: no change)
+  BootRow<NCH> R0, R1, R2;
+  fetch(R0, i_begin);
+  fetch(R1, i_begin + 1);
+  for (int i = i_begin;;) {
+    fetch(R2, i + 2);
+    process(R0);
+    if (++i >= i_end) break;
+    fetch(R0, i + 2);
+    process(R1);
+    if (++i >= i_end) break;
+    fetch(R1, i + 2);
+    process(R2);
+    if (++i >= i_end) break;
   }
 
   if (j < a.n) {

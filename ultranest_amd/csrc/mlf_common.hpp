@@ -17,7 +17,6 @@ namespace mlf {
 constexpr int kWave = 64;
 constexpr int kScanQB = 64;        // queries staged in LDS per scan workgroup
 constexpr int kScanThreads = 256;  // 4 waves; wave w owns live-point tiles w, w+4, ...
-constexpr int kBootTI = 32;        // live points per LDS sub-tile in the bootstrap kernel
 constexpr int kBootGroup = 32;     // bootstrap rounds handled per launch (one selection bit each)
 constexpr int kNone = 0x7fffffff;  // "no neighbour found yet"
 
@@ -90,7 +89,7 @@ struct BootArgs {
   const unsigned *sel;  // [npad] bit b set = live point selected in bootstrap round b of this group
   const unsigned *selmask;  // [npad][kBootGroup] 0 if the live point is selected in the round, 0xffffffff otherwise
   int n, npad;
-  int chunk;            // live points per blockIdx.y (multiple of kBootTI)
+  int chunk;            // live points per blockIdx.y
   unsigned long long *M;  // [kBootGroup][npad] running minima as ordered bit patterns
 };
 
