@@ -230,3 +230,45 @@ def tree_points(seed, nnodes, udim=3):
 
 RESULT_TREES = [(1201, 20, 160, 6), (1202, 8, 90, 3)]      # (seed, nroots, nnodes, nbootstraps of the run counter)
 RESULT_PARAMNAMES = (["a", "b", "c"], ["r2"])
+
+
+# ---- dump_tree through a recording stand-in for h5py (g14; h5py is not in this image) ----
+class RecordingH5File(object):
+    """Stand-in for ``h5py.File`` (h5py is not in this image): records what the writer hands to ``create_dataset``."""
+    written = {}
+
+    def __init__(self, filename, mode):
+        RecordingH5File.written = dict(filename=filename, mode=mode, datasets={})
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def create_dataset(self, name, data=None, **options):
+        RecordingH5File.written["datasets"][name] = (np.array(data), options)
+
+
+def recorded_tree_dump(netiter, seed, nroots, nnodes):
+    """`dump_tree` of a seeded tree (the trees of g12) with the recording stand-in as h5py"""
+    import sys
+    import types
+    values, children = random_tree(seed, nroots, nnodes)
+    us, ps = tree_points(seed, len(values))
+    pile = netiter.PointPile(us.shape[1], ps.shape[1])
+    for urow, prow in zip(us, ps):
+        pile.add(urow, prow)
+    roots = build_nodes(netiter.TreeNode, values, children, nroots)
+    fake = types.ModuleType("h5py")
+    fake.File = RecordingH5File
+    saved = sys.modules.get("h5py")
+    sys.modules["h5py"] = fake
+    try:
+        netiter.dump_tree("tree_%d.hdf5" % seed, roots, pile)
+    finally:
+        if saved is None:
+            del sys.modules["h5py"]
+        else:
+            sys.modules["h5py"] = saved
+    return RecordingH5File.written

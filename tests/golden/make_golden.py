@@ -687,7 +687,26 @@ def g13(ref):
     save("g13_overclustered", **out)
 
 
-GROUPS = dict(g13=g13, g12=g12, g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
+# ------------------------------------------------------------------ G14 -----
+
+def g14(ref):
+    """`dump_tree` (reference netiter.py:220-256): the arrays and dataset options the reference
+    hands to h5py for the seeded trees of g12."""
+    import ultranest.netiter as netiter
+    out = {}
+    for seed, nroots, nnodes, _ in inputs.RESULT_TREES:
+        w = inputs.recorded_tree_dump(netiter, seed, nroots, nnodes)
+        k = "t%d_" % seed
+        out[k + "mode"] = np.array(w["mode"])
+        out[k + "names"] = np.array(list(w["datasets"]))
+        for name, (data, options) in w["datasets"].items():
+            out[k + name] = data
+            out[k + name + "_options"] = np.array(json.dumps(options, sort_keys=True))
+        print("  tree", seed, {n: d.shape for n, (d, _) in w["datasets"].items()})
+    save("g14_tree_dump", **out)
+
+
+GROUPS = dict(g14=g14, g13=g13, g12=g12, g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

@@ -9,6 +9,7 @@ computed through the compiled counter: 1e-10 (libm instead of numpy's vector exp
 import hashlib
 import json
 import os
+import sys
 import types
 
 import numpy as np
@@ -183,3 +184,28 @@ def test_make_run_dir_numbering_limit(tmp_path):
     assert os.path.exists(os.path.join(base, 'run2'))
     with pytest.raises(ValueError):
         make_run_dir(base, max_run_num=3)
+
+
+# ---- dump_tree (reference netiter.py:220-256) ----------------------------------------------------
+@pytest.mark.parametrize("seed,nroots,nnodes,nboot", inputs.RESULT_TREES)
+def test_dump_tree_hands_h5py_what_the_reference_does(golden, seed, nroots, nnodes, nboot):
+    """h5py is not in the image: the reference's dump_tree and ours both write through the recording stand-in of
+    tests/golden/inputs.py (g14); same file mode, same datasets in the same order, same arrays bit for bit, same options."""
+    import json
+    import ultranest_amd.netiter as netiter
+    g = golden("g14_tree_dump")
+    k = "t%d_" % seed
+    w = inputs.recorded_tree_dump(netiter, seed, nroots, nnodes)
+    assert w["mode"] == str(g[k + "mode"]) and w["filename"] == "tree_%d.hdf5" % seed
+    assert list(w["datasets"]) == list(g[k + "names"])
+    for name, (data, options) in w["datasets"].items():
+        want = g[k + name]
+        assert data.dtype == want.dtype and np.array_equal(data, want), name
+        assert json.dumps(options, sort_keys=True) == str(g[k + name + "_options"]), name
+
+
+def test_dump_tree_without_h5py_raises_importerror(monkeypatch):
+    import ultranest_amd.netiter as netiter
+    monkeypatch.setitem(sys.modules, "h5py", None)
+    with pytest.raises(ImportError):
+        netiter.dump_tree("nowhere.hdf5", [], netiter.PointPile(2, 2))

@@ -340,6 +340,34 @@ def find_nodes_before(root, value):
     return parents, parent_weights
 
 
+def dump_tree(filename, roots, pointpile):
+    """Write the tree and its points to an HDF5 file (reference netiter.py:220-256, called by
+    ``ReactiveNestedSampler.store_tree``, integrator.py:2995-2999): datasets ``unit_points`` / ``points`` (the first
+    ``pointpile.nrows`` rows) and the edge list ``nodes_parent_id`` / ``nodes_child_id`` / ``nodes_child_logl`` in the
+    order the breadth-first walk meets the parents; all gzip-compressed with the shuffle filter.  h5py is imported here,
+    as in the reference, and is not part of this image (an ImportError without it)."""
+    import h5py
+
+    edges = [(node.id, kid.id, kid.value) for node in _expanded(roots) for kid in node.children]
+    columns = {
+        'unit_points': pointpile.us[:pointpile.nrows, :],
+        'points': pointpile.ps[:pointpile.nrows, :],
+        'nodes_parent_id': [e[0] for e in edges],
+        'nodes_child_id': [e[1] for e in edges],
+        'nodes_child_logl': [e[2] for e in edges],
+    }
+    with h5py.File(filename, 'w') as out:
+        for name, data in columns.items():
+            out.create_dataset(name, data=data, compression='gzip', shuffle=True)
+
+
+def _expanded(roots):
+    """every node of the tree, in the driver's breadth-first order"""
+    for walk, rootid, node, _ in _walk(roots):
+        yield node
+        walk.expand_children_of(rootid, node)
+
+
 class PointPile(object):
     """Append-only table of the points behind the tree nodes: row ``node.id`` holds the unit-cube coordinates and the
     transformed parameters (reference netiter.py:386-465; attributes ``us``, ``ps``, ``nrows``, ``udim``, ``pdim``,

@@ -7,6 +7,7 @@ reference integrator.py:2933-2995 ``_update_results``):
     <run_dir>/chains/run.txt                             per-iteration logz, logzerr, logvol, nlive, logl, logwt, insert_order
     <run_dir>/info/results.json                          scalar summary (everything except the sample arrays)
     <run_dir>/info/post_summary.csv                      mean, stdev, median, errlo, errup per parameter
+    <run_dir>/results/tree.hdf5                          the tree and its points (``store_tree``, :2995-2999; needs h5py)
 
 Column order, headers and number formatting (numpy.savetxt defaults, ``json.dump(indent=4)``) are
 the reference's, so its plotting / post-processing tools read these files unchanged."""
@@ -61,3 +62,10 @@ def write_results(logs, results, sequence, paramnames):
     np.savetxt(os.path.join(chains, 'run.txt'),
                np.hstack(tuple(np.reshape(sequence[k], (-1, 1)) for k in RUN_COLUMNS)),
                header=' '.join(RUN_COLUMNS), comments='')
+
+
+def store_tree(logs, root, pointpile):
+    """<run_dir>/results/tree.hdf5: the tree below `root` and its points (reference ``store_tree``,
+    integrator.py:2995-2999 -> ``netiter.dump_tree``; needs h5py, as the reference does)."""
+    from .netiter import dump_tree
+    dump_tree(os.path.join(logs['results'], 'tree.hdf5'), root.children, pointpile)
