@@ -125,6 +125,22 @@ def test_bootstrap_radius_golden(case, golden, K, oracle):
     assert np.array_equal(r, g[name + "_r"])
 
 
+@pytest.mark.parametrize("n,d", [(150, 1), (9, 3), (130, 15), (200, 16), (131, 17), (257, 31), (190, 33), (333, 47), (129, 63),
+                                 (300, 64), (140, 65), (128, 100), (170, 127), (90, 128)])
+def test_bootstrap_radius_every_size_class(n, d, K, oracle):
+    """k_boot holds a live point 16 coordinates per register pair and hands them round by DPP row broadcast; one
+    instance per padded dimension, one wave per SIMD (and scratch) above 64 dimensions: every chunk boundary, live-point
+    counts that are no multiple of the wave or of the per-wave share.  Bit-exact against the oracle."""
+    rs = np.random.RandomState(1000 * d + n)
+    u = rs.uniform(size=(n, d))
+    u[n // 2] = u[0]                                              # a duplicate: distance exactly 0
+    masks = oracle.draw_bootstrap_masks(rs, n, 7)
+    r, skipped = K.maxradiussq_bootstrap(u, masks)
+    ro, so = oracle.maxradiussq_bootstrap(u, masks)
+    assert np.array_equal(skipped, so)
+    assert np.array_equal(r, ro)
+
+
 def test_bootstrap_radius_degenerate_masks(K, oracle):
     u = inputs.live_points(1, 100, 3)
     masks = np.zeros((3, 100), dtype=bool)
@@ -249,6 +265,25 @@ def test_bootstrap_factor_on_device(case, golden, K, oracle):
     flat[:, 0] = 0.25
     bad = K.bootstrap_factor(flat, masks[:2], d + 2)
     assert np.isnan(bad).all()
+
+
+@pytest.mark.parametrize("n,d", [(90, 2), (300, 8), (257, 9), (500, 16), (1000, 23), (255, 24), (700, 33), (513, 40), (400, 41),
+                                 (600, 48), (900, 55), (1025, 57), (300, 64)])
+def test_bootstrap_factor_every_size_class(n, d, K, oracle):
+    """k_boot_solvemax: one lane per row, the factor's column through the DPP operand of v_fmac_f64, one instance per
+    multiple of 8 dimensions; row counts on both sides of the 256-row workgroup.  Against numpy's inverse + quadratic form
+    (the reference's formulation, mlfriends.pyx:1056-1066), tolerance class 1e-10."""
+    rs = np.random.RandomState(77 * d + n)
+    u = rs.uniform(size=(n, d)) * rs.uniform(0.2, 1.0, size=d)
+    masks = oracle.draw_bootstrap_masks(rs, n, 5)
+    f = K.bootstrap_factor(u, masks, d + 2)
+    for b in range(len(masks)):
+        sel = u[masks[b]]
+        ctr = sel.mean(axis=0)
+        cov = np.atleast_2d(np.cov(sel, rowvar=0)) * (d + 2)
+        delta = u[~masks[b]] - ctr
+        want = np.einsum("ij,jk,ik->i", delta, np.linalg.inv(cov), delta).max()
+        np.testing.assert_allclose(f[b], want, rtol=1e-9)
 
 
 # ------------------------------------------------------------------ likelihoods ---------------

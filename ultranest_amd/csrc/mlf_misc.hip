@@ -4,6 +4,8 @@
 
 #include <math.h>
 
+#include <type_traits>
+
 namespace mlf {
 
 // ---------------------------------------------------------------- layouts ----------------
@@ -135,7 +137,7 @@ void launch_boot_final(const unsigned long long *M, const unsigned *sel, int n, 
 // LocalAffineLayer radius quirk every point is a neighbour of every point, and one wave per workgroup re-read
 // the whole array from L2 for each point (6.4 GB at N = 4000: 0.48 ms).
 constexpr int kAccumWaves = 8;
-constexpr int kAccumPer = 2;   // points per wave: one LDS read feeds both sums
+constexpr int kAccumPer = 2;   // points per wave: one LDS read feeds both sums (4 points on 4 waves: 147 -> 162 us, the kernel is not issue bound)
 template <int H>               // 64-column halves (d <= 64 H); lanes past d work on column 0, their sums are not stored
 __global__ __launch_bounds__(64 * kAccumWaves) void k_subtract_accum(const double *__restrict__ pts, int n, int d,
                                                                     const unsigned long long *__restrict__ flags,
@@ -488,12 +490,11 @@ __global__ __launch_bounds__(64 * kCovWaves) void k_boot_cov(const double *__res
 //   k_boot_chol      one WAVE per round: scale cov_b = L L^T, lane = matrix row held in registers, the pivot column
 //                    travels by v_readlane; no barriers, no LDS (the first version factorised in LDS with three
 //                    workgroup barriers per column, and once in each of 8 row slices: 0.75 ms for 30 rounds)
-//   k_boot_solvemax  one wave per (round, slice of the rows): solves L y = u_i - m_b row by row, f = |y|^2, per-round
-//                    maximum by atomicMax on the bit pattern
+//   k_boot_solvemax  one LANE per row: solves L y = u_i - m_b, f = |y|^2, per-round maximum over the left-out rows by
+//                    atomicMax on the bit pattern (see the kernel)
 // The host version inverted the B matrices with LAPACK (1.1 ms at B = 30, d = 50) between two device calls.  Result
 // class: like the reference's inv + einsum to rounding (tolerance class of `f`); a round whose matrix is not positive
 // definite or not finite returns NaN.  Same sequence of roundings as the LDS version (right-looking, column by column).
-constexpr int kCholSlices = 64;
 
 // value of `v` on lane `lane` (wave-uniform index) through the scalar unit: two v_readlane_b32 instead of the two
 // ds_bpermute round trips of __shfl (the substitution below is one dependent chain of 64 such broadcasts per row)
@@ -541,47 +542,81 @@ __global__ __launch_bounds__(64) void k_boot_chol(const double *__restrict__ cov
   if (r == 0) bad_out[b] = bad ? 1 : 0;
 }
 
-// One wave per (round, slice of the rows); lane r holds row r of the factor in registers.  A row of u is solved
-// right-looking: y_k = acc_k / L_kk on lane k, broadcast, acc_r -= L_rk y_k on the lanes below -- 64 short steps without a
-// single memory access.  (One THREAD per row with y[] in registers looked cheaper on paper; the compiler hoisted the
-// 2016 loads of the unrolled substitution and spilled 4108 registers: that was most of the old kernel's 0.75 ms.)
-template <int DPC>
-__global__ __launch_bounds__(64) void k_boot_solvemax(const double *__restrict__ u, int n, int d,
-                                                      const uint8_t *__restrict__ selected,
-                                                      const double *__restrict__ mean, const double *__restrict__ Lin,
-                                                      const int *__restrict__ bad_in,
-                                                      unsigned long long *__restrict__ out_bits) {
-  __shared__ double Ls[DPC][DPC + 1];
-  const int r = threadIdx.x, b = blockIdx.x;
-  const double *src = Lin + (size_t)b * DPC * (DPC + 1);
-  for (int e = r; e < DPC * (DPC + 1); e += 64) {   // coalesced; column DPC (1 / L_rr) rides along
+// Forward substitution for 64 rows of u at a time, one row per LANE: acc[0..d) = u_i - m_b in registers, and column by
+// column (right-looking, the order of the factorisation above)  y_k = acc[k] / L_kk,  ss += y_k^2,  acc[r] -= L_rk y_k
+// for r > k.  L_rk is the same for every lane: the column sits in registers 16 rows at a time (lane l holds row
+// 16 c + (l mod 16), read from the LDS copy of the factor) and enters the update through the DPP operand of
+// `v_fmac_f64` (row_newbcast: lane r mod 16 of every row of 16 lanes -- the operand broadcast the instruction set has
+// for binary64 matrix products): one vector instruction per multiply-add, no scalar or cross-lane traffic in the chain,
+// every lane busy.  Per row the roundings are those of the earlier kernel (one WAVE per row, lane = r, y_k handed round
+// by v_readlane: a dependent chain of 64 broadcasts per row, 0.138 ms for 30 rounds at N = 4000, d = 50): the results are
+// bit-identical to it.  All rows go through the substitution; selected ones are left out of the maximum.
+template <int K>
+__device__ __forceinline__ void fmac_row_bcast(double &acc, double column16, double y) {   // acc += column16[lane K of the row] * y
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(column16), "v"(y), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ double row_bcast_f64(double x) {
+  return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + K, 0xf, 0xf, true);
+}
+template <int K, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (K < N) {
+    f(std::integral_constant<int, K>{});
+    static_for<K + 1, N>(f);
+  }
+}
+
+constexpr int kSolveWaves = 4;
+
+template <int DPC>   // d <= DPC, DPC a multiple of 8
+__global__ __launch_bounds__(64 * kSolveWaves) void k_boot_solvemax(const double *__restrict__ u, int n, int d,
+                                                                    const uint8_t *__restrict__ selected,
+                                                                    const double *__restrict__ mean, const double *__restrict__ Lin,
+                                                                    int lrows, const int *__restrict__ bad_in,
+                                                                    unsigned long long *__restrict__ out_bits) {
+  constexpr int NCH = (DPC + 15) / 16;
+  __shared__ double Ls[DPC][DPC + 1];   // column DPC: 1 / L_rr
+  __shared__ double ms[DPC];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, sub = lane & 15;
+  const double *src = Lin + (size_t)b * lrows * (lrows + 1);
+  for (int e = threadIdx.x; e < DPC * (DPC + 1); e += 64 * kSolveWaves) {
     const int rr = e / (DPC + 1), c = e - rr * (DPC + 1);
-    Ls[rr][c] = src[e];
+    Ls[rr][c] = src[(size_t)rr * (lrows + 1) + (c < DPC ? c : lrows)];
   }
-  __builtin_amdgcn_wave_barrier();
-  double Lr[DPC];
-  const int rc = r < DPC ? r : 0;
+  if (threadIdx.x < DPC) ms[threadIdx.x] = threadIdx.x < d ? mean[(size_t)b * d + threadIdx.x] : 0.0;
+  __syncthreads();
+  const int i = blockIdx.x * (64 * kSolveWaves) + threadIdx.x;
+  const int ic = i < n ? i : n - 1;
+  double acc[DPC];
 #pragma unroll
-  for (int c = 0; c < DPC; ++c) Lr[c] = Ls[rc][c];
-  const double invd = r < DPC ? Ls[rc][DPC] : 1.0;
-  const double mr = r < d ? mean[(size_t)b * d + r] : 0.0;
-  double fbest = 0.0;
-  bool nan_seen = false;
-  const uint8_t *sel = selected + (size_t)b * n;
-  for (int i = blockIdx.y; i < n; i += kCholSlices) {   // wave-uniform
-    if (sel[i]) continue;
-    double acc = r < d ? u[(size_t)i * d + r] - mr : 0.0;
-    double ss = 0.0;
+  for (int r = 0; r < DPC; ++r) acc[r] = r < d ? u[(size_t)ic * d + r] - ms[r] : 0.0;
+  double inv16[NCH];   // 1 / L_rr, 16 rows per register
 #pragma unroll
-    for (int k = 0; k < DPC; ++k) {
-      const double yk = lane_value(acc * invd, k);
+  for (int c = 0; c < NCH; ++c) inv16[c] = Ls[16 * c + sub < DPC ? 16 * c + sub : 0][DPC];
+  double ss = 0.0;
+  static_for<0, DPC>([&](auto kc) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value;
+    if (k < d) {   // wave-uniform
+      const double yk = acc[k] * row_bcast_f64<(k & 15)>(inv16[k >> 4]);
       ss = __builtin_fma(yk, yk, ss);
-      if (r > k) acc = __builtin_fma(-Lr[k], yk, acc);
+      const double ny = -yk;
+      static_for<(k + 1) / 16, NCH>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+        const double col = Ls[16 * c + sub < DPC ? 16 * c + sub : 0][k];   // L[16 c + sub][k]
+        static_for<(16 * c > k + 1 ? 16 * c : k + 1), (16 * c + 16 < DPC ? 16 * c + 16 : DPC)>([&](auto rc) __attribute__((always_inline)) {
+          constexpr int r = decltype(rc)::value;
+          fmac_row_bcast<(r & 15)>(acc[r], col, ny);
+        });
+      });
     }
-    if (ss != ss) nan_seen = true;
-    fbest = fmax(fbest, ss);
-  }
-  if (r == 0) {
+  });
+  const bool counts = i < n && selected[(size_t)b * n + ic] == 0;
+  const bool nan_seen = __ballot(counts && ss != ss) != 0ull;
+  double fbest = counts ? fmax(0.0, ss) : 0.0;
+#pragma unroll
+  for (int w = 32; w > 0; w >>= 1) fbest = fmax(fbest, __shfl_xor(fbest, w));
+  if (lane == 0) {
     // non-negative doubles order like their bit patterns; NaN / failed factorisation -> all ones
     atomicMax(&out_bits[b], (bad_in[b] || nan_seen) ? ~0ull : (unsigned long long)__double_as_longlong(fbest));
   }
@@ -598,13 +633,21 @@ hipError_t launch_boot_cholmax(const double *u, int n, int d, const uint8_t *sel
                                const double *cov, double scale, unsigned long long *out_bits, void *scratch,
                                hipStream_t s) {
   if (n <= 0 || B <= 0) return hipSuccess;
-  const dim3 grid((unsigned)B, kCholSlices);
+  const dim3 grid((unsigned)((n + 64 * kSolveWaves - 1) / (64 * kSolveWaves)), (unsigned)B);
+  const int dps = (d + 7) / 8 * 8;   // the substitution's own size class: multiples of 8
+#define MLF_SOLVE(DPS, LROWS)                                                                                         \
+  case DPS:                                                                                                         \
+    hipLaunchKernelGGL(k_boot_solvemax<DPS>, grid, dim3(64 * kSolveWaves), 0, s, u, n, d, selected, mean, Ls, LROWS, bad, out_bits); \
+    break;
 #define MLF_CHOL(DPC)                                                                                               \
   {                                                                                                                 \
     double *Ls = static_cast<double *>(scratch);                                                                    \
     int *bad = reinterpret_cast<int *>(Ls + (size_t)B * DPC * (DPC + 1));                                           \
     hipLaunchKernelGGL(k_boot_chol<DPC>, dim3((unsigned)B), dim3(64), 0, s, cov, d, scale, Ls, bad);                \
-    hipLaunchKernelGGL(k_boot_solvemax<DPC>, grid, dim3(64), 0, s, u, n, d, selected, mean, Ls, bad, out_bits);     \
+    switch (dps) {                                                                                                  \
+      MLF_SOLVE(8, DPC) MLF_SOLVE(16, DPC) MLF_SOLVE(24, DPC) MLF_SOLVE(32, DPC)                                    \
+      MLF_SOLVE(40, DPC) MLF_SOLVE(48, DPC) MLF_SOLVE(56, DPC) MLF_SOLVE(64, DPC)                                   \
+    }                                                                                                               \
   }
   if (d <= 8)
     MLF_CHOL(8)
@@ -616,6 +659,7 @@ hipError_t launch_boot_cholmax(const double *u, int n, int d, const uint8_t *sel
     MLF_CHOL(64)
   else
     return hipErrorInvalidValue;
+#undef MLF_SOLVE
 #undef MLF_CHOL
   return hipGetLastError();
 }
