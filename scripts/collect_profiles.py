@@ -55,6 +55,9 @@ cp("rebuild_modes.json", "%s_rebuild_modes.json" % tag)
 cp("midsize.json", "%s_midsize_batches.json" % tag)
 cp("host_api.json", "%s_host_api.json" % tag)
 cp("loglike_bench.json", "%s_loglike_bench.json" % tag)
+cp("active_u_breakdown.json", "%s_active_u_breakdown.json" % tag)
+cp("fp64_issue_probe.json", "%s_fp64_issue_probe.json" % tag)
+cp("minphase_probe.json", "%s_minphase_probe.json" % tag)
 
 # kernel-trace: average duration of the headline launches only (the stats CSV mixes them with the
 # small scans of the region rebuild)

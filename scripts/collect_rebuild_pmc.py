@@ -41,6 +41,7 @@ out = {}
 sq = table("pmc_rebuild_SQ")
 fe = table("pmc_rebuild_FETCH_SIZE")
 wr = table("pmc_rebuild_WRITE_SIZE")
+act = table("pmc_rebuild_ACT")
 dur = collections.defaultdict(list)
 tr = glob.glob(os.path.join(G, "prof_rebuild", "*kernel_trace.csv"))
 if tr:
@@ -59,9 +60,19 @@ for k in KEYS:
         c = {n: sum(v) / len(v) for n, v in sq[k].items()}
         e["per_launch"] = {n: c[n] for n in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM") if n in c}
         if c.get("SQ_WAVE_CYCLES"):
-            e["wave_time_waiting"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+            e["wave_time_waiting_to_issue"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
         if c.get("GRBM_GUI_ACTIVE") and e.get("avg_us"):
             e["clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / (e["avg_us"] * 1e3)
+    if k in act:   # second SQ pass: SQ_WAIT_ANY counts every wait (s_waitcnt included), SQ_WAIT_INST_ANY the wait for an issue slot
+        c = {n: sum(v) / len(v) for n, v in act[k].items()}
+        if c.get("SQ_WAVE_CYCLES"):
+            e["activity_pass"] = {
+                "wave_time_waiting_for_anything": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
+                "wave_time_waiting_to_issue": c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
+                "wave_time_issuing_vector_instructions": c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"],
+                "vector_instructions_per_launch": c.get("SQ_INSTS_VALU"),
+                "vector_memory_instructions_per_launch": c.get("SQ_INSTS_VMEM"),
+                "waves": c.get("SQ_WAVES")}
     if k in fe:
         f_kb = sum(fe[k]["FETCH_SIZE"]) / len(fe[k]["FETCH_SIZE"])
         w_kb = sum(wr[k]["WRITE_SIZE"]) / len(wr[k]["WRITE_SIZE"]) if k in wr and wr[k].get("WRITE_SIZE") else 0.0

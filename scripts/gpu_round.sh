@@ -13,6 +13,8 @@ echo "== rebuild modes"; timeout 300 python scripts/rebuild_modes.py > $O/rebuil
 echo "== mid-size batches"; timeout 300 python scripts/midsize_profile.py > $O/midsize.json 2> $O/midsize.err; cat $O/midsize.json
 echo "== host API"; timeout 300 python scripts/host_api_bench.py > $O/host_api.json 2> $O/host_api.err; tail -c 600 $O/host_api.json
 echo "== likelihood kernels"; timeout 300 python scripts/loglike_bench.py > $O/loglike_bench.json 2> $O/loglike_bench.err; grep -c ms $O/loglike_bench.json
+echo "== where inside(active_u) goes"; timeout 200 python scripts/active_u_breakdown.py --save > $O/active_u_breakdown.log 2>&1; tail -9 $O/active_u_breakdown.log | tr -d '\n'; echo
+echo "== FP64 / DPP issue probes"; timeout 100 scripts/probes/bin/fp64_issue_probe > $O/fp64_issue_probe.json 2>&1; timeout 60 scripts/probes/bin/minphase_probe > $O/minphase_probe.json 2>&1; wc -l $O/fp64_issue_probe.json $O/minphase_probe.json
 echo "== small batches through the reference API"; timeout 300 python scripts/small_batch_latency.py --save > $O/small_batch.log 2>&1; tail -2 $O/small_batch.log | cut -c1-200
 if [ "$2" != "quick" ]; then
 echo "== step sampler bench (row f1)"; timeout 600 python scripts/walk_bench.py device > $O/walk_bench.log 2>&1; tail -3 $O/walk_bench.log
@@ -43,6 +45,7 @@ tail -1 $O/pmc_SQ2.log
 echo "== rocprofv3 pmc over the REBUILD kernels (k_boot, k_scan flags, k_subtract_accum, k_boot_*): instruction mix and traffic"
 timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_rebuild_SQ -o rb -- python $R/scripts/rebuild_modes.py > $O/pmc_rebuild_SQ.log 2>&1
 python $R/scripts/pmc_table.py $(find $O/pmc_rebuild_SQ -name "*counter_collection.csv" | head -1) 1000 > $O/pmc_rebuild_SQ.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM SQ_BUSY_CYCLES --output-format csv -d $O/pmc_rebuild_ACT -o rb -- python $R/scripts/rebuild_modes.py > $O/pmc_rebuild_ACT.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_rebuild_$C -o rb -- python $R/scripts/rebuild_modes.py > $O/pmc_rebuild_$C.log 2>&1
   python $R/scripts/pmc_table.py $(find $O/pmc_rebuild_$C -name "*counter_collection.csv" | head -1) 1000 > $O/pmc_rebuild_$C.txt 2>&1

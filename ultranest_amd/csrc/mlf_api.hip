@@ -759,9 +759,23 @@ int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2,
   // live points uses the ellipsoid's extent, 1 / (smallest diagonal entry of L) being a bound on its semi-axes' scale
   const double *ctr = r->use_scan ? layer_ctr : ell_center;
   double amax = 0.0;
-  if (live)
-    for (size_t i = 0; i < nlive; ++i)
-      for (int k = 0; k < d; ++k) amax = std::fmax(amax, std::fabs(live[i * d + k] - ctr[k]));
+  if (live) {   // four running maxima (a NaN never wins a comparison, as with fmax): one chain of dependent maxima cost 0.1 ms at N = 4000, d = 50
+    double m[4] = {0.0, 0.0, 0.0, 0.0};
+    for (size_t i = 0; i < nlive; ++i) {
+      const double *row = live + i * d;
+      int k = 0;
+      for (; k + 4 <= d; k += 4)
+        for (int q = 0; q < 4; ++q) {
+          const double v = std::fabs(row[k + q] - ctr[k + q]);
+          m[q] = v > m[q] ? v : m[q];
+        }
+      for (; k < d; ++k) {
+        const double v = std::fabs(row[k] - ctr[k]);
+        m[0] = v > m[0] ? v : m[0];
+      }
+    }
+    amax = std::fmax(std::fmax(m[0], m[1]), std::fmax(m[2], m[3]));
+  }
   if (!(amax > 0.0) || !std::isfinite(amax)) amax = 4.0 / dmin;
   if (!(amax > 1e-60) || !(amax < 1e60)) return 0;
   const double sx = pow2_scale(amax, 5);

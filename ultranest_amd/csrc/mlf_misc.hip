@@ -485,6 +485,130 @@ __global__ __launch_bounds__(64 * kCovWaves) void k_boot_cov(const double *__res
   }
 }
 
+template <int K>
+__device__ __forceinline__ void fmac_row_bcast(double &acc, double column16, double y) {   // acc += column16[lane K of the row] * y
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(column16), "v"(y), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ double row_bcast_f64(double x) {
+  return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + K, 0xf, 0xf, true);
+}
+template <int K>
+__device__ __forceinline__ unsigned row_bcast_u32(unsigned x) {
+  return __builtin_amdgcn_update_dpp(0u, x, 0x150 + K, 0xf, 0xf, true);
+}
+template <int K, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (K < N) {
+    f(std::integral_constant<int, K>{});
+    static_for<K + 1, N>(f);
+  }
+}
+
+// d <= 64: the same sums with the operand broadcast the instruction set has for binary64 products.  A wave takes FOUR
+// selected rows per step, one per group of 16 lanes; lane l of a group holds the centred coordinates 16 c + (l mod 16),
+// c = 0 ... NCH - 1, and acc[kk][c] += x[16 CK + kk] * x[16 c + l mod 16] is ONE v_fmac_f64 whose first operand comes from
+// lane kk of the lane's own group through DPP (row_newbcast): no v_readlane pair per (row, k), every lane busy, and a
+// workgroup (8 waves) owns a whole 16-row block CK of the matrix for one round, the upper chunks c >= CK only (the lower
+// ones are the mirror image).  Per (k, l) the products of a wave's group are added in ascending list order; the four
+// groups, then the eight waves, in a fixed order: deterministic, tolerance class of the moments (1e-9 relative).
+// 30 rounds at N = 4000, d = 50: 0.076 -> see profiles (the v_readlane version read every selected row in 7 workgroups).
+template <int NCH, int CK>
+__device__ __forceinline__ void cov_block(const double *__restrict__ u, int d, const int *__restrict__ list, int cnt,
+                                          const double *__restrict__ mean_b, double *__restrict__ cov_b, double (*part)[16][4][16]) {
+  constexpr int NC = NCH - CK;   // chunks c = CK ... NCH - 1
+  const int g = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+  int col[NCH];
+  double ml[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    col[c] = 16 * c + sub < d ? 16 * c + sub : 0;
+    ml[c] = mean_b[col[c]];
+  }
+  double acc[16][NC];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[kk][c] = 0.0;
+  // list entries of this wave: 4 (g + kCovWaves t) + grp, t = 0, 1, ...  Sixteen steps at a time: lane `sub` of a group
+  // loads the group's entry of step t0 + sub, each step picks its row index up by DPP broadcast inside the group, and the
+  // rows of the next kAhead steps are on their way while a step's products are formed (the row loads depend on the
+  // list loads: one step ahead left the wave waiting ~0.5 us per step)
+  constexpr int kAhead = 7;
+  const int steps = (cnt + 4 * kCovWaves - 1) / (4 * kCovWaves);   // wave-uniform
+  for (int t0 = 0; t0 < steps; t0 += 16) {
+    const int e = 4 * (g + kCovWaves * (t0 + sub)) + grp;
+    const int mine = e < cnt ? list[e] : -1;
+    double x[8][NCH];
+    int row[8];
+    auto fetch = [&](auto tc) __attribute__((always_inline)) {
+      constexpr int tt = decltype(tc)::value;
+      // no branch on "is there such a step": steps past the list load row 0 and add zeros (a branch per step makes every
+      // wait a wait for ALL outstanding loads: the counter is not tracked across the blocks)
+      row[tt & 7] = (int)row_bcast_u32<tt>((unsigned)mine);
+      const long long r = row[tt & 7] < 0 ? 0 : row[tt & 7];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) x[tt & 7][c] = u[r * d + col[c]];
+    };
+    static_for<0, kAhead>(fetch);
+    static_for<0, 16>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int tt = decltype(tc)::value;
+      if constexpr (tt + kAhead < 16) fetch(std::integral_constant<int, tt + kAhead>{});
+      {
+        double(&xs)[NCH] = x[tt & 7];
+        const bool ok = row[tt & 7] >= 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) xs[c] = ok ? xs[c] - ml[c] : 0.0;
+        // v_fmac_f64_dpp reads xs[CK] through DPP: a register just written by a vector instruction needs two wait states
+        asm volatile("s_nop 1" : "+v"(xs[CK]));
+        static_for<0, 16>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int kk = decltype(kc)::value;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) fmac_row_bcast<kk>(acc[kk][c], xs[CK], xs[CK + c]);
+        });
+      }
+    });
+  }
+  // the four groups of the wave, then the waves of the workgroup
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      double v = acc[kk][c];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (grp == 0) part[g][kk][c][sub] = v;
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 16 * NC * 16; e += 64 * kCovWaves) {
+    const int kk = e / (NC * 16), c = (e / 16) % NC, l = e % 16;
+    const int k = 16 * CK + kk, col_l = 16 * (CK + c) + l;
+    if (k < d && col_l < d) {
+      double tot = 0.0;
+      for (int w = 0; w < kCovWaves; ++w) tot += part[w][kk][c][l];
+      tot /= (double)(cnt - 1);
+      cov_b[(long long)k * d + col_l] = tot;
+      if (c > 0) cov_b[(long long)col_l * d + k] = tot;   // the mirror image of an off-diagonal chunk
+    }
+  }
+}
+
+template <int NCH>   // d <= 16 NCH <= 64
+__global__ __launch_bounds__(64 * kCovWaves) void k_boot_cov16(const double *__restrict__ u, int d, const int *__restrict__ idx,
+                                                               int n, const double *__restrict__ mean,
+                                                               const int *__restrict__ count, double *__restrict__ cov) {
+  __shared__ double part[kCovWaves][16][4][16];   // 64 KB
+  const int b = blockIdx.y, ck = blockIdx.x;
+  const int *list = idx + (long long)b * n;
+  const double *mean_b = mean + (long long)b * d;
+  double *cov_b = cov + (long long)b * d * d;
+  const int cnt = count[b];
+  if (ck == 0) cov_block<NCH, 0>(u, d, list, cnt, mean_b, cov_b, part);
+  if constexpr (NCH > 1) if (ck == 1) cov_block<NCH, 1>(u, d, list, cnt, mean_b, cov_b, part);
+  if constexpr (NCH > 2) if (ck == 2) cov_block<NCH, 2>(u, d, list, cnt, mean_b, cov_b, part);
+  if constexpr (NCH > 3) if (ck == 3) cov_block<NCH, 3>(u, d, list, cnt, mean_b, cov_b, part);
+}
+
 // Bootstrap enlargement without leaving the device (reference mlfriends.pyx:1056-1066 with minvol = 0):
 // f_b = max over the left-out rows of (u_i - m_b)^T (scale cov_b)^-1 (u_i - m_b).  Two launches:
 //   k_boot_chol      one WAVE per round: scale cov_b = L L^T, lane = matrix row held in registers, the pivot column
@@ -551,22 +675,6 @@ __global__ __launch_bounds__(64) void k_boot_chol(const double *__restrict__ cov
 // every lane busy.  Per row the roundings are those of the earlier kernel (one WAVE per row, lane = r, y_k handed round
 // by v_readlane: a dependent chain of 64 broadcasts per row, 0.138 ms for 30 rounds at N = 4000, d = 50): the results are
 // bit-identical to it.  All rows go through the substitution; selected ones are left out of the maximum.
-template <int K>
-__device__ __forceinline__ void fmac_row_bcast(double &acc, double column16, double y) {   // acc += column16[lane K of the row] * y
-  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(column16), "v"(y), "n"(K));
-}
-template <int K>
-__device__ __forceinline__ double row_bcast_f64(double x) {
-  return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + K, 0xf, 0xf, true);
-}
-template <int K, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-  if constexpr (K < N) {
-    f(std::integral_constant<int, K>{});
-    static_for<K + 1, N>(f);
-  }
-}
-
 constexpr int kSolveWaves = 4;
 
 template <int DPC>   // d <= DPC, DPC a multiple of 8
@@ -623,7 +731,7 @@ __global__ __launch_bounds__(64 * kSolveWaves) void k_boot_solvemax(const double
 }
 
 size_t boot_cholmax_scratch_bytes(int d, int B) {
-  const int dpc = d <= 8 ? 8 : (d <= 16 ? 16 : (d <= 32 ? 32 : 64));
+  const int dpc = (d + 7) / 8 * 8;
   return (size_t)B * dpc * (dpc + 1) * sizeof(double) + (size_t)B * sizeof(int);
 }
 
@@ -633,34 +741,20 @@ hipError_t launch_boot_cholmax(const double *u, int n, int d, const uint8_t *sel
                                const double *cov, double scale, unsigned long long *out_bits, void *scratch,
                                hipStream_t s) {
   if (n <= 0 || B <= 0) return hipSuccess;
+  if (d > 64) return hipErrorInvalidValue;
   const dim3 grid((unsigned)((n + 64 * kSolveWaves - 1) / (64 * kSolveWaves)), (unsigned)B);
-  const int dps = (d + 7) / 8 * 8;   // the substitution's own size class: multiples of 8
-#define MLF_SOLVE(DPS, LROWS)                                                                                         \
-  case DPS:                                                                                                         \
-    hipLaunchKernelGGL(k_boot_solvemax<DPS>, grid, dim3(64 * kSolveWaves), 0, s, u, n, d, selected, mean, Ls, LROWS, bad, out_bits); \
+  const int dpc = (d + 7) / 8 * 8;   // size class of both kernels: multiples of 8 (padding rows / columns are identity)
+  double *Ls = static_cast<double *>(scratch);
+  int *bad = reinterpret_cast<int *>(Ls + (size_t)B * dpc * (dpc + 1));
+  switch (dpc) {
+#define MLF_CHOLMAX(DPC)                                                                                                          \
+  case DPC:                                                                                                                       \
+    hipLaunchKernelGGL(k_boot_chol<DPC>, dim3((unsigned)B), dim3(64), 0, s, cov, d, scale, Ls, bad);                              \
+    hipLaunchKernelGGL(k_boot_solvemax<DPC>, grid, dim3(64 * kSolveWaves), 0, s, u, n, d, selected, mean, Ls, DPC, bad, out_bits); \
     break;
-#define MLF_CHOL(DPC)                                                                                               \
-  {                                                                                                                 \
-    double *Ls = static_cast<double *>(scratch);                                                                    \
-    int *bad = reinterpret_cast<int *>(Ls + (size_t)B * DPC * (DPC + 1));                                           \
-    hipLaunchKernelGGL(k_boot_chol<DPC>, dim3((unsigned)B), dim3(64), 0, s, cov, d, scale, Ls, bad);                \
-    switch (dps) {                                                                                                  \
-      MLF_SOLVE(8, DPC) MLF_SOLVE(16, DPC) MLF_SOLVE(24, DPC) MLF_SOLVE(32, DPC)                                    \
-      MLF_SOLVE(40, DPC) MLF_SOLVE(48, DPC) MLF_SOLVE(56, DPC) MLF_SOLVE(64, DPC)                                   \
-    }                                                                                                               \
+    MLF_CHOLMAX(8) MLF_CHOLMAX(16) MLF_CHOLMAX(24) MLF_CHOLMAX(32) MLF_CHOLMAX(40) MLF_CHOLMAX(48) MLF_CHOLMAX(56) MLF_CHOLMAX(64)
+#undef MLF_CHOLMAX
   }
-  if (d <= 8)
-    MLF_CHOL(8)
-  else if (d <= 16)
-    MLF_CHOL(16)
-  else if (d <= 32)
-    MLF_CHOL(32)
-  else if (d <= 64)
-    MLF_CHOL(64)
-  else
-    return hipErrorInvalidValue;
-#undef MLF_SOLVE
-#undef MLF_CHOL
   return hipGetLastError();
 }
 
@@ -673,8 +767,15 @@ void launch_boot_moments(const double *u, int n, int d, const uint8_t *selected,
   else
     hipLaunchKernelGGL(k_boot_mean<2>, dim3(B), dim3(1024), 0, s, u, d, idx, n, count, mean);
   const dim3 cgrid((unsigned)((d + kCovRows - 1) / kCovRows), (unsigned)B);
-  if (d <= 64)
-    hipLaunchKernelGGL(k_boot_cov<1>, cgrid, dim3(64 * kCovWaves), 0, s, u, d, idx, n, mean, count, cov);
+  const dim3 bgrid((unsigned)((d + 15) / 16), (unsigned)B);   // one workgroup per 16-row block of the matrix and round
+  if (d <= 16)
+    hipLaunchKernelGGL(k_boot_cov16<1>, bgrid, dim3(64 * kCovWaves), 0, s, u, d, idx, n, mean, count, cov);
+  else if (d <= 32)
+    hipLaunchKernelGGL(k_boot_cov16<2>, bgrid, dim3(64 * kCovWaves), 0, s, u, d, idx, n, mean, count, cov);
+  else if (d <= 48)
+    hipLaunchKernelGGL(k_boot_cov16<3>, bgrid, dim3(64 * kCovWaves), 0, s, u, d, idx, n, mean, count, cov);
+  else if (d <= 64)
+    hipLaunchKernelGGL(k_boot_cov16<4>, bgrid, dim3(64 * kCovWaves), 0, s, u, d, idx, n, mean, count, cov);
   else
     hipLaunchKernelGGL(k_boot_cov<2>, cgrid, dim3(64 * kCovWaves), 0, s, u, d, idx, n, mean, count, cov);
 }
