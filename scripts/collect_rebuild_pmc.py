@@ -61,7 +61,7 @@ for k in KEYS:
         e["per_launch"] = {n: c[n] for n in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM") if n in c}
         if c.get("SQ_WAVE_CYCLES"):
             e["wave_time_waiting_to_issue"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
-        if c.get("GRBM_GUI_ACTIVE") and e.get("avg_us"):
+        if c.get("GRBM_GUI_ACTIVE") and e.get("avg_us", 0.0) >= 50.0:   # shorter launches: the counter's idle lead-in dominates
             e["clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / (e["avg_us"] * 1e3)
     if k in act:   # second SQ pass: SQ_WAIT_ANY counts every wait (s_waitcnt included), SQ_WAIT_INST_ANY the wait for an issue slot
         c = {n: sum(v) / len(v) for n, v in act[k].items()}
