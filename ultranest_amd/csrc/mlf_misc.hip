@@ -136,8 +136,8 @@ void launch_boot_final(const unsigned long long *M, const unsigned *sel, int n, 
 // A workgroup holds 16 points (8 waves x 2) and stages every 64-row tile of pts in LDS once for all of them: with the
 // LocalAffineLayer radius quirk every point is a neighbour of every point, and one wave per workgroup re-read
 // the whole array from L2 for each point (6.4 GB at N = 4000: 0.48 ms).
-constexpr int kAccumWaves = 8;
-constexpr int kAccumPer = 2;   // points per wave: one LDS read feeds both sums (4 points on 4 waves: 147 -> 162 us, the kernel is not issue bound)
+constexpr int kAccumWaves = 4;
+constexpr int kAccumPer = 4;   // points per wave: one LDS read (4 cycles of the CU's LDS port per wave) feeds four sums (16 cycles of its SIMD)
 template <int H>               // 64-column halves (d <= 64 H); lanes past d work on column 0, their sums are not stored
 __global__ __launch_bounds__(64 * kAccumWaves) void k_subtract_accum(const double *__restrict__ pts, int n, int d,
                                                                     const unsigned long long *__restrict__ flags,
@@ -156,10 +156,10 @@ __global__ __launch_bounds__(64 * kAccumWaves) void k_subtract_accum(const doubl
     for (int h = 0; h < H; ++h) sum[p][h] = 0.0;
     nn[p] = 0;
   }
-  // the next tile travels in registers while this one is consumed
+  // the next tile travels in registers while this one is consumed (two tiles ahead: no change)
   constexpr int kPer = (kWave * 64 * H + 64 * kAccumWaves - 1) / (64 * kAccumWaves);
   double nxt[kPer];
-  auto fetch = [&](int t) {
+  auto fetch = [&](int t) __attribute__((always_inline)) {
     const int rows = (n - t * kWave) < kWave ? (n - t * kWave) : kWave;
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
@@ -168,8 +168,26 @@ __global__ __launch_bounds__(64 * kAccumWaves) void k_subtract_accum(const doubl
     }
   };
   fetch(0);
-  for (int t = 0; t < ntiles; ++t) {
+  unsigned long long fl[kAccumPer];
+  auto one_tile = [&](int t) __attribute__((always_inline)) {
     const int rows = (n - t * kWave) < kWave ? (n - t * kWave) : kWave;
+    if ((t & 63) == 0) {
+#pragma unroll
+      for (int p = 0; p < kAccumPer; ++p)
+        fl[p] = (j0 + p < n && t + lane < ntiles) ? flags[(long long)(j0 + p) * ntiles + t + lane] : 0ull;
+    }
+    // the hit words of 64 tiles at a time, lane = tile, picked up HERE: behind the requests for the next tile any wait for
+    // them is a wait for that tile as well (the counter is in order), and the prefetch hid nothing
+    unsigned long long m[kAccumPer];
+    unsigned long long any = 0ull, all = ~0ull;
+#pragma unroll
+    for (int p = 0; p < kAccumPer; ++p) {
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)fl[p], t & 63);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(fl[p] >> 32), t & 63);
+      m[p] = ((unsigned long long)hi << 32) | lo;
+      any |= m[p];
+      all &= m[p];
+    }
     __syncthreads();   // the previous tile is consumed
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
@@ -178,27 +196,39 @@ __global__ __launch_bounds__(64 * kAccumWaves) void k_subtract_accum(const doubl
     }
     if (t + 1 < ntiles) fetch(t + 1);
     __syncthreads();
-    unsigned long long m[kAccumPer];
-    unsigned long long any = 0ull, all = ~0ull;
-#pragma unroll
-    for (int p = 0; p < kAccumPer; ++p) {
-      m[p] = (j0 + p < n) ? flags[(long long)(j0 + p) * ntiles + t] : 0ull;
-      any |= m[p];
-      all &= m[p];
-    }
     if (all == ~0ull) {   // whole tile for every point of this wave: no bit scanning
-#pragma unroll 16
-      for (int q = 0; q < kWave; ++q) {
+      // 16 rows per batch, the next batch's LDS reads issued before this batch's adds (left to the scheduler, five reads
+      // were in flight per wave and every row waited for its own)
+      constexpr int kB = 16;
+      double va[kB][H], vb[kB][H];
+      auto rd = [&](double (&v)[kB][H], int q0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-          const double v = tile[q * d + col[h]];
+        for (int q = 0; q < kB; ++q)
 #pragma unroll
-          for (int p = 0; p < kAccumPer; ++p) sum[p][h] += v;
-        }
-      }
+          for (int h = 0; h < H; ++h) v[q][h] = tile[(q0 + q) * d + col[h]];
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto add = [&](const double (&v)[kB][H]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < kB; ++q)
+#pragma unroll
+          for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int p = 0; p < kAccumPer; ++p) sum[p][h] += v[q][h];
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      static_assert(kWave == 4 * kB, "four batches per tile");
+      rd(va, 0);
+      rd(vb, kB);
+      add(va);
+      rd(va, 2 * kB);
+      add(vb);
+      rd(vb, 3 * kB);
+      add(va);
+      add(vb);
 #pragma unroll
       for (int p = 0; p < kAccumPer; ++p) nn[p] += kWave;
-      continue;
+      return;
     }
     while (any) {   // ascending row order over the union; each point adds only its own neighbours
       const int q = __ffsll((long long)any) - 1;
@@ -214,7 +244,8 @@ __global__ __launch_bounds__(64 * kAccumWaves) void k_subtract_accum(const doubl
           ++nn[p];
         }
     }
-  }
+  };
+  for (int t = 0; t < ntiles; ++t) one_tile(t);
 #pragma unroll
   for (int p = 0; p < kAccumPer; ++p) {
     const int j = j0 + p;
@@ -611,58 +642,54 @@ __global__ __launch_bounds__(64 * kCovWaves) void k_boot_cov16(const double *__r
 
 // Bootstrap enlargement without leaving the device (reference mlfriends.pyx:1056-1066 with minvol = 0):
 // f_b = max over the left-out rows of (u_i - m_b)^T (scale cov_b)^-1 (u_i - m_b).  Two launches:
-//   k_boot_chol      one WAVE per round: scale cov_b = L L^T, lane = matrix row held in registers, the pivot column
-//                    travels by v_readlane; no barriers, no LDS (the first version factorised in LDS with three
-//                    workgroup barriers per column, and once in each of 8 row slices: 0.75 ms for 30 rounds)
+//   k_boot_chol      one WAVE per round: scale cov_b = L L^T, lane = matrix row held in registers (see the kernel)
 //   k_boot_solvemax  one LANE per row: solves L y = u_i - m_b, f = |y|^2, per-round maximum over the left-out rows by
 //                    atomicMax on the bit pattern (see the kernel)
 // The host version inverted the B matrices with LAPACK (1.1 ms at B = 30, d = 50) between two device calls.  Result
 // class: like the reference's inv + einsum to rounding (tolerance class of `f`); a round whose matrix is not positive
-// definite or not finite returns NaN.  Same sequence of roundings as the LDS version (right-looking, column by column).
+// definite or not finite returns NaN.  Same sequence of roundings in every version so far (right-looking, column by column).
 
-// value of `v` on lane `lane` (wave-uniform index) through the scalar unit: two v_readlane_b32 instead of the two
-// ds_bpermute round trips of __shfl (the substitution below is one dependent chain of 64 such broadcasts per row)
-__device__ __forceinline__ double lane_value(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
-// Lout: [B][DPC][DPC + 1] (lower triangle incl. diagonal; column DPC holds 1 / L_rr); bad[b] != 0: not positive definite
-template <int DPC>
-__global__ __launch_bounds__(64) void k_boot_chol(const double *__restrict__ cov, int d, double scale,
+// Lout: [B][dpc][dpc + 1] (lower triangle incl. diagonal; column dpc holds 1 / L_rr); bad[b] != 0: not positive definite.
+// One wave per round, lane = matrix row, the row in registers SHIFTED left by one per column: at step j register c holds
+// element (r, j + c) of the trailing matrix, so the pivot column is always register 0 and the loop over the columns is a
+// run-time loop whose body (one column: pivot by v_readlane, then per remaining column the owner's L_cj by v_readlane and
+// a_rc = fma(-L_rj, L_cj, a_rc), written one register to the left) is compiled once.  Element (r, c) receives its updates
+// for j = 0, 1, ... in this order, L_rj = a_rj / sqrt(a_jj): the roundings of the first version of this kernel (both loops
+// unrolled with the row in place: d^2 / 2 x 3 instructions per size class and 3.3 minutes of compile time for four
+// classes); results bit-identical.
+template <int DPC>   // registers per row: d <= dpc <= DPC
+__global__ __launch_bounds__(64) void k_boot_chol(const double *__restrict__ cov, int d, int dpc, double scale,
                                                   double *__restrict__ Lout, int *__restrict__ bad_out) {
   const int r = threadIdx.x, b = blockIdx.x;
-  double a[DPC];   // row r of the matrix; entries right of the diagonal are never used
+  double a[DPC];
 #pragma unroll
   for (int c = 0; c < DPC; ++c)
     a[c] = (r < d && c < d) ? cov[((size_t)b * d + (r < d ? r : 0)) * d + (c < d ? c : 0)] * scale : (r == c ? 1.0 : 0.0);
   bool bad = false;
   double invd = 1.0;
-#pragma unroll
-  for (int j = 0; j < DPC; ++j) {
-    const double p = lane_value(a[j], j);   // the pivot: element (j, j)
+  double *dst = Lout + ((size_t)b * dpc + (r < dpc ? r : 0)) * (dpc + 1);
+  for (int j = 0; j < dpc; ++j) {
+    const double p = readlane_f64(a[0], j);   // the pivot: element (j, j)
     if (!(p > 0.0) || !(p < 1e300)) bad = true;
     const double sp = sqrt(p > 0.0 ? p : 1.0);
     const double ip = 1.0 / sp;
+    double lr = a[0];
     if (r == j) {
-      a[j] = sp;
+      lr = sp;
       invd = ip;
     } else if (r > j) {
-      a[j] *= ip;
+      lr *= ip;
     }
+    if (r < dpc) dst[j] = r >= j ? lr : 0.0;
 #pragma unroll
-    for (int c = j + 1; c < DPC; ++c) {
-      const double lc = lane_value(a[j], c);               // L[c][j]
-      if (r >= c) a[c] = __builtin_fma(-a[j], lc, a[c]);   // element (r, c) of the trailing matrix
+    for (int c = 1; c < DPC; ++c) {
+      if ((c & 7) == 1 && j + c >= dpc) break;                  // wave-uniform: nothing right of column dpc - 1
+      const int owner = j + c < 64 ? j + c : 63;
+      const double lc = readlane_f64(lr, owner);                  // L[j + c][j]
+      a[c - 1] = __builtin_fma(-lr, lc, a[c]);   // element (r, j + c) of the trailing matrix (rows above the diagonal: never read)
     }
   }
-  if (r < DPC) {
-    double *dst = Lout + ((size_t)b * DPC + r) * (DPC + 1);
-#pragma unroll
-    for (int c = 0; c < DPC; ++c) dst[c] = c <= r ? a[c] : 0.0;
-    dst[DPC] = invd;
-  }
+  if (r < dpc) dst[dpc] = invd;
   if (r == 0) bad_out[b] = bad ? 1 : 0;
 }
 
@@ -746,10 +773,13 @@ hipError_t launch_boot_cholmax(const double *u, int n, int d, const uint8_t *sel
   const int dpc = (d + 7) / 8 * 8;   // size class of both kernels: multiples of 8 (padding rows / columns are identity)
   double *Ls = static_cast<double *>(scratch);
   int *bad = reinterpret_cast<int *>(Ls + (size_t)B * dpc * (dpc + 1));
+  if (dpc <= 32)
+    hipLaunchKernelGGL(k_boot_chol<32>, dim3((unsigned)B), dim3(64), 0, s, cov, d, dpc, scale, Ls, bad);
+  else
+    hipLaunchKernelGGL(k_boot_chol<64>, dim3((unsigned)B), dim3(64), 0, s, cov, d, dpc, scale, Ls, bad);
   switch (dpc) {
 #define MLF_CHOLMAX(DPC)                                                                                                          \
   case DPC:                                                                                                                       \
-    hipLaunchKernelGGL(k_boot_chol<DPC>, dim3((unsigned)B), dim3(64), 0, s, cov, d, scale, Ls, bad);                              \
     hipLaunchKernelGGL(k_boot_solvemax<DPC>, grid, dim3(64 * kSolveWaves), 0, s, u, n, d, selected, mean, Ls, DPC, bad, out_bits); \
     break;
     MLF_CHOLMAX(8) MLF_CHOLMAX(16) MLF_CHOLMAX(24) MLF_CHOLMAX(32) MLF_CHOLMAX(40) MLF_CHOLMAX(48) MLF_CHOLMAX(56) MLF_CHOLMAX(64)
