@@ -187,8 +187,11 @@ std::vector<double> pad_vector(const double *v, int d, int dp, double fill = 0.0
 // synchronisations and a dozen pageable copies, 0.2 of the call's 0.6 ms).  The arena is rewound by the caller once the
 // stream has been synchronised.
 struct HostArena {
-  unsigned char *p = nullptr;
+  unsigned char *p = nullptr;       // pinned host memory ...
+  unsigned char *p_dev = nullptr;   // ... as the device sees it
   size_t cap = 0, used = 0;
+  ScatterArgs pending{};            // uploads staged but not yet sent (arena_flush)
+  int npending = 0;
   void *take(size_t bytes) {
     const size_t at = (used + 63) / 64 * 64;
     if (!p || at + bytes > cap) return nullptr;
@@ -201,16 +204,33 @@ constexpr size_t kArenaBytes = 1u << 20, kArenaMaxPiece = 128u << 10;
 
 bool arena_active() { return g_arena != nullptr; }
 
+// Everything staged so far leaves in ONE launch (the device reads the pinned arena itself).  To be called in front of every
+// kernel that reads a constant uploaded under the arena, and before the arena is dropped.
+int arena_flush(hipStream_t s) {
+  if (!g_arena || g_arena->npending == 0) return 0;
+  launch_scatter_copy(g_arena->pending, g_arena->npending, s);
+  g_arena->npending = 0;
+  CK(hipGetLastError());
+  return 0;
+}
+
 int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t s) {
   CK(b.reserve(bytes ? bytes : 1));
   if (!bytes) return 0;
   if (g_arena && bytes <= kArenaMaxPiece) {
     if (void *stage = g_arena->take(bytes)) {
       memcpy(stage, src, bytes);
-      CK(hipMemcpyAsync(b.p, stage, bytes, hipMemcpyHostToDevice, s));
+      if (g_arena->npending == kScatterMax)
+        if (int rc = arena_flush(s)) return rc;
+      HostArena &a = *g_arena;
+      a.pending.dst[a.npending] = b.p;
+      a.pending.src[a.npending] = a.p_dev + (static_cast<unsigned char *>(stage) - a.p);
+      a.pending.bytes[a.npending] = (unsigned)bytes;
+      ++a.npending;
       return 0;
     }
   }
+  if (int rc = arena_flush(s)) return rc;   // keep the order of the stream
   CK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyDefault, s));
   if (g_arena) CK(hipStreamSynchronize(s));   // did not fit: the caller relies on the source being consumed
   return 0;
@@ -843,7 +863,10 @@ int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2,
 // whiten `n` cube-space rows already on the device with the region's own layer (same kernels and
 // arithmetic as for proposals, so a live point is at distance exactly 0 from itself)
 int region_whiten_rows(mlf_region *r, const double *d_u, size_t n, double *d_t, hipStream_t s) {
-  if (r->layer_kind == 0) {
+  if (r->layer_kind == 0 && r->dp <= 64) {   // a few thousand rows at most: the wave-per-8-rows form of the same chain
+    CK(launch_whiten_rows(d_u, (long long)n, r->d, r->dp, r->lay_ctr.as<double>(), r->lay_T8.as<double>(), (r->dp + 7) / 8 * 8,
+                          r->has_wrap ? r->wrap.as<double>() : nullptr, d_t, r->d, s));
+  } else if (r->layer_kind == 0) {
     PrepArgs pa{};
     pa.pts = d_u;
     pa.np = (long long)n;
@@ -1572,12 +1595,14 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
   if (int rc = ensure_ctx()) return rc;
   Ctx &c = g_ctx;
   if (!r->arena.p) {   // pinned staging of the constants (kept with the handle; handles are recycled)
-    if (hipHostMalloc(reinterpret_cast<void **>(&r->arena.p), kArenaBytes, hipHostMallocDefault) == hipSuccess)
+    if (hipHostMalloc(reinterpret_cast<void **>(&r->arena.p), kArenaBytes, hipHostMallocMapped) == hipSuccess &&
+        hipHostGetDevicePointer(reinterpret_cast<void **>(&r->arena.p_dev), r->arena.p, 0) == hipSuccess)
       r->arena.cap = kArenaBytes;
     else
       (void)hipGetLastError();
   }
   r->arena.used = 0;
+  r->arena.npending = 0;
   struct ArenaScope {   // every exit path of this call drops the arena
     explicit ArenaScope(HostArena *a) { g_arena = a->p ? a : nullptr; }
     ~ArenaScope() { g_arena = nullptr; }
@@ -1666,6 +1691,7 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
     }
     if (int rc = upload(c.src, unormed, n * d * sizeof(double), c.stream)) return rc;
     const double *rows = c.src.as<double>();
+    if (int rc = arena_flush(c.stream)) return rc;   // the layer constants, in front of the kernels that read them
     if (r->live_space) {  // rows are cube-space live points: whiten them on the device
       CK(c.tq.reserve(n * d * sizeof(double)));
       if (int rc = region_whiten_rows(r, c.src.as<double>(), n, c.tq.as<double>(), c.stream)) return rc;
@@ -1699,6 +1725,7 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
     }
     if (int rc = region_prep4_setup(r, L, fro_sq, ell_center, layer_ctr, layer_T, live_host, n_for_scale, c.stream)) return rc;
   }
+  if (int rc = arena_flush(c.stream)) return rc;
   CK(hipStreamSynchronize(c.stream));
   r->ready = true;
   return 0;

@@ -14,9 +14,8 @@
 // non-negative doubles).
 //
 // Compiled with -ffp-contract=off: diff = a_i[k] - b_j[k]; acc += diff*diff, k ascending.
-#include <type_traits>
-
 #include "mlf_common.hpp"
+#include "mlf_dpp_dev.hpp"
 
 namespace mlf {
 
@@ -37,25 +36,6 @@ namespace mlf {
 // selmask[i][r] (0 if i is selected in round r, 0xffffffff otherwise): an unselected i turns the candidate into a quiet
 // NaN, which v_min_f64 ignores -- 2 vector instructions per round where select + compare + select took 4-5.  The
 // non-NaN candidates are the same binary64 values as before and min is exact: results bit-identical.
-constexpr int kDppRowNewBcast = 0x150;   // DPP control row_newbcast:0 (gfx90a+): lane k of each row of 16 to the whole row
-
-template <int K>
-__device__ __forceinline__ double row_bcast(double x) {
-  return __builtin_amdgcn_update_dpp(0.0, x, kDppRowNewBcast + K, 0xf, 0xf, true);
-}
-template <int K>
-__device__ __forceinline__ unsigned row_bcast(unsigned x) {
-  return __builtin_amdgcn_update_dpp(0u, x, kDppRowNewBcast + K, 0xf, 0xf, true);
-}
-
-template <int K, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-  if constexpr (K < N) {
-    f(std::integral_constant<int, K>{});
-    static_for<K + 1, N>(f);
-  }
-}
-
 template <int NCH>
 struct BootRow {        // one live point as the wave holds it: 16 coordinates per register pair, 16 selection words per register
   double x[NCH];

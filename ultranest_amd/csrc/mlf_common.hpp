@@ -126,6 +126,8 @@ int pick_dp(int d);
 hipError_t launch_scan(int dp, const ScanArgs &a, hipStream_t s);
 hipError_t launch_boot(int dp, const BootArgs &a, int nchunks, hipStream_t s);
 hipError_t launch_prep(int dp, const PrepArgs &a, hipStream_t s);
+hipError_t launch_whiten_rows(const double *pts, long long n, int d, int dp, const double *lay_ctr, const double *T8, int ldt8,
+                              const double *wrap_shift, double *t_out, long long ldt, hipStream_t s);
 hipError_t launch_boot_quadmax(int dp, const QuadMaxArgs &a, int B, hipStream_t s);
 
 // instantiated dimensionalities: every even value up to 32, every 4th up to 64 (+50, the

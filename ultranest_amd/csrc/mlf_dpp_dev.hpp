@@ -1,0 +1,48 @@
+// mlf_dpp_dev.hpp -- the DPP row broadcast (gfx90a+: `row_newbcast:k`, lane k of every row of 16 lanes to the whole row;
+// the operand broadcast the instruction set has for binary64 matrix products) and a compile-time loop.
+//
+// Pattern shared by k_boot, k_boot_cov16, k_boot_solvemax and k_whiten_rows: a value that is the same for every lane
+// (a coordinate of the live point a wave works on, a column of a small matrix) is kept 16 entries per register -- lane l
+// holds entry 16 c + (l mod 16) of chunk c, so every row of 16 lanes holds the same 16 entries -- and reaches all lanes
+// either through `v_mov_b64_dpp` (one extra vector instruction) or directly as the first operand of `v_fmac_f64`
+// (inline asm: the compiler does not fold the DPP move into that instruction).  No scalar loads (they return out of
+// order: every wait is lgkmcnt(0)), no LDS, no v_readlane pairs.
+//
+// Hazard: a DPP read of a register written by a VECTOR instruction needs two wait states.  The compiler inserts them
+// for the builtins; in front of the inline-asm forms the caller ties an `s_nop 1` to the register (dpp_settle) unless the
+// register comes straight from a memory instruction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+namespace mlf {
+
+constexpr int kDppRowNewBcast = 0x150;   // DPP control row_newbcast:0
+
+template <int K>
+__device__ __forceinline__ double row_bcast(double x) {
+  return __builtin_amdgcn_update_dpp(0.0, x, kDppRowNewBcast + K, 0xf, 0xf, true);
+}
+template <int K>
+__device__ __forceinline__ unsigned row_bcast(unsigned x) {
+  return __builtin_amdgcn_update_dpp(0u, x, kDppRowNewBcast + K, 0xf, 0xf, true);
+}
+
+// acc += entries16[lane K of the row] * y   (one fused multiply-add, as __builtin_fma)
+template <int K>
+__device__ __forceinline__ void fmac_row_bcast(double &acc, double entries16, double y) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(entries16), "v"(y), "n"(K));
+}
+
+__device__ __forceinline__ void dpp_settle(double &x) { asm volatile("s_nop 1" : "+v"(x)); }
+
+template <int K, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (K < N) {
+    f(std::integral_constant<int, K>{});
+    static_for<K + 1, N>(f);
+  }
+}
+
+}  // namespace mlf

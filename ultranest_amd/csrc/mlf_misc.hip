@@ -4,7 +4,7 @@
 
 #include <math.h>
 
-#include <type_traits>
+#include "mlf_dpp_dev.hpp"
 
 namespace mlf {
 
@@ -128,6 +128,22 @@ __global__ __launch_bounds__(256) void k_boot_final(const unsigned long long *M,
 void launch_boot_final(const unsigned long long *M, const unsigned *sel, int n, int npad, int nb,
                        double *maxd, uint8_t *skipped, hipStream_t s) {
   hipLaunchKernelGGL(k_boot_final, dim3(nb), dim3(256), 0, s, M, sel, n, npad, maxd, skipped);
+}
+
+// ------------------------------------------------------- constants of a region, one launch ---
+__global__ __launch_bounds__(256) void k_scatter_copy(ScatterArgs a) {
+  const int seg = blockIdx.x;
+  unsigned char *dst = static_cast<unsigned char *>(a.dst[seg]);
+  const unsigned char *src = static_cast<const unsigned char *>(a.src[seg]);
+  const unsigned bytes = a.bytes[seg];
+  const unsigned words = bytes / 8u;   // both ends are 8-byte aligned (64-byte arena pieces, 256-byte device buffers)
+  for (unsigned w = threadIdx.x; w < words; w += 256)
+    reinterpret_cast<unsigned long long *>(dst)[w] = reinterpret_cast<const unsigned long long *>(src)[w];
+  for (unsigned t = words * 8u + threadIdx.x; t < bytes; t += 256) dst[t] = src[t];
+}
+
+void launch_scatter_copy(const ScatterArgs &a, int count, hipStream_t s) {
+  if (count > 0) hipLaunchKernelGGL(k_scatter_copy, dim3((unsigned)count), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------- K3 pass 2 -----------------------
@@ -516,26 +532,6 @@ __global__ __launch_bounds__(64 * kCovWaves) void k_boot_cov(const double *__res
   }
 }
 
-template <int K>
-__device__ __forceinline__ void fmac_row_bcast(double &acc, double column16, double y) {   // acc += column16[lane K of the row] * y
-  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(column16), "v"(y), "n"(K));
-}
-template <int K>
-__device__ __forceinline__ double row_bcast_f64(double x) {
-  return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + K, 0xf, 0xf, true);
-}
-template <int K>
-__device__ __forceinline__ unsigned row_bcast_u32(unsigned x) {
-  return __builtin_amdgcn_update_dpp(0u, x, 0x150 + K, 0xf, 0xf, true);
-}
-template <int K, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-  if constexpr (K < N) {
-    f(std::integral_constant<int, K>{});
-    static_for<K + 1, N>(f);
-  }
-}
-
 // d <= 64: the same sums with the operand broadcast the instruction set has for binary64 products.  A wave takes FOUR
 // selected rows per step, one per group of 16 lanes; lane l of a group holds the centred coordinates 16 c + (l mod 16),
 // c = 0 ... NCH - 1, and acc[kk][c] += x[16 CK + kk] * x[16 c + l mod 16] is ONE v_fmac_f64 whose first operand comes from
@@ -576,7 +572,7 @@ __device__ __forceinline__ void cov_block(const double *__restrict__ u, int d, c
       constexpr int tt = decltype(tc)::value;
       // no branch on "is there such a step": steps past the list load row 0 and add zeros (a branch per step makes every
       // wait a wait for ALL outstanding loads: the counter is not tracked across the blocks)
-      row[tt & 7] = (int)row_bcast_u32<tt>((unsigned)mine);
+      row[tt & 7] = (int)row_bcast<tt>((unsigned)mine);
       const long long r = row[tt & 7] < 0 ? 0 : row[tt & 7];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) x[tt & 7][c] = u[r * d + col[c]];
@@ -591,7 +587,7 @@ __device__ __forceinline__ void cov_block(const double *__restrict__ u, int d, c
 #pragma unroll
         for (int c = 0; c < NCH; ++c) xs[c] = ok ? xs[c] - ml[c] : 0.0;
         // v_fmac_f64_dpp reads xs[CK] through DPP: a register just written by a vector instruction needs two wait states
-        asm volatile("s_nop 1" : "+v"(xs[CK]));
+        dpp_settle(xs[CK]);
         static_for<0, 16>([&](auto kc) __attribute__((always_inline)) {
           constexpr int kk = decltype(kc)::value;
 #pragma unroll
@@ -733,7 +729,7 @@ __global__ __launch_bounds__(64 * kSolveWaves) void k_boot_solvemax(const double
   static_for<0, DPC>([&](auto kc) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value;
     if (k < d) {   // wave-uniform
-      const double yk = acc[k] * row_bcast_f64<(k & 15)>(inv16[k >> 4]);
+      const double yk = acc[k] * row_bcast<(k & 15)>(inv16[k >> 4]);
       ss = __builtin_fma(yk, yk, ss);
       const double ny = -yk;
       static_for<(k + 1) / 16, NCH>([&](auto cc) __attribute__((always_inline)) {

@@ -8,6 +8,15 @@ void launch_build_layouts(const double *src, int n, int d, int dp, int npad, dou
                           double *refR, hipStream_t s);
 void launch_update_rows(const double *rows, int count, int d, int dp, int npad, const long long *index, double *refT,
                         double *refR, hipStream_t s);
+// up to kScatterMax (destination, source, bytes) copies in ONE launch: the small constants of mlf_region_set, staged in a
+// pinned arena the device reads directly (ten separate copies on the stream cost ~4 us each, and as much on the host)
+constexpr int kScatterMax = 24;
+struct ScatterArgs {
+  void *dst[kScatterMax];
+  const void *src[kScatterMax];
+  unsigned bytes[kScatterMax];
+};
+void launch_scatter_copy(const ScatterArgs &a, int count, hipStream_t s);
 void launch_fill_u64(unsigned long long *p, long long n, unsigned long long v, hipStream_t s);
 void launch_pack_selection(const uint8_t *selected, int n, int npad, int b0, int nb, unsigned *sel,
                            hipStream_t s, unsigned *selmask = nullptr);

@@ -11,6 +11,7 @@
 // T1 is a k-ascending fused-multiply-add chain (explicit fma(): BLAS order is implementation
 // defined, this is what OpenBLAS produced for most probed shapes; tolerance class).
 #include "mlf_common.hpp"
+#include "mlf_dpp_dev.hpp"
 
 namespace mlf {
 
@@ -150,6 +151,78 @@ hipError_t launch_boot_quadmax(int dp, const QuadMaxArgs &a, int B, hipStream_t 
     default:
       return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+// T1 for a few rows (the live points of a region: 4000 rows are 63 waves of k_prep, each lane a chain of d x d dependent
+// multiply-adds: 0.036 ms, latency bound).  Here a wave takes 8 rows and lane c computes their OUTPUT coordinate c:
+// t_c = sum_k x_k T[k][c], k ascending, one fused multiply-add per term -- the chain of k_prep, bit for bit (the padded
+// terms k >= d, zeros times zeros, are kept: they turn an accumulated -0 into +0 there, so they do here).  T[k][.] is one
+// coalesced load per k for all 8 rows; x_k is the same for every lane: the centred row sits 16 coordinates per register
+// and enters through the DPP operand of v_fmac_f64 (mlf_dpp_dev.hpp).
+constexpr int kWhitenRows = 8;
+template <int NCH>   // dp <= 16 NCH <= 64
+__global__ __launch_bounds__(256) void k_whiten_rows(const double *__restrict__ pts, long long n, int d, int dp,
+                                                     const double *__restrict__ lay_ctr, const double *__restrict__ T8, int ldt8,
+                                                     const double *__restrict__ wrap_shift, double *__restrict__ t_out, long long ldt) {
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kWhitenRows;
+  if (r0 >= n) return;
+  double x[kWhitenRows][NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int k = 16 * ch + sub;
+    const double ctr = k < d ? lay_ctr[k] : 0.0;
+    double sh = NAN;
+    if (wrap_shift && k < d) sh = wrap_shift[k];
+#pragma unroll
+    for (int i = 0; i < kWhitenRows; ++i) {
+      const long long row = r0 + i < n ? r0 + i : n - 1;
+      double w = 0.0;
+      if (k < d) {
+        w = pts[row * d + k];
+        if (sh == sh) w = fmod(w + sh, 1.0);   // NaN marks an unwrapped dimension
+        w -= ctr;
+      }
+      x[i][ch] = w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kWhitenRows; ++i)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) dpp_settle(x[i][ch]);
+  double acc[kWhitenRows];
+#pragma unroll
+  for (int i = 0; i < kWhitenRows; ++i) acc[i] = 0.0;
+  const int c = lane < d ? lane : 0;
+  static_for<0, 16 * NCH>([&](auto kc) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value;
+    if (k < dp) {   // wave-uniform
+      const double tv = T8[(long long)k * ldt8 + c];
+#pragma unroll
+      for (int i = 0; i < kWhitenRows; ++i) fmac_row_bcast<(k & 15)>(acc[i], x[i][k >> 4], tv);
+    }
+  });
+  if (lane < d) {
+#pragma unroll
+    for (int i = 0; i < kWhitenRows; ++i)
+      if (r0 + i < n) t_out[(r0 + i) * ldt + lane] = acc[i];
+  }
+}
+
+// rows -> whitened rows with an affine layer; T8: T row-major (row k = input coordinate), stride ldt8, zero padded to dp rows
+hipError_t launch_whiten_rows(const double *pts, long long n, int d, int dp, const double *lay_ctr, const double *T8, int ldt8,
+                              const double *wrap_shift, double *t_out, long long ldt, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (dp > 64) return hipErrorInvalidValue;
+  const unsigned grid = (unsigned)((n + 4 * kWhitenRows - 1) / (4 * kWhitenRows));
+  const int nch = (dp + 15) / 16;
+#define X(NCH)                                                                                                          \
+  case NCH:                                                                                                             \
+    hipLaunchKernelGGL(k_whiten_rows<NCH>, dim3(grid), dim3(256), 0, s, pts, n, d, dp, lay_ctr, T8, ldt8, wrap_shift, t_out, ldt); \
+    break;
+  switch (nch) { X(1) X(2) X(3) X(4) }
+#undef X
   return hipGetLastError();
 }
 
