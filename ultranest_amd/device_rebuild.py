@@ -222,7 +222,7 @@ class DeviceRebuild(object):
         region._dev = regions._DeviceState()
         region.transformLayer = nxt
         host = torch.cat((unormed_d.reshape(-1), box)).cpu().numpy()
-        region.unormed = host[:n * d].reshape(n, d).copy()
+        region.unormed = host[:n * d].reshape(n, d)                    # a view of the array torch has just created
         region.bbox_lo = host[n * d:n * d + d].copy()
         region.bbox_hi = host[n * d + d:].copy()
         region.maxradiussq = maxd

@@ -406,7 +406,7 @@ class _DeviceState(object):
         shift = region.transformLayer.wrap_shift_vector(ndim)
         consts = (kind, lctr, lmat, shift, np.asarray(region.ellipsoid_invcov), int(use_scan), len(region.u))
         self.consts = tuple(None if c is None else (c if np.isscalar(c) else np.array(c, dtype=float)) for c in consts)
-        self.live = np.array(region.u, dtype=float)
+        self.live = None      # region.u has just been assigned: its writes are counted (see _sync_slow)
         self.ell_center = np.array(region.ellipsoid_center, dtype=float)
         self.thresholds = (float(region.enlarge), float(region.maxradiussq))
         cell = region.__dict__.get("_u_cell")
@@ -451,10 +451,17 @@ class _DeviceState(object):
         changed = ()
         cell = region.__dict__.get("_u_cell")
         rows = cell[1] if cell is not None else None
-        known = (not full and use_scan and rows is not None and key[2] >= 0 and self.fast_key is not None
-                 and self.fast_key[1] is key[1] and len(rows) <= max(8, nlive // 8))
+        distinct = None
+        if (not full and use_scan and rows is not None and key[2] >= 0 and self.fast_key is not None
+                and self.fast_key[1] is key[1]):
+            distinct = set(r % nlive for r in rows)      # a row written twice counts once
+        known = distinct is not None and len(distinct) <= max(8, nlive // 8)
         if known:      # only plain row assignments since the last sync: no diff
-            changed = sorted(set(r % nlive for r in rows))
+            changed = sorted(distinct)
+        elif not full and use_scan and self.live is None:
+            # writes the counter could not name, and no host snapshot to diff against (a snapshot of a TRACKED array cost a
+            # 1.6 MB copy per rebuild at N = 4000, d = 50 for a case nothing in the reference produces): send everything
+            full = True
         elif not full and use_scan:
             u_now = np.asarray(region.u)
             if u_now.dtype == np.float64 and u_now.flags.c_contiguous and u_now.shape == self.live.shape:
@@ -474,7 +481,9 @@ class _DeviceState(object):
                             region.ellipsoid_center, region.ellipsoid_invcov, thresholds[0], thresholds[1],
                             use_scan=use_scan, live_space=1)
             self.consts = tuple(None if c is None else (c if np.isscalar(c) else np.array(c, dtype=float)) for c in consts)
-            self.live = np.array(region.u, dtype=float) if use_scan else None
+            # host snapshot only for an array whose writes are NOT counted (e.g. a region that came out of a pickle):
+            # there every call diffs against it; a counted array names its rows or is sent again
+            self.live = np.array(region.u, dtype=float) if (use_scan and key[2] < 0) else None
             self.ell_center = np.array(region.ellipsoid_center, dtype=float)
             self.thresholds = thresholds
             return self.handle
@@ -482,7 +491,8 @@ class _DeviceState(object):
             rows = np.asarray(changed, dtype=np.int64)
             fresh = np.asarray(region.u)[rows]
             self.handle.update_points(rows, fresh)
-            self.live[rows] = fresh
+            if self.live is not None:
+                self.live[rows] = fresh
         if not np.array_equal(self.ell_center, region.ellipsoid_center):
             self.handle.set_ellipsoid_center(region.ellipsoid_center)
             self.ell_center = np.array(region.ellipsoid_center, dtype=float)
