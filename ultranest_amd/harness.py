@@ -28,6 +28,7 @@ class RegionUpdater(object):
         # class 1e-10 on T / radius instead of the default path's bit parity with the reference's numpy calls)
         self.device_resident = bool(device_resident)
         self._device_rebuild = None
+        self._pool = None          # one worker thread for the host work that overlaps the GPU passes of a rebuild
         self.region = None
         self.transformLayer = None
         self.tregion = None
@@ -42,6 +43,16 @@ class RegionUpdater(object):
         if self._device_rebuild is None:
             self._device_rebuild = device_rebuild.DeviceRebuild()
         return True
+
+    def _ellipsoid_job(self, live_u, minvol):
+        cls = self.region_class
+        parts = getattr(cls, "ellipsoid_parts", None)
+        if parts is None or getattr(cls, "create_ellipsoid", None) is not MLFriends.create_ellipsoid:
+            return None      # a region class with its own ellipsoid: leave the order of its calls alone
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1)
+        return self._pool.submit(parts, live_u, minvol, np.geterr())
 
     def _bootstrap(self, region, nbootstraps, minvol):
         return distributed.update_region_bootstrap(region, nbootstraps, minvol, group=self.group)
@@ -97,8 +108,16 @@ class RegionUpdater(object):
                     assert not (nxt_layer.clusterids == 0).any()
                     _, sizes = np.unique(nxt_layer.clusterids, return_counts=True)
                     nxt = self.region_class(active_u, nxt_layer)
+                    # create_ellipsoid's numpy / LAPACK work depends on the live points alone: it runs on a worker thread
+                    # while this one waits for the GPU's bootstrap passes (0.55 of 0.7 ms hidden at N = 4000, d = 50; started
+                    # before the layer is built it competes with that host work for the interpreter: no gain);
+                    # same calls, same inputs, same results; an error surfaces where create_ellipsoid would have raised it
+                    job = self._ellipsoid_job(nxt.u, minvol)
                     self._bootstrap(nxt, nbootstraps, minvol)
-                    nxt.create_ellipsoid(minvol=minvol)
+                    if job is None:
+                        nxt.create_ellipsoid(minvol=minvol)
+                    else:
+                        nxt.create_ellipsoid(minvol=minvol, parts=job.result())
                     contains_live = nxt.inside(active_u).all()
                 sensible = nxt_layer.nclusters < len(nxt.u) and sizes.max() >= nxt.u.shape[1]
                 shrinks = need_accept or nxt.estimate_volume() <= self.region.estimate_volume()

@@ -82,6 +82,17 @@ def bounding_ellipsoid(x, minvol=0.):
     return ctr, cov
 
 
+def _principal_axes(precision, cov):
+    """(axlens, axes, axes_T, inv_axlens, inv_axes) of an ellipsoid matrix and its inverse (reference :1226-1235)."""
+    lam, vec = np.linalg.eigh(precision)
+    axlens = 1. / np.sqrt(lam)
+    axes = np.dot(vec, np.diag(axlens))
+    lam2, vec2 = np.linalg.eigh(cov)
+    inv_axlens = 1. / np.sqrt(lam2)
+    inv_axes = np.dot(vec2, np.diag(inv_axlens))
+    return axlens, axes, axes.transpose(), inv_axlens, inv_axes
+
+
 def _inside_ellipsoid(points, ellipsoid_center, ellipsoid_invcov, square_radius):
     """``(p-c)^T invcov (p-c) <= square_radius`` per row (reference mlfriends.pyx:882-912); the
     quadratic form is evaluated on the GPU in numpy's einsum order."""
@@ -540,25 +551,32 @@ class MLFriends(_LivePoints):
         ndim = self.u.shape[1]
         return self.transformLayer.logvolscale + np.log(r) * ndim
 
+    @staticmethod
+    def ellipsoid_parts(u, minvol=0.0, errstate=None):
+        """What `create_ellipsoid` derives from the live points ALONE (centre, inflated covariance, its inverse, the axes):
+        the numpy / LAPACK calls of reference :1213-1237 in their order.  A rebuild may run this on a worker thread while
+        the GPU bootstraps the radius (harness.RegionUpdater); `errstate` = the caller's ``np.geterr()``, which numpy keeps
+        per thread."""
+        with np.errstate(**(errstate or np.geterr())):
+            ctr, cov = bounding_ellipsoid(u, minvol=minvol)
+            precision = np.linalg.inv(cov)
+            return ctr, cov, precision, _principal_axes(precision, cov)
+
     @single_blas_thread
-    def create_ellipsoid(self, minvol=0.0):
-        """Wrapping ellipsoid of all live points and its principal axes (reference :1213-1237)."""
+    def create_ellipsoid(self, minvol=0.0, parts=None):
+        """Wrapping ellipsoid of all live points and its principal axes (reference :1213-1237).  `parts`: the result of
+        `ellipsoid_parts(self.u, minvol)` if the caller has it already."""
         assert self.enlarge is not None
-        ctr, cov = bounding_ellipsoid(self.u, minvol=minvol)
-        precision = np.linalg.inv(cov)
+        ctr, cov, precision, axes = parts if parts is not None else self.ellipsoid_parts(self.u, minvol)
         self.ellipsoid_center = ctr
         self.ellipsoid_invcov = precision
         self.ellipsoid_cov = cov
-        self._set_axes(precision, cov)
+        (self.ellipsoid_axlens, self.ellipsoid_axes, self.ellipsoid_axes_T, self.ellipsoid_inv_axlens,
+         self.ellipsoid_inv_axes) = axes
 
     def _set_axes(self, precision, cov):
-        lam, vec = np.linalg.eigh(precision)
-        self.ellipsoid_axlens = 1. / np.sqrt(lam)
-        self.ellipsoid_axes = np.dot(vec, np.diag(self.ellipsoid_axlens))
-        self.ellipsoid_axes_T = self.ellipsoid_axes.transpose()
-        lam2, vec2 = np.linalg.eigh(cov)
-        self.ellipsoid_inv_axlens = 1. / np.sqrt(lam2)
-        self.ellipsoid_inv_axes = np.dot(vec2, np.diag(self.ellipsoid_inv_axlens))
+        (self.ellipsoid_axlens, self.ellipsoid_axes, self.ellipsoid_axes_T, self.ellipsoid_inv_axlens,
+         self.ellipsoid_inv_axes) = _principal_axes(precision, cov)
 
     # ---- bootstrapping ---------------------------------------------------------------------
     def compute_maxradiussq(self, nbootstraps=50):
