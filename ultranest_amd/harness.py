@@ -8,7 +8,7 @@ passing these classes through its plug points."""
 import numpy as np
 
 from . import distributed
-from .layers import single_blas_thread
+from .layers import host_worker, single_blas_thread
 from .mlfriends import LocalAffineLayer, MLFriends, WrappingEllipsoid, find_nearby, int_dtype
 
 
@@ -28,7 +28,6 @@ class RegionUpdater(object):
         # class 1e-10 on T / radius instead of the default path's bit parity with the reference's numpy calls)
         self.device_resident = bool(device_resident)
         self._device_rebuild = None
-        self._pool = None          # one worker thread for the host work that overlaps the GPU passes of a rebuild
         self.region = None
         self.transformLayer = None
         self.tregion = None
@@ -49,10 +48,7 @@ class RegionUpdater(object):
         parts = getattr(cls, "ellipsoid_parts", None)
         if parts is None or getattr(cls, "create_ellipsoid", None) is not MLFriends.create_ellipsoid:
             return None      # a region class with its own ellipsoid: leave the order of its calls alone
-        if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=1)
-        return self._pool.submit(parts, live_u, minvol, np.geterr())
+        return host_worker().submit(parts, live_u, minvol, np.geterr())
 
     def _bootstrap(self, region, nbootstraps, minvol):
         return distributed.update_region_bootstrap(region, nbootstraps, minvol, group=self.group)
