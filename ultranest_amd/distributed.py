@@ -122,6 +122,9 @@ def sharded_enlargement(region, nbootstraps, minvol=0., rng=np.random, group=Non
     Single process: identical to ``region.compute_enlargement`` (same draws, same bits)."""
     rank, size = world(group)
     npoints = len(region.u)
+    start = getattr(region, "_start_ellipsoid_parts", None)
+    if start is not None:
+        start(minvol)      # the host LAPACK of the create_ellipsoid that follows: on the worker thread from here on
     # every rank draws (so that rank-replicated host logic that uses the same stream afterwards stays in step across
     # the ranks when they are seeded alike); rank 0's draw is the one that counts
     masks = regions._draw_selection(rng, npoints, nbootstraps)

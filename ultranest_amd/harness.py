@@ -8,7 +8,7 @@ passing these classes through its plug points."""
 import numpy as np
 
 from . import distributed
-from .layers import host_worker, single_blas_thread
+from .layers import single_blas_thread
 from .mlfriends import LocalAffineLayer, MLFriends, WrappingEllipsoid, find_nearby, int_dtype
 
 
@@ -42,13 +42,6 @@ class RegionUpdater(object):
         if self._device_rebuild is None:
             self._device_rebuild = device_rebuild.DeviceRebuild()
         return True
-
-    def _ellipsoid_job(self, live_u, minvol):
-        cls = self.region_class
-        parts = getattr(cls, "ellipsoid_parts", None)
-        if parts is None or getattr(cls, "create_ellipsoid", None) is not MLFriends.create_ellipsoid:
-            return None      # a region class with its own ellipsoid: leave the order of its calls alone
-        return host_worker().submit(parts, live_u, minvol, np.geterr())
 
     def _bootstrap(self, region, nbootstraps, minvol):
         return distributed.update_region_bootstrap(region, nbootstraps, minvol, group=self.group)
@@ -104,16 +97,8 @@ class RegionUpdater(object):
                     assert not (nxt_layer.clusterids == 0).any()
                     _, sizes = np.unique(nxt_layer.clusterids, return_counts=True)
                     nxt = self.region_class(active_u, nxt_layer)
-                    # create_ellipsoid's numpy / LAPACK work depends on the live points alone: it runs on a worker thread
-                    # while this one waits for the GPU's bootstrap passes (0.55 of 0.7 ms hidden at N = 4000, d = 50; started
-                    # before the layer is built it competes with that host work for the interpreter: no gain);
-                    # same calls, same inputs, same results; an error surfaces where create_ellipsoid would have raised it
-                    job = self._ellipsoid_job(nxt.u, minvol)
-                    self._bootstrap(nxt, nbootstraps, minvol)
-                    if job is None:
-                        nxt.create_ellipsoid(minvol=minvol)
-                    else:
-                        nxt.create_ellipsoid(minvol=minvol, parts=job.result())
+                    self._bootstrap(nxt, nbootstraps, minvol)      # starts create_ellipsoid's host LAPACK on the worker thread
+                    nxt.create_ellipsoid(minvol=minvol)
                     contains_live = nxt.inside(active_u).all()
                 sensible = nxt_layer.nclusters < len(nxt.u) and sizes.max() >= nxt.u.shape[1]
                 shrinks = need_accept or nxt.estimate_volume() <= self.region.estimate_volume()

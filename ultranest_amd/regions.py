@@ -16,10 +16,12 @@ What runs where:
   host  d x d LAPACK (cov inverse, eigh), random draws (the reference's ``np.random`` call
         order is preserved so seeded runs follow the same trajectory)
 """
+import weakref
+
 import numpy as np
 
 from . import _lib, kernels
-from .layers import int_dtype, single_blas_thread
+from .layers import host_worker, int_dtype, single_blas_thread
 
 # When True, ``MLFriends.inside`` transforms ellipsoid-passing points on the host with the same
 # ``np.dot`` the reference uses (bit-identical t-space points on the same machine) and only the
@@ -80,6 +82,9 @@ def bounding_ellipsoid(x, minvol=0.):
     if minvol > 0:
         cov = make_eigvals_positive(cov, minvol)
     return ctr, cov
+
+
+_ELLIPSOID_JOBS = weakref.WeakKeyDictionary()      # region -> (future of ellipsoid_parts, minvol, write count of region.u)
 
 
 def _principal_axes(precision, cov):
@@ -554,20 +559,42 @@ class MLFriends(_LivePoints):
     @staticmethod
     def ellipsoid_parts(u, minvol=0.0, errstate=None):
         """What `create_ellipsoid` derives from the live points ALONE (centre, inflated covariance, its inverse, the axes):
-        the numpy / LAPACK calls of reference :1213-1237 in their order.  A rebuild may run this on a worker thread while
-        the GPU bootstraps the radius (harness.RegionUpdater); `errstate` = the caller's ``np.geterr()``, which numpy keeps
-        per thread."""
+        the numpy / LAPACK calls of reference :1213-1237 in their order.  `_start_ellipsoid_parts` runs this on the worker
+        thread while the GPU bootstraps the radius; `errstate` = the caller's ``np.geterr()``, which numpy keeps per
+        thread."""
         with np.errstate(**(errstate or np.geterr())):
             ctr, cov = bounding_ellipsoid(u, minvol=minvol)
             precision = np.linalg.inv(cov)
             return ctr, cov, precision, _principal_axes(precision, cov)
 
+    def _write_count(self):
+        cell = self.__dict__.get("_u_cell")
+        return (id(self.__dict__.get("_u")), cell[0] if cell is not None else None)
+
+    def _start_ellipsoid_parts(self, minvol):
+        """Every caller of the bootstrap (the reference's driver, `integrator.py:375-415` then `:2098`; the harness) calls
+        `create_ellipsoid` next, and that call's numpy / LAPACK work -- `cov`, `inv`, two `eigh`: 0.7 ms at N = 4000,
+        d = 50 -- depends on the live points alone.  It starts here, on the worker thread, while the calling thread waits
+        for the GPU's bootstrap passes inside the C-ABI calls; `create_ellipsoid` takes the result if the live points
+        have not been written to since and `minvol` is the same.  Same calls, same inputs, same results."""
+        if type(self).ellipsoid_parts is not MLFriends.ellipsoid_parts:
+            return
+        stamp = self._write_count()
+        started = _ELLIPSOID_JOBS.get(self)
+        if started is not None and started[1] == minvol and started[2] == stamp:
+            return      # on its way already
+        job = host_worker().submit(self.ellipsoid_parts, self.u, minvol, np.geterr())
+        _ELLIPSOID_JOBS[self] = (job, minvol, stamp)
+
     @single_blas_thread
-    def create_ellipsoid(self, minvol=0.0, parts=None):
-        """Wrapping ellipsoid of all live points and its principal axes (reference :1213-1237).  `parts`: the result of
-        `ellipsoid_parts(self.u, minvol)` if the caller has it already."""
+    def create_ellipsoid(self, minvol=0.0):
+        """Wrapping ellipsoid of all live points and its principal axes (reference :1213-1237)."""
         assert self.enlarge is not None
-        ctr, cov, precision, axes = parts if parts is not None else self.ellipsoid_parts(self.u, minvol)
+        started = _ELLIPSOID_JOBS.pop(self, None)
+        if started is not None and started[1] == minvol and started[2] == self._write_count():
+            ctr, cov, precision, axes = started[0].result()      # raises here what the calls raised there
+        else:
+            ctr, cov, precision, axes = self.ellipsoid_parts(self.u, minvol)
         self.ellipsoid_center = ctr
         self.ellipsoid_invcov = precision
         self.ellipsoid_cov = cov
@@ -593,6 +620,7 @@ class MLFriends(_LivePoints):
         """(maxradiussq, enlarge) from `nbootstraps` leave-out rounds (reference :1017-1070).
         Rounds that select all or no points contribute nothing (:1048)."""
         assert np.isfinite(self.unormed).all(), self.unormed
+        self._start_ellipsoid_parts(minvol)
         masks = _draw_selection(rng, len(self.u), nbootstraps)
         maxd, maxf = self.enlargement_from_masks(masks, minvol=minvol)
         assert maxd > 0, (maxd, self.u, self.unormed)
@@ -606,6 +634,7 @@ class MLFriends(_LivePoints):
         maxd, maxf = 0.0, 0.0
         if len(masks) == 0:
             return maxd, maxf
+        self._start_ellipsoid_parts(minvol)      # host LAPACK of the create_ellipsoid that follows, behind the GPU passes below
         r2, skipped = kernels.maxradiussq_bootstrap(self.unormed, masks)
         use = ~skipped
         if use.any():
