@@ -360,3 +360,75 @@ def test_ellipsoids_contain_their_points(backend):
         moved[:, 0] += 1                             # off the constant coordinate: outside
         if umax == 0.5:
             assert not tregion.inside(moved).any()
+
+
+def test_ellipsoid_started_by_the_bootstrap_is_the_one_create_ellipsoid_computes(backend):
+    """The bootstrap starts `create_ellipsoid`'s host LAPACK on the worker thread (regions.MLFriends._start_ellipsoid_parts);
+    `create_ellipsoid` takes that result only for the SAME live points and the same `minvol` -- in every case the
+    attributes are those of a region that computes them on the spot (reference mlfriends.pyx:1213-1237)."""
+    import ultranest_amd.mlfriends as M
+    from ultranest_amd import regions as R
+    rs = np.random.RandomState(3)
+    u = 0.5 + 0.05 * rs.normal(size=(300, 4))
+    layer = M.AffineLayer()
+    layer.optimize(u, u)
+
+    def attributes(region):
+        return [np.array(getattr(region, k)) for k in ("ellipsoid_center", "ellipsoid_cov", "ellipsoid_invcov", "ellipsoid_axlens",
+                                                      "ellipsoid_axes", "ellipsoid_axes_T", "ellipsoid_inv_axlens", "ellipsoid_inv_axes")]
+
+    def on_the_spot(points, minvol):
+        other = M.MLFriends(np.array(points), layer)
+        other.enlarge = 1.0
+        other.create_ellipsoid(minvol=minvol)       # nothing was started for this region
+        assert other not in R._ELLIPSOID_JOBS
+        return attributes(other)
+
+    region = M.MLFriends(u, layer)
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=5, rng=np.random.RandomState(1))
+    assert region in R._ELLIPSOID_JOBS                          # on its way (or done)
+    region.create_ellipsoid()
+    assert region not in R._ELLIPSOID_JOBS
+    assert all(np.array_equal(a, b) for a, b in zip(attributes(region), on_the_spot(u, 0.0)))
+    # live points written to between the bootstrap and the ellipsoid: the started result is not taken
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=5, rng=np.random.RandomState(1))
+    region.u[7] = np.clip(region.u[7] + 0.01, 1e-6, 1 - 1e-6)
+    region.create_ellipsoid()
+    assert all(np.array_equal(a, b) for a, b in zip(attributes(region), on_the_spot(region.u, 0.0)))
+    # another minvol than the bootstrap's: computed again
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=5, minvol=0.0, rng=np.random.RandomState(1))
+    region.create_ellipsoid(minvol=1e-3)
+    assert all(np.array_equal(a, b) for a, b in zip(attributes(region), on_the_spot(region.u, 1e-3)))
+    # an error of the LAPACK calls surfaces in create_ellipsoid, as it would without the worker
+    flat = np.array(u)
+    flat[:, 0] = 0.25
+    bad = M.MLFriends(flat, layer)
+    bad.enlarge = 1.0
+    bad._start_ellipsoid_parts(0.0)
+    with np.errstate(all="raise"):
+        with pytest.raises((np.linalg.LinAlgError, FloatingPointError)):
+            bad.create_ellipsoid()
+
+
+def test_host_worker_is_per_process():
+    """a forked child must not inherit the parent's worker (its thread does not exist there: a job would never run)"""
+    import os
+    from ultranest_amd import layers
+    parent = layers.host_worker()
+    assert parent.submit(os.getpid).result() == os.getpid()
+    if not hasattr(os, "fork"):
+        return
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:      # child: a job submitted here must run
+        ok = b"0"
+        try:
+            child = layers.host_worker()
+            if child is not parent and child.submit(lambda: 41 + 1).result(timeout=20) == 42:
+                ok = b"1"
+        finally:
+            os.write(w, ok)
+            os._exit(0)
+    os.close(w)
+    assert os.read(r, 1) == b"1"
+    os.waitpid(pid, 0)

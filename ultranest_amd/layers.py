@@ -48,17 +48,19 @@ def single_blas_thread(fn):
     return wrapper
 
 
-_HOST_WORKER = None
+_HOST_WORKER = (None, None)      # (executor, pid of the process that created it)
 
 
 def host_worker():
     """The one worker thread that takes host numpy / LAPACK work while the calling thread waits for the GPU inside a
-    C-ABI call (ctypes releases the interpreter lock there)."""
+    C-ABI call (ctypes releases the interpreter lock there).  A forked child starts its own: the parent's thread does not
+    exist there, and an executor that still counts it would never run a job."""
     global _HOST_WORKER
-    if _HOST_WORKER is None:
+    import os
+    if _HOST_WORKER[0] is None or _HOST_WORKER[1] != os.getpid():
         from concurrent.futures import ThreadPoolExecutor
-        _HOST_WORKER = ThreadPoolExecutor(max_workers=1)
-    return _HOST_WORKER
+        _HOST_WORKER = (ThreadPoolExecutor(max_workers=1), os.getpid())
+    return _HOST_WORKER[0]
 
 
 def _call_with_errstate(errstate, fn, *args):
