@@ -126,3 +126,26 @@ def test_static_nested_sampler_writes_reference_result_files(backend, tmp_path):
     assert summary["niter"] == s.results["niter"] and abs(summary["logz"] - res["logz_tree"]) < 1e-12
     assert "insertion_order_MWW_test" in summary and "weighted_samples" not in summary
     assert open(os.path.join(info, "post_summary.csv")).readline().startswith('"x_mean","x_stdev"')
+
+
+# ---- callback contract helper and work split (reference tests/test_utils.py:9-24, 114-120) --------------------------
+def test_vectorize_gives_the_batch_form_of_a_one_point_function():
+    from ultranest_amd.utils import vectorize
+
+    def sum_of_squares(x):
+        return (x**2).sum()
+    batch = vectorize(sum_of_squares)
+    assert batch.__name__ == "sum_of_squares"
+    rows = np.array([[1.2, 2.3, 3.4], [0.0, 1.0, 2.0]])
+    np.testing.assert_allclose(batch(rows), [(r**2).sum() for r in rows])
+    assert batch(np.empty((0, 3))).shape == (0,)
+    assert vectorize(lambda u: 2 * u)(rows).shape == rows.shape          # a transform keeps its (n, d) shape
+
+
+@pytest.mark.parametrize("mpi_size", [1, 4, 10, 37, 53, 100, 1000, 513])
+@pytest.mark.parametrize("ntasks", [0, 1, 4, 10, 17, 31, 100, 1000, 513])
+def test_distributed_work_chunk_size_is_the_reference_formula(mpi_size, ntasks):
+    from ultranest_amd.utils import distributed_work_chunk_size
+    todo = [distributed_work_chunk_size(ntasks, rank, mpi_size) for rank in range(mpi_size)]
+    assert sum(todo) == ntasks and max(todo) - min(todo) in (0, 1)
+    assert todo == [(ntasks + mpi_size - 1 - rank) // mpi_size for rank in range(mpi_size)]      # reference utils.py:477

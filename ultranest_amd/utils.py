@@ -47,3 +47,24 @@ def resample_equal(samples, weights, rstate=None):
     picks = np.minimum(np.searchsorted(np.cumsum(weights), ladder, side='right'), n - 1).astype(np.int_)
     rstate.shuffle(picks)
     return samples[picks]
+
+
+def vectorize(function):
+    """The batch form of a one-point likelihood or prior transform: the callback contract of the vectorized driver
+    (reference ``utils.vectorize``, utils.py:133-142, applied by ``ReactiveNestedSampler`` when
+    ``vectorized=False``) takes an (n, ...) array and returns one result per row.  The wrapper keeps the wrapped
+    function's name where it has one."""
+    def over_rows(rows):
+        return np.asarray([function(row) for row in rows])
+
+    over_rows.__name__ = getattr(function, '__name__', over_rows.__name__)
+    return over_rows
+
+
+def distributed_work_chunk_size(num_total_tasks, mpi_rank, mpi_size):
+    """How many of `num_total_tasks` tasks process `mpi_rank` of `mpi_size` takes (reference utils.py:456-477; the driver
+    splits the initial live points with it, integrator.py:1528): the sizes of ``distributed.shard_bounds`` -- all ranks
+    within one task of each other, the low ranks first."""
+    from .distributed import shard_bounds
+    lo, hi = shard_bounds(num_total_tasks, mpi_rank, mpi_size)
+    return hi - lo
