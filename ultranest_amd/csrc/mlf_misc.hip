@@ -539,7 +539,8 @@ __global__ __launch_bounds__(64 * kCovWaves) void k_boot_cov(const double *__res
 // workgroup (8 waves) owns a whole 16-row block CK of the matrix for one round, the upper chunks c >= CK only (the lower
 // ones are the mirror image).  Per (k, l) the products of a wave's group are added in ascending list order; the four
 // groups, then the eight waves, in a fixed order: deterministic, tolerance class of the moments (1e-9 relative).
-// 30 rounds at N = 4000, d = 50: 0.076 -> see profiles (the v_readlane version read every selected row in 7 workgroups).
+// 30 rounds at N = 4000, d = 50: 0.076 -> 0.044 ms (the v_readlane version read every selected row in 7 workgroups; here
+// only 120 workgroups exist and block CK = 0 has four times the work of CK = 3).
 template <int NCH, int CK>
 __device__ __forceinline__ void cov_block(const double *__restrict__ u, int d, const int *__restrict__ list, int cnt,
                                           const double *__restrict__ mean_b, double *__restrict__ cov_b, double (*part)[16][4][16]) {
