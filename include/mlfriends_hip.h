@@ -102,6 +102,12 @@ int mlf_host_cluster_replay(const unsigned long long *adj, size_t n, const int64
  * no points (reference :1048 `continue`); maxd_out[b] = 0 then.  skipped_out may be NULL. */
 int mlf_maxradiussq_bootstrap(const double *pts, size_t n, size_t d, const uint8_t *selected,
                               size_t B, double *maxd_out, uint8_t *skipped_out);
+/* The same over the rows [row_lo, row_hi) as left-out points only (every live point i, all B rounds): one rank's share
+ * when the bootstrap of integrator.py:375-415 is sharded over W GPUs by ROW BLOCKS -- each rank computes 1/W of the pair
+ * distances, and the max over ranks of maxd_out[b] (an all-reduce MAX; narrowing to binary32 is monotone) is bit for bit
+ * what mlf_maxradiussq_bootstrap returns.  skipped_out[b] is the property of the round (all n rows), identical on all ranks. */
+int mlf_maxradiussq_bootstrap_rows(const double *pts, size_t n, size_t d, const uint8_t *selected, size_t B,
+                                   size_t row_lo, size_t row_hi, double *maxd_out, uint8_t *skipped_out);
 
 /* ---- K5: pair distances for compute_mean_pair_distance -- mlfriends.pyx:229-270 -------------
  * dist2_out is the packed strict lower triangle: entry j*(j-1)/2 + i for i < j.  The host

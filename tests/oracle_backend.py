@@ -23,8 +23,20 @@ def subtract_nearby(upoints, maxradiussq):
     return orc.subtract_nearby(upoints, maxradiussq)
 
 
-def maxradiussq_bootstrap(unormed, selected):
-    return orc.maxradiussq_bootstrap(unormed, selected)
+def maxradiussq_bootstrap(unormed, selected, rows=None):
+    if rows is None:
+        return orc.maxradiussq_bootstrap(unormed, selected)
+    # one rank's share under row-block sharding: the left-out points of rows [lo, hi) only
+    sel = np.asarray(selected, dtype=bool)
+    inrange = np.zeros(sel.shape[1], dtype=bool)
+    inrange[int(rows[0]):int(rows[1])] = True
+    r2 = np.zeros(len(sel))
+    skipped = sel.all(axis=1) | ~sel.any(axis=1)
+    for b, m in enumerate(sel):
+        out = ~m & inrange
+        if not skipped[b] and out.any():
+            r2[b] = orc.maxradiussq(unormed[m], unormed[out])
+    return r2, skipped
 
 
 def compute_mean_pair_distance(pts, clusterids):

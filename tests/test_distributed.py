@@ -31,6 +31,29 @@ def test_shard_bounds_cover_exactly():
     assert [shard_bounds(30, r, 8) for r in range(8)] == [(0, 4), (4, 8), (8, 12), (12, 16), (16, 20), (20, 24), (24, 27), (27, 30)]
 
 
+@pytest.mark.parametrize("n,W", [(300, 2), (300, 3), (131, 8), (64, 4), (1000, 8)])
+def test_row_block_shares_combine_to_the_full_bootstrap(n, W, monkeypatch):
+    """MLFriends.enlargement_share: radius by 64-row blocks (all rounds), factor by rounds; the element-wise maximum over
+    the ranks' shares (the all-reduce of C1) equals enlargement_from_masks on all rounds, bit for bit -- also when a rank's
+    block range is empty (more ranks than blocks) or a round is skipped."""
+    import oracle_backend
+    oracle_backend.install(monkeypatch)
+    import ultranest_amd.mlfriends as M
+    from ultranest_amd import regions
+    u = inputs.live_points(77 + n, n, 4)
+    layer = M.AffineLayer()
+    layer.optimize(u, u)
+    region = M.MLFriends(u, layer)
+    masks = regions._draw_selection(np.random.RandomState(n), n, 30)
+    masks[7] = True      # skipped round (reference :1048)
+    r1, f1 = region.enlargement_from_masks(masks)
+    shares = [region.enlargement_share(masks, r, W) for r in range(W)]
+    assert max(s[0] for s in shares) == r1
+    assert max(s[1] for s in shares) == f1
+    if n <= 64 * (W - 1):                   # fewer row blocks than ranks: the surplus ranks contribute the neutral 0
+        assert min(s[0] for s in shares) == 0.0
+
+
 def _free_port():
     """rendezvous token for the spawned ranks: a fresh temporary FILE (file:// store) -- a port found free here could be
     taken by the time the ranks bind it (seen once in a few hundred runs: EADDRINUSE)"""
@@ -208,18 +231,20 @@ def _one_rank_fails_worker(rank, world_size, port, out, exc_name="FloatingPointE
         layer = M.AffineLayer()
         layer.optimize(u, u)
         region = M.MLFriends(u, layer)
-        good = region.enlargement_from_masks
+        good = region.enlargement_share
 
-        def shard(masks, minvol=0.):
+        def shard(masks, rank_, size_, minvol=0.):
             if rank == 1:
                 raise exc("invalid value encountered in this rank's shard")
-            return good(masks, minvol=minvol)
-        region.enlargement_from_masks = shard
+            return good(masks, rank_, size_, minvol=minvol)
+        region.enlargement_share = shard
         try:
             distributed.update_region_bootstrap(region, 30, minvol=0., rng=np.random.RandomState(3))
             out[rank] = "no error"
         except np.linalg.LinAlgError:
             out[rank] = "LinAlgError"
+        except RuntimeError:
+            out[rank] = "RuntimeError"
         # the wrapping ellipsoid of the harness: same hazard, same cure
         upd = RegionUpdater(4)
         np.random.seed(5)
@@ -231,8 +256,11 @@ def _one_rank_fails_worker(rank, world_size, port, out, exc_name="FloatingPointE
             return real(self, masks)
         import ultranest_amd.harness as H
         H.WrappingEllipsoid.enlargement_from_masks = tshard
-        upd.update(u, nbootstraps=10, active_p=u * 3.0)
-        out[10 + rank] = upd.tregion is None
+        try:
+            upd.update(u, nbootstraps=10, active_p=u * 3.0)
+            out[10 + rank] = upd.tregion is None
+        except RuntimeError:
+            out[10 + rank] = "RuntimeError"
         t = distributed.allreduce_max([float(rank)])       # the group is still in step
         out[20 + rank] = float(t[0])
     finally:
@@ -247,8 +275,14 @@ def test_failure_on_one_rank_only_keeps_the_group_in_step(exc_name):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_one_rank_fails_worker, args=(2, _free_port(), out, exc_name), nprocs=2, join=True)
-    assert out[0] == "LinAlgError" and out[1] == "LinAlgError", dict(out)
-    assert out[10] is True and out[11] is True, dict(out)
+    # a NUMERICAL failure comes back as LinAlgError on every rank (the caller keeps its old region, integrator.py:385-411);
+    # anything else as RuntimeError on every rank -- it must not be swallowed by that handler
+    if exc_name == "FloatingPointError":
+        assert out[0] == "LinAlgError" and out[1] == "LinAlgError", dict(out)
+        assert out[10] is True and out[11] is True, dict(out)
+    else:
+        assert out[0] == "RuntimeError" and out[1] == "RuntimeError", dict(out)
+        assert out[10] == "RuntimeError" and out[11] == "RuntimeError", dict(out)
     assert out[20] == 1.0 and out[21] == 1.0, dict(out)
 
 

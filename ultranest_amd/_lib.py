@@ -38,6 +38,7 @@ SIGNATURES = {
     "mlf_region_set_option": [_vp, ctypes.c_char_p, ctypes.c_longlong, ctypes.c_int],
     "mlf_option_name": [ctypes.c_int, _vp, _sz],
     "mlf_maxradiussq_bootstrap": [_vp, _sz, _sz, _vp, _sz, _vp, _vp],
+    "mlf_maxradiussq_bootstrap_rows": [_vp, _sz, _sz, _vp, _sz, _sz, _sz, _vp, _vp],
     "mlf_pair_dist2_lower": [_vp, _sz, _sz, _vp],
     "mlf_inside_ellipsoid": [_vp, _sz, _sz, _vp, _vp, _dbl, _vp, _vp],
     "mlf_affine_transform": [_vp, _sz, _sz, _vp, _vp, _vp, _vp],

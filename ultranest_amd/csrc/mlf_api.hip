@@ -214,10 +214,14 @@ int arena_flush(hipStream_t s) {
   return 0;
 }
 
+bool is_device_pointer(const void *p);
+
 int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t s) {
   CK(b.reserve(bytes ? bytes : 1));
   if (!bytes) return 0;
-  if (g_arena && bytes <= kArenaMaxPiece) {
+  // the arena branch reads `src` with a host memcpy: never for a device pointer (mlf_region_set accepts the live points
+  // from either side; VRAM is host-readable only on large-BAR boxes)
+  if (g_arena && bytes <= kArenaMaxPiece && !is_device_pointer(src)) {
     if (void *stage = g_arena->take(bytes)) {
       memcpy(stage, src, bytes);
       if (g_arena->npending == kScatterMax)
@@ -1325,9 +1329,18 @@ int mlf_cluster_labels(const double *tpts, size_t n, size_t d, double radiussq, 
 // ------------------------------------------------------------------------------ K4 ---------
 int mlf_maxradiussq_bootstrap(const double *pts, size_t n, size_t d, const uint8_t *selected,
                               size_t B, double *maxd_out, uint8_t *skipped_out) {
+  return mlf_maxradiussq_bootstrap_rows(pts, n, d, selected, B, 0, n, maxd_out, skipped_out);
+}
+
+// One rank's share of K4 under ROW-BLOCK sharding: all B rounds, every live point i, but only the rows j in
+// [row_lo, row_hi) as the left-out point -- the rank does 1/W of the pair distances (sharding by rounds would repeat all
+// of them on every rank: k_boot computes a distance once for all 32 rounds of a pass).
+int mlf_maxradiussq_bootstrap_rows(const double *pts, size_t n, size_t d, const uint8_t *selected, size_t B,
+                                   size_t row_lo, size_t row_hi, double *maxd_out, uint8_t *skipped_out) {
   if (int rc = check_dims(d)) return rc;
   if (B == 0) return 0;
   if (!pts || !selected || !maxd_out || n == 0) return fail_arg(MLF_E_BADARG, "null pointer or no points");
+  if (row_lo > row_hi || row_hi > n) return fail_arg(MLF_E_BADARG, "row range outside [0, n]");
   if (int rc = ensure_ctx()) return rc;
   Ctx &c = g_ctx;
   const int dp = pick_dp((int)d);
@@ -1341,8 +1354,12 @@ int mlf_maxradiussq_bootstrap(const double *pts, size_t n, size_t d, const uint8
   CK(c.small1.reserve(B));
   // live-point chunks: one round of the 2048 waves the chip holds at two per SIMD (k_boot's register budget), equal shares
   // (a wave pays ~1 us of set-up for its own 64 rows: no chunk below 8 live points)
-  const int rowblocks = npad / kWave;
-  int want_chunks = 2048 / rowblocks;
+  const int blk0 = (int)(row_lo / kWave);
+  const int rowblocks = row_hi > row_lo ? (int)((row_hi + kWave - 1) / kWave) - blk0 : 0;
+  // a rank's share of a sharded pass is short: one wave per SIMD runs this kernel as fast as two, and half the
+  // waves means half the atomicMin traffic on M, which does not shrink with the shard
+  const int target_waves = 2 * rowblocks <= npad / kWave ? 1024 : 2048;
+  int want_chunks = rowblocks ? target_waves / rowblocks : 1;
   if (want_chunks < 1) want_chunks = 1;
   int chunk = ((int)n + want_chunks - 1) / want_chunks;
   if (chunk < 8) chunk = 8;
@@ -1364,9 +1381,10 @@ int mlf_maxradiussq_bootstrap(const double *pts, size_t n, size_t d, const uint8
     a.npad = npad;
     a.chunk = chunk;
     a.M = c.M.as<unsigned long long>();
-    CK(launch_boot(dp, a, nchunks, c.stream));
+    a.blk0 = blk0;
+    CK(launch_boot(dp, a, nchunks, c.stream, rowblocks));
     launch_boot_final(c.M.as<unsigned long long>(), c.sel.as<unsigned>(), (int)n, npad, nb,
-                      c.small0.as<double>() + b0, c.small1.as<uint8_t>() + b0, c.stream);
+                      c.small0.as<double>() + b0, c.small1.as<uint8_t>() + b0, c.stream, (int)row_lo, (int)row_hi);
     CK(hipGetLastError());
   }
   CK(hipMemcpyAsync(maxd_out, c.small0.p, B * sizeof(double), hipMemcpyDeviceToHost, c.stream));

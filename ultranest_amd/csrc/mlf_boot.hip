@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(DP <= 64 
   constexpr int NCH = (DP + 15) / 16;
   const int lane = threadIdx.x;
   const int sub = lane & 15;
-  const int j = blockIdx.x * kWave + lane;  // < npad by construction of the grid
+  const int j = (blockIdx.x + a.blk0) * kWave + lane;  // < npad by construction of the grid
   double b[DP];
 #pragma unroll
   for (int k = 0; k < DP; ++k) b[k] = a.refT[(size_t)k * a.npad + j];
@@ -139,8 +139,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(DP <= 64 
   }
 }
 
-hipError_t launch_boot(int dp, const BootArgs &a, int nchunks, hipStream_t s) {
-  const dim3 grid((unsigned)(a.npad / kWave), (unsigned)nchunks);
+hipError_t launch_boot(int dp, const BootArgs &a, int nchunks, hipStream_t s, int nblocks) {
+  // nblocks 64-row blocks starting at a.blk0 (default: all of them)
+  const dim3 grid((unsigned)(nblocks >= 0 ? nblocks : a.npad / kWave), (unsigned)nchunks);
+  if (grid.x == 0) return hipSuccess;
   switch (dp) {
 #define X(D)                                                        \
   case D:                                                           \

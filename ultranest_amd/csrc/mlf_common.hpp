@@ -91,6 +91,7 @@ struct BootArgs {
   int n, npad;
   int chunk;            // live points per blockIdx.y
   unsigned long long *M;  // [kBootGroup][npad] running minima as ordered bit patterns
+  int blk0;             // first 64-row block of the launch (row-block sharding over ranks: blockIdx.x + blk0)
 };
 
 struct PrepArgs {
@@ -124,7 +125,7 @@ struct QuadMaxArgs {
 int pick_dp(int d);
 
 hipError_t launch_scan(int dp, const ScanArgs &a, hipStream_t s);
-hipError_t launch_boot(int dp, const BootArgs &a, int nchunks, hipStream_t s);
+hipError_t launch_boot(int dp, const BootArgs &a, int nchunks, hipStream_t s, int nblocks = -1);
 hipError_t launch_prep(int dp, const PrepArgs &a, hipStream_t s);
 hipError_t launch_whiten_rows(const double *pts, long long n, int d, int dp, const double *lay_ctr, const double *T8, int ldt8,
                               const double *wrap_shift, double *t_out, long long ldt, hipStream_t s);

@@ -90,9 +90,11 @@ void launch_pack_selection(const uint8_t *selected, int n, int npad, int b0, int
 // ------------------------------------------------------- K4 epilogue ---------------------
 // maxd[r] = (double)(float) max over unselected j of M[r][j]   (reference :222-224: the
 // `cdef float` return narrows to binary32, round-to-nearest-even = v_cvt_f32_f64)
+// Row-block sharding (one rank of several): the maximum runs over the rows [row_lo, row_hi) only; `skipped` still looks at
+// all n rows (it is a property of the round).  Narrowing is monotone, so max over ranks of these = the one-rank value.
 __global__ __launch_bounds__(256) void k_boot_final(const unsigned long long *M, const unsigned *sel,
                                                     int n, int npad, double *maxd,
-                                                    uint8_t *skipped) {
+                                                    uint8_t *skipped, int row_lo, int row_hi) {
   __shared__ unsigned long long smax[256];
   __shared__ int scnt[256];
   const int r = blockIdx.x;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void k_boot_final(const unsigned long long *M,
   for (int j = threadIdx.x; j < n; j += 256) {
     if ((sel[j] >> r) & 1u) {
       ++nsel;
-    } else {
+    } else if (j >= row_lo && j < row_hi) {
       const unsigned long long v = M[(long long)r * npad + j];
       best = v > best ? v : best;
     }
@@ -126,8 +128,9 @@ __global__ __launch_bounds__(256) void k_boot_final(const unsigned long long *M,
 }
 
 void launch_boot_final(const unsigned long long *M, const unsigned *sel, int n, int npad, int nb,
-                       double *maxd, uint8_t *skipped, hipStream_t s) {
-  hipLaunchKernelGGL(k_boot_final, dim3(nb), dim3(256), 0, s, M, sel, n, npad, maxd, skipped);
+                       double *maxd, uint8_t *skipped, hipStream_t s, int row_lo, int row_hi) {
+  if (row_hi < 0) row_hi = n;
+  hipLaunchKernelGGL(k_boot_final, dim3(nb), dim3(256), 0, s, M, sel, n, npad, maxd, skipped, row_lo, row_hi);
 }
 
 // ------------------------------------------------------- constants of a region, one launch ---

@@ -21,7 +21,7 @@ void launch_fill_u64(unsigned long long *p, long long n, unsigned long long v, h
 void launch_pack_selection(const uint8_t *selected, int n, int npad, int b0, int nb, unsigned *sel,
                            hipStream_t s, unsigned *selmask = nullptr);
 void launch_boot_final(const unsigned long long *M, const unsigned *sel, int n, int npad, int nb,
-                       double *maxd, uint8_t *skipped, hipStream_t s);
+                       double *maxd, uint8_t *skipped, hipStream_t s, int row_lo = 0, int row_hi = -1);
 void launch_subtract_accum(const double *pts, int n, int d, const unsigned long long *flags,
                            int ntiles, double *out, hipStream_t s);
 void launch_pair_dist2_lower(const double *pts, int n, int d, double *out, hipStream_t s);

@@ -37,7 +37,9 @@ namespace mlf {
 // answers in plain device memory, at the price of an L2 write-back per workgroup across the 8 XCDs.)
 __device__ __forceinline__ bool finish_point(const SmallArgs &a) {
   if (a.np == 1) return true;
-  return __hip_atomic_fetch_add(a.finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.np - 1u;
+  // release: this workgroup's state word is visible before the count moves; acquire: the workgroup that completes the
+  // count sees every other workgroup's state word (a relaxed count left the two updates unordered)
+  return __hip_atomic_fetch_add(a.finished, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.np - 1u;
 }
 
 // LDS: d x (d|1) doubles per matrix when STAGE (d <= 64): rows of L^T, then the layer matrix; all loads of a call --
@@ -161,8 +163,9 @@ __global__ __launch_bounds__(256) void k_inside_small(SmallArgs a) {
   bool publish = false;   // thread 0: this workgroup completed the last proposal of the call
   if (!a.use_scan) {
     if (part == 0 && tid == 0) {
-      (void)atomicAdd(a.state + p, (inside ? 0x10000u : 0u) + 1u);   // returned (waited for) before the count below moves
-      publish = finish_point(a);
+      // the returned value is consumed, so the update is a returning atomic that has completed before the count moves
+      const unsigned old = __hip_atomic_fetch_add(a.state + p, (inside ? 0x10000u : 0u) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      publish = (old & 0xffffu) == 0u && finish_point(a);
     }
   } else {
 

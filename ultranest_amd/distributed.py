@@ -31,6 +31,15 @@ from . import regions
 # per rank, exchanged as a flag and re-raised on every rank after the all-reduce: a rank that skipped the collective
 # would leave the other ranks blocked in it.
 SHARD_ERRORS = (Exception,)
+# what a shard's failure means for the caller: numerical failures (the set the driver's own try/except keeps the old region
+# on, integrator.py:2066-2122) travel as class 1, everything else as class 2 and comes back as a RuntimeError on every rank
+NUMERICAL_ERRORS = (np.linalg.LinAlgError, FloatingPointError, AssertionError, Warning, ZeroDivisionError)
+
+
+def _error_class(error):
+    if error is None:
+        return 0.0
+    return 1.0 if isinstance(error, NUMERICAL_ERRORS) else 2.0
 
 
 def _dist():
@@ -133,16 +142,25 @@ def sharded_enlargement(region, nbootstraps, minvol=0., rng=np.random, group=Non
     error = None
     r = f = 0.0
     try:
-        out = region.enlargement_from_masks(masks[lo:hi], minvol=minvol) if hi > lo else (0.0, 0.0)
+        share = getattr(region, "enlargement_share", None)
+        if share is not None and size > 1:
+            # MLFriends: the radius by ROW BLOCKS (all rounds, 1/size of the pair distances), the factor by rounds
+            out = share(masks, rank, size, minvol=minvol)
+        else:
+            out = region.enlargement_from_masks(masks[lo:hi], minvol=minvol) if hi > lo else (0.0, 0.0)
         r, f = out if isinstance(out, tuple) else (0.0, out)
     except SHARD_ERRORS as e:     # whatever happens in this rank's shard, the rank still takes part in the collective
         error = e
-    r, f, flag = allreduce_max([r, f, 0.0 if error is None else 1.0], group=group)
+    r, f, flag = allreduce_max([r, f, _error_class(error)], group=group)
     if flag > 0:
-        # the same exception type on every rank (the ranks must take the same branch in the caller); a failure in a
-        # single-process run keeps its own type
+        # a failure in a single-process run keeps its own type
         if size == 1 and error is not None:
             raise error
+        # the same exception type on every rank (the ranks must take the same branch in the caller).  Class 1 = a
+        # NUMERICAL failure somewhere (the caller keeps its old region, as the reference does: integrator.py:385-411);
+        # class 2 = anything else -- a device error, out of memory, a plain bug -- must not be swallowed by that handler
+        if flag >= 2:
+            raise RuntimeError("a rank of the group failed in its bootstrap shard (not a numerical error)") from error
         raise np.linalg.LinAlgError("compute_enlargement failed on rank(s) of the group") from error
     return float(r), float(f)
 

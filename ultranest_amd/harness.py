@@ -5,6 +5,8 @@ proposal batch through the vectorized-likelihood callbacks (`_refill_samples` :1
 B).  Control flow only; every numerical stage is a call into ultranest_amd.mlfriends /
 ultranest_amd.distributed.  The reference's own driver can be used instead, unmodified, by
 passing these classes through its plug points."""
+import gc
+
 import numpy as np
 
 from . import distributed
@@ -16,9 +18,18 @@ class RegionUpdater(object):
     """Holds (region, transformLayer, tregion) like the driver does and rebuilds them from the
     current live points."""
 
+    _gc_frozen = False
+
     def __init__(self, x_dim, region_class=MLFriends, transform_layer_class=LocalAffineLayer,
-                 wrapped_axes=(), group=None, build_tregion=True, device_resident=False):
+                 wrapped_axes=(), group=None, build_tregion=True, device_resident=False, freeze_gc=True):
         self.x_dim = x_dim
+        # The objects the imports leave behind (~170000) make CPython's first generation-2 collector pass cost 37-42 ms,
+        # somewhere in the first ~40 rebuilds (scripts/rebuild_rounds.py).  Moving what exists NOW into the permanent
+        # generation keeps that pass out of the rebuild loop; `freeze_gc=False` leaves the collector alone.
+        if freeze_gc and not RegionUpdater._gc_frozen:
+            gc.collect()
+            gc.freeze()
+            RegionUpdater._gc_frozen = True
         self.region_class = region_class
         self.transform_layer_class = transform_layer_class
         self.wrapped_axes = list(wrapped_axes)
@@ -123,11 +134,13 @@ class RegionUpdater(object):
                     try:      # the shard may fail on ONE rank only: every rank still joins the all-reduce
                         f = tregion.enlargement_from_masks(masks[lo:hi]) if hi > lo else 0.0
                     except distributed.SHARD_ERRORS as e:
-                        failed, err = 1.0, e
+                        failed, err = distributed._error_class(e), e
                     f, failed = distributed.allreduce_max([f, failed], group=self.group)
                     if failed > 0:
                         if size == 1 and err is not None:
                             raise err     # a single process keeps the exception's own type, as the reference does
+                        if failed >= 2:   # not a numerical failure: do not let the handler below swallow it
+                            raise RuntimeError("tregion bootstrap: a rank failed (not a numerical error)") from err
                         raise np.linalg.LinAlgError("tregion bootstrap failed on a rank") from err
                     tregion.enlarge = float(f)
                     tregion.create_ellipsoid()

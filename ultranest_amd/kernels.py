@@ -51,18 +51,24 @@ def subtract_nearby(upoints, maxradiussq):
     return out
 
 
-def maxradiussq_bootstrap(unormed, selected):
+def maxradiussq_bootstrap(unormed, selected, rows=None):
     """Per-bootstrap ``compute_maxradiussq(unormed[sel], unormed[~sel])`` (reference
     mlfriends.pyx:188-224, called at :1012 and :1052) for a (B, N) boolean selection matrix.
 
-    Returns (r2[B] -- already float32-rounded like the reference's ``cdef float`` --, skipped[B])."""
+    Returns (r2[B] -- already float32-rounded like the reference's ``cdef float`` --, skipped[B]).
+    ``rows=(lo, hi)``: only the rows lo <= j < hi count as left-out points (one rank's share of a bootstrap sharded by
+    row blocks, ``mlf_maxradiussq_bootstrap_rows``); the maximum over the shares is the full result, bit for bit."""
     pts = f64(unormed)
     sel_ptr, B, n, _keep = _mask_arg(selected)
     if n != pts.shape[0]:
         raise ValueError("selection mask length != number of points")
     r2 = np.empty(B, dtype=np.float64)
     skipped = np.empty(B, dtype=np.uint8)
-    check(_lib.lib().mlf_maxradiussq_bootstrap(ptr(pts), n, pts.shape[1], sel_ptr, B, ptr(r2), ptr(skipped)))
+    if rows is None:
+        check(_lib.lib().mlf_maxradiussq_bootstrap(ptr(pts), n, pts.shape[1], sel_ptr, B, ptr(r2), ptr(skipped)))
+    else:
+        lo, hi = int(rows[0]), int(rows[1])
+        check(_lib.lib().mlf_maxradiussq_bootstrap_rows(ptr(pts), n, pts.shape[1], sel_ptr, B, lo, hi, ptr(r2), ptr(skipped)))
     return r2, skipped.astype(bool)
 
 

@@ -116,6 +116,13 @@ def _draw_selection(rng, npoints, nbootstraps):
     return masks
 
 
+def _shard_bounds(nitems, rank, world_size):
+    """contiguous, balanced [lo, hi) slice (the same split as ``distributed.shard_bounds``)"""
+    base, extra = divmod(int(nitems), int(world_size))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
 def _select_rounds(masks, use):
     """rows `use` of the (B, N) selection matrix (numpy on the host or a torch tensor on the device)"""
     if use.all():
@@ -640,6 +647,37 @@ class MLFriends(_LivePoints):
         if use.any():
             maxd = float(r2[use].max())
             f = _bootstrap_enlargement(self.u, _select_rounds(masks, use), minvol)
+            assert np.isfinite(f).all(), (f, self.unormed)
+            if not (f > 0).all():
+                raise np.linalg.LinAlgError("Distances are not positive")
+            maxf = float(f.max())
+        return maxd, maxf
+
+    def enlargement_share(self, masks, rank, size, minvol=0.):
+        """Rank `rank`'s share of ``enlargement_from_masks(masks)`` in a group of `size` GPUs; the element-wise maximum of
+        the shares over the ranks is that call's result, bit for bit (max is exact and order independent, the binary32
+        narrowing of the radius monotone).
+
+        The RADIUS is sharded by ROW BLOCKS: every rank runs all rounds and every live point i, but only its own 64-row
+        blocks of left-out points j -- 1/size of the pair distances.  (Sharding the rounds divides nothing there: the
+        kernel computes a distance once for all 32 rounds of a pass, so a rank with 4 of 30 rounds would still do all of
+        them.)  The ellipsoid factor f is sharded by ROUNDS (moments, Cholesky factor and substitution are per round)."""
+        nrounds, npoints = len(masks), len(self.u)
+        if nrounds == 0:
+            return 0.0, 0.0
+        self._start_ellipsoid_parts(minvol)
+        nblocks = (npoints + 63) // 64
+        blo, bhi = _shard_bounds(nblocks, rank, size)
+        rows = (min(blo * 64, npoints), min(bhi * 64, npoints))
+        r2, skipped = kernels.maxradiussq_bootstrap(self.unormed, masks, rows=rows)
+        use = ~skipped
+        maxd = float(r2[use].max()) if use.any() else 0.0
+        lo, hi = _shard_bounds(nrounds, rank, size)
+        mine = np.zeros(nrounds, dtype=bool)
+        mine[lo:hi] = use[lo:hi]
+        maxf = 0.0
+        if mine.any():
+            f = _bootstrap_enlargement(self.u, _select_rounds(masks, mine), minvol)
             assert np.isfinite(f).all(), (f, self.unormed)
             if not (f > 0).all():
                 raise np.linalg.LinAlgError("Distances are not positive")
