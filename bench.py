@@ -138,7 +138,20 @@ def cpu_baseline(region, pts_host, u):
     orc.maxradiussq_bootstrap(region.unormed, masks)
     boot_ms = (time.perf_counter() - t0) * 1e3 / 3 * NBOOT
     parallel = cpu_baseline_parallel(region, sample, min(32, os.cpu_count() or 1))
+    # how the port's speed relates to the real Cython path: timed side by side in the dev container by
+    # tests/golden/make_golden.py, a fixture, not a measurement of this run
+    cython_over_port = None
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "META.json")) as fh:
+            tm = json.load(fh).get("timing", {})
+        cython_over_port = {k: round(v["cython_over_port"], 3) for k, v in tm.items()
+                            if isinstance(v, dict) and "cython_over_port" in v}
+        cython_over_port["note"] = ("time of the reference's Cython build / time of this port, same inputs, one core of the "
+                                    "dev container (tests/golden/META.json): > 1 = the port is faster, the baseline conservative")
+    except (OSError, ValueError):
+        pass
     return mask, dict(value=len(sample) / dt, unit="proposals/s", cores=1, kind="port", parallel=parallel,
+                      cython_over_port=cython_over_port,
                       sample="first %d proposals of the timed batch (%.1f s); oracle/mlfriends_oracle.c, gcc -O3 "
                              "-ffp-contract=off, 1 thread" % (len(sample), dt),
                       bootstrap30_ms=boot_ms, host_cores_available=os.cpu_count())

@@ -13,6 +13,14 @@ for p in (ROOT, GOLDEN):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # MLF_TEST_OPTIONS="name=value,name=value": process-wide tuning options for this run of the GPU suite (results never depend
+    # on them: that is what running the suite under a non-default routing checks)
+    spec = os.environ.get("MLF_TEST_OPTIONS", "")
+    if spec:
+        from ultranest_amd import _lib
+        for kv in spec.split(","):
+            name, value = kv.split("=")
+            _lib.set_option(name.strip(), int(value))
 
 
 @pytest.fixture(scope="session")

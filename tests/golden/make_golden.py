@@ -706,15 +706,90 @@ def g14(ref):
     save("g14_tree_dump", **out)
 
 
+def timing(ref):
+    """SURVEY 8(d) / BASELINE.md 3.2: how good a TIMING stand-in is the C restatement (oracle/) for the real Cython path?
+    Both on this container's CPU, one core, the 8(d) inputs (N = 4000, d = 50, seed 1), a bounded query sample.  Stored in
+    META.json as `timing`; bench.py quotes `cython_over_port` next to `cpu_baseline` (the port is what travels to the
+    GPU box)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import oracle as orc
+    rs = np.random.RandomState(1)
+    N, d, P = 4000, 50, 2000
+    u = 0.5 + 0.05 * rs.normal(size=(N, d))
+    layer = ref.AffineLayer()
+    layer.optimize(u, u)
+    region = ref.MLFriends(u, layer)
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=30, minvol=0., rng=np.random.RandomState(1))
+    region.create_ellipsoid()
+    z = rs.normal(size=(P, d))
+    z /= np.linalg.norm(z, axis=1)[:, None]
+    w = region.ellipsoid_center + (z * region.enlarge**0.5 * rs.uniform(size=(P, 1))**(1. / d)) @ region.ellipsoid_axes_T
+    tq = np.ascontiguousarray(layer.transform(w))
+    un = np.ascontiguousarray(region.unormed)
+
+    def best(f, reps=3):
+        t = 1e30
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            f()
+            t = min(t, time.perf_counter() - t0)
+        return t
+    out = {}
+    idx = np.empty(P, dtype=int)
+    for name, r2 in (("set_E_early_exit", region.maxradiussq), ("set_F_full_scan", 1e-300)):
+        t_ref = best(lambda: ref.find_nearby(un, tq, r2, idx))
+        want = idx.copy()
+        t_port = best(lambda: orc.find_nearby(un, tq, r2))
+        assert np.array_equal(orc.find_nearby(un, tq, r2), want)
+        out["find_nearby_" + name] = dict(cython_s=t_ref, port_s=t_port, cython_over_port=t_ref / t_port,
+                                          queries=P, cython_queries_per_s=P / t_ref, port_queries_per_s=P / t_port)
+    # K4 is a `cdef` function (mlfriends.pyx:188): reached through MLFriends.compute_maxradiussq (:996-1016), which draws
+    # the selection from np.random -- the port gets the same draws from a generator seeded alike
+    def ref_rounds():
+        np.random.seed(2)
+        return region.compute_maxradiussq(nbootstraps=3)
+
+    def port_rounds():
+        rs2 = np.random.RandomState(2)
+        m = 0.0
+        for _ in range(3):
+            mask = np.zeros(N, dtype=bool)
+            mask[rs2.randint(N, size=N)] = True
+            m = max(m, orc.maxradiussq(un[mask], un[~mask]))
+        return m
+    t_ref = best(ref_rounds, reps=2)
+    t_port = best(port_rounds, reps=2)
+    assert port_rounds() == ref_rounds()
+    out["compute_maxradiussq_3_rounds"] = dict(cython_s=t_ref, port_s=t_port, cython_over_port=t_ref / t_port)
+    t_ref = best(lambda: region.compute_enlargement(nbootstraps=30, minvol=0., rng=np.random.RandomState(3)), reps=1)
+    out["compute_enlargement_30_rounds_cython_s"] = t_ref
+    out["note"] = ("one core of the dev container; cython = the reference's mlfriends.pyx built -O3 (setup.py:21-25); "
+                   "port = oracle/mlfriends_oracle.c (-O3 -ffp-contract=off); a ratio > 1 means the port is FASTER, "
+                   "i.e. cpu_baseline.kind = 'port' overstates the reference's speed by that factor (conservative)")
+    import platform
+    out["cpu"] = platform.processor() or platform.machine()
+    print(json.dumps(out, indent=1))
+    return out
+
+
 GROUPS = dict(g14=g14, g13=g13, g12=g12, g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
 
 if __name__ == "__main__":
-    want = sys.argv[1:] or list(GROUPS)
+    want = sys.argv[1:] or (list(GROUPS) + ["timing"])
     ref = build_reference()
     meta = dict(numpy=np.__version__, reference="UltraNest 4.5.0 (/root/reference)",
                 generated=time.strftime("%Y-%m-%d"))
+    meta_path = os.path.join(HERE, "META.json")
+    if os.path.exists(meta_path):        # keep what this invocation does not regenerate (the timing block)
+        with open(meta_path) as f:
+            old_meta = json.load(f)
+        if "timing" in old_meta:
+            meta["timing"] = old_meta["timing"]
     for g in want:
         print(g)
-        GROUPS[g](ref)
-    with open(os.path.join(HERE, "META.json"), "w") as f:
+        if g == "timing":
+            meta["timing"] = timing(ref)
+        else:
+            GROUPS[g](ref)
+    with open(meta_path, "w") as f:
         json.dump(meta, f, indent=1)
