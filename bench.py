@@ -38,8 +38,9 @@ sys.path.insert(0, ROOT)
 N_LIVE, NDIM, NPROPOSALS, NBOOT = 4000, 50, 1000000, 30
 FP64_VALU_PEAK_TFLOPS = 39.3     # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz, one flop per non-fused v_*_f64
 F16_MFMA_PEAK_TFLOPS = 2500.0    # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
-PROBE_F16_MFMA_TFLOPS = 1580.0   # what v_mfma_f32_32x32x16_f16 sustains ALONE on this part (4 chains, operands in registers:
-# scripts/probes/mfma16_issue_probe.hip, profiles/r03_issue_probe.json): the clock under matrix load, not the issue slots, sets it
+PROBE_F16_MFMA_TFLOPS = 1620.0   # what v_mfma_f32_32x32x16_f16 sustains ALONE on this part on random binary16 operands (4 chains,
+# operands in registers, 2 waves per SIMD, pipe 98 % occupied, clock 1.59-1.60 GHz measured inside the kernel:
+# scripts/probes/sweep_src_probe.hip, profiles/r04_sweep_src_probe.json): the part's power limit, not the issue slots, sets it
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F16_FLOPS = 2 * 32 * 32 * 16   # one v_mfma_f32_32x32x16_f16
 CLOCK_SETTLE_STEPS = 100         # untimed steps in front of the W warm-up steps of a timed loop (see run_steps)
@@ -329,7 +330,7 @@ def main():
         assert bool((mask_exact == mask_filter).all().item()), "filter and exact scan disagree"
     # ---- per-stage breakdown (separate pass with stage events) ---------------------------------------------
     nsteps_b = max(3, args.steps // 2)
-    run_steps(nsteps_b, True)
+    stage_pass_s, _ = run_steps(nsteps_b, True)
     ncalls, ms_prep, ms_scan, ms_rest = handle.timing_collect()
     assert bool((mask == mask_filter).all().item())
 
@@ -502,33 +503,52 @@ def main():
         nlaunch, ms_kernels = filter_launches
         per_step = max(1, round(nlaunch / max(args.steps, 1)))
         ngroups1 = (NPROPOSALS + 31) // 32
-        tiles = [ntiles32 * (i + 1) // per_step - ntiles32 * i // per_step for i in range(per_step)]
-        groups = [ngroups1] + [stats["second_range_groups"]] * (per_step - 1)
-        mfma_per_launch = [g * t * ks for g, t in zip(groups, tiles)]
-        exec_flops = float(sum(mfma_per_launch)) * MFMA_F16_FLOPS
-        launch_ms = ms_kernels / max(nlaunch, 1)
         by_phase = [float(np.mean(launch_ms_list[i::per_step])) for i in range(per_step)] if len(launch_ms_list) else []
-        ach = (exec_flops / per_step) / (launch_ms * 1e-3) / 1e12
+        cut = ntiles32 * 50 // 100          # filter_first_range_pct = 50 (default)
+        if per_step == 3:
+            # min-only sweep (mlf_sweepmin.hip): first range over every group, second over the groups left, then the
+            # uncertain queries (sets of 4 groups) once more over all tiles
+            usets = -(-(-(-stats["uncertain_queries"] // 32)) // 4)
+            mfma_per_launch = [ngroups1 * cut * ks, stats["second_range_groups"] * (ntiles32 - cut) * ks, usets * 4 * ntiles32 * ks]
+            names = ["k_sweep_min<4, 4, 2> (first live-point range: running minima only; compacts the proposals without a certain hit, with their minima)",
+                     "k_sweep_min<4, 2, 1> (second range: two query groups per wave; compacts the proposals whose minimum ended in the band)",
+                     "k_sweep_list<4> (the uncertain proposals over all tiles: lists and re-checks their band pairs; carries the ellipsoid band)"]
+            dominant = 2            # launches of the dominant kernel (k_sweep_min)
+        else:
+            tiles = [ntiles32 * (i + 1) // per_step - ntiles32 * i // per_step for i in range(per_step)]
+            groups = [ngroups1] + [stats["second_range_groups"]] * (per_step - 1)
+            mfma_per_launch = [g * t * ks for g, t in zip(groups, tiles)]
+            names = ["k_sweep<4, 4, true, 2> (first live-point range, compacts the undecided proposals)",
+                     "k_sweep<4, 2, false, 1> (second range: two query groups per wave)"] if per_step == 2 else None
+            dominant = per_step
+        exec_flops = float(sum(mfma_per_launch[:dominant])) * MFMA_F16_FLOPS
+        launch_ms = float(sum(by_phase[:dominant])) / dominant if by_phase else ms_kernels / max(nlaunch, 1)
+        ach = (exec_flops / dominant) / (launch_ms * 1e-3) / 1e12
         allpairs = 2.0 * N_LIVE * NPROPOSALS * (NDIM + 6)
-        roofline = {"kernel": "k_sweep (mlf_sweep.hip: v_mfma_f32_32x32x16_f16 bound on the pair distances, mask mode; two launches per step)",
+        roofline = {"kernel": ("k_sweep_min (mlf_sweepmin.hip: v_mfma_f32_32x32x16_f16 bound on the pair distances, running minima "
+                               "only; two launches per step, the uncertain proposals go through k_sweep_list afterwards)") if per_step == 3 else
+                              "k_sweep (mlf_sweep.hip: v_mfma_f32_32x32x16_f16 bound on the pair distances, mask mode; two launches per step)",
                     "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / F16_MFMA_PEAK_TFLOPS, "ms_per_launch": launch_ms,
-                    "launches_per_step": per_step,
+                    "launches_per_step": per_step, "launches_of_the_dominant_kernel": dominant,
                     "ms_per_launch_by_phase": by_phase,
                     "executed_mfma_per_launch_by_phase": mfma_per_launch,
-                    "executed_flops_per_launch": exec_flops / per_step,
+                    "executed_flops_per_launch": exec_flops / dominant,
                     "achieved_by_phase": [m * MFMA_F16_FLOPS / (t * 1e-3) / 1e12 for m, t in zip(mfma_per_launch, by_phase)],
-                    "kernel_names": ["k_sweep<4, 4, true, 2> (first live-point range, compacts the undecided proposals)",
-                                     "k_sweep<4, 2, false, 1> (second range: two query groups per wave)"] if per_step == 2 else None,
-                    "practical_ceiling": {"TFLOPs": PROBE_F16_MFMA_TFLOPS, "frac": ach / PROBE_F16_MFMA_TFLOPS,
-                                          "source": "scripts/probes/mfma16_issue_probe.hip: the matrix instruction ALONE (4 independent "
-                                                    "chains, operands in registers, 1 or 2 waves per SIMD) sustains 1.56-1.58 PFLOP/s on "
-                                                    "this part, 1.50-1.53 with three vector instructions pinned behind each (k_sweep has 2.5); "
-                                                    "a sweep over zero-valued query operands runs at 1.82 PFLOP/s: the chip's clock under "
-                                                    "matrix load depends on the data (profiles/r03_issue_probe.json, DESIGN.md 4b)"},
+                    "kernel_names": names,
+                    "peak_at_measured_clock": {
+                        "what": "the part is power-limited under this instruction: scripts/probes/sweep_src_probe.hip measures clock and "
+                                "cycles per matrix instruction INSIDE the kernel (s_memtime / s_memrealtime): the instruction alone, "
+                                "4 independent chains, operands in registers, matrix pipe 98 % occupied, runs at 2.20-2.26 GHz = "
+                                "2.23-2.33 PFLOP/s on ZERO operands and at 1.50-1.60 GHz = 1.48-1.63 PFLOP/s on random binary16 operands "
+                                "(bf16: 1.64-1.71 GHz); the sweep loop of this kernel holds 1.67-1.72 GHz with the pipe 97-100 % occupied "
+                                "inside the loop (profiles/r04_sweep_src_probe.json, r04_sweep_src_probe2.json)",
+                        "instruction_alone_random_operands_TFLOPs": PROBE_F16_MFMA_TFLOPS,
+                        "frac_of_that": ach / PROBE_F16_MFMA_TFLOPS},
                     "equivalent_allpairs_flops_per_step": allpairs,
-                    "equivalent_allpairs_TFLOPs": allpairs / (launch_ms * per_step * 1e-3) / 1e12,
+                    "equivalent_allpairs_TFLOPs": allpairs / (float(sum(by_phase)) * 1e-3) / 1e12 if by_phase else None,
                     "executed_k_columns": kdim, "second_range_groups": stats["second_range_groups"],
+                    "uncertain_queries": stats.get("uncertain_queries"), "uncertain_pairs": stats.get("uncertain_pairs"),
                     "note": "achieved = executed matrix-instruction flops of one launch (average of the launches of a step) "
                             "over the average launch duration from hipEvents inside the timed region; pairs skipped by the "
                             "second range are not counted (they are an algorithmic saving)",
@@ -580,7 +600,13 @@ def main():
                       "per-proposal stage with the FP64 kernel instead (k_prep3, prep_bounded=0)":
                           (ms_prep_p3 / max(ncalls_p3, 1)) if not args.headline_only else None,
                       "measured_in": "a separate pass of %d steps with stage events (the headline loop carries events only "
-                                     "around the k_sweep launches)" % nsteps_b},
+                                     "around the matrix-kernel launches)" % nsteps_b,
+                      # the stages add up to the wall time of THAT pass, not of the headline loop: every stage boundary is a
+                      # hipEventRecord between two dependent kernels, i.e. a bubble in the queue and a time stamp taken after
+                      # the device has drained; the three figures below make the difference visible (+14 %)
+                      "sum_of_the_stages": prep_ms + scan_ms + rest_ms,
+                      "wall_ms_per_step_of_the_stage_event_pass": stage_pass_s / nsteps_b * 1e3,
+                      "wall_ms_per_step_of_the_headline_loop": headline["ms_per_step"]},
         "batch_counters": stats,
         "roofline": roofline,
         "roofline_exact_scan": exact_roof,

@@ -41,6 +41,20 @@ int mlf_device_count(int *count);
 int mlf_set_device(int device);            /* device used by this process (default 0)      */
 int mlf_device_name(char *buf, size_t buflen);
 int mlf_synchronize(void);
+
+/* ---- device memory for callers that keep arrays resident between calls.  The reference has no counterpart (its arrays
+ * are numpy arrays); ultranest_amd.device_rebuild keeps the live points of a region rebuild (integrator.py:2055-2122) in
+ * HBM across the calls below instead of re-uploading them per call.  Every array argument of the stateless entry points
+ * documented as "host or device" may be such a pointer.  mlf_dev_copy: either side host or device, ordered on the
+ * library's stream, sync != 0 waits for completion. */
+int mlf_dev_alloc(size_t bytes, void **out);
+int mlf_dev_free(void *p);
+int mlf_dev_copy(void *dst, const void *src, size_t bytes, int sync);
+
+/* Column extents of an (n, d) row-major array (host or device): lo[c] = min, hi[c] = max over the rows (host outputs).
+ * The bounding box of the whitened live points (mlfriends.pyx:969-970: unormed.min(axis=0) / .max(axis=0)) and the
+ * driver's cube test (integrator.py:2059-2061) on the resident copy.  min / max are exact: same bits as numpy's. */
+int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi);
 /* Tuning options.  Every option has a PROCESS default (mlf_set_option) and can be overridden per region handle
  * (mlf_region_set_option; inherit != 0 returns one option -- or, with name == NULL, all of them -- to the process
  * default), so that two regions of one process can run different routings.  Results never depend on them.
@@ -391,7 +405,8 @@ int mlf_comm_destroy(void);
 /* Diagnostic counters of the LAST filtered batch of this region (synchronises the device): out[0] proposals the
  * bounded ellipsoid form could not decide (decided in binary64 by the tail of the re-check launch), out[1] reserved
  * (0), out[2] uncertain pairs listed by the pre-filter, out[3] largest list segment, out[4]
- * list segments, out[5] 32-query groups left for the second live-point range.  cap >= 6. */
+ * list segments, out[5] 32-query groups left for the second live-point range, out[6] (cap > 6) queries whose minimum
+ * over all live points ended in the band (the set the min-only sweep hands to its listing pass).  cap >= 6. */
 int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap);
 /* Measured issue rate of independent v_add_f64/v_mul_f64 (the non-fused FP64 vector rate that
  * bounds the distance kernels), in Tera-instructions*lanes per second (= TFLOP/s, 1 flop each). */

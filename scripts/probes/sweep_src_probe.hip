@@ -119,7 +119,7 @@ __device__ __forceinline__ void pin_step() {
   }
 }
 
-template <int SRC, int NW>
+template <int SRC, int NW, int CHECK = 1>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_loop(SweepArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int KS = 4, QW = 4;
@@ -168,9 +168,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     };
     auto reduce = [&](int g) __attribute__((always_inline)) {
       run[g] = tree_min(acc[g], run[g]);
-      const float rm = __int_as_float(run[g]);
-      lo_m[g] = __ballot(rm <= tlo[g]);
-      hi_m[g] = __ballot(rm <= thi[g]);
+      if (CHECK) {
+        const float rm = __int_as_float(run[g]);
+        lo_m[g] = __ballot(rm <= tlo[g]);
+        hi_m[g] = __ballot(rm <= thi[g]);
+      }
     };
     auto list_band = [&](int g, unsigned long long candm) __attribute__((always_inline)) {
       const float16v &c = acc[g];
@@ -207,10 +209,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
           reduce(2 * (p - 1));
           reduce(2 * (p - 1) + 1);
         }
-        if (p == 1) pin_step<0, 2 * KS, 20>();
+        if (p == 1) pin_step<0, 2 * KS, CHECK ? 20 : 16>();
       }
       __builtin_amdgcn_sched_barrier(0);
-      check();
+      if (CHECK) check();
     };
     const unsigned long long ci0 = __builtin_readcyclecounter();
     if (SRC == 0) {
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     cin += __builtin_readcyclecounter() - ci0;
 #pragma unroll
     for (int g = 0; g < QW; ++g) {
+      if (!CHECK) listed += (!(__int_as_float(run[g]) <= tlo[g]) && __int_as_float(run[g]) <= thi[g]) ? 1u : 0u;
       const int mine = __int_as_float(run[g]) <= tlo[g] ? 1 : 0;
       const int res = (mine | __shfl_xor(mine, 32)) ? 0 : -1;
       if (lane < 32) a.best[((size_t)set * QW + g) * 32 + lane] = res;
@@ -371,18 +374,18 @@ static void run_alone(const char *data, int kind, float *sink, Stamp *dst) {
   CK(hipFree(ops));
 }
 
-template <int SRC, int NW>
+template <int SRC, int NW, int CHECK = 1>
 static void run_loop(int ntiles, int nsets, const void *refF, const void *qF, const float *tlo, const float *thi, int *best,
                      unsigned *listcount, Stamp *dst, std::vector<int> *ref_best) {
   // SRC = 0: 4-wave workgroups, two per CU (as the library); LDS variants: one 8-wave workgroup per CU
   const int blocks = SRC == 0 ? 512 : 256;
   const size_t ldsb = SRC == 0 ? 0 : (size_t)ntiles * 4096;
-  if (ldsb) CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_loop<SRC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+  if (ldsb) CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_loop<SRC, NW, CHECK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
   SweepArgs a{refF, qF, tlo, thi, ntiles, nsets, best, listcount, dst};
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k_loop<SRC, NW>), dim3(blocks), dim3(NW * 64), ldsb, 0, a);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k_loop<SRC, NW, CHECK>), dim3(blocks), dim3(NW * 64), ldsb, 0, a);
   CK(hipDeviceSynchronize());
   float best_ms = 1e30f;
   const int nw = blocks * NW;
@@ -391,7 +394,7 @@ static void run_loop(int ntiles, int nsets, const void *refF, const void *qF, co
   for (int rep = 0; rep < 5; ++rep) {
     CK(hipMemset(listcount, 0, 4));
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k_loop<SRC, NW>), dim3(blocks), dim3(NW * 64), ldsb, 0, a);
+    hipLaunchKernelGGL((k_loop<SRC, NW, CHECK>), dim3(blocks), dim3(NW * 64), ldsb, 0, a);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -427,11 +430,11 @@ static void run_loop(int ntiles, int nsets, const void *refF, const void *qF, co
   const double pf = nm * 32768.0 / (best_ms * 1e-3) / 1e15;
   // clock from the launch: matrix instructions x 32 cycles / 1024 SIMDs / pipe occupancy is not known a priori, so report
   // the clock implied by wave cycles: every wave's (c1 - c0 of the whole kernel) is not kept; use in-loop cycles and wall
-  printf("{\"probe\": \"sweep loop\", \"tiles_from\": \"%s\", \"ntiles\": %d, \"sets\": %d, \"ms\": %.4f, \"PFLOPs\": %.3f, "
+  printf("{\"probe\": \"sweep loop\", \"per_tile_band_check\": %d, \"tiles_from\": \"%s\", \"ntiles\": %d, \"sets\": %d, \"ms\": %.4f, \"PFLOPs\": %.3f, "
          "\"clock_GHz\": %.3f, \"pipe_busy_over_launch\": %.3f, \"wave_time_inside_tile_loops\": %.3f, "
          "\"cycles_per_tile_per_wave_in_loop\": %.1f, \"pipe_busy_in_loop\": %.3f, \"certain_hits\": %lld, \"band_entries\": %u, "
          "\"results_differ_from_first_variant\": %lld}\n",
-         SRC == 0 ? "L2, buffer loads two ahead" : (SRC == 1 ? "LDS resident, one ahead" : "LDS resident, two ahead"), ntiles, nsets,
+         CHECK, SRC == 0 ? "L2, buffer loads two ahead" : (SRC == 1 ? "LDS resident, one ahead" : "LDS resident, two ahead"), ntiles, nsets,
          best_ms, pf, ghz, nm * 32.0 / 1024.0 / (best_ms * 1e-3 * ghz * 1e9), inloop, cyc_tile, 1024.0 / cyc_tile, hits, lc, diff);
   fflush(stdout);
 }
@@ -527,6 +530,12 @@ int main(int argc, char **argv) {
         run_loop<2, 8>(ntiles, nsets, refF, qF, tlo, thi, best, lc, dst, &ref_best);
       }
       run_loop<0, 4>(ntiles, nsets, refF, qF, tlo, thi, best, lc, dst, &ref_best);
+      {   // running minimum only: no per-tile comparison with the thresholds, the band is read off the final minimum
+        std::vector<int> ref2;
+        run_loop<0, 4, 0>(ntiles, nsets, refF, qF, tlo, thi, best, lc, dst, &ref2);
+        if (ntiles * 4096 <= 160 * 1024 - 1024) run_loop<2, 8, 0>(ntiles, nsets, refF, qF, tlo, thi, best, lc, dst, &ref2);
+        run_loop<0, 4, 0>(ntiles, nsets, refF, qF, tlo, thi, best, lc, dst, &ref2);
+      }
       CK(hipFree(refF));
       CK(hipFree(qF));
       CK(hipFree(tlo));

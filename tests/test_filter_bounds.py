@@ -20,7 +20,9 @@ def thresholds(sigma, namax, nbn2, r2, K):
     sr = sigma * np.sqrt(r2)
     lo = sr * (1 - 2.0**-30) - delta
     hi = sr * (1 + 2.0**-30) + delta
-    t_lo = lo * lo - eacc if lo > 0 else -np.inf   # no certain hit possible: nothing compares <= -inf (Dt itself can be negative)
+    # no certain hit possible: nothing compares <= -inf (Dt itself can be negative); a negative finite threshold becomes
+    # -inf as well (the kernels' integer minima order negative values the wrong way round)
+    t_lo = lo * lo - eacc if (lo > 0 and lo * lo - eacc >= 0) else -np.inf
     t_hi = hi * hi + eacc
     lo_f = np.float32(t_lo)
     if float(lo_f) > t_lo:

@@ -208,6 +208,8 @@ def thresholds4(namax, nb, zeta, sqrt_k, sr_lo, sr_hi):
     lo = (sr_lo * DN - delta) * DN
     hi = (sr_hi * UP + delta) * UP
     t_lo = (lo * lo) * DN - eacc * UP if lo > 0 else f32(-np.inf)
+    if t_lo < 0:
+        t_lo = f32(-np.inf)      # never negative and finite (filter_thresholds4)
     t_hi = ((hi * hi) * UP + eacc) * UP
     return float(t_lo), float(t_hi), bool(t_hi < 30000)
 

@@ -37,6 +37,10 @@ SIGNATURES = {
     "mlf_region_hint_live_extent": [_vp, _dbl],
     "mlf_region_set_option": [_vp, ctypes.c_char_p, ctypes.c_longlong, ctypes.c_int],
     "mlf_option_name": [ctypes.c_int, _vp, _sz],
+    "mlf_dev_alloc": [_sz, _vp],
+    "mlf_dev_free": [_vp],
+    "mlf_dev_copy": [_vp, _vp, _sz, ctypes.c_int],
+    "mlf_col_extent": [_vp, _sz, _sz, _vp, _vp],
     "mlf_maxradiussq_bootstrap": [_vp, _sz, _sz, _vp, _sz, _vp, _vp],
     "mlf_maxradiussq_bootstrap_rows": [_vp, _sz, _sz, _vp, _sz, _sz, _sz, _vp, _vp],
     "mlf_pair_dist2_lower": [_vp, _sz, _sz, _vp],

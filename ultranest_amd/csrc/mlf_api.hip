@@ -65,12 +65,13 @@ enum Opt : int {
   OPT_TIME_LAUNCHES,       // "time_filter_launches" 0/1: event pairs around every matrix-kernel launch of every call
   OPT_PREP_BOUNDED,        // "prep_bounded" 0/1: bounded matrix-core per-proposal stage (mlf_prep4.hip) or the binary64 one
   OPT_MIN_QUERIES,         // "filter_min_queries": smaller batches go straight to the exact scan
+  OPT_SWEEP_MIN,           // "sweep_min" 0/1: two-range batches through the min-only sweep (mlf_sweepmin.hip) or k_sweep
   OPT_COUNT
 };
 const char *const kOptNames[OPT_COUNT] = {"filter", "filter_first_range_pct", "filter_split_waves", "filter_narrow_tail",
                                           "small_path", "fused_prep", "filter_phase_min_queries", "filter_phases",
-                                          "time_filter_launches", "prep_bounded", "filter_min_queries"};
-long long g_opt[OPT_COUNT] = {1, 50, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault};
+                                          "time_filter_launches", "prep_bounded", "filter_min_queries", "sweep_min"};
+long long g_opt[OPT_COUNT] = {1, 50, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1};
 
 struct OptOverrides {
   long long v[OPT_COUNT] = {};
@@ -102,7 +103,7 @@ struct FilterCtx {
   double sigma = 1.0, amax = 0.0;
   DevBuf stats, statscratch, refF, qF, tlo, thi, route, best, counters, list, segcnt, gate2;
   // phased sweep: two compacted query sets (ping-pong)
-  DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png;
+  DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png, pmin;
   // bounded per-proposal stage (mlf_prep4.hip): ellipsoid band list, per-call counters
   // misc: [0] band proposals, [1] k_ell_exact workgroups done -- both return to zero by themselves (no memset per batch),
   // zeroed once when the buffer is allocated; [2], [3] "a proposal is routed to the exact scan", used alternately by
@@ -119,7 +120,7 @@ struct FilterCtx {
   OptOverrides ov;            // per-handle tuning (mlf_region_set_option); the stateless calls' context has none
   void release() {
     DevBuf *b[] = {&stats, &statscratch, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2,
-                   &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png,
+                   &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png, &pmin,
                    &ell_list, &misc};
     for (DevBuf *x : b) x->release();
     refs_ready = usable = false;
@@ -454,6 +455,99 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   // its group count (k_phase_finish: a 5 us launch) -- the second range reads the slot counter itself, the tail resets it
   const bool fold_finish = fused && nphase == 2 && xs != nullptr;
 
+  // Two ranges in mask mode behind the bounded per-proposal stage: the min-only sweep (mlf_sweepmin.hip).  The two long
+  // launches carry the running minimum only; the queries whose minimum ends in the band are swept once more by
+  // k_uncertain (band pairs found, queries whitened, pairs decided in one launch), which also carries the ellipsoid band.
+  const bool min_path = fold_finish && out_idx == nullptr && f.ks <= 4 && opt(f, OPT_SWEEP_MIN);
+  if (min_path) {
+    const long long lw = uncertain_blocks();
+    CK(f.segcnt.reserve((size_t)(lw + 8) * sizeof(unsigned)));
+    CK(f.pmin.reserve((size_t)nqpad * sizeof(int)));
+    const int cut = (int)((long long)f.ntiles32 * opt(f, OPT_FIRST_RANGE_PCT) / 100);
+    const int c = cut < 4 ? 4 : (cut > f.ntiles32 - 4 ? f.ntiles32 - 4 : cut);
+    auto timed = [&](auto &&launch) -> int {
+      const bool time_launch = ev_after_filter || opt(f, OPT_TIME_LAUNCHES);
+      if (time_launch) {
+        while (f.kev.size() < f.kev_used + 2) {
+          hipEvent_t e;
+          CK(hipEventCreate(&e));
+          f.kev.push_back(e);
+        }
+        CK(hipEventRecord(f.kev[f.kev_used], s));
+      }
+      CK(launch());
+      if (time_launch) {
+        CK(hipEventRecord(f.kev[f.kev_used + 1], s));
+        f.kev_used += 2;
+      }
+      return 0;
+    };
+    MinArgs m{};
+    m.refF = f.refF.p;
+    m.ntiles32 = f.ntiles32;
+    m.nq = nq;
+    m.best = f.best.as<int>();
+    m.ngroups = ngroups;
+    m.ccap = (unsigned)nqpad;
+    // first range: slot = query; the queries without a certain hit go to set 0 with their minimum
+    m.tile0 = 0;
+    m.tile1 = c;
+    m.qF = f.qF.p;
+    m.tlo = f.tlo.as<float>();
+    m.thi = f.thi.as<float>();
+    m.cq = f.pqF[0].p;
+    m.ctlo = f.ptlo[0].as<float>();
+    m.cthi = f.pthi[0].as<float>();
+    m.cmap = f.pmap[0].as<int>();
+    m.cmin = f.pmin.as<int>();
+    m.ccount = f.png.as<unsigned>() + 2;
+    m.last = 0;
+    if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, 0), m, s); })) return rc;
+    // second range: set 0 with its minima; the uncertain queries go to set 1
+    m.tile0 = c;
+    m.tile1 = f.ntiles32;
+    m.qF = f.pqF[0].p;
+    m.tlo = f.ptlo[0].as<float>();
+    m.thi = f.pthi[0].as<float>();
+    m.qmap = f.pmap[0].as<int>();
+    m.qmin = f.pmin.as<int>();
+    m.nslots_dev = f.png.as<unsigned>() + 2;
+    m.cq = f.pqF[1].p;
+    m.ctlo = f.ptlo[1].as<float>();
+    m.cthi = f.pthi[1].as<float>();
+    m.cmap = f.pmap[1].as<int>();
+    m.cmin = nullptr;
+    m.ccount = f.png.as<unsigned>() + 3;
+    m.last = 1;
+    if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, narrow_tail), m, s); })) return rc;
+    // the uncertain set: band pairs, exact whitening, exact distances -- one launch; the ellipsoid band rides along
+    UncertainArgs ua{};
+    ua.refF = f.refF.p;
+    ua.ntiles32 = f.ntiles32;
+    ua.qF = f.pqF[1].p;
+    ua.thi = f.pthi[1].as<float>();
+    ua.qmap = f.pmap[1].as<int>();
+    ua.nslots_dev = f.png.as<unsigned>() + 3;
+    ua.pts = xs->pts;
+    ua.d = d;
+    ua.dp = dp;
+    ua.lay_ctr = xs->lay_ctr;
+    ua.T8 = xs->T8;
+    ua.ldt8 = xs->ldt;
+    ua.refR = refR;
+    ua.n = n;
+    ua.r2 = r2;
+    ua.best = f.best.as<int>();
+    ua.counters = f.counters.as<unsigned>();
+    ua.seg_count = f.segcnt.as<unsigned>();
+    if (f.ell_pending) {   // the band proposals of k_prep4: trailing workgroups of this launch
+      ua.ell = f.ell_args;
+      f.ell_pending = false;
+    }
+    if (int rc = timed([&] { return launch_uncertain(f.ks, ua, s); })) return rc;
+    if (ev_after_filter) CK(hipEventRecord(ev_after_filter, s));
+    f.last_nsegs = (size_t)lw;
+  } else {
   for (int ph = 0; ph < nphase; ++ph) {
     fa.tile0 = (int)((long long)f.ntiles32 * ph / nphase);
     fa.tile1 = (int)((long long)f.ntiles32 * (ph + 1) / nphase);
@@ -526,7 +620,9 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   if (nsegs_all < filter_wave_count(f.ks, ngroups)) nsegs_all = filter_wave_count(f.ks, ngroups);
   if (fa.split > 1) nsegs_all = (filter_wave_count(f.ks, ngroups) + 3) / 4 * 4 * fa.split;
   f.last_nsegs = (size_t)nsegs_all;
-  if (own_recheck) {
+  }   // k_sweep / k_filter phases
+  long long nsegs_all = f.last_nsegs;
+  if (own_recheck || min_path) {
     // nothing left to do here: every sweeping wave has re-checked its own pairs
   } else if (xs) {   // no whitened coordinates were stored: the re-check whitens the queries of its pairs itself
     RecheckWArgs rw{};
@@ -607,6 +703,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       if (fold_finish) {
         a.fin_slots = f.png.as<unsigned>() + 2;
         a.fin_groups = f.png.as<unsigned>();   // where k_phase_finish would have left the group count (debug_stats)
+        if (min_path) a.fin_slots2 = f.png.as<unsigned>() + 3;
       }
     }
     CK(launch_scan(dp, a, s));
@@ -1157,6 +1254,56 @@ int mlf_synchronize(void) {
   return 0;
 }
 
+// ---- device memory for callers that keep arrays resident between calls (ultranest_amd.device_rebuild) -------------------
+int mlf_dev_alloc(size_t bytes, void **out) {
+  if (!out) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (int rc = ensure_ctx()) return rc;
+  CK(hipMalloc(out, bytes ? bytes : 1));
+  return 0;
+}
+
+int mlf_dev_free(void *p) {
+  if (!p) return 0;
+  if (int rc = ensure_ctx()) return rc;
+  CK(hipFree(p));
+  return 0;
+}
+
+// dst / src: host or device (unified addressing picks the direction); ordered on the library's stream; `sync` != 0 waits
+// for it (needed before a host destination is read or a host source is re-used)
+int mlf_dev_copy(void *dst, const void *src, size_t bytes, int sync) {
+  if (bytes && (!dst || !src)) return fail_arg(MLF_E_BADARG, "null pointer");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  if (bytes) CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c.stream));
+  if (sync) CK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+// lo[c], hi[c] = extents of column c of the (n, d) row-major array `pts` (host or device); lo / hi on the host
+int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi) {
+  if (int rc = check_dims(d)) return rc;
+  if (!pts || !lo || !hi || n == 0) return fail_arg(MLF_E_BADARG, "null pointer or no rows");
+  if (int rc = ensure_ctx()) return rc;
+  Ctx &c = g_ctx;
+  const double *dp = pts;
+  if (!is_device_pointer(pts)) {
+    if (int rc = upload(c.src, pts, n * d * sizeof(double), c.stream)) return rc;
+    dp = c.src.as<double>();
+  }
+  CK(c.small2.reserve((size_t)(kExtentScratchBlocks + 1) * 2 * d * sizeof(double)));
+  double *part = c.small2.as<double>();
+  double *out = part + (size_t)kExtentScratchBlocks * 2 * d;
+  launch_col_extent(dp, (int)n, (int)d, part, out, c.stream);
+  CK(hipGetLastError());
+  std::vector<double> h(2 * d);
+  CK(hipMemcpyAsync(h.data(), out, 2 * d * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+  memcpy(lo, h.data(), d * sizeof(double));
+  memcpy(hi, h.data() + d, d * sizeof(double));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------ K1 / K2 ----
 int mlf_find_nearby(const double *apts, size_t na, const double *bpts, size_t nb, size_t d,
                     double radiussq, int64_t *out) {
@@ -1456,21 +1603,42 @@ int mlf_affine_transform(const double *pts, size_t np, size_t d, const double *c
     if (int rc = upload(c.small2, w.data(), w.size() * sizeof(double), c.stream)) return rc;
     CK(hipStreamSynchronize(c.stream));
   }
-  if (int rc = upload(c.q, pts, np * d * sizeof(double), c.stream)) return rc;
-  CK(c.out.reserve(np * d * sizeof(double)));
-  PrepArgs a{};
-  a.pts = c.q.as<double>();
-  a.np = (long long)np;
-  a.d = (int)d;
-  a.do_tr = 1;
-  a.lay_ctr = c.small0.as<double>();
-  a.lay_Tt = c.small1.as<double>();
-  a.wrap_shift = wrap_shift ? c.small2.as<double>() : nullptr;
-  a.t_out = c.out.as<double>();
-  a.ldt = (long long)d;
-  CK(launch_prep(dp, a, c.stream));
-  CK(hipMemcpyAsync(out, c.out.p, np * d * sizeof(double), hipMemcpyDefault, c.stream));
-  CK(hipStreamSynchronize(c.stream));
+  // device in: read in place; device out: written in place (the device-resident rebuild whitens its live points twice)
+  const bool in_dev = is_device_pointer(pts), out_dev = is_device_pointer(out);
+  const double *src = pts;
+  if (!in_dev) {
+    if (int rc = upload(c.q, pts, np * d * sizeof(double), c.stream)) return rc;
+    src = c.q.as<double>();
+  }
+  double *dst = out;
+  if (!out_dev) {
+    CK(c.out.reserve(np * d * sizeof(double)));
+    dst = c.out.as<double>();
+  }
+  if (dp <= 64) {
+    // wave-per-8-rows form of the same chain (k_whiten_rows: bit for bit what k_prep computes, 36 -> 5 us for 4000 rows)
+    const int dp8 = (dp + 7) / 8 * 8;
+    std::vector<double> t8((size_t)dp * dp8, 0.0);
+    for (size_t k = 0; k < d; ++k)
+      for (size_t cc = 0; cc < d; ++cc) t8[k * dp8 + cc] = T[k * d + cc];
+    if (int rc = upload(c.small3, t8.data(), t8.size() * sizeof(double), c.stream)) return rc;
+    CK(launch_whiten_rows(src, (long long)np, (int)d, dp, c.small0.as<double>(), c.small3.as<double>(), dp8,
+                          wrap_shift ? c.small2.as<double>() : nullptr, dst, (long long)d, c.stream));
+  } else {
+    PrepArgs a{};
+    a.pts = src;
+    a.np = (long long)np;
+    a.d = (int)d;
+    a.do_tr = 1;
+    a.lay_ctr = c.small0.as<double>();
+    a.lay_Tt = c.small1.as<double>();
+    a.wrap_shift = wrap_shift ? c.small2.as<double>() : nullptr;
+    a.t_out = dst;
+    a.ldt = (long long)d;
+    CK(launch_prep(dp, a, c.stream));
+  }
+  if (!out_dev) CK(hipMemcpyAsync(out, c.out.p, np * d * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));   // the host vectors above leave scope; a host destination is read next
   return 0;
 }
 
@@ -2378,6 +2546,12 @@ int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap) {
     unsigned g[2];
     CK(hipMemcpy(g, f.png.p, sizeof g, hipMemcpyDeviceToHost));
     out[5] = g[0];
+    if (cap > 6) out[6] = g[1];   // queries of the last min-only batch whose minimum ended in the band (uncertain set)
+    if (cap >= 16 && f.last_nsegs == (size_t)uncertain_blocks() && f.segcnt.cap >= (f.last_nsegs + 8) * sizeof(unsigned)) {
+      unsigned st[8];   // shader-clock stamps of k_uncertain's workgroup 0 (stage boundaries of its first set)
+      CK(hipMemcpy(st, f.segcnt.as<unsigned>() + uncertain_stamp_base(), sizeof st, hipMemcpyDeviceToHost));
+      for (int i = 0; i < 8; ++i) out[8 + i] = st[i];
+    }
   }
   return 0;
 }

@@ -78,6 +78,7 @@ struct ScanArgs {
   unsigned *fin_reset;            // optional word zeroed by the tail
   unsigned *fin_slots;            // optional: slot counter of the fused compaction -- *fin_groups = ceil(it / 32), then zeroed
   unsigned *fin_groups;
+  unsigned *fin_slots2;           // optional: slot counter of the uncertain set (mlf_sweepmin.hip) -- fin_groups[1] = its value, then zeroed
   long long *out_idx;             // SCAN_FIRST / SCAN_COUNT
   unsigned long long *out_flags;  // SCAN_FLAGS  [nq][ntiles]
   uint8_t *out_mask;              // SCAN_MASK

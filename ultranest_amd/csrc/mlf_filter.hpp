@@ -48,6 +48,57 @@ struct FilterArgs {
   // in kEllWaves leading waves -- no separate re-check launch
   RecheckWArgs rw;
 };
+// ---- min-only phased sweep (mlf_sweepmin.hip) ----
+struct MinArgs {
+  const void *refF;      // f16 fragments of the live points  [ntiles32][KS][64][8]
+  int ntiles32;
+  int tile0, tile1;      // live-point tiles of this range
+  // the set that is swept: slot = query (qmap == nullptr) or a compacted set of nslots_dev[0] slots
+  const void *qF;
+  const float *tlo, *thi;
+  const int *qmap;
+  const int *qmin;       // minima (bit patterns) the slots bring along from earlier ranges, nullptr = none
+  long long ngroups;     // groups of 32 slots the grid is sized for
+  const unsigned *nslots_dev;
+  long long nq;
+  int *best;             // certain hit: best[query] = 0
+  // the set that is written: slots from one atomic per wave on *ccount
+  void *cq;
+  float *ctlo, *cthi;
+  int *cmap;
+  int *cmin;             // nullptr when last
+  unsigned *ccount;
+  unsigned ccap;
+  int last;              // 0: keeps the queries without a certain hit; 1: keeps the uncertain ones (minimum in the band)
+};
+constexpr unsigned kUncertainListCap = 4096;   // band pairs of one set of 128 uncertain queries (expected: ~140)
+struct UncertainArgs {
+  const void *refF;
+  int ntiles32;
+  const void *qF;        // the uncertain set (compacted by the last k_sweep_min launch)
+  const float *thi;
+  const int *qmap;
+  const unsigned *nslots_dev;
+  // exact side: the proposals as handed over, the layer, the whitened live points
+  const double *pts;
+  int d, dp;
+  const double *lay_ctr;
+  const double *T8;      // row-major layer matrix, row stride ldt8, zero padded to dp rows
+  int ldt8;
+  const double *refR;    // [npad][dp]
+  int n;
+  double r2;
+  int *best;
+  unsigned *counters;    // [1] overflow flag
+  unsigned *seg_count;   // [uncertain_blocks()]: pairs listed per workgroup (statistics)
+  EllExactArgs ell;      // ell.count != nullptr: the band proposals of k_prep4, in kEllWaves / 8 trailing workgroups
+  unsigned nsweepblk;    // filled in by the launcher
+};
+hipError_t launch_sweep_min(int ks, int qw, const MinArgs &a, hipStream_t s);
+hipError_t launch_uncertain(int ks, const UncertainArgs &a, hipStream_t s);
+long long uncertain_blocks();
+__host__ __device__ constexpr unsigned uncertain_stamp_base() { return 256u; }   // = uncertain_blocks(): 8 diagnostic words behind the per-workgroup counts
+
 // after a compacting launch: group count of the compacted set, padding of its last group, counter reset
 void launch_phase_finish(void *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount, unsigned *ngroups_dst,
                          int ks, hipStream_t s);

@@ -41,7 +41,9 @@ __device__ __forceinline__ bool filter_thresholds(double sigma, double namax, do
   const double lo = sr * (1.0 - 0x1p-30) - delta;
   const double hi = sr * (1.0 + 0x1p-30) + delta;
   // lo <= 0: no pair may count as a certain hit; -inf and not -1, because a computed Dt can be as low as -eacc
-  const double t_lo = lo > 0.0 ? lo * lo - eacc : -INFINITY;
+  // ... and never negative and finite: the kernels take minima on the bit patterns, which order negative values the wrong way
+  // round; with T_lo >= 0 every negative Dt is a certain hit whichever of them the minimum keeps
+  const double t_lo = (lo > 0.0 && lo * lo - eacc >= 0.0) ? lo * lo - eacc : -INFINITY;
   const double t_hi = hi * hi + eacc;
   float l = (float)t_lo;
   if ((double)l > t_lo) l = nextafterf(l, -INFINITY);
@@ -74,7 +76,8 @@ __device__ __forceinline__ bool filter_thresholds4(float namax, float nb, float 
   const float eacc = (0x1p-15f * w * w + 0x1p-22f + 0x1p-18f * nb) * up;
   const float lo = (sr_lo * dn - delta) * dn;
   const float hi = (sr_hi * up + delta) * up;
-  *lo_f = lo > 0.0f ? (lo * lo) * dn - eacc * up : -INFINITY;
+  const float t_lo = (lo * lo) * dn - eacc * up;
+  *lo_f = (lo > 0.0f && t_lo >= 0.0f) ? t_lo : -INFINITY;   // never negative and finite (see filter_thresholds)
   const float t_hi = ((hi * hi) * up + eacc) * up;
   *hi_f = t_hi;
   return t_hi < 30000.0f;   // false for NaN

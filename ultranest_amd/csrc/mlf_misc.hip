@@ -304,6 +304,54 @@ __global__ __launch_bounds__(256) void k_pair_dist2_lower(const double *pts, int
   out[(long long)j * (j - 1) / 2 + i] = acc;
 }
 
+// ------------------------------------------------------- column extents (device-resident rebuild) ---------
+// lo[c] = min over rows of pts[row][c], hi[c] = max: the bounding box of the whitened live points (mlfriends.pyx:969-970),
+// and -- on the unit-cube points -- the cube test of the driver (integrator.py:2059-2061) and the largest |u - ctr|.
+// Stage 1: workgroup b scans rows b, b + G, ...; thread = (row within a step, column); partial extents per workgroup.
+// Stage 2: one workgroup folds the G partials.  min / max are exact: any order gives the same bits.
+constexpr int kExtentBlocks = 64;
+__global__ __launch_bounds__(256) void k_col_extent(const double *__restrict__ pts, int n, int d, double *__restrict__ part) {
+  __shared__ double slo[256], shi[256];
+  const int rows_per_step = 256 / d > 0 ? 256 / d : 1;   // d <= 128: at least two rows per step
+  const int r = threadIdx.x / d, c = threadIdx.x - r * d;
+  double lo = INFINITY, hi = -INFINITY;
+  if (r < rows_per_step)
+    for (long long row = (long long)blockIdx.x * rows_per_step + r; row < n; row += (long long)gridDim.x * rows_per_step) {
+      const double v = pts[row * d + c];
+      lo = (v < lo || v != v) ? v : lo;      // a NaN stays (every later comparison is false): numpy's min / max propagate it too
+      hi = (v > hi || v != v) ? v : hi;
+    }
+  slo[threadIdx.x] = lo;
+  shi[threadIdx.x] = hi;
+  __syncthreads();
+  if (threadIdx.x < d) {
+    for (int rr = 1; rr < rows_per_step; ++rr) {
+      const double l2 = slo[rr * d + threadIdx.x], h2 = shi[rr * d + threadIdx.x];
+      lo = (l2 < lo || l2 != l2) ? l2 : lo;
+      hi = (h2 > hi || h2 != h2) ? h2 : hi;
+    }
+    part[(size_t)blockIdx.x * 2 * d + threadIdx.x] = lo;
+    part[(size_t)blockIdx.x * 2 * d + d + threadIdx.x] = hi;
+  }
+}
+__global__ __launch_bounds__(128) void k_col_extent_fold(const double *__restrict__ part, int nblk, int d, double *__restrict__ out) {
+  const int c = threadIdx.x;
+  if (c >= d) return;
+  double lo = INFINITY, hi = -INFINITY;
+  for (int b = 0; b < nblk; ++b) {
+    const double l2 = part[(size_t)b * 2 * d + c], h2 = part[(size_t)b * 2 * d + d + c];
+    lo = (l2 < lo || l2 != l2) ? l2 : lo;
+    hi = (h2 > hi || h2 != h2) ? h2 : hi;
+  }
+  out[c] = lo;
+  out[d + c] = hi;
+}
+// part: kExtentBlocks * 2 * d doubles of scratch; out: 2 * d doubles (lo then hi)
+void launch_col_extent(const double *pts, int n, int d, double *part, double *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_col_extent, dim3(kExtentBlocks), dim3(256), 0, s, pts, n, d, part);
+  hipLaunchKernelGGL(k_col_extent_fold, dim3(1), dim3(128), 0, s, part, kExtentBlocks, d, out);
+}
+
 void launch_pair_dist2_lower(const double *pts, int n, int d, double *out, hipStream_t s) {
   const unsigned g = (unsigned)((n + 15) / 16);
   hipLaunchKernelGGL(k_pair_dist2_lower, dim3(g, g), dim3(256), 0, s, pts, n, d, out);

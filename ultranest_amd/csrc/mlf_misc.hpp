@@ -25,6 +25,8 @@ void launch_boot_final(const unsigned long long *M, const unsigned *sel, int n, 
 void launch_subtract_accum(const double *pts, int n, int d, const unsigned long long *flags,
                            int ntiles, double *out, hipStream_t s);
 void launch_pair_dist2_lower(const double *pts, int n, int d, double *out, hipStream_t s);
+constexpr int kExtentScratchBlocks = 64;
+void launch_col_extent(const double *pts, int n, int d, double *part, double *out, hipStream_t s);
 void launch_scaling_transform(const double *pts, long long np, int d, const double *mean,
                               const double *std, const double *wrap_shift, const uint8_t *gate,
                               double *out, long long ldt, hipStream_t s);

@@ -515,9 +515,9 @@ __global__ __launch_bounds__(64) void k_recheck_whiten(RecheckWArgs a) {
   const int lane = threadIdx.x;
   // the ellipsoid band goes FIRST in the grid: its waves (a few proposals each, 50-step chains) then run next to the
   // segment waves instead of after the last of them (44 -> 41 us)
-  const unsigned nell = a.ell.count ? kEllWaves : 0u;
+  const unsigned nell = a.ell.count ? a.ell_waves : 0u;
   if (blockIdx.x < nell) {
-    ell_exact_wave(a.ell, lds_r, blockIdx.x, kEllWaves);
+    ell_exact_wave(a.ell, lds_r, blockIdx.x, nell);
     return;
   }
   const unsigned sidx = blockIdx.x - nell;
@@ -533,7 +533,8 @@ void launch_recheck_whiten(const RecheckWArgs &a_in, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_recheck_whiten), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_bytes = lds;
   }
-  const unsigned grid = (unsigned)a.nsegs + (a.ell.count ? kEllWaves : 0u);
+  if (a.ell_waves == 0u) a.ell_waves = kEllWaves;
+  const unsigned grid = (unsigned)a.nsegs + (a.ell.count ? a.ell_waves : 0u);
   hipLaunchKernelGGL(k_recheck_whiten, dim3(grid), dim3(64), lds, s, a);
 }
 

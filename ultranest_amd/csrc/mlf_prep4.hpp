@@ -84,6 +84,7 @@ struct RecheckWArgs {
   double r2;
   int *best;
   EllExactArgs ell;        // ell.count != nullptr: the band proposals are decided by the last waves of this launch
+  unsigned ell_waves;      // waves of k_recheck_whiten that take the band proposals (0 = kEllWaves)
 };
 void launch_recheck_whiten(const RecheckWArgs &a, hipStream_t s);
 

@@ -6,23 +6,30 @@ of :927-986, 1017-1070, 1213-1237).
 The default rebuild keeps every d x d and N x d numpy call of the reference on the host, so that `T`, `unormed` and
 with them a seeded run's trajectory are the reference's bit for bit -- and pays for it: 3.1 of its 5.7 ms at N = 4000,
 d = 50 are host numpy (np.cov twice, np.dot twice, reductions) and 0.7 ms eight pageable uploads of the same two
-arrays.  Here the live points are uploaded ONCE and everything that touches all N points stays in HBM:
+arrays.  Here the live points are uploaded ONCE into memory of the library's own allocator (mlf_dev_alloc: no torch in
+this module since round 4) and everything that touches all N points is one of the library's kernels:
 
-  whitening with the old and the new layer     (N, d) x (d, d) products        torch.mm (rocBLAS: a plain GEMM)
-  friends-of-friends labels                    mlf_cluster_labels              one all-pairs pass + bit-row replay
+  cube test, |u - ctr| extent, bounding box    mlf_col_extent                  column minima / maxima (exact)
+  whitening with the old and the new layer     mlf_affine_transform            k_whiten_rows: the SAME k-ascending FMA chain
+                                                                               that whitens the region's live points and the
+                                                                               re-checked proposals (device in, device out)
+  friends-of-friends labels                    mlf_adjacency_bits + replay     one all-pairs pass + bit-row replay (worker thread)
   neighbour-mean subtraction (LocalAffineLayer) mlf_subtract_nearby            device in, device out
-  means / covariances                          torch.mean / torch.cov          (d, d) results go to the host
+  means / covariances                          mlf_bootstrap_moments           the bootstrap's own mean / covariance kernels with
+                                                                               an all-ones selection (fixed summation order)
   bootstrapped radius and enlargement          mlf_maxradiussq_bootstrap / mlf_bootstrap_factor on device pointers
   membership of the live points                mlf_region_set + mlf_region_inside_dev on device pointers
 
 and the host keeps what is O(d^3) on one d x d matrix: `eigh` of the layer covariance (T = V L^-1/2, invT = L^1/2 V^T,
 logvolscale = 1/2 sum log L: no explicit inverse), `inv` + two `eigh` for the wrapping ellipsoid.
 
-TOLERANCE CLASS, not bit parity: T, cov, unormed agree with the default path to ~1e-12 relative (different summation
-orders in the GEMMs and moments), the radius to ~1e-10, cluster labels exactly (as long as no pair sits within that
-distance of the linking length); masks are exact FOR THE REGION AS BUILT.  `np.random` is consumed exactly as by the
-default path (one `randint(N, size=N)` per bootstrap round).  Supported: AffineLayer / LocalAffineLayer without
-wrapped axes, MLFriends, minvol = 0, d <= 64, one process; anything else -> `supported()` is False and the caller
+TOLERANCE CLASS, not bit parity with the default path: T, cov agree to ~1e-12 relative (different summation orders in the
+moments; eigh instead of inv), `unormed` with them; GIVEN T, the whitening is the region's own chain, so the radius is the
+kernel's exact answer for the `unormed` it is handed (tests/test_device_rebuild.py: against the golden bootstrap vectors
+g3 on their own inputs bit for bit, against the default path equal-or-adjacent binary32).  Cluster labels exactly (as long
+as no pair sits within rounding of the linking length); masks are exact FOR THE REGION AS BUILT.  `np.random` is consumed
+exactly as by the default path (one `randint(N, size=N)` per bootstrap round).  Supported: AffineLayer / LocalAffineLayer
+without wrapped axes, MLFriends, minvol = 0, d <= 64, one process; anything else -> `supported()` is False and the caller
 uses the default path.
 """
 import ctypes
@@ -41,14 +48,13 @@ def supported(layer, region_class, ndim, minvol, world_size=1):
     if getattr(layer, "has_wraps", False) or np.ndim(getattr(layer, "T", 1)) != 2:
         return False
     try:
-        import torch
-        return torch.cuda.is_available()
-    except ImportError:
+        return _lib.device_count() >= 1
+    except Exception:
         return False
 
 
-def _p(t):
-    return ctypes.c_void_p(t.data_ptr())
+def _p(a):
+    return a.ptr
 
 
 def _ellipsoid_axes(cov):
@@ -65,12 +71,9 @@ def _ellipsoid_axes(cov):
 
 
 class DeviceRebuild(object):
-    """One instance per RegionUpdater; keeps nothing between rebuilds but the torch device."""
+    """One instance per RegionUpdater; keeps nothing between rebuilds."""
 
     def __init__(self):
-        import torch
-        self.torch = torch
-        self.dev = torch.device("cuda", torch.cuda.current_device())
         from concurrent.futures import ThreadPoolExecutor
         self.pool = ThreadPoolExecutor(max_workers=2)
         self.trace = None     # a list: (label, seconds) checkpoints of the next call, each behind a device synchronisation
@@ -78,7 +81,7 @@ class DeviceRebuild(object):
     def _mark(self, label):
         if self.trace is not None:
             import time
-            self.torch.cuda.synchronize()
+            _lib.check(_lib.lib().mlf_synchronize())
             self.trace.append((label, time.perf_counter()))
 
     def next_region(self, active_u, layer, maxradiussq, nbootstraps):
@@ -100,23 +103,27 @@ class DeviceRebuild(object):
             raise
 
     def _next_region(self, active_u, layer, maxradiussq, nbootstraps):
-        torch, dev, L = self.torch, self.dev, _lib.lib()
+        L = _lib.lib()
+        DevArray = kernels.DevArray
         active_u = np.ascontiguousarray(active_u, dtype=np.float64)
         n, d = active_u.shape
+        nbytes = n * d * 8
         self._mark('start')
         # the bootstrap's selection masks (0.17 ms of host work) are drawn by a worker while the device starts: nothing
         # else touches np.random before they are used, so the stream is consumed exactly as by the default path
         draw_job = self._draw_job = self.pool.submit(regions._draw_selection, np.random, n, nbootstraps)
-        U = torch.from_numpy(active_u).to(dev)                       # the ONE upload of the live points
-        in_cube = bool(((U > 0) & (U < 1)).all().item())
+        U = DevArray.from_host(active_u)                              # the ONE upload of the live points
+        ulo, uhi = kernels.col_extent(U, n, d)                        # NaN propagates: a non-finite row fails the test
+        in_cube = bool((ulo > 0).all() and (uhi < 1).all())
         self._mark('upload + cube test')
         if not in_cube:
             ok = np.logical_and(active_u > 0, active_u < 1)
             raise ValueError("not all u values are between 0 and 1: %s" % active_u[~ok.all(axis=1)])
         # ---- create_new (mlfriends.pyx:712-735, 827-850): clusters in the OLD layer's space ------------------------
-        ctr_old = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(layer.ctr, (d,)), dtype=np.float64)).to(dev)
-        T_old = torch.from_numpy(np.ascontiguousarray(layer.T, dtype=np.float64)).to(dev)
-        t_old = torch.mm(U - ctr_old, T_old)
+        ctr_old = np.ascontiguousarray(np.broadcast_to(layer.ctr, (d,)), dtype=np.float64)
+        T_old = np.ascontiguousarray(layer.T, dtype=np.float64)
+        t_old = DevArray(nbytes)
+        _lib.check(L.mlf_affine_transform(_p(U), n, d, _lib.ptr(ctr_old), _lib.ptr(T_old), None, _p(t_old)))
         prev = None if layer.clusterids is None else np.ascontiguousarray(np.asarray(layer.clusterids)[:n], dtype=int_dtype)
         labels = np.empty(n, dtype=int_dtype)
         ncl = ctypes.c_int64(0)
@@ -131,40 +138,43 @@ class DeviceRebuild(object):
         nclusters = int(ncl.value)
         self._mark('old-layer whitening + cluster labels')
         if local:
-            centred = torch.empty_like(U)
+            centred = DevArray(nbytes)
             _lib.check(L.mlf_subtract_nearby(_p(U), n, d, float(maxradiussq), _p(centred)))   # u-space points, t-space radius (:844-849)
         elif nclusters == 1:
             centred = U
-        else:                                # cluster means removed; a singleton is centred on the global mean (:333-341)
-            lab = torch.from_numpy(labels).to(dev)
-            centred = torch.empty_like(U)
+        else:
+            # cluster means removed; a singleton is centred on the global mean (:333-341).  A handful of group means over
+            # an index set the host has just computed: the reference's own numpy statements on the host copy, one upload
+            chost = np.empty_like(active_u)
             everyone = None
             for cid in np.unique(labels):
-                members = lab == int(cid)
-                group = U[members]
+                members = labels == cid
+                group = active_u[members]
                 if group.shape[0] > 1:
-                    centre = group.mean(dim=0)
+                    centre = group.mean(axis=0)
                 else:
                     if everyone is None:
-                        everyone = U.mean(dim=0)
+                        everyone = active_u.mean(axis=0)
                     centre = everyone
-                centred[members] = group - centre
+                chost[members] = group - centre
+            centred = DevArray.from_host(chost)
         self._mark('neighbour-mean subtraction')
-        # ---- optimize (mlfriends.pyx:666-710) ----------------------------------------------------------------------
-        ctr_d = U.mean(dim=0)
-        # both covariances as ONE batched product over row slabs (a single 50 x 4000 x 50 GEMM runs on one tile of the
-        # chip: 0.3 ms each through torch.cov; 2 x 32 slab products are summed afterwards)
-        slabs = 32 if n % 32 == 0 and n >= 1024 else 1
-        both = torch.stack((centred - centred.mean(dim=0), U - ctr_d)).reshape(2 * slabs, n // slabs, d)
-        covs = torch.bmm(both.transpose(1, 2), both).reshape(2, slabs, d, d).sum(dim=1) * ((d + 2.0) / (n - 1.0))
-        amax_d = (U - ctr_d).abs().max().reshape(1)
-        small = torch.cat((ctr_d, covs.reshape(-1), amax_d)).cpu().numpy()
-        ctr = small[:d].copy()
-        cov = small[d:d + d * d].reshape(d, d).copy()
-        ecov = small[d + d * d:d + 2 * d * d].reshape(d, d).copy()    # wrapping ellipsoid of all live points (:447-476)
+        # ---- optimize (mlfriends.pyx:666-710): mean and covariance of the centred points (layer) and of the points
+        # themselves (wrapping ellipsoid, :447-476) -- the bootstrap's moment kernels with every row selected
+        ones = np.ones((1, n), dtype=np.uint8)
+        cmean, ccov = np.empty((1, d)), np.empty((1, d, d))
+        _lib.check(L.mlf_bootstrap_moments(_p(centred), n, d, _lib.ptr(ones), 1, _lib.ptr(cmean), _lib.ptr(ccov)))
+        if centred is U:
+            umean, ucov = cmean, ccov
+        else:
+            umean, ucov = np.empty((1, d)), np.empty((1, d, d))
+            _lib.check(L.mlf_bootstrap_moments(_p(U), n, d, _lib.ptr(ones), 1, _lib.ptr(umean), _lib.ptr(ucov)))
+        ctr = umean[0].copy()
+        cov = ccov[0] * (d + 2.0)
+        ecov = ucov[0] * (d + 2.0)
         cov = 0.5 * (cov + cov.T)
         ecov = 0.5 * (ecov + ecov.T)
-        amax = float(small[-1])
+        amax = float(max((uhi - ctr).max(), (ctr - ulo).max()))       # = max |u - ctr| (subtraction is monotone)
         # the wrapping ellipsoid's LAPACK calls (inv, two eigh: 0.35 ms) only need ecov: they run on a worker thread
         # next to the device calls below (ctypes and LAPACK both release the interpreter lock)
         assert np.isfinite(ecov).all(), ecov
@@ -176,7 +186,7 @@ class DeviceRebuild(object):
         logvolscale = 0.5 * np.sum(np.log(eigval))                   # = -0.5 slogdet(inv(cov))
         floor = eigval.max() * 1e-40
         eigval = np.where(eigval < floor, floor, eigval)
-        T = eigvec * eigval**-0.5
+        T = np.ascontiguousarray(eigvec * eigval**-0.5)
         invT = (eigvec * eigval**0.5).T
         _lib.check(label_job.result())
         nclusters = int(ncl.value)
@@ -185,15 +195,15 @@ class DeviceRebuild(object):
         nxt.logvolscale = logvolscale
         nxt.axes = invT
         self._mark('eigh, layer object')
-        # ---- region constructor (mlfriends.pyx:927-986) --------------------------------------------------------------
-        T_d = torch.from_numpy(np.ascontiguousarray(T)).to(dev)
-        unormed_d = torch.mm(U - ctr_d, T_d)
-        box = torch.cat((unormed_d.amin(dim=0), unormed_d.amax(dim=0)))
+        # ---- region constructor (mlfriends.pyx:927-986): the whitening chain of the region's own live points ----------
+        unormed_d = t_old                                              # its buffer is free again
+        _lib.check(L.mlf_affine_transform(_p(U), n, d, _lib.ptr(ctr), _lib.ptr(T), None, _p(unormed_d)))
+        bbox_lo, bbox_hi = kernels.col_extent(unormed_d, n, d)
         # ---- bootstrap (mlfriends.pyx:1017-1070): the draws are the default path's ----------------------------------------
         self._mark('new-layer whitening, box')
         self._draws_due = True
         masks = draw_job.result()
-        masks_d = torch.from_numpy(masks.view(np.uint8)).to(dev)
+        masks_d = DevArray.from_host(masks.view(np.uint8))
         self._mark('draw + upload of the selection masks')
         r2s = np.empty(nbootstraps)
         skipped = np.empty(nbootstraps, dtype=np.uint8)
@@ -203,8 +213,7 @@ class DeviceRebuild(object):
         maxd = maxf = 0.0
         if use.any():
             maxd = float(r2s[use].max())
-            sel_d = masks_d if use.all() else masks_d[torch.from_numpy(np.flatnonzero(use)).to(dev)].contiguous()
-            # (the library's stream is a blocking stream and torch runs on the legacy default stream here: implicitly ordered)
+            sel_d = masks_d if use.all() else DevArray.from_host(np.ascontiguousarray(masks[use]).view(np.uint8))
             f = np.empty(int(use.sum()))
             _lib.check(L.mlf_bootstrap_factor(_p(U), n, d, _p(sel_d), len(f), float(d + 2), _lib.ptr(f)))
             if not np.isfinite(f).all():
@@ -221,10 +230,9 @@ class DeviceRebuild(object):
         region.device_rng = None
         region._dev = regions._DeviceState()
         region.transformLayer = nxt
-        host = torch.cat((unormed_d.reshape(-1), box)).cpu().numpy()
-        region.unormed = host[:n * d].reshape(n, d)                    # a view of the array torch has just created
-        region.bbox_lo = host[n * d:n * d + d].copy()
-        region.bbox_hi = host[n * d + d:].copy()
+        region.unormed = unormed_d.to_host(np.float64, (n, d))
+        region.bbox_lo = bbox_lo
+        region.bbox_hi = bbox_hi
         region.maxradiussq = maxd
         region.enlarge = maxf
         region.sampling_methods = [region.sample_from_transformed_boundingbox, region.sample_from_boundingbox,
@@ -245,9 +253,8 @@ class DeviceRebuild(object):
                                use_scan=True, live_space=1, live_amax=amax)
         state.adopt(region, True)
         self._mark('region state on the device')
-        mask = torch.empty(n, dtype=torch.uint8, device=dev)
-        handle.inside_dev(U.data_ptr(), n, mask.data_ptr(), 0)
-        _lib.check(L.mlf_synchronize())
-        contains_live = bool(mask.all().item())
+        mask_d = DevArray(n)
+        handle.inside_dev(U.data_ptr(), n, mask_d.data_ptr(), 0)
+        contains_live = bool(mask_d.to_host(np.uint8, (n,)).all())
         self._mark('membership of the live points')
         return nxt, region, contains_live

@@ -72,6 +72,58 @@ def maxradiussq_bootstrap(unormed, selected, rows=None):
     return r2, skipped.astype(bool)
 
 
+class DevArray(object):
+    """A block of device memory owned by the library's allocator (mlf_dev_alloc): what ultranest_amd.device_rebuild keeps
+    its live points in between calls.  `ptr` goes wherever an entry point documents "host or device"."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        check(_lib.lib().mlf_dev_alloc(self.nbytes, ctypes.byref(p)))
+        self.ptr = p
+
+    @classmethod
+    def from_host(cls, array):
+        a = np.ascontiguousarray(array)
+        self = cls(a.nbytes)
+        self._src = a       # the copy is stream ordered: the source stays alive with the array
+        check(_lib.lib().mlf_dev_copy(self.ptr, ptr(a), a.nbytes, 0))
+        return self
+
+    def to_host(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(_lib.lib().mlf_dev_copy(ptr(out), self.ptr, out.nbytes, 1))
+        return out
+
+    def data_ptr(self):
+        return self.ptr.value
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            _lib.lib().mlf_dev_free(self.ptr)
+            self.ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def col_extent(pts, n=None, d=None):
+    """(lo[d], hi[d]) of the columns of an (n, d) float64 array: a numpy array or a DevArray (then n, d are required)."""
+    if isinstance(pts, DevArray):
+        p = pts.ptr
+    else:
+        pts = f64(pts)
+        n, d = pts.shape
+        p = ptr(pts)
+    lo, hi = np.empty(d), np.empty(d)
+    check(_lib.lib().mlf_col_extent(p, int(n), int(d), ptr(lo), ptr(hi)))
+    return lo, hi
+
+
 def _mask_arg(selected):
     """(pointer, B, n, keep-alive) of a (B, n) selection matrix: numpy bool / uint8 on the host, or a uint8 torch
     tensor on the device (the masks of a device-side broadcast stay where they are)."""
@@ -238,7 +290,7 @@ class DeviceRegion(object):
 
     def set_from_device(self, live_dev, n, d, layer_kind, layer_ctr, layer_T, wrap_shift, ell_center, ell_invcov,
                         enlarge, radiussq, use_scan=True, live_space=1, live_amax=None):
-        """`set` with the live points already on the device (`live_dev`: a C-contiguous float64 (n, d) torch tensor;
+        """`set` with the live points already on the device (`live_dev`: a C-contiguous float64 (n, d) DevArray or torch tensor;
         mlf_region_set takes host or device pointers for the point array).  `live_amax`: the largest |u - layer centre|
         coordinate if the caller knows it (otherwise the rows are fetched back once to find it)."""
         if live_amax is not None:
@@ -353,10 +405,15 @@ class DeviceRegion(object):
 
     def debug_stats(self):
         """Counters of the last filtered batch (see mlf_region_debug_stats in include/mlfriends_hip.h)."""
-        out = np.zeros(8, dtype=np.uint64)
-        check(_lib.lib().mlf_region_debug_stats(self._h, ptr(out), 8))
-        keys = ("ellipsoid_band", None, "uncertain_pairs", "largest_segment", "segments", "second_range_groups")
-        return {k: int(v) for k, v in zip(keys, out[:6]) if k}
+        out = np.zeros(16, dtype=np.uint64)
+        check(_lib.lib().mlf_region_debug_stats(self._h, ptr(out), 16))
+        keys = ("ellipsoid_band", None, "uncertain_pairs", "largest_segment", "segments", "second_range_groups",
+                "uncertain_queries")
+        stats = {k: int(v) for k, v in zip(keys, out[:7]) if k}
+        if out[8]:     # k_uncertain, workgroup 0: shader cycles between the stage boundaries of its first set
+            st = out[8:16].astype(np.int64)
+            stats["uncertain_stage_cycles"] = [int((st[i + 1] - st[i]) & 0xffffffff) for i in range(7) if st[i + 1]]
+        return stats
 
     def time_inside_dev(self, d_pts, npts, d_mask, stream=0, reps=3):
         tot, scan = ctypes.c_float(0), ctypes.c_float(0)
