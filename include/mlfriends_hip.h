@@ -68,6 +68,9 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *   "filter_split_waves"       waves a single-sweep launch over a small batch aims at when it splits the tiles (1-16 ranges)
  *   "fused_prep"               1/0: fused per-proposal stage, or k_prep followed by a separate quantisation
  *   "prep_bounded"             1/0: the bounded matrix-core per-proposal stage (split binary16) or the binary64 one
+ *   "sweep_min"                1 (default): two-range batches through the min-only sweep (k_sweep_min: running minima only
+ *                              in the two long launches, the proposals whose minimum ends in the band handled by
+ *                              k_uncertain); 0: k_sweep (per-tile band test) followed by the re-check launch
  *   "small_path"               1/0: mlf_region_inside with up to 256 proposals as ONE launch over pinned staging -- the calls
  *                              of the scalar step samplers -- or through the batched pipeline
  *   "time_filter_launches"     1/0: event pairs around every matrix-kernel launch (mlf_region_timing_filter_launch_ms)
