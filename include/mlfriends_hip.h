@@ -68,6 +68,8 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *   "filter_split_waves"       waves a single-sweep launch over a small batch aims at when it splits the tiles (1-16 ranges)
  *   "fused_prep"               1/0: fused per-proposal stage, or k_prep followed by a separate quantisation
  *   "prep_bounded"             1/0: the bounded matrix-core per-proposal stage (split binary16) or the binary64 one
+ *   "mid_max_queries"          default 2048: batches up to this size (and at least "filter_min_queries") run the per-proposal
+ *                              stage, the pre-filter sweep, the re-check and the answers in ONE launch (k_inside_mid); 0 = never
  *   "sweep_min"                1 (default): two-range batches through the min-only sweep (k_sweep_min: running minima only
  *                              in the two long launches, the proposals whose minimum ends in the band handled by
  *                              k_uncertain); 0: k_sweep (per-tile band test) followed by the re-check launch

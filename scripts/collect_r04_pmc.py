@@ -1,0 +1,57 @@
+"""Round-4 PMC summary: per kernel of the C5 membership pipeline (scripts/stage_profile.py under rocprofv3 --pmc, separate
+passes: matrix / instruction counters, wait split, FETCH_SIZE, WRITE_SIZE) -> profiles/r04_pmc_summary.json.
+    python scripts/collect_r04_pmc.py gpurun_out/r04h profiles/r04"""
+import csv
+import json
+import re
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+
+
+def table(path):
+    out, name = {}, None
+    for line in open(path):
+        if line.startswith(" "):
+            k, v = line.split()[:2]
+            out[name][k] = float(v)
+        elif line.strip():
+            name = line.strip()
+            out[name] = {}
+    return out
+
+
+sq, wait = table(src + "_pmc_sq.txt"), table(src + "_pmc_wait.txt")
+fetch, write = table(src + "_pmc_FETCH_SIZE.txt"), table(src + "_pmc_WRITE_SIZE.txt")
+stats = {}
+import glob
+for f in glob.glob(src + "_stats/*kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        stats[r["Name"][:44]] = float(r["AverageNs"]) * 1e-6
+summary = {}
+for k in sq:
+    if not k.startswith(("void mlf::k_sweep_min", "void mlf::k_uncertain", "void mlf::k_prep4", "void mlf::k_scan", "mlf::k_recheck")):
+        continue
+    a, w = sq[k], wait.get(k, {})
+    cycles = a["GRBM_GUI_ACTIVE"] / 8.0                      # per XCD = launch duration in shader cycles
+    ms = stats.get(k)
+    e = dict(avg_ms_kernel_stats=ms, launch_cycles=cycles, clock_GHz=(cycles / (ms * 1e6)) if ms else None,
+             SQ_INSTS_MFMA=a["SQ_INSTS_MFMA"], SQ_INSTS_VALU=a["SQ_INSTS_VALU"], SQ_INSTS_SALU=a["SQ_INSTS_SALU"],
+             matrix_pipe_busy=a["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cycles if cycles else None,
+             non_matrix_instructions_per_matrix_instruction=((a["SQ_INSTS_VALU"] + a["SQ_INSTS_SALU"]) / a["SQ_INSTS_MFMA"]) if a["SQ_INSTS_MFMA"] else None,
+             executed_TFLOPs=(a["SQ_INSTS_MFMA"] * 32768.0 / (ms * 1e-3) / 1e12) if ms else None)
+    if w:
+        e.update(wave_cycles_quads=w["SQ_WAVE_CYCLES"], parked_in_s_waitcnt=w["SQ_WAIT_ANY"] / w["SQ_WAVE_CYCLES"],
+                 issue_stalled=w["SQ_WAIT_INST_ANY"] / w["SQ_WAVE_CYCLES"], issuing=w["SQ_ACTIVE_INST_ANY"] / w["SQ_WAVE_CYCLES"],
+                 waves=w["SQ_WAVES"])
+    if k in fetch and k in write:
+        # MI355X_MICROARCH.md, HBM / rocprofv3: FETCH_SIZE and WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts 32-byte units of
+        # 64-byte requests once: bytes = (2 FETCH_SIZE + WRITE_SIZE) x 1024
+        e["hbm_bytes_gfx950_corrected"] = (2.0 * fetch[k]["FETCH_SIZE"] + write[k]["WRITE_SIZE"]) * 1024.0
+        e["FETCH_SIZE_KiB"], e["WRITE_SIZE_KiB"] = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
+    summary[k] = e
+tot = sum(v.get("hbm_bytes_gfx950_corrected", 0.0) for v in summary.values())
+summary["_per_step"] = dict(hbm_bytes_all_kernels=tot, algorithmic_bytes=402640000, ratio=tot / 402640000.0,
+                            kernel_ms_sum=sum(v["avg_ms_kernel_stats"] or 0.0 for k, v in summary.items() if not k.startswith("_")))
+json.dump(summary, open(dst + "_pmc_summary.json", "w"), indent=1)
+print(json.dumps(summary, indent=1))

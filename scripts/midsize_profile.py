@@ -33,4 +33,6 @@ for p in sizes:
         handle.inside_dev(pts.data_ptr(), p, mask.data_ptr(), stream)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 200
-    print(json.dumps(dict(batch=p, us_per_call=round(dt * 1e6, 2), proposals_per_s=round(p / dt), accept=float(mask.float().mean().item()))), flush=True)
+    st = handle.debug_stats()
+    print(json.dumps(dict(batch=p, us_per_call=round(dt * 1e6, 2), proposals_per_s=round(p / dt), accept=float(mask.float().mean().item()),
+                          stage_cycles=st.get("uncertain_stage_cycles"), band_pairs_of_wave_0=st.get("stamp7"))), flush=True)

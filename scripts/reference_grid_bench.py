@@ -107,7 +107,7 @@ def benchmark_transform():
             if CPU:
                 from oracle import oracle as orc
                 niter, total = 0, 0.0
-                ctr = np.ascontiguousarray(np.broadcast_to(layer.ctr, (ndim,)), dtype=float)
+                ctr = np.ascontiguousarray(np.broadcast_to(layer.ctr if lname == "affine" else layer.mean, (ndim,)), dtype=float)
 
                 def port_inside(u):      # R3 = H3 -> T1 -> K1 (mlfriends.pyx:1186-1211) on the C port
                     mask = orc.inside_ellipsoid(u, region.ellipsoid_center, region.ellipsoid_invcov, region.enlarge)

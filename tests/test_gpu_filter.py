@@ -13,21 +13,32 @@ FUZZ_OFFSET = int(os.environ.get("MLF_FUZZ_OFFSET", "0"))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["phased", "single-sweep"])
+@pytest.fixture(scope="module", params=["phased", "single-sweep", "one-launch"])
 def K(request):
-    """Every test runs twice: with the phased sweep (undecided queries compacted between live-point ranges, inside the
-    matrix kernel's epilogue) forced on for small batches, and with the single sweep."""
+    """Every test runs three times: with the phased sweep (undecided queries compacted between live-point ranges; the
+    min-only kernels of mlf_sweepmin.hip) forced on for small batches, with the single sweep (k_sweep with its own
+    re-check), and with the one-launch path of mlf_mid.hip that batches of this size take by default."""
     from ultranest_amd import _lib, kernels
     assert _lib.device_count() >= 1
     _lib.set_option("filter", 1)
     _lib.set_option("filter_min_queries", 64)      # let small test batches take the filter path
     _lib.set_option("filter_phases", 0 if request.param == "single-sweep" else 1)
     _lib.set_option("filter_phase_min_queries", 64)
+    _lib.set_option("mid_max_queries", 131072 if request.param == "one-launch" else 0)
+    _MODE["param"] = request.param
     yield kernels
     _lib.set_option("filter_min_queries", 257)
     _lib.set_option("filter_phase_min_queries", 32768)
     _lib.set_option("filter_phases", 1)
+    _lib.set_option("mid_max_queries", 2048)
     _lib.set_option("filter", 1)
+
+
+_MODE = {"param": "phased"}
+
+
+def request_param_one_launch():
+    return _MODE["param"] == "one-launch"
 
 
 def _find(K, apts, bpts, r2, filt):
@@ -244,11 +255,15 @@ def test_region_inside_random_shapes_filter_equals_exact_scan(seed, K):
     reg.set(u, 0, ctr, T, None, ctr, inv, enlarge, r2, live_space=1)
     got = {}
     for name, opts in (("default", {}), ("exact", {"filter": 0}), ("binary64 stage", {"prep_bounded": 0}),
-                       ("single sweep", {"filter_phases": 0}), ("wide tail", {"filter_narrow_tail": 0})):
+                       ("single sweep", {"filter_phases": 0}), ("wide tail", {"filter_narrow_tail": 0}),
+                       ("one launch", {"mid_max_queries": 131072}), ("three launches", {"mid_max_queries": 0}),
+                       ("per-tile band test", {"mid_max_queries": 0, "sweep_min": 0})):
+        mid_before = 131072 if request_param_one_launch() else 0
         for k, v in opts.items():
             _lib.set_option(k, v)
         got[name] = reg.inside(pts)
-        for k, v in (("filter", 1), ("prep_bounded", 1), ("filter_phases", 1), ("filter_narrow_tail", 1)):
+        for k, v in (("filter", 1), ("prep_bounded", 1), ("filter_phases", 1), ("filter_narrow_tail", 1), ("sweep_min", 1),
+                     ("mid_max_queries", mid_before)):
             _lib.set_option(k, v)
     reg.close()
     wrong = {name: (np.flatnonzero(m != got["exact"])[:5].tolist(), m[np.flatnonzero(m != got["exact"])[:5]].tolist())

@@ -66,12 +66,13 @@ enum Opt : int {
   OPT_PREP_BOUNDED,        // "prep_bounded" 0/1: bounded matrix-core per-proposal stage (mlf_prep4.hip) or the binary64 one
   OPT_MIN_QUERIES,         // "filter_min_queries": smaller batches go straight to the exact scan
   OPT_SWEEP_MIN,           // "sweep_min" 0/1: two-range batches through the min-only sweep (mlf_sweepmin.hip) or k_sweep
+  OPT_MID_MAX,             // "mid_max_queries": batches up to this size take the one-launch path (mlf_mid.hip); 0 = never
   OPT_COUNT
 };
 const char *const kOptNames[OPT_COUNT] = {"filter", "filter_first_range_pct", "filter_split_waves", "filter_narrow_tail",
                                           "small_path", "fused_prep", "filter_phase_min_queries", "filter_phases",
-                                          "time_filter_launches", "prep_bounded", "filter_min_queries", "sweep_min"};
-long long g_opt[OPT_COUNT] = {1, 50, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1};
+                                          "time_filter_launches", "prep_bounded", "filter_min_queries", "sweep_min", "mid_max_queries"};
+long long g_opt[OPT_COUNT] = {1, 50, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048};
 
 struct OptOverrides {
   long long v[OPT_COUNT] = {};
@@ -90,6 +91,7 @@ long long opt_clamp(int id, long long value) {
     case OPT_SPLIT_WAVES: return value < 256 ? 256 : (value > 16384 ? 16384 : value);
     case OPT_PHASES: return value < 0 ? 0 : (value > 64 ? 64 : value);
     case OPT_PHASE_MIN_QUERIES:
+    case OPT_MID_MAX:
     case OPT_MIN_QUERIES: return value;
     default: return value != 0;
   }
@@ -104,6 +106,8 @@ struct FilterCtx {
   DevBuf stats, statscratch, refF, qF, tlo, thi, route, best, counters, list, segcnt, gate2;
   // phased sweep: two compacted query sets (ping-pong)
   DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png, pmin;
+  DevBuf mid_rec, mid_meta, mid_arrive;   // one-launch path (mlf_mid.hip): records of the tile ranges, arrival counters
+  bool mid_last = false;                  // the last batch took that path (debug_stats)
   // bounded per-proposal stage (mlf_prep4.hip): ellipsoid band list, per-call counters
   // misc: [0] band proposals, [1] k_ell_exact workgroups done -- both return to zero by themselves (no memset per batch),
   // zeroed once when the buffer is allocated; [2], [3] "a proposal is routed to the exact scan", used alternately by
@@ -120,7 +124,7 @@ struct FilterCtx {
   OptOverrides ov;            // per-handle tuning (mlf_region_set_option); the stateless calls' context has none
   void release() {
     DevBuf *b[] = {&stats, &statscratch, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2,
-                   &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png, &pmin,
+                   &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png, &pmin, &mid_rec, &mid_meta, &mid_arrive,
                    &ell_list, &misc};
     for (DevBuf *x : b) x->release();
     refs_ready = usable = false;
@@ -387,6 +391,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   const long long ngroups = (nq + 31) / 32;
   const long long nqpad = ngroups * 32;
   unsigned cap = 0;
+  f.mid_last = false;
   if (int rc = filter_reserve(f, nq, &cap)) return rc;
   if (!quantised)
   launch_quant_queries(q, ldq, nq, nqpad, d, dp, f.ks, f.stats.as<double>(), r2, gate, f.qF.p, f.tlo.as<float>(),
@@ -1005,6 +1010,94 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
   ExactSrc xsrc{};
   if (r->use_scan && !bounded) CK(r->tq.reserve(np * (size_t)r->d * sizeof(double)));
   if (ev) CK(hipEventRecord(ev[0], s));
+  // The batch sizes of a real run (ndraw 128 ... 65536): per-proposal stage, sweep, re-check and answers in ONE launch
+  // (mlf_mid.hip); the exact-scan launch behind it only works if a proposal was routed to it.
+  const bool mid = bounded && r->use_scan && use_filter && !pregate && !d_idx && r->filter.ks <= 4 && mid_usable(r->dp) &&
+                   (long long)np <= opt(r->filter, OPT_MID_MAX);
+  if (mid) {
+    FilterCtx &f = r->filter;
+    if (int rc = misc_reserve(f)) return rc;
+    CK(f.route.reserve(np));
+    CK(f.counters.reserve(4 * sizeof(unsigned)));
+    const long long ngroups = ((long long)np + 31) / 32, nsets = (ngroups + 3) / 4;
+    const int ny = mid_range_quads(ngroups, f.ntiles32), R = 4 * ny;
+    CK(f.mid_rec.reserve((size_t)nsets * R * 3 * sizeof(unsigned long long)));
+    CK(f.mid_meta.reserve((size_t)nsets * 4 * sizeof(unsigned long long)));
+    {
+      const size_t before = f.mid_arrive.cap;
+      CK(f.mid_arrive.reserve((size_t)nsets * sizeof(unsigned)));
+      if (f.mid_arrive.cap != before) CK(hipMemsetAsync(f.mid_arrive.p, 0, f.mid_arrive.cap, s));   // they return to zero by themselves afterwards
+    }
+    MidArgs ma{};
+    ma.pts = d_pts;
+    ma.np = (long long)np;
+    ma.d = r->d;
+    ma.dp = r->dp;
+    ma.ks = f.ks;
+    ma.LtF = r->p4_LtF.p;
+    ma.y0 = r->p4_y0.as<float>();
+    ma.TtF = r->p4_TtF.p;
+    ma.lay_ctr = r->lay_ctr.as<double>();
+    ma.c = r->p4c;
+    ma.c.enl_lo = f32_dn(r->enlarge);
+    ma.c.enl_hi = f32_up(r->enlarge);
+    ma.stats = f.stats.as<double>();
+    ma.r2 = r->r2;
+    ma.ell_ctr = r->ell_ctr.as<double>();
+    ma.ell_L = r->ell_L.as<double>();
+    ma.ell_A = r->ell_A.as<double>();
+    ma.ell_eps_scale = r->ell_eps_scale;
+    ma.enlarge = r->enlarge;
+    ma.chol_ok = r->chol_ok ? 1 : 0;
+    ma.refF = f.refF.p;
+    ma.ntiles32 = f.ntiles32;
+    ma.refR = r->refR.as<double>();
+    ma.n = r->n;
+    ma.T64 = r->lay_T64.as<double>();
+    ma.rec = f.mid_rec.as<unsigned long long>();
+    ma.meta = f.mid_meta.as<unsigned long long>();
+    ma.arrive = f.mid_arrive.as<unsigned>();
+    ma.mask = d_mask;
+    ma.route = f.route.as<uint8_t>();
+    f.batch_parity ^= 1u;
+    ma.scan_flag = f.misc.as<unsigned>() + 2 + f.batch_parity;
+    ma.counters = f.counters.as<unsigned>();
+    if (opt(f, OPT_TIME_LAUNCHES)) {   // diagnostics: stage stamps of workgroup (0, 0) (mlf_region_debug_stats)
+      CK(f.segcnt.reserve(16 * sizeof(unsigned)));
+      ma.stamps = f.segcnt.as<unsigned>();
+    }
+    f.mid_last = ma.stamps != nullptr;
+    CK(launch_inside_mid(ma, ny, s));
+    if (ev) {
+      CK(hipEventRecord(ev[1], s));
+      CK(hipEventRecord(ev[2], s));
+    }
+    ScanArgs a{};   // proposals the pre-filter cannot take (route 2): the exact scan, idle unless the batch's flag is up
+    a.refT = r->refT.as<double>();
+    a.n = r->n;
+    a.npad = r->npad;
+    a.ntiles = r->npad / kWave;
+    a.q = d_pts;
+    a.ldq = r->d;
+    a.ldk = 1;
+    a.nq = (long long)np;
+    a.d = r->d;
+    a.r2 = r->r2;
+    a.mode = SCAN_MASK;
+    a.out_mask = d_mask;
+    a.only_gated = 1;
+    a.raw_ctr = r->lay_ctr.as<double>();
+    a.raw_T8 = r->lay_T8.as<double>();
+    a.raw_ldt = (r->dp + 7) / 8 * 8;
+    a.route = f.route.as<uint8_t>();
+    a.counters = f.counters.as<unsigned>();
+    a.any_flag = f.misc.as<unsigned>() + 2 + f.batch_parity;
+    a.fin_reset = f.misc.as<unsigned>() + 2 + (f.batch_parity ^ 1u);
+    CK(launch_scan(r->dp, a, s));
+    f.last_nsegs = 0;
+    if (ev) CK(hipEventRecord(ev[3], s));
+    return 0;
+  }
   if (bounded) {   // matrix cores (split binary16): bounded ellipsoid test + approximate whitening straight into the filter operand
     FilterCtx &f = r->filter;
     if (int rc = misc_reserve(f)) return rc;
@@ -2547,7 +2640,11 @@ int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap) {
     CK(hipMemcpy(g, f.png.p, sizeof g, hipMemcpyDeviceToHost));
     out[5] = g[0];
     if (cap > 6) out[6] = g[1];   // queries of the last min-only batch whose minimum ended in the band (uncertain set)
-    if (cap >= 16 && f.last_nsegs == (size_t)uncertain_blocks() && f.segcnt.cap >= (f.last_nsegs + 8) * sizeof(unsigned)) {
+    if (cap >= 16 && f.mid_last && f.segcnt.p) {   // k_inside_mid, workgroup (0, 0): stage boundaries
+      unsigned st[8];
+      CK(hipMemcpy(st, f.segcnt.p, sizeof st, hipMemcpyDeviceToHost));
+      for (int i = 0; i < 8; ++i) out[8 + i] = st[i];
+    } else if (cap >= 16 && f.last_nsegs == (size_t)uncertain_blocks() && f.segcnt.cap >= (f.last_nsegs + 8) * sizeof(unsigned)) {
       unsigned st[8];   // shader-clock stamps of k_uncertain's workgroup 0 (stage boundaries of its first set)
       CK(hipMemcpy(st, f.segcnt.as<unsigned>() + uncertain_stamp_base(), sizeof st, hipMemcpyDeviceToHost));
       for (int i = 0; i < 8; ++i) out[8 + i] = st[i];

@@ -99,6 +99,47 @@ hipError_t launch_uncertain(int ks, const UncertainArgs &a, hipStream_t s);
 long long uncertain_blocks();
 __host__ __device__ constexpr unsigned uncertain_stamp_base() { return 256u; }   // = uncertain_blocks(): 8 diagnostic words behind the per-workgroup counts
 
+// ---- one launch for the batch sizes of a real run (mlf_mid.hip) ----
+struct MidArgs {
+  // per-proposal stage (k_prep4's)
+  const double *pts;      // (np, d) row-major proposals, 16-byte aligned
+  long long np;
+  int d, dp, ks;
+  const void *LtF;
+  const float *y0;
+  const void *TtF;
+  const double *lay_ctr;
+  Prep4Consts c;
+  const double *stats;    // [0] sigma, [1] namax, [8 + c] centre of the whitened live points
+  double r2;
+  // exact ellipsoid test of the band proposals
+  const double *ell_ctr, *ell_L, *ell_A;
+  double ell_eps_scale, enlarge;
+  int chol_ok;
+  // sweep + re-check
+  const void *refF;
+  int ntiles32;
+  const double *refR;     // [npad][dp]
+  int n;
+  const double *T64;
+  // hand-off between the tile ranges of a set
+  unsigned long long *rec;    // [nsets][R][3]
+  unsigned long long *meta;   // [nsets][4]
+  unsigned *arrive;           // [nsets], zero between batches
+  // answers
+  uint8_t *mask;
+  uint8_t *route;             // 2 = left to the exact scan launch that follows
+  unsigned *scan_flag;
+  unsigned *counters;
+  unsigned *stamps;           // optional: 8 diagnostic words
+};
+#define MLF_FOR_EACH_DP_MID(X)                                                                \
+  X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) \
+  X(36) X(40) X(44) X(48) X(50) X(52) X(56)
+bool mid_usable(int dp);
+int mid_range_quads(long long ngroups, int ntiles32);
+hipError_t launch_inside_mid(const MidArgs &a, int ny, hipStream_t s);
+
 // after a compacting launch: group count of the compacted set, padding of its last group, counter reset
 void launch_phase_finish(void *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount, unsigned *ngroups_dst,
                          int ks, hipStream_t s);

@@ -66,6 +66,9 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     }
     return;
   }
+  // no tail in this launch (the one-launch path of mlf_mid.hip writes its own answers): the flag word of the NEXT batch
+  // is cleared here
+  if (EXTRA && !a.fin_best && a.fin_reset && blockIdx.x == 0 && tid == 0) *a.fin_reset = 0u;
   const unsigned scan_blocks = (EXTRA && a.fin_best) ? a.fin_grid0 : gridDim.x;
   const bool overflow = EXTRA && a.route && a.counters[1] != 0u;
   if (EXTRA && a.any_flag && *a.any_flag == 0u && !overflow) return;   // nothing was routed to the exact scan

@@ -412,7 +412,8 @@ class DeviceRegion(object):
         stats = {k: int(v) for k, v in zip(keys, out[:7]) if k}
         if out[8]:     # k_uncertain, workgroup 0: shader cycles between the stage boundaries of its first set
             st = out[8:16].astype(np.int64)
-            stats["uncertain_stage_cycles"] = [int((st[i + 1] - st[i]) & 0xffffffff) for i in range(7) if st[i + 1]]
+            stats["uncertain_stage_cycles"] = [int((st[i + 1] - st[i]) & 0xffffffff) for i in range(6) if st[i + 1]]
+            stats["stamp7"] = int(st[7])
         return stats
 
     def time_inside_dev(self, d_pts, npts, d_mask, stream=0, reps=3):
