@@ -140,8 +140,9 @@ __device__ __forceinline__ void recheck_segment(const RecheckWArgs &a, const uns
       double acc[kTQ];
 #pragma unroll
       for (int t = 0; t < kTQ; ++t) acc[t] = 0.0;
-      if (nr <= 2u) {   // the common case: keep the chains short
-#pragma unroll 10
+      if (nr <= 2u) {   // the common case: keep the chains short; 25 rows of the matrix requested at a time (ten: five L2 round
+                        // trips of ~0.6 us each in a chain that is all latency)
+#pragma unroll 25
         for (int k = 0; k < d; ++k) {
           const double tk = tp[k * 64];
           acc[0] = __builtin_fma(dlw[k], tk, acc[0]);
@@ -164,8 +165,8 @@ __device__ __forceinline__ void recheck_segment(const RecheckWArgs &a, const uns
         const double *br = tq + (myid - r0) * ds;
         double accd = 0.0;
         const int d2 = d >> 1;
-#pragma unroll 5
-        for (int k2 = 0; k2 < d2; ++k2) {   // the reference's loop: sub, mul, add, each rounded, k ascending
+#pragma unroll 13
+        for (int k2 = 0; k2 < d2; ++k2) {   // the reference's loop: sub, mul, add, each rounded, k ascending (26 coordinates requested at a time)
           const double2 av = ar[k2];
           const double d0 = av.x - br[2 * k2];
           accd += d0 * d0;
