@@ -68,6 +68,9 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *   "filter_split_waves"       waves a single-sweep launch over a small batch aims at when it splits the tiles (1-16 ranges)
  *   "fused_prep"               1/0: fused per-proposal stage, or k_prep followed by a separate quantisation
  *   "prep_bounded"             1/0: the bounded matrix-core per-proposal stage (split binary16) or the binary64 one
+ *   "fused_first_range"        1: on the min-only path the per-proposal stage runs inside the first sweep launch (k_prep_sweep:
+ *                              the binary16 operand never leaves the registers, 256 MB less HBM traffic per 10^6 x 50 batch);
+ *                              0 (default): k_prep4, then k_sweep_min -- measured 3 % faster
  *   "mid_max_queries"          default 2048: batches up to this size (and at least "filter_min_queries") run the per-proposal
  *                              stage, the pre-filter sweep, the re-check and the answers in ONE launch (k_inside_mid); 0 = never
  *   "sweep_min"                1 (default): two-range batches through the min-only sweep (k_sweep_min: running minima only

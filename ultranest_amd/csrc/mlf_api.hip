@@ -67,12 +67,13 @@ enum Opt : int {
   OPT_MIN_QUERIES,         // "filter_min_queries": smaller batches go straight to the exact scan
   OPT_SWEEP_MIN,           // "sweep_min" 0/1: two-range batches through the min-only sweep (mlf_sweepmin.hip) or k_sweep
   OPT_MID_MAX,             // "mid_max_queries": batches up to this size take the one-launch path (mlf_mid.hip); 0 = never
+  OPT_FUSED_FIRST,         // "fused_first_range" 0/1: per-proposal stage and first range of the min-only sweep in one launch (mlf_fused.hip)
   OPT_COUNT
 };
 const char *const kOptNames[OPT_COUNT] = {"filter", "filter_first_range_pct", "filter_split_waves", "filter_narrow_tail",
                                           "small_path", "fused_prep", "filter_phase_min_queries", "filter_phases",
-                                          "time_filter_launches", "prep_bounded", "filter_min_queries", "sweep_min", "mid_max_queries"};
-long long g_opt[OPT_COUNT] = {1, 50, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048};
+                                          "time_filter_launches", "prep_bounded", "filter_min_queries", "sweep_min", "mid_max_queries", "fused_first_range"};
+long long g_opt[OPT_COUNT] = {1, 50, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 0};
 
 struct OptOverrides {
   long long v[OPT_COUNT] = {};
@@ -382,7 +383,18 @@ struct ExactSrc {
   const double *T8;   // row-major layer matrix, row stride ldt
   int ldt;
   const double *T64;  // the same as 64 x 64, zero padded (d <= 64)
+  const Prep4Args *prep;   // not null: the per-proposal stage has NOT run yet -- the min-only path runs it inside its first launch
 };
+
+// does a batch of nq queries take the two-range min-only path?  (the phase rule of filter_run)
+bool filter_takes_min_path(const FilterCtx &f, long long nq) {
+  const int want_phases = (int)opt(f, OPT_PHASES);
+  const long long phase_min = opt(f, OPT_PHASE_MIN_QUERIES);
+  int nphase = 1;
+  if (want_phases && nq >= phase_min && (phase_min < 32768 || nq * f.ntiles32 >= 30000000ll))
+    nphase = want_phases >= 2 ? (want_phases <= f.ntiles32 / 4 ? want_phases : (f.ntiles32 >= 16 ? 2 : 1)) : (f.ntiles32 >= 16 ? 2 : 1);
+  return nphase == 2 && f.ks <= 4 && opt(f, OPT_SWEEP_MIN);
+}
 
 int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int npad, int d, int dp,
                const double *q, long long ldq, long long ldk, long long nq, double r2, const uint8_t *gate,
@@ -464,6 +476,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   // launches carry the running minimum only; the queries whose minimum ends in the band are swept once more by
   // k_uncertain (band pairs found, queries whitened, pairs decided in one launch), which also carries the ellipsoid band.
   const bool min_path = fold_finish && out_idx == nullptr && f.ks <= 4 && opt(f, OPT_SWEEP_MIN);
+  if (xs && xs->prep && !min_path) CK(launch_prep4(*xs->prep, s));   // (the caller's forecast and this routing agree: belt and braces)
   if (min_path) {
     const long long lw = uncertain_blocks();
     CK(f.segcnt.reserve((size_t)(lw + 8) * sizeof(unsigned)));
@@ -507,7 +520,22 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     m.cmin = f.pmin.as<int>();
     m.ccount = f.png.as<unsigned>() + 2;
     m.last = 0;
-    if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, 0), m, s); })) return rc;
+    if (xs->prep) {   // per-proposal stage + first range in one launch: the operand never leaves the registers
+      FusedArgs fu{};
+      fu.p = *xs->prep;
+      fu.refF = f.refF.p;
+      fu.ntiles32 = f.ntiles32;
+      fu.tile0 = 0;
+      fu.tile1 = c;
+      fu.cq = m.cq;
+      fu.ctlo = m.ctlo;
+      fu.cthi = m.cthi;
+      fu.cmap = m.cmap;
+      fu.cmin = m.cmin;
+      fu.ccount = m.ccount;
+      fu.ccap = m.ccap;
+      if (int rc = timed([&] { return launch_prep_sweep(fu, s); })) return rc;
+    } else if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, 0), m, s); })) return rc;
     // second range: set 0 with its minima; the uncertain queries go to set 1
     m.tile0 = c;
     m.tile1 = f.ntiles32;
@@ -524,7 +552,9 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     m.cmin = nullptr;
     m.ccount = f.png.as<unsigned>() + 3;
     m.last = 1;
-    if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, narrow_tail), m, s); })) return rc;
+    // four query groups per wave here too: with the min-only loop the narrow form (two groups, twice the waves) that paid for
+    // k_sweep's second range loses (0.080 against 0.085-0.088 ms; profiles/r04_first_range_ab.jsonl)
+    if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, 0), m, s); })) return rc;
     // the uncertain set: band pairs, exact whitening, exact distances -- one launch; the ellipsoid band rides along
     UncertainArgs ua{};
     ua.refF = f.refF.p;
@@ -1140,7 +1170,16 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
       xsrc.ldt = (r->dp + 7) / 8 * 8;
       xsrc.T64 = r->lay_T64.as<double>();
     }
-    CK(launch_prep4(pa, s));
+    // large batches on the min-only path: the per-proposal stage runs inside the first sweep launch (mlf_fused.hip)
+    const bool defer_prep = r->use_scan && use_filter && !pregate && !d_idx && opt(f, OPT_FUSED_FIRST) && fused_usable(r->dp) &&
+                            filter_takes_min_path(f, (long long)np);
+    static thread_local Prep4Args deferred;
+    if (defer_prep) {
+      deferred = pa;
+      xsrc.prep = &deferred;
+    } else {
+      CK(launch_prep4(pa, s));
+    }
     EllExactArgs ea{};
     ea.count = f.misc.as<unsigned>();
     ea.done = f.misc.as<unsigned>() + 1;

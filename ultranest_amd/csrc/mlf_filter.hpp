@@ -140,6 +140,21 @@ bool mid_usable(int dp);
 int mid_range_quads(long long ngroups, int ntiles32);
 hipError_t launch_inside_mid(const MidArgs &a, int ny, hipStream_t s);
 
+// ---- per-proposal stage + first range of the min-only sweep in one launch (mlf_fused.hip) ----
+struct FusedArgs {
+  Prep4Args p;           // qF / tlo / thi are not written (the operand never leaves the registers)
+  const void *refF;
+  int ntiles32;
+  int tile0, tile1;
+  void *cq;              // the proposals without a certain hit: fragments, thresholds, query, minimum
+  float *ctlo, *cthi;
+  int *cmap, *cmin;
+  unsigned *ccount;
+  unsigned ccap;
+};
+bool fused_usable(int dp);
+hipError_t launch_prep_sweep(const FusedArgs &a, hipStream_t s);
+
 // after a compacting launch: group count of the compacted set, padding of its last group, counter reset
 void launch_phase_finish(void *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount, unsigned *ngroups_dst,
                          int ks, hipStream_t s);

@@ -1,0 +1,508 @@
+// mlf_fused.hip -- the per-proposal stage of MLFriends.inside (H3 ellipsoid test + T1 whitening, mlfriends.pyx:882-912,
+// 737-743: k_prep4's bounded split-binary16 form, mlf_prep4.hip) and the FIRST live-point range of the min-only sweep
+// (k_sweep_min, mlf_sweepmin.hip) in ONE launch for the large batches.
+//
+// k_prep4 is HBM bound (reads 8 d bytes per proposal, 0.115 ms per 10^6 x 50 at 4.7 TB/s) and leaves the matrix cores 87 %
+// idle; k_sweep_min is matrix bound and leaves HBM idle; between them the binary16 operand makes a 128 MB write + 128 MB
+// read round trip (per-step traffic 2.2x the algorithmic bytes).  After the per-proposal stage of a query group a lane
+// HOLDS its 8-column pieces of the filter operand (the row order of T^T), so a wave that prepares its own four groups can
+// sweep them straight from its registers: no operand array, no thresholds array, and the waves that are fetching rows run
+// next to the ones that are multiplying.
+//   workgroup = 8 waves (one per CU: 28 KiB of matrix fragments shared + a 13.5 KiB row buffer per wave), wave = one set of
+//   4 query groups: group g's rows travel to LDS while group g - 1 is processed (k_prep4's pipeline), its fragments and
+//   thresholds stay in registers; then k_sweep_min's tile loop over the first range and its epilogue (certain hits -> best,
+//   the rest compacted with their minima, one atomic per workgroup).
+// Everything k_prep4 wrote for the later stages is written here too: gate, route, best = none, the ellipsoid band list.
+// (Round 2 measured this fusion with k_filter's loop: 395 against 112 + 273 us; with the min-only loop see DESIGN 4f.)
+#include "mlf_filter.hpp"
+#include "mlf_filter_dev.hpp"
+#include "mlf_prep4.hpp"
+
+#include <math.h>
+
+namespace mlf {
+
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <int DP>
+struct F4 {
+  static constexpr int NS = (DP + 15) / 16;
+  static constexpr int KS = (DP + 6 + 15) / 16;
+  static constexpr int NT = (KS + 1) / 2;
+  static constexpr int NE = (DP + 31) / 32;
+  static constexpr int KMIN = DP <= 32 ? DP - 1 : (DP == 50 ? 49 : DP - 3);
+  static constexpr int NLT = NS + (NE > 1 ? NS - 2 : 0);
+  static constexpr int NPC = (DP + 3) / 4;
+  static constexpr size_t r16(size_t x) { return (x + 15) / 16 * 16; }
+  static constexpr size_t WAVE = r16((size_t)NPC * 1024 + 512);
+  static constexpr size_t FRAG = (size_t)(2 * NT * NS + 2 * NLT) * 1024 + (size_t)(32 * NE + 32 * NT) * 4 + (size_t)(16 * NS) * 8;
+  static constexpr size_t LDS = r16(FRAG) + 8 * WAVE + 64;   // + the workgroup's compaction counts (all LDS in the dynamic region)
+};
+
+__host__ __device__ inline int f4_column(int t, int i) {
+  return 32 * t + 16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3);
+}
+__device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ int min3i(int a, int b, int c) {
+  const int m = a < b ? a : b;
+  return m < c ? m : c;
+}
+constexpr int kPosInf = 0x7f800000;
+__device__ __forceinline__ int tree_min(const float16v &c, int run) {
+  const int m0 = min3i(__float_as_int(c[0]), __float_as_int(c[1]), __float_as_int(c[2]));
+  const int m1 = min3i(__float_as_int(c[3]), __float_as_int(c[4]), __float_as_int(c[5]));
+  const int m2 = min3i(__float_as_int(c[6]), __float_as_int(c[7]), __float_as_int(c[8]));
+  const int m3 = min3i(__float_as_int(c[9]), __float_as_int(c[10]), __float_as_int(c[11]));
+  const int m4 = min3i(__float_as_int(c[12]), __float_as_int(c[13]), __float_as_int(c[14]));
+  return min3i(min3i(m0, m1, m2), min3i(m3, m4, __float_as_int(c[15])), run);
+}
+template <int I, int NM, int NV>
+__device__ __forceinline__ void pin_step() {
+  if constexpr (I < NM) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, (NV * (I + 1)) / NM - (NV * I) / NM, 0);
+    pin_step<I + 1, NM, NV>();
+  }
+}
+
+}  // namespace
+
+template <int DP>
+__global__ __launch_bounds__(512, 1) void k_prep_sweep(FusedArgs a) {
+  using C = F4<DP>;
+  constexpr int NS = C::NS, NT = C::NT, NE = C::NE, KS = C::KS, QW = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsf[];
+  const uint4 *Th = reinterpret_cast<const uint4 *>(ldsf);
+  const uint4 *Tl = Th + NT * NS * 64;
+  const uint4 *Lh = Tl + NT * NS * 64;
+  const uint4 *Ll = Lh + C::NLT * 64;
+  float *y0l = reinterpret_cast<float *>(const_cast<uint4 *>(Ll + C::NLT * 64));
+  float *csl = y0l + 32 * NE;
+  double *ctrl = reinterpret_cast<double *>(csl + 32 * NT);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int p32 = lane & 31, h = lane >> 5;
+  unsigned char *area = ldsf + C::r16(C::FRAG) + (size_t)wv * C::WAVE;
+  double *xs = reinterpret_cast<double *>(area);
+  const int d = a.p.d;
+  constexpr float up = 1.0f + 0x1p-18f, dn = 1.0f - 0x1p-18f;
+  unsigned *wg_keep = reinterpret_cast<unsigned *>(ldsf + C::r16(C::FRAG) + 8 * C::WAVE);   // [8] + base
+  unsigned &wg_base = wg_keep[8];
+
+  const double sigma = a.p.stats[0];
+  const bool sig_ok = sigma >= 0x1p-60 && sigma <= 0x1p60;
+  const float sig_f = sig_ok ? (float)sigma : 1.0f;
+  if (blockIdx.x == 0 && tid == 0 && a.p.counters) {
+    a.p.counters[0] = 0;
+    a.p.counters[1] = 0;
+  }
+  {
+    uint4 *dst = reinterpret_cast<uint4 *>(ldsf);
+    const uint4 *srcT = reinterpret_cast<const uint4 *>(a.p.TtF);
+    const uint4 *srcL = reinterpret_cast<const uint4 *>(a.p.LtF);
+    for (int e = tid; e < 2 * NT * NS * 64; e += 512) dst[e] = srcT[e];
+    for (int e = tid; e < 2 * C::NLT * 64; e += 512) dst[2 * NT * NS * 64 + e] = srcL[e];
+  }
+  if (tid < 32 * NE) y0l[tid] = a.p.y0[tid];
+  if (tid < 32 * NT) {
+    const int col = f4_column(tid >> 5, tid & 31);
+    csl[tid] = col < DP ? 2.0f * (float)(sigma * a.p.stats[8 + col]) : 0.0f;
+  }
+  if (tid < 16 * NS) ctrl[tid] = tid < d ? (double)a.p.c.s_x * a.p.lay_ctr[tid] : 0.0;
+
+  const long long np = a.p.np;
+  const long long ngroups = (np + 31) / 32;
+  const long long set = (long long)blockIdx.x * 8 + wv;
+  const long long g0 = set * QW;
+  const long long total = np * (long long)d;
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+  auto fetch_group = [&](long long grp) __attribute__((always_inline)) {
+    if (grp >= ngroups) return;
+    const long long base = grp * 32 * (long long)d;
+    if (base + 128 * C::NPC <= total) {
+#pragma unroll
+      for (int i = 0; i < C::NPC; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t *)(a.p.pts + base + 2 * (lane + 64 * i)), (lptr_t *)(area + i * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::NPC; ++i) {
+        const int e = lane + 64 * i;
+        const long long g = base + 2 * e;
+        if (e < 16 * d && g + 1 < total)
+          __builtin_amdgcn_global_load_lds((gptr_t *)(a.p.pts + g), (lptr_t *)(area + i * 1024), 16, 0, 0);
+        else if (e < 16 * d && g + 1 == total)
+          xs[2 * e] = a.p.pts[g];
+      }
+    }
+  };
+  fetch_group(g0);
+  __syncthreads();   // fragments and constants are in LDS
+
+  const float sqrt_k = __builtin_sqrtf((float)(16 * KS));
+  const float namax = (float)a.p.stats[1] * up;
+  float cs2 = 0.0f;
+  for (int e = 0; e < 32 * NT; ++e) cs2 = __builtin_fmaf(csl[e], csl[e], cs2);
+  const float csn = 0.5f * __builtin_sqrtf(cs2) * up;
+  const float zeta_scale = sig_f * a.p.c.zt * up;
+  const float zeta0 = (a.p.c.g_chain * csn + sig_f * a.p.c.zt_abs) * up + 0x1p-100f;
+  const float kappa = -2.0f * sig_f * a.p.c.inv_st_sx;
+  const double sr = sigma * sqrt(a.p.r2);
+  const float sr_lo = (float)(sr * (1.0 - 0x1p-30)) * dn;
+  const float sr_hi = (float)(sr * (1.0 + 0x1p-30)) * up;
+  const float inv_sx2 = a.p.c.inv_sx * a.p.c.inv_sx, inv_slsx2 = a.p.c.inv_sl_sx * a.p.c.inv_sl_sx;
+  const double sxd = (double)a.p.c.s_x;
+
+  // ---- A. the per-proposal stage of this wave's four groups (k_prep4's body); fragments and thresholds stay in registers
+  half8v bq[QW][KS];
+  float tlo[QW], thi[QW];
+  half8v hia[NS], loa[NS];
+  float dn2a = 0.0f;
+  auto operands = [&]() __attribute__((always_inline)) {
+    float dn2 = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int j2 = 0; j2 < 4; ++j2) {
+        float x32[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int jj = 2 * j2 + e;
+          const int k = 16 * s + 8 * h + jj;
+          const bool ok = 16 * s + 8 + jj < C::KMIN || k < d;
+          const double xv = __builtin_fma(xs[p32 * d + k], sxd, -ctrl[k < 16 * NS ? k : 0]);
+          x32[e] = ok ? (float)xv : 0.0f;
+          dn2 = __builtin_fmaf(x32[e], x32[e], dn2);
+        }
+        const half2v hp = __builtin_convertvector((float2v){x32[0], x32[1]}, half2v);
+        const float2v res = {x32[0] - (float)hp[0], x32[1] - (float)hp[1]};
+        const half2v lp = __builtin_convertvector(res, half2v);
+        hia[s][2 * j2] = hp[0];
+        hia[s][2 * j2 + 1] = hp[1];
+        loa[s][2 * j2] = lp[0];
+        loa[s][2 * j2 + 1] = lp[1];
+      }
+    }
+    return dn2;
+  };
+  auto frag = [&](const uint4 *base, int idx) __attribute__((always_inline)) {
+    union { uint4 u; half8v h8; } cv;
+    cv.u = base[idx * 64 + lane];
+    return cv.h8;
+  };
+  if (g0 < ngroups) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    dn2a = operands();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    fetch_group(g0 + 1);
+  }
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+    const long long grp = g0 + g;
+    unsigned pk[KS * 4];
+#pragma unroll
+    for (int i = 0; i < KS * 4; ++i) pk[i] = 0u;
+    float lo_f = -1.0f, hi_f = -1.0f;
+    if (grp < ngroups) {   // wave-uniform
+      const long long p = grp * 32 + p32;
+      const bool live = p < np;
+      float qs = 0.0f;
+      {
+        float16v ye[NE];
+#pragma unroll
+        for (int t = 0; t < NE; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ye[t][r] = y0l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+        for (int t = 0; t < NE; ++t)
+#pragma unroll
+          for (int s = 2 * t; s < NS; ++s) {
+            const int f = (t ? NS : 0) + s - 2 * t;
+            const half8v lh = frag(Lh, f), ll = frag(Ll, f);
+            ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh, hia[s], ye[t], 0, 0, 0);
+            ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh, loa[s], ye[t], 0, 0, 0);
+            ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ll, hia[s], ye[t], 0, 0, 0);
+          }
+#pragma unroll
+        for (int t = 0; t < NE; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) qs = __builtin_fmaf(ye[t][r], ye[t][r], qs);
+      }
+      float16v tt[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        tt[t] = (float16v){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const half8v th = frag(Th, t * NS + s), tl = frag(Tl, t * NS + s);
+          tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, hia[s], tt[t], 0, 0, 0);
+          tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, loa[s], tt[t], 0, 0, 0);
+          tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, hia[s], tt[t], 0, 0, 0);
+        }
+      }
+      qs = half_sum(qs) * inv_slsx2;
+      const float dn2 = half_sum(dn2a) * inv_sx2;
+      bool sure_in = false, sure_out = false;
+      float dnorm = 0.0f;
+      {
+        const bool finite = qs < 3.0e38f && dn2 < 3.0e38f;
+        const float sq = __builtin_sqrtf(qs);
+        dnorm = __builtin_sqrtf(dn2) * up + 0x1p-100f;
+        const float eta = (a.p.c.g_chain * (a.p.c.y0n + a.p.c.lf * dnorm) + a.p.c.el * dnorm + a.p.c.l_abs) * up;
+        const float de = dnorm + a.p.c.s0n;
+        const float eps = a.p.c.eps_scale * (de * de) * up;
+        const float hi = sq * up + eta;
+        const float qhi = ((hi * hi) * up + eps) * up;
+        const float lo = (sq * dn - eta) * dn;
+        const float qlo = ((lo * lo) * dn - eps * up) * dn;
+        sure_in = finite && qhi < a.p.c.enl_lo;
+        sure_out = finite && lo > 0.0f && qlo > a.p.c.enl_hi;
+      }
+      const bool band = live && !sure_in && !sure_out;
+      const bool ins_any = live && !sure_out;
+      {
+        const unsigned long long bm = __ballot(band && h == 0);
+        if (bm != 0ull) {   // wave-uniform, rare: the band list for the exact test (k_uncertain's trailing workgroups)
+          unsigned base = 0;
+          if (lane == 0) base = atomicAdd(a.p.ell_count, (unsigned)__popcll(bm));
+          base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+          if (band && h == 0) {
+            const unsigned slot = base + (unsigned)__popcll(bm & ((1ull << lane) - 1ull));
+            if (slot < a.p.ell_cap) a.p.ell_list[slot] = (int)p;
+          }
+        }
+      }
+      if (live && h == 0) a.p.gate[p] = ins_any ? 1 : 0;
+      float nbq = 0.0f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const float v0 = __builtin_fmaf(tt[t][2 * m], kappa, csl[32 * t + ((2 * m) & 3) + 8 * ((2 * m) >> 2) + 4 * h]);
+          const float v1 = __builtin_fmaf(tt[t][2 * m + 1], kappa, csl[32 * t + ((2 * m + 1) & 3) + 8 * ((2 * m + 1) >> 2) + 4 * h]);
+          union { half2v v; unsigned u; } cv;
+          cv.v = __builtin_convertvector((float2v){v0, v1}, half2v);
+          const float f0 = (float)cv.v[0], f1 = (float)cv.v[1];
+          nbq = __builtin_fmaf(f0, f0, nbq);
+          nbq = __builtin_fmaf(f1, f1, nbq);
+          if (t * 8 + m < KS * 4) pk[t * 8 + m] = cv.u;
+        }
+      const float nb = 0.25f * half_sum(nbq);
+      int rt = ins_any ? 1 : 0;
+      if (rt == 1 && (!sig_ok || !(nb <= 29000.0f))) rt = 2;
+      if (rt == 1) {
+        const float zeta = (zeta_scale * dnorm + zeta0) * up;
+        if (!filter_thresholds4(namax, nb, zeta, sqrt_k, sr_lo, sr_hi, &lo_f, &hi_f)) {
+          rt = 2;
+          lo_f = hi_f = -1.0f;
+        }
+      }
+      const _Float16 p1 = (_Float16)nb;
+      const float r1 = nb - (float)p1;
+      const _Float16 p2 = (_Float16)r1;
+      const float r2 = r1 - (float)p2;
+      const _Float16 p3 = (_Float16)r2;
+      const _Float16 one = (_Float16)1.0f;
+      union { half2v v; unsigned u; } sp[3];
+      sp[0].v = (half2v){one, one};
+      sp[1].v = (half2v){one, p1};
+      sp[2].v = (half2v){p2, p3};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int c = DP + 2 * q;
+        if (h == ((c >> 3) & 1)) pk[4 * (c >> 4) + ((c & 7) >> 1)] = sp[q].u;
+      }
+      if (rt != 1) {
+#pragma unroll
+        for (int i = 0; i < KS * 4; ++i) pk[i] = 0u;
+      }
+      if (__any(rt == 2) && lane == 0) *a.p.scan_flag = 1u;
+      if (live && h == 0) {
+        a.p.route[p] = (uint8_t)rt;
+        a.p.best[p] = kNone;
+      }
+      // operands of the next group (its rows have been on their way since this one's were read); then the one after sets out
+      if (g + 1 < QW && grp + 1 < ngroups) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        dn2a = operands();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (g + 2 < QW) fetch_group(grp + 2);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      union { uint4v u; half8v h8; } cv;
+      cv.u = (uint4v){pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]};
+      bq[g][s] = cv.h8;
+    }
+    // every lane of a query needs its thresholds (the per-proposal stage leaves them in the low half)
+    tlo[g] = __shfl(lo_f, p32, 64);
+    thi[g] = __shfl(hi_f, p32, 64);
+  }
+
+  // ---- B. the first live-point range, running minima only (k_sweep_min's loop)
+  int run[QW];
+#pragma unroll
+  for (int g = 0; g < QW; ++g) run[g] = kPosInf;
+  if (g0 < ngroups) {
+    const int ntl = a.tile1 - a.tile0;
+    const int tstart = a.tile0 + (int)((set * 37) % ntl);
+    constexpr int kTileBytes = KS * 1024;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.refF), 0, a.ntiles32 * kTileBytes, 0x00020000);
+    const int voff = lane * 16;
+    const int off_begin = a.tile0 * kTileBytes, off_end = a.tile1 * kTileBytes;
+    float16v acc[QW];
+    auto load_tile = [&](half8v(&A)[KS], int soff) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        union { uint4v u; half8v h8; } c;
+        c.u = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + s * 1024, 0);
+        A[s] = c.h8;
+      }
+    };
+    auto mm = [&](const half8v(&A)[KS], int ga, int gb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float16v z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[ga] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], bq[ga][s], s == 0 ? z : acc[ga], 0, 0, 0);
+        acc[gb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], bq[gb][s], s == 0 ? z : acc[gb], 0, 0, 0);
+      }
+    };
+    auto next_off = [&](int off) __attribute__((always_inline)) {
+      const int n = off + kTileBytes;
+      return n == off_end ? off_begin : n;
+    };
+    auto tile = [&](const half8v(&A)[KS]) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      mm(A, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(A, 2, 3);
+      run[0] = tree_min(acc[0], run[0]);
+      run[1] = tree_min(acc[1], run[1]);
+      pin_step<0, 2 * KS, 16>();
+      __builtin_amdgcn_sched_barrier(0);
+      run[2] = tree_min(acc[2], run[2]);
+      run[3] = tree_min(acc[3], run[3]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    half8v A0[KS], A1[KS], A2[KS];
+    int o0 = tstart * kTileBytes, o1 = next_off(o0), o2 = next_off(o1);
+    load_tile(A0, o0);
+    load_tile(A1, o1);
+    for (int it = 0; it < ntl; it += 3) {
+      load_tile(A2, o2);
+      tile(A0);
+      if (it + 1 >= ntl) break;
+      o0 = next_off(o2);
+      load_tile(A0, o0);
+      tile(A1);
+      if (it + 2 >= ntl) break;
+      o1 = next_off(o0);
+      load_tile(A1, o1);
+      tile(A2);
+      o2 = next_off(o1);
+    }
+  }
+
+  // ---- C. certain hits -> best; the rest goes on with its minimum (one atomic per workgroup)
+  unsigned keepm[QW];
+  int qmn[QW];
+  unsigned total_keep = 0u;
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+    keepm[g] = 0u;
+    qmn[g] = kPosInf;
+    if (g0 + g >= ngroups) continue;
+    const long long qi = (g0 + g) * 32 + p32;
+    const int other = __shfl_xor(run[g], 32);
+    const int m = run[g] < other ? run[g] : other;
+    const float mf = __int_as_float(m);
+    const bool valid = qi < np && thi[g] > 0.0f;
+    const bool hit = valid && mf <= tlo[g];
+    if (lane < 32 && hit) a.p.best[qi] = 0;
+    keepm[g] = (unsigned)__ballot(valid && !hit);
+    qmn[g] = m;
+    total_keep += (unsigned)__popc(keepm[g]);
+  }
+  if (lane == 0) wg_keep[wv] = total_keep;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned all = 0u;
+    for (int w = 0; w < 8; ++w) all += wg_keep[w];
+    wg_base = all ? atomicAdd(a.ccount, all) : 0u;
+  }
+  __syncthreads();
+  if (total_keep != 0u) {
+    unsigned base = wg_base;
+    for (int w = 0; w < wv; ++w) base += wg_keep[w];
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    uint4 *dst = reinterpret_cast<uint4 *>(a.cq);
+    const unsigned row = (unsigned)p32;
+#pragma unroll
+    for (int g = 0; g < QW; ++g) {
+      if ((keepm[g] >> row) & 1u) {
+        const unsigned rank = base + (unsigned)__popc(keepm[g] & ((1u << row) - 1u));
+        const size_t gd = rank >> 5;
+        const unsigned rd = (rank & 31u) + (unsigned)(lane & 32);
+        if (rank < a.ccap) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            union { half8v h8; uint4 u; } cv;
+            cv.h8 = bq[g][s];
+            dst[(gd * KS + s) * 64 + rd] = cv.u;
+          }
+        }
+        if (lane < 32 && rank < a.ccap) {
+          a.ctlo[rank] = tlo[g];
+          a.cthi[rank] = thi[g];
+          a.cmap[rank] = (int)((g0 + g) * 32 + p32);
+          a.cmin[rank] = qmn[g];
+        }
+      }
+      base += (unsigned)__popc(keepm[g]);
+    }
+  }
+}
+
+bool fused_usable(int dp) { return dp >= 2 && dp <= 56 && (dp & 1) == 0; }
+
+hipError_t launch_prep_sweep(const FusedArgs &a, hipStream_t s) {
+  if (a.p.np <= 0) return hipSuccess;
+  const long long ngroups = (a.p.np + 31) / 32;
+  const long long nsets = (ngroups + 3) / 4;
+  const dim3 grid((unsigned)((nsets + 7) / 8));
+  switch (a.p.dp) {
+#define X(D)                                                                                                         \
+  case D: {                                                                                                          \
+    constexpr size_t lds = F4<D>::LDS;                                                                               \
+    static_assert(lds <= 160 * 1024 - 64, "LDS budget");                                                             \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_sweep<D>),                           \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+      if (e != hipSuccess) return e;                                                                                 \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    if (a.p.ks != F4<D>::KS) return hipErrorInvalidValue;                                                            \
+    hipLaunchKernelGGL((k_prep_sweep<D>), grid, dim3(512), lds, s, a);                                               \
+    break;                                                                                                           \
+  }
+    MLF_FOR_EACH_DP_MID(X)
+#undef X
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace mlf
