@@ -19,6 +19,12 @@ def count_nearby(apts, bpts, radiussq, nnearby):
     nnearby[:] = orc.count_nearby(apts, bpts, radiussq)
 
 
+def cluster_labels(tpoints, radiussq, previous=None):
+    tpoints = np.asarray(tpoints, dtype=float)
+    ncl, labels, _ = orc.update_clusters(tpoints, tpoints, radiussq, previous)
+    return int(ncl), np.asarray(labels)
+
+
 def subtract_nearby(upoints, maxradiussq):
     return orc.subtract_nearby(upoints, maxradiussq)
 
@@ -140,7 +146,7 @@ class DeviceRegion(object):
         return mask
 
 
-PATCHED = ["find_nearby", "count_nearby", "subtract_nearby", "maxradiussq_bootstrap", "compute_mean_pair_distance",
+PATCHED = ["find_nearby", "count_nearby", "cluster_labels", "subtract_nearby", "maxradiussq_bootstrap", "compute_mean_pair_distance",
            "inside_ellipsoid", "affine_transform", "bootstrap_moments", "bootstrap_quadform_max", "bootstrap_factor",
            "DeviceRegion"]
 

@@ -89,11 +89,12 @@ def test_device_resident_rebuild_matches_default(n, d, layer_name, blobs):
     assert rb.inside(np.asarray(rb.u)[3:4])[0] == rb.inside(np.asarray(rb.u)[5:6])[0]
 
 
-def test_cluster_labels_equal_update_clusters():
-    """mlf_cluster_labels replays update_clusters' growth rounds: labels, numbering, carried-over seeds."""
+def test_cluster_labels_equal_update_clusters(oracle):
+    """mlf_cluster_labels replays update_clusters' growth rounds (the oracle's: one neighbour scan per round, mlfriends.pyx:
+    275-343): labels, numbering, carried-over seeds."""
     import ctypes
     from ultranest_amd import _lib
-    from ultranest_amd.layers import update_clusters
+    update_clusters = oracle.update_clusters
     rs = np.random.RandomState(4)
     for case in range(6):
         n, d = 300 + 50 * case, 3

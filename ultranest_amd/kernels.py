@@ -51,6 +51,23 @@ def subtract_nearby(upoints, maxradiussq):
     return out
 
 
+def cluster_labels(tpoints, radiussq, previous=None):
+    """Friends-of-friends labels of `tpoints` (linking length sqrt(`radiussq`)): ``(nclusters, labels)`` with the
+    numbering of the reference's growth loop (mlfriends.pyx:275-343: labels from 1, cluster c seeded at the first point
+    that carried c in `previous`).  One all-pairs pass of exact distances on the device (hit bits), the growth rounds
+    replayed on the bit rows (mlf_cluster_labels)."""
+    import ctypes
+    tpoints = f64(tpoints)
+    n, d = tpoints.shape
+    prev = None if previous is None else np.ascontiguousarray(np.asarray(previous)[:n], dtype=int_dtype)
+    if prev is not None and len(prev) < n:   # fewer old ids than points: the rest carried none
+        prev = np.concatenate((prev, np.zeros(n - len(prev), dtype=int_dtype)))
+    labels = np.empty(n, dtype=int_dtype)
+    ncl = ctypes.c_int64(0)
+    check(_lib.lib().mlf_cluster_labels(ptr(tpoints), n, d, float(radiussq), ptr(prev), ptr(labels), ctypes.byref(ncl)))
+    return int(ncl.value), labels
+
+
 def maxradiussq_bootstrap(unormed, selected, rows=None):
     """Per-bootstrap ``compute_maxradiussq(unormed[sel], unormed[~sel])`` (reference
     mlfriends.pyx:188-224, called at :1012 and :1052) for a (B, N) boolean selection matrix.

@@ -76,35 +76,17 @@ def update_clusters(upoints, tpoints, maxradiussq, clusterids=None):
     clusters keep their identity; ``overlapped_upoints`` are `upoints` with their cluster mean
     removed (a singleton is centred on the global mean instead).
 
-    Each growth round is one GPU neighbour scan: members of the current cluster against all
-    still unlabelled points (K1, first-hit semantics are irrelevant here, only hit / no hit).
+    The labels come from ONE all-pairs pass of exact distances on the device (hit bits, K1's arithmetic) and the
+    reference's growth rounds replayed on the bit rows (kernels.cluster_labels -> mlf_cluster_labels): the same partition
+    and the same numbering as one neighbour scan per growth round, without the rounds' host copies and launches.
     """
     upoints = np.asarray(upoints)
     tpoints = np.asarray(tpoints)
     if upoints.shape != tpoints.shape:
         raise AssertionError(('different shapes of points', upoints.shape, tpoints.shape))
-    npts = len(tpoints)
-    previous = np.zeros(npts, dtype=int_dtype) if clusterids is None else np.asarray(clusterids)[:npts]
-    labels = np.zeros(npts, dtype=int_dtype)
-
-    def seed_for(cid, default):
-        carried = np.flatnonzero(previous == cid)
-        return carried[0] if len(carried) else default
-
-    current = 1
-    labels[seed_for(current, 0)] = current
-    while True:
-        unlabelled = np.flatnonzero(labels == 0)
-        if len(unlabelled) == 0:
-            break
-        hits = np.empty(len(unlabelled), dtype=int_dtype)
-        kernels.find_nearby(tpoints[labels == current], tpoints[unlabelled], maxradiussq, hits)
-        joined = unlabelled[hits >= 0]
-        if len(joined):
-            labels[joined] = current
-        else:
-            current += 1
-            labels[seed_for(current, unlabelled[0])] = current
+    if len(tpoints) == 0:
+        raise IndexError('update_clusters: no points')   # the reference seeds clusterids[0] (:287)
+    _, labels = kernels.cluster_labels(tpoints, maxradiussq, clusterids)
 
     assert (labels > 0).all()
     present = np.unique(labels)

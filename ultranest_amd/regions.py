@@ -530,8 +530,9 @@ class MLFriends(_LivePoints):
     live points, intersected with a wrapping ellipsoid (reference mlfriends.pyx:915-1257)."""
 
     def __init__(self, u, transformLayer):
-        ok = np.logical_and(u > 0, u < 1)
-        if not ok.all():
+        plain = np.asarray(u)
+        if not (plain.size == 0 or (plain.min() > 0 and plain.max() < 1)):   # NaN fails both comparisons, as in the reference's test
+            ok = np.logical_and(u > 0, u < 1)
             raise ValueError("not all u values are between 0 and 1: %s" % u[~ok.all(axis=1)])
         self.u = u
         self.enlarge = None
@@ -552,9 +553,10 @@ class MLFriends(_LivePoints):
         """Adopt a new whitening layer; the radius becomes invalid (reference :972-986)."""
         self.transformLayer = transformLayer
         self.unormed = self.transformLayer.transform(self.u)
-        assert np.isfinite(self.unormed).all(), (self.unormed, self.u)
         self.bbox_lo = self.unormed.min(axis=0)
         self.bbox_hi = self.unormed.max(axis=0)
+        # every element finite <=> every column's extremes finite (min / max propagate NaN; an infinity is an extreme)
+        assert np.isfinite(self.bbox_lo).all() and np.isfinite(self.bbox_hi).all(), (self.unormed, self.u)
         self.maxradiussq = None
 
     def estimate_volume(self):
