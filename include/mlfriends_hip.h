@@ -76,6 +76,10 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *   "sweep_min"                1 (default): two-range batches through the min-only sweep (k_sweep_min: running minima only
  *                              in the two long launches, the proposals whose minimum ends in the band handled by
  *                              k_uncertain); 0: k_sweep (per-tile band test) followed by the re-check launch
+ *   "boot_symmetric"           1 (default): a whole-range mlf_maxradiussq_bootstrap pass over enough live points (>= 1024 tiles
+ *                              of 64 x 64 pairs, i.e. n > 2816; d <= 64) computes every pair distance once and uses it for both
+ *                              points of the pair (k_boot_sym); 0: k_boot (both orders); 2: k_boot_sym whatever the number of
+ *                              tiles (tests).  Same minima, bit for bit
  *   "small_path"               1/0: mlf_region_inside with up to 256 proposals as ONE launch over pinned staging -- the calls
  *                              of the scalar step samplers -- or through the batched pipeline
  *   "time_filter_launches"     1/0: event pairs around every matrix-kernel launch (mlf_region_timing_filter_launch_ms)

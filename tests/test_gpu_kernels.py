@@ -172,6 +172,49 @@ def test_bootstrap_radius_row_block_shares(n, d, W, K, oracle):
     assert not share.any()
 
 
+@pytest.mark.parametrize("n,d,B", [(2880, 3, 30), (3000, 17, 7), (4000, 50, 30), (4033, 64, 9), (5000, 2, 40)])
+def test_bootstrap_radius_pairs_once(n, d, B, K, oracle):
+    """k_boot_sym (whole-range passes over > 2816 live points: every pair distance once, used for both points of the pair
+    through an LDS tile) against k_boot (option boot_symmetric = 0) and against the oracle, bit for bit: tile runs that change
+    the row block mid-way, a last block that is not full, more rounds than one pass holds (B = 40), duplicates."""
+    from ultranest_amd import _lib
+    rs = np.random.RandomState(7 * n + d)
+    u = rs.uniform(size=(n, d))
+    u[n // 2] = u[0]
+    u[n - 1] = u[65]
+    masks = oracle.draw_bootstrap_masks(rs, n, B)
+    masks[1] = True                                               # a skipped round rides along
+    try:
+        _lib.set_option("boot_symmetric", 0)
+        r0, s0 = K.maxradiussq_bootstrap(u, masks)
+        _lib.set_option("boot_symmetric", 1)
+        r1, s1 = K.maxradiussq_bootstrap(u, masks)
+    finally:
+        _lib.set_option("boot_symmetric", 1)
+    ro, so = oracle.maxradiussq_bootstrap(u, masks)
+    assert np.array_equal(s0, so) and np.array_equal(s1, so)
+    assert np.array_equal(r0, ro)
+    assert np.array_equal(r1, ro)
+
+
+@pytest.mark.parametrize("n,d", [(9, 3), (64, 2), (65, 5), (150, 1), (200, 16), (257, 31), (333, 47), (300, 64), (1000, 50)])
+def test_bootstrap_radius_pairs_once_small(n, d, K, oracle):
+    """The same kernel forced onto small arrays (boot_symmetric = 2): one tile, a lone partial block, a diagonal tile only."""
+    from ultranest_amd import _lib
+    rs = np.random.RandomState(11 * n + d)
+    u = rs.uniform(size=(n, d))
+    u[n // 2] = u[0]
+    masks = oracle.draw_bootstrap_masks(rs, n, 11)
+    try:
+        _lib.set_option("boot_symmetric", 2)
+        r, skipped = K.maxradiussq_bootstrap(u, masks)
+    finally:
+        _lib.set_option("boot_symmetric", 1)
+    ro, so = oracle.maxradiussq_bootstrap(u, masks)
+    assert np.array_equal(skipped, so)
+    assert np.array_equal(r, ro)
+
+
 def test_bootstrap_radius_degenerate_masks(K, oracle):
     u = inputs.live_points(1, 100, 3)
     masks = np.zeros((3, 100), dtype=bool)

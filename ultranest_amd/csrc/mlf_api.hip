@@ -68,12 +68,14 @@ enum Opt : int {
   OPT_SWEEP_MIN,           // "sweep_min" 0/1: two-range batches through the min-only sweep (mlf_sweepmin.hip) or k_sweep
   OPT_MID_MAX,             // "mid_max_queries": batches up to this size take the one-launch path (mlf_mid.hip); 0 = never
   OPT_FUSED_FIRST,         // "fused_first_range" 0/1: per-proposal stage and first range of the min-only sweep in one launch (mlf_fused.hip)
+  OPT_BOOT_SYM,            // "boot_symmetric" 0/1: whole-range bootstrap passes compute every pair distance once (k_boot_sym)
   OPT_COUNT
 };
 const char *const kOptNames[OPT_COUNT] = {"filter", "filter_first_range_pct", "filter_split_waves", "filter_narrow_tail",
                                           "small_path", "fused_prep", "filter_phase_min_queries", "filter_phases",
-                                          "time_filter_launches", "prep_bounded", "filter_min_queries", "sweep_min", "mid_max_queries", "fused_first_range"};
-long long g_opt[OPT_COUNT] = {1, 50, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 0};
+                                          "time_filter_launches", "prep_bounded", "filter_min_queries", "sweep_min", "mid_max_queries", "fused_first_range",
+                                          "boot_symmetric"};
+long long g_opt[OPT_COUNT] = {1, 50, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 0, 1};
 
 struct OptOverrides {
   long long v[OPT_COUNT] = {};
@@ -91,6 +93,7 @@ long long opt_clamp(int id, long long value) {
     case OPT_FIRST_RANGE_PCT: return value < 10 ? 10 : (value > 90 ? 90 : value);
     case OPT_SPLIT_WAVES: return value < 256 ? 256 : (value > 16384 ? 16384 : value);
     case OPT_PHASES: return value < 0 ? 0 : (value > 64 ? 64 : value);
+    case OPT_BOOT_SYM: return value < 0 ? 0 : (value > 2 ? 2 : value);
     case OPT_PHASE_MIN_QUERIES:
     case OPT_MID_MAX:
     case OPT_MIN_QUERIES: return value;
@@ -1661,7 +1664,11 @@ int mlf_maxradiussq_bootstrap_rows(const double *pts, size_t n, size_t d, const 
     a.chunk = chunk;
     a.M = c.M.as<unsigned long long>();
     a.blk0 = blk0;
-    CK(launch_boot(dp, a, nchunks, c.stream, rowblocks));
+    if (row_lo == 0 && row_hi == n && dp <= 64 && (g_opt[OPT_BOOT_SYM] == 2 || (g_opt[OPT_BOOT_SYM] == 1 && boot_sym_usable(dp, npad)))) {
+      CK(launch_boot_sym(dp, a, c.stream));   // every pair distance once (a rank's row share keeps k_boot: its minima must be complete)
+    } else {
+      CK(launch_boot(dp, a, nchunks, c.stream, rowblocks));
+    }
     launch_boot_final(c.M.as<unsigned long long>(), c.sel.as<unsigned>(), (int)n, npad, nb,
                       c.small0.as<double>() + b0, c.small1.as<uint8_t>() + b0, c.stream, (int)row_lo, (int)row_hi);
     CK(hipGetLastError());

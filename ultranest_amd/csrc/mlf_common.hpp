@@ -127,6 +127,8 @@ int pick_dp(int d);
 
 hipError_t launch_scan(int dp, const ScanArgs &a, hipStream_t s);
 hipError_t launch_boot(int dp, const BootArgs &a, int nchunks, hipStream_t s, int nblocks = -1);
+bool boot_sym_usable(int dp, int npad);   // k_boot_sym: every pair distance once (whole-range passes with >= 1024 tiles)
+hipError_t launch_boot_sym(int dp, const BootArgs &a, hipStream_t s);
 hipError_t launch_prep(int dp, const PrepArgs &a, hipStream_t s);
 hipError_t launch_whiten_rows(const double *pts, long long n, int d, int dp, const double *lay_ctr, const double *T8, int ldt8,
                               const double *wrap_shift, double *t_out, long long ldt, hipStream_t s);
