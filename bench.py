@@ -511,8 +511,9 @@ def main():
             usets = -(-(-(-stats["uncertain_queries"] // 32)) // 4)
             mfma_per_launch = [ngroups1 * cut * ks, stats["second_range_groups"] * (ntiles32 - cut) * ks, usets * 4 * ntiles32 * ks]
             names = ["k_sweep_min<4, 4, 2> (first live-point range: running minima only; compacts the proposals without a certain hit, with their minima)",
-                     "k_sweep_min<4, 2, 1> (second range: two query groups per wave; compacts the proposals whose minimum ended in the band)",
-                     "k_sweep_list<4> (the uncertain proposals over all tiles: lists and re-checks their band pairs; carries the ellipsoid band)"]
+                     "k_sweep_min<4, 4, 2> (second range over the proposals left; compacts those whose minimum ended in the band)",
+                     "k_uncertain<4, 4> (the proposals whose minimum ended in the band: all tiles again with their band pairs listed, "
+                     "binary64 whitening, the pairs in the reference's arithmetic; trailing workgroups decide the ellipsoid band)"]
             dominant = 2            # launches of the dominant kernel (k_sweep_min)
         else:
             tiles = [ntiles32 * (i + 1) // per_step - ntiles32 * i // per_step for i in range(per_step)]
@@ -526,7 +527,7 @@ def main():
         ach = (exec_flops / dominant) / (launch_ms * 1e-3) / 1e12
         allpairs = 2.0 * N_LIVE * NPROPOSALS * (NDIM + 6)
         roofline = {"kernel": ("k_sweep_min (mlf_sweepmin.hip: v_mfma_f32_32x32x16_f16 bound on the pair distances, running minima "
-                               "only; two launches per step, the uncertain proposals go through k_sweep_list afterwards)") if per_step == 3 else
+                               "only; two launches per step, the uncertain proposals go through k_uncertain afterwards)") if per_step == 3 else
                               "k_sweep (mlf_sweep.hip: v_mfma_f32_32x32x16_f16 bound on the pair distances, mask mode; two launches per step)",
                     "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / F16_MFMA_PEAK_TFLOPS, "ms_per_launch": launch_ms,
@@ -592,9 +593,9 @@ def main():
                                         "instead of bit parity (tests/test_device_rebuild.py); N = 1 only",
         "accept_fraction": accept, "ellipsoid_pass_fraction": ell_pass,
         "kernel_ms": {"per-proposal stage (k_prep4: bounded ellipsoid test + whitening on the matrix cores with split binary16 operands -> f16 "
-                      "operand; the ellipsoid band is decided by the tail of the re-check launch)": prep_ms,
-                      ("scan kernel (k_sweep, both launches)" if filter_on else "scan kernel (k_scan)"): scan_ms,
-                      "rest of scan stage (re-check of uncertain pairs incl. exact whitening of their queries, "
+                      "operand; the ellipsoid band is decided by trailing workgroups of the k_uncertain launch)": prep_ms,
+                      ("scan kernel (k_sweep_min, both launches)" if filter_on else "scan kernel (k_scan)"): scan_ms,
+                      "rest of scan stage (k_uncertain: the proposals whose minimum ended in the band, incl. exact whitening; "
                       "routing, finalise)": rest_ms,
                       "scan kernel as a single sweep over all live points (phases off)": ms_scan_single,
                       "per-proposal stage with the FP64 kernel instead (k_prep3, prep_bounded=0)":

@@ -50,8 +50,29 @@ for k in sq:
         e["hbm_bytes_gfx950_corrected"] = (2.0 * fetch[k]["FETCH_SIZE"] + write[k]["WRITE_SIZE"]) * 1024.0
         e["FETCH_SIZE_KiB"], e["WRITE_SIZE_KiB"] = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
     summary[k] = e
-tot = sum(v.get("hbm_bytes_gfx950_corrected", 0.0) for v in summary.values())
+tot = sum(v.get("hbm_bytes_gfx950_corrected", 0.0) * (2 if k.startswith("void mlf::k_sweep_min") and len([x for x in summary if x.startswith("void mlf::k_sweep_min")]) == 1 else 1)
+          for k, v in summary.items())
 summary["_per_step"] = dict(hbm_bytes_all_kernels=tot, algorithmic_bytes=402640000, ratio=tot / 402640000.0,
                             kernel_ms_sum=sum(v["avg_ms_kernel_stats"] or 0.0 for k, v in summary.items() if not k.startswith("_")))
 json.dump(summary, open(dst + "_pmc_summary.json", "w"), indent=1)
+# what bench.py imports as roofline.traffic (per launch of the dominant kernel, like roofline.achieved: the k_sweep_min launches)
+import os
+sweeps = {k: v["hbm_bytes_gfx950_corrected"] for k, v in summary.items() if k.startswith("void mlf::k_sweep_min") and "hbm_bytes_gfx950_corrected" in v}
+stats_calls = {}
+for f in glob.glob(src + "_stats/*kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        stats_calls[r["Name"][:44]] = int(r["Calls"])
+if sweeps:
+    # both ranges run the same instance: its counters are the mean over its launches already
+    per_launch = sum(sweeps.values()) / len(sweeps)
+    per_kernel_all = {k.replace("void mlf::", "").split("(")[0]: v["hbm_bytes_gfx950_corrected"] for k, v in summary.items()
+                      if not k.startswith("_") and "hbm_bytes_gfx950_corrected" in v}
+    launches = {k.replace("void mlf::", "").split("(")[0]: (2 if k.startswith("void mlf::k_sweep_min") else 1) for k in summary if not k.startswith("_")}
+    step_sum = sum(per_kernel_all[k] * launches.get(k, 1) for k in per_kernel_all)
+    json.dump({"hbm_bytes_per_launch": per_launch, "per_kernel_all": per_kernel_all, "launches_per_step": launches,
+               "hbm_bytes_per_step_all_kernels": step_sum, "source": os.path.basename(dst) + "_pmc_summary.json",
+               "kernel": "k_sweep_min<4, 4, 2> (both live-point ranges: mean over its launches)",
+               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over scripts/stage_profile.py (the bench workload, "
+                       "1e6 proposals per step); (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md; per launch, like roofline.achieved"},
+              open(os.path.join(os.path.dirname(dst), "pmc_scan_traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))

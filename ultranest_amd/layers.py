@@ -11,6 +11,7 @@ the MI355X through ``ultranest_amd.kernels``.  ``transform`` of the N live point
 transformed on the device inside the region's ``inside`` pipeline.
 """
 import functools
+import threading
 
 import numpy as np
 
@@ -36,15 +37,37 @@ def _blas_controller():
     return _blas["controller"]
 
 
+_blas_lock = threading.Lock()
+_blas_scope = {"depth": 0, "limit": None}
+
+
 def single_blas_thread(fn):
-    """Decorator: run `fn` with the BLAS pool limited to one thread (a no-op without threadpoolctl)."""
+    """Decorator: run `fn` with the BLAS pool limited to one thread (a no-op without threadpoolctl).
+
+    threadpoolctl's limit is a process-global save / restore.  The scopes of this module overlap across TWO threads (the
+    calling thread and the host worker that takes `ellipsoid_parts` during the bootstrap), and not nested: the limit is
+    therefore taken by whoever enters first and given back by whoever leaves last (a counter under a lock) -- an inner
+    scope that restored "its" saved state while another thread is still inside, or in the wrong order, would leave the
+    pool at one thread for the rest of the process, the user's likelihood included."""
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
         ctl = _blas_controller()
         if ctl is None:
             return fn(*args, **kwargs)
-        with ctl.limit(limits=1, user_api="blas"):
+        with _blas_lock:
+            if _blas_scope["depth"] == 0:
+                limit = ctl.limit(limits=1, user_api="blas")
+                limit.__enter__()
+                _blas_scope["limit"] = limit
+            _blas_scope["depth"] += 1
+        try:
             return fn(*args, **kwargs)
+        finally:
+            with _blas_lock:
+                _blas_scope["depth"] -= 1
+                if _blas_scope["depth"] == 0:
+                    limit, _blas_scope["limit"] = _blas_scope["limit"], None
+                    limit.__exit__(None, None, None)
     return wrapper
 
 

@@ -71,14 +71,23 @@ class BreadthFirstIterator(object):
     def next_node(self):
         """``(rootid, node, (active_nodes, active_root_ids, active_node_values, active_node_ids))`` of the live node
         with the lowest value -- it stays in the live set until dropped or expanded -- or None when nothing is left."""
-        if self._n == 0:
+        step = self._next_index()
+        if step is None:
             return None
-        i = self.next_index = int(np.argmin(self._val[:self._n]))
+        i = self.next_index
         # the caller gets arrays of its own: the buffers behind the public attributes are shifted in place when a slot
         # closes, and a caller that keeps the tuple across expand_children_of / drop_next_node (the reference hands out
         # fresh arrays on a fork or drop, netiter.py:110-161) must not see that
         return self._root[i], self._nodes[i], (list(self._nodes), self.active_root_ids.copy(),
                                                self.active_node_values.copy(), self.active_node_ids.copy())
+
+    def _next_index(self):
+        """``(rootid, node)`` of the lowest live node, nothing copied: for the walks of this module that look at the live set
+        only until their next expand / drop (the public attributes are views of the buffers and valid exactly that long)."""
+        if self._n == 0:
+            return None
+        i = self.next_index = int(np.argmin(self._val[:self._n]))
+        return self._root[i], self._nodes[i]
 
     def _close_gap(self, i):
         n = self._n
@@ -280,10 +289,10 @@ def _walk(roots):
     """Yield (explorer, rootid, node, active_rootids) in the driver's breadth-first order; the consumer
     decides whether to expand, drop or stop."""
     walk = BreadthFirstIterator(roots)
-    step = walk.next_node()
+    step = walk._next_index()
     while step is not None:
-        yield walk, step[0], step[1], step[2][1]
-        step = walk.next_node()
+        yield walk, step[0], step[1], walk.active_root_ids     # a view: read before the consumer expands or drops
+        step = walk._next_index()
 
 
 def _tree_extent(roots, lo=-np.inf, hi=np.inf):
@@ -319,10 +328,10 @@ def find_nodes_before(root, value):
     weight_of = {child.id: 1. for child in root.children}
     walk = BreadthFirstIterator(root.children)     # the live-set walk itself: equal values are met in ITS slot order
     while True:
-        step = walk.next_node()
+        step = walk._next_index()
         if step is None:
             break
-        rootid, node, _ = step
+        rootid, node = step
         if node.value >= value:          # only a child of the root can get here: everything still live lies above too
             parents.append(root)
             parent_weights.append(1)

@@ -592,7 +592,8 @@ class MLFriends(_LivePoints):
         started = _ELLIPSOID_JOBS.get(self)
         if started is not None and started[1] == minvol and started[2] == stamp:
             return      # on its way already
-        job = host_worker().submit(self.ellipsoid_parts, self.u, minvol, np.geterr())
+        # the worker's cov / inv / eigh under the same one-thread BLAS limit as the caller's scopes (counted, layers.single_blas_thread)
+        job = host_worker().submit(single_blas_thread(self.ellipsoid_parts), self.u, minvol, np.geterr())
         _ELLIPSOID_JOBS[self] = (job, minvol, stamp)
 
     @single_blas_thread
