@@ -11,6 +11,16 @@ for p in (ROOT, GOLDEN):
         sys.path.insert(0, p)
 
 
+@pytest.fixture(autouse=True)
+def _watchdog():
+    """A test that has not returned after 15 minutes dumps the stacks of all its threads and ends the run (the watchdog is a
+    C thread of faulthandler: it also fires when the interpreter itself is stuck, e.g. in a lock held across threads)."""
+    import faulthandler
+    faulthandler.dump_traceback_later(900, exit=True)
+    yield
+    faulthandler.cancel_dump_traceback_later()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
     # MLF_TEST_OPTIONS="name=value,name=value": process-wide tuning options for this run of the GPU suite (results never depend

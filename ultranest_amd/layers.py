@@ -37,6 +37,12 @@ def _blas_controller():
     return _blas["controller"]
 
 
+# The controller is made HERE, while the module is imported: threadpoolctl finds the BLAS libraries with dl_iterate_phdr
+# and a Python callback, i.e. it needs the interpreter lock while it holds the loader's lock -- made lazily on the host worker
+# thread, it met a dlopen (ctypes.CDLL) on the main thread, which holds the interpreter lock while it waits for the
+# loader's: a deadlock, seen as a two-rank CPU test that never returned once in a few runs.
+_blas_controller()
+
 _blas_lock = threading.Lock()
 _blas_scope = {"depth": 0, "limit": None}
 
