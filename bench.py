@@ -469,9 +469,8 @@ def main():
         pmc = json.load(open(pmc_file))
         traffic = pmc.get("hbm_bytes_per_launch")
         step_sum = pmc.get("hbm_bytes_per_step_all_kernels")
-        traffic_detail = {"source": "profiles/%s via profiles/pmc_scan_traffic.json: separate rocprofv3 --pmc passes "
-                                    "(FETCH_SIZE, WRITE_SIZE; gfx950 correction of MI355X_MICROARCH.md) over bench.py "
-                                    "--headline-only on the profiled tree -- imported, NOT measured in this run" % pmc.get("source"),
+        traffic_detail = {"source": "profiles/%s via profiles/pmc_scan_traffic.json (%s) -- imported from the last profiled tree, "
+                                    "NOT measured in this run" % (pmc.get("source"), pmc.get("note")),
                           "per_launch_average_of_the_sweep_launches": traffic,
                           "per_kernel_bytes": pmc.get("per_kernel_all"),
                           "per_step_sum_all_kernels": step_sum,
@@ -594,9 +593,9 @@ def main():
         "accept_fraction": accept, "ellipsoid_pass_fraction": ell_pass,
         "kernel_ms": {"per-proposal stage (k_prep4: bounded ellipsoid test + whitening on the matrix cores with split binary16 operands -> f16 "
                       "operand; the ellipsoid band is decided by trailing workgroups of the k_uncertain launch)": prep_ms,
-                      ("scan kernel (k_sweep_min, both launches)" if filter_on else "scan kernel (k_scan)"): scan_ms,
-                      "rest of scan stage (k_uncertain: the proposals whose minimum ended in the band, incl. exact whitening; "
-                      "routing, finalise)": rest_ms,
+                      ("scan kernels (k_sweep_min over both live-point ranges + k_uncertain: the proposals whose minimum ended in "
+                       "the band, incl. their exact whitening)" if filter_on else "scan kernel (k_scan)"): scan_ms,
+                      "rest of scan stage (k_scan tail: what the filter could not take, routing, finalise)": rest_ms,
                       "scan kernel as a single sweep over all live points (phases off)": ms_scan_single,
                       "per-proposal stage with the FP64 kernel instead (k_prep3, prep_bounded=0)":
                           (ms_prep_p3 / max(ncalls_p3, 1)) if not args.headline_only else None,
