@@ -57,8 +57,142 @@ struct M4 {
   static constexpr size_t TAIL = r16(RCK) + kListCap * 8 + 128 * 4;        // re-check scratch, list, best[]
   static constexpr size_t WAVE = r16(STAGE > XCH ? (STAGE > TAIL ? STAGE : TAIL) : (XCH > TAIL ? XCH : TAIL));
   static constexpr size_t FRAG = (size_t)(2 * NT * NS + 2 * NLT) * 1024 + (size_t)(32 * NE + 32 * NT) * 4 + (size_t)(16 * NS) * 8;
-  static constexpr size_t LDS = r16(FRAG) + 8 * WAVE;
+  // the layer matrix in binary64 for the re-check, [DP][DP], behind the wave areas -- where the 160 KB allow it (d <= 52)
+  static constexpr size_t TLB = (size_t)DP * DP * 8;
+  static constexpr bool TL_OK = r16(FRAG) + 8 * WAVE + r16(TLB) <= 160 * 1024;
+  static constexpr size_t LDS = r16(FRAG) + 8 * WAVE + (TL_OK ? r16(TLB) : 0);
 };
+
+// recheck_segment (mlf_recheck_dev.hpp) for the one-launch path, where the re-check is the longest stage of a short kernel and
+// all latency (round 4 stamps at 300 proposals: 12 of 26 us -- five dependent round trips for a handful of pairs: the
+// queries' rows, two batches of matrix rows, two batches of live-point coordinates).  Same arithmetic, statement by
+// statement; what differs is where the operands come from and when they are asked for:
+//   * the layer matrix is read from LDS (tl: put there by the whole workgroup in the kernel's prologue) -- no round trip;
+//   * a lane's live-point row is requested in full BEFORE the whitening (it depends on the list entry alone) and waits in
+//     registers: one round trip, shared with the gather of the queries' rows.
+template <int DP, bool TL>
+__device__ __forceinline__ void recheck_mid(const RecheckWArgs &a, const double *tl, const unsigned long long *seg, unsigned count,
+                                            double *lds_r, int lane) {
+  if (count == 0) return;
+  const int d = a.d;
+  const int ds = (d + 1) | 1;
+  double *tq = lds_r;                                          // [kTQ][ds]
+  double *dlw = tq + kTQ * ds;                                 // [kTQ][64]
+  int *hkey = reinterpret_cast<int *>(dlw + kTQ * 64);         // [64]
+  int *hid = hkey + 64;
+  int *qlist = hid + 64;
+  const bool inrow = lane < d;
+  const double myctr = inrow ? a.lay_ctr[lane] : 0.0;
+  for (unsigned e0 = 0; e0 < count; e0 += kChunk) {
+    __builtin_amdgcn_wave_barrier();
+    hkey[lane] = -1;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned e = e0 + (unsigned)lane;
+    long long qi = -1;
+    int i = 0;
+    bool livee = false;
+    unsigned h = 0;
+    if (lane < kChunk && e < count) {
+      const unsigned long long ent = seg[e];
+      qi = (long long)(ent >> 32);
+      i = (int)(ent & 0xffffffffu);
+      livee = i < a.n && qi < a.nq && a.best[qi] > i;
+    }
+    // the live point of this lane's entry: all of it, now
+    double2 av[DP / 2];
+    {
+      const double2 *ar = reinterpret_cast<const double2 *>(a.refR + (size_t)(livee ? i : 0) * a.dp);
+#pragma unroll
+      for (int k2 = 0; k2 < DP / 2; ++k2) av[k2] = ar[k2];
+    }
+    if (livee) {
+      h = ((unsigned)qi * 2654435761u) & 63u;
+      while (true) {
+        const int old = atomicCAS(&hkey[h], -1, (int)qi);
+        if (old == -1 || old == (int)qi) break;
+        h = (h + 1u) & 63u;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool occ = hkey[lane] != -1;
+    const unsigned long long bm = __ballot(occ);
+    const unsigned nqb = (unsigned)__popcll(bm);
+    if (occ) {
+      const unsigned id = (unsigned)__popcll(bm & ((1ull << lane) - 1ull));
+      hid[lane] = (int)id;
+      qlist[id] = hkey[lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned myid = livee ? (unsigned)hid[h] : 0xffffffffu;
+    const double *tg = a.T64 + lane;
+    const double *tp = tl + (lane < DP ? lane : 0);
+    for (unsigned r0 = 0; r0 < nqb; r0 += kTQ) {
+      const unsigned nr = nqb - r0 < (unsigned)kTQ ? nqb - r0 : (unsigned)kTQ;   // wave-uniform
+      // the centred rows stay in REGISTERS, lane l holding coordinate l of each (one round trip for all of them); term k of
+      // the chain reaches the lanes through v_readlane (a scalar operand of the fused multiply-add) -- through LDS every one
+      // of the 50 dependent steps waited for its reads (9.7 of the re-check's 21 thousand cycles at 300 proposals)
+      double dq[kTQ];
+#pragma unroll
+      for (int t = 0; t < kTQ; ++t) dq[t] = ((unsigned)t < nr && inrow) ? a.pts[(long long)qlist[r0 + t] * d + lane] - myctr : 0.0;
+      double acc[kTQ];
+#pragma unroll
+      for (int t = 0; t < kTQ; ++t) acc[t] = 0.0;
+      auto bcast = [&](double v, int k) __attribute__((always_inline)) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, k);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), k);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+      };
+      auto chains = [&](auto nq_c) __attribute__((always_inline)) {
+        constexpr int NQ = decltype(nq_c)::value;
+        constexpr int KB = 10;   // matrix rows requested together
+        for (int k0 = 0; k0 < d; k0 += KB) {
+          double tk[KB];
+#pragma unroll
+          for (int q = 0; q < KB; ++q) {
+            const int k = k0 + q < d ? k0 + q : d - 1;
+            tk[q] = TL ? tp[k * DP] : tg[k * 64];
+          }
+#pragma unroll
+          for (int q = 0; q < KB; ++q) {
+            if (k0 + q < d) {
+#pragma unroll
+              for (int t = 0; t < NQ; ++t) acc[t] = __builtin_fma(bcast(dq[t], k0 + q), tk[q], acc[t]);
+            }
+          }
+        }
+      };
+      if (nr <= 2u) {
+        chains(std::integral_constant<int, 2>{});
+      } else if (nr <= 4u) {
+        chains(std::integral_constant<int, 4>{});
+      } else {
+        chains(std::integral_constant<int, kTQ>{});
+      }
+#pragma unroll
+      for (int t = 0; t < kTQ; ++t)
+        if ((unsigned)t < nr && inrow) tq[t * ds + lane] = acc[t];
+      __builtin_amdgcn_wave_barrier();
+      if (livee && myid >= r0 && myid < r0 + kTQ && a.best[qi] > i) {
+        const double *br = tq + (myid - r0) * ds;
+        double accd = 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 < DP / 2; ++k2) {   // the reference's loop: sub, mul, add, each rounded, k ascending
+          if (2 * k2 < d) {
+            const double d0 = av[k2].x - br[2 * k2];
+            accd += d0 * d0;
+          }
+          if (2 * k2 + 1 < d) {
+            const double d1 = av[k2].y - br[2 * k2 + 1];
+            accd += d1 * d1;
+          }
+        }
+        if (accd <= a.r2) atomicMin(&a.best[qi], i);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
 
 __host__ __device__ inline int m4_column(int t, int i) {
   return 32 * t + 16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3);
@@ -158,6 +292,10 @@ __global__ __launch_bounds__(512, 1) void k_inside_mid(MidArgs a) {
     const uint4 *srcL = reinterpret_cast<const uint4 *>(a.LtF);
     for (int e = tid; e < 2 * NT * NS * 64; e += 512) dst[e] = srcT[e];
     for (int e = tid; e < 2 * C::NLT * 64; e += 512) dst[2 * NT * NS * 64 + e] = srcL[e];
+  }
+  double *tlds = reinterpret_cast<double *>(ldsm + C::r16(C::FRAG) + 8 * C::WAVE);   // [DP][DP] (TL_OK)
+  if constexpr (C::TL_OK) {
+    for (int e = tid; e < DP * DP; e += 512) tlds[e] = a.T64[(e / DP) * 64 + (e % DP)];
   }
   if (tid < 32 * NE) y0l[tid] = a.y0[tid];
   if (tid < 32 * NT) {
@@ -540,7 +678,7 @@ __global__ __launch_bounds__(512, 1) void k_inside_mid(MidArgs a) {
     rw.T64 = a.T64;
     rw.r2 = a.r2;
     rw.best = lbest - set * 128;   // best[query] of the wave's own 128 queries
-    recheck_segment(rw, plist, cursor, lds_r, lane);
+    recheck_mid<DP, C::TL_OK>(rw, tlds, plist, cursor, lds_r, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
   }
