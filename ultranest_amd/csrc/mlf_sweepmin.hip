@@ -33,7 +33,6 @@
 #include "mlf_filter.hpp"
 #include "mlf_filter_dev.hpp"
 #include "mlf_recheck_dev.hpp"
-#include "mlf_dpp_dev.hpp"
 
 #include <math.h>
 
@@ -355,7 +354,12 @@ __device__ __attribute__((noinline)) void uncertain_sweep(const void *refF_, int
     for (int g = 0; g < QW; ++g) list_group(g, t);
   };
   // tiles requested TWO ahead (three register sets): with one ahead every tile waited for its L2 round trip (2 500 cycles
-  // per tile against ~1 000 of matrix instructions for the two waves of a SIMD); requests past the range re-read its last tile
+  // per tile against ~1 000 of matrix instructions for the two waves of a SIMD); requests past the range re-read its last tile.
+  // Still ~2 400 cycles per tile.  Tried: three and four ahead (four / five register sets): spills inside the loop at KS = 4,
+  // 48 600 against 38 800 cycles for the stage; every workgroup starting at another tile of its range (so that the workgroups
+  // of an XCD find each other's tiles in L2): no change.  The loop's own slow path (a group with a value in reach: 16 compares,
+  // an LDS atomic, the list stores; one group in four here -- every proposal of the set has a band pair somewhere) costs about
+  // as much as the matrix instructions
   half8 A0[KS], A1[KS], A2[KS];
   if (tile0 < tile1) {
     auto req = [&](half8(&A)[KS], int t) __attribute__((always_inline)) {
@@ -412,36 +416,56 @@ __device__ __attribute__((noinline)) void uncertain_pairs(const unsigned *plist,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 16 queries of a set (rows 16 wv .. 16 wv + 15 of tq[.][stride]: the CENTRED proposals x - c) whitened in place: lane =
-// output coordinate, t_c = sum_k x_k T[k][c] with k ascending and one fused multiply-add per term -- the chain of k_prep /
-// k_whiten_rows, the same operands, bit for bit (the padded terms k >= d are kept as there).  T[k][.] is one LDS read per k
-// for all 16 queries, x_k a broadcast LDS read per query.  (First version: k_whiten_rows' own form, rows in registers and
-// x_k through the DPP operand of v_fmac_f64, eight rows at a time: 30 000 cycles for the 16 rows; this one: see DESIGN.)
-__device__ __attribute__((noinline)) void whiten16(const double *tl, int ldt8_, int d_, int dp_, double *tq, int wv_, int lane) {
+// 16 queries of a set (rows 16 wv .. 16 wv + 15 of tq[.][stride]: the CENTRED proposals x - c) whitened in place:
+// t_c = sum_k x_k T[k][c] with k ascending and one fused multiply-add per term -- the chain of k_prep / k_whiten_rows, the same
+// operands, bit for bit (the padded terms k >= d are kept as there).  History: k_whiten_rows' own form (rows in registers, x_k
+// through the DPP operand of v_fmac_f64, eight rows at a time) 30 000 cycles for the 16 rows; lane = output coordinate with
+// T[k][.] one LDS read per k and x_k a broadcast LDS read per query: 20 800; this form: 11 700.
+// On the FP64 matrix cores: v_mfma_f64_16x16x4_f64 accumulates k-ascending with one rounding per fused
+// multiply-add (measured bit-identical to the scalar chain: scripts/probes/mfma64_probe.hip; k_prep3 whitens whole batches
+// this way), so C[c][q] += sum over 4 k of T[k][c] x_q[k] IS four steps of the chain of query q, output c.  A = T^T fragment
+// (lane l: T[4 ks + (l >> 4)][16 ct + (l & 15)], LDS), B = the centred rows (lane l: x_{q = l & 15}[4 ks + (l >> 4)], LDS), 13 x 4
+// instructions and 65 LDS reads per lane for the wave's 16 queries where the vector form takes 800 fused multiply-adds and 850
+// LDS reads.  Terms past d contribute 0 x T (kept, as in the chain); past dp both operands are zero.
+typedef double double4m __attribute__((ext_vector_type(4)));
+
+template <int NK>
+__device__ __attribute__((noinline)) void whiten16_mfma(const double *tl, int ldt8_, int d_, int dp_, double *tq, int wv_, int lane) {
   const int ldt8 = uni(ldt8_), d = uni(d_), dp = uni(dp_), wv = uni(wv_);
+  constexpr int NC = (NK + 3) / 4;   // output tiles of 16 coordinates
   const int ds = uncertain_row_stride(d);
-  const int c = lane < d ? lane : 0;
-  const double *rows = tq + 16 * wv * ds;
-  const double *tcol = tl + c;
-  double acc[16];
+  const int q = lane & 15, kq = lane >> 4;
+  const double *row = tq + (16 * wv + q) * ds;
+  double bfr[NK];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-#pragma unroll 2
-  for (int k = 0; k < d; ++k) {
-    const double tv = tcol[k * ldt8];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = __builtin_fma(rows[i * ds + k], tv, acc[i]);
+  for (int ks = 0; ks < NK; ++ks) {
+    const int k = 4 * ks + kq;
+    bfr[ks] = k < d ? row[k] : 0.0;
   }
-  for (int k = d; k < dp; ++k) {   // the padded terms of k_prep / k_whiten_rows: 0 x T[k][c]
-    const double tv = tcol[k * ldt8];
+  double4m t[NC];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = __builtin_fma(0.0, tv, acc[i]);
+  for (int ct = 0; ct < NC; ++ct) t[ct] = (double4m){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    const int k = 4 * ks + kq;
+    double afr[NC];
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+      const int c = 16 * ct + q;
+      afr[ct] = (k < dp && c < d) ? tl[k * ldt8 + c] : 0.0;
+    }
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) t[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ct], bfr[ks], t[ct], 0, 0, 0);
   }
   __builtin_amdgcn_wave_barrier();   // every lane has read the rows before they are overwritten
-  if (lane < d) {
+  double *out = tq + (16 * wv + q) * ds;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tq[(16 * wv + i) * ds + lane] = acc[i];
-  }
+  for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * ct + kq + 4 * r;   // output row of the accumulator register (mlf_prep3.hip)
+      if (c < d) out[c] = t[ct][r];
+    }
 }
 
 // The uncertain queries: band pairs found, queries whitened, pairs decided -- in ONE launch, a workgroup of 8 waves per
@@ -532,7 +556,11 @@ __global__ __launch_bounds__(512, 1) void k_uncertain(UncertainArgs a) {
     }
     __syncthreads();
     stamp();
-    whiten16(tl, a.ldt8, d, a.dp, tq, wv, lane);
+    // d <= 64 here (launch_uncertain): 4 NK >= dp
+    if (a.dp <= 16) whiten16_mfma<4>(tl, a.ldt8, d, a.dp, tq, wv, lane);
+    else if (a.dp <= 32) whiten16_mfma<8>(tl, a.ldt8, d, a.dp, tq, wv, lane);
+    else if (a.dp <= 52) whiten16_mfma<13>(tl, a.ldt8, d, a.dp, tq, wv, lane);
+    else whiten16_mfma<16>(tl, a.ldt8, d, a.dp, tq, wv, lane);
     stamp();
     __syncthreads();
     stamp();
