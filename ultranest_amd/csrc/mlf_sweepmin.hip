@@ -187,8 +187,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(min_waves(K
   if (PF == 2) {
     half8 A2[KS];
     int o0 = tstart * kTileBytes, o1 = next_off(o0), o2 = next_off(o1);
+    // the two requests in THIS order, nothing moved across: the compiler interleaved them (three loads of the second tile in
+    // front of the first tile's), and the wait counts of the loop -- which must also be right for its first pass -- then
+    // demanded half of the NEXT tile's loads before the current tile's matrix instructions in every pass: vmcnt(6), (6), (5), (4)
+    // where the steady state allows (10), (9), (9), (8)
     load_tile<KS>(A0, rsrc, voff, o0);
+    __builtin_amdgcn_sched_barrier(0);
     load_tile<KS>(A1, rsrc, voff, o1);
+    __builtin_amdgcn_sched_barrier(0);
     for (int it = 0; it < ntl; it += 3) {
       load_tile<KS>(A2, rsrc, voff, o2);
       tile(A0);
@@ -284,17 +290,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(min_waves(K
 // The stages of k_uncertain are functions of their own (not inlined): compiled into one body the sweep's 160 registers of
 // operands and accumulators, the whitening's 80 and the pair stage's 140 ended in spills INSIDE the tile loop (6 500 cycles
 // per tile instead of ~1 000).
+// Their LDS arguments arrive as GENERIC pointers; used as such they become flat_* instructions, which count on vmcnt AND
+// lgkmcnt and return in no fixed order relative to either: the compiler then waits with vmcnt(0) around them -- in
+// uncertain_sweep that wait sat right behind the request for the tile two ahead, i.e. every third tile waited for a full
+// memory round trip and the list's slow path for another (the stage: 38 800 cycles for 16 tiles).  Each function therefore
+// casts them to LDS pointers first (lds_ptr).
+template <class T>
+using lds_t = __attribute__((address_space(3))) T;
+template <class T>
+__device__ __forceinline__ lds_t<T> *lds_ptr(T *p) {
+  return (lds_t<T> *)p;
+}
+template <class T>
+__device__ __forceinline__ const lds_t<T> *lds_ptr(const T *p) {
+  return (const lds_t<T> *)p;
+}
+
 template <int KS>
 __device__ __attribute__((noinline)) void uncertain_sweep(const void *refF_, int ntiles32_, const void *qF_, const float *thi_, long long set_,
-                                                          long long ngroups_, long long nslots_, unsigned *plist, unsigned *lcount,
+                                                          long long ngroups_, long long nslots_, unsigned *plist_, unsigned *lcount_,
                                                           int wv_, int lane) {
   constexpr int QW = 4;
+  lds_t<unsigned> *plist = lds_ptr(plist_);
+  lds_t<unsigned> *lcount = lds_ptr(lcount_);
   const void *refF = uni(refF_);
   const int ntiles32 = uni(ntiles32_), wv = uni(wv_);
   const long long set = uni(set_), ngroups = uni(ngroups_), nslots = uni(nslots_);
   qF_ = uni(qF_);
   thi_ = uni(thi_);
-  const half8 *qF = reinterpret_cast<const half8 *>(qF_);
+  typedef __attribute__((address_space(1))) const half8 ghalf8;   // global, not generic: ordered with the tile loads on vmcnt
+  typedef __attribute__((address_space(1))) const float gfloat;
+  ghalf8 *qF = (ghalf8 *)qF_;
+  gfloat *thig = (gfloat *)thi_;
   constexpr int kTileBytes = KS * 1024;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(refF), 0, ntiles32 * kTileBytes, 0x00020000);
@@ -310,13 +337,16 @@ __device__ __attribute__((noinline)) void uncertain_sweep(const void *refF_, int
     for (int s = 0; s < KS; ++s) bq[g][s] = qF[((size_t)grp * KS + s) * 64 + lane];
     const long long qi = grp * 32 + (lane & 31);
     const bool have = g0 + g < ngroups && qi < nslots;
-    thi[g] = have ? thi_[qi] : -1.0f;
+    thi[g] = have ? thig[qi] : -1.0f;
     if (!have) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) bq[g][s] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
   const int tile0 = ntiles32 * wv / 8, tile1 = ntiles32 * (wv + 1) / 8;
+  // the query operands are HERE before the first tile is asked for: left pending, their wait would sit at the head of the tile
+  // loop -- as vmcnt(0), behind every request for the tile two ahead
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   float16v acc[QW];
   auto mm = [&](const half8(&A)[KS], int ga, int gb) __attribute__((always_inline)) {
 #pragma unroll
@@ -337,7 +367,7 @@ __device__ __attribute__((noinline)) void uncertain_sweep(const void *refF_, int
       for (int r = 0; r < 16; ++r) bits |= (c[r] <= thi[g]) ? (1u << r) : 0u;
     }
     if (bits != 0u) {
-      unsigned at = atomicAdd(lcount, (unsigned)__popc(bits));
+      unsigned at = __hip_atomic_fetch_add(lcount, (unsigned)__popc(bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const unsigned ql = (unsigned)(g * 32 + (lane & 31));
       while (bits != 0u) {
         const int r = __builtin_ctz(bits);
@@ -366,7 +396,9 @@ __device__ __attribute__((noinline)) void uncertain_sweep(const void *refF_, int
       load_tile<KS>(A, rsrc, voff, (t < tile1 ? t : tile1 - 1) * kTileBytes);
     };
     req(A0, tile0);
+    __builtin_amdgcn_sched_barrier(0);   // in this order (see k_sweep_min)
     req(A1, tile0 + 1);
+    __builtin_amdgcn_sched_barrier(0);
     for (int t = tile0; t < tile1; t += 3) {
       req(A2, t + 2);
       tile(A0, t);
@@ -384,9 +416,13 @@ __device__ __attribute__((noinline)) void uncertain_sweep(const void *refF_, int
 // one round trip instead of one per unrolled batch of a 50-step chain -- then the reference's loop: sub, mul, add, each
 // rounded, k ascending (this file is compiled with -ffp-contract=off)
 template <int NCH>
-__device__ __attribute__((noinline)) void uncertain_pairs(const unsigned *plist, unsigned cnt_, const int *qid, const double *tq,
+__device__ __attribute__((noinline)) void uncertain_pairs(const unsigned *plist_, unsigned cnt_, const int *qid_, const double *tq_,
                                                           const double *refR_, int dp_, int d_, int n_, double r2, int *best_) {
-  const double *refR = uni(refR_);
+  const lds_t<unsigned> *plist = lds_ptr(plist_);
+  const lds_t<int> *qid = lds_ptr(qid_);
+  const lds_t<double> *tq = lds_ptr(tq_);
+  typedef __attribute__((address_space(1))) const double gdouble;
+  gdouble *refR = (gdouble *)uni(refR_);
   int *best = uni(best_);
   const int dp = uni(dp_), d = uni(d_), n = uni(n_);
   const unsigned cnt = (unsigned)uni((int)cnt_);
@@ -398,9 +434,11 @@ __device__ __attribute__((noinline)) void uncertain_pairs(const unsigned *plist,
     if (q < 0 || i >= n) continue;
     // 16 NCH >= dp coordinates are requested whatever d is (past dp they belong to the next row: the array has a spare row
     // behind its last); the arithmetic stops at d
-    const double2 *ar = reinterpret_cast<const double2 *>(refR + (size_t)i * dp);
-    const double *br = tq + ql * ds;
-    double2 row[8 * NCH];
+    typedef double double2v __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) const double2v gdouble2;
+    gdouble2 *ar = (gdouble2 *)(refR + (size_t)i * dp);
+    const lds_t<double> *br = tq + ql * ds;
+    double2v row[8 * NCH];
 #pragma unroll
     for (int k2 = 0; k2 < 8 * NCH; ++k2) row[k2] = ar[k2];
     double accd = 0.0;
@@ -430,12 +468,14 @@ __device__ __attribute__((noinline)) void uncertain_pairs(const unsigned *plist,
 typedef double double4m __attribute__((ext_vector_type(4)));
 
 template <int NK>
-__device__ __attribute__((noinline)) void whiten16_mfma(const double *tl, int ldt8_, int d_, int dp_, double *tq, int wv_, int lane) {
+__device__ __attribute__((noinline)) void whiten16_mfma(const double *tl_, int ldt8_, int d_, int dp_, double *tq_, int wv_, int lane) {
+  const lds_t<double> *tl = lds_ptr(tl_);
+  lds_t<double> *tq = lds_ptr(tq_);
   const int ldt8 = uni(ldt8_), d = uni(d_), dp = uni(dp_), wv = uni(wv_);
   constexpr int NC = (NK + 3) / 4;   // output tiles of 16 coordinates
   const int ds = uncertain_row_stride(d);
   const int q = lane & 15, kq = lane >> 4;
-  const double *row = tq + (16 * wv + q) * ds;
+  const lds_t<double> *row = tq + (16 * wv + q) * ds;
   double bfr[NK];
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
@@ -458,7 +498,7 @@ __device__ __attribute__((noinline)) void whiten16_mfma(const double *tl, int ld
     for (int ct = 0; ct < NC; ++ct) t[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ct], bfr[ks], t[ct], 0, 0, 0);
   }
   __builtin_amdgcn_wave_barrier();   // every lane has read the rows before they are overwritten
-  double *out = tq + (16 * wv + q) * ds;
+  lds_t<double> *out = tq + (16 * wv + q) * ds;
 #pragma unroll
   for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
