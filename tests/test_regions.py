@@ -432,3 +432,21 @@ def test_host_worker_is_per_process():
     os.close(w)
     assert os.read(r, 1) == b"1"
     os.waitpid(pid, 0)
+
+
+def test_update_clusters_both_label_routes_agree(backend, monkeypatch):
+    """layers.update_clusters takes its labels from one all-pairs pass (kernels.cluster_labels) up to 32768 points and from one
+    neighbour scan per growth round above: same labels, numbering, carried-over seeds and cluster means either way."""
+    from ultranest_amd import layers
+    rs = np.random.RandomState(12)
+    centres = rs.uniform(size=(5, 3))
+    t = centres[rs.randint(5, size=700)] + 0.02 * rs.normal(size=(700, 3))
+    prev = rs.randint(1, 7, size=700)
+    for ids in (None, prev):
+        want = layers.update_clusters(t, t, 0.003, ids)
+        with monkeypatch.context() as m:
+            m.setattr(layers, "_ADJACENCY_MAX_POINTS", 10)
+            got = layers.update_clusters(t, t, 0.003, ids)
+        assert got[0] == want[0] > 1
+        assert np.array_equal(got[1], want[1])
+        assert np.array_equal(got[2], want[2])

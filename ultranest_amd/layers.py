@@ -97,6 +97,39 @@ def _call_with_errstate(errstate, fn, *args):
         return fn(*args)
 
 
+# the all-pairs pass keeps one hit bit per pair (n^2 / 8 bytes on the device and in pinned host memory: 2 MB at n = 4000,
+# 128 MB at 32768); larger live sets take one neighbour scan per growth round instead
+_ADJACENCY_MAX_POINTS = 32768
+
+
+def _labels_by_growth_rounds(tpoints, maxradiussq, clusterids):
+    """The reference's loop as it stands (mlfriends.pyx:275-331): each growth round is one GPU neighbour scan (K1) of the
+    current cluster's members against all still unlabelled points."""
+    npts = len(tpoints)
+    previous = np.zeros(npts, dtype=int_dtype) if clusterids is None else np.asarray(clusterids)[:npts]
+    labels = np.zeros(npts, dtype=int_dtype)
+
+    def seed_for(cid, default):
+        carried = np.flatnonzero(previous == cid)
+        return carried[0] if len(carried) else default
+
+    current = 1
+    labels[seed_for(current, 0)] = current
+    while True:
+        unlabelled = np.flatnonzero(labels == 0)
+        if len(unlabelled) == 0:
+            break
+        hits = np.empty(len(unlabelled), dtype=int_dtype)
+        kernels.find_nearby(tpoints[labels == current], tpoints[unlabelled], maxradiussq, hits)
+        joined = unlabelled[hits >= 0]
+        if len(joined):
+            labels[joined] = current
+        else:
+            current += 1
+            labels[seed_for(current, unlabelled[0])] = current
+    return labels
+
+
 def update_clusters(upoints, tpoints, maxradiussq, clusterids=None):
     """Friends-of-friends clustering of `tpoints` with linking length sqrt(`maxradiussq`).
 
@@ -115,7 +148,10 @@ def update_clusters(upoints, tpoints, maxradiussq, clusterids=None):
         raise AssertionError(('different shapes of points', upoints.shape, tpoints.shape))
     if len(tpoints) == 0:
         raise IndexError('update_clusters: no points')   # the reference seeds clusterids[0] (:287)
-    _, labels = kernels.cluster_labels(tpoints, maxradiussq, clusterids)
+    if len(tpoints) <= _ADJACENCY_MAX_POINTS:
+        _, labels = kernels.cluster_labels(tpoints, maxradiussq, clusterids)
+    else:
+        labels = _labels_by_growth_rounds(tpoints, maxradiussq, clusterids)
 
     assert (labels > 0).all()
     present = np.unique(labels)
