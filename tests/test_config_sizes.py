@@ -161,3 +161,34 @@ def test_c5_full_size_filter_equals_exact_scan(case, fuzz_draws):
             assert 0.0 < got.mean() < 1.0, got.mean()
         if case == "r2-edge-lo":
             assert got.sum() <= len(pts[5::1000]) + 5, got.sum()
+
+
+@pytest.mark.parametrize("name,opts", [("per-proposal stage inside the first sweep launch", {"fused_first_range": 1}),
+                                       ("per-tile band test", {"sweep_min": 0}),
+                                       ("binary64 per-proposal stage", {"prep_bounded": 0}),
+                                       ("single sweep", {"filter_phases": 0})])
+def test_c5_full_size_optional_routings(name, opts, fuzz_draws):
+    """The routings that are off by default (k_prep_sweep; k_sweep with its own re-check; k_prep3; one sweep over all tiles) on a
+    full-size batch, against the default routing and the exact scan: results never depend on options."""
+    from ultranest_amd import _lib
+    z, rad = fuzz_draws
+    N, d = 4000, z.shape[1]
+    rs = np.random.RandomState(77 + FUZZ_OFFSET)
+    u = np.where(rs.uniform(size=(N, 1)) < 0.5, 0.35, 0.65) + 0.03 * rs.normal(size=(N, d))
+    region = _c5_region(u)
+    pts = _ellipsoid_draws(region, z, rad)
+    pts[5::1000] = u[rs.randint(N, size=len(pts[5::1000]))]
+    default = region.inside(pts)
+    restore = {"fused_first_range": 0, "sweep_min": 1, "prep_bounded": 1, "filter_phases": 1, "filter": 1}
+    try:
+        for k, v in opts.items():
+            _lib.set_option(k, v)
+        got = region.inside(pts)
+        _lib.set_option("filter", 0)
+        want = region.inside(pts)
+    finally:
+        for k, v in restore.items():
+            _lib.set_option(k, v)
+    assert np.array_equal(default, want), (name, int((default != want).sum()))
+    assert np.array_equal(got, want), (name, int((got != want).sum()))
+    assert 0.0 < got.mean() < 1.0
