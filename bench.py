@@ -81,7 +81,7 @@ def time_rebuild(u, group, device_resident=False):
     from ultranest_amd.harness import RegionUpdater
     rs = np.random.RandomState(7)
     upd = RegionUpdater(NDIM, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer, group=group,
-                        device_resident=device_resident)
+                        device_resident=device_resident, freeze_gc=True)
     np.random.seed(11)
     t0 = time.perf_counter()
     upd.update(u, nbootstraps=NBOOT, minvol=0.)

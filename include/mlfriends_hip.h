@@ -64,6 +64,10 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *                              (the compaction rides in the first range's epilogue); n >= 2: n ranges
  *   "filter_phase_min_queries" smaller batches sweep all tiles in one launch
  *   "filter_first_range_pct"   10 ... 90, default 50: share of the live-point tiles the first of two ranges takes
+ *   "filter_order"             1 (default): the mask-mode kernels (MLFriends.inside: any hit decides, mlfriends.pyx:1186-1211) sweep a
+ *                              copy of the live points ordered nearest-to-the-centre first, so that the first of two tile
+ *                              ranges decides more proposals; 0: storage order.  find_nearby's first-index operand always
+ *                              keeps storage order (mlfriends.pyx:176-183).  Set per handle it takes effect with the next batch
  *   "filter_narrow_tail"       0: every range with 4 query groups per wave; 1 (default): later ranges with 2
  *   "filter_split_waves"       waves a single-sweep launch over a small batch aims at when it splits the tiles (1-16 ranges)
  *   "fused_prep"               1/0: fused per-proposal stage, or k_prep followed by a separate quantisation

@@ -74,7 +74,7 @@ for name, n, d, p in (("C2", 2000, 20, 100000), ("C5", 4000, 50, 1000000), ("C1-
         handle.set_thresholds(region.enlarge, r2)
         rate, acc = timed_inside(handle, pts)
         res[label] = {"proposals_per_s": rate, "accept": acc}
-    upd = RegionUpdater(d, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer)
+    upd = RegionUpdater(d, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer, freeze_gc=True)
     np.random.seed(11)
     upd.update(u, nbootstraps=30, minvol=0.)
     rs = np.random.RandomState(7)

@@ -14,7 +14,7 @@ from ultranest_amd.harness import RegionUpdater  # noqa: E402
 
 u, region = bench.build_region(None)
 rs = np.random.RandomState(7)
-upd = RegionUpdater(bench.NDIM, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer)
+upd = RegionUpdater(bench.NDIM, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer, freeze_gc=True)
 np.random.seed(11)
 upd.update(u, nbootstraps=bench.NBOOT, minvol=0.)
 for rep in range(3):

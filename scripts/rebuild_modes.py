@@ -16,7 +16,7 @@ u, region = bench.build_region(None)
 out = {}
 for name, dev in (("default", False), ("device_resident", True), ("default_again", False), ("device_resident_again", True)):
     rs = np.random.RandomState(7)
-    upd = RegionUpdater(bench.NDIM, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer, device_resident=dev)
+    upd = RegionUpdater(bench.NDIM, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer, device_resident=dev, freeze_gc=True)
     np.random.seed(11)
     upd.update(u, nbootstraps=bench.NBOOT, minvol=0.)
     ts = []
@@ -31,7 +31,7 @@ for name, dev in (("default", False), ("device_resident", True), ("default_again
 print(json.dumps(out, indent=1))
 
 # where the device-resident path spends its time (each checkpoint behind a device synchronisation)
-upd = RegionUpdater(bench.NDIM, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer, device_resident=True)
+upd = RegionUpdater(bench.NDIM, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer, device_resident=True, freeze_gc=True)
 np.random.seed(11)
 upd.update(u, nbootstraps=bench.NBOOT, minvol=0.)
 rs = np.random.RandomState(7)

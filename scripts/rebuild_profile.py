@@ -18,7 +18,7 @@ from ultranest_amd.harness import RegionUpdater  # noqa: E402
 N, D = 4000, 50
 rs = np.random.RandomState(1)
 u = 0.5 + 0.05 * rs.normal(size=(N, D))
-upd = RegionUpdater(D, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer)
+upd = RegionUpdater(D, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer, freeze_gc=True)
 np.random.seed(11)
 upd.update(u, nbootstraps=30, minvol=0.)
 u2 = u.copy()

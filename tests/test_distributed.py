@@ -420,3 +420,107 @@ def test_allgather_samples_uneven_ranks():
     from ultranest_amd import distributed
     u, v, l_, nc = distributed.allgather_samples(np.ones((2, 3)), np.zeros((2, 1)), [1.0, 2.0], 7)
     assert u.shape == (2, 3) and v.shape == (2, 1) and list(l_) == [1.0, 2.0] and nc == 7
+
+
+# ---- round 5: every region class through a real group; a world-size-8 rehearsal at C4 -------------------------------
+def _plain_install():
+    """install the oracle stand-in in a spawned rank (no pytest there)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import oracle_backend
+    import ultranest_amd.kernels as K
+    import ultranest_amd.mlfriends as M
+    for name in oracle_backend.PATCHED:
+        setattr(K, name, getattr(oracle_backend, name))
+        if hasattr(M, name):
+            setattr(M, name, getattr(oracle_backend, name))
+    return M
+
+
+def _make_region(M, cls_name, seed, n, d):
+    u = inputs.live_points(seed, n, d)
+    layer = M.AffineLayer()
+    layer.optimize(u, u)
+    return getattr(M, cls_name)(u, layer)
+
+
+def _class_worker(rank, world_size, port, out, cls_name, n, d, nboot, failing_rank, exc_name):
+    M = _plain_install()
+    import torch.distributed as dist
+    from ultranest_amd import distributed
+    _init(dist, "gloo", port, rank, world_size)
+    try:
+        region = _make_region(M, cls_name, 31, n, d)
+        if failing_rank is not None and rank == failing_rank:
+            exc = {"AssertionError": AssertionError, "FloatingPointError": FloatingPointError,
+                   "ZeroDivisionError": ZeroDivisionError}[exc_name]
+
+            def shard(masks, rank_, size_, minvol=0.):
+                raise exc("this rank's shard only")
+            region.enlargement_share = shard
+        rng = np.random.RandomState(1234 if rank == 0 else 999 + rank)     # only rank 0's draws may matter
+        try:
+            r, f = distributed.update_region_bootstrap(region, nboot, minvol=0., rng=rng)
+            out[rank] = (r, f, region.maxradiussq, region.enlarge)
+        except np.linalg.LinAlgError:
+            out[rank] = "LinAlgError"
+        except RuntimeError:
+            out[rank] = "RuntimeError"
+        t = distributed.allreduce_max([float(rank), 1.0])                    # still in step; every rank is seen
+        ones = distributed.allreduce_max([1.0])
+        out[100 + rank] = (float(t[0]), float(ones[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cls_name", ["RobustEllipsoidRegion", "SimpleRegion", "MLFriends"])
+def test_every_region_class_keeps_its_own_rule_across_ranks(cls_name, monkeypatch):
+    """with more than one rank RobustEllipsoidRegion / SimpleRegion went through the inherited MLFriends
+    share -- friends radius instead of 1e300, full-covariance factor instead of the per-axis one.  Two ranks must return
+    what one process returns, bit for bit, for every region class (reference: mlfriends.pyx:1392-1440, 1511-1548)."""
+    import torch.multiprocessing as mp
+    import oracle_backend
+    oracle_backend.install(monkeypatch)
+    import ultranest_amd.mlfriends as M
+    region = _make_region(M, cls_name, 31, 300, 4)
+    r1, f1 = region.compute_enlargement(nbootstraps=30, rng=np.random.RandomState(1234))
+    if cls_name != "MLFriends":
+        assert r1 == 1e300
+    out = mp.Manager().dict()
+    mp.spawn(_class_worker, args=(2, _free_port(), out, cls_name, 300, 4, 30, None, None), nprocs=2, join=True)
+    for rank in range(2):
+        assert out[rank] == (r1, f1, r1, f1), (rank, out[rank], (r1, f1))
+
+
+def test_world_size_8_rehearsal_at_c4(monkeypatch):
+    """C4's shape (N = 4000, d = 50, 30 rounds) through EIGHT real ranks and their collectives --
+    the (4,4,4,4,4,4,3,3) round split and the 63-row-block split (8,8,8,8,8,8,8,7) -- bit-identical to one process
+    (integrator.py:375-415 is the step this replaces)."""
+    import torch.multiprocessing as mp
+    import oracle_backend
+    oracle_backend.install(monkeypatch)
+    import ultranest_amd.mlfriends as M
+    from ultranest_amd.distributed import shard_bounds
+    assert [b - a for a, b in (shard_bounds(63, r, 8) for r in range(8))] == [8, 8, 8, 8, 8, 8, 8, 7]
+    region = _make_region(M, "MLFriends", 31, 4000, 50)
+    r1, f1 = region.compute_enlargement(nbootstraps=30, rng=np.random.RandomState(1234))
+    out = mp.Manager().dict()
+    mp.spawn(_class_worker, args=(8, _free_port(), out, "MLFriends", 4000, 50, 30, None, None), nprocs=8, join=True)
+    for rank in range(8):
+        assert out[rank] == (r1, f1, r1, f1), (rank, out[rank], (r1, f1))
+        assert out[100 + rank] == (7.0, 1.0)
+
+
+@pytest.mark.parametrize("exc_name,want", [("FloatingPointError", "LinAlgError"), ("AssertionError", "RuntimeError"),
+                                           ("ZeroDivisionError", "RuntimeError")])
+def test_error_class_from_rank_5_of_8_reaches_every_rank(exc_name, want):
+    """only rank 5 fails; all eight leave with the same exception type and the group stays in step.  A numerical failure
+    (the three types of the driver's handlers, integrator.py:2123-2131) -> LinAlgError; an AssertionError or a
+    ZeroDivisionError is NOT one of them (a single process propagates those) -> RuntimeError everywhere."""
+    import torch.multiprocessing as mp
+    out = mp.Manager().dict()
+    mp.spawn(_class_worker, args=(8, _free_port(), out, "MLFriends", 300, 4, 30, 5, exc_name), nprocs=8, join=True)
+    for rank in range(8):
+        assert out[rank] == want, dict(out)
+        assert out[100 + rank] == (7.0, 1.0)

@@ -257,11 +257,16 @@ def test_region_inside_random_shapes_filter_equals_exact_scan(seed, K):
     for name, opts in (("default", {}), ("exact", {"filter": 0}), ("binary64 stage", {"prep_bounded": 0}),
                        ("single sweep", {"filter_phases": 0}), ("wide tail", {"filter_narrow_tail": 0}),
                        ("one launch", {"mid_max_queries": 131072}), ("three launches", {"mid_max_queries": 0}),
-                       ("per-tile band test", {"mid_max_queries": 0, "sweep_min": 0})):
+                       ("per-tile band test", {"mid_max_queries": 0, "sweep_min": 0}),
+                       ("storage order", {"filter_order": 0}), ("storage order, three launches", {"filter_order": 0, "mid_max_queries": 0})):
         mid_before = 131072 if request_param_one_launch() else 0
         for k, v in opts.items():
-            _lib.set_option(k, v)
+            if k == "filter_order":      # per handle: the next batch rebuilds (or drops) the centre-first operand
+                reg.set_option(k, v)
+            else:
+                _lib.set_option(k, v)
         got[name] = reg.inside(pts)
+        reg.set_option("filter_order")
         for k, v in (("filter", 1), ("prep_bounded", 1), ("filter_phases", 1), ("filter_narrow_tail", 1), ("sweep_min", 1),
                      ("mid_max_queries", mid_before)):
             _lib.set_option(k, v)

@@ -69,13 +69,14 @@ enum Opt : int {
   OPT_MID_MAX,             // "mid_max_queries": batches up to this size take the one-launch path (mlf_mid.hip); 0 = never
   OPT_FUSED_FIRST,         // "fused_first_range" 0/1: per-proposal stage and first range of the min-only sweep in one launch (mlf_fused.hip)
   OPT_BOOT_SYM,            // "boot_symmetric" 0/1: whole-range bootstrap passes compute every pair distance once (k_boot_sym)
+  OPT_ORDER,               // "filter_order" 0/1: mask-mode operand in storage order / nearest to the centre first (k_ref_rank)
   OPT_COUNT
 };
 const char *const kOptNames[OPT_COUNT] = {"filter", "filter_first_range_pct", "filter_split_waves", "filter_narrow_tail",
                                           "small_path", "fused_prep", "filter_phase_min_queries", "filter_phases",
                                           "time_filter_launches", "prep_bounded", "filter_min_queries", "sweep_min", "mid_max_queries", "fused_first_range",
-                                          "boot_symmetric"};
-long long g_opt[OPT_COUNT] = {1, 50, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 0, 1};
+                                          "boot_symmetric", "filter_order"};
+long long g_opt[OPT_COUNT] = {1, 50, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 0, 1, 1};
 
 struct OptOverrides {
   long long v[OPT_COUNT] = {};
@@ -108,6 +109,11 @@ struct FilterCtx {
   int ks = 0, ntiles32 = 0;
   double sigma = 1.0, amax = 0.0;
   DevBuf stats, statscratch, refF, qF, tlo, thi, route, best, counters, list, segcnt, gate2;
+  // mask-mode operand: the live points nearest to the centre first (launch_ref_order): binary16 fragments, the rows the exact
+  // re-check reads (same order), keys and permutation (slot -> storage row).  The first-index operand refF keeps storage order.
+  DevBuf refFm, refRm, okeys, operm;
+  bool ordered = false;      // refFm / refRm are current
+  int order_n = -1;          // the live-set size the permutation was ranked for
   // phased sweep: two compacted query sets (ping-pong)
   DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png, pmin;
   DevBuf mid_rec, mid_meta, mid_arrive;   // one-launch path (mlf_mid.hip): records of the tile ranges, arrival counters
@@ -127,11 +133,12 @@ struct FilterCtx {
   size_t kev_used = 0;
   OptOverrides ov;            // per-handle tuning (mlf_region_set_option); the stateless calls' context has none
   void release() {
-    DevBuf *b[] = {&stats, &statscratch, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2,
+    DevBuf *b[] = {&stats, &statscratch, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2, &refFm, &refRm, &okeys, &operm,
                    &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png, &pmin, &mid_rec, &mid_meta, &mid_arrive,
                    &ell_list, &misc};
     for (DevBuf *x : b) x->release();
-    refs_ready = usable = false;
+    refs_ready = usable = ordered = false;
+    order_n = -1;
   }
 };
 
@@ -311,6 +318,25 @@ int filter_prepare_refs(FilterCtx &f, const double *refR, int n, int d, int dp, 
   launch_ref_stats(refR, n, dp, dp, f.stats.as<double>(), f.statscratch.as<double>(), s);
   launch_quant_refs(refR, n, npad32, dp, dp, ks, f.stats.as<double>(), f.refF.p, s);
   CK(hipGetLastError());
+  f.ordered = false;
+  if (opt(f, OPT_ORDER) && n <= 65536) {
+    // a NEW live set (host_sync) is ranked; a refresh behind row replacements keeps the permutation -- the replaced rows stay
+    // in their slots (the order is a heuristic of the sweep, not part of any answer) -- and only gathers and requantises
+    const int nrows = round_up(n, 64) + 1;   // the re-check requests whole 16-coordinate blocks: a spare row behind the last
+    const bool rerank = host_sync || f.order_n != n;
+    CK(f.refFm.reserve((size_t)npad32 * ks * 16 * 2));
+    CK(f.refRm.reserve((size_t)nrows * dp * sizeof(double)));
+    CK(f.okeys.reserve((size_t)n * sizeof(unsigned long long)));
+    CK(f.operm.reserve((size_t)n * sizeof(int)));
+    launch_ref_order(refR, n, nrows, dp, dp, f.stats.as<double>(), f.okeys.as<unsigned long long>(), f.operm.as<int>(),
+                     f.refRm.as<double>(), rerank, s);
+    launch_quant_refs(f.refRm.as<double>(), n, npad32, dp, dp, ks, f.stats.as<double>(), f.refFm.p, s);
+    CK(hipGetLastError());
+    f.ordered = true;
+    f.order_n = n;
+  } else if (host_sync) {
+    f.order_n = -1;
+  }
   if (host_sync) {
     double h[4];
     CK(hipMemcpyAsync(h, f.stats.p, sizeof h, hipMemcpyDeviceToHost, s));
@@ -408,12 +434,16 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   unsigned cap = 0;
   f.mid_last = false;
   if (int rc = filter_reserve(f, nq, &cap)) return rc;
+  // mask mode sweeps the centre-first copy of the live points (any hit decides); the first-index mode keeps storage order
+  const bool use_m = out_idx == nullptr && f.ordered && opt(f, OPT_ORDER);
+  const void *const opF = use_m ? f.refFm.p : f.refF.p;
+  const double *const opR = use_m ? f.refRm.as<double>() : refR;
   if (!quantised)
   launch_quant_queries(q, ldq, nq, nqpad, d, dp, f.ks, f.stats.as<double>(), r2, gate, f.qF.p, f.tlo.as<float>(),
                        f.thi.as<float>(), f.route.as<uint8_t>(), f.best.as<int>(), f.counters.as<unsigned>(), s);
   CK(hipGetLastError());
   FilterArgs fa{};
-  fa.refF = f.refF.p;
+  fa.refF = opF;
   fa.qF = f.qF.p;
   fa.tlo = f.tlo.as<float>();
   fa.thi = f.thi.as<float>();
@@ -459,7 +489,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     fa.rw.list = f.list.as<unsigned long long>();
     fa.rw.seg_cap = cap;
     fa.rw.seg_count = f.segcnt.as<unsigned>();
-    fa.rw.refR = refR;
+    fa.rw.refR = opR;
     fa.rw.n = n;
     fa.rw.d = d;
     fa.rw.dp = dp;
@@ -504,7 +534,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       return 0;
     };
     MinArgs m{};
-    m.refF = f.refF.p;
+    m.refF = opF;
     m.ntiles32 = f.ntiles32;
     m.nq = nq;
     m.best = f.best.as<int>();
@@ -526,7 +556,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     if (xs->prep) {   // per-proposal stage + first range in one launch: the operand never leaves the registers
       FusedArgs fu{};
       fu.p = *xs->prep;
-      fu.refF = f.refF.p;
+      fu.refF = opF;
       fu.ntiles32 = f.ntiles32;
       fu.tile0 = 0;
       fu.tile1 = c;
@@ -560,7 +590,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, 0), m, s); })) return rc;
     // the uncertain set: band pairs, exact whitening, exact distances -- one launch; the ellipsoid band rides along
     UncertainArgs ua{};
-    ua.refF = f.refF.p;
+    ua.refF = opF;
     ua.ntiles32 = f.ntiles32;
     ua.qF = f.pqF[1].p;
     ua.thi = f.pthi[1].as<float>();
@@ -572,7 +602,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     ua.lay_ctr = xs->lay_ctr;
     ua.T8 = xs->T8;
     ua.ldt8 = xs->ldt;
-    ua.refR = refR;
+    ua.refR = opR;
     ua.n = n;
     ua.r2 = r2;
     ua.best = f.best.as<int>();
@@ -669,7 +699,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     rw.seg_count = f.segcnt.as<unsigned>();
     rw.nsegs = nsegs_all;
     rw.unit_cap = (unsigned)(nphase * (f.ks <= 4 ? 4 : (f.ks <= 8 ? 2 : 1)) * 32);   // queries per filter wave, all phases (a narrow later range has fewer)
-    rw.refR = refR;
+    rw.refR = opR;
     rw.n = n;
     rw.d = d;
     rw.dp = dp;
@@ -690,7 +720,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     ra.list = f.list.as<unsigned long long>();
     ra.seg_cap = cap;
     ra.seg_count = f.segcnt.as<unsigned>();
-    ra.refR = refR;
+    ra.refR = opR;
     ra.n = n;
     ra.d = d;
     ra.dp = dp;
@@ -1082,9 +1112,10 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
     ma.ell_eps_scale = r->ell_eps_scale;
     ma.enlarge = r->enlarge;
     ma.chol_ok = r->chol_ok ? 1 : 0;
-    ma.refF = f.refF.p;
+    const bool use_m = f.ordered && opt(f, OPT_ORDER);
+    ma.refF = use_m ? f.refFm.p : f.refF.p;
     ma.ntiles32 = f.ntiles32;
-    ma.refR = r->refR.as<double>();
+    ma.refR = use_m ? f.refRm.as<double>() : r->refR.as<double>();
     ma.n = r->n;
     ma.T64 = r->lay_T64.as<double>();
     ma.rec = f.mid_rec.as<unsigned long long>();
@@ -2075,6 +2106,7 @@ int mlf_region_set_option(mlf_region *r, const char *name, long long value, int 
   if (!r) return fail_arg(MLF_E_BADARG, "null pointer");
   if (!name) {   // every option of the handle back to the process defaults (a recycled handle starts clean)
     if (!inherit) return fail_arg(MLF_E_BADARG, "null pointer");
+    if (r->filter.ov.set[OPT_ORDER] && r->filter.refs_ready) r->filter.refs_dirty = true;
     r->filter.ov = OptOverrides{};
     return 0;
   }
@@ -2082,6 +2114,7 @@ int mlf_region_set_option(mlf_region *r, const char *name, long long value, int 
   if (id < 0) return fail_arg(MLF_E_BADARG, "unknown option");
   r->filter.ov.set[id] = !inherit;
   r->filter.ov.v[id] = inherit ? 0 : opt_clamp(id, value);
+  if (id == OPT_ORDER && r->filter.refs_ready) r->filter.refs_dirty = true;   // the next batch builds (or drops) the ordered operand
   return 0;
 }
 

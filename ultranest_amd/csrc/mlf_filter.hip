@@ -155,6 +155,59 @@ __global__ void k_quant_refs(const double *refR, int n, int npad32, int d, int d
   for (int k = d + 6; k < K; ++k) refF[frag_index(i, k, ks)] = (half_t)0.0f;
 }
 
+// ---------------------------------------------------------------- order of the mask-mode operand
+// MLFriends.inside needs "is there ANY live point within the radius" (mlfriends.pyx:1186-1211); only find_nearby reports the
+// FIRST index (:176-183).  The mask-mode kernels therefore sweep a PERMUTED copy of the live points -- nearest to the
+// centre first: a proposal's nearest live points are, far more often than not, the central ones (|x - a|^2 = |x|^2 + |a|^2 -
+// 2 x.a), so the first tile range of a two-range sweep decides more proposals (C5 set E, scripts/order_study.py: 75 % after
+// half of the tiles against 62 % in storage order; 65 % against 46 % after 30 %).  The first-index operand keeps storage order.
+// key = bit pattern of |a_i - c|^2 (non-negative doubles order like their bit patterns; NaN sorts last: always a permutation)
+__global__ void k_ref_keys(const double *__restrict__ refR, int n, int d, int dp, const double *__restrict__ stats,
+                           unsigned long long *__restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double acc = 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double v = refR[(size_t)i * dp + k] - stats[8 + k];
+    acc += v * v;
+  }
+  keys[i] = (unsigned long long)__double_as_longlong(acc);
+}
+
+// rank by counting: slot of row i = #{j : key_j < key_i or (key_j == key_i and j < i)}; perm[slot] = i.  Workgroup = 64 rows
+// x 4 slices of the keys (wave w walks slice w: every lane reads the same key -- an LDS broadcast)
+__global__ __launch_bounds__(256) void k_ref_rank(const unsigned long long *__restrict__ keys, int n, int *__restrict__ perm) {
+  __shared__ unsigned long long kb[1024];
+  __shared__ unsigned part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const unsigned long long mine = i < n ? keys[i] : ~0ull;
+  unsigned count = 0;
+  for (int base = 0; base < n; base += 1024) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += 256) kb[e] = base + e < n ? keys[base + e] : ~0ull;
+    __syncthreads();
+    const int stop = n - base < 1024 ? n - base : 1024;
+    for (int e = wave; e < stop; e += 4) {
+      const unsigned long long kj = kb[e];
+      const int j = base + e;
+      count += (kj < mine || (kj == mine && j < i)) ? 1u : 0u;
+    }
+  }
+  part[wave][lane] = count;
+  __syncthreads();
+  if (wave == 0 && i < n) perm[part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]] = i;
+}
+
+// refRm[slot] = refR[perm[slot]] (rows of dp doubles); slots n .. nrows - 1 are zero rows
+__global__ void k_ref_gather(const double *__restrict__ refR, const int *__restrict__ perm, int n, int nrows, int dp,
+                             double *__restrict__ refRm) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)nrows * dp) return;
+  const int slot = (int)(e / dp), k = (int)(e - (long long)slot * dp);
+  refRm[e] = slot < n ? refR[(size_t)perm[slot] * dp + k] : 0.0;
+}
+
 // ---------------------------------------------------------------- queries -> f16 fragments ---
 // one thread per query.  route: 0 = not scanned (gated out), 1 = filtered, 2 = exact scan only.
 __global__ void k_quant_queries(const double *q, long long ldq, long long nq, long long nqpad,
@@ -544,6 +597,16 @@ void launch_quant_refs(const double *refR, int n, int npad32, int d, int dp, int
                        const double *stats, void *refF, hipStream_t s) {
   hipLaunchKernelGGL(k_quant_refs, dim3((unsigned)((npad32 + 127) / 128)), dim3(128), 0, s, refR, n, npad32,
                      d, dp, ks, stats, reinterpret_cast<half_t *>(refF));
+}
+
+void launch_ref_order(const double *refR, int n, int nrows, int d, int dp, const double *stats, unsigned long long *keys,
+                      int *perm, double *refRm, bool rerank, hipStream_t s) {
+  if (rerank) {
+    hipLaunchKernelGGL(k_ref_keys, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, refR, n, d, dp, stats, keys);
+    hipLaunchKernelGGL(k_ref_rank, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, keys, n, perm);
+  }
+  const long long total = (long long)nrows * dp;
+  hipLaunchKernelGGL(k_ref_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, refR, perm, n, nrows, dp, refRm);
 }
 
 void launch_quant_queries(const double *q, long long ldq, long long nq, long long nqpad, int d_src, int d,

@@ -26,14 +26,16 @@ from . import regions
 
 
 # A shard of bootstrap rounds can raise numerical errors (the driver runs the rebuild under np.errstate(all='raise'),
-# integrator.py:2066: LinAlgError, FloatingPointError, AssertionError, Warning) and anything the device layer reports
+# integrator.py:2066: LinAlgError, FloatingPointError, Warning), assertions of its own and anything the device layer reports
 # (HipLibraryError is a RuntimeError; an out-of-memory allocation a MemoryError).  EVERY exception of a shard is caught
 # per rank, exchanged as a flag and re-raised on every rank after the all-reduce: a rank that skipped the collective
 # would leave the other ranks blocked in it.
 SHARD_ERRORS = (Exception,)
-# what a shard's failure means for the caller: numerical failures (the set the driver's own try/except keeps the old region
-# on, integrator.py:2066-2122) travel as class 1, everything else as class 2 and comes back as a RuntimeError on every rank
-NUMERICAL_ERRORS = (np.linalg.LinAlgError, FloatingPointError, AssertionError, Warning, ZeroDivisionError)
+# what a shard's failure means for the caller: numerical failures -- exactly the three types the driver's own handlers keep
+# the old region on (integrator.py:2123-2131: Warning, FloatingPointError, LinAlgError) -- travel as class 1; everything else,
+# AssertionError and ZeroDivisionError included (a single process lets those propagate, so must a group), as class 2 and
+# comes back as a RuntimeError on every rank
+NUMERICAL_ERRORS = (np.linalg.LinAlgError, FloatingPointError, Warning)
 
 
 def _error_class(error):
@@ -144,7 +146,8 @@ def sharded_enlargement(region, nbootstraps, minvol=0., rng=np.random, group=Non
     try:
         share = getattr(region, "enlargement_share", None)
         if share is not None and size > 1:
-            # MLFriends: the radius by ROW BLOCKS (all rounds, 1/size of the pair distances), the factor by rounds
+            # MLFriends: the radius by ROW BLOCKS (all rounds, 1/size of the pair distances), the factor by rounds;
+            # RobustEllipsoidRegion / SimpleRegion override the share with their OWN per-round rule (round shards)
             out = share(masks, rank, size, minvol=minvol)
         else:
             out = region.enlargement_from_masks(masks[lo:hi], minvol=minvol) if hi > lo else (0.0, 0.0)

@@ -21,11 +21,13 @@ class RegionUpdater(object):
     _gc_frozen = False
 
     def __init__(self, x_dim, region_class=MLFriends, transform_layer_class=LocalAffineLayer,
-                 wrapped_axes=(), group=None, build_tregion=True, device_resident=False, freeze_gc=True):
+                 wrapped_axes=(), group=None, build_tregion=True, device_resident=False, freeze_gc=False):
         self.x_dim = x_dim
         # The objects the imports leave behind (~170000) make CPython's first generation-2 collector pass cost 37-42 ms,
         # somewhere in the first ~40 rebuilds (scripts/rebuild_rounds.py).  Moving what exists NOW into the permanent
-        # generation keeps that pass out of the rebuild loop; `freeze_gc=False` leaves the collector alone.
+        # generation keeps that pass out of the rebuild loop.  That is a PROCESS-WIDE side effect (everything alive in the
+        # host application stops being collectable), so it is opt-in (`freeze_gc=True`: bench.py and the timing scripts pass
+        # it); a library object leaves the collector alone by default.
         if freeze_gc and not RegionUpdater._gc_frozen:
             gc.collect()
             gc.freeze()

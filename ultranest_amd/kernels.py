@@ -103,8 +103,10 @@ class DevArray(object):
     def from_host(cls, array):
         a = np.ascontiguousarray(array)
         self = cls(a.nbytes)
-        self._src = a       # the copy is stream ordered: the source stays alive with the array
-        check(_lib.lib().mlf_dev_copy(self.ptr, ptr(a), a.nbytes, 0))
+        # synchronous: `a` may be the CALLER's own array (ascontiguousarray copies nothing then) and pageable memory is
+        # read when the stream reaches the copy -- the call returns only after that, so the caller may write to its array
+        # again at once (sync = 0 saved nothing, no upload here is followed by another host-side copy)
+        check(_lib.lib().mlf_dev_copy(self.ptr, ptr(a), a.nbytes, 1))
         return self
 
     def to_host(self, dtype, shape):

@@ -123,6 +123,13 @@ def _shard_bounds(nitems, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _host_masks(masks):
+    """the (B, N) selection matrix as a numpy bool array (a device-side broadcast hands over a uint8 torch tensor)"""
+    if hasattr(masks, "data_ptr"):
+        return masks.cpu().numpy().astype(bool)
+    return np.asarray(masks, dtype=bool)
+
+
 def _select_rounds(masks, use):
     """rows `use` of the (B, N) selection matrix (numpy on the host or a torch tensor on the device)"""
     if use.all():
@@ -874,6 +881,16 @@ class RobustEllipsoidRegion(MLFriends):
             raise np.linalg.LinAlgError("Distances are not positive")
         return 1e300, float(f.max())
 
+    def enlargement_share(self, masks, rank, size, minvol=0.):
+        """Rank `rank`'s share in a group of `size`: a contiguous shard of the ROUNDS through this class's own
+        ``enlargement_from_masks`` (the inherited MLFriends share would apply the friends radius and the
+        full-covariance factor to the ellipsoid-only classes).  The element-wise maximum over the ranks is the one-process
+        result bit for bit: the radius is the constant 1e300 on every rank that holds a round, f a maximum over rounds."""
+        lo, hi = _shard_bounds(len(masks), rank, size)
+        if hi <= lo:
+            return 0.0, 0.0
+        return self.enlargement_from_masks(_host_masks(masks)[lo:hi], minvol=minvol)
+
     def estimate_volume(self):
         """log-volume of the ellipsoid (reference :1442-1457)."""
         ndim = len(self.ellipsoid_cov)
@@ -908,7 +925,7 @@ class SimpleRegion(RobustEllipsoidRegion):
 
     def enlargement_from_masks(self, masks, minvol=0.):
         maxf = 0.0
-        for sel in masks:
+        for sel in _host_masks(masks):
             ctr = np.mean(self.u[sel, :], axis=0)
             var = np.var(self.u[sel, :], axis=0)
             f = np.sum((self.u[~sel, :] - ctr.reshape((1, -1)))**2 / var, axis=0).max()
