@@ -489,9 +489,11 @@ def main():
             "measured_valu_probe_tflops": kernels.bench_fp64_valu(),
             "proposals_per_s_filter_off": NPROPOSALS * world * nsteps_x / exact_elapsed,
             "note": "bit-exactness forbids FMA/MFMA in the distance itself: peak = non-fused FP64 vector issue rate"}
-    stage_ms = prep_ms + scan_ms + rest_ms
-    hbm = {"algorithmic_bytes_per_step": alg_bytes, "achieved_GBps": alg_bytes / (stage_ms * 1e-3) / 1e9,
-           "peak_GBps": HBM_PEAK_GBPS, "frac": alg_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    # whole-step algorithmic bytes over the HEADLINE step time (round 4 divided by the stage-event pass, which is longer)
+    step_ms = elapsed / args.steps * 1e3
+    hbm = {"algorithmic_bytes_per_step": alg_bytes, "achieved_GBps": alg_bytes / (step_ms * 1e-3) / 1e9,
+           "peak_GBps": HBM_PEAK_GBPS, "frac": alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "over": "ms_per_step of the timed loop (this rank's batch)"}
     if filter_on:
         # f16 GEMM of the pre-filter on v_mfma_f32_32x32x16_f16 (32768 flop each).  EXECUTED work per step: the first
         # live-point range sweeps every 32-query group, the second only the groups left after the device-side
@@ -503,7 +505,9 @@ def main():
         per_step = max(1, round(nlaunch / max(args.steps, 1)))
         ngroups1 = (NPROPOSALS + 31) // 32
         by_phase = [float(np.mean(launch_ms_list[i::per_step])) for i in range(per_step)] if len(launch_ms_list) else []
-        cut = ntiles32 * 50 // 100          # filter_first_range_pct = 50 (default)
+        # the first range's share as the library routes it (filter_run: filter_first_range_pct of the tiles, at least 4 on each side)
+        first_pct = lib_mod.get_option("filter_first_range_pct")
+        cut = max(4, min(ntiles32 - 4, ntiles32 * first_pct // 100))
         if per_step == 3:
             # min-only sweep (mlf_sweepmin.hip): first range over every group, second over the groups left, then the
             # uncertain queries (sets of 4 groups) once more over all tiles
@@ -548,6 +552,8 @@ def main():
                     "equivalent_allpairs_flops_per_step": allpairs,
                     "equivalent_allpairs_TFLOPs": allpairs / (float(sum(by_phase)) * 1e-3) / 1e12 if by_phase else None,
                     "executed_k_columns": kdim, "second_range_groups": stats["second_range_groups"],
+                    "first_range_pct": first_pct, "first_range_tiles": cut, "tiles": ntiles32,
+                    "mask_operand_order": "nearest to the centre first" if lib_mod.get_option("filter_order") else "storage order",
                     "uncertain_queries": stats.get("uncertain_queries"), "uncertain_pairs": stats.get("uncertain_pairs"),
                     "note": "achieved = executed matrix-instruction flops of one launch (average of the launches of a step) "
                             "over the average launch duration from hipEvents inside the timed region; pairs skipped by the "
@@ -591,14 +597,15 @@ def main():
                                         "the device, d x d LAPACK on the host; tolerance class 1e-10 on T, radius, enlargement "
                                         "instead of bit parity (tests/test_device_rebuild.py); N = 1 only",
         "accept_fraction": accept, "ellipsoid_pass_fraction": ell_pass,
-        "kernel_ms": {"per-proposal stage (k_prep4: bounded ellipsoid test + whitening on the matrix cores with split binary16 operands -> f16 "
-                      "operand; the ellipsoid band is decided by trailing workgroups of the k_uncertain launch)": prep_ms,
-                      ("scan kernels (k_sweep_min over both live-point ranges + k_uncertain: the proposals whose minimum ended in "
-                       "the band, incl. their exact whitening)" if filter_on else "scan kernel (k_scan)"): scan_ms,
-                      "rest of scan stage (k_scan tail: what the filter could not take, routing, finalise)": rest_ms,
-                      "scan kernel as a single sweep over all live points (phases off)": ms_scan_single,
-                      "per-proposal stage with the FP64 kernel instead (k_prep3, prep_bounded=0)":
-                          (ms_prep_p3 / max(ncalls_p3, 1)) if not args.headline_only else None,
+        "kernel_ms": {"prep": prep_ms, "scan": scan_ms, "tail": rest_ms, "scan_single_sweep": ms_scan_single,
+                      "prep_fp64": (ms_prep_p3 / max(ncalls_p3, 1)) if not args.headline_only else None,
+                      "keys": {"prep": "per-proposal stage (k_prep4: bounded ellipsoid test + whitening on the matrix cores with split "
+                                       "binary16 operands -> f16 operand; the ellipsoid band is decided by trailing workgroups of the k_uncertain launch)",
+                               "scan": ("k_sweep_min over both live-point ranges + k_uncertain (the proposals whose minimum ended in the band, "
+                                        "incl. their exact whitening)" if filter_on else "k_scan"),
+                               "tail": "k_scan tail: what the filter could not take, routing, finalise",
+                               "scan_single_sweep": "the scan stage as a single sweep over all live points (filter_phases = 0)",
+                               "prep_fp64": "per-proposal stage with the FP64 kernel instead (k_prep3, prep_bounded = 0)"},
                       "measured_in": "a separate pass of %d steps with stage events (the headline loop carries events only "
                                      "around the matrix-kernel launches)" % nsteps_b,
                       # the stages add up to the wall time of THAT pass, not of the headline loop: every stage boundary is a

@@ -63,7 +63,8 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *   "filter_phases"            0: one sweep; 1 (default): two live-point ranges, decided proposals dropped in between
  *                              (the compaction rides in the first range's epilogue); n >= 2: n ranges
  *   "filter_phase_min_queries" smaller batches sweep all tiles in one launch
- *   "filter_first_range_pct"   10 ... 90, default 50: share of the live-point tiles the first of two ranges takes
+ *   "filter_first_range_pct"   10 ... 90, default 30 (50 until the operand was ordered, "filter_order"): share of the live-point tiles the
+ *                              first of two ranges takes
  *   "filter_order"             1 (default): the mask-mode kernels (MLFriends.inside: any hit decides, mlfriends.pyx:1186-1211) sweep a
  *                              copy of the live points ordered nearest-to-the-centre first, so that the first of two tile
  *                              ranges decides more proposals; 0: storage order.  find_nearby's first-index operand always
@@ -87,8 +88,10 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *   "small_path"               1/0: mlf_region_inside with up to 256 proposals as ONE launch over pinned staging -- the calls
  *                              of the scalar step samplers -- or through the batched pipeline
  *   "time_filter_launches"     1/0: event pairs around every matrix-kernel launch (mlf_region_timing_filter_launch_ms)
- * mlf_option_name enumerates the names (index 0, 1, ... until it fails). */
+ * mlf_option_name enumerates the names (index 0, 1, ... until it fails); mlf_get_option returns the process default in force
+ * (so that a caller that reports a routing -- bench.py -- reads it instead of assuming it). */
 int mlf_set_option(const char *name, long long value);
+int mlf_get_option(const char *name, long long *value);
 int mlf_option_name(int index, char *buf, size_t buflen);
 
 /* ---- K1: find_nearby -- ultranest/mlfriends.pyx:143-183 -----------------------------------
@@ -409,9 +412,13 @@ int mlf_region_filter_info(mlf_region *r, size_t np, int *active, int *kdim, int
  * MAX all-reduce of a few doubles over RCCL for callers without torch.distributed.  librccl is dlopen()ed at the
  * first call.  One process per GPU: rank 0 obtains 128 bytes with mlf_comm_unique_id and distributes them (MPI, file,
  * socket ...), every rank calls mlf_comm_init_rank after mlf_set_device; mlf_allreduce_max(v, count) then leaves the
- * element-wise maximum over the ranks in v.  One process driving ndev devices: mlf_comm_init(ndev), and
- * mlf_allreduce_max takes ndev rows of `count` doubles.  NaN must travel as an explicit flag element, not through MAX
- * (the Python layer does that: ultranest_amd.distributed). */
+ * element-wise maximum over the ranks in v.  mlf_comm_init(ndev) is the EXCHANGE STEP ONLY for a process that holds ndev
+ * rows of `count` doubles (one per device 0 ... ndev - 1) obtained elsewhere: mlf_allreduce_max then leaves the column maxima in
+ * every row.  It does NOT make the compute entry points multi-device: the library has ONE compute context per process (the
+ * device of mlf_set_device, one stream, shared scratch; the C ABI is not re-entrant) -- compute on several GPUs
+ * means one process per GPU and mlf_comm_init_rank.  (Tested with ndev = the devices present, 1 on this pool:
+ * tests/test_distributed.py::test_abi_allreduce_max_one_rank_and_one_process.)  NaN must travel as an explicit flag element,
+ * not through MAX (the Python layer does that: ultranest_amd.distributed). */
 int mlf_comm_unique_id(char *id_out, size_t len /* >= 128 */);
 int mlf_comm_init_rank(const char *id, size_t len, int nranks, int rank);
 int mlf_comm_init(int ndev);

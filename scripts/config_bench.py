@@ -73,7 +73,11 @@ for name, n, d, p in (("C2", 2000, 20, 100000), ("C5", 4000, 50, 1000000), ("C1-
                            ("N", E, region.maxradiussq * 0.2)):
         handle.set_thresholds(region.enlarge, r2)
         rate, acc = timed_inside(handle, pts)
-        res[label] = {"proposals_per_s": rate, "accept": acc}
+        on, _, _ = handle.filter_info(p)
+        res[label] = {"proposals_per_s": rate, "accept": acc,
+                      "scan_kernel": "MFMA pre-filter + exact re-check" if on else
+                                     "k_scan: the exact FP64 scan alone (the radius is outside the pre-filter's range -- set F's r2 = 1e-300 "
+                                     "is SURVEY 8d's no-early-exit worst case, not a radius a run produces)"}
     upd = RegionUpdater(d, region_class=M.MLFriends, transform_layer_class=M.LocalAffineLayer, freeze_gc=True)
     np.random.seed(11)
     upd.update(u, nbootstraps=30, minvol=0.)

@@ -8,11 +8,13 @@ import time
 import numpy as np
 
 sys.path.insert(0, ".")
+t_import = time.perf_counter()
 from ultranest_amd import likelihoods  # noqa: E402
 from ultranest_amd.harness import StaticNestedSampler  # noqa: E402
 from ultranest_amd.regions import DeviceRNG  # noqa: E402
 
 out = []
+IMPORT_S = time.perf_counter() - t_import     # package import incl. loading libmlfriends_hip.so (the first device call comes later)
 
 
 def laplace_logz(d):
@@ -32,7 +34,9 @@ for d, nlive, ndraw, max_iters in CASES:
     dt = time.perf_counter() - t0
     res.update(d=d, nlive=nlive, ndraw=ndraw, laplace_logz=float(laplace_logz(d)), seconds=dt, iterations_per_s=res["niter"] / dt,
                likelihood_evaluations_per_s=res["ncall"] / dt, proposals_per_s=res["ncall_region"] / dt,
-               finished=res["niter"] < max_iters)
+               finished=res["niter"] < max_iters,
+               # where the wall time goes (StaticNestedSampler.phases)
+               phases=dict(s.phases, import_s=IMPORT_S))
     out.append(res)
     print(json.dumps(res), flush=True)
 # C3 proper: 10-d eggbox (5^10 modes).  Region rejection sampling cannot follow the volume there; the
@@ -48,7 +52,7 @@ for d, nlive, popsize, nsteps in [(2, 1000, 1024, 10), (10, 1000, 1024, 40)]:
     dt = time.perf_counter() - t0
     res.update(d=d, nlive=nlive, laplace_logz=float(laplace_logz(d)), sampler="PopulationSliceSampler(popsize=%d, nsteps=%d, mixture directions)" % (popsize, nsteps),
                seconds=dt, iterations_per_s=res["niter"] / dt, likelihood_evaluations_per_s=res["ncall"] / dt,
-               far_enough_fraction=float(step.far_enough_fraction), finished=res["niter"] < 400000)
+               far_enough_fraction=float(step.far_enough_fraction), finished=res["niter"] < 400000, phases=dict(s.phases))
     out.append(res)
     print(json.dumps(res), flush=True)
 json.dump(out, open("gpurun_out/e2e_run.json", "w"), indent=1)

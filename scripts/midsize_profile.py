@@ -35,4 +35,4 @@ for p in sizes:
     dt = (time.perf_counter() - t0) / 200
     st = handle.debug_stats()
     print(json.dumps(dict(batch=p, us_per_call=round(dt * 1e6, 2), proposals_per_s=round(p / dt), accept=float(mask.float().mean().item()),
-                          stage_cycles=st.get("uncertain_stage_cycles"), band_pairs_of_wave_0=st.get("stamp7"))), flush=True)
+                          stage_cycles=st.get("uncertain_stage_cycles"), stamp7=st.get("stamp7"))), flush=True)

@@ -112,7 +112,7 @@ def test_every_documented_option_is_accepted_without_a_device():
     while _lib.lib().mlf_option_name(len(listed), buf, 64) == 0:
         listed.append(buf.value.decode())
     assert sorted(names) == sorted(listed) and len(listed) == 16
-    defaults = {"filter_min_queries": 257, "filter_phase_min_queries": 32768, "filter_first_range_pct": 50,
+    defaults = {"filter_min_queries": 257, "filter_phase_min_queries": 32768, "filter_first_range_pct": 30,
                 "filter_split_waves": 2048, "time_filter_launches": 0, "mid_max_queries": 2048}
     for name in names:
         _lib.set_option(name, defaults.get(name, 1))

@@ -24,7 +24,7 @@ def K(request):
     _lib.set_option("filter_min_queries", 64)      # let small test batches take the filter path
     _lib.set_option("filter_phases", 0 if request.param == "single-sweep" else 1)
     _lib.set_option("filter_phase_min_queries", 64)
-    _lib.set_option("mid_max_queries", 131072 if request.param == "one-launch" else 0)
+    _lib.set_option("mid_max_queries", 131072 if request.param.startswith("one-launch") else 0)
     _MODE["param"] = request.param
     yield kernels
     _lib.set_option("filter_min_queries", 257)
@@ -38,7 +38,7 @@ _MODE = {"param": "phased"}
 
 
 def request_param_one_launch():
-    return _MODE["param"] == "one-launch"
+    return _MODE["param"].startswith("one-launch")
 
 
 def _find(K, apts, bpts, r2, filt):

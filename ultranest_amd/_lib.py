@@ -28,6 +28,7 @@ SIGNATURES = {
     "mlf_device_name": [_vp, _sz],
     "mlf_synchronize": [],
     "mlf_set_option": [ctypes.c_char_p, ctypes.c_longlong],
+    "mlf_get_option": [ctypes.c_char_p, _vp],
     "mlf_find_nearby": [_vp, _sz, _vp, _sz, _sz, _dbl, _vp],
     "mlf_count_nearby": [_vp, _sz, _vp, _sz, _sz, _dbl, _vp],
     "mlf_subtract_nearby": [_vp, _sz, _sz, _dbl, _vp],
@@ -209,6 +210,13 @@ def set_device(i):
 def set_option(name, value):
     """Tuning switch of the library (e.g. set_option("filter", 0) forces the exact scan only)."""
     check(lib().mlf_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    """The process default of a tuning switch that is in force (mlf_get_option)."""
+    v = ctypes.c_longlong(0)
+    check(lib().mlf_get_option(name.encode(), ctypes.byref(v)))
+    return int(v.value)
 
 
 def draw_selection(rng, npoints, nbootstraps):

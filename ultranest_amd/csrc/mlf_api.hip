@@ -76,7 +76,7 @@ const char *const kOptNames[OPT_COUNT] = {"filter", "filter_first_range_pct", "f
                                           "small_path", "fused_prep", "filter_phase_min_queries", "filter_phases",
                                           "time_filter_launches", "prep_bounded", "filter_min_queries", "sweep_min", "mid_max_queries", "fused_first_range",
                                           "boot_symmetric", "filter_order"};
-long long g_opt[OPT_COUNT] = {1, 50, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 0, 1, 1};
+long long g_opt[OPT_COUNT] = {1, 30, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 0, 1, 1};
 
 struct OptOverrides {
   long long v[OPT_COUNT] = {};
@@ -118,6 +118,7 @@ struct FilterCtx {
   DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png, pmin;
   DevBuf mid_rec, mid_meta, mid_arrive;   // one-launch path (mlf_mid.hip): records of the tile ranges, arrival counters
   bool mid_last = false;                  // the last batch took that path (debug_stats)
+  bool mid_dirty = false;                 // a launch of that path failed: its self-resetting counters are zeroed before the next batch
   // bounded per-proposal stage (mlf_prep4.hip): ellipsoid band list, per-call counters
   // misc: [0] band proposals, [1] k_ell_exact workgroups done -- both return to zero by themselves (no memset per batch),
   // zeroed once when the buffer is allocated; [2], [3] "a proposal is routed to the exact scan", used alternately by
@@ -1089,7 +1090,10 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
     {
       const size_t before = f.mid_arrive.cap;
       CK(f.mid_arrive.reserve((size_t)nsets * sizeof(unsigned)));
-      if (f.mid_arrive.cap != before) CK(hipMemsetAsync(f.mid_arrive.p, 0, f.mid_arrive.cap, s));   // they return to zero by themselves afterwards
+      // they return to zero by themselves afterwards -- unless a launch failed part-way: then the next batch starts clean
+      if (f.mid_arrive.cap != before || f.mid_dirty) CK(hipMemsetAsync(f.mid_arrive.p, 0, f.mid_arrive.cap, s));
+      if (f.mid_dirty && f.misc.p) CK(hipMemsetAsync(f.misc.p, 0, 8 * sizeof(unsigned), s));
+      f.mid_dirty = false;
     }
     MidArgs ma{};
     ma.pts = d_pts;
@@ -1131,7 +1135,10 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
       ma.stamps = f.segcnt.as<unsigned>();
     }
     f.mid_last = ma.stamps != nullptr;
-    CK(launch_inside_mid(ma, ny, s));
+    if (hipError_t le = launch_inside_mid(ma, ny, s); le != hipSuccess) {
+      f.mid_dirty = true;
+      CK(le);
+    }
     if (ev) {
       CK(hipEventRecord(ev[1], s));
       CK(hipEventRecord(ev[2], s));
@@ -1157,7 +1164,10 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
     a.counters = f.counters.as<unsigned>();
     a.any_flag = f.misc.as<unsigned>() + 2 + f.batch_parity;
     a.fin_reset = f.misc.as<unsigned>() + 2 + (f.batch_parity ^ 1u);
-    CK(launch_scan(r->dp, a, s));
+    if (hipError_t le = launch_scan(r->dp, a, s); le != hipSuccess) {
+      f.mid_dirty = true;
+      CK(le);
+    }
     f.last_nsegs = 0;
     if (ev) CK(hipEventRecord(ev[3], s));
     return 0;
@@ -1405,6 +1415,14 @@ int mlf_set_option(const char *name, long long value) {
   const int id = opt_id(name);
   if (id < 0) return fail_arg(MLF_E_BADARG, "unknown option");
   g_opt[id] = opt_clamp(id, value);
+  return 0;
+}
+
+int mlf_get_option(const char *name, long long *value) {
+  if (!name || !value) return fail_arg(MLF_E_BADARG, "null pointer");
+  const int id = opt_id(name);
+  if (id < 0) return fail_arg(MLF_E_BADARG, "unknown option");
+  *value = g_opt[id];
   return 0;
 }
 
@@ -2719,6 +2737,8 @@ int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap) {
     CK(hipMemcpy(g, f.png.p, sizeof g, hipMemcpyDeviceToHost));
     out[5] = g[0];
     if (cap > 6) out[6] = g[1];   // queries of the last min-only batch whose minimum ended in the band (uncertain set)
+  }
+  {
     if (cap >= 16 && f.mid_last && f.segcnt.p) {   // k_inside_mid, workgroup (0, 0): stage boundaries
       unsigned st[8];
       CK(hipMemcpy(st, f.segcnt.p, sizeof st, hipMemcpyDeviceToHost));

@@ -30,6 +30,8 @@
 
 #include <math.h>
 
+#include <atomic>
+
 namespace mlf {
 
 typedef float float16v __attribute__((ext_vector_type(16)));
@@ -765,32 +767,37 @@ size_t mid_lds_bytes(int dp) {
   }
 }
 
+template <int D>
+static hipError_t launch_inside_mid_t(const MidArgs &a, dim3 grid, hipStream_t s) {
+  constexpr size_t lds = M4<D>::LDS;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static std::atomic<int> attr_device{-1};   // the attribute belongs to (function, device): set once per device
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (attr_device.load(std::memory_order_acquire) != dev) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_inside_mid<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_device.store(dev, std::memory_order_release);
+  }
+  if (a.ks != M4<D>::KS) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((k_inside_mid<D>), grid, dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_inside_mid(const MidArgs &a, int ny, hipStream_t s) {
   if (a.np <= 0) return hipSuccess;
   const long long ngroups = (a.np + 31) / 32;
   const dim3 grid((unsigned)((ngroups + 7) / 8), (unsigned)ny);
   switch (a.dp) {
-#define X(D)                                                                                                         \
-  case D: {                                                                                                          \
-    constexpr size_t lds = M4<D>::LDS;                                                                               \
-    static_assert(lds <= 160 * 1024, "LDS budget");                                                                  \
-    static bool attr_set = false;                                                                                    \
-    if (!attr_set) {                                                                                                 \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_inside_mid<D>),                           \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
-      if (e != hipSuccess) return e;                                                                                 \
-      attr_set = true;                                                                                               \
-    }                                                                                                                \
-    if (a.ks != M4<D>::KS) return hipErrorInvalidValue;                                                              \
-    hipLaunchKernelGGL((k_inside_mid<D>), grid, dim3(512), lds, s, a);                                               \
-    break;                                                                                                           \
-  }
+#define X(D) \
+  case D:    \
+    return launch_inside_mid_t<D>(a, grid, s);
     MLF_FOR_EACH_DP_MID(X)
 #undef X
     default:
       return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
 
 }  // namespace mlf

@@ -224,8 +224,16 @@ class StaticNestedSampler(object):
         self.seed = seed
         self.ncall = 0
         self.ncall_region = 0
+        # where a run's wall time goes (seconds and call counts): filled by run(); "host_loop_s" is what is left for the
+        # per-iteration bookkeeping of the loop itself (scripts/e2e_run.py reports it)
+        self.phases = {}
 
     def run(self, dlogz=0.5, max_iters=200000):
+        import time
+        tick = time.perf_counter
+        ph = self.phases = dict(initial_points_s=0.0, first_rebuild_s=0.0, rebuild_s=0.0, rebuilds=0, refill_s=0.0, refills=0,
+                                first_refill_s=0.0, stepsampler_s=0.0, stepsampler_calls=0, summary_s=0.0)
+        t_run = tick()
         np.random.seed(self.seed)
         N = self.nlive
         u = np.random.uniform(size=(N, self.x_dim))
@@ -260,6 +268,7 @@ class StaticNestedSampler(object):
             self.pointpile = PointPile(self.x_dim, v_live.shape[1])
             live_nodes = [self.pointpile.make_node(li, ui, vi) for li, ui, vi in zip(logl, u, v_live)]
             self.root = TreeNode(id=-1, value=-np.inf, children=list(live_nodes))
+        ph["initial_points_s"] = tick() - t_run
         logz = -np.inf
         h_terms = []
         logvol = 0.0
@@ -270,10 +279,13 @@ class StaticNestedSampler(object):
         it = 0
         while it < max_iters:
             if logvol <= next_update_logvol:
+                t0 = tick()
                 self.updater.update(u, nbootstraps=self.nbootstraps, minvol=np.exp(logvol))
                 next_update_logvol = logvol + np.log(0.8)
                 if self.stepsampler is not None:
                     self.stepsampler.region_changed(logl, self.updater.region)
+                ph["first_rebuild_s" if ph["rebuilds"] == 0 and ph["first_rebuild_s"] == 0.0 else "rebuild_s"] += tick() - t0
+                ph["rebuilds"] += 1
             region = self.updater.region
             region.device_rng = self.device_rng
             worst = int(np.argmin(logl))
@@ -289,8 +301,11 @@ class StaticNestedSampler(object):
                 break
             # a replacement above Lmin from the region
             while self.stepsampler is not None:
+                t0 = tick()
                 newu, newv, newl, nc = self.stepsampler.__next__(region, Lmin, region.u, logl, self.transform,
                                                                   self.loglike)
+                ph["stepsampler_s"] += tick() - t0
+                ph["stepsampler_calls"] += 1
                 self.ncall += nc
                 if newu is not None:
                     break
@@ -311,8 +326,11 @@ class StaticNestedSampler(object):
                         pending_l = np.array([row[1]])
                         ip = 0
                         continue
+                t0 = tick()
                 nu, nv, nl, nc = refill_samples(region, None, self.transform, self.loglike, Lmin, self.ndraw,
                                                 pointstore=self.pointstore, ncall=self.ncall)
+                ph["first_refill_s" if ph["refills"] == 0 else "refill_s"] += tick() - t0
+                ph["refills"] += 1
                 self.ncall += nc
                 self.ncall_region += self.ndraw
                 pending_u, pending_v, pending_l = nu, nv, nl
@@ -341,7 +359,12 @@ class StaticNestedSampler(object):
         out = dict(logz=float(logz), logzerr=float(np.sqrt(max(info, 0.0) / N)), niter=it, ncall=self.ncall,
                    ncall_region=self.ncall_region, nclusters=int(self.updater.transformLayer.nclusters))
         if self.keep_tree:
+            t0 = tick()
             out.update(self._summarize())
+            ph["summary_s"] = tick() - t0
+        ph["total_s"] = tick() - t_run
+        ph["host_loop_s"] = ph["total_s"] - sum(v for k, v in ph.items() if k.endswith("_s") and k not in ("total_s", "host_loop_s"))
+        ph["host_loop_us_per_iteration"] = 1e6 * ph["host_loop_s"] / max(it, 1)
         return out
 
     def _summarize(self):
