@@ -32,7 +32,7 @@ extern "C" {
 #define MLF_E_NODEVICE 3    /* no usable gfx950 device                                      */
 #define MLF_E_STATE 4       /* region handle used before mlf_region_set                     */
 
-#define MLF_MAX_DIM 128
+#define MLF_MAX_DIM 1024
 
 /* ---- library / device ---------------------------------------------------------------- */
 int mlf_abi_version(void);

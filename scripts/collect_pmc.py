@@ -1,6 +1,12 @@
-"""Round-4 PMC summary: per kernel of the C5 membership pipeline (scripts/stage_profile.py under rocprofv3 --pmc, separate
-passes: matrix / instruction counters, wait split, FETCH_SIZE, WRITE_SIZE) -> profiles/r04_pmc_summary.json.
-    python scripts/collect_r04_pmc.py gpurun_out/r04h profiles/r04"""
+"""PMC summary: per kernel of the C5 membership pipeline (scripts/stage_profile.py under rocprofv3 --pmc, separate passes:
+matrix / instruction counters, wait split, FETCH_SIZE, WRITE_SIZE) -> profiles/rNN_pmc_summary.json + profiles/pmc_scan_traffic.json.
+    python scripts/collect_pmc.py gpurun_out/r05z profiles/r05
+Round 5: `clock_GHz` and `matrix_pipe_busy` are derived from GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 =
+"launch duration in shader cycles" -- true only for a launch that keeps every XCD busy from start to end.  Round 4 printed them
+for every kernel and got 3.0 / 3.5 / 5.4 GHz for k_prep4 / k_uncertain / k_scan (short launches and launches that leave XCDs idle:
+the counter keeps running on the busy ones while the wall time is that of the longest).  They are reported for the sweep launches
+only (which fill the chip for their whole duration: 1.77-1.9 GHz, consistent with the in-kernel clock of the probes); the other
+kernels carry null and the instruction / wait counters, which do not depend on that assumption."""
 import csv
 import json
 import re
@@ -35,9 +41,11 @@ for k in sq:
     a, w = sq[k], wait.get(k, {})
     cycles = a["GRBM_GUI_ACTIVE"] / 8.0                      # per XCD = launch duration in shader cycles
     ms = stats.get(k)
-    e = dict(avg_ms_kernel_stats=ms, launch_cycles=cycles, clock_GHz=(cycles / (ms * 1e6)) if ms else None,
+    fills_the_chip = k.startswith("void mlf::k_sweep_min")   # see the module docstring
+    e = dict(avg_ms_kernel_stats=ms, launch_cycles=cycles if fills_the_chip else None,
+             clock_GHz=(cycles / (ms * 1e6)) if (ms and fills_the_chip) else None,
              SQ_INSTS_MFMA=a["SQ_INSTS_MFMA"], SQ_INSTS_VALU=a["SQ_INSTS_VALU"], SQ_INSTS_SALU=a["SQ_INSTS_SALU"],
-             matrix_pipe_busy=a["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cycles if cycles else None,
+             matrix_pipe_busy=(a["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cycles) if (cycles and fills_the_chip) else None,
              non_matrix_instructions_per_matrix_instruction=((a["SQ_INSTS_VALU"] + a["SQ_INSTS_SALU"]) / a["SQ_INSTS_MFMA"]) if a["SQ_INSTS_MFMA"] else None,
              executed_TFLOPs=(a["SQ_INSTS_MFMA"] * 32768.0 / (ms * 1e-3) / 1e12) if ms else None)
     if w:

@@ -7,7 +7,7 @@ CPU port (oracle/, test infrastructure) timed next to it on the host of the same
                                 point, and region.inside of 10 points
 
 Same loops and the same stopping rule as the reference (repeat until 1 s / 0.1 s of accumulated time), JSON instead of the
-plots.  d > 128 is outside this library's size classes (MLF_E_DIM, loud): recorded as unsupported.
+plots.  d = 256 runs on the run-time-dimensionality kernels of mlf_wide.hip (round 5; until round 4: MLF_E_DIM above 128).
 
     python scripts/reference_grid_bench.py [--no-cpu] > profiles/r04_reference_grid.json
 """

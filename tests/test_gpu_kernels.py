@@ -57,7 +57,7 @@ def test_find_nearby_edge_cases(K):
     K.find_nearby(np.zeros((0, 3)), np.zeros((4, 3)), 1.0, out)          # no live points
     assert (out == -1).all()
     with pytest.raises(ValueError):
-        K.find_nearby(np.zeros((5, 200)), np.zeros((4, 200)), 1.0, out)  # d > MLF_MAX_DIM, loud
+        K.find_nearby(np.zeros((5, 1025)), np.zeros((4, 1025)), 1.0, out)  # d > MLF_MAX_DIM (1024), loud
     # non-contiguous inputs are accepted like the reference's strided buffers
     rs = np.random.RandomState(5)
     a = rs.normal(size=(40, 6))[:, ::2]
@@ -441,7 +441,7 @@ def test_integration_md_ctypes_stub_runs_verbatim(K):
     np.testing.assert_array_equal(r2, o_r2)
     z = rng.uniform(0, 10 * np.pi, size=(500, 4))
     np.testing.assert_allclose(ns["loglike"](z), orc.loglike_eggbox(z), rtol=1e-12, atol=0)
-    wide = rng.uniform(size=(4, 129))     # above MLF_MAX_DIM: the stub surfaces mlf_last_error()
+    wide = rng.uniform(size=(4, 1025))     # above MLF_MAX_DIM: the stub surfaces mlf_last_error()
     with pytest.raises(RuntimeError, match="MLF_MAX_DIM"):
         ns["find_nearby"](wide, wide, 0.3, near[:4].copy())
 
@@ -476,3 +476,110 @@ print("ok", int((out >= 0).sum()))
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] and outs[0].startswith("ok ")
+
+
+# ------------------------------------------------------------------ above 128 dimensions (mlf_wide.hip) -------------
+# The reference has no dimension limit (every loop runs `for k in range(ndim)`, mlfriends.pyx:63-66, 178-180, 217-219; its own
+# benchmark goes to d = 256, tests/benchmark_maxradius.py:36-98).  Round 4 stopped at 128 with a loud error.
+WIDE_DIMS = [129, 200, 256, 515]
+
+
+@pytest.mark.parametrize("d", WIDE_DIMS)
+def test_wide_find_count_subtract_vs_oracle(d, K, oracle):
+    """K1 / K2 / K3 above 128 dimensions: first-hit indices, counts and neighbour means bit for bit"""
+    rs = np.random.RandomState(9000 + d)
+    n, p = 333, 150
+    apts = rs.normal(size=(n, d))
+    bpts = apts[rs.randint(n, size=p)] + rs.normal(size=(p, d)) * rs.uniform(0.2, 1.2, size=(p, 1))
+    bpts[0] = apts[n - 1]
+    d2 = ((bpts[:, None, :] - apts[None, :60, :]) ** 2).sum(axis=2).min(axis=1)
+    r2 = float(np.median(d2))
+    for rr in (r2, 0.0, 1e300):
+        assert np.array_equal(_find(K, apts, bpts, rr), oracle.find_nearby(apts, bpts, rr)), (d, rr)
+        cnt = np.empty(p, dtype=np.int64)
+        K.count_nearby(apts, bpts, rr, cnt)
+        assert np.array_equal(cnt, oracle.count_nearby(apts, bpts, rr)), (d, rr)
+    pd = ((apts[:, None, :] - apts[None, :, :]) ** 2).sum(axis=2)
+    rq = float(np.quantile(pd[pd > 0], 0.1))
+    assert np.array_equal(K.subtract_nearby(apts, rq), oracle.subtract_nearby(apts, rq)), d
+
+
+@pytest.mark.parametrize("d", WIDE_DIMS)
+def test_wide_bootstrap_radius_and_moments_vs_oracle(d, K, oracle):
+    """K4 above 128 dimensions: per-round radii (binary32-narrowed) bit for bit, all 32-round passes incl. a second group;
+    row-block shares combine to the full pass; the moments within their tolerance class"""
+    rs = np.random.RandomState(9100 + d)
+    n, B = 300, 35
+    pts = rs.normal(size=(n, d))
+    masks = oracle.draw_bootstrap_masks(np.random.RandomState(d), n, B)
+    masks[3] = True
+    r2, skipped = K.maxradiussq_bootstrap(pts, masks)
+    r2_o, skipped_o = oracle.maxradiussq_bootstrap(pts, masks)
+    assert np.array_equal(skipped, skipped_o) and np.array_equal(r2, r2_o), d
+    parts = [K.maxradiussq_bootstrap(pts, masks, rows=(lo, hi))[0] for lo, hi in ((0, 128), (128, 256), (256, n))]
+    assert np.array_equal(np.max(parts, axis=0), r2)
+    ctrs, covs = K.bootstrap_moments(pts, masks[:4])
+    for b in range(4):
+        sel = pts[masks[b]]
+        np.testing.assert_allclose(ctrs[b], sel.mean(axis=0), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(covs[b], np.cov(sel, rowvar=0), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("d", [129, 200, 256])
+def test_wide_region_inside_vs_oracle(d, K, oracle):
+    """H3 + T1 + R3 above 128 dimensions: quadratic form in the einsum order and the whitening chain bit for bit, the
+    membership mask of a device-resident region (live points whitened on the device) equal to the oracle's, small calls
+    (which take the single-launch path below 129 dimensions) included, a live point replaced in place"""
+    rs = np.random.RandomState(9200 + d)
+    n, p = 400, 700
+    u = 0.5 + 0.05 * rs.normal(size=(n, d))
+    ctr = u.mean(axis=0)
+    cov = np.cov(u, rowvar=0) * (d + 2) + 1e-6 * np.eye(d)      # n > d: full rank; the jitter keeps eigh well away from zero
+    ev, evec = np.linalg.eigh(cov)
+    T = evec * ev ** -0.5
+    inv = np.linalg.inv(cov)
+    pts = inputs.proposal_mix(9300 + d, u, p, shell_q=2.0)
+    emask, q = K.inside_ellipsoid(pts, ctr, inv, 2.0 * d, return_q=True)
+    emask_o, q_o = oracle.inside_ellipsoid(pts, ctr, inv, 2.0 * d, return_q=True)
+    assert np.array_equal(q, q_o) and np.array_equal(emask, emask_o)
+    t = K.affine_transform(pts, ctr, T)
+    assert np.array_equal(t, oracle.affine_transform(pts, ctr, T))
+    tl = K.affine_transform(u, ctr, T)
+    dd = ((tl[:150, None, :] - tl[None, :150, :]) ** 2).sum(axis=2)
+    np.fill_diagonal(dd, np.inf)
+    r2 = float(np.quantile(dd.min(axis=1), 0.8))
+    reg = K.DeviceRegion()
+    reg.set(u, 0, ctr, T, None, ctr, inv, 2.0 * d, r2, live_space=1)
+    want = oracle.region_inside(pts, tl, ctr, T, ctr, inv, 2.0 * d, r2)
+    assert np.array_equal(reg.inside(pts), want)
+    assert 0 < want.sum() < p
+    assert np.array_equal(reg.inside(pts[:10]), want[:10])          # 10 host points: no single-launch path up here
+    assert reg.inside(u).all()
+    un2 = tl.copy()
+    un2[7] = t[1]
+    reg.update_point(7, pts[1])
+    assert np.array_equal(reg.inside(pts), oracle.region_inside(pts, un2, ctr, T, ctr, inv, 2.0 * d, r2))
+    reg.close()
+
+
+def test_wide_reference_classes_at_d_200(K, oracle):
+    """the drop-in classes above 128 dimensions: AffineLayer + MLFriends, bootstrapped radius / enlargement (moments on the
+    device, LAPACK inverse on the host, quadratic form on the device), create_ellipsoid, inside"""
+    import ultranest_amd.mlfriends as M
+    rs = np.random.RandomState(77)
+    n, d = 450, 200
+    u = 0.5 + 0.04 * rs.normal(size=(n, d))
+    layer = M.AffineLayer()
+    layer.optimize(u, u)
+    region = M.MLFriends(u, layer)
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=6, rng=np.random.RandomState(5))
+    masks = oracle.draw_bootstrap_masks(np.random.RandomState(5), n, 6)
+    r_o, f_o = oracle.compute_enlargement(u, region.unormed, masks)
+    assert region.maxradiussq == r_o
+    assert abs(region.enlarge - f_o) <= 1e-9 * f_o
+    region.create_ellipsoid()
+    pts = inputs.proposal_mix(78, u, 600, shell_q=region.enlarge)
+    want = oracle.region_inside(pts, region.unormed, layer.ctr, layer.T, region.ellipsoid_center, region.ellipsoid_invcov,
+                                region.enlarge, region.maxradiussq)
+    assert np.array_equal(region.inside(pts), want)
+    assert region.inside(u).all()

@@ -276,7 +276,7 @@ int upload_any(DevBuf &b, const void *src, size_t bytes, hipStream_t s) {
 
 int check_dims(size_t d) {
   if (d == 0) return fail_arg(MLF_E_BADARG, "dimensionality must be positive");
-  if (d > MLF_MAX_DIM) return fail_arg(MLF_E_DIM, "dimensionality above MLF_MAX_DIM (128) is not supported");
+  if (d > MLF_MAX_DIM) return fail_arg(MLF_E_DIM, "dimensionality above MLF_MAX_DIM (1024) is not supported");
   return 0;
 }
 
@@ -1467,6 +1467,7 @@ int mlf_dev_copy(void *dst, const void *src, size_t bytes, int sync) {
 // lo[c], hi[c] = extents of column c of the (n, d) row-major array `pts` (host or device); lo / hi on the host
 int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi) {
   if (int rc = check_dims(d)) return rc;
+  if (d > 128) return fail_arg(MLF_E_DIM, "mlf_col_extent covers up to 128 columns (the device-resident rebuild it serves: d <= 64)");
   if (!pts || !lo || !hi || n == 0) return fail_arg(MLF_E_BADARG, "null pointer or no rows");
   if (int rc = ensure_ctx()) return rc;
   Ctx &c = g_ctx;
@@ -1909,7 +1910,7 @@ int mlf_bootstrap_quadform_max(const double *u, size_t n, size_t d, const uint8_
   }
   if (int rc = upload(c.small0, pc.data(), pc.size() * sizeof(double), c.stream)) return rc;
   if (int rc = upload(c.small1, pm.data(), pm.size() * sizeof(double), c.stream)) return rc;
-  const size_t nblk = (n + 255) / 256;
+  const size_t nblk = wide_dims(dp) ? (size_t)quadmax_blocks_wide((int)n, (int)d) : (n + 255) / 256;
   CK(c.small2.reserve(B * nblk * sizeof(double)));
   QuadMaxArgs qa{};
   qa.u = c.src.as<double>();
@@ -2852,6 +2853,7 @@ int pick_dp(int d) {
   if (d <= D) return D;
   MLF_FOR_EACH_DP(X)
 #undef X
+  if (d <= MLF_MAX_DIM) return (d + 15) / 16 * 16;   // above 128: the run-time kernels of mlf_wide.hip, coordinates padded to 16
   return -1;
 }
 

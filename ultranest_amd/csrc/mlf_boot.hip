@@ -376,6 +376,7 @@ hipError_t launch_boot(int dp, const BootArgs &a, int nchunks, hipStream_t s, in
   // nblocks 64-row blocks starting at a.blk0 (default: all of them)
   const dim3 grid((unsigned)(nblocks >= 0 ? nblocks : a.npad / kWave), (unsigned)nchunks);
   if (grid.x == 0) return hipSuccess;
+  if (wide_dims(dp)) return launch_boot_wide(dp, a, dp, nchunks, s, nblocks);   // padded coordinates are zero: (0 - 0)^2 adds +0.0
   switch (dp) {
 #define X(D)                                                        \
   case D:                                                           \

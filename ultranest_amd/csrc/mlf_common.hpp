@@ -122,8 +122,19 @@ struct QuadMaxArgs {
   double *part;             // [B][ceil(n/256)] per-workgroup maxima
 };
 
-// smallest instantiated DP >= d, or -1 (d > MLF_MAX_DIM)
+// smallest instantiated DP >= d; above 128: d rounded up to 16 (the run-time kernels of mlf_wide.hip); -1 above MLF_MAX_DIM
 int pick_dp(int d);
+
+// ---- dimensionalities above 128 (mlf_wide.hip): k-chunked forms with the dimensionality at run time, same arithmetic
+bool wide_dims(int dp);
+hipError_t launch_scan_wide(int dp, const ScanArgs &a, hipStream_t s);
+hipError_t launch_boot_wide(int dp, const BootArgs &a, int d, int nchunks, hipStream_t s, int nblocks);
+hipError_t launch_prep_wide(int dp, const PrepArgs &a, hipStream_t s);
+int quadmax_blocks_wide(int n, int d);   // workgroups per round (= partial maxima per round) of launch_quadmax_wide
+hipError_t launch_quadmax_wide(int dp, const QuadMaxArgs &a, int B, hipStream_t s);
+void launch_subtract_wide(const double *pts, int n, int d, const unsigned long long *flags, int ntiles, double *out, hipStream_t s);
+void launch_boot_mean_cov_wide(const double *u, int n, int d, const int *idx, const int *count, int B, double *mean, double *cov, hipStream_t s);
+void launch_update_rows_wide(const double *rows, int count, int d, int dp, int npad, const long long *index, double *refT, double *refR, hipStream_t s);
 
 hipError_t launch_scan(int dp, const ScanArgs &a, hipStream_t s);
 hipError_t launch_boot(int dp, const BootArgs &a, int nchunks, hipStream_t s, int nblocks = -1);

@@ -46,6 +46,7 @@ __global__ void k_update_row(const double *rows, int d, int dp, int npad, const 
 // `count` whitened rows (count x d, packed) replace the live points index[0..count) in both layouts
 void launch_update_rows(const double *rows, int count, int d, int dp, int npad, const long long *index, double *refT,
                         double *refR, hipStream_t s) {
+  if (dp > 128) return launch_update_rows_wide(rows, count, d, dp, npad, index, refT, refR, s);
   hipLaunchKernelGGL(k_update_row, dim3((unsigned)count), dim3(128), 0, s, rows, d, dp, npad, index, refT, refR);
 }
 
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(64 * kAccumWaves) void k_subtract_accum(const doubl
 
 void launch_subtract_accum(const double *pts, int n, int d, const unsigned long long *flags,
                            int ntiles, double *out, hipStream_t s) {
+  if (d > 128) return launch_subtract_wide(pts, n, d, flags, ntiles, out, s);
   const int per_block = kAccumWaves * kAccumPer;
   const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
   const size_t lds = (size_t)kWave * d * sizeof(double);
@@ -840,6 +842,7 @@ hipError_t launch_boot_cholmax(const double *u, int n, int d, const uint8_t *sel
 void launch_boot_moments(const double *u, int n, int d, const uint8_t *selected, int B, double *mean,
                          int *count, double *cov, int *idx, hipStream_t s) {
   hipLaunchKernelGGL(k_boot_index, dim3(B), dim3(256), 0, s, selected, n, idx, count);
+  if (d > 128) return launch_boot_mean_cov_wide(u, n, d, idx, count, B, mean, cov, s);
   if (d <= 64)
     hipLaunchKernelGGL(k_boot_mean<1>, dim3(B), dim3(1024), 0, s, u, d, idx, n, count, mean);
   else
@@ -1020,9 +1023,20 @@ static void launch_loglike_rows(const double *params, int d, long long n, const 
   }
 }
 
+// above 128 parameters: one thread per row straight from global memory (a row no longer fits the staging of k_loglike)
+__global__ __launch_bounds__(256) void k_loglike_wide(int kind, const double *params, int d, long long n, const double *aux, double sigma,
+                                                     double *like) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) like[i] = loglike_row(kind, params + i * d, d, aux, sigma);
+}
+
 void launch_loglike(int kind, const double *params, int d, long long n, const double *aux,
                     double sigma, double *like, hipStream_t s) {
   if (n <= 0) return;
+  if (d > 128) {
+    hipLaunchKernelGGL(k_loglike_wide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kind, params, d, n, aux, sigma, like);
+    return;
+  }
   if (d % 2 == 0 && d <= 128 && (reinterpret_cast<uintptr_t>(params) & 15u) == 0) {   // rows are 16-byte aligned
     switch (kind) {
       case 0: launch_loglike_rows<0>(params, d, n, aux, sigma, like, s); return;

@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void k_boot_quadmax(QuadMaxArgs a) {
 
 hipError_t launch_boot_quadmax(int dp, const QuadMaxArgs &a, int B, hipStream_t s) {
   if (a.n <= 0 || B <= 0) return hipSuccess;
+  if (wide_dims(dp)) return launch_quadmax_wide(dp, a, B, s);
   const dim3 grid((unsigned)((a.n + 255) / 256), (unsigned)B);
   const size_t lds = (size_t)a.d * dp * sizeof(double);
   switch (dp) {
@@ -227,6 +228,7 @@ hipError_t launch_whiten_rows(const double *pts, long long n, int d, int dp, con
 }
 
 hipError_t launch_prep(int dp, const PrepArgs &a, hipStream_t s) {
+  if (wide_dims(dp)) return launch_prep_wide(dp, a, s);
   if (a.np <= 0) return hipSuccess;
   const unsigned grid = (unsigned)((a.np + 255) / 256);
   const size_t lds = (size_t)a.d * dp * sizeof(double);

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
 
 hipError_t launch_scan(int dp, const ScanArgs &a_in, hipStream_t s) {
   if (a_in.nq <= 0) return hipSuccess;
+  if (wide_dims(dp)) return launch_scan_wide(dp, a_in, s);
   ScanArgs a = a_in;
   const bool small = a.nq <= 16384;
   const int qb = small ? 16 : kScanQB;

@@ -140,7 +140,7 @@ int mlf_walkers_create(mlf_walkers **out, size_t popsize, size_t nsteps, size_t 
   *out = nullptr;
   if (popsize == 0 || nsteps == 0 || d == 0 || popsize > (1u << 24) || nsteps > 65535)
     return ctx_fail_arg(MLF_E_BADARG, "mlf_walkers_create: popsize, nsteps, d must be positive");
-  if (d > MLF_MAX_DIM) return ctx_fail_arg(MLF_E_DIM, "dimensionality above MLF_MAX_DIM (128) is not supported");
+  if (d > 128) return ctx_fail_arg(MLF_E_DIM, "the resident walkers (one wave per walker, lane = coordinate pair) cover up to 128 dimensions");
   if (int rc = ctx_ensure()) return rc;
   mlf_walkers *w = new mlf_walkers();
   w->P = (int)popsize;
