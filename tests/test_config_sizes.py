@@ -166,10 +166,13 @@ def test_c5_full_size_filter_equals_exact_scan(case, fuzz_draws):
 @pytest.mark.parametrize("name,opts", [("per-proposal stage inside the first sweep launch", {"fused_first_range": 1}),
                                        ("per-tile band test", {"sweep_min": 0}),
                                        ("binary64 per-proposal stage", {"prep_bounded": 0}),
-                                       ("single sweep", {"filter_phases": 0})])
+                                       ("single sweep", {"filter_phases": 0}),
+                                       ("storage order of the mask-mode operand, first range 50 %", {"filter_order": 0, "filter_first_range_pct": 50}),
+                                       ("first range 15 %", {"filter_first_range_pct": 15})])
 def test_c5_full_size_optional_routings(name, opts, fuzz_draws):
-    """The routings that are off by default (k_prep_sweep; k_sweep with its own re-check; k_prep3; one sweep over all tiles) on a
-    full-size batch, against the default routing and the exact scan: results never depend on options."""
+    """The routings that are off by default (k_prep_sweep; k_sweep with its own re-check; k_prep3; one sweep over all tiles; round
+    4's order of the live points and share of the first range; a short first range) on a full-size batch, against the default
+    routing and the exact scan: results never depend on options."""
     from ultranest_amd import _lib
     z, rad = fuzz_draws
     N, d = 4000, z.shape[1]
@@ -179,7 +182,8 @@ def test_c5_full_size_optional_routings(name, opts, fuzz_draws):
     pts = _ellipsoid_draws(region, z, rad)
     pts[5::1000] = u[rs.randint(N, size=len(pts[5::1000]))]
     default = region.inside(pts)
-    restore = {"fused_first_range": 0, "sweep_min": 1, "prep_bounded": 1, "filter_phases": 1, "filter": 1}
+    restore = {"fused_first_range": 0, "sweep_min": 1, "prep_bounded": 1, "filter_phases": 1, "filter": 1, "filter_order": 1,
+               "filter_first_range_pct": 30}
     try:
         for k, v in opts.items():
             _lib.set_option(k, v)

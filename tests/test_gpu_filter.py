@@ -145,6 +145,40 @@ def test_region_inside_filter_vs_exact(K, oracle):
     reg.close()
 
 
+@pytest.mark.parametrize("p", [12000, 70001])
+def test_exact_scan_tail_of_the_unbounded_path_covers_the_whole_batch(p, K, oracle):
+    """Round 5 regression: behind the binary64 per-proposal stage (d = 65 ... 128, wrapped axes, prep_bounded = 0) the exact
+    scan that takes what the pre-filter cannot (route 2) is a GATED launch of the plain k_scan instance, one query block per
+    workgroup -- and its grid was capped at 512 workgroups, so route-2 proposals past the first 8192 (small batches) / 32768
+    never got their answer.  Here EVERY proposal is route 2: a live cloud of extent 1e-6 and proposals at distance ~1 (their
+    scaled coordinates do not fit binary16), half of them within the radius."""
+    from ultranest_amd import _lib
+    n, d = 512, 4
+    rs = np.random.RandomState(2)
+    c = np.array([0.25, 0.5, 0.75, 0.125])
+    u = c + 1e-6 * rs.normal(size=(n, d))
+    dirs = rs.normal(size=(p, d))
+    dirs /= np.sqrt((dirs ** 2).sum(axis=1, keepdims=True))
+    pts = c + dirs * (1.0 + 1e-3 * rs.normal(size=(p, 1)))
+    ctr, T, inv = np.zeros(d), np.eye(d), np.eye(d)
+    want = oracle.region_inside(pts, u, ctr, T, c, inv, 1e6, 1.0)
+    assert 0.3 < want.mean() < 0.7
+    reg = K.DeviceRegion()
+    reg.set(u, 0, ctr, T, None, c, inv, 1e6, 1.0)
+    got = {}
+    for name, opts in (("default", {}), ("binary64 stage", {"prep_bounded": 0}), ("exact", {"filter": 0})):
+        for k, v in opts.items():
+            _lib.set_option(k, v)
+        # poison the answer buffer first: a proposal nobody answers must not pass by luck
+        reg.inside(np.tile(u[:1], (p, 1)))
+        got[name] = reg.inside(pts)
+        for k in opts:
+            _lib.set_option(k, 1)
+    reg.close()
+    for name, m in got.items():
+        assert np.array_equal(m, want), (name, p, np.flatnonzero(m != want)[:5])
+
+
 @pytest.mark.parametrize("n,d,p", [(500, 3, 4097), (700, 1, 3000), (900, 17, 2049), (1200, 20, 5000), (4000, 50, 6001),
                                    (300, 64, 2500), (300, 70, 2500)])
 def test_fused_prep_matches_unfused(n, d, p, K, oracle):

@@ -210,12 +210,17 @@ hipError_t launch_scan(int dp, const ScanArgs &a_in, hipStream_t s) {
   const bool small = a.nq <= 16384;
   const int qb = small ? 16 : kScanQB;
   unsigned grid = (unsigned)((a.nq + qb - 1) / qb);
-  if (a.only_gated && grid > 512u) grid = 512u;   // mostly idle: keep the dispatch short (the workgroups stride over the query blocks)
+  const bool extra = a.fin_best || a.route || a.any_flag || a.raw_ctr;
+  // mostly idle second-stage launches: keep the dispatch short -- the workgroups of the EXTRA instance stride over the query
+  // blocks.  The plain instance handles ONE block per workgroup: its grid is never capped (round 5: until then a gated launch
+  // of the plain instance -- the scan behind the binary64 per-proposal stage, d = 65 ... 128, wrapped axes, prep_bounded = 0
+  // -- covered only the first 512 blocks: a proposal past the first 32768 that the pre-filter had routed to the exact scan
+  // kept its initial answer; tests/test_gpu_filter.py::test_exact_scan_tail_of_the_unbounded_path_covers_the_whole_batch)
+  if (extra && a.only_gated && grid > 512u) grid = 512u;
   if (a.fin_best) {
     a.fin_grid0 = grid;
     grid += (unsigned)((a.nq + 4 * kScanThreads - 1) / (4 * kScanThreads));
   }
-  const bool extra = a.fin_best || a.route || a.any_flag || a.raw_ctr;
   unsigned ny = 1;
   if (a.mode == SCAN_FLAGS && !extra) {   // aim at ~4 waves per SIMD (4096 waves), at least 4 tiles per range
     ny = 4096u / (grid * 4u > 0u ? grid * 4u : 1u);

@@ -6,7 +6,7 @@
 // These are their k-CHUNKED forms with the dimensionality at run time: the same arithmetic, term by term, in the same
 // order -- k ascending ACROSS the chunks, every sub / mul / add rounded on its own (this file is compiled with
 // -ffp-contract=off), explicit fma() where the narrow kernels use one -- so every result is bit-identical to what the
-// templated kernels would give (and to the oracle).  They are the slow forms by construction (a point's coordinates come
+// templated kernels would give (and to the CPU restatement the tests compare with).  They are the slow forms by construction (a point's coordinates come
 // from L2 / LDS every time they are used); nothing below 129 dimensions is routed here.
 //
 //   k_scan_wide        K1 / K2 / K3 pass 1 / the scan of R3 (find_nearby :143-183, count_nearby :31-68): lane = live point,
