@@ -316,27 +316,30 @@ int filter_prepare_refs(FilterCtx &f, const double *refR, int n, int d, int dp, 
     CK(f.statscratch.reserve(bytes));
     if (f.statscratch.p != before) CK(hipMemsetAsync(f.statscratch.p, 0, bytes, s));   // running maxima start at zero
   }
-  launch_ref_stats(refR, n, dp, dp, f.stats.as<double>(), f.statscratch.as<double>(), s);
-  launch_quant_refs(refR, n, npad32, dp, dp, ks, f.stats.as<double>(), f.refF.p, s);
-  CK(hipGetLastError());
-  f.ordered = false;
-  if (opt(f, OPT_ORDER) && n <= 65536) {
-    // a NEW live set (host_sync) is ranked; a refresh behind row replacements keeps the permutation -- the replaced rows stay
-    // in their slots (the order is a heuristic of the sweep, not part of any answer) -- and only gathers and requantises
-    const int nrows = round_up(n, 64) + 1;   // the re-check requests whole 16-coordinate blocks: a spare row behind the last
-    const bool rerank = host_sync || f.order_n != n;
-    CK(f.refFm.reserve((size_t)npad32 * ks * 16 * 2));
-    CK(f.refRm.reserve((size_t)nrows * dp * sizeof(double)));
+  // the mask-mode operand: the live points nearest to the centre first.  A NEW live set (host_sync) is ranked -- the keys
+  // come out of the statistics pass --; a refresh behind row replacements keeps the permutation (the replaced rows stay in
+  // their slots: the order is a heuristic of the sweep, not part of any answer) and only requantises
+  const bool want_order = opt(f, OPT_ORDER) && n <= 65536;
+  const bool rerank = want_order && (host_sync || f.order_n != n);
+  if (want_order) {
     CK(f.okeys.reserve((size_t)n * sizeof(unsigned long long)));
     CK(f.operm.reserve((size_t)n * sizeof(int)));
-    launch_ref_order(refR, n, nrows, dp, dp, f.stats.as<double>(), f.okeys.as<unsigned long long>(), f.operm.as<int>(),
-                     f.refRm.as<double>(), rerank, s);
-    launch_quant_refs(f.refRm.as<double>(), n, npad32, dp, dp, ks, f.stats.as<double>(), f.refFm.p, s);
+  }
+  launch_ref_stats(refR, n, dp, dp, f.stats.as<double>(), f.statscratch.as<double>(), s, rerank ? f.okeys.as<unsigned long long>() : nullptr);
+  f.ordered = false;
+  if (want_order) {
+    const int nrows = round_up(n, 64) + 1;   // the re-check requests whole 16-coordinate blocks: a spare row behind the last
+    CK(f.refFm.reserve((size_t)npad32 * ks * 16 * 2));
+    CK(f.refRm.reserve((size_t)nrows * dp * sizeof(double)));
+    if (rerank) launch_ref_rank(f.okeys.as<unsigned long long>(), n, f.operm.as<int>(), s);
+    launch_quant_refs(refR, n, npad32, dp, dp, ks, f.stats.as<double>(), f.refF.p, s, f.refFm.p, f.operm.as<int>(), f.refRm.as<double>(), nrows);
     CK(hipGetLastError());
     f.ordered = true;
     f.order_n = n;
-  } else if (host_sync) {
-    f.order_n = -1;
+  } else {
+    launch_quant_refs(refR, n, npad32, dp, dp, ks, f.stats.as<double>(), f.refF.p, s);
+    CK(hipGetLastError());
+    if (host_sync) f.order_n = -1;
   }
   if (host_sync) {
     double h[4];

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void k_ref_colsum(const double *__restrict__ r
 // |a_i - c|^2 as bit patterns (non-negative doubles order like their bit patterns; NaN / inf -> all ones)
 __global__ __launch_bounds__(256) void k_ref_extent(const double *__restrict__ refR, int n, int d, int dp,
                                                     const double *__restrict__ scratch,
-                                                    unsigned long long *__restrict__ maxima, double *__restrict__ stats) {
+                                                    unsigned long long *__restrict__ maxima, double *__restrict__ stats,
+                                                    unsigned long long *__restrict__ keys) {
   __shared__ double cc[128];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 128) {
@@ -97,6 +98,9 @@ __global__ __launch_bounds__(256) void k_ref_extent(const double *__restrict__ r
     double sq = v0 * v0 + v1 * v1;
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
     n2max = fmax(n2max, sq);
+    // |a_i - c|^2 is also the key of the mask-mode operand's order (k_ref_rank): non-negative doubles order like their bit
+    // patterns, a NaN sorts last
+    if (keys && lane == 0) keys[i] = (unsigned long long)__double_as_longlong(sq);
   }
   for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
   const bool all_finite = __all(finite) && amax <= 1.7e308 && n2max <= 1.7e308;
@@ -127,32 +131,80 @@ __global__ void k_ref_finish(unsigned long long *maxima, double *stats) {
 
 // ---------------------------------------------------------------- live points -> f16 fragments
 // one thread per live-point row (rows >= n are sentinels that can never be hit)
-__global__ void k_quant_refs(const double *refR, int n, int npad32, int d, int dp, int ks,
-                             const double *stats, half_t *refF) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npad32) return;
+// Both operands in ONE launch: blockIdx.y = 0 the storage-order operand refF (first-index mode), blockIdx.y = 1 the mask-mode
+// operand refFm -- slot i holds storage row perm[i] -- together with the rows in that order (rows_out: what the exact re-check
+// of the mask-mode kernels reads; slots n .. nrows_out - 1 are zero rows).  SIXTEEN lanes per row, lane l the 16-byte pieces
+// (8 columns) l and l + 16: eight loads issued together, the norm summed over the row's lanes, one store per piece.  (Rounds
+// 1-4: one thread per row, one 2-byte store per element behind one load at a time: 16 us for 4000 rows.)
+struct half8pack {
+  half_t h[8];
+};
+__global__ __launch_bounds__(256) void k_quant_refs(const double *refR, int n, int npad32, int d, int dp, int ks,
+                                                    const double *stats, half_t *refF, half_t *refFm, const int *perm, double *rows_out,
+                                                    int nrows_out) {
+  const bool ordered = blockIdx.y != 0;
+  if (ordered && !refFm) return;
+  half_t *dst = ordered ? refFm : refF;
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  if (ordered && rows_out && i >= n && i < nrows_out)
+    for (int k = sub; k < dp; k += 16) rows_out[(size_t)i * dp + k] = 0.0;
+  if (i >= npad32) return;   // whole 16-lane groups leave together
   const int K = ks * 16;
   const double sigma = stats[0];
+  const bool have = i < n;
+  const int src = (ordered && have) ? perm[i] : (have ? i : 0);
+  const double *row = refR + (size_t)src * dp;
+  double v[2][8];
   double na = 0.0;
-  for (int k = 0; k < d; ++k) {
-    half_t h = (half_t)0.0f;
-    if (i < n) {
-      h = (half_t)(float)(sigma * (refR[(size_t)i * dp + k] - stats[8 + k]));
-      const double hv = (double)(float)h;
-      na += hv * hv;  // exact: 22-bit products, <= 128 terms
-    }
-    refF[frag_index(i, k, ks)] = h;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k0 = 8 * (sub + 16 * u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[u][j] = (have && k0 + j < d) ? row[k0 + j] : 0.0;
   }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k0 = 8 * (sub + 16 * u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (have && k0 + j < d) {
+        const half_t h = (half_t)(float)(sigma * (v[u][j] - stats[8 + k0 + j]));
+        const double hv = (double)(float)h;
+        na += hv * hv;  // exact: 22-bit products, <= 128 terms -- any order of the sum gives the same bits
+      }
+  }
+  for (int o = 8; o > 0; o >>= 1) na += __shfl_xor(na, o, 16);
   half_t p[3];
-  if (i < n) {
+  if (have) {
     split3(na, p);
   } else {
     p[0] = (half_t)60000.0f;  // sentinel row: Dt >= 60000 > every admissible T_hi
     p[1] = p[2] = (half_t)0.0f;
   }
-  for (int j = 0; j < 3; ++j) refF[frag_index(i, d + j, ks)] = p[j];       // x 1 in the queries
-  for (int j = 3; j < 6; ++j) refF[frag_index(i, d + j, ks)] = (half_t)1.0f;  // x |bh|^2 pieces
-  for (int k = d + 6; k < K; ++k) refF[frag_index(i, k, ks)] = (half_t)0.0f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k0 = 8 * (sub + 16 * u);
+    if (k0 >= K) continue;
+    half8pack pk;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      half_t h = (half_t)0.0f;
+      if (k < d) {
+        if (have) h = (half_t)(float)(sigma * (v[u][j] - stats[8 + k]));
+      } else if (k < d + 3) {
+        h = p[k - d];               // x 1 in the queries
+      } else if (k < d + 6) {
+        h = (half_t)1.0f;           // x |bh|^2 pieces
+      }
+      pk.h[j] = h;
+    }
+    *reinterpret_cast<half8pack *>(dst + frag_index(i, k0, ks)) = pk;   // 16-byte aligned: k0 is a multiple of 8
+    if (ordered && rows_out && have)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + j < dp) rows_out[(size_t)i * dp + k0 + j] = k0 + j < d ? v[u][j] : 0.0;
+  }
 }
 
 // ---------------------------------------------------------------- order of the mask-mode operand
@@ -161,51 +213,42 @@ __global__ void k_quant_refs(const double *refR, int n, int npad32, int d, int d
 // centre first: a proposal's nearest live points are, far more often than not, the central ones (|x - a|^2 = |x|^2 + |a|^2 -
 // 2 x.a), so the first tile range of a two-range sweep decides more proposals (C5 set E, scripts/order_study.py: 75 % after
 // half of the tiles against 62 % in storage order; 65 % against 46 % after 30 %).  The first-index operand keeps storage order.
-// key = bit pattern of |a_i - c|^2 (non-negative doubles order like their bit patterns; NaN sorts last: always a permutation)
-__global__ void k_ref_keys(const double *__restrict__ refR, int n, int d, int dp, const double *__restrict__ stats,
-                           unsigned long long *__restrict__ keys) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double acc = 0.0;
-  for (int k = 0; k < d; ++k) {
-    const double v = refR[(size_t)i * dp + k] - stats[8 + k];
-    acc += v * v;
-  }
-  keys[i] = (unsigned long long)__double_as_longlong(acc);
-}
-
+// key = bit pattern of |a_i - c|^2, written by k_ref_extent on its way (always a permutation: bit patterns are totally ordered)
 // rank by counting: slot of row i = #{j : key_j < key_i or (key_j == key_i and j < i)}; perm[slot] = i.  Workgroup = 64 rows
-// x 4 slices of the keys (wave w walks slice w: every lane reads the same key -- an LDS broadcast)
-__global__ __launch_bounds__(256) void k_ref_rank(const unsigned long long *__restrict__ keys, int n, int *__restrict__ perm) {
-  __shared__ unsigned long long kb[1024];
-  __shared__ unsigned part[4][64];
+// x 16 slices of the keys (wave w walks slice w: every lane reads the same key -- an LDS broadcast)
+constexpr int kRankSlices = 16;
+__global__ __launch_bounds__(64 * kRankSlices) void k_ref_rank(const unsigned long long *__restrict__ keys, int n, int *__restrict__ perm) {
+  __shared__ unsigned long long kb[2048];
+  __shared__ unsigned part[kRankSlices][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   const unsigned long long mine = i < n ? keys[i] : ~0ull;
   unsigned count = 0;
-  for (int base = 0; base < n; base += 1024) {
+  for (int base = 0; base < n; base += 2048) {
     __syncthreads();
-    for (int e = threadIdx.x; e < 1024; e += 256) kb[e] = base + e < n ? keys[base + e] : ~0ull;
+    for (int e = threadIdx.x; e < 2048; e += 64 * kRankSlices) kb[e] = base + e < n ? keys[base + e] : ~0ull;
     __syncthreads();
-    const int stop = n - base < 1024 ? n - base : 1024;
-    for (int e = wave; e < stop; e += 4) {
-      const unsigned long long kj = kb[e];
-      const int j = base + e;
-      count += (kj < mine || (kj == mine && j < i)) ? 1u : 0u;
+    // slots past n hold ~0 with an index past every row: they never count.  Eight keys per step, their LDS reads issued
+    // together (one read per step waited out its own latency: 66 us for 4000 keys with 4 slices)
+    for (int e = wave; e < 2048; e += 8 * kRankSlices) {
+      unsigned long long kj[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) kj[q] = kb[e + kRankSlices * q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = base + e + kRankSlices * q;
+        count += (kj[q] < mine || (kj[q] == mine && j < i)) ? 1u : 0u;
+      }
     }
   }
   part[wave][lane] = count;
   __syncthreads();
-  if (wave == 0 && i < n) perm[part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]] = i;
-}
-
-// refRm[slot] = refR[perm[slot]] (rows of dp doubles); slots n .. nrows - 1 are zero rows
-__global__ void k_ref_gather(const double *__restrict__ refR, const int *__restrict__ perm, int n, int nrows, int dp,
-                             double *__restrict__ refRm) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (long long)nrows * dp) return;
-  const int slot = (int)(e / dp), k = (int)(e - (long long)slot * dp);
-  refRm[e] = slot < n ? refR[(size_t)perm[slot] * dp + k] : 0.0;
+  if (wave == 0 && i < n) {
+    unsigned slot = 0;
+#pragma unroll
+    for (int w = 0; w < kRankSlices; ++w) slot += part[w][lane];
+    perm[slot] = i;
+  }
 }
 
 // ---------------------------------------------------------------- queries -> f16 fragments ---
@@ -586,27 +629,22 @@ __global__ void k_route_gate(const uint8_t *route, const unsigned *counters, lon
 }
 
 // ---------------------------------------------------------------- launchers -------------------
-void launch_ref_stats(const double *refR, int n, int d, int dp, double *stats, double *scratch, hipStream_t s) {
+void launch_ref_stats(const double *refR, int n, int d, int dp, double *stats, double *scratch, hipStream_t s, unsigned long long *keys) {
   unsigned long long *maxima = reinterpret_cast<unsigned long long *>(scratch + (size_t)kStatBlocks * 128);
   hipLaunchKernelGGL(k_ref_colsum, dim3(kStatBlocks), dim3(256), 0, s, refR, n, d, dp, scratch);
-  hipLaunchKernelGGL(k_ref_extent, dim3(kStatBlocks), dim3(256), 0, s, refR, n, d, dp, scratch, maxima, stats);
+  hipLaunchKernelGGL(k_ref_extent, dim3(kStatBlocks), dim3(256), 0, s, refR, n, d, dp, scratch, maxima, stats, keys);
   hipLaunchKernelGGL(k_ref_finish, dim3(1), dim3(1), 0, s, maxima, stats);
 }
 
 void launch_quant_refs(const double *refR, int n, int npad32, int d, int dp, int ks,
-                       const double *stats, void *refF, hipStream_t s) {
-  hipLaunchKernelGGL(k_quant_refs, dim3((unsigned)((npad32 + 127) / 128)), dim3(128), 0, s, refR, n, npad32,
-                     d, dp, ks, stats, reinterpret_cast<half_t *>(refF));
+                       const double *stats, void *refF, hipStream_t s, void *refFm, const int *perm, double *rows_out, int nrows_out) {
+  const int rows = refFm && rows_out && nrows_out > npad32 ? nrows_out : npad32;
+  hipLaunchKernelGGL(k_quant_refs, dim3((unsigned)((rows + 15) / 16), refFm ? 2u : 1u), dim3(256), 0, s, refR, n, npad32,
+                     d, dp, ks, stats, reinterpret_cast<half_t *>(refF), reinterpret_cast<half_t *>(refFm), perm, rows_out, nrows_out);
 }
 
-void launch_ref_order(const double *refR, int n, int nrows, int d, int dp, const double *stats, unsigned long long *keys,
-                      int *perm, double *refRm, bool rerank, hipStream_t s) {
-  if (rerank) {
-    hipLaunchKernelGGL(k_ref_keys, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, refR, n, d, dp, stats, keys);
-    hipLaunchKernelGGL(k_ref_rank, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, keys, n, perm);
-  }
-  const long long total = (long long)nrows * dp;
-  hipLaunchKernelGGL(k_ref_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, refR, perm, n, nrows, dp, refRm);
+void launch_ref_rank(const unsigned long long *keys, int n, int *perm, hipStream_t s) {
+  hipLaunchKernelGGL(k_ref_rank, dim3((unsigned)((n + 63) / 64)), dim3(64 * kRankSlices), 0, s, keys, n, perm);
 }
 
 void launch_quant_queries(const double *q, long long ldq, long long nq, long long nqpad, int d_src, int d,

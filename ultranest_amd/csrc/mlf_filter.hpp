@@ -172,13 +172,16 @@ struct RecheckArgs {
 };
 
 // scratch: (64 * 128 + 2) doubles, zero-initialised once (the last two words are running maxima, reset by the launch)
-void launch_ref_stats(const double *refR, int n, int d, int dp, double *stats, double *scratch, hipStream_t s);
+// keys (optional, [n] u64): bit patterns of |a_i - c|^2, the sort key of the mask-mode operand's order
+void launch_ref_stats(const double *refR, int n, int d, int dp, double *stats, double *scratch, hipStream_t s,
+                      unsigned long long *keys = nullptr);
+// refF: the storage-order operand; refFm (optional): the mask-mode operand, slot i = storage row perm[i], with the rows in that
+// order in rows_out [nrows_out][dp] -- both in one launch
 void launch_quant_refs(const double *refR, int n, int npad32, int d, int dp, int ks,
-                       const double *stats, void *refF, hipStream_t s);
-// mask-mode operand order (nearest to the centre first): keys [n] u64, perm [n] (slot -> storage row), refRm [nrows][dp] the
-// permuted rows (rows past n zero); rerank = false keeps the permutation and only gathers the rows again
-void launch_ref_order(const double *refR, int n, int nrows, int d, int dp, const double *stats, unsigned long long *keys,
-                      int *perm, double *refRm, bool rerank, hipStream_t s);
+                       const double *stats, void *refF, hipStream_t s, void *refFm = nullptr, const int *perm = nullptr,
+                       double *rows_out = nullptr, int nrows_out = 0);
+// perm[slot] = storage row, slots in ascending key order (ties: ascending row)
+void launch_ref_rank(const unsigned long long *keys, int n, int *perm, hipStream_t s);
 void launch_quant_queries(const double *q, long long ldq, long long nq, long long nqpad, int d_src, int d, int ks,
                           const double *stats, double r2, const uint8_t *gate, void *qF, float *tlo,
                           float *thi, uint8_t *route, int *best, unsigned *counters, hipStream_t s);

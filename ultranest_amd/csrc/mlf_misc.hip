@@ -135,19 +135,24 @@ void launch_boot_final(const unsigned long long *M, const unsigned *sel, int n, 
 }
 
 // ------------------------------------------------------- constants of a region, one launch ---
+// kScatterSplit workgroups per segment (grid.y), each with its share of the words: the source is pinned HOST memory read over
+// the fabric, one workgroup per segment walked its 10-30 KB in dependent 2 KB steps (19 us for the longest segment of
+// mlf_region_set, two such launches per call)
+constexpr unsigned kScatterSplit = 8;
 __global__ __launch_bounds__(256) void k_scatter_copy(ScatterArgs a) {
   const int seg = blockIdx.x;
   unsigned char *dst = static_cast<unsigned char *>(a.dst[seg]);
   const unsigned char *src = static_cast<const unsigned char *>(a.src[seg]);
   const unsigned bytes = a.bytes[seg];
   const unsigned words = bytes / 8u;   // both ends are 8-byte aligned (64-byte arena pieces, 256-byte device buffers)
-  for (unsigned w = threadIdx.x; w < words; w += 256)
+  for (unsigned w = blockIdx.y * 256u + threadIdx.x; w < words; w += 256u * kScatterSplit)
     reinterpret_cast<unsigned long long *>(dst)[w] = reinterpret_cast<const unsigned long long *>(src)[w];
-  for (unsigned t = words * 8u + threadIdx.x; t < bytes; t += 256) dst[t] = src[t];
+  if (blockIdx.y == 0)
+    for (unsigned t = words * 8u + threadIdx.x; t < bytes; t += 256) dst[t] = src[t];
 }
 
 void launch_scatter_copy(const ScatterArgs &a, int count, hipStream_t s) {
-  if (count > 0) hipLaunchKernelGGL(k_scatter_copy, dim3((unsigned)count), dim3(256), 0, s, a);
+  if (count > 0) hipLaunchKernelGGL(k_scatter_copy, dim3((unsigned)count, kScatterSplit), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------- K3 pass 2 -----------------------

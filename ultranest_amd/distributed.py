@@ -128,9 +128,11 @@ def allreduce_max(values, group=None):
     return t.cpu().numpy()
 
 
-def sharded_enlargement(region, nbootstraps, minvol=0., rng=np.random, group=None):
+def sharded_enlargement(region, nbootstraps, minvol=0., rng=np.random, group=None, masks=None):
     """(maxradiussq, enlarge) over `nbootstraps` rounds sharded across the process group.
-    Single process: identical to ``region.compute_enlargement`` (same draws, same bits)."""
+    Single process: identical to ``region.compute_enlargement`` (same draws, same bits).
+    `masks`: the (B, N) selection matrix if the caller has drawn it already -- from the same stream position this call would
+    have drawn it from (harness.RegionUpdater draws on its worker thread while the region object is being built)."""
     rank, size = world(group)
     npoints = len(region.u)
     start = getattr(region, "_start_ellipsoid_parts", None)
@@ -138,7 +140,8 @@ def sharded_enlargement(region, nbootstraps, minvol=0., rng=np.random, group=Non
         start(minvol)      # the host LAPACK of the create_ellipsoid that follows: on the worker thread from here on
     # every rank draws (so that rank-replicated host logic that uses the same stream afterwards stays in step across
     # the ranks when they are seeded alike); rank 0's draw is the one that counts
-    masks = regions._draw_selection(rng, npoints, nbootstraps)
+    if masks is None:
+        masks = regions._draw_selection(rng, npoints, nbootstraps)
     masks = broadcast_masks(masks, npoints, nbootstraps, group=group, keep_on_device=True)
     lo, hi = shard_bounds(nbootstraps, rank, size)
     error = None
@@ -168,11 +171,11 @@ def sharded_enlargement(region, nbootstraps, minvol=0., rng=np.random, group=Non
     return float(r), float(f)
 
 
-def update_region_bootstrap(region, nbootstraps, minvol=0., group=None, rng=np.random):
+def update_region_bootstrap(region, nbootstraps, minvol=0., group=None, rng=np.random, masks=None):
     """Counterpart of the reference's ``_update_region_bootstrap`` (integrator.py:375-415): sets
     ``region.maxradiussq`` and ``region.enlarge`` and returns them."""
     assert nbootstraps > 0, nbootstraps
-    r, f = sharded_enlargement(region, nbootstraps, minvol=minvol, rng=rng, group=group)
+    r, f = sharded_enlargement(region, nbootstraps, minvol=minvol, rng=rng, group=group, masks=masks)
     if not (r > 0 and f > 0 and np.isfinite(r) and np.isfinite(f)):
         raise np.linalg.LinAlgError("compute_enlargement failed")
     region.maxradiussq = r

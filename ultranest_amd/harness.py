@@ -10,7 +10,7 @@ import gc
 import numpy as np
 
 from . import distributed
-from .layers import single_blas_thread
+from .layers import host_worker, single_blas_thread
 from .mlfriends import LocalAffineLayer, MLFriends, WrappingEllipsoid, find_nearby, int_dtype
 
 
@@ -56,8 +56,8 @@ class RegionUpdater(object):
             self._device_rebuild = device_rebuild.DeviceRebuild()
         return True
 
-    def _bootstrap(self, region, nbootstraps, minvol):
-        return distributed.update_region_bootstrap(region, nbootstraps, minvol, group=self.group)
+    def _bootstrap(self, region, nbootstraps, minvol, masks=None):
+        return distributed.update_region_bootstrap(region, nbootstraps, minvol, group=self.group, masks=masks)
 
     def _revalidate_radius(self, active_u, nbootstraps, minvol):
         """Radius was invalidated (driver sets maxradiussq = None, :2827): bootstrap it again on
@@ -109,8 +109,21 @@ class RegionUpdater(object):
                     nxt_layer = self.transformLayer.create_new(active_u, self.region.maxradiussq, minvol=minvol)
                     assert not (nxt_layer.clusterids == 0).any()
                     _, sizes = np.unique(nxt_layer.clusterids, return_counts=True)
-                    nxt = self.region_class(active_u, nxt_layer)
-                    self._bootstrap(nxt, nbootstraps, minvol)      # starts create_ellipsoid's host LAPACK on the worker thread
+                    # the bootstrap's selection masks are drawn on the worker thread (the compiled walk of numpy's MT19937
+                    # stream: 0.2 ms for 30 x 4000 draws) while this thread builds the region object (its `transform` product and
+                    # range checks: 0.7 ms).  Nothing between here and the bootstrap touches np.random, so the draws are the ones
+                    # the reference's order makes; if the constructor raises, the generator is put back where it was
+                    rng_state = np.random.get_state()
+                    draw = host_worker().submit(_draw, len(active_u), nbootstraps)
+                    try:
+                        nxt = self.region_class(active_u, nxt_layer)
+                    except BaseException:
+                        try:
+                            draw.result()
+                        finally:
+                            np.random.set_state(rng_state)
+                        raise
+                    self._bootstrap(nxt, nbootstraps, minvol, masks=draw.result())   # starts create_ellipsoid's host LAPACK on the worker thread
                     nxt.create_ellipsoid(minvol=minvol)
                     contains_live = nxt.inside(active_u).all()
                 sensible = nxt_layer.nclusters < len(nxt.u) and sizes.max() >= nxt.u.shape[1]

@@ -364,10 +364,26 @@ class LocalAffineLayer(AffineLayer):
         # The reference clusters first and subtracts the neighbour means second (:843-848); the two do not depend on each
         # other and draw no random numbers.  Here the host product of `transform` (0.3 ms at N = 4000, d = 50) runs on
         # the worker thread while this one waits for the GPU's neighbour pass; same calls, same inputs, same results.
+        # Round 5: the new layer's own host work -- `optimize`: np.cov, eigh, two inverses, slogdet: 0.8 ms -- needs the
+        # neighbour means but not the cluster labels, so it follows `transform` on the worker thread while this one waits for
+        # the GPU's all-pairs clustering pass (0.5 ms): the labels are attached afterwards (an error of either side surfaces
+        # here, in the reference's order: clustering first).
         uwpoints = self.wrap(upoints)
-        job = host_worker().submit(_call_with_errstate, np.geterr(), self.transform, upoints)
+        errstate = np.geterr()
+        job = host_worker().submit(_call_with_errstate, errstate, self.transform, upoints)
         local = kernels.subtract_nearby(uwpoints, maxradiussq)
-        nclusters, ids, _ = update_clusters(uwpoints, job.result(), maxradiussq, self.clusterids)
-        nxt = self.__class__(nclusters=nclusters, wrapped_dims=self.wrapped_dims, clusterids=ids)
-        nxt.optimize(upoints, local, minvol=minvol)
+        nxt = self.__class__(nclusters=1, wrapped_dims=self.wrapped_dims)
+        opt_job = host_worker().submit(_call_with_errstate, errstate, nxt.optimize, upoints, local, None, minvol)
+        try:
+            nclusters, ids, _ = update_clusters(uwpoints, job.result(), maxradiussq, self.clusterids)
+        except BaseException:
+            opt_job.cancel()
+            try:
+                opt_job.result()       # never leave the worker running behind an exception of this thread
+            except BaseException:
+                pass
+            raise
+        opt_job.result()
+        nxt.nclusters = nclusters
+        nxt.set_clusterids(clusterids=ids, npoints=len(upoints))
         return nxt
