@@ -69,7 +69,9 @@ def test_device_resident_rebuild_matches_default(n, d, layer_name, blobs):
     # binary32 value or one of its neighbours (north_star: 1e-10 on radii -- met up to the one rounding the reference's
     # own `cdef float` return applies, mlfriends.pyx:188, 224)
     _equal_or_adjacent_binary32(ra.maxradiussq, rb.maxradiussq)
-    assert abs(ra.enlarge - rb.enlarge) <= 1e-9 * ra.enlarge
+    # the factor comes from the same device kernel on the same points and draws in both paths (measured: identical,
+    # scripts/enlargement_tolerance_probe.py); north_star's class for it is 1e-10
+    assert abs(ra.enlarge - rb.enlarge) <= 1e-12 * ra.enlarge
     assert np.allclose(ra.ellipsoid_center, rb.ellipsoid_center, **tol)
     assert np.allclose(ra.ellipsoid_cov, rb.ellipsoid_cov, **tol)
     assert np.allclose(ra.ellipsoid_invcov, rb.ellipsoid_invcov, rtol=1e-8, atol=1e-8 * np.abs(ra.ellipsoid_invcov).max())
@@ -117,7 +119,7 @@ def test_device_resident_rebuild_against_the_reference_generations(lname, golden
     device-resident path against the recorded next layer -- cluster count and ids exactly, centre / covariance / log volume
     scale to 1e-10, T through what it generates -- and the region it builds, bootstrapped with the SAME draws the
     recording used for the next generation (RandomState(77 + gen + 1): the global stream seeded alike), against the
-    recorded radius (equal or adjacent binary32) and enlargement (1e-9)."""
+    recorded radius (equal or adjacent binary32) and enlargement (1e-10: north_star's class; measured 7e-16)."""
     import ultranest_amd.mlfriends as M
     from ultranest_amd import device_rebuild
     g = golden("g456_region")
@@ -143,6 +145,6 @@ def test_device_resident_rebuild_against_the_reference_generations(lname, golden
         if gen == 1:                                   # generation 2's (r, f) were recorded on THIS layer with these draws
             r_next, f_next = (float(v) for v in g["g5_%s2_r_f" % lname])
             _equal_or_adjacent_binary32(region.maxradiussq, r_next)
-            assert abs(region.enlarge - f_next) <= 1e-9 * f_next
+            assert abs(region.enlarge - f_next) <= 1e-10 * f_next     # measured against the reference's recording: 7e-16
         assert contains
         layer = nxt
