@@ -110,7 +110,9 @@ def hbm_probe_ceiling(achieved_gbps):
                 "copy" if r["variant"].startswith("copy") else "read_plus_11_32_write")
         best[kind] = max(best.get(kind, 0.0), float(r["GBps"]))
     return {"source": "profiles/r05_hbm_stream_probe.json (float4 / LDS-DMA streaming kernels over the same 400 MB, best of the grid sizes)",
-            "GBps": best, "this_kernel_over_measured_copy": achieved_gbps / best["copy"] if best.get("copy") else None}
+            "GBps": best, "this_kernel_over_measured_copy": achieved_gbps / best["copy"] if best.get("copy") else None,
+            "this_kernel_over_the_probe_with_its_own_mix": (achieved_gbps / best["read_plus_11_32_write"])
+            if best.get("read_plus_11_32_write") else None}
 
 
 def host_api(region, pts_dev):
