@@ -58,7 +58,7 @@ def timed_inside(handle, pts, reps=5):
 
 def prep_kernel(d):
     return ("k_prep4 (split-binary16 matrix cores, bounded)" if d <= 64 else
-            "k_prep (binary64 vector form: einsum-order quadratic form + fma-chain whitening)" if d <= 128 else
+            "k_prep_mfma64 (bounded quadratic form + whitening chain on the FP64 matrix cores, matrices streamed from L2)" if d <= 128 else
             "k_prep_wide (run-time dimensionality, mlf_wide.hip)")
 
 

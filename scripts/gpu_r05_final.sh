@@ -47,6 +47,11 @@ d=json.load(open('gpurun_out/rebuild_modes.json'))
 print({k: v.get('median_ms') for k, v in d.items() if isinstance(v, dict)})
 PY
 echo "== config bench"; timeout 1200 python scripts/config_bench.py > $O/config_bench.json 2> $O/config_bench.err; tail -2 $O/config_bench.err | cut -c1-200
+echo "== kernel trace of the d = 100 configuration"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05_d100_stats -o st -- python $R/scripts/config_bench.py C5-at-d100 > $O/r05_d100.log 2>&1
+cp $(find $O/r05_d100_stats -name "*kernel_stats.csv" | head -1) $O/r05_d100_kernel_stats.csv; head -8 $O/r05_d100_kernel_stats.csv | cut -c1-160
+cd $R
 echo "== end-to-end runs"; timeout 900 python scripts/e2e_run.py > $O/e2e_run.log 2>&1; tail -4 $O/e2e_run.log | cut -c1-700
 echo "== 8 ranks on this box's single device over gloo (rehearsal of the driver's multi-GPU pass: rendezvous, barriers, collectives)"
 timeout 900 python bench.py --gpus 8 --scaling strong --steps 5 --warmup 2 --no-cpu > $O/bench_8rank_selfspawn_gloo.json 2> $O/bench_8rank.err; python - <<'PY'

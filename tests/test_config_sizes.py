@@ -168,7 +168,11 @@ def test_c5_full_size_filter_equals_exact_scan(case, fuzz_draws):
                                        ("binary64 per-proposal stage", {"prep_bounded": 0}),
                                        ("single sweep", {"filter_phases": 0}),
                                        ("storage order of the mask-mode operand, first range 50 %", {"filter_order": 0, "filter_first_range_pct": 50}),
-                                       ("first range 15 %", {"filter_first_range_pct": 15})])
+                                       ("first range 15 %", {"filter_first_range_pct": 15}),
+                                       ("unfused per-proposal stage (k_prep + k_quant_queries)", {"fused_prep": 0}),
+                                       ("per-tile band test, wide later range", {"sweep_min": 0, "filter_narrow_tail": 0}),
+                                       ("single sweep in 512-wave tile ranges", {"filter_phases": 0, "filter_split_waves": 512}),
+                                       ("three ranges, per-tile band test", {"filter_phases": 3, "sweep_min": 0})])
 def test_c5_full_size_optional_routings(name, opts, fuzz_draws):
     """The routings that are off by default (k_prep_sweep; k_sweep with its own re-check; k_prep3; one sweep over all tiles; round
     4's order of the live points and share of the first range; a short first range) on a full-size batch, against the default
@@ -183,7 +187,7 @@ def test_c5_full_size_optional_routings(name, opts, fuzz_draws):
     pts[5::1000] = u[rs.randint(N, size=len(pts[5::1000]))]
     default = region.inside(pts)
     restore = {"fused_first_range": 0, "sweep_min": 1, "prep_bounded": 1, "filter_phases": 1, "filter": 1, "filter_order": 1,
-               "filter_first_range_pct": 30}
+               "filter_first_range_pct": 30, "fused_prep": 1, "filter_narrow_tail": 1, "filter_split_waves": 2048}
     try:
         for k, v in opts.items():
             _lib.set_option(k, v)

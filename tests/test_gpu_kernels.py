@@ -525,9 +525,10 @@ def test_wide_bootstrap_radius_and_moments_vs_oracle(d, K, oracle):
         np.testing.assert_allclose(covs[b], np.cov(sel, rowvar=0), rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("d", [129, 200, 256])
+@pytest.mark.parametrize("d", [65, 72, 80, 100, 127, 128, 129, 200, 256])
 def test_wide_region_inside_vs_oracle(d, K, oracle):
-    """H3 + T1 + R3 above 128 dimensions: quadratic form in the einsum order and the whitening chain bit for bit, the
+    """H3 + T1 + R3 above 64 dimensions (65 ... 128: the FP64 matrix-core stage of mlf_prep64.hip in front of the f16 sweep with
+    K up to 144 columns; above 128: mlf_wide.hip): quadratic form in the einsum order and the whitening chain bit for bit, the
     membership mask of a device-resident region (live points whitened on the device) equal to the oracle's, small calls
     (which take the single-launch path below 129 dimensions) included, a live point replaced in place"""
     rs = np.random.RandomState(9200 + d)
@@ -555,10 +556,66 @@ def test_wide_region_inside_vs_oracle(d, K, oracle):
     assert 0 < want.sum() < p
     assert np.array_equal(reg.inside(pts[:10]), want[:10])          # 10 host points: no single-launch path up here
     assert reg.inside(u).all()
+    from ultranest_amd import _lib
+    for name, opts in (("exact scan only", {"filter": 0}), ("vector per-proposal stage", {"fused_prep": 0})):
+        for k_, v_ in opts.items():
+            _lib.set_option(k_, v_)
+        try:
+            assert np.array_equal(reg.inside(pts), want), name
+        finally:
+            for k_ in opts:
+                _lib.set_option(k_, 1)
     un2 = tl.copy()
     un2[7] = t[1]
     reg.update_point(7, pts[1])
     assert np.array_equal(reg.inside(pts), oracle.region_inside(pts, un2, ctr, T, ctr, inv, 2.0 * d, r2))
+    reg.close()
+
+
+@pytest.mark.parametrize("d", [70, 100, 128])
+def test_prep64_proposals_on_the_ellipsoid_boundary_and_wrapped_axes(d, K, oracle):
+    """the bounded quadratic form of mlf_prep64.hip must hand every proposal inside its band to the einsum-order evaluation:
+    proposals placed ON the ellipsoid (q within a few ulp of the enlargement, both sides), and a layer with wrapped axes"""
+    rs = np.random.RandomState(9400 + d)
+    n, p = 300, 4000
+    u = 0.5 + 0.05 * rs.normal(size=(n, d))
+    ctr = u.mean(axis=0)
+    cov = np.cov(u, rowvar=0) * (d + 2) + 1e-6 * np.eye(d)
+    ev, evec = np.linalg.eigh(cov)
+    T = evec * ev ** -0.5
+    inv = np.linalg.inv(cov)
+    enlarge = 1.7
+    z = rs.normal(size=(p, d))
+    pts = ctr + z * 0.05
+    # scale every second proposal onto the boundary: q(x) = enlarge up to rounding
+    dl = pts - ctr
+    q = np.einsum('ij,jk,ik->i', dl, inv, dl)
+    scale = np.sqrt(enlarge / q)
+    scale[1::2] *= 1.0 + rs.uniform(-3e-16, 3e-16, size=len(scale[1::2]))
+    pts[::1] = ctr + dl * np.where(np.arange(p) % 4 < 2, scale, 1.0)[:, None]
+    emask_o = oracle.inside_ellipsoid(pts, ctr, inv, enlarge)
+    assert 0.2 < emask_o.mean() < 0.9
+    tl = K.affine_transform(u, ctr, T)
+    reg = K.DeviceRegion()
+    reg.set(u, 0, ctr, T, None, ctr, inv, enlarge, 1e300, live_space=1)      # radius huge: the mask IS the ellipsoid test
+    assert np.array_equal(reg.inside(pts), emask_o)
+    # wrapped axes: the proposals' wrap happens inside the stage
+    shift = np.full(d, np.nan)
+    shift[[0, 3, d - 1]] = [0.3, 0.9, 0.55]
+    def wrapped(x):      # the wrap of circular axes (mlfriends.pyx:529-536), then the plain chain
+        w = np.array(x, dtype=float)
+        for k_, sh in enumerate(shift):
+            if sh == sh:
+                w[:, k_] = np.fmod(w[:, k_] + sh, 1.0)
+        return w
+    tl_w = oracle.affine_transform(wrapped(u), ctr, T)
+    dd = ((tl_w[:100, None, :] - tl_w[None, :100, :]) ** 2).sum(axis=2)
+    np.fill_diagonal(dd, np.inf)
+    r2 = float(np.quantile(dd.min(axis=1), 0.8))
+    reg.set(tl_w, 0, ctr, T, shift, ctr, inv, 3.0, r2)
+    pts2 = inputs.proposal_mix(9500 + d, u, 3000, shell_q=2.0)
+    want = oracle.inside_ellipsoid(pts2, ctr, inv, 3.0) & (oracle.find_nearby(tl_w, oracle.affine_transform(wrapped(pts2), ctr, T), r2) >= 0)
+    assert np.array_equal(reg.inside(pts2), want)
     reg.close()
 
 

@@ -17,6 +17,7 @@
 #include "mlf_small.hpp"
 #include "mlf_prep3.hpp"
 #include "mlf_prep4.hpp"
+#include "mlf_prep64.hpp"
 #include "mlf_sample.hpp"
 
 namespace {
@@ -1298,6 +1299,32 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
       }
     }
     CK(launch_prep3(pa, s));
+  } else if (r->layer_kind == 0 && prep64_usable(r->d) && r->chol_ready && r->chol_ok && opt(r->filter, OPT_FUSED_PREP)) {
+    // 65 ... 128 dimensions: the bounded quadratic form and the whitening chain on the FP64 matrix cores, the matrices streamed
+    // from L2 (mlf_prep64.hip; rounds 1-4: the vector kernel below, 4-6 ms per 10^6 x 100)
+    Prep64Args pa{};
+    pa.pts = d_pts;
+    pa.np = (long long)np;
+    pa.d = r->d;
+    pa.dp = r->dp;
+    pa.ell_ctr = r->ell_ctr.as<double>();
+    pa.ell_L = r->ell_L.as<double>();
+    pa.ell_A = r->ell_A.as<double>();
+    pa.lda = r->dp;
+    pa.ell_eps_scale = r->ell_eps_scale;
+    pa.chol_ok = 1;
+    pa.enlarge = r->enlarge;
+    pa.gate = gate;
+    if (r->use_scan) {
+      pa.do_tr = 1;
+      pa.lay_ctr = r->lay_ctr.as<double>();
+      pa.T8 = r->lay_T8.as<double>();
+      pa.ldt8 = (r->dp + 7) / 8 * 8;
+      pa.wrap_shift = r->has_wrap ? r->wrap.as<double>() : nullptr;
+      pa.t_out = r->tq.as<double>();
+      pa.ldt = r->d;
+    }
+    CK(launch_prep64(pa, s));
   } else {
     PrepArgs pa{};
     pa.pts = d_pts;
@@ -2035,6 +2062,12 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
     r->chol_ok = ok && std::isfinite(fro);
     r->ell_eps_scale = std::ldexp(1.0, -34) * std::sqrt(fro);
     if (int rc = upload(r->ell_Lt, Lt.data(), Lt.size() * sizeof(double), c.stream)) return rc;
+    if (prep64_usable((int)d) && ok) {   // 65 ... 128 dimensions: the factor itself, row-major (mlf_prep64.hip reads its rows)
+      std::vector<double> lrm((size_t)dp * dp, 0.0);
+      for (size_t j = 0; j < d; ++j)
+        for (size_t k = 0; k <= j; ++k) lrm[j * dp + k] = L[j * d + k];
+      if (int rc = upload(r->ell_L, lrm.data(), lrm.size() * sizeof(double), c.stream)) return rc;
+    }
     if (prep3_usable((int)d)) {   // the same factor as 16 x 4 matrix-core fragments: (row kb, k j) = L[j][kb]
       std::vector<double> frag(prep3_fragment_count((int)d));
       prep3_fragments(L.data(), (int)d, true, true, frag.data());
