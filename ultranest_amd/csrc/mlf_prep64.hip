@@ -189,16 +189,18 @@ hipError_t launch_prep64(const Prep64Args &a, hipStream_t s) {
   long long wgs = (ntiles + kP64Waves - 1) / kP64Waves;
   if (wgs > 256 * 8) wgs = 256 * 8;   // grid-stride beyond 8 workgroups per CU
   const dim3 grid((unsigned)wgs), block(64 * kP64Waves);
-  if (lds > 48 * 1024) {   // above the default grant (66 KB at d = 128)
-    static std::atomic<int> granted{0};
-    if (!granted.load(std::memory_order_acquire)) {
-      hipError_t e = hipSuccess;
+  if (lds > 48 * 1024) {   // above the default grant (66 KB at d = 128): the attribute belongs to (function, device)
+    static std::atomic<int> granted_device{-1};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (granted_device.load(std::memory_order_acquire) != dev) {
       e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_mfma64<20>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_mfma64<24>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_mfma64<28>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_mfma64<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       if (e != hipSuccess) return e;
-      granted.store(1, std::memory_order_release);
+      granted_device.store(dev, std::memory_order_release);
     }
   }
   // instances by k-steps: dp is a multiple of 16 above 64 (80, 96, 112, 128)

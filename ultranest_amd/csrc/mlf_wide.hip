@@ -19,7 +19,6 @@
 //   k_subtract_wide    K3 pass 2 (_subtract_nearby :100-109): one wave per point, neighbours in ascending order
 //   k_boot_mean_wide / k_boot_cov_wide   moments of the selected rows (bounding_ellipsoid :426-476; tolerance class)
 #include "mlf_common.hpp"
-#include "mlf_misc.hpp"
 
 #include <math.h>
 
