@@ -352,6 +352,18 @@ def main():
     stage_pass_s, _ = run_steps(nsteps_b, True)
     ncalls, ms_prep, ms_scan, ms_rest = handle.timing_collect()
     assert bool((mask == mask_filter).all().item())
+    # the per-proposal stage rides in the first sweep launch by default (fused_first_range): its own kernel (k_prep4) is
+    # timed in one more pass with the option off, for `roofline_prep` and `kernel_ms.unfused`
+    fused_first = bool(lib_mod.get_option("fused_first_range")) and NDIM % 2 == 0 and NDIM <= 56
+    unfused = None
+    if fused_first and not args.headline_only:
+        lib_mod.set_option("fused_first_range", 0)
+        unfused_pass_s, _ = run_steps(nsteps_b, True)
+        ncalls_u, ms_prep_u, ms_scan_u, ms_rest_u = handle.timing_collect()
+        lib_mod.set_option("fused_first_range", 1)
+        assert bool((mask == mask_filter).all().item()), "the per-proposal stage inside and in front of the first sweep launch disagree"
+        unfused = {"prep": ms_prep_u / max(ncalls_u, 1), "scan": ms_scan_u / max(ncalls_u, 1), "tail": ms_rest_u / max(ncalls_u, 1),
+                   "wall_ms_per_step": unfused_pass_s / nsteps_b * 1e3}
 
     # single-sweep variant of the pre-filter (no compaction between live-point ranges), for the record
     ms_scan_single = None
@@ -524,32 +536,57 @@ def main():
         per_step = max(1, round(nlaunch / max(args.steps, 1)))
         ngroups1 = (NPROPOSALS + 31) // 32
         by_phase = [float(np.mean(launch_ms_list[i::per_step])) for i in range(per_step)] if len(launch_ms_list) else []
-        # the first range's share as the library routes it (filter_run: filter_first_range_pct of the tiles, at least 4 on each side)
+        # the tile ranges as the library cut them for this batch (filter_run / filter_range_cuts)
+        cut, cut2 = stats["range_cuts"]
         first_pct = lib_mod.get_option("filter_first_range_pct")
-        cut = max(4, min(ntiles32 - 4, ntiles32 * first_pct // 100))
-        if per_step == 3:
-            # min-only sweep (mlf_sweepmin.hip): first range over every group, second over the groups left, then the
-            # uncertain queries (sets of 4 groups) once more over all tiles
+        second_pct = lib_mod.get_option("filter_second_range_pct")
+        first_launch = None
+        if per_step in (3, 4) and cut:
+            # min-only sweep (mlf_sweepmin.hip): first range over every group, the later ones over the groups left after the
+            # compaction in front of them, then the uncertain queries (sets of 4 groups) once more over all tiles
+            nranges = per_step - 1
+            assert (cut2 > 0) == (nranges == 3), (per_step, stats)
+            tiles = [cut, cut2 - cut, ntiles32 - cut2] if cut2 else [cut, ntiles32 - cut]
+            groups = [ngroups1, stats["second_range_groups"], stats.get("third_range_groups", 0)][:nranges]
             usets = -(-(-(-stats["uncertain_queries"] // 32)) // 4)
-            mfma_per_launch = [ngroups1 * cut * ks, stats["second_range_groups"] * (ntiles32 - cut) * ks, usets * 4 * ntiles32 * ks]
-            names = ["k_sweep_min<4, 4, 2> (first live-point range: running minima only; compacts the proposals without a certain hit, with their minima)",
-                     "k_sweep_min<4, 4, 2> (second range over the proposals left; compacts those whose minimum ended in the band)",
-                     "k_uncertain<4, 4> (the proposals whose minimum ended in the band: all tiles again with their band pairs listed, "
-                     "binary64 whitening, the pairs in the reference's arithmetic; trailing workgroups decide the ellipsoid band)"]
-            dominant = 2            # launches of the dominant kernel (k_sweep_min)
+            mfma_per_launch = [g * t * ks for g, t in zip(groups, tiles)] + [usets * 4 * ntiles32 * ks]
+            first_name = ("k_prep_sweep<50, 4> (per-proposal stage + first live-point range in one launch: the binary16 operand stays in registers; "
+                          "running minima only; compacts the proposals without a certain hit, with their minima)" if fused_first else
+                          "k_sweep_min<4, 4, 2> (first live-point range: running minima only; compacts the proposals without a certain hit, with their minima)")
+            names = [first_name] + ["k_sweep_min<4, 4, 2> (range %d of %d over the proposals left; compacts %s)" %
+                                    (i + 2, nranges, "those whose minimum ended in the band" if i + 2 == nranges else "again, with the minima")
+                                    for i in range(nranges - 1)]
+            names.append("k_uncertain<4, 4> (the proposals whose minimum ended in the band: all tiles again with their band pairs listed, "
+                         "binary64 whitening, the pairs in the reference's arithmetic; trailing workgroups decide the ellipsoid band)")
+            # the launches of k_sweep_min proper: with the per-proposal stage inside the first launch that launch is another
+            # kernel (k_prep_sweep) and is reported on its own below
+            sweep_idx = list(range(1 if fused_first else 0, nranges))
+            if fused_first and by_phase:
+                fl_bytes = NPROPOSALS * (8 * NDIM + 1) + groups[1] * 32 * (ks * 32 + 16)
+                first_launch = {"kernel": first_name, "ms": by_phase[0], "executed_mfma_of_the_sweep_part": mfma_per_launch[0],
+                                "sweep_part_TFLOPs_over_the_whole_launch": mfma_per_launch[0] * MFMA_F16_FLOPS / (by_phase[0] * 1e-3) / 1e12,
+                                "algorithmic_bytes": fl_bytes, "achieved_GBps": fl_bytes / (by_phase[0] * 1e-3) / 1e9,
+                                "frac_of_hbm_peak": fl_bytes / (by_phase[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                "what": "proposals in (binary64) + mask + the compacted set out; the per-proposal stage of a workgroup is HBM-bound, "
+                                        "its sweep part matrix-core-bound, and workgroups in different stages overlap"}
         else:
             tiles = [ntiles32 * (i + 1) // per_step - ntiles32 * i // per_step for i in range(per_step)]
+            if per_step == 2:
+                tiles = [cut, ntiles32 - cut] if cut else tiles
             groups = [ngroups1] + [stats["second_range_groups"]] * (per_step - 1)
             mfma_per_launch = [g * t * ks for g, t in zip(groups, tiles)]
             names = ["k_sweep<4, 4, true, 2> (first live-point range, compacts the undecided proposals)",
                      "k_sweep<4, 2, false, 1> (second range: two query groups per wave)"] if per_step == 2 else None
-            dominant = per_step
-        exec_flops = float(sum(mfma_per_launch[:dominant])) * MFMA_F16_FLOPS
-        launch_ms = float(sum(by_phase[:dominant])) / dominant if by_phase else ms_kernels / max(nlaunch, 1)
+            sweep_idx = list(range(per_step))
+        dominant = len(sweep_idx)
+        exec_flops = float(sum(mfma_per_launch[i] for i in sweep_idx)) * MFMA_F16_FLOPS
+        launch_ms = float(sum(by_phase[i] for i in sweep_idx)) / dominant if by_phase else ms_kernels / max(nlaunch, 1)
         ach = (exec_flops / dominant) / (launch_ms * 1e-3) / 1e12
         allpairs = 2.0 * N_LIVE * NPROPOSALS * (NDIM + 6)
         roofline = {"kernel": ("k_sweep_min (mlf_sweepmin.hip: v_mfma_f32_32x32x16_f16 bound on the pair distances, running minima "
-                               "only; two launches per step, the uncertain proposals go through k_uncertain afterwards)") if per_step == 3 else
+                               "only; %d launches per step%s; the uncertain proposals go through k_uncertain afterwards)" %
+                               (dominant, " behind k_prep_sweep, which carries the per-proposal stage and the first range (first_launch)" if fused_first else ""))
+                              if per_step in (3, 4) else
                               "k_sweep (mlf_sweep.hip: v_mfma_f32_32x32x16_f16 bound on the pair distances, mask mode; two launches per step)",
                     "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / F16_MFMA_PEAK_TFLOPS, "ms_per_launch": launch_ms,
@@ -571,10 +608,12 @@ def main():
                     "equivalent_allpairs_flops_per_step": allpairs,
                     "equivalent_allpairs_TFLOPs": allpairs / (float(sum(by_phase)) * 1e-3) / 1e12 if by_phase else None,
                     "executed_k_columns": kdim, "second_range_groups": stats["second_range_groups"],
-                    "first_range_pct": first_pct, "first_range_tiles": cut, "tiles": ntiles32,
+                    "first_range_pct": first_pct, "second_range_pct": second_pct, "range_cuts_tiles": [cut, cut2], "tiles": ntiles32,
+                    "third_range_groups": stats.get("third_range_groups") if cut2 else None,
+                    "first_launch": first_launch,
                     "mask_operand_order": "nearest to the centre first" if lib_mod.get_option("filter_order") else "storage order",
                     "uncertain_queries": stats.get("uncertain_queries"), "uncertain_pairs": stats.get("uncertain_pairs"),
-                    "note": "achieved = executed matrix-instruction flops of one launch (average of the launches of a step) "
+                    "note": "achieved = executed matrix-instruction flops of one k_sweep_min launch (average of its launches of a step) "
                             "over the average launch duration from hipEvents inside the timed region; pairs skipped by the "
                             "second range are not counted (they are an algorithmic saving)",
                     "traffic": traffic, "traffic_detail": traffic_detail, "hbm": hbm}
@@ -584,6 +623,7 @@ def main():
         roofline["traffic_detail"] = traffic_detail
         roofline["hbm"] = hbm
     # per-proposal stage: row in (8 d), binary16 operand + thresholds + route / slot / best words out
+    prep4_ms = (unfused["prep"] if unfused else None) if fused_first else prep_ms      # k_prep4 in its own launch
     prep_bytes = NPROPOSALS * (8 * NDIM + 2 * kdim + 8 + 1 + 4 + 4 + 1)
     prep_mfma_flops = NPROPOSALS / 32 * 42 * 2.0 * 32 * 32 * 16    # 42 v_mfma_f32_32x32x16_f16 per 32 proposals (d = 50):
     # 3 partial products (hi hi, hi lo, lo hi) x [6 k-steps of the triangular L^T + 8 of T^T]
@@ -616,12 +656,16 @@ def main():
                                         "the device, d x d LAPACK on the host; tolerance class 1e-10 on T, radius, enlargement "
                                         "instead of bit parity (tests/test_device_rebuild.py); N = 1 only",
         "accept_fraction": accept, "ellipsoid_pass_fraction": ell_pass,
-        "kernel_ms": {"prep": prep_ms, "scan": scan_ms, "tail": rest_ms, "scan_single_sweep": ms_scan_single,
+        "kernel_ms": {"prep": prep_ms, "scan": scan_ms, "tail": rest_ms, "unfused": unfused, "scan_single_sweep": ms_scan_single,
                       "prep_fp64": (ms_prep_p3 / max(ncalls_p3, 1)) if not args.headline_only else None,
-                      "keys": {"prep": "per-proposal stage (k_prep4: bounded ellipsoid test + whitening on the matrix cores with split "
-                                       "binary16 operands -> f16 operand; the ellipsoid band is decided by trailing workgroups of the k_uncertain launch)",
-                               "scan": ("k_sweep_min over both live-point ranges + k_uncertain (the proposals whose minimum ended in the band, "
-                                        "incl. their exact whitening)" if filter_on else "k_scan"),
+                      "keys": {"prep": ("nothing of its own: the per-proposal stage runs inside the first sweep launch (k_prep_sweep); the stage event pair brackets an empty interval"
+                                        if fused_first else
+                                        "per-proposal stage (k_prep4: bounded ellipsoid test + whitening on the matrix cores with split "
+                                        "binary16 operands -> f16 operand; the ellipsoid band is decided by trailing workgroups of the k_uncertain launch)"),
+                               "scan": ((("k_prep_sweep (per-proposal stage + first live-point range) + k_sweep_min over the later ranges" if fused_first else
+                                          "k_sweep_min over the live-point ranges") +
+                                         " + k_uncertain (the proposals whose minimum ended in the band, incl. their exact whitening)") if filter_on else "k_scan"),
+                               "unfused": "the same three stages with fused_first_range = 0: k_prep4 in its own launch (prep), k_sweep_min over all ranges + k_uncertain (scan)",
                                "tail": "k_scan tail: what the filter could not take, routing, finalise",
                                "scan_single_sweep": "the scan stage as a single sweep over all live points (filter_phases = 0)",
                                "prep_fp64": "per-proposal stage with the FP64 kernel instead (k_prep3, prep_bounded = 0)"},
@@ -636,14 +680,15 @@ def main():
         "batch_counters": stats,
         "roofline": roofline,
         "roofline_exact_scan": exact_roof,
-        "roofline_prep": {"kernel": "k_prep4<50> (split-binary16 v_mfma_f32_32x32x16_f16 + global_load_lds staging)", "bound": "hbm",
-                          "unit": "GB/s", "achieved": prep_bytes / (prep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
-                          "frac": prep_bytes / (prep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "roofline_prep": None if prep4_ms is None else {"kernel": "k_prep4<50> (split-binary16 v_mfma_f32_32x32x16_f16 + global_load_lds staging)", "bound": "hbm",
+                          "unit": "GB/s", "achieved": prep_bytes / (prep4_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                          "frac": prep_bytes / (prep4_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                           "algorithmic_bytes_per_launch": prep_bytes,
                           "mfma_f16": {"executed_flops_per_launch": prep_mfma_flops,
-                                       "achieved_TFLOPs": prep_mfma_flops / (prep_ms * 1e-3) / 1e12,
+                                       "achieved_TFLOPs": prep_mfma_flops / (prep4_ms * 1e-3) / 1e12,
                                        "peak_TFLOPs": F16_MFMA_PEAK_TFLOPS},
-                          "peak_measured": hbm_probe_ceiling(prep_bytes / (prep_ms * 1e-3) / 1e9),
+                          "peak_measured": hbm_probe_ceiling(prep_bytes / (prep4_ms * 1e-3) / 1e9),
+                          "measured_with": "fused_first_range = 0 (k_prep4 in its own launch: a separate pass; by default the stage rides in k_prep_sweep, roofline.first_launch)" if fused_first else "the default routing",
                           "note": "the stage time includes the launch gap in front of the filter; the matrix work is 13 % "
                                   "of the SIMD time (profiles/); DESIGN.md section 4c"},
         "host_api": hostapi,

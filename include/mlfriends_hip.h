@@ -65,6 +65,13 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *   "filter_phase_min_queries" smaller batches sweep all tiles in one launch
  *   "filter_first_range_pct"   10 ... 90, default 30 (50 until the operand was ordered, "filter_order"): share of the live-point tiles the
  *                              first of two ranges takes
+ *   "filter_second_range_pct"  default 50; 0 ... 90.  Batches of at least "filter_third_range_min_work" run the min-only sweep in THREE
+ *                              ranges: the last starts at this share of the tiles, and the tiles before it are split at
+ *                              "filter_first_range_pct" of them (30 % of 50 %: ranges of 15 %, 35 % and 50 %); the proposals
+ *                              without a certain hit are compacted after each.  0: always two ranges.  Ignored where a range
+ *                              would have fewer than 4 tiles
+ *   "filter_third_range_min_work"  default 100000000: (proposals x 32-row live-point tiles) from which three ranges are used (at
+ *                              N = 4000: 800 000 proposals); below, the third launch and its compaction cost more than the pairs it saves
  *   "filter_order"             1 (default): the mask-mode kernels (MLFriends.inside: any hit decides, mlfriends.pyx:1186-1211) sweep a
  *                              copy of the live points ordered nearest-to-the-centre first, so that the first of two tile
  *                              ranges decides more proposals; 0: storage order.  find_nearby's first-index operand always
@@ -73,9 +80,10 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *   "filter_split_waves"       waves a single-sweep launch over a small batch aims at when it splits the tiles (1-16 ranges)
  *   "fused_prep"               1/0: fused per-proposal stage, or k_prep followed by a separate quantisation
  *   "prep_bounded"             1/0: the bounded matrix-core per-proposal stage (split binary16) or the binary64 one
- *   "fused_first_range"        1: on the min-only path the per-proposal stage runs inside the first sweep launch (k_prep_sweep:
+ *   "fused_first_range"        1 (default): on the min-only path the per-proposal stage runs inside the first sweep launch (k_prep_sweep:
  *                              the binary16 operand never leaves the registers, 256 MB less HBM traffic per 10^6 x 50 batch);
- *                              0 (default): k_prep4, then k_sweep_min -- measured 3 % faster
+ *                              0: k_prep4, then k_sweep_min (the default until the first range became short: with a first range
+ *                              of 30 % and more of the tiles the separate launches were 3 % faster)
  *   "mid_max_queries"          default 2048: batches up to this size (and at least "filter_min_queries") run the per-proposal
  *                              stage, the pre-filter sweep, the re-check and the answers in ONE launch (k_inside_mid); 0 = never
  *   "sweep_min"                1 (default): two-range batches through the min-only sweep (k_sweep_min: running minima only
@@ -429,7 +437,10 @@ int mlf_comm_destroy(void);
  * bounded ellipsoid form could not decide (decided in binary64 by the tail of the re-check launch), out[1] reserved
  * (0), out[2] uncertain pairs listed by the pre-filter, out[3] largest list segment, out[4]
  * list segments, out[5] 32-query groups left for the second live-point range, out[6] (cap > 6) queries whose minimum
- * over all live points ended in the band (the set the min-only sweep hands to its listing pass).  cap >= 6. */
+ * over all live points ended in the band (the set the min-only sweep hands to its listing pass), out[7] (cap > 7)
+ * 32-query groups left for the third range ("filter_second_range_pct"), out[8 ... 15] (cap >= 16) shader-clock stamps of the
+ * stage boundaries of one workgroup of the last launch that records them, out[16], out[17] (cap >= 18) the tile cuts of the last
+ * min-only batch (the second is 0 with two ranges).  cap >= 6. */
 int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap);
 /* Measured issue rate of independent v_add_f64/v_mul_f64 (the non-fused FP64 vector rate that
  * bounds the distance kernels), in Tera-instructions*lanes per second (= TFLOP/s, 1 flop each). */

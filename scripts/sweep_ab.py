@@ -1,7 +1,10 @@
 """A/B of pre-filter options on the C5 membership pipeline: per setting, wall time per step, the event time of every
 matrix-kernel launch, the batch counters, and the mask against the exact scan's.  The settings are cycled `rounds` times
 after a warm-up (the chip's clock settles over the first few hundred launches).
-    python scripts/sweep_ab.py [steps] name=v[,name=v...] [name=v...] ...      (one argument per setting)"""
+    python scripts/sweep_ab.py [steps] name=v[,name=v...] [name=v...] ...      (one argument per setting)
+Environment: MLF_AB_P proposals per batch, MLF_AB_N / MLF_AB_D live points and dimensionality of the region (default: the
+headline's), MLF_AB_R2_SCALE factor on the squared radius (0.2: set N of scripts/config_bench.py, almost no neighbour within
+reach), MLF_AB_ROUNDS passes over the settings."""
 import json
 import os
 import sys
@@ -18,7 +21,10 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 settings = sys.argv[2:] or ["filter_sweep=0", "filter_sweep=1", "filter_sweep=2"]
 rounds = int(os.environ.get("MLF_AB_ROUNDS", "2"))
 dev = torch.device("cuda", 0)
+bench.N_LIVE = int(os.environ.get("MLF_AB_N", bench.N_LIVE))
+bench.NDIM = int(os.environ.get("MLF_AB_D", bench.NDIM))
 u, region = bench.build_region(None)
+region.maxradiussq *= float(os.environ.get("MLF_AB_R2_SCALE", "1"))
 handle = region._dev.sync(region, True)
 P = int(os.environ.get("MLF_AB_P", bench.NPROPOSALS))
 pts = bench.proposals_in_ellipsoid(region, P, 1000, dev)

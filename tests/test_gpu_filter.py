@@ -292,7 +292,10 @@ def test_region_inside_random_shapes_filter_equals_exact_scan(seed, K):
                        ("single sweep", {"filter_phases": 0}), ("wide tail", {"filter_narrow_tail": 0}),
                        ("one launch", {"mid_max_queries": 131072}), ("three launches", {"mid_max_queries": 0}),
                        ("per-tile band test", {"mid_max_queries": 0, "sweep_min": 0}),
-                       ("storage order", {"filter_order": 0}), ("storage order, three launches", {"filter_order": 0, "mid_max_queries": 0})):
+                       ("storage order", {"filter_order": 0}), ("storage order, three launches", {"filter_order": 0, "mid_max_queries": 0}),
+                       ("per-proposal stage in its own launch", {"fused_first_range": 0}),
+                       ("three ranges", {"filter_third_range_min_work": 0}),
+                       ("three ranges, per-proposal stage in its own launch", {"filter_third_range_min_work": 0, "fused_first_range": 0})):
         mid_before = 131072 if request_param_one_launch() else 0
         for k, v in opts.items():
             if k == "filter_order":      # per handle: the next batch rebuilds (or drops) the centre-first operand
@@ -302,7 +305,7 @@ def test_region_inside_random_shapes_filter_equals_exact_scan(seed, K):
         got[name] = reg.inside(pts)
         reg.set_option("filter_order")
         for k, v in (("filter", 1), ("prep_bounded", 1), ("filter_phases", 1), ("filter_narrow_tail", 1), ("sweep_min", 1),
-                     ("mid_max_queries", mid_before)):
+                     ("mid_max_queries", mid_before), ("fused_first_range", 1), ("filter_third_range_min_work", 100000000)):
             _lib.set_option(k, v)
     reg.close()
     wrong = {name: (np.flatnonzero(m != got["exact"])[:5].tolist(), m[np.flatnonzero(m != got["exact"])[:5]].tolist())
@@ -358,6 +361,67 @@ def test_second_range_ignores_stale_slots_of_an_unpadded_last_group(K):
             _lib.set_option("filter", 1)
             assert np.array_equal(got, want), (rnd, d, n, p, np.flatnonzero(got != want)[:5])
     reg.close()
+
+
+def test_three_range_min_sweep_alternates_with_two_ranges(K):
+    """"filter_second_range_pct": the min-only sweep in three ranges (the middle range carries the minima through a
+    second array, the uncertain set lands in the first set's arrays, three slot counters return to zero in the tail).
+    Batches alternate between two and three ranges on one handle, with the per-proposal stage inside the first launch and
+    in front of it, cuts at both ends of what is accepted, and cuts the library ignores; every mask equals the exact
+    scan's (MLFriends.inside, mlfriends.pyx:1186-1211)."""
+    import inputs
+    from ultranest_amd import _lib
+    reg = K.DeviceRegion()
+    rs = np.random.RandomState(91 + FUZZ_OFFSET)
+    _lib.set_option("filter_phase_min_queries", 1024)
+    _lib.set_option("filter_phases", 1)
+    _lib.set_option("mid_max_queries", 0)
+    _lib.set_option("filter_third_range_min_work", 0)
+    try:
+        for d, n, p in ((20, 3000, 9000), (50, 4000, 40001), (5, 700, 3001), (33, 1400, 5000)):
+            u = inputs.live_points(5 + d, n, d)
+            ctr = u.mean(axis=0)
+            cov = np.atleast_2d(np.cov(u, rowvar=0)) * (d + 2)
+            ev, evec = np.linalg.eigh(cov)
+            T = evec * ev ** -0.5
+            inv = np.linalg.inv(cov)
+            tl = (u - ctr) @ T
+            dd = ((tl[:150, None, :] - tl[None, :150, :]) ** 2).sum(axis=2)
+            np.fill_diagonal(dd, np.inf)
+            r2 = float(np.sort(dd.min(axis=1))[100]) * float(rs.uniform(0.7, 1.5))
+            reg.set(u, 0, ctr, T, None, ctr, inv, float(d) * 2.0, r2, live_space=1)
+            pts = inputs.proposal_mix(3 + d, u, p, shell_q=2.0)
+            _lib.set_option("filter", 0)
+            want = reg.inside(pts)
+            _lib.set_option("filter", 1)
+            ntiles = (n + 31) // 32
+            for i, (first, second) in enumerate(((30, 0), (30, 50), (30, 0), (20, 40), (40, 50), (50, 90), (90, 90), (10, 10),
+                                                 (60, 60), (30, 0), (30, 50))):
+                _lib.set_option("filter_first_range_pct", first)
+                _lib.set_option("filter_second_range_pct", second)
+                _lib.set_option("fused_first_range", i % 3 != 1)
+                got = reg.inside(pts)
+                stats = reg.debug_stats()
+                assert np.array_equal(got, want), (d, n, p, first, second, np.flatnonzero(got != want)[:5])
+                c2 = ntiles * second // 100
+                c1 = max(4, c2 * first // 100)
+                three = second > 0 and c1 + 4 <= c2 <= ntiles - 4
+                assert stats["range_cuts"] == ([c1, c2] if three else [max(4, min(ntiles - 4, ntiles * first // 100)), 0]), (first, second, stats)
+                if three:
+                    assert 0 < stats["third_range_groups"] <= stats["second_range_groups"], (first, second, stats)
+        _lib.set_option("filter_third_range_min_work", 100000000)      # the default rule: these batches are too small for a third range
+        _lib.set_option("filter_first_range_pct", 30)
+        _lib.set_option("filter_second_range_pct", 50)
+        assert np.array_equal(reg.inside(pts), want) and reg.debug_stats()["range_cuts"][1] == 0
+    finally:
+        _lib.set_option("filter_phase_min_queries", 64)
+        _lib.set_option("filter_phases", 0 if _MODE["param"] == "single-sweep" else 1)
+        _lib.set_option("mid_max_queries", 131072 if request_param_one_launch() else 0)
+        _lib.set_option("filter_first_range_pct", 30)
+        _lib.set_option("filter_second_range_pct", 50)
+        _lib.set_option("filter_third_range_min_work", 100000000)
+        _lib.set_option("fused_first_range", 1)
+        reg.close()
 
 
 def test_options_are_per_region_handle(K, oracle):

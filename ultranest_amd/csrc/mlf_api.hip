@@ -71,13 +71,15 @@ enum Opt : int {
   OPT_FUSED_FIRST,         // "fused_first_range" 0/1: per-proposal stage and first range of the min-only sweep in one launch (mlf_fused.hip)
   OPT_BOOT_SYM,            // "boot_symmetric" 0/1: whole-range bootstrap passes compute every pair distance once (k_boot_sym)
   OPT_ORDER,               // "filter_order" 0/1: mask-mode operand in storage order / nearest to the centre first (k_ref_rank)
+  OPT_SECOND_RANGE_PCT,    // "filter_second_range_pct" 0 ... 90: min-only sweep in three ranges, the second ending at this share of the tiles (0: two ranges)
+  OPT_THIRD_MIN_WORK,      // "filter_third_range_min_work": three ranges from this many (proposals x 32-row live-point tiles) on
   OPT_COUNT
 };
 const char *const kOptNames[OPT_COUNT] = {"filter", "filter_first_range_pct", "filter_split_waves", "filter_narrow_tail",
                                           "small_path", "fused_prep", "filter_phase_min_queries", "filter_phases",
                                           "time_filter_launches", "prep_bounded", "filter_min_queries", "sweep_min", "mid_max_queries", "fused_first_range",
-                                          "boot_symmetric", "filter_order"};
-long long g_opt[OPT_COUNT] = {1, 30, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 0, 1, 1};
+                                          "boot_symmetric", "filter_order", "filter_second_range_pct", "filter_third_range_min_work"};
+long long g_opt[OPT_COUNT] = {1, 30, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 1, 1, 1, 50, 100000000ll};
 
 struct OptOverrides {
   long long v[OPT_COUNT] = {};
@@ -95,7 +97,9 @@ long long opt_clamp(int id, long long value) {
     case OPT_FIRST_RANGE_PCT: return value < 10 ? 10 : (value > 90 ? 90 : value);
     case OPT_SPLIT_WAVES: return value < 256 ? 256 : (value > 16384 ? 16384 : value);
     case OPT_PHASES: return value < 0 ? 0 : (value > 64 ? 64 : value);
+    case OPT_SECOND_RANGE_PCT: return value < 0 ? 0 : (value > 90 ? 90 : value);
     case OPT_BOOT_SYM: return value < 0 ? 0 : (value > 2 ? 2 : value);
+    case OPT_THIRD_MIN_WORK: return value < 0 ? 0 : value;
     case OPT_PHASE_MIN_QUERIES:
     case OPT_MID_MAX:
     case OPT_MIN_QUERIES: return value;
@@ -116,7 +120,7 @@ struct FilterCtx {
   bool ordered = false;      // refFm / refRm are current
   int order_n = -1;          // the live-set size the permutation was ranked for
   // phased sweep: two compacted query sets (ping-pong)
-  DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png, pmin;
+  DevBuf pqF[2], ptlo[2], pthi[2], pmap[2], png, pmin, pmin2;
   DevBuf mid_rec, mid_meta, mid_arrive;   // one-launch path (mlf_mid.hip): records of the tile ranges, arrival counters
   bool mid_last = false;                  // the last batch took that path (debug_stats)
   bool mid_dirty = false;                 // a launch of that path failed: its self-resetting counters are zeroed before the next batch
@@ -128,6 +132,7 @@ struct FilterCtx {
   DevBuf ell_list, misc;
   unsigned batch_parity = 0;
   size_t last_nsegs = 0;      // list segments of the last filtered batch
+  int last_cut[2] = {0, 0};   // tile cuts of the last min-only batch (second: 0 with two ranges)
   bool ell_pending = false;   // band list of the running call not decided yet (the tail of the re-check launch decides it)
   EllExactArgs ell_args{};
   // (start, stop) event pairs around every k_filter launch of the timed calls
@@ -136,7 +141,7 @@ struct FilterCtx {
   OptOverrides ov;            // per-handle tuning (mlf_region_set_option); the stateless calls' context has none
   void release() {
     DevBuf *b[] = {&stats, &statscratch, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2, &refFm, &refRm, &okeys, &operm,
-                   &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png, &pmin, &mid_rec, &mid_meta, &mid_arrive,
+                   &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png, &pmin, &pmin2, &mid_rec, &mid_meta, &mid_arrive,
                    &ell_list, &misc};
     for (DevBuf *x : b) x->release();
     refs_ready = usable = ordered = false;
@@ -420,7 +425,25 @@ struct ExactSrc {
   const Prep4Args *prep;   // not null: the per-proposal stage has NOT run yet -- the min-only path runs it inside its first launch
 };
 
-// does a batch of nq queries take the two-range min-only path?  (the phase rule of filter_run)
+// does a batch of nq queries take the min-only path?  (the phase rule of filter_run)
+// Tile ranges of the min-only sweep, every range at least 4 tiles.  Two ranges: [0, c1) [c1, ntiles32) with c1 = first_pct of
+// the tiles (c2 = 0).  Three -- batches of at least min_work (proposals x tiles), where the pairs a third range saves outweigh
+// its launch and its compaction: the last range starts at c2 = second_pct of the tiles and [0, c2) is split at first_pct of
+// c2 (30 % of 50 % = 15 %, 50 %: profiles/r05_three_range_ab.jsonl).
+void filter_range_cuts(int ntiles32, long long nq, int first_pct, int second_pct, long long min_work, int *c1, int *c2) {
+  const int cut = (int)((long long)ntiles32 * first_pct / 100);
+  *c1 = cut < 4 ? 4 : (cut > ntiles32 - 4 ? ntiles32 - 4 : cut);
+  *c2 = 0;
+  if (second_pct <= 0 || nq * ntiles32 < min_work) return;
+  const int cut2 = (int)((long long)ntiles32 * second_pct / 100);
+  int a = (int)((long long)cut2 * first_pct / 100);
+  a = a < 4 ? 4 : a;
+  if (cut2 >= a + 4 && cut2 <= ntiles32 - 4) {
+    *c1 = a;
+    *c2 = cut2;
+  }
+}
+
 bool filter_takes_min_path(const FilterCtx &f, long long nq) {
   const int want_phases = (int)opt(f, OPT_PHASES);
   const long long phase_min = opt(f, OPT_PHASE_MIN_QUERIES);
@@ -479,8 +502,10 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       CK(f.pmap[i].reserve((size_t)nqpad * sizeof(int)));
     }
     if (!f.png.p) {   // group counts + the slot counter of the fused compaction (returns to zero by itself: k_phase_finish)
-      CK(f.png.reserve(4 * sizeof(unsigned)));
-      CK(hipMemset(f.png.p, 0, 4 * sizeof(unsigned)));
+      // words: [0] groups after the first range, [1] size of the uncertain set (statistics of the last batch), [2] [3] [4] slot
+      // counters of the compacted sets, [5] groups after the second of three ranges
+      CK(f.png.reserve(8 * sizeof(unsigned)));
+      CK(hipMemset(f.png.p, 0, 8 * sizeof(unsigned)));
     }
   }
   const bool fused = nphase > 1;   // the compaction of the undecided queries rides in the matrix kernel's epilogue
@@ -514,13 +539,19 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
   // launches carry the running minimum only; the queries whose minimum ends in the band are swept once more by
   // k_uncertain (band pairs found, queries whitened, pairs decided in one launch), which also carries the ellipsoid band.
   const bool min_path = fold_finish && out_idx == nullptr && f.ks <= 4 && opt(f, OPT_SWEEP_MIN);
+  // filter_second_range_pct > 0: three ranges (the middle one reads set 0 and writes set 1 with a second array of minima;
+  // the uncertain set then reuses set 0's arrays, which nobody reads any more)
+  int c = 0, c2 = 0;
+  filter_range_cuts(f.ntiles32, nq, (int)opt(f, OPT_FIRST_RANGE_PCT), (int)opt(f, OPT_SECOND_RANGE_PCT), opt(f, OPT_THIRD_MIN_WORK), &c, &c2);
+  const bool min3 = min_path && c2 > c;
   if (xs && xs->prep && !min_path) CK(launch_prep4(*xs->prep, s));   // (the caller's forecast and this routing agree: belt and braces)
   if (min_path) {
     const long long lw = uncertain_blocks();
     CK(f.segcnt.reserve((size_t)(lw + 8) * sizeof(unsigned)));
     CK(f.pmin.reserve((size_t)nqpad * sizeof(int)));
-    const int cut = (int)((long long)f.ntiles32 * opt(f, OPT_FIRST_RANGE_PCT) / 100);
-    const int c = cut < 4 ? 4 : (cut > f.ntiles32 - 4 ? f.ntiles32 - 4 : cut);
+    if (min3) CK(f.pmin2.reserve((size_t)nqpad * sizeof(int)));
+    f.last_cut[0] = c;
+    f.last_cut[1] = min3 ? c2 : 0;
     auto timed = [&](auto &&launch) -> int {
       const bool time_launch = ev_after_filter || opt(f, OPT_TIME_LAUNCHES);
       if (time_launch) {
@@ -574,9 +605,11 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       fu.ccap = m.ccap;
       if (int rc = timed([&] { return launch_prep_sweep(fu, s); })) return rc;
     } else if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, 0), m, s); })) return rc;
-    // second range: set 0 with its minima; the uncertain queries go to set 1
+    // next range: set 0 with its minima.  Two ranges: this is the last, the uncertain queries go to set 1.  Three: the
+    // queries still without a certain hit go to set 1 with their minima, and the last range sweeps those into set 0's arrays
+    const int usrc = min3 ? 0 : 1;   // the set that holds the uncertain queries in the end
     m.tile0 = c;
-    m.tile1 = f.ntiles32;
+    m.tile1 = min3 ? c2 : f.ntiles32;
     m.qF = f.pqF[0].p;
     m.tlo = f.ptlo[0].as<float>();
     m.thi = f.pthi[0].as<float>();
@@ -587,9 +620,27 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     m.ctlo = f.ptlo[1].as<float>();
     m.cthi = f.pthi[1].as<float>();
     m.cmap = f.pmap[1].as<int>();
-    m.cmin = nullptr;
+    m.cmin = min3 ? f.pmin2.as<int>() : nullptr;
     m.ccount = f.png.as<unsigned>() + 3;
-    m.last = 1;
+    m.last = min3 ? 0 : 1;
+    if (min3) {
+      if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, 0), m, s); })) return rc;
+      m.tile0 = c2;
+      m.tile1 = f.ntiles32;
+      m.qF = f.pqF[1].p;
+      m.tlo = f.ptlo[1].as<float>();
+      m.thi = f.pthi[1].as<float>();
+      m.qmap = f.pmap[1].as<int>();
+      m.qmin = f.pmin2.as<int>();
+      m.nslots_dev = f.png.as<unsigned>() + 3;
+      m.cq = f.pqF[0].p;
+      m.ctlo = f.ptlo[0].as<float>();
+      m.cthi = f.pthi[0].as<float>();
+      m.cmap = f.pmap[0].as<int>();
+      m.cmin = nullptr;
+      m.ccount = f.png.as<unsigned>() + 4;
+      m.last = 1;
+    }
     // four query groups per wave here too: with the min-only loop the narrow form (two groups, twice the waves) that paid for
     // k_sweep's second range loses (0.080 against 0.085-0.088 ms; profiles/r04_first_range_ab.jsonl)
     if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, 0), m, s); })) return rc;
@@ -597,10 +648,10 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     UncertainArgs ua{};
     ua.refF = opF;
     ua.ntiles32 = f.ntiles32;
-    ua.qF = f.pqF[1].p;
-    ua.thi = f.pthi[1].as<float>();
-    ua.qmap = f.pmap[1].as<int>();
-    ua.nslots_dev = f.png.as<unsigned>() + 3;
+    ua.qF = f.pqF[usrc].p;
+    ua.thi = f.pthi[usrc].as<float>();
+    ua.qmap = f.pmap[usrc].as<int>();
+    ua.nslots_dev = f.png.as<unsigned>() + (min3 ? 4 : 3);
     ua.pts = xs->pts;
     ua.d = d;
     ua.dp = dp;
@@ -776,7 +827,8 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       if (fold_finish) {
         a.fin_slots = f.png.as<unsigned>() + 2;
         a.fin_groups = f.png.as<unsigned>();   // where k_phase_finish would have left the group count (debug_stats)
-        if (min_path) a.fin_slots2 = f.png.as<unsigned>() + 3;
+        if (min_path) a.fin_slots2 = f.png.as<unsigned>() + (min3 ? 4 : 3);
+        if (min3) a.fin_slots3 = f.png.as<unsigned>() + 3;
       }
     }
     CK(launch_scan(dp, a, s));
@@ -2770,10 +2822,15 @@ int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap) {
     out[4] = n;
   }
   if (f.png.p) {
-    unsigned g[2];
+    unsigned g[6];
     CK(hipMemcpy(g, f.png.p, sizeof g, hipMemcpyDeviceToHost));
     out[5] = g[0];
     if (cap > 6) out[6] = g[1];   // queries of the last min-only batch whose minimum ended in the band (uncertain set)
+    if (cap > 7) out[7] = g[5];   // three ranges: groups that entered the third
+  }
+  if (cap > 17) {
+    out[16] = (unsigned long long)f.last_cut[0];
+    out[17] = (unsigned long long)f.last_cut[1];
   }
   {
     if (cap >= 16 && f.mid_last && f.segcnt.p) {   // k_inside_mid, workgroup (0, 0): stage boundaries

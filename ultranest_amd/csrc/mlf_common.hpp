@@ -79,6 +79,7 @@ struct ScanArgs {
   unsigned *fin_slots;            // optional: slot counter of the fused compaction -- *fin_groups = ceil(it / 32), then zeroed
   unsigned *fin_groups;
   unsigned *fin_slots2;           // optional: slot counter of the uncertain set (mlf_sweepmin.hip) -- fin_groups[1] = its value, then zeroed
+  unsigned *fin_slots3;           // optional: slot counter of the middle set of three ranges -- fin_groups[5] = ceil(it / 32), then zeroed
   long long *out_idx;             // SCAN_FIRST / SCAN_COUNT
   unsigned long long *out_flags;  // SCAN_FLAGS  [nq][ntiles]
   uint8_t *out_mask;              // SCAN_MASK

@@ -44,6 +44,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
       a.fin_groups[1] = *a.fin_slots2;
       *a.fin_slots2 = 0u;
     }
+    if (p0 == 0 && a.fin_slots3) {
+      a.fin_groups[5] = (*a.fin_slots3 + 31u) / 32u;
+      *a.fin_slots3 = 0u;
+    }
     if (p0 >= a.nq) return;
     const bool overflowed = a.counters[1] != 0u;
     int rt[4], b[4];
