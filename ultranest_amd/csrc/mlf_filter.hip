@@ -699,11 +699,28 @@ static hipError_t launch_filter_t(const FilterArgs &a, hipStream_t s) {
 }
 
 int filter_tile_split(int ks, long long ngroups, int ntiles, int target_waves) {
-  const long long waves = filter_wave_count(ks, ngroups);
-  long long k = target_waves / (waves > 0 ? waves : 1);   // default 2048: one round of the resident waves
-  if (k > kFilterMaxSplit) k = kFilterMaxSplit;
-  if (k > ntiles / 4) k = ntiles / 4;   // a wave of a few thousand proposals is latency bound: 4 tiles are 64 dependent matrix instructions
-  return k < 1 ? 1 : (int)k;
+  const long long waves = filter_wave_count(ks, ngroups) > 0 ? filter_wave_count(ks, ngroups) : 1;
+  long long kmax = kFilterMaxSplit;
+  if (kmax > ntiles / 4) kmax = ntiles / 4;   // a wave of a few thousand proposals is latency bound: 4 tiles are 64 dependent matrix instructions
+  if (kmax < 1) kmax = 1;
+  // up to half a round of waves (target_waves resident slots, default 2048: two waves per SIMD): as many ranges as fit ONE round
+  if (target_waves / waves >= 2) return (int)(target_waves / waves > kmax ? kmax : target_waves / waves);
+  // More waves than that used to sweep all tiles each, in one partly filled round (163 840 proposals at N = 4000: 1280 waves
+  // of 125 tiles, 113 us against 76 us for 131 072).  Cost of a split: rounds x (a task's start and end -- 16 KiB of operand,
+  // thresholds, list segment, re-check: about 10 tiles' worth -- plus its tiles), a partly filled last round counted as a
+  // whole one; a larger split has to win 3 % (its extra list segments).  140 000-165 000 proposals: -8 %
+  // (profiles/r05_tile_split_ab.jsonl); from 1408 waves on the choice makes no measurable difference.
+  double best = 0.0;
+  int best_k = 1;
+  for (long long k = 1; k <= kmax; ++k) {
+    const double rounds = (double)((waves * k + target_waves - 1) / target_waves);
+    const double cost = rounds * (10.0 + (double)((ntiles + k - 1) / k));
+    if (k == 1 || cost < best * 0.97) {
+      best = cost;
+      best_k = (int)k;
+    }
+  }
+  return best_k;
 }
 
 // first = first-index mode (k_filter); otherwise the mask-mode sweep (k_sweep, mlf_sweep.hip).  narrow: two query
