@@ -36,12 +36,13 @@ for f in glob.glob(src + "_stats/*kernel_stats.csv"):
         stats[r["Name"][:44]] = float(r["AverageNs"]) * 1e-6
 summary = {}
 for k in sq:
-    if not k.startswith(("void mlf::k_sweep_min", "void mlf::k_uncertain", "void mlf::k_prep4", "void mlf::k_scan", "mlf::k_recheck")):
+    if not k.startswith(("void mlf::k_sweep_min", "void mlf::k_uncertain", "void mlf::k_prep4", "void mlf::k_prep_sweep", "void mlf::k_scan",
+                         "mlf::k_recheck")):
         continue
     a, w = sq[k], wait.get(k, {})
     cycles = a["GRBM_GUI_ACTIVE"] / 8.0                      # per XCD = launch duration in shader cycles
     ms = stats.get(k)
-    fills_the_chip = k.startswith("void mlf::k_sweep_min")   # see the module docstring
+    fills_the_chip = k.startswith(("void mlf::k_sweep_min", "void mlf::k_prep_sweep"))   # see the module docstring
     e = dict(avg_ms_kernel_stats=ms, launch_cycles=cycles if fills_the_chip else None,
              clock_GHz=(cycles / (ms * 1e6)) if (ms and fills_the_chip) else None,
              SQ_INSTS_MFMA=a["SQ_INSTS_MFMA"], SQ_INSTS_VALU=a["SQ_INSTS_VALU"], SQ_INSTS_SALU=a["SQ_INSTS_SALU"],
@@ -73,7 +74,7 @@ for f in glob.glob(src + "_stats/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         stats_calls[r["Name"][:44]] = int(r["Calls"])
 if sweeps:
-    # both ranges run the same instance: its counters are the mean over its launches already
+    # the ranges run the same instance: its counters are the mean over its launches already
     per_launch = sum(sweeps.values()) / len(sweeps)
     per_kernel_all = {k.replace("void mlf::", "").split("(")[0]: v["hbm_bytes_gfx950_corrected"] for k, v in summary.items()
                       if not k.startswith("_") and "hbm_bytes_gfx950_corrected" in v}
@@ -81,7 +82,7 @@ if sweeps:
     step_sum = sum(per_kernel_all[k] * launches.get(k, 1) for k in per_kernel_all)
     json.dump({"hbm_bytes_per_launch": per_launch, "per_kernel_all": per_kernel_all, "launches_per_step": launches,
                "hbm_bytes_per_step_all_kernels": step_sum, "source": os.path.basename(dst) + "_pmc_summary.json",
-               "kernel": "k_sweep_min<4, 4, 2> (both live-point ranges: mean over its launches)",
+               "kernel": "k_sweep_min<4, 4, 2> (its launches of a step -- the ranges behind the first, which rides in k_prep_sweep by default: mean over them)",
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over scripts/stage_profile.py (the bench workload, "
                        "1e6 proposals per step); (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md; per launch, like roofline.achieved"},
               open(os.path.join(os.path.dirname(dst), "pmc_scan_traffic.json"), "w"), indent=1)
