@@ -57,7 +57,8 @@ def timed_inside(handle, pts, reps=5):
 
 
 def prep_kernel(d):
-    return ("k_prep4 (split-binary16 matrix cores, bounded)" if d <= 64 else
+    return ("k_prep4's arithmetic (split-binary16 matrix cores, bounded): inside the first sweep launch (k_prep_sweep) for phased batches of even d <= 56, "
+            "in its own launch (k_prep4) otherwise" if d <= 64 else
             "k_prep_mfma64 (bounded quadratic form + whitening chain on the FP64 matrix cores, matrices streamed from L2)" if d <= 128 else
             "k_prep_wide (run-time dimensionality, mlf_wide.hip)")
 
