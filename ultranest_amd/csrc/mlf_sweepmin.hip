@@ -539,8 +539,17 @@ __global__ __launch_bounds__(512, 1) void k_uncertain(UncertainArgs a) {
     if (a.ell.count) ell_exact_wave(a.ell, lds_u + wv * 64, (blockIdx.x - nsweepblk) * 8 + wv, (gridDim.x - nsweepblk) * 8);
     return;
   }
+  // Every sweeping workgroup writes its own statistics word, and workgroup 0's stamping thread clears the stamp words it will
+  // write: no memset per batch (it was a 5 us fill kernel between the last sweep and this launch).
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a.seg_count[uncertain_stamp_base() + k] = 0u;
+  }
   const long long nslots = (long long)*a.nslots_dev;
-  if ((long long)blockIdx.x * 128 >= nslots) return;   // no set for this workgroup
+  if ((long long)blockIdx.x * 128 >= nslots) {   // no set for this workgroup
+    if (threadIdx.x == 0) a.seg_count[blockIdx.x] = 0u;
+    return;
+  }
   // diagnostics: shader-clock stamps of workgroup 0 at the stage boundaries of its first set (mlf_region_debug_stats)
   unsigned nstamp = 0u;
   auto stamp = [&]() __attribute__((always_inline)) {
@@ -614,7 +623,7 @@ __global__ __launch_bounds__(512, 1) void k_uncertain(UncertainArgs a) {
     listed_total += cnt;
     stamp();
   }
-  if (threadIdx.x == 0) a.seg_count[blockIdx.x] = listed_total;   // statistics (workgroups without a set: zeroed by the launcher's memset)
+  if (threadIdx.x == 0) a.seg_count[blockIdx.x] = listed_total;   // statistics (a workgroup without a set wrote 0 above)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -647,8 +656,6 @@ long long uncertain_blocks() { return 256; }
 
 hipError_t launch_uncertain(int ks, const UncertainArgs &a_in, hipStream_t s) {
   UncertainArgs a = a_in;
-  hipError_t e0 = hipMemsetAsync(a.seg_count, 0, (size_t)(uncertain_blocks() + 8) * sizeof(unsigned), s);
-  if (e0 != hipSuccess) return e0;
   a.nsweepblk = (unsigned)uncertain_blocks();
   const dim3 grid(a.nsweepblk + (a.ell.count ? kEllWaves / 8 : 0u));
   const int ds = a.d | 1;
