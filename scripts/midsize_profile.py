@@ -22,7 +22,10 @@ warm = bench.proposals_in_ellipsoid(region, 262144, 999, dev)
 wmask = torch.empty(262144, dtype=torch.uint8, device=dev)
 for _ in range(200):     # the chip's clock settles over the first tens of milliseconds of load
     handle.inside_dev(warm.data_ptr(), 262144, wmask.data_ptr(), stream)
-for p in sizes:
+# one throw-away pass over the first size: in some processes the first measurement after the warm-up carries a one-time ~60 ms
+# (263-300 us per call at 300 proposals instead of 27; the same size measured again in the same process: 27-28 -- profiles/README)
+first_pass = True
+for p in [sizes[0]] + list(sizes):
     pts = bench.proposals_in_ellipsoid(region, p, 1000, dev)
     mask = torch.empty(p, dtype=torch.uint8, device=dev)
     for _ in range(20):
@@ -34,5 +37,8 @@ for p in sizes:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 200
     st = handle.debug_stats()
+    if first_pass:
+        first_pass = False
+        continue
     print(json.dumps(dict(batch=p, us_per_call=round(dt * 1e6, 2), proposals_per_s=round(p / dt), accept=float(mask.float().mean().item()),
                           stage_cycles=st.get("uncertain_stage_cycles"), stamp7=st.get("stamp7"))), flush=True)
