@@ -101,32 +101,45 @@ constexpr int min_waves(int ks, int qw, int pf) {
   return (qw <= 2 && ks * qw <= 8) ? 4 : (need <= 128 ? 4 : (need <= 168 ? 3 : 2));
 }
 
+// workgroups of a k_sweep_min launch over a compacted set: two rounds of the 512 resident workgroups (two per CU)
+constexpr long long kSweepMinSetGrid = 1024;
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
 template <int KS, int QW, int PF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(min_waves(KS, QW, PF)))) void k_sweep_min(MinArgs a) {
   const int lane = threadIdx.x & 63;
-  const unsigned bidx = blockIdx.x;
-  const long long wave = (long long)bidx * 4 + (threadIdx.x >> 6);
-  const long long g0 = wave * QW;
   const long long nslots = a.nslots_dev ? (long long)*a.nslots_dev : -1;
   const long long ngroups = nslots >= 0 ? (nslots + 31) / 32 : a.ngroups;
   // slots of the compaction: ONE atomic per workgroup (the four waves share the tile order and finish together; one
   // atomic per wave on the same word -- 15 600 of them in 0.1 ms in the second range, where nearly every wave keeps a
   // query or two -- queues up at the L2: measured 0.111 against 0.092 ms for the launch)
   __shared__ unsigned wg_keep[4], wg_base;
-  if (g0 >= ngroups) {   // past the set: nothing to sweep, but the workgroup's two barriers are met
+  // A compacted set's size is known on the device only, so its launch used to carry a workgroup for every 16 groups of the
+  // BATCH: 1 953 at 10^6 proposals, of which a third range fills 510 -- the other 1 443 start, read the count and leave, two
+  // or three rounds of them through the 512 resident slots behind the working ones.  For batches of that size the launcher
+  // caps the grid of such a launch (kSweepMinSetGrid) and a workgroup walks the set with the grid's stride (C5: 0.082 -> 0.080
+  // and 0.0571 -> 0.0567 ms for the two launches); every other launch passes this loop once.
+  for (unsigned bidx = blockIdx.x, pass = 0;; bidx += gridDim.x, ++pass) {
+  if ((long long)bidx * (4 * QW) >= ngroups) break;   // the whole workgroup is past the set
+  if (pass) __syncthreads();                          // wg_keep / wg_base of the pass before are free
+  const long long wave = (long long)bidx * 4 + (threadIdx.x >> 6);
+  const long long g0 = wave * QW;
+  if (g0 >= ngroups) {   // this wave is past the set: nothing to sweep, but the workgroup's two barriers are met
     if (lane == 0) wg_keep[threadIdx.x >> 6] = 0u;
     __syncthreads();
     __syncthreads();
-    return;
+    continue;
   }
+  // (Asking for the operands BEFORE looking at the count -- the arrays are sized for every group of the batch -- saves the
+  // count's round trip in the waves that have work and costs 16 KiB of reads in each of the others: the grid is sized for all
+  // 31 250 groups, a third range holds 8 160: 0.062 against 0.056 ms for that launch.)
 
   const half8 *qF = reinterpret_cast<const half8 *>(a.qF);
   half8 bq[QW][KS];
   float tlo[QW], thi[QW];
-  int run[QW];
+  int run[QW], qnum[QW];
 #pragma unroll
   for (int g = 0; g < QW; ++g) {
     const long long grp = (g0 + g < ngroups) ? g0 + g : ngroups - 1;   // clamp (results discarded)
@@ -143,6 +156,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(min_waves(K
     }
     // the minimum the query brought along from the ranges before (kept by the low half; +inf in the high half)
     run[g] = (a.qmin && have && lane < 32) ? a.qmin[qi] : kPosInf;
+    // the query's number in the batch: asked for here, with the operands (in the epilogue it was a memory round trip at the
+    // end of every wave's life)
+    qnum[g] = have ? (a.qmap ? a.qmap[qi] : (int)qi) : -1;
   }
 
   const int ntl = a.tile1 - a.tile0;
@@ -231,8 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(min_waves(K
     qid[g] = -1;
     qmn[g] = kPosInf;
     if (g0 + g >= ngroups) continue;
-    const long long slot_q = (g0 + g) * 32 + (lane & 31);
-    const long long qi = a.qmap ? (long long)a.qmap[slot_q] : slot_q;
+    const long long qi = qnum[g];
     const int other = __shfl_xor(run[g], 32);
     const int m = run[g] < other ? run[g] : other;                 // both halves hold the query's minimum now
     const float mf = __int_as_float(m);
@@ -284,6 +299,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(min_waves(K
       base += (unsigned)__popc(keepm[g]);
     }
   }
+  }   // walk over the set
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -630,7 +646,13 @@ __global__ __launch_bounds__(512, 1) void k_uncertain(UncertainArgs a) {
 template <int KS, int QW>
 static hipError_t launch_sweep_min_t(const MinArgs &a, hipStream_t s) {
   const long long waves = (a.ngroups + QW - 1) / QW;
-  const dim3 grid((unsigned)((waves + 3) / 4));
+  long long wgs = (waves + 3) / 4;
+  // a compacted set (its size is on the device) of a batch of up to 2 kSweepMinSetGrid x 16 groups (10^6 proposals: 1 953
+  // workgroups): kSweepMinSetGrid workgroups, which walk the set in at most two passes (see the kernel).  Larger batches keep
+  // one workgroup per 16 groups of the batch: there the empty workgroups are a small share of a long launch, and four passes
+  // per workgroup measured 3-5 % slower than the hardware's own dispatch (4 * 10^6 proposals)
+  if (a.nslots_dev && wgs > kSweepMinSetGrid && wgs <= 2 * kSweepMinSetGrid) wgs = kSweepMinSetGrid;
+  const dim3 grid((unsigned)wgs);
   constexpr int PF = (KS * QW >= 12 && KS <= 4) ? 2 : 1;
   hipLaunchKernelGGL((k_sweep_min<KS, QW, PF>), grid, dim3(256), 0, s, a);
   return hipGetLastError();
