@@ -124,6 +124,7 @@ struct FilterCtx {
   DevBuf mid_rec, mid_meta, mid_arrive;   // one-launch path (mlf_mid.hip): records of the tile ranges, arrival counters
   bool mid_last = false;                  // the last batch took that path (debug_stats)
   bool mid_dirty = false;                 // a launch of that path failed: its self-resetting counters are zeroed before the next batch
+  bool png_dirty = false;                 // a phased batch did not reach its scan launch (whose tail returns the slot counters to zero)
   // bounded per-proposal stage (mlf_prep4.hip): ellipsoid band list, per-call counters
   // misc: [0] band proposals, [1] k_ell_exact workgroups done -- both return to zero by themselves (no memset per batch),
   // zeroed once when the buffer is allocated; [2], [3] "a proposal is routed to the exact scan", used alternately by
@@ -506,7 +507,10 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       // counters of the compacted sets, [5] groups after the second of three ranges
       CK(f.png.reserve(8 * sizeof(unsigned)));
       CK(hipMemset(f.png.p, 0, 8 * sizeof(unsigned)));
+    } else if (f.png_dirty) {   // an earlier phased batch failed between its first compaction and its scan launch
+      CK(hipMemsetAsync(f.png.p, 0, 8 * sizeof(unsigned), s));
     }
+    f.png_dirty = true;   // until the scan launch of this batch is queued
   }
   const bool fused = nphase > 1;   // the compaction of the undecided queries rides in the matrix kernel's epilogue
   // mask mode behind the bounded per-proposal stage, single-sweep batches (below ~262144 proposals at N = 4000): the
@@ -834,6 +838,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     CK(launch_scan(dp, a, s));
   }
   CK(hipGetLastError());
+  f.png_dirty = false;
   return 0;
 }
 
