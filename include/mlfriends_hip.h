@@ -64,7 +64,7 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *                              (the compaction rides in the first range's epilogue); n >= 2: n ranges
  *   "filter_phase_min_queries" smaller batches sweep all tiles in one launch
  *   "filter_first_range_pct"   10 ... 90, default 30 (50 until the operand was ordered, "filter_order"): share of the live-point tiles the
- *                              first of two ranges takes
+ *                              first of two ranges takes (with three ranges: its share of the tiles in front of the last range)
  *   "filter_second_range_pct"  default 50; 0 ... 90.  Batches of at least "filter_third_range_min_work" run the min-only sweep in THREE
  *                              ranges: the last starts at this share of the tiles, and the tiles before it are split at
  *                              "filter_first_range_pct" of them (30 % of 50 %: ranges of 15 %, 35 % and 50 %); the proposals
@@ -86,8 +86,8 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *                              of 30 % and more of the tiles the separate launches were 3 % faster)
  *   "mid_max_queries"          default 2048: batches up to this size (and at least "filter_min_queries") run the per-proposal
  *                              stage, the pre-filter sweep, the re-check and the answers in ONE launch (k_inside_mid); 0 = never
- *   "sweep_min"                1 (default): two-range batches through the min-only sweep (k_sweep_min: running minima only
- *                              in the two long launches, the proposals whose minimum ends in the band handled by
+ *   "sweep_min"                1 (default): phased batches through the min-only sweep (k_sweep_min: running minima only
+ *                              in the long launches, the proposals whose minimum ends in the band handled by
  *                              k_uncertain); 0: k_sweep (per-tile band test) followed by the re-check launch
  *   "boot_symmetric"           1 (default): a whole-range mlf_maxradiussq_bootstrap pass over enough live points (>= 1024 tiles
  *                              of 64 x 64 pairs, i.e. n > 2816; d <= 64) computes every pair distance once and uses it for both
