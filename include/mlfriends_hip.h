@@ -32,6 +32,12 @@ extern "C" {
 #define MLF_E_NODEVICE 3    /* no usable gfx950 device                                      */
 #define MLF_E_STATE 4       /* region handle used before mlf_region_set                     */
 
+/* Largest dimensionality of the K1-K5 / H3 / T1 / R3 entry points.  Up to 128 the templated kernels; 129 ... 1024 the
+ * run-time-dimensionality kernels (csrc/mlf_wide.hip: exact binary64 scan only, no matrix-core pre-filter).  Entry points
+ * that stop earlier and say so with MLF_E_DIM: mlf_walkers_create (d <= 128: one wave per walker, lane = coordinate pair),
+ * mlf_col_extent (d <= 128), mlf_bootstrap_factor (d <= 64; above: mlf_bootstrap_moments + mlf_bootstrap_quadmax);
+ * the single-launch small-batch path of mlf_region_inside (up to 256 host proposals) is used for d <= 128 and the batched
+ * pipeline above. */
 #define MLF_MAX_DIM 1024
 
 /* ---- library / device ---------------------------------------------------------------- */
@@ -100,6 +106,10 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  * (so that a caller that reports a routing -- bench.py -- reads it instead of assuming it). */
 int mlf_set_option(const char *name, long long value);
 int mlf_get_option(const char *name, long long *value);
+/* test hook: forget which (kernel, device) pairs hold their dynamic-LDS grant (hipFuncSetAttribute belongs to the pair), so
+ * that the next launch of every kernel grants again -- what a second device would need; *grants_so_far (optional) receives
+ * the number of grants issued by the process up to now. */
+int mlf_debug_forget_grants(unsigned long long *grants_so_far);
 int mlf_option_name(int index, char *buf, size_t buflen);
 
 /* ---- K1: find_nearby -- ultranest/mlfriends.pyx:143-183 -----------------------------------
@@ -208,8 +218,12 @@ int mlf_region_set(mlf_region *r, const double *live, size_t n, size_t d, int li
  * of the binary16 proposal operand; without the hint the rows are fetched back once to find it).  Consumed by the next
  * mlf_region_set of the handle. */
 int mlf_region_hint_live_extent(mlf_region *r, double amax);
-/* per-handle tuning option (see mlf_set_option) */
+/* per-handle tuning option (see mlf_set_option); mlf_region_get_option: the value IN FORCE for this handle (its override, else
+ * the process default) -- what a caller that reports a routing should read.  A changed "filter_order" (process default or
+ * per handle) takes effect with the next mlf_region_set / row replacement / batch of the handle, when the ordered operand is
+ * rebuilt or dropped. */
 int mlf_region_set_option(mlf_region *r, const char *name, long long value, int inherit);
+int mlf_region_get_option(mlf_region *r, const char *name, long long *value);
 /* in-place live point replacement, integrator.py:2753-2754; the row is in the space given by
  * live_space at mlf_region_set */
 int mlf_region_update_point(mlf_region *r, size_t row, const double *live_row);

@@ -156,68 +156,16 @@ def test_c5_full_size_filter_equals_exact_scan(case, fuzz_draws):
         finally:
             _lib.set_option("filter", 1)
         assert np.array_equal(got, want), (case, r2, int((got != want).sum()))
-        assert got[5::1000].mean() > 0.9, got[5::1000].mean()      # copies of live points: distance exactly 0
-        if case == "two-clusters":
-            assert 0.0 < got.mean() < 1.0, got.mean()
-        if case == "r2-edge-lo":
-            assert got.sum() <= len(pts[5::1000]) + 5, got.sum()
-
-
-@pytest.mark.parametrize("name,opts", [("per-proposal stage in its own launch (k_prep4, then three ranges)", {"fused_first_range": 0}),
-                                       ("two ranges", {"filter_second_range_pct": 0}),
-                                       ("two ranges, per-proposal stage in its own launch", {"filter_second_range_pct": 0, "fused_first_range": 0}),
-                                       ("three ranges cut at 8 % and 40 %", {"filter_first_range_pct": 20, "filter_second_range_pct": 40}),
-                                       ("three ranges cut at 45 % and 90 %, per-proposal stage in its own launch",
-                                        {"fused_first_range": 0, "filter_first_range_pct": 50, "filter_second_range_pct": 90}),
-                                       ("per-tile band test", {"sweep_min": 0}),
-                                       ("binary64 per-proposal stage", {"prep_bounded": 0}),
-                                       ("single sweep", {"filter_phases": 0}),
-                                       ("storage order of the mask-mode operand, two ranges, first range 50 %",
-                                        {"filter_order": 0, "filter_first_range_pct": 50, "filter_second_range_pct": 0}),
-                                       ("two ranges, first range 15 %", {"filter_first_range_pct": 15, "filter_second_range_pct": 0}),
-                                       ("unfused per-proposal stage (k_prep + k_quant_queries)", {"fused_prep": 0}),
-                                       ("per-tile band test, wide later range", {"sweep_min": 0, "filter_narrow_tail": 0}),
-                                       ("single sweep in 512-wave tile ranges", {"filter_phases": 0, "filter_split_waves": 512}),
-                                       ("three ranges, per-tile band test", {"filter_phases": 3, "sweep_min": 0})])
-def test_c5_full_size_optional_routings(name, opts, fuzz_draws):
-    """The routings that are off by default (k_prep4 in its own launch; two ranges; other cuts of three ranges; k_sweep with its own
-    re-check; k_prep3; one sweep over all tiles; round 4's order of the live points and share of the first range; a short first
-    range) on a full-size batch, against the default routing and the exact scan: results never depend on options."""
-    from ultranest_amd import _lib
-    z, rad = fuzz_draws
-    P, d = z.shape
-    N = 4000
-    rs = np.random.RandomState(FUZZ_CASES.index(case) + 5 + FUZZ_OFFSET)
-    if case == "tiny-scale":
-        u = 0.5 + 1e-4 * rs.normal(size=(N, d)) * np.linspace(0.2, 3.0, d)
-    elif case == "offset-mixed":
-        u = 0.9 + 0.01 * rs.normal(size=(N, d))
-    elif case == "two-clusters":
-        u = np.where(rs.uniform(size=(N, 1)) < 0.5, 0.3, 0.7) + 0.02 * rs.normal(size=(N, d))
-    else:
-        u = 0.5 + 0.05 * rs.normal(size=(N, d))
-    assert np.logical_and(u > 0, u < 1).all()
-    region = _c5_region(u)
-    pts = _ellipsoid_draws(region, z, rad)
-    if case == "offset-mixed":            # a third of the batch are uniform-cube draws: gated out by the ellipsoid
-        pts[::3] = rs.uniform(size=pts[::3].shape)
-    pts[5::1000] = u[rs.randint(N, size=len(pts[5::1000]))]       # exact copies of live points: distance 0
-    amax = np.abs(region.unormed - region.unormed.mean(axis=0)).max()
-    sigma = 2.0 ** -np.ceil(np.log2(amax))
-    r2_list = [region.maxradiussq]
-    if case == "r2-edge-hi":              # sigma^2 r^2 around 4096: the host-side switch between filter and exact scan
-        r2_list = [3600.0 / sigma**2, 4090.0 / sigma**2, 4100.0 / sigma**2]
-    if case == "r2-edge-lo":              # ... and around 1e-30; only the exact copies can hit
-        r2_list = [3e-30 / sigma**2, 0.5e-30 / sigma**2, 1e-26 / sigma**2]
-    for r2 in r2_list:
-        region.maxradiussq = float(r2)
-        got = region.inside(pts)
-        _lib.set_option("filter", 0)
-        try:
-            want = region.inside(pts)
-        finally:
-            _lib.set_option("filter", 1)
-        assert np.array_equal(got, want), (case, r2, int((got != want).sum()))
+        if case == "baseline":
+            # ... and the CPU oracle itself on a 200 000-row slice of the SAME full-size batch (strided, so that the slice
+            # crosses every workgroup / compaction set of the batch): the filtered mask of a 10^6 batch is then pinned to
+            # the oracle inside pytest, not only to the HIP exact scan (~4 s of one host core)
+            from oracle import oracle as orc
+            layer = region.transformLayer
+            sl = slice(3, None, 5)
+            want_o = orc.region_inside(np.ascontiguousarray(pts[sl]), region.unormed, layer.ctr, layer.T, region.ellipsoid_center,
+                                       region.ellipsoid_invcov, region.enlarge, region.maxradiussq).astype(bool)
+            assert len(want_o) == 200000 and np.array_equal(got[sl], want_o), int((got[sl] != want_o).sum())
         assert got[5::1000].mean() > 0.9, got[5::1000].mean()      # copies of live points: distance exactly 0
         if case == "two-clusters":
             assert 0.0 < got.mean() < 1.0, got.mean()

@@ -443,6 +443,8 @@ def test_options_are_per_region_handle(K, oracle):
     assert a.filter_info(p)[0] and b.filter_info(p)[0]
     b.set_option("filter", 0)
     assert a.filter_info(p)[0] and not b.filter_info(p)[0], "the override must reach one handle only"
+    # the getter resolves through the handle (mlf_get_option alone reports the process default)
+    assert a.get_option("filter") == 1 and b.get_option("filter") == 0 and _lib.get_option("filter") == 1
     ma, mb = a.inside(pts), b.inside(pts)
     tl = oracle.affine_transform(u, ctr, T)
     want = oracle.inside_ellipsoid(pts, ctr, inv, 40.0) & (oracle.find_nearby(tl, oracle.affine_transform(pts, ctr, T), 1.2) >= 0)
@@ -463,5 +465,41 @@ def test_options_are_per_region_handle(K, oracle):
     assert c.filter_info(p)[0]
     with pytest.raises(ValueError, match="unknown option"):
         c.set_option("no_such_switch", 1)
+    with pytest.raises(ValueError, match="unknown option"):
+        c.get_option("no_such_switch")
     a.close()
     c.close()
+
+
+def test_lds_grants_are_per_device_and_reissued(K, oracle):
+    """hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to (function, DEVICE).  Every kernel instance keeps a bit per
+    device ordinal (csrc/mlf_common.hpp: DeviceGrant); mlf_debug_forget_grants clears them as a second device would find
+    them.  A batch through the > 64 KiB-LDS kernels, `mlf_set_device` again, the grants forgotten, the same batch: the
+    launches must ask again (the counter of issued grants moves) and give the same mask."""
+    import inputs
+    from ultranest_amd import _lib
+    n, d, p = 2000, 20, 300000 if _MODE["param"] == "phased" else 5000
+    u = inputs.live_points(91, n, d)
+    ctr = u.mean(axis=0)
+    cov = np.atleast_2d(np.cov(u, rowvar=0)) * (d + 2)
+    ev, evec = np.linalg.eigh(cov)
+    T = evec * ev ** -0.5
+    inv = np.linalg.inv(cov)
+    pts = inputs.proposal_mix(92, u, p, shell_q=2.0)
+    reg = K.DeviceRegion()
+    reg.set(u, 0, ctr, T, None, ctr, inv, 40.0, 1.1, live_space=1)
+    first = reg.inside(pts)
+    small = reg.inside(pts[:40])          # k_inside_small: its own grant
+    before = _lib.forget_grants()
+    _lib.set_device(0)
+    again = reg.inside(pts)
+    small_again = reg.inside(pts[:40])
+    after = _lib.forget_grants()
+    assert after > before, (before, after)
+    assert np.array_equal(first, again) and np.array_equal(small, small_again)
+    _lib.set_option("filter", 0)
+    try:
+        assert np.array_equal(reg.inside(pts), first)
+    finally:
+        _lib.set_option("filter", 1)
+    reg.close()

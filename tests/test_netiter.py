@@ -8,6 +8,15 @@ import pytest
 
 from golden import inputs
 
+
+
+@pytest.fixture(params=["cpu", pytest.param("gpu-box", marks=pytest.mark.gpu)], autouse=True)
+def where(request):
+    """The bookkeeping is host code (compiled into libmlfriends_hip.so), but harness.StaticNestedSampler uses it on the GPU box:
+    every test of this module runs in BOTH suites (`-m "not gpu"` here, `-m gpu` on the MI355X box), VERDICT r5."""
+    return request.param
+
+
 CASES = [(1001, 40, 900, 10, False), (1002, 400, 4000, 30, False), (1003, 25, 600, 5, True), (1004, 1, 50, 3, False)]
 
 

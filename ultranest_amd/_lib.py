@@ -29,6 +29,8 @@ SIGNATURES = {
     "mlf_synchronize": [],
     "mlf_set_option": [ctypes.c_char_p, ctypes.c_longlong],
     "mlf_get_option": [ctypes.c_char_p, _vp],
+    "mlf_debug_forget_grants": [_vp],
+    "mlf_region_get_option": [_vp, ctypes.c_char_p, _vp],
     "mlf_find_nearby": [_vp, _sz, _vp, _sz, _sz, _dbl, _vp],
     "mlf_count_nearby": [_vp, _sz, _vp, _sz, _sz, _dbl, _vp],
     "mlf_subtract_nearby": [_vp, _sz, _sz, _dbl, _vp],
@@ -217,6 +219,14 @@ def get_option(name):
     v = ctypes.c_longlong(0)
     check(lib().mlf_get_option(name.encode(), ctypes.byref(v)))
     return int(v.value)
+
+
+def forget_grants():
+    """Test hook (mlf_debug_forget_grants): every kernel asks for its dynamic-LDS grant again at its next launch; returns
+    the number of grants the process had issued so far."""
+    n = ctypes.c_ulonglong(0)
+    check(lib().mlf_debug_forget_grants(ctypes.byref(n)))
+    return int(n.value)
 
 
 def draw_selection(rng, npoints, nbootstraps):

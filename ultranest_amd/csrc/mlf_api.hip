@@ -79,6 +79,12 @@ const char *const kOptNames[OPT_COUNT] = {"filter", "filter_first_range_pct", "f
                                           "small_path", "fused_prep", "filter_phase_min_queries", "filter_phases",
                                           "time_filter_launches", "prep_bounded", "filter_min_queries", "sweep_min", "mid_max_queries", "fused_first_range",
                                           "boot_symmetric", "filter_order", "filter_second_range_pct", "filter_third_range_min_work"};
+}  // namespace
+namespace mlf {
+std::atomic<unsigned> g_grant_epoch{0u};
+std::atomic<unsigned long long> g_grant_calls{0ull};
+}  // namespace mlf
+namespace {
 long long g_opt[OPT_COUNT] = {1, 30, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 1, 1, 1, 50, 100000000ll};
 
 struct OptOverrides {
@@ -838,7 +844,9 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     CK(launch_scan(dp, a, s));
   }
   CK(hipGetLastError());
-  f.png_dirty = false;
+  // only a PHASED batch's scan tail (or its k_phase_finish) returns the slot counters to zero: a single-sweep batch that
+  // follows a failed phased one must leave the flag standing for the next phased batch
+  if (nphase > 1) f.png_dirty = false;
   return 0;
 }
 
@@ -1510,6 +1518,20 @@ int mlf_get_option(const char *name, long long *value) {
   const int id = opt_id(name);
   if (id < 0) return fail_arg(MLF_E_BADARG, "unknown option");
   *value = g_opt[id];
+  return 0;
+}
+
+int mlf_region_get_option(mlf_region *r, const char *name, long long *value) {
+  if (!r || !name || !value) return fail_arg(MLF_E_BADARG, "null pointer");
+  const int id = opt_id(name);
+  if (id < 0) return fail_arg(MLF_E_BADARG, "unknown option");
+  *value = opt(r->filter, id);
+  return 0;
+}
+
+int mlf_debug_forget_grants(unsigned long long *grants_so_far) {
+  if (grants_so_far) *grants_so_far = g_grant_calls.load(std::memory_order_relaxed);
+  g_grant_epoch.fetch_add(1u, std::memory_order_acq_rel);
   return 0;
 }
 

@@ -12,7 +12,40 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace mlf {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to (function, DEVICE): a grant made while device 0 was current
+// says nothing about device 1.  One DeviceGrant per kernel instance: a bit per device ordinal, set after the first
+// successful grant on that device; `ensure(f)` runs f() (the hipFuncSetAttribute calls of the instance) once per device.
+// mlf_debug_forget_grants() (tests: a second mlf_set_device on a 1-GPU box must re-grant) starts a new epoch.
+extern std::atomic<unsigned> g_grant_epoch;
+extern std::atomic<unsigned long long> g_grant_calls;   // grants actually issued (statistics for the test)
+struct DeviceGrant {
+  std::atomic<unsigned long long> bits[4];
+  std::atomic<unsigned> epoch;
+  constexpr DeviceGrant() : bits{}, epoch(0u) {}
+  template <class F>
+  hipError_t ensure(F &&grant) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned now = g_grant_epoch.load(std::memory_order_acquire);
+    if (epoch.load(std::memory_order_acquire) != now) {
+      for (auto &w : bits) w.store(0ull, std::memory_order_relaxed);
+      epoch.store(now, std::memory_order_release);
+    }
+    const bool tracked = dev >= 0 && dev < 256;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (tracked && (bits[dev >> 6].load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = grant();
+    if (e != hipSuccess) return e;
+    g_grant_calls.fetch_add(1ull, std::memory_order_relaxed);
+    if (tracked) bits[dev >> 6].fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+  }
+};
 
 constexpr int kWave = 64;
 constexpr int kScanQB = 64;        // queries staged in LDS per scan workgroup

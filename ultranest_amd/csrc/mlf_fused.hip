@@ -486,13 +486,12 @@ hipError_t launch_prep_sweep(const FusedArgs &a, hipStream_t s) {
   case D: {                                                                                                          \
     constexpr size_t lds = F4<D>::LDS;                                                                               \
     static_assert(lds <= 160 * 1024 - 64, "LDS budget");                                                             \
-    static bool attr_set = false;                                                                                    \
-    if (!attr_set) {                                                                                                 \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_sweep<D>),                           \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
-      if (e != hipSuccess) return e;                                                                                 \
-      attr_set = true;                                                                                               \
-    }                                                                                                                \
+    static DeviceGrant grant;                                                                                        \
+    if (hipError_t e = grant.ensure([] {                                                                             \
+          return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_sweep<D>),                               \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+        }))                                                                                                          \
+      return e;                                                                                                      \
     if (a.p.ks != F4<D>::KS) return hipErrorInvalidValue;                                                            \
     hipLaunchKernelGGL((k_prep_sweep<D>), grid, dim3(512), lds, s, a);                                               \
     break;                                                                                                           \

@@ -771,15 +771,11 @@ template <int D>
 static hipError_t launch_inside_mid_t(const MidArgs &a, dim3 grid, hipStream_t s) {
   constexpr size_t lds = M4<D>::LDS;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static std::atomic<int> attr_device{-1};   // the attribute belongs to (function, device): set once per device
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  if (attr_device.load(std::memory_order_acquire) != dev) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_inside_mid<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_device.store(dev, std::memory_order_release);
-  }
+  static DeviceGrant grant;   // the attribute belongs to (function, device): set once per device
+  if (hipError_t e = grant.ensure([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_inside_mid<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      }))
+    return e;
   if (a.ks != M4<D>::KS) return hipErrorInvalidValue;
   hipLaunchKernelGGL((k_inside_mid<D>), grid, dim3(512), lds, s, a);
   return hipGetLastError();

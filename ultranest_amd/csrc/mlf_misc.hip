@@ -1051,12 +1051,10 @@ void launch_loglike(int kind, const double *params, int d, long long n, const do
     }
   }
   const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_loglike),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static DeviceGrant grant;
+  (void)grant.ensure([] {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_loglike), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
   hipLaunchKernelGGL(k_loglike, dim3((unsigned)((n + 127) / 128)), dim3(128), lds, s, kind, params, d, n,
                      aux, sigma, like);
 }

@@ -397,16 +397,16 @@ hipError_t launch_prep3(const Prep3Args &a_in, hipStream_t s) {
   const bool wrap = a.wrap_shift != nullptr;
 #define LAUNCH3(NKV)                                                                                        \
   case NKV: {                                                                                               \
-    static bool attr_set = false;                                                                           \
-    if (!attr_set) {                                                                                        \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep3<NKV, false>),              \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);           \
-      if (e == hipSuccess)                                                                                  \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep3<NKV, true>),                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);                    \
-      if (e != hipSuccess) return e;                                                                        \
-      attr_set = true;                                                                                      \
-    }                                                                                                       \
+    static DeviceGrant grant;                                                                               \
+    if (hipError_t e = grant.ensure([] {                                                                    \
+          hipError_t g = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep3<NKV, false>),          \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);       \
+          if (g == hipSuccess)                                                                              \
+            g = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep3<NKV, true>),                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);                \
+          return g;                                                                                         \
+        }))                                                                                                 \
+      return e;                                                                                             \
     if (wrap)                                                                                               \
       hipLaunchKernelGGL((k_prep3<NKV, true>), dim3((unsigned)grid), dim3(256), lds, s, a);                 \
     else                                                                                                    \

@@ -462,13 +462,12 @@ hipError_t launch_prep4(const Prep4Args &a, hipStream_t s) {
 #define X(D)                                                                                                     \
   case D: {                                                                                                      \
     constexpr size_t lds = P4<D>::lds_bytes();                                                                   \
-    static bool attr_set = false;                                                                                \
-    if (!attr_set) {                                                                                             \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep4<D>),                            \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
-      if (e != hipSuccess) return e;                                                                             \
-      attr_set = true;                                                                                           \
-    }                                                                                                            \
+    static DeviceGrant grant;                                                                                    \
+    if (hipError_t e = grant.ensure([] {                                                                         \
+          return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep4<D>),                                \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+        }))                                                                                                      \
+      return e;                                                                                                  \
     if (a.do_tr && a.ks != P4<D>::KS) return hipErrorInvalidValue;                                               \
     long long grid = (groups + P4<D>::NW - 1) / P4<D>::NW;                                                       \
     if (grid > 256) grid = 256;                                                                                  \
@@ -528,10 +527,11 @@ void launch_recheck_whiten(const RecheckWArgs &a_in, hipStream_t s) {
   if (a_in.nsegs <= 0) return;
   RecheckWArgs a = a_in;
   const size_t lds = recheck_w_lds(a.d);
-  static size_t attr_bytes = 0;
-  if (lds > 48 * 1024 && lds > attr_bytes) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_recheck_whiten), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_bytes = lds;
+  if (lds > 48 * 1024) {   // (not reached for d <= 128: 12 KiB) the whole LDS, once per device
+    static DeviceGrant grant;
+    (void)grant.ensure([] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_recheck_whiten), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    });
   }
   if (a.ell_waves == 0u) a.ell_waves = kEllWaves;
   const unsigned grid = (unsigned)a.nsegs + (a.ell.count ? a.ell_waves : 0u);

@@ -190,18 +190,15 @@ hipError_t launch_prep64(const Prep64Args &a, hipStream_t s) {
   if (wgs > 256 * 8) wgs = 256 * 8;   // grid-stride beyond 8 workgroups per CU
   const dim3 grid((unsigned)wgs), block(64 * kP64Waves);
   if (lds > 48 * 1024) {   // above the default grant (66 KB at d = 128): the attribute belongs to (function, device)
-    static std::atomic<int> granted_device{-1};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (granted_device.load(std::memory_order_acquire) != dev) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_mfma64<20>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_mfma64<24>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_mfma64<28>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_mfma64<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      if (e != hipSuccess) return e;
-      granted_device.store(dev, std::memory_order_release);
-    }
+    static DeviceGrant grant;
+    if (hipError_t e = grant.ensure([] {
+          hipError_t g = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_mfma64<20>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+          if (g == hipSuccess) g = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_mfma64<24>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+          if (g == hipSuccess) g = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_mfma64<28>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+          if (g == hipSuccess) g = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_mfma64<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+          return g;
+        }))
+      return e;
   }
   // instances by k-steps: dp is a multiple of 16 above 64 (80, 96, 112, 128)
   switch (nk) {

@@ -47,6 +47,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(ScanArgs a) {
     if (p0 == 0 && a.fin_slots3) {
       a.fin_groups[5] = (*a.fin_slots3 + 31u) / 32u;
       *a.fin_slots3 = 0u;
+    } else if (p0 == 0 && a.fin_slots2) {   // a two-range batch of the min-only path: no stale third-range statistic
+      a.fin_groups[5] = 0u;
     }
     if (p0 >= a.nq) return;
     const bool overflowed = a.counters[1] != 0u;

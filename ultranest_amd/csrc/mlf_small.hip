@@ -225,12 +225,11 @@ void launch_inside_small(const SmallArgs &a, hipStream_t s) {
   const dim3 grid((unsigned)(a.np * a.wpp));
   if (a.d <= 64) {
     const size_t lds = (size_t)2 * a.d * (a.d | 1) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_inside_small<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(double));
-      attr_set = true;
-    }
+    static DeviceGrant grant;
+    (void)grant.ensure([] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_inside_small<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(double));
+    });
     hipLaunchKernelGGL(k_inside_small<true>, grid, dim3(256), lds, s, a);
   } else {
     hipLaunchKernelGGL(k_inside_small<false>, grid, dim3(256), 0, s, a);

@@ -5,7 +5,7 @@
 namespace mlf {
 
 constexpr int kSmallMaxPoints = 256;   // proposals per call the single-launch path takes
-constexpr int kSmallMaxDim = 128;      // = MLF_MAX_DIM
+constexpr int kSmallMaxDim = 128;      // the templated kernels' range (MLF_MAX_DIM = 1024: above 128 the batched pipeline)
 
 struct SmallArgs {
   const double *pts;      // (np, d) row-major; may be pinned host memory mapped into the device (read once per workgroup)

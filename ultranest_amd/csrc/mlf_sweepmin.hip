@@ -687,13 +687,12 @@ hipError_t launch_uncertain(int ks, const UncertainArgs &a_in, hipStream_t s) {
   if (a.dp > 64 || nch < 1) return hipErrorInvalidValue;
 #define X(KS, NCH)                                                                                                          \
   if (ks == KS && nch == NCH) {                                                                                             \
-    static bool attr_set = false;                                                                                           \
-    if (!attr_set) {                                                                                                        \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_uncertain<KS, NCH>),                             \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
-      if (e != hipSuccess) return e;                                                                                        \
-      attr_set = true;                                                                                                      \
-    }                                                                                                                       \
+    static DeviceGrant grant;                                                                                               \
+    if (hipError_t e = grant.ensure([] {                                                                                    \
+          return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_uncertain<KS, NCH>),                                 \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                               \
+        }))                                                                                                                 \
+      return e;                                                                                                             \
     hipLaunchKernelGGL((k_uncertain<KS, NCH>), grid, dim3(512), lds, s, a);                                                 \
     return hipGetLastError();                                                                                               \
   }

@@ -327,8 +327,10 @@ int rows_per_block(int d) {
 }
 
 // dynamic LDS above the default 64 KB has to be granted per kernel; the grant leaves room for the kernel's static arrays
-hipError_t allow_lds(const void *fn, size_t bytes) {
-  return bytes > 48 * 1024 ? hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) : hipSuccess;
+// (the attribute belongs to (function, device): one DeviceGrant per kernel, asked once per device -- ADVICE r5)
+hipError_t allow_lds(DeviceGrant &grant, const void *fn, size_t bytes) {
+  if (bytes <= 48 * 1024) return hipSuccess;
+  return grant.ensure([fn] { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); });
 }
 
 }  // namespace
@@ -341,7 +343,8 @@ hipError_t launch_scan_wide(int dp, const ScanArgs &a, hipStream_t s) {
   // above 128 dimensions nothing is filtered
   if (a.fin_best || a.route || a.any_flag || a.raw_ctr) return hipErrorInvalidValue;
   const size_t lds = (size_t)kWideQB * dp * sizeof(double);
-  if (hipError_t e = allow_lds(reinterpret_cast<const void *>(&k_scan_wide), lds)) return e;
+  static DeviceGrant grant_k_scan_wide;
+  if (hipError_t e = allow_lds(grant_k_scan_wide, reinterpret_cast<const void *>(&k_scan_wide), lds)) return e;
   const unsigned grid = (unsigned)((a.nq + kWideQB - 1) / kWideQB);
   hipLaunchKernelGGL(k_scan_wide, dim3(grid), dim3(kScanThreads), lds, s, a, dp);
   return hipGetLastError();
@@ -359,7 +362,8 @@ hipError_t launch_prep_wide(int dp, const PrepArgs &a, hipStream_t s) {
   const int pb = rows_per_block(a.d);
   if (pb == 0) return hipErrorInvalidValue;
   const size_t lds = (size_t)pb * a.d * sizeof(double);
-  if (hipError_t e = allow_lds(reinterpret_cast<const void *>(&k_prep_wide), lds)) return e;
+  static DeviceGrant grant_k_prep_wide;
+  if (hipError_t e = allow_lds(grant_k_prep_wide, reinterpret_cast<const void *>(&k_prep_wide), lds)) return e;
   hipLaunchKernelGGL(k_prep_wide, dim3((unsigned)((a.np + pb - 1) / pb)), dim3(pb), lds, s, a, dp);
   return hipGetLastError();
 }
@@ -374,7 +378,8 @@ hipError_t launch_quadmax_wide(int dp, const QuadMaxArgs &a, int B, hipStream_t 
   const int rb = rows_per_block(a.d);
   if (rb == 0) return hipErrorInvalidValue;
   const size_t lds = (size_t)rb * a.d * sizeof(double);
-  if (hipError_t e = allow_lds(reinterpret_cast<const void *>(&k_quadmax_wide), lds)) return e;
+  static DeviceGrant grant_k_quadmax_wide;
+  if (hipError_t e = allow_lds(grant_k_quadmax_wide, reinterpret_cast<const void *>(&k_quadmax_wide), lds)) return e;
   hipLaunchKernelGGL(k_quadmax_wide, dim3((unsigned)((a.n + rb - 1) / rb), (unsigned)B), dim3(rb), lds, s, a, dp);
   return hipGetLastError();
 }

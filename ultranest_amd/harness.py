@@ -113,17 +113,25 @@ class RegionUpdater(object):
                     # stream: 0.2 ms for 30 x 4000 draws) while this thread builds the region object (its `transform` product and
                     # range checks: 0.7 ms).  Nothing between here and the bootstrap touches np.random, so the draws are the ones
                     # the reference's order makes; if the constructor raises, the generator is put back where it was
-                    rng_state = np.random.get_state()
-                    draw = host_worker().submit(_draw, len(active_u), nbootstraps)
-                    try:
-                        nxt = self.region_class(active_u, nxt_layer)
-                    except BaseException:
+                    # -- for THIS package's region classes, whose constructors never touch np.random.  A user-supplied
+                    # region_class may (the reference's duck-typed contract says nothing about it): its constructor runs
+                    # first and the masks are drawn afterwards, on this thread, exactly in the reference's order
+                    if _builtin_region_class(self.region_class):
+                        rng_state = np.random.get_state()
+                        draw = host_worker().submit(_draw, len(active_u), nbootstraps)
                         try:
-                            draw.result()
-                        finally:
-                            np.random.set_state(rng_state)
-                        raise
-                    self._bootstrap(nxt, nbootstraps, minvol, masks=draw.result())   # starts create_ellipsoid's host LAPACK on the worker thread
+                            nxt = self.region_class(active_u, nxt_layer)
+                        except BaseException:
+                            try:
+                                draw.result()
+                            finally:
+                                np.random.set_state(rng_state)
+                            raise
+                        masks = draw.result()
+                    else:
+                        nxt = self.region_class(active_u, nxt_layer)
+                        masks = _draw(len(active_u), nbootstraps)
+                    self._bootstrap(nxt, nbootstraps, minvol, masks=masks)   # starts create_ellipsoid's host LAPACK on the worker thread
                     nxt.create_ellipsoid(minvol=minvol)
                     contains_live = nxt.inside(active_u).all()
                 sensible = nxt_layer.nclusters < len(nxt.u) and sizes.max() >= nxt.u.shape[1]
@@ -163,6 +171,12 @@ class RegionUpdater(object):
             except (FloatingPointError, np.linalg.LinAlgError):
                 self.tregion = None       # on every rank alike
         return updated
+
+
+def _builtin_region_class(cls):
+    """True for the region classes of this package (exact types, not subclasses: a subclass may override __init__)."""
+    from . import regions
+    return cls in (regions.MLFriends, regions.RobustEllipsoidRegion, regions.SimpleRegion, regions.WrappingEllipsoid)
 
 
 def _draw(npoints, nbootstraps):

@@ -270,6 +270,13 @@ class DeviceRegion(object):
         (_lib.set_option).  Results never depend on options."""
         check(_lib.lib().mlf_region_set_option(self._h, name.encode(), 0 if value is None else int(value), int(value is None)))
 
+    def get_option(self, name):
+        """The value of a tuning option IN FORCE for this region: its own override, else the process default
+        (mlf_region_get_option)."""
+        v = ctypes.c_longlong(0)
+        check(_lib.lib().mlf_region_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return int(v.value)
+
     def release(self):
         """hand the handle (and its buffers) to the next region"""
         if self._h:
