@@ -44,6 +44,10 @@ PROBE_F16_MFMA_TFLOPS = 1620.0   # what v_mfma_f32_32x32x16_f16 sustains ALONE o
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F16_FLOPS = 2 * 32 * 32 * 16   # one v_mfma_f32_32x32x16_f16
 CLOCK_SETTLE_STEPS = 100         # untimed steps in front of the W warm-up steps of a timed loop (see run_steps)
+NBATCHES = 3                     # distinct 400 MB proposal batches a timed loop visits in turn (1.2 GB > the 256 MB Infinity Cache)
+PREP_MFMA_PER_GROUP = 42         # v_mfma_f32_32x32x16_f16 of the per-proposal stage per 32 proposals at d = 50: 3 partial products
+# (hi hi, hi lo, lo hi) x [6 k-steps of the triangular L^T (ellipsoid form) + 8 of T^T (whitening)]
+SET_BYTES_PER_SLOT = lambda ks: ks * 32 + 16   # noqa: E731 -- a compacted proposal: K = 16 ks binary16 columns + T_lo, T_hi, index, minimum
 
 
 def build_region(group):
@@ -217,6 +221,179 @@ def cpu_baseline_parallel(region, sample, nproc):
                        % (nproc, len(sample), max(inner), wall))
 
 
+def imported_traffic():
+    """HBM bytes per kernel launch from the PMC counters.  rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE need passes of their own (they
+    cannot be collected inside this run): the figures of the last profiled tree are IMPORTED from profiles/pmc_scan_traffic.json
+    (scripts/collect_pmc.py) and carry the hash of the kernel sources they were measured on; if the library built from THIS tree
+    has another hash the figures are marked stale (a kernel change must not ship with old traffic figures)."""
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_scan_traffic.json")
+    if not os.path.exists(pmc_file):
+        return None
+    pmc = json.load(open(pmc_file))
+    try:
+        from ultranest_amd.csrc import build as _build
+        now = _build.source_hash()
+    except Exception:       # noqa: BLE001
+        now = None
+    then = pmc.get("source_hash")
+    pmc["fresh"] = bool(now and then and now == then)
+    pmc["source_hash_now"] = now
+    pmc["status"] = ("measured on this tree's kernel sources" if pmc["fresh"] else
+                     "STALE: measured on kernel sources with hash %s, this tree has %s" % (then, now))
+    return pmc
+
+
+def step_roofline(handle, stats, kdim, ntiles32, filter_launches, launch_ms_list, steps, fused_first, step_ms, launch_pass_ms,
+                  alg_bytes, pmc, hbm, scan_flops):
+    """The roofline object of the JSON line: every matrix-kernel launch of a step with its time (hipEvents of the launch-event
+    pass), executed matrix instructions, bytes and both fractions; the kernel that takes most of the step named at the top."""
+    ks = kdim // 16
+    nlaunch, ms_kernels = filter_launches
+    per_step = max(1, round(nlaunch / max(steps, 1)))
+    ngroups1 = (NPROPOSALS + 31) // 32
+    by_phase = [float(np.mean(launch_ms_list[i::per_step])) for i in range(per_step)] if len(launch_ms_list) else []
+    cut, cut2 = stats["range_cuts"]       # the tile ranges as the library cut them for this batch
+    slot = SET_BYTES_PER_SLOT(ks)
+    per_kernel_pmc = (pmc or {}).get("per_kernel_all") or {}
+
+    def counter_bytes(prefix):
+        for k, v in per_kernel_pmc.items():
+            if k.startswith(prefix):
+                return v
+        return None
+
+    launches = []
+    if per_step in (3, 4) and cut and len(by_phase) == per_step:
+        # min-only sweep (mlf_sweepmin.hip): first range over every group, the later ones over the groups left after the
+        # compaction in front of them, then the uncertain proposals (sets of 4 groups) once more over all tiles
+        nranges = per_step - 1
+        assert (cut2 > 0) == (nranges == 3), (per_step, stats)
+        tiles = [cut, cut2 - cut, ntiles32 - cut2] if cut2 else [cut, ntiles32 - cut]
+        groups = [ngroups1, stats["second_range_groups"], stats.get("third_range_groups", 0)][:nranges]
+        nunc = stats["uncertain_queries"]
+        usets = -(-(-(-nunc // 32)) // 4)
+        for i in range(nranges):
+            first = i == 0
+            name = "k_prep_sweep<50>" if (first and fused_first) else "k_sweep_min<4, 4, 2>"
+            sweep_mfma = groups[i] * tiles[i] * ks
+            prep_mfma = ngroups1 * PREP_MFMA_PER_GROUP if (first and fused_first) else 0
+            set_in = 0 if (first and fused_first) else groups[i] * 32 * slot
+            set_out = (groups[i + 1] * 32 * slot) if i + 1 < nranges else nunc * slot
+            alg_in = NPROPOSALS * (8 * NDIM + 1) if (first and fused_first) else 0
+            launches.append({
+                "kernel": name,
+                "what": ("per-proposal stage (ellipsoid bound + whitening on the matrix cores, split binary16) AND the first live-point range "
+                         "in one launch; running minima only; compacts the proposals without a certain hit, with their minima" if (first and fused_first)
+                         else "range %d of %d over the proposals left; running minima only; compacts %s" %
+                         (i + 1, nranges, "the proposals whose minimum ended in the band" if i + 1 == nranges else "again, with the minima")),
+                "ms": by_phase[i], "tiles": tiles[i], "groups_of_32_proposals": groups[i],
+                "executed_mfma": prep_mfma + sweep_mfma, "executed_mfma_whitening": prep_mfma, "executed_mfma_sweep": sweep_mfma,
+                "algorithmic_bytes_in": alg_in, "compacted_set_bytes_in": set_in, "compacted_set_bytes_out": set_out,
+                "bytes": alg_in + set_in + set_out, "counter_bytes": counter_bytes(name.split("<")[0])})
+        launches.append({
+            "kernel": "k_uncertain<4, 4>",
+            "what": "the proposals whose minimum ended in the band: all tiles again with their band pairs listed, binary64 whitening, "
+                    "the pairs in the reference's arithmetic; trailing workgroups decide the ellipsoid band",
+            "ms": by_phase[nranges], "tiles": ntiles32, "groups_of_32_proposals": usets * 4,
+            "executed_mfma": usets * 4 * ntiles32 * ks, "executed_mfma_whitening": 0, "executed_mfma_sweep": usets * 4 * ntiles32 * ks,
+            "algorithmic_bytes_in": 0, "compacted_set_bytes_in": nunc * slot, "compacted_set_bytes_out": 0,
+            "bytes": nunc * (slot + 8 * NDIM), "counter_bytes": counter_bytes("k_uncertain")})
+    else:
+        tiles = [ntiles32 * (i + 1) // per_step - ntiles32 * i // per_step for i in range(per_step)]
+        if per_step == 2 and cut:
+            tiles = [cut, ntiles32 - cut]
+        groups = [ngroups1] + [stats["second_range_groups"]] * (per_step - 1)
+        for i in range(min(per_step, len(by_phase))):
+            launches.append({"kernel": "k_sweep<4, %d, ...>" % (4 if i == 0 else 2), "what": "range %d of %d, per-tile band test" % (i + 1, per_step),
+                             "ms": by_phase[i], "tiles": tiles[i], "groups_of_32_proposals": groups[i], "executed_mfma": groups[i] * tiles[i] * ks,
+                             "executed_mfma_whitening": 0, "executed_mfma_sweep": groups[i] * tiles[i] * ks, "algorithmic_bytes_in": 0,
+                             "compacted_set_bytes_in": 0, "compacted_set_bytes_out": 0, "bytes": 0, "counter_bytes": None})
+    for e in launches:
+        sec = e["ms"] * 1e-3
+        e["mfma_TFLOPs"] = e["executed_mfma"] * MFMA_F16_FLOPS / sec / 1e12
+        e["mfma_frac_of_2500"] = e["mfma_TFLOPs"] / F16_MFMA_PEAK_TFLOPS
+        e["GBps"] = e["bytes"] / sec / 1e9
+        e["hbm_frac_of_8000"] = e["GBps"] / HBM_PEAK_GBPS
+        e["share_of_step_time"] = e["ms"] / step_ms
+    # the kernel that takes most of the step (summed over its launches)
+    by_kernel = {}
+    for e in launches:
+        by_kernel[e["kernel"]] = by_kernel.get(e["kernel"], 0.0) + e["ms"]
+    dominant = max(by_kernel, key=by_kernel.get) if by_kernel else None
+    dom = [e for e in launches if e["kernel"] == dominant]
+    dom_ms = float(np.mean([e["ms"] for e in dom])) if dom else None
+    dom_bytes = float(np.mean([e["bytes"] for e in dom])) if dom else 0.0
+    dom_mfma = float(np.mean([e["executed_mfma"] for e in dom])) if dom else 0.0
+    hbm_bound = bool(dominant and dominant.startswith("k_prep_sweep"))
+    ach_hbm = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else None
+    ach_mfma = dom_mfma * MFMA_F16_FLOPS / (dom_ms * 1e-3) / 1e12 if dom_ms else None
+    sweeps = [e for e in launches if e["kernel"].startswith("k_sweep_min")]
+    sweep_entry = None
+    if sweeps:
+        sm_ms = float(np.mean([e["ms"] for e in sweeps]))
+        sm_flops = float(np.mean([e["executed_mfma"] for e in sweeps])) * MFMA_F16_FLOPS
+        sweep_entry = {"kernel": "k_sweep_min<4, 4, 2> (average over its %d launches of a step)" % len(sweeps), "bound": "mfma",
+                       "achieved": sm_flops / (sm_ms * 1e-3) / 1e12, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": sm_flops / (sm_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, "ms_per_launch": sm_ms,
+                       "frac_of_what_the_instruction_sustains_alone_on_random_operands": sm_flops / (sm_ms * 1e-3) / 1e12 / PROBE_F16_MFMA_TFLOPS,
+                       "share_of_step_time": sum(e["ms"] for e in sweeps) / step_ms}
+    mfma_step = float(sum(e["executed_mfma"] for e in launches))
+    step_counter = (pmc or {}).get("hbm_bytes_per_step_all_kernels")
+    fp64 = None
+    if scan_flops:
+        eq = scan_flops / (step_ms * 1e-3) / 1e12
+        fp64 = {"reference_loop_flops_of_this_batch": scan_flops, "flop_per_proposal": scan_flops / NPROPOSALS,
+                "equivalent_TFLOPs_over_the_step": eq, "peak": FP64_VALU_PEAK_TFLOPS, "ratio_to_that_peak": eq / FP64_VALU_PEAK_TFLOPS,
+                "why_above_1": "SURVEY.md 8d prices the path as 3 d binary64 flops per (proposal, live point visited) on the vector ALUs "
+                               "(39.3 T non-fused op/s).  That roofline no longer binds: 99.99 % of the pair decisions are made by a PROVEN "
+                               "binary16 / binary32 matrix-core bound on the pair distance (DESIGN 4b, tests/test_filter_bounds.py); only the "
+                               "pairs inside the bound's band (uncertain_pairs) are evaluated in the reference's binary64 arithmetic, and the "
+                               "masks are asserted equal to the exact binary64 scan's in this run.  No work is skipped that the answer depends "
+                               "on; the binding roofs are HBM (first launch) and the f16 matrix pipe (the sweeps)"}
+    return {
+        "kernel": dominant, "dominant_by": "time: %.4f of the %.4f ms step" % (by_kernel.get(dominant, 0.0), step_ms),
+        "bound": "hbm" if hbm_bound else "mfma",
+        "achieved": ach_hbm if hbm_bound else ach_mfma,
+        "peak": HBM_PEAK_GBPS if hbm_bound else F16_MFMA_PEAK_TFLOPS,
+        "unit": "GB/s" if hbm_bound else "TFLOP/s",
+        "frac": (ach_hbm / HBM_PEAK_GBPS if hbm_bound else ach_mfma / F16_MFMA_PEAK_TFLOPS) if dom_ms else None,
+        "traffic": dom[0]["counter_bytes"] if (dom and pmc and pmc.get("fresh")) else None,
+        "traffic_status": (pmc or {}).get("status", "no PMC file"),
+        "traffic_imported_value": dom[0]["counter_bytes"] if dom else None,
+        "ms_per_launch": dom_ms,
+        "bytes_per_launch": dom_bytes,
+        "bytes_what": "proposals in (8 d + 1 B each) + the compacted set out (%d B per proposal without a certain hit)" % slot if hbm_bound else "operand sets in / out",
+        "other_roof": ({"bound": "mfma", "achieved": ach_mfma, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_mfma / F16_MFMA_PEAK_TFLOPS,
+                        "executed_mfma_per_launch": dom_mfma} if hbm_bound else
+                       {"bound": "hbm", "achieved": ach_hbm, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (ach_hbm or 0.0) / HBM_PEAK_GBPS}),
+        "hbm_peak_measured": hbm_probe_ceiling(ach_hbm) if ach_hbm else None,
+        "mfma_peak_at_measured_clock": {
+            "instruction_alone_random_operands_TFLOPs": PROBE_F16_MFMA_TFLOPS,
+            "what": "the part is power-limited under v_mfma_f32_32x32x16_f16: the instruction alone (4 independent chains, operands in "
+                    "registers, matrix pipe 98 % occupied) runs at 2.2 GHz = 2.23-2.33 PFLOP/s on ZERO operands and at 1.50-1.60 GHz = "
+                    "1.48-1.63 PFLOP/s on random binary16 operands (scripts/probes/sweep_src_probe.hip, profiles/r04_sweep_src_probe.json)"},
+        "how_measured": "ms: hipEvent pairs around every matrix-kernel launch on the library's stream, in a pass of its own over the same "
+                        "%d steps (wall %.4f ms per step with the events, %.4f without: the headline loop carries none); executed_mfma: "
+                        "group counts read back from the device x tiles x K / 16 (= SQ_INSTS_MFMA of profiles/); bytes: see bytes_what; "
+                        "counter_bytes: (2 FETCH_SIZE + WRITE_SIZE) x 1024 of the rocprofv3 --pmc passes (profiles/), imported" % (steps, launch_pass_ms, step_ms),
+        "launches": launches,
+        "launches_per_step": per_step,
+        "k_sweep_min": sweep_entry,
+        "step": {"ms": step_ms, "sum_of_the_matrix_launches_ms": float(sum(e["ms"] for e in launches)),
+                 "executed_mfma": mfma_step, "mfma_TFLOPs": mfma_step * MFMA_F16_FLOPS / (step_ms * 1e-3) / 1e12,
+                 "mfma_frac_of_2500": mfma_step * MFMA_F16_FLOPS / (step_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
+                 "algorithmic_bytes": alg_bytes, "algorithmic_GBps": hbm["achieved_GBps"], "algorithmic_hbm_frac": hbm["frac"],
+                 "counter_bytes": step_counter, "counter_bytes_status": (pmc or {}).get("status", "no PMC file"),
+                 "counter_GBps": (step_counter / (step_ms * 1e-3) / 1e9) if step_counter else None,
+                 "counter_bytes_over_algorithmic": (step_counter / alg_bytes) if step_counter else None},
+        "fp64_valu_roofline_of_survey_8d": fp64,
+        "range_cuts_tiles": [cut, cut2], "tiles": ntiles32, "executed_k_columns": kdim,
+        "first_range_pct": handle.get_option("filter_first_range_pct"), "second_range_pct": handle.get_option("filter_second_range_pct"),
+        "mask_operand_order": "nearest to the centre first" if handle.get_option("filter_order") else "storage order",
+        "uncertain_queries": stats.get("uncertain_queries"), "uncertain_pairs": stats.get("uncertain_pairs"),
+        "hbm": hbm}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks under torch.distributed.run ourselves."""
     import socket
@@ -291,28 +468,31 @@ def main():
 
     u, region = build_region(group)
     handle = region._dev.sync(region, True)          # device-resident region state
-    pts = proposals_in_ellipsoid(region, NPROPOSALS, 1000 + rank, dev)
-    mask = torch.empty(NPROPOSALS, dtype=torch.uint8, device=dev)
+    # THREE distinct batches, visited in turn by every timed loop: one 400 MB batch filtered again and again could sit in the
+    # 256 MB Infinity Cache between steps (MI355X_MICROARCH.md: FETCH_SIZE counts MALL hits too) -- 1.2 GB cannot
+    batches = [proposals_in_ellipsoid(region, NPROPOSALS, 1000 + rank + 7919 * k, dev) for k in range(NBATCHES)]
+    masks = [torch.empty(NPROPOSALS, dtype=torch.uint8, device=dev) for _ in range(NBATCHES)]
+    pts, mask = batches[0], masks[0]
     stream = torch.cuda.current_stream().cuda_stream
 
     from ultranest_amd import _lib as lib_mod
 
     def run_steps(nsteps, stage_events, settle=0):
-        """nsteps passes between two barriers; returns (max-over-ranks seconds, this rank's seconds).
+        """nsteps passes between two barriers, batch (step mod 3); returns (max-over-ranks seconds, this rank's seconds).
         settle: untimed steps in front of the W warm-up steps (CLOCK_SETTLE_STEPS for the headline: the device's clock
         management needs tens of milliseconds of load before the chip runs at its sustained clock; the first 10 ms
         after an idle period -- such as the host-side region build in front of this loop -- run ~8 % slower).
         stage_events: also record the per-stage hipEvents (only outside the headline loop: six extra events per pass
-        cost ~7 % of a 0.6 ms step).  The k_sweep launches are bracketed by events in both modes."""
+        cost ~7 % of a 0.6 ms step)."""
         call = handle.inside_dev_timed if stage_events else handle.inside_dev
-        for _ in range(settle + args.warmup):
-            handle.inside_dev(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
+        for i in range(settle + args.warmup):
+            handle.inside_dev(batches[i % NBATCHES].data_ptr(), NPROPOSALS, masks[i % NBATCHES].data_ptr(), stream)
         handle.timing_collect()
         handle.timing_filter_launches()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(nsteps):
-            call(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
+        for i in range(nsteps):
+            call(batches[i % NBATCHES].data_ptr(), NPROPOSALS, masks[i % NBATCHES].data_ptr(), stream)
         barrier()
         mine = time.perf_counter() - t0
         dt = mine
@@ -325,41 +505,57 @@ def main():
         run_steps.filter_launches = handle.timing_filter_launches()
         return dt, mine
 
-    lib_mod.set_option("time_filter_launches", 1)
+    def batch0_once():
+        handle.inside_dev(pts.data_ptr(), NPROPOSALS, mask.data_ptr(), stream)
+        torch.cuda.synchronize()
+
+    lib_mod.set_option("time_filter_launches", 0)
     exact_elapsed = ncalls_x = ms_scan_x = scan_flops = ell_pass = None
     nsteps_x = max(3, args.steps // 4)
-    mask_exact = None
+    masks_exact = None
     if not args.headline_only:
         # ---- the reference answer first: the exact FP64 scan kernel alone (MFMA pre-filter switched off) on the same
-        # batch.  Its mask is what the timed path is compared with below; its time is `roofline_exact_scan`.
+        # batches.  Its masks are what the timed path is compared with below; its time is `roofline_exact_scan`.
         lib_mod.set_option("filter", 0)
-        exact_elapsed, _ = run_steps(nsteps_x, True)
+        exact_elapsed, _ = run_steps(max(nsteps_x, NBATCHES), True)
         ncalls_x, ms_prep_x, ms_scan_x, ms_rest_x = handle.timing_collect()
         lib_mod.set_option("filter", 1)
-        mask_exact = mask.clone()
-    # ---- the headline: W warm-up steps, then exactly K steps, hipEvents only around the dominant kernel's launches ----
+        masks_exact = [m.clone() for m in masks]
+    # ---- the headline: W warm-up steps, then exactly K steps; NO events inside the loop (the event pairs around the
+    # matrix launches cost 7 %; the per-launch times come from the separate pass below) -------------------------------------
     elapsed, elapsed_mine = run_steps(args.steps, False, settle=CLOCK_SETTLE_STEPS)
-    filter_launches = run_steps.filter_launches
-    launch_ms_list = run_steps.launch_ms
+    for i in range(NBATCHES):      # every batch's mask is the timed path's (a short loop may not have reached all three)
+        handle.inside_dev(batches[i].data_ptr(), NPROPOSALS, masks[i].data_ptr(), stream)
+    batch0_once()
     stats = handle.debug_stats()
     accept = float(mask.float().mean().item())
     filter_on, kdim, ntiles32 = handle.filter_info(NPROPOSALS)
-    mask_filter = mask.clone()
-    if mask_exact is not None:
-        assert bool((mask_exact == mask_filter).all().item()), "filter and exact scan disagree"
+    masks_filter = [m.clone() for m in masks]
+    mask_filter = masks_filter[0]
+    if masks_exact is not None:
+        for me, mf in zip(masks_exact, masks_filter):
+            assert bool((me == mf).all().item()), "filter and exact scan disagree"
+    # ---- per-launch times of the matrix kernels: the same K steps once more with an event pair around every such launch ----
+    lib_mod.set_option("time_filter_launches", 1)
+    launch_pass_s, _ = run_steps(args.steps, False, settle=args.warmup)
+    filter_launches = run_steps.filter_launches
+    launch_ms_list = run_steps.launch_ms
+    lib_mod.set_option("time_filter_launches", 0)
     # ---- per-stage breakdown (separate pass with stage events) ---------------------------------------------
     nsteps_b = max(3, args.steps // 2)
     stage_pass_s, _ = run_steps(nsteps_b, True)
     ncalls, ms_prep, ms_scan, ms_rest = handle.timing_collect()
+    batch0_once()
     assert bool((mask == mask_filter).all().item())
     # the per-proposal stage rides in the first sweep launch by default (fused_first_range): its own kernel (k_prep4) is
     # timed in one more pass with the option off, for `roofline_prep` and `kernel_ms.unfused`
-    fused_first = bool(lib_mod.get_option("fused_first_range")) and NDIM % 2 == 0 and NDIM <= 56
+    fused_first = bool(handle.get_option("fused_first_range")) and NDIM % 2 == 0 and NDIM <= 56
     unfused = None
     if fused_first and not args.headline_only:
         lib_mod.set_option("fused_first_range", 0)
         unfused_pass_s, _ = run_steps(nsteps_b, True)
         ncalls_u, ms_prep_u, ms_scan_u, ms_rest_u = handle.timing_collect()
+        batch0_once()
         lib_mod.set_option("fused_first_range", 1)
         assert bool((mask == mask_filter).all().item()), "the per-proposal stage inside and in front of the first sweep launch disagree"
         unfused = {"prep": ms_prep_u / max(ncalls_u, 1), "scan": ms_scan_u / max(ncalls_u, 1), "tail": ms_rest_u / max(ncalls_u, 1),
@@ -373,12 +569,14 @@ def main():
         run_steps(nsteps_x, True)
         ncalls_single, _, ms_scan_single, _ = handle.timing_collect()
         ms_scan_single /= max(ncalls_single, 1)
+        batch0_once()
         lib_mod.set_option("filter_phases", 1)
         assert bool((mask == mask_filter).all().item()), "single sweep and phased sweep disagree"
         # ... and the FP64 per-proposal stage (k_prep3) in front of the filter instead of the bounded FP32 one
         lib_mod.set_option("prep_bounded", 0)
         run_steps(nsteps_x, True)
         ncalls_p3, ms_prep_p3, _, ms_rest_p3 = handle.timing_collect()
+        batch0_once()
         lib_mod.set_option("prep_bounded", 1)
         assert bool((mask == mask_filter).all().item()), "bounded and exact per-proposal stage disagree"
 
@@ -392,9 +590,9 @@ def main():
         scan_flops = 3.0 * NDIM * float(visited.sum().item())
         ell_pass = float((idx != -2).float().mean().item())
         assert bool(((idx >= 0) == (mask != 0)).all().item()), "index and mask pipelines disagree"
+        del idx, visited
         if rank == 0:
             hostapi = host_api(region, pts)
-    lib_mod.set_option("time_filter_launches", 0)
 
     # ---- strong scaling: ONE batch of P proposals per step, rows sharded over the ranks (distributed.shard_bounds; no
     # collective in the data path, integrator.py:1916-1928 gathers only accepted rows), and the 30-round bootstrap of
@@ -410,10 +608,24 @@ def main():
         return float(t.item())
 
     lo, hi = distributed.shard_bounds(NPROPOSALS, rank, world)
+    ranks_agree = None
     if world > 1:
         full = proposals_in_ellipsoid(region, NPROPOSALS, 1000, dev)     # the SAME batch on every rank; each takes its rows
         shard = full[lo:hi].contiguous()
-        del full
+        # every rank also filters the SAME first 65536 rows of that batch: a digest of the mask must be the same number on
+        # every rank (MIN == MAX over the ranks) -- a rank whose region, library or device disagrees fails the run loudly
+        nshared = 65536
+        shared_mask = torch.empty(nshared, dtype=torch.uint8, device=dev)
+        handle.inside_dev(full.data_ptr(), nshared, shared_mask.data_ptr(), stream)
+        torch.cuda.synchronize()
+        digest = int((shared_mask.long() * (torch.arange(nshared, device=dev, dtype=torch.int64) % 1000003 + 1)).sum().item())
+        import torch.distributed as dist
+        dg = torch.tensor([digest, -digest], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(dg, op=dist.ReduceOp.MAX)
+        ranks_agree = bool(int(dg[0].item()) == -int(dg[1].item()))
+        assert ranks_agree, "rank %d: the ranks' masks on the shared rows differ (digest %d, max %d, min %d)" % (
+            rank, digest, int(dg[0].item()), -int(dg[1].item()))
+        del full, shared_mask
     else:
         shard = pts
     smask = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
@@ -441,11 +653,20 @@ def main():
     boot_elapsed = maxed(boot_mine)
     region.maxradiussq, region.enlarge = r2_keep, f_keep     # the timed batches (and the CPU baseline below) belong to THIS region
     ranks_seen = 1
+    collective_library = None
     if use_dist:
         import torch.distributed as dist
         ones = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         ranks_seen = int(round(float(ones.item())))
+        if backend == "nccl":
+            try:
+                collective_library = "RCCL %s (torch.cuda.nccl.version(); backend 'nccl' IS RCCL on ROCm)" % ".".join(
+                    str(x) for x in torch.cuda.nccl.version())
+            except Exception as e:       # noqa: BLE001 -- the version string is a report field, not a requirement
+                collective_library = "RCCL (version unavailable: %s)" % e
+        else:
+            collective_library = "gloo (ranks share this box's device(s): rehearsal, not RCCL)"
     strong = {
         "what": "ONE batch of %d proposals per step, rows sharded over %d rank(s) by shard_bounds (region replicated, no "
                 "collective in the data path); value = P x steps / max-over-ranks seconds between two barriers" % (NPROPOSALS, world),
@@ -456,7 +677,9 @@ def main():
                                     "broadcast, ceil(30 / ranks) rounds per rank on the device, ONE all-reduce(MAX) of (r2, f, "
                                     "error flag), INCLUDED in the time; max over ranks",
         "bootstrap_result": [r_b, f_b],
-        "collective_backend": (backend if use_dist else None), "ranks_seen_by_allreduce": ranks_seen,
+        "collective_backend": (backend if use_dist else None), "collective_library": collective_library,
+        "ranks_seen_by_allreduce": ranks_seen,
+        "ranks_agree_on_the_shared_rows": ranks_agree,
     }
 
     first_ms, rebuild_ms, rebuild_all = time_rebuild(u, group)
@@ -489,24 +712,9 @@ def main():
             "value": value, "unit": "proposals/s", "ms_per_step": elapsed / args.steps * 1e3,
             "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank]}
     headline = strong if args.scaling == "strong" else weak
+    step_ms = elapsed / args.steps * 1e3
     alg_bytes = NPROPOSALS * (8 * NDIM + 1) + 8 * N_LIVE * NDIM + 2 * 8 * NDIM * NDIM
-    # HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE need their own passes (they cannot be
-    # collected inside this run); the figures of the last profiled tree are IMPORTED from profiles/pmc_scan_traffic.json
-    # (scripts/collect_profiles.py) and labelled as such
-    traffic = None
-    traffic_detail = None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_scan_traffic.json")
-    if os.path.exists(pmc_file):
-        pmc = json.load(open(pmc_file))
-        traffic = pmc.get("hbm_bytes_per_launch")
-        step_sum = pmc.get("hbm_bytes_per_step_all_kernels")
-        traffic_detail = {"source": "profiles/%s via profiles/pmc_scan_traffic.json (%s) -- imported from the last profiled tree, "
-                                    "NOT measured in this run" % (pmc.get("source"), pmc.get("note")),
-                          "per_launch_average_of_the_sweep_launches": traffic,
-                          "per_kernel_bytes": pmc.get("per_kernel_all"),
-                          "per_step_sum_all_kernels": step_sum,
-                          "algorithmic_bytes_per_step": alg_bytes,
-                          "ratio_to_algorithmic": (step_sum / alg_bytes) if step_sum else None}
+    traffic_file = imported_traffic()
     exact_roof = scan_x_ms = None
     if not args.headline_only:
         scan_x_ms = ms_scan_x / max(ncalls_x, 1)
@@ -518,115 +726,22 @@ def main():
             "frac": exact_tflops / FP64_VALU_PEAK_TFLOPS, "ms_per_launch": scan_x_ms,
             "algorithmic_flops_per_launch": scan_flops,
             "measured_valu_probe_tflops": kernels.bench_fp64_valu(),
-            "proposals_per_s_filter_off": NPROPOSALS * world * nsteps_x / exact_elapsed,
+            "proposals_per_s_filter_off": NPROPOSALS * world * max(nsteps_x, NBATCHES) / exact_elapsed,
             "note": "bit-exactness forbids FMA/MFMA in the distance itself: peak = non-fused FP64 vector issue rate"}
-    # whole-step algorithmic bytes over the HEADLINE step time (round 4 divided by the stage-event pass, which is longer)
-    step_ms = elapsed / args.steps * 1e3
     hbm = {"algorithmic_bytes_per_step": alg_bytes, "achieved_GBps": alg_bytes / (step_ms * 1e-3) / 1e9,
            "peak_GBps": HBM_PEAK_GBPS, "frac": alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
            "over": "ms_per_step of the timed loop (this rank's batch)"}
     if filter_on:
-        # f16 GEMM of the pre-filter on v_mfma_f32_32x32x16_f16 (32768 flop each).  EXECUTED work per step: the first
-        # live-point range sweeps every 32-query group, the second only the groups left after the device-side
-        # compaction (group count read back from the device); per (group, 32-row live tile): KS = kdim / 16 matrix
-        # instructions.  This is the number SQ_INSTS_MFMA x 32768 / average ns of the rocprofv3 summaries in profiles/
-        # reproduces; the all-pairs figure of round 1 is kept as `equivalent_*`.
-        ks = kdim // 16
-        nlaunch, ms_kernels = filter_launches
-        per_step = max(1, round(nlaunch / max(args.steps, 1)))
-        ngroups1 = (NPROPOSALS + 31) // 32
-        by_phase = [float(np.mean(launch_ms_list[i::per_step])) for i in range(per_step)] if len(launch_ms_list) else []
-        # the tile ranges as the library cut them for this batch (filter_run / filter_range_cuts)
-        cut, cut2 = stats["range_cuts"]
-        first_pct = lib_mod.get_option("filter_first_range_pct")
-        second_pct = lib_mod.get_option("filter_second_range_pct")
-        first_launch = None
-        if per_step in (3, 4) and cut:
-            # min-only sweep (mlf_sweepmin.hip): first range over every group, the later ones over the groups left after the
-            # compaction in front of them, then the uncertain queries (sets of 4 groups) once more over all tiles
-            nranges = per_step - 1
-            assert (cut2 > 0) == (nranges == 3), (per_step, stats)
-            tiles = [cut, cut2 - cut, ntiles32 - cut2] if cut2 else [cut, ntiles32 - cut]
-            groups = [ngroups1, stats["second_range_groups"], stats.get("third_range_groups", 0)][:nranges]
-            usets = -(-(-(-stats["uncertain_queries"] // 32)) // 4)
-            mfma_per_launch = [g * t * ks for g, t in zip(groups, tiles)] + [usets * 4 * ntiles32 * ks]
-            first_name = ("k_prep_sweep<50, 4> (per-proposal stage + first live-point range in one launch: the binary16 operand stays in registers; "
-                          "running minima only; compacts the proposals without a certain hit, with their minima)" if fused_first else
-                          "k_sweep_min<4, 4, 2> (first live-point range: running minima only; compacts the proposals without a certain hit, with their minima)")
-            names = [first_name] + ["k_sweep_min<4, 4, 2> (range %d of %d over the proposals left; compacts %s)" %
-                                    (i + 2, nranges, "those whose minimum ended in the band" if i + 2 == nranges else "again, with the minima")
-                                    for i in range(nranges - 1)]
-            names.append("k_uncertain<4, 4> (the proposals whose minimum ended in the band: all tiles again with their band pairs listed, "
-                         "binary64 whitening, the pairs in the reference's arithmetic; trailing workgroups decide the ellipsoid band)")
-            # the launches of k_sweep_min proper: with the per-proposal stage inside the first launch that launch is another
-            # kernel (k_prep_sweep) and is reported on its own below
-            sweep_idx = list(range(1 if fused_first else 0, nranges))
-            if fused_first and by_phase:
-                fl_bytes = NPROPOSALS * (8 * NDIM + 1) + groups[1] * 32 * (ks * 32 + 16)
-                first_launch = {"kernel": first_name, "ms": by_phase[0], "executed_mfma_of_the_sweep_part": mfma_per_launch[0],
-                                "sweep_part_TFLOPs_over_the_whole_launch": mfma_per_launch[0] * MFMA_F16_FLOPS / (by_phase[0] * 1e-3) / 1e12,
-                                "algorithmic_bytes": fl_bytes, "achieved_GBps": fl_bytes / (by_phase[0] * 1e-3) / 1e9,
-                                "frac_of_hbm_peak": fl_bytes / (by_phase[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                "what": "proposals in (binary64) + mask + the compacted set out; the per-proposal stage of a workgroup is HBM-bound, "
-                                        "its sweep part matrix-core-bound, and workgroups in different stages overlap"}
-        else:
-            tiles = [ntiles32 * (i + 1) // per_step - ntiles32 * i // per_step for i in range(per_step)]
-            if per_step == 2:
-                tiles = [cut, ntiles32 - cut] if cut else tiles
-            groups = [ngroups1] + [stats["second_range_groups"]] * (per_step - 1)
-            mfma_per_launch = [g * t * ks for g, t in zip(groups, tiles)]
-            names = ["k_sweep<4, 4, true, 2> (first live-point range, compacts the undecided proposals)",
-                     "k_sweep<4, 2, false, 1> (second range: two query groups per wave)"] if per_step == 2 else None
-            sweep_idx = list(range(per_step))
-        dominant = len(sweep_idx)
-        exec_flops = float(sum(mfma_per_launch[i] for i in sweep_idx)) * MFMA_F16_FLOPS
-        launch_ms = float(sum(by_phase[i] for i in sweep_idx)) / dominant if by_phase else ms_kernels / max(nlaunch, 1)
-        ach = (exec_flops / dominant) / (launch_ms * 1e-3) / 1e12
-        allpairs = 2.0 * N_LIVE * NPROPOSALS * (NDIM + 6)
-        roofline = {"kernel": ("k_sweep_min (mlf_sweepmin.hip: v_mfma_f32_32x32x16_f16 bound on the pair distances, running minima "
-                               "only; %d launches per step%s; the uncertain proposals go through k_uncertain afterwards)" %
-                               (dominant, " behind k_prep_sweep, which carries the per-proposal stage and the first range (first_launch)" if fused_first else ""))
-                              if per_step in (3, 4) else
-                              "k_sweep (mlf_sweep.hip: v_mfma_f32_32x32x16_f16 bound on the pair distances, mask mode; two launches per step)",
-                    "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / F16_MFMA_PEAK_TFLOPS, "ms_per_launch": launch_ms,
-                    "launches_per_step": per_step, "launches_of_the_dominant_kernel": dominant,
-                    "ms_per_launch_by_phase": by_phase,
-                    "executed_mfma_per_launch_by_phase": mfma_per_launch,
-                    "executed_flops_per_launch": exec_flops / dominant,
-                    "achieved_by_phase": [m * MFMA_F16_FLOPS / (t * 1e-3) / 1e12 for m, t in zip(mfma_per_launch, by_phase)],
-                    "kernel_names": names,
-                    "peak_at_measured_clock": {
-                        "what": "the part is power-limited under this instruction: scripts/probes/sweep_src_probe.hip measures clock and "
-                                "cycles per matrix instruction INSIDE the kernel (s_memtime / s_memrealtime): the instruction alone, "
-                                "4 independent chains, operands in registers, matrix pipe 98 % occupied, runs at 2.20-2.26 GHz = "
-                                "2.23-2.33 PFLOP/s on ZERO operands and at 1.50-1.60 GHz = 1.48-1.63 PFLOP/s on random binary16 operands "
-                                "(bf16: 1.64-1.71 GHz); the sweep loop of this kernel holds 1.67-1.72 GHz with the pipe 97-100 % occupied "
-                                "inside the loop (profiles/r04_sweep_src_probe.json, r04_sweep_src_probe2.json)",
-                        "instruction_alone_random_operands_TFLOPs": PROBE_F16_MFMA_TFLOPS,
-                        "frac_of_that": ach / PROBE_F16_MFMA_TFLOPS},
-                    "equivalent_allpairs_flops_per_step": allpairs,
-                    "equivalent_allpairs_TFLOPs": allpairs / (float(sum(by_phase)) * 1e-3) / 1e12 if by_phase else None,
-                    "executed_k_columns": kdim, "second_range_groups": stats["second_range_groups"],
-                    "first_range_pct": first_pct, "second_range_pct": second_pct, "range_cuts_tiles": [cut, cut2], "tiles": ntiles32,
-                    "third_range_groups": stats.get("third_range_groups") if cut2 else None,
-                    "first_launch": first_launch,
-                    "mask_operand_order": "nearest to the centre first" if lib_mod.get_option("filter_order") else "storage order",
-                    "uncertain_queries": stats.get("uncertain_queries"), "uncertain_pairs": stats.get("uncertain_pairs"),
-                    "note": "achieved = executed matrix-instruction flops of one k_sweep_min launch (average of its launches of a step) "
-                            "over the average launch duration from hipEvents inside the timed region; pairs skipped by the "
-                            "second range are not counted (they are an algorithmic saving)",
-                    "traffic": traffic, "traffic_detail": traffic_detail, "hbm": hbm}
+        roofline = step_roofline(handle, stats, kdim, ntiles32, filter_launches, launch_ms_list, args.steps, fused_first, step_ms,
+                                 launch_pass_s / args.steps * 1e3, alg_bytes, traffic_file, hbm, scan_flops)
     else:
         roofline = dict(exact_roof or {})
-        roofline["traffic"] = traffic
-        roofline["traffic_detail"] = traffic_detail
+        roofline["traffic"] = None
         roofline["hbm"] = hbm
     # per-proposal stage: row in (8 d), binary16 operand + thresholds + route / slot / best words out
     prep4_ms = (unfused["prep"] if unfused else None) if fused_first else prep_ms      # k_prep4 in its own launch
     prep_bytes = NPROPOSALS * (8 * NDIM + 2 * kdim + 8 + 1 + 4 + 4 + 1)
-    prep_mfma_flops = NPROPOSALS / 32 * 42 * 2.0 * 32 * 32 * 16    # 42 v_mfma_f32_32x32x16_f16 per 32 proposals (d = 50):
-    # 3 partial products (hi hi, hi lo, lo hi) x [6 k-steps of the triangular L^T + 8 of T^T]
+    prep_mfma_flops = NPROPOSALS / 32 * PREP_MFMA_PER_GROUP * MFMA_F16_FLOPS
     out = {
         "metric": "proposal-points filtered/sec (MLFriends.inside) + region-rebuild ms, N=4000 d=50",
         "value": headline["value"], "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -636,14 +751,15 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "C5: N=4000 live points, d=50, P=1e6 proposals/step/GPU drawn uniformly inside the "
                                "wrapping ellipsoid (set E), AffineLayer, 30 bootstraps; one step = MLFriends.inside "
-                               "on a batch resident in HBM",
+                               "on a batch resident in HBM; the timed loop visits %d distinct batches in turn" % NBATCHES,
                    "n_live": N_LIVE, "d": NDIM, "proposals_per_step_per_gpu": NPROPOSALS, "bootstraps": NBOOT,
+                   "distinct_batches_in_the_timed_loop": NBATCHES,
                    "parallelism": "proposal rows sharded over " + str(world) + " GPU(s), region replicated",
                    "mfma_prefilter": bool(filter_on),
                    "arithmetic": "inputs, thresholds and every decision that depends on the reference's rounding: binary64 "
                                  "(non-fused); deciding bounds for the other 99.99 % of the pairs: binary16 operands / "
                                  "binary32 accumulate on the matrix cores, bounded whitening with split binary16 operands; masks bit-identical "
-                                 "to the exact FP64 scan (asserted in this run)"},
+                                 "to the exact FP64 scan (asserted in this run, all %d batches)" % NBATCHES},
         "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
         "rebuild_ms": rebuild_ms, "rebuild_first_ms": first_ms, "rebuild_ms_each": rebuild_all,
         "rebuild_what": "steady-state rebuild through harness.RegionUpdater (LocalAffineLayer create_new incl. clustering + "
@@ -669,13 +785,13 @@ def main():
                                "tail": "k_scan tail: what the filter could not take, routing, finalise",
                                "scan_single_sweep": "the scan stage as a single sweep over all live points (filter_phases = 0)",
                                "prep_fp64": "per-proposal stage with the FP64 kernel instead (k_prep3, prep_bounded = 0)"},
-                      "measured_in": "a separate pass of %d steps with stage events (the headline loop carries events only "
-                                     "around the matrix-kernel launches)" % nsteps_b,
+                      "measured_in": "a separate pass of %d steps with stage events (the headline loop carries no events at all)" % nsteps_b,
                       # the stages add up to the wall time of THAT pass, not of the headline loop: every stage boundary is a
                       # hipEventRecord between two dependent kernels, i.e. a bubble in the queue and a time stamp taken after
                       # the device has drained; the three figures below make the difference visible (+14 %)
                       "sum_of_the_stages": prep_ms + scan_ms + rest_ms,
                       "wall_ms_per_step_of_the_stage_event_pass": stage_pass_s / nsteps_b * 1e3,
+                      "wall_ms_per_step_of_the_launch_event_pass": launch_pass_s / args.steps * 1e3,
                       "wall_ms_per_step_of_the_headline_loop": headline["ms_per_step"]},
         "batch_counters": stats,
         "roofline": roofline,
@@ -688,7 +804,7 @@ def main():
                                        "achieved_TFLOPs": prep_mfma_flops / (prep4_ms * 1e-3) / 1e12,
                                        "peak_TFLOPs": F16_MFMA_PEAK_TFLOPS},
                           "peak_measured": hbm_probe_ceiling(prep_bytes / (prep4_ms * 1e-3) / 1e9),
-                          "measured_with": "fused_first_range = 0 (k_prep4 in its own launch: a separate pass; by default the stage rides in k_prep_sweep, roofline.first_launch)" if fused_first else "the default routing",
+                          "measured_with": "fused_first_range = 0 (k_prep4 in its own launch: a separate pass; by default the stage rides in k_prep_sweep, roofline.launches[0])" if fused_first else "the default routing",
                           "note": "the stage time includes the launch gap in front of the filter; the matrix work is 13 % "
                                   "of the SIMD time (profiles/); DESIGN.md section 4c"},
         "host_api": hostapi,
@@ -696,7 +812,7 @@ def main():
     if world == 1 and not args.no_cpu:
         sample = pts[:args.cpu_sample].cpu().numpy()
         cmask, base = cpu_baseline(region, sample, u)
-        gmask = mask[:args.cpu_sample].cpu().numpy().astype(bool)
+        gmask = mask_filter[:args.cpu_sample].cpu().numpy().astype(bool)
         base["gpu_mask_equals_cpu_mask_on_sample"] = bool(np.array_equal(cmask, gmask))
         base["speedup_1gpu_vs_1core"] = value / base["value"]
         out["cpu_baseline"] = base

@@ -90,6 +90,9 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *                              the binary16 operand never leaves the registers, 256 MB less HBM traffic per 10^6 x 50 batch);
  *                              0: k_prep4, then k_sweep_min (the default until the first range became short: with a first range
  *                              of 30 % and more of the tiles the separate launches were 3 % faster)
+ *   "fused_waves"              8 (default) / 4: waves per workgroup of k_prep_sweep.  8: one workgroup per CU (137 KiB of LDS at d = 50);
+ *                              4: 79 KiB per workgroup, two per CU -- workgroups that start and end independently of each other, so
+ *                              that one streams proposal rows while the other multiplies
  *   "mid_max_queries"          default 2048: batches up to this size (and at least "filter_min_queries") run the per-proposal
  *                              stage, the pre-filter sweep, the re-check and the answers in ONE launch (k_inside_mid); 0 = never
  *   "sweep_min"                1 (default): phased batches through the min-only sweep (k_sweep_min: running minima only
@@ -365,6 +368,23 @@ int mlf_walkers_step_dev(mlf_walkers *w, double Lmin, double scale, int dirkind,
 int mlf_walkers_step_graph(mlf_walkers *w, double Lmin, double scale, int dirkind, double dirscale,
                            uint64_t seed, uint64_t offset, int tkind, double ta, double tb, int lkind,
                            const double *aux, double sigma, double *rec, uint64_t *next_offset);
+/* SEVERAL such steps ("rounds") without a host round trip in between.  PopulationSliceSampler.__next__ advances every walker
+ * by one likelihood evaluation and returns a point only when the walker under the ring index has finished its nsteps
+ * (popstepsampler.py:610-697); the driver calls it again and again with the SAME threshold, live points and scale until
+ * it does (integrator.py:1839-1950).  This call runs that loop on the device: round 0 for every walker, then the ring
+ * walker alone until it has finished (at most max_rounds rounds; that fixes the number R of rounds the driver's loop
+ * would have made), then the other walkers' rounds 1 ... R - 1, each walker's rounds back to back inside the wave that owns
+ * it.  Round r draws from the Philox counters call r of mlf_walkers_step_dev would use, so the resident state, the
+ * record and *next_offset are those of R consecutive mlf_walkers_step_dev calls, bit for bit.
+ *   rec         10 + 2 d doubles: [0] harvested, [1] L, [2] left, [3] right, [4] R, [9 ...] u (d), p (d), ring index after
+ *   round_rows  max_rounds x 5 doubles, rows 0 ... R - 1 filled: (likelihood evaluations, movable walkers, successes,
+ *               far-enough moves, sum log(distance / radius + 1e-10)) of each round -- one row of the sampler's logstat each
+ *   *rounds     R.  rec[0] == 0 with R == max_rounds: call again (the driver's loop does exactly that).
+ * max_rounds is clamped to 4096 and to 64 MiB of per-round bookkeeping (9 bytes per walker and round). */
+int mlf_walkers_rounds_dev(mlf_walkers *w, double Lmin, double scale, int dirkind, double dirscale,
+                           uint64_t seed, uint64_t offset, int tkind, double ta, double tb, int lkind,
+                           const double *aux, double sigma, int max_rounds, double *rec, double *round_rows,
+                           int *rounds, uint64_t *next_offset);
 int mlf_walkers_export(mlf_walkers *w, double *allu, double *allL, int64_t *generation,
                        double *currentt, double *currentv, double *left, double *right,
                        uint8_t *searching_left, uint8_t *searching_right);
@@ -456,6 +476,11 @@ int mlf_comm_destroy(void);
  * stage boundaries of one workgroup of the last launch that records them, out[16], out[17] (cap >= 18) the tile cuts of the last
  * min-only batch (the second is 0 with two ranges).  cap >= 6. */
 int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap);
+/* diagnostics of the fused first launch (k_prep_sweep): returns in out[0 ... 12] the shader-clock stamps wave 0 of the workgroup
+ * chosen by the PREVIOUS call wrote during the last phased batch -- [0] entry, [1] matrix fragments in LDS, [2 + 2 g] rows of
+ * query group g landed, [3 + 2 g] group g's per-proposal stage done (g = 0 ... 3), [10] first-range sweep starts, [11] sweep
+ * done, [12] compaction done -- and selects workgroup `block` for the following batches (block < 0: off). */
+int mlf_region_debug_fused_stamps(mlf_region *r, int block, unsigned long long *out, int cap);
 /* Measured issue rate of independent v_add_f64/v_mul_f64 (the non-fused FP64 vector rate that
  * bounds the distance kernels), in Tera-instructions*lanes per second (= TFLOP/s, 1 flop each). */
 int mlf_bench_fp64_valu(double *tflops);

@@ -80,7 +80,9 @@ if sweeps:
                       if not k.startswith("_") and "hbm_bytes_gfx950_corrected" in v}
     launches = {k.replace("void mlf::", "").split("(")[0]: (2 if k.startswith("void mlf::k_sweep_min") else 1) for k in summary if not k.startswith("_")}
     step_sum = sum(per_kernel_all[k] * launches.get(k, 1) for k in per_kernel_all)
-    json.dump({"hbm_bytes_per_launch": per_launch, "per_kernel_all": per_kernel_all, "launches_per_step": launches,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from ultranest_amd.csrc import build as _build
+    json.dump({"source_hash": _build.source_hash(), "hbm_bytes_per_launch": per_launch, "per_kernel_all": per_kernel_all, "launches_per_step": launches,
                "hbm_bytes_per_step_all_kernels": step_sum, "source": os.path.basename(dst) + "_pmc_summary.json",
                "kernel": "k_sweep_min<4, 4, 2> (its launches of a step -- the ranges behind the first, which rides in k_prep_sweep by default: mean over them)",
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over scripts/stage_profile.py (the bench workload, "

@@ -1,0 +1,56 @@
+"""k_prep_sweep with 8 waves per workgroup (one per CU) against 4 (two per CU), C5 batch; stage stamps of single waves.
+    python scripts/fused_ab.py [steps]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import bench  # noqa: E402
+from ultranest_amd import _lib  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+dev = torch.device("cuda", 0)
+u, region = bench.build_region(None)
+handle = region._dev.sync(region, True)
+stream = torch.cuda.current_stream().cuda_stream
+batches = [bench.proposals_in_ellipsoid(region, bench.NPROPOSALS, 1000 + 7919 * k, dev) for k in range(3)]
+masks = [torch.empty(bench.NPROPOSALS, dtype=torch.uint8, device=dev) for _ in range(3)]
+
+
+def run(n):
+    for i in range(n):
+        handle.inside_dev(batches[i % 3].data_ptr(), bench.NPROPOSALS, masks[i % 3].data_ptr(), stream)
+    torch.cuda.synchronize()
+
+
+_lib.set_option("filter", 0)
+run(3)
+exact = [m.clone() for m in masks]
+_lib.set_option("filter", 1)
+out = {}
+for rep in range(2):
+    for waves in (8, 4):
+        _lib.set_option("fused_waves", waves)
+        run(150)
+        t0 = time.perf_counter()
+        run(steps)
+        dt = (time.perf_counter() - t0) / steps
+        ok = all(bool((a == b).all().item()) for a, b in zip(exact, masks))
+        _lib.set_option("time_filter_launches", 1)
+        handle.timing_filter_launches()
+        run(30)
+        lm = handle.timing_filter_launch_ms()
+        _lib.set_option("time_filter_launches", 0)
+        per = [float(lm[i::4].mean()) for i in range(4)] if len(lm) % 4 == 0 and len(lm) else []
+        row = dict(fused_waves=waves, ms_per_step=dt * 1e3, masks_equal_exact=ok, launch_ms=per)
+        if rep == 1:
+            stamps = {}
+            for blk in (0, 3, 500, 1200, 1900) if waves == 4 else (0, 3, 250, 600, 950):
+                handle.fused_stamps(blk)
+                run(4)
+                stamps[blk] = handle.fused_stamps(None)
+            row["stamps_cycles"] = stamps
+        print(json.dumps(row), flush=True)
+_lib.set_option("fused_waves", 8)

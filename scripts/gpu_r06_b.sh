@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 6, call b: k_prep_sweep 8 / 4 waves per workgroup + stage stamps, end-to-end runs with the multi-round walker loop,
+# kernel traces of mid-size calls, bench (new roofline object)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+echo "== fused A/B"
+timeout 300 python scripts/fused_ab.py 300 > $O/r06b_fused_ab.jsonl 2> $O/r06b_fused_ab.err; cut -c1-700 $O/r06b_fused_ab.jsonl; tail -3 $O/r06b_fused_ab.err
+echo "== e2e (population slice sampler, multi-round device loop)"
+timeout 600 python scripts/e2e_run.py nsteps10=40,80 > $O/r06b_e2e.log 2>&1; cut -c1-330 $O/r06b_e2e.log | tail -6
+cp $O/e2e_run.json $O/r06b_e2e_run.json 2>/dev/null
+echo "== e2e, one round per call (as round 5)"
+timeout 300 python scripts/e2e_run.py max_rounds=1 > $O/r06b_e2e_single.log 2>&1; cut -c1-330 $O/r06b_e2e_single.log | tail -3
+echo "== mid-size traces"
+bash scripts/gpu_trace_mid.sh r06b 16384 65536 131072 2>&1 | tail -30
+echo "== bench"; timeout 900 python bench.py --steps 20 --warmup 5 > $O/r06b_bench.json 2> $O/r06b_bench.err; tail -3 $O/r06b_bench.err; python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r06b_bench.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d.get('rebuild_ms'), d.get('rebuild_device_resident_ms'), d['strong_scaling']['ms_per_step'])
+r=d['roofline']; print({k:r.get(k) for k in ('kernel','bound','achieved','frac','traffic','traffic_status','ms_per_launch')})
+print([(e['kernel'], round(e['ms'],4), round(e['mfma_frac_of_2500'],3), round(e['hbm_frac_of_8000'],3)) for e in r['launches']])
+print(r['step']); print(r['fp64_valu_roofline_of_survey_8d'] and r['fp64_valu_roofline_of_survey_8d']['ratio_to_that_peak'])
+print(d['kernel_ms']['wall_ms_per_step_of_the_launch_event_pass'], d['cpu_baseline']['value'], d['cpu_baseline']['gpu_mask_equals_cpu_mask_on_sample'])
+PY

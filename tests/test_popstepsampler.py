@@ -200,6 +200,7 @@ def test_graph_replay_equals_kernel_by_kernel_launches(direction):
         sampler = pop.PopulationSliceSampler(popsize=96, nsteps=8, generate_direction=getattr(pop, direction), scale=0.3,
                                              device_rng=DeviceRNG(77))
         sampler.use_graph = graph
+        sampler.max_rounds = 1                                  # one round per call: the path the graph captures
         out, nfound = [], 0
         for it in range(400):
             Lcut = thresholds[min(nfound // 4, 200)]          # rising threshold: step_back and restarts happen
@@ -216,6 +217,62 @@ def test_graph_replay_equals_kernel_by_kernel_launches(direction):
             nfound += 1
             assert np.array_equal(ua, ub) and np.array_equal(pa, pb) and La == Lb
     assert nfound > 30
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("problem,d,direction,max_rounds", [
+    ("gauss", 5, "generate_mixture_random_direction", 64),          # odd d: the likelihood row on one lane
+    ("gauss", 8, "generate_cube_oriented_direction", 3),            # the cap is hit: __next__ returns None and is called again
+    ("eggbox", 10, "generate_mixture_random_direction", 256),
+    ("rosenbrock", 6, "generate_region_random_direction", 17),
+    ("eggbox", 2, "generate_random_direction", 2)])
+def test_rounds_equal_single_steps(problem, d, direction, max_rounds):
+    """mlf_walkers_rounds_dev (every walker's rounds back to back inside its wave, the ring walker deciding how many) against
+    one mlf_walkers_step_dev call per round, driven as the reference's driver drives __next__ (integrator.py:1839-1950: call
+    until a point comes back, then raise the threshold): same points, likelihoods, evaluation counts, scale, ring index,
+    Philox offset, per-round statistics rows and resident state, bit for bit."""
+    import ultranest_amd.popstepsampler as pop
+    from ultranest_amd import likelihoods
+    from ultranest_amd.regions import DeviceRNG
+    rs = np.random.RandomState(100 + d)
+    if problem == "gauss":
+        u = 0.5 + 0.08 * rs.normal(size=(300, d))
+        loglike, transform = likelihoods.GaussLikelihood(0.5, 0.1, d), likelihoods.identity_transform
+    elif problem == "eggbox":
+        u = rs.uniform(size=(400, d))
+        loglike, transform = likelihoods.eggbox_loglike, likelihoods.eggbox_transform
+    else:
+        u = 0.5 + 0.04 * rs.normal(size=(300, d))
+        loglike, transform = likelihoods.rosenbrock_loglike, likelihoods.rosenbrock_transform
+    u = np.clip(u, 1e-3, 1 - 1e-3)
+    region = _gpu_region(u)
+    Ls = loglike(transform(u))
+    thresholds = np.sort(Ls)
+    runs = []
+    for mr in (1, max_rounds):
+        sampler = pop.PopulationSliceSampler(popsize=64, nsteps=7, generate_direction=getattr(pop, direction), scale=0.4,
+                                             device_rng=DeviceRNG(31))
+        sampler.max_rounds = mr
+        out = []
+        for it in range(120):
+            Lcut = thresholds[min(it // 3, len(Ls) // 2)]          # rising threshold: step_back and restarts happen
+            nc_total, calls = 0, 0
+            while True:
+                unew, pnew, Lnew, nc = sampler.__next__(region, Lcut, u, Ls, transform, loglike)
+                nc_total += nc
+                calls += 1
+                assert calls < 5000
+                if unew is not None:
+                    break
+            out.append((unew, pnew, Lnew, nc_total))
+        runs.append((out, sampler.scale, sampler.ringindex, sampler.device_rng.offset, np.array(sampler.logstat), sampler.state()))
+    (a, scale_a, ring_a, off_a, log_a, st_a), (b, scale_b, ring_b, off_b, log_b, st_b) = runs
+    for (ua, pa, La, nca), (ub, pb, Lb, ncb) in zip(a, b):
+        assert np.array_equal(ua, ub) and np.array_equal(pa, pb) and La == Lb and nca == ncb
+    assert scale_a == scale_b and ring_a == ring_b and off_a == off_b
+    assert log_a.shape == log_b.shape and np.array_equal(log_a, log_b)
+    for key in st_a:
+        assert np.array_equal(st_a[key], st_b[key], equal_nan=True), key
 
 
 # ---- the reference's own small tests of this module (tests/test_popstepsampling.py), same recipes -------------

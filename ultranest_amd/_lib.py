@@ -101,6 +101,8 @@ SIGNATURES = {
                              _vp, _vp],
     "mlf_walkers_step_graph": [_vp, _dbl, _dbl, _int, _dbl, ctypes.c_uint64, ctypes.c_uint64, _int, _dbl, _dbl, _int, _vp, _dbl,
                                _vp, _vp],
+    "mlf_walkers_rounds_dev": [_vp, _dbl, _dbl, _int, _dbl, ctypes.c_uint64, ctypes.c_uint64, _int, _dbl, _dbl, _int, _vp, _dbl,
+                               _int, _vp, _vp, _vp, _vp],
     "mlf_walkers_export": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlf_host_changed_rows": [_vp, _vp, _sz, _sz, _vp, _sz, _vp],
     "mlf_host_draw_selection": [_vp, _vp, _sz, _sz, _vp],
@@ -116,6 +118,7 @@ SIGNATURES = {
     "mlf_region_filter_info": [_vp, _sz, _vp, _vp, _vp],
     "mlf_bench_fp64_valu": [_vp],
     "mlf_region_debug_stats": [_vp, _vp, _int],
+    "mlf_region_debug_fused_stamps": [_vp, _int, _vp, _int],
     "mlf_comm_unique_id": [_vp, _sz],
     "mlf_comm_init_rank": [_vp, _sz, _int, _int],
     "mlf_comm_init": [_int],

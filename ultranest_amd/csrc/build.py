@@ -17,7 +17,7 @@ PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libmlfriends_hip.so")
 OBJ = os.path.join(HERE, "build")
 SOURCES = ["mlf_scan.hip", "mlf_boot.hip", "mlf_prep.hip", "mlf_misc.hip", "mlf_filter.hip", "mlf_sweep.hip", "mlf_sweepmin.hip", "mlf_mid.hip", "mlf_fused.hip", "mlf_prep3.hip", "mlf_prep4.hip", "mlf_prep64.hip", "mlf_sample.hip", "mlf_walk.hip", "mlf_walk_api.hip", "mlf_netiter.hip", "mlf_comm.hip", "mlf_small.hip", "mlf_wide.hip", "mlf_api.hip"]
-HEADERS = ["mlf_common.hpp", "mlf_dpp_dev.hpp", "mlf_recheck_dev.hpp", "mlf_ell_exact.hpp", "mlf_misc.hpp", "mlf_filter.hpp", "mlf_filter_dev.hpp", "mlf_prep3.hpp", "mlf_prep4.hpp", "mlf_prep64.hpp", "mlf_small.hpp", "mlf_sample.hpp", "mlf_walk.hpp", "mlf_ctx.hpp", "mlf_philox_dev.hpp", os.path.join("..", "..", "include", "mlfriends_hip.h")]
+HEADERS = ["mlf_common.hpp", "mlf_dpp_dev.hpp", "mlf_recheck_dev.hpp", "mlf_ell_exact.hpp", "mlf_misc.hpp", "mlf_filter.hpp", "mlf_filter_dev.hpp", "mlf_prep3.hpp", "mlf_prep4.hpp", "mlf_prep64.hpp", "mlf_small.hpp", "mlf_sample.hpp", "mlf_walk.hpp", "mlf_ctx.hpp", "mlf_philox_dev.hpp", "mlf_loglike_dev.hpp", os.path.join("..", "..", "include", "mlfriends_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-strict-aliasing",
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-result"]
 
@@ -28,6 +28,18 @@ EXTRA_FLAGS = {"mlf_filter.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "mlf_swee
                "mlf_sweepmin.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "mlf_mid.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "mlf_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
+def source_hash():
+    """16 hex digits over the kernel sources and headers (what the library is built from): profiles record it next to their
+    counters so that a figure measured on another tree can be told apart (bench.py: roofline.traffic)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + [x for x in HEADERS if not x.startswith("..")]):
+        with open(os.path.join(HERE, name), "rb") as fh:
+            h.update(name.encode())
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def _stale(target, deps):

@@ -73,19 +73,20 @@ enum Opt : int {
   OPT_ORDER,               // "filter_order" 0/1: mask-mode operand in storage order / nearest to the centre first (k_ref_rank)
   OPT_SECOND_RANGE_PCT,    // "filter_second_range_pct" 0 ... 90: min-only sweep in three ranges, the second ending at this share of the tiles (0: two ranges)
   OPT_THIRD_MIN_WORK,      // "filter_third_range_min_work": three ranges from this many (proposals x 32-row live-point tiles) on
+  OPT_FUSED_WAVES,         // "fused_waves" 8 / 4: waves per workgroup of k_prep_sweep (8: one workgroup per CU; 4: two, out of step)
   OPT_COUNT
 };
 const char *const kOptNames[OPT_COUNT] = {"filter", "filter_first_range_pct", "filter_split_waves", "filter_narrow_tail",
                                           "small_path", "fused_prep", "filter_phase_min_queries", "filter_phases",
                                           "time_filter_launches", "prep_bounded", "filter_min_queries", "sweep_min", "mid_max_queries", "fused_first_range",
-                                          "boot_symmetric", "filter_order", "filter_second_range_pct", "filter_third_range_min_work"};
+                                          "boot_symmetric", "filter_order", "filter_second_range_pct", "filter_third_range_min_work", "fused_waves"};
 }  // namespace
 namespace mlf {
 std::atomic<unsigned> g_grant_epoch{0u};
 std::atomic<unsigned long long> g_grant_calls{0ull};
 }  // namespace mlf
 namespace {
-long long g_opt[OPT_COUNT] = {1, 30, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 1, 1, 1, 50, 100000000ll};
+long long g_opt[OPT_COUNT] = {1, 30, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 1, 1, 1, 50, 100000000ll, 8};
 
 struct OptOverrides {
   long long v[OPT_COUNT] = {};
@@ -104,6 +105,7 @@ long long opt_clamp(int id, long long value) {
     case OPT_SPLIT_WAVES: return value < 256 ? 256 : (value > 16384 ? 16384 : value);
     case OPT_PHASES: return value < 0 ? 0 : (value > 64 ? 64 : value);
     case OPT_SECOND_RANGE_PCT: return value < 0 ? 0 : (value > 90 ? 90 : value);
+    case OPT_FUSED_WAVES: return value == 4 ? 4 : 8;
     case OPT_BOOT_SYM: return value < 0 ? 0 : (value > 2 ? 2 : value);
     case OPT_THIRD_MIN_WORK: return value < 0 ? 0 : value;
     case OPT_PHASE_MIN_QUERIES:
@@ -130,6 +132,8 @@ struct FilterCtx {
   DevBuf mid_rec, mid_meta, mid_arrive;   // one-launch path (mlf_mid.hip): records of the tile ranges, arrival counters
   bool mid_last = false;                  // the last batch took that path (debug_stats)
   bool mid_dirty = false;                 // a launch of that path failed: its self-resetting counters are zeroed before the next batch
+  DevBuf fstamps;                         // diagnostics: stage stamps of one k_prep_sweep wave
+  int stamp_block = -1;
   bool png_dirty = false;                 // a phased batch did not reach its scan launch (whose tail returns the slot counters to zero)
   // bounded per-proposal stage (mlf_prep4.hip): ellipsoid band list, per-call counters
   // misc: [0] band proposals, [1] k_ell_exact workgroups done -- both return to zero by themselves (no memset per batch),
@@ -149,7 +153,7 @@ struct FilterCtx {
   void release() {
     DevBuf *b[] = {&stats, &statscratch, &refF, &qF, &tlo, &thi, &route, &best, &counters, &list, &segcnt, &gate2, &refFm, &refRm, &okeys, &operm,
                    &pqF[0], &pqF[1], &ptlo[0], &ptlo[1], &pthi[0], &pthi[1], &pmap[0], &pmap[1], &png, &pmin, &pmin2, &mid_rec, &mid_meta, &mid_arrive,
-                   &ell_list, &misc};
+                   &ell_list, &misc, &fstamps};
     for (DevBuf *x : b) x->release();
     refs_ready = usable = ordered = false;
     order_n = -1;
@@ -613,7 +617,13 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       fu.cmin = m.cmin;
       fu.ccount = m.ccount;
       fu.ccap = m.ccap;
-      if (int rc = timed([&] { return launch_prep_sweep(fu, s); })) return rc;
+      if (f.stamp_block >= 0) {   // diagnostics (mlf_region_debug_fused_stamps)
+        CK(f.fstamps.reserve(16 * sizeof(unsigned long long)));
+        fu.stamps = f.fstamps.as<unsigned long long>();
+        fu.stamp_block = (unsigned)f.stamp_block;
+      }
+      const int fused_waves = (int)opt(f, OPT_FUSED_WAVES);
+      if (int rc = timed([&] { return launch_prep_sweep(fu, s, fused_waves); })) return rc;
     } else if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, 0), m, s); })) return rc;
     // next range: set 0 with its minima.  Two ranges: this is the last, the uncertain queries go to set 1.  Three: the
     // queries still without a certain hit go to set 1 with their minima, and the last range sweeps those into set 0's arrays
@@ -2819,6 +2829,20 @@ int mlf_region_filter_info(mlf_region *r, size_t np, int *active, int *kdim, int
   *active = (r->ready && r->use_scan && filter_applies(r->filter, (long long)np, r->r2)) ? 1 : 0;
   *kdim = r->filter.ks * 16;
   *ntiles32 = r->filter.ntiles32;
+  return 0;
+}
+
+int mlf_region_debug_fused_stamps(mlf_region *r, int block, unsigned long long *out, int cap) {
+  if (!r) return fail_arg(MLF_E_BADARG, "null region");
+  FilterCtx &f = r->filter;
+  if (out && cap > 0) {
+    for (int i = 0; i < cap; ++i) out[i] = 0ull;
+    if (f.fstamps.p && f.stamp_block >= 0) {
+      CK(hipStreamSynchronize(g_ctx.stream));
+      CK(hipMemcpy(out, f.fstamps.p, (size_t)(cap < 16 ? cap : 16) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+  }
+  f.stamp_block = block;
   return 0;
 }
 

@@ -151,9 +151,11 @@ struct FusedArgs {
   int *cmap, *cmin;
   unsigned *ccount;
   unsigned ccap;
+  unsigned long long *stamps;   // optional diagnostics: 13 shader-clock stamps of wave 0 of workgroup `stamp_block`
+  unsigned stamp_block;
 };
 bool fused_usable(int dp);
-hipError_t launch_prep_sweep(const FusedArgs &a, hipStream_t s);
+hipError_t launch_prep_sweep(const FusedArgs &a, hipStream_t s, int waves = 8);
 
 // after a compacting launch: group count of the compacted set, padding of its last group, counter reset
 void launch_phase_finish(void *cq, float *ctlo, float *cthi, int *cmap, unsigned *ccount, unsigned *ngroups_dst,

@@ -30,7 +30,7 @@ typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
-template <int DP>
+template <int DP, int NW = 8>
 struct F4 {
   static constexpr int NS = (DP + 15) / 16;
   static constexpr int KS = (DP + 6 + 15) / 16;
@@ -40,9 +40,14 @@ struct F4 {
   static constexpr int NLT = NS + (NE > 1 ? NS - 2 : 0);
   static constexpr int NPC = (DP + 3) / 4;
   static constexpr size_t r16(size_t x) { return (x + 15) / 16 * 16; }
-  static constexpr size_t WAVE = r16((size_t)NPC * 1024 + 512);
+  // row buffer of a wave: 8 waves per workgroup -- whole 1 KiB pieces (the last one overshoots the 32 rows); 4 waves per
+  // workgroup -- exactly the 32 rows (the lanes of a piece that lie behind them are masked out of the request), so that TWO
+  // such workgroups fit one CU's 160 KiB (d = 50: 2 x 80 960 B)
+  static constexpr size_t WAVE = NW == 8 ? r16((size_t)NPC * 1024 + 512) : r16((size_t)32 * DP * 8);
   static constexpr size_t FRAG = (size_t)(2 * NT * NS + 2 * NLT) * 1024 + (size_t)(32 * NE + 32 * NT) * 4 + (size_t)(16 * NS) * 8;
-  static constexpr size_t LDS = r16(FRAG) + 8 * WAVE + 64;   // + the workgroup's compaction counts (all LDS in the dynamic region)
+  // + the workgroup's compaction counts (all LDS in the dynamic region); the operand reads of the padded coordinates
+  // (k >= d, values discarded) reach up to 16 NS - d doubles behind the last wave's rows: they stay inside the allocation
+  static constexpr size_t LDS = r16(FRAG) + NW * WAVE + 64 + (NW == 8 ? 0 : 128);
 };
 
 __host__ __device__ inline int f4_column(int t, int i) {
@@ -73,9 +78,9 @@ __device__ __forceinline__ void pin_step() {
 
 }  // namespace
 
-template <int DP>
-__global__ __launch_bounds__(512, 1) void k_prep_sweep(FusedArgs a) {
-  using C = F4<DP>;
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedArgs a) {
+  using C = F4<DP, NW>;
   constexpr int NS = C::NS, NT = C::NT, NE = C::NE, KS = C::KS, QW = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsf[];
   const uint4 *Th = reinterpret_cast<const uint4 *>(ldsf);
@@ -91,8 +96,17 @@ __global__ __launch_bounds__(512, 1) void k_prep_sweep(FusedArgs a) {
   double *xs = reinterpret_cast<double *>(area);
   const int d = a.p.d;
   constexpr float up = 1.0f + 0x1p-18f, dn = 1.0f - 0x1p-18f;
-  unsigned *wg_keep = reinterpret_cast<unsigned *>(ldsf + C::r16(C::FRAG) + 8 * C::WAVE);   // [8] + base
+  unsigned *wg_keep = reinterpret_cast<unsigned *>(ldsf + C::r16(C::FRAG) + NW * C::WAVE);   // [NW] + base
   unsigned &wg_base = wg_keep[8];
+  // diagnostics (mlf_region_debug_fused_stamps): shader-clock stamps of ONE wave's stage boundaries
+  const bool stamp_on = a.stamps != nullptr && blockIdx.x == a.stamp_block && wv == 0;
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (stamp_on) {   // wave-uniform
+      const unsigned long long t = __builtin_readcyclecounter();
+      if (lane == 0) a.stamps[k] = t;
+    }
+  };
+  stamp(0);
 
   const double sigma = a.p.stats[0];
   const bool sig_ok = sigma >= 0x1p-60 && sigma <= 0x1p60;
@@ -105,9 +119,10 @@ __global__ __launch_bounds__(512, 1) void k_prep_sweep(FusedArgs a) {
     uint4 *dst = reinterpret_cast<uint4 *>(ldsf);
     const uint4 *srcT = reinterpret_cast<const uint4 *>(a.p.TtF);
     const uint4 *srcL = reinterpret_cast<const uint4 *>(a.p.LtF);
-    for (int e = tid; e < 2 * NT * NS * 64; e += 512) dst[e] = srcT[e];
-    for (int e = tid; e < 2 * C::NLT * 64; e += 512) dst[2 * NT * NS * 64 + e] = srcL[e];
+    for (int e = tid; e < 2 * NT * NS * 64; e += 64 * NW) dst[e] = srcT[e];
+    for (int e = tid; e < 2 * C::NLT * 64; e += 64 * NW) dst[2 * NT * NS * 64 + e] = srcL[e];
   }
+  static_assert(32 * NE <= 64 * NW && 32 * NT <= 64 * NW && 16 * NS <= 64 * NW, "one thread per constant");
   if (tid < 32 * NE) y0l[tid] = a.p.y0[tid];
   if (tid < 32 * NT) {
     const int col = f4_column(tid >> 5, tid & 31);
@@ -117,7 +132,7 @@ __global__ __launch_bounds__(512, 1) void k_prep_sweep(FusedArgs a) {
 
   const long long np = a.p.np;
   const long long ngroups = (np + 31) / 32;
-  const long long set = (long long)blockIdx.x * 8 + wv;
+  const long long set = (long long)blockIdx.x * NW + wv;
   const long long g0 = set * QW;
   const long long total = np * (long long)d;
   typedef __attribute__((address_space(1))) const void gptr_t;
@@ -125,10 +140,19 @@ __global__ __launch_bounds__(512, 1) void k_prep_sweep(FusedArgs a) {
   auto fetch_group = [&](long long grp) __attribute__((always_inline)) {
     if (grp >= ngroups) return;
     const long long base = grp * 32 * (long long)d;
-    if (base + 128 * C::NPC <= total) {
+    if (NW == 8 && base + 128 * C::NPC <= total) {
 #pragma unroll
       for (int i = 0; i < C::NPC; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t *)(a.p.pts + base + 2 * (lane + 64 * i)), (lptr_t *)(area + i * 1024), 16, 0, 0);
+    } else if (NW != 8 && base + 32 * (long long)d <= total) {   // the group's 32 rows lie inside the batch: only they are requested
+      const int nfull = (16 * d) >> 6, rem = (16 * d) & 63;   // whole 1 KiB pieces of the 32 rows, 16-byte units of the last one
+#pragma unroll
+      for (int i = 0; i < C::NPC; ++i) {
+        if (i < nfull)        // (scalar conditions: no per-lane compare per piece)
+          __builtin_amdgcn_global_load_lds((gptr_t *)(a.p.pts + base + 2 * (lane + 64 * i)), (lptr_t *)(area + i * 1024), 16, 0, 0);
+        else if (i == nfull && lane < rem)
+          __builtin_amdgcn_global_load_lds((gptr_t *)(a.p.pts + base + 2 * (lane + 64 * i)), (lptr_t *)(area + i * 1024), 16, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < C::NPC; ++i) {
@@ -143,6 +167,7 @@ __global__ __launch_bounds__(512, 1) void k_prep_sweep(FusedArgs a) {
   };
   fetch_group(g0);
   __syncthreads();   // fragments and constants are in LDS
+  stamp(1);
 
   const float sqrt_k = __builtin_sqrtf((float)(16 * KS));
   const float namax = (float)a.p.stats[1] * up;
@@ -198,6 +223,7 @@ __global__ __launch_bounds__(512, 1) void k_prep_sweep(FusedArgs a) {
   if (g0 < ngroups) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    stamp(2);
     dn2a = operands();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -329,9 +355,11 @@ __global__ __launch_bounds__(512, 1) void k_prep_sweep(FusedArgs a) {
         a.p.best[p] = kNone;
       }
       // operands of the next group (its rows have been on their way since this one's were read); then the one after sets out
+      stamp(3 + 2 * g);
       if (g + 1 < QW && grp + 1 < ngroups) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        stamp(4 + 2 * g);
         dn2a = operands();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -399,6 +427,7 @@ __global__ __launch_bounds__(512, 1) void k_prep_sweep(FusedArgs a) {
     int o0 = tstart * kTileBytes, o1 = next_off(o0), o2 = next_off(o1);
     load_tile(A0, o0);
     load_tile(A1, o1);
+    stamp(10);
     for (int it = 0; it < ntl; it += 3) {
       load_tile(A2, o2);
       tile(A0);
@@ -414,6 +443,7 @@ __global__ __launch_bounds__(512, 1) void k_prep_sweep(FusedArgs a) {
     }
   }
 
+  stamp(11);
   // ---- C. certain hits -> best; the rest goes on with its minimum (one atomic per workgroup)
   unsigned keepm[QW];
   int qmn[QW];
@@ -438,7 +468,7 @@ __global__ __launch_bounds__(512, 1) void k_prep_sweep(FusedArgs a) {
   __syncthreads();
   if (tid == 0) {
     unsigned all = 0u;
-    for (int w = 0; w < 8; ++w) all += wg_keep[w];
+    for (int w = 0; w < NW; ++w) all += wg_keep[w];
     wg_base = all ? atomicAdd(a.ccount, all) : 0u;
   }
   __syncthreads();
@@ -472,36 +502,41 @@ __global__ __launch_bounds__(512, 1) void k_prep_sweep(FusedArgs a) {
       base += (unsigned)__popc(keepm[g]);
     }
   }
+  stamp(12);
 }
 
 bool fused_usable(int dp) { return dp >= 2 && dp <= 56 && (dp & 1) == 0; }
 
-hipError_t launch_prep_sweep(const FusedArgs &a, hipStream_t s) {
+template <int D, int NW>
+static hipError_t launch_prep_sweep_t(const FusedArgs &a, long long nsets, hipStream_t s) {
+  constexpr size_t lds = F4<D, NW>::LDS;
+  static_assert(lds <= 160 * 1024 - 64, "LDS budget");   // NW = 4: two workgroups per CU up to d = 50 (2 x 81 088 B); 52, 56: one
+  static DeviceGrant grant;
+  if (hipError_t e = grant.ensure([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_sweep<D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      }))
+    return e;
+  if (a.p.ks != F4<D, NW>::KS) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((nsets + NW - 1) / NW));
+  hipLaunchKernelGGL((k_prep_sweep<D, NW>), grid, dim3(64 * NW), lds, s, a);
+  return hipGetLastError();
+}
+
+// waves: 8 = one workgroup of 8 waves per CU; 4 = workgroups of 4 waves, two per CU (which fall out of step: one streams rows
+// while the other multiplies)
+hipError_t launch_prep_sweep(const FusedArgs &a, hipStream_t s, int waves) {
   if (a.p.np <= 0) return hipSuccess;
   const long long ngroups = (a.p.np + 31) / 32;
   const long long nsets = (ngroups + 3) / 4;
-  const dim3 grid((unsigned)((nsets + 7) / 8));
   switch (a.p.dp) {
-#define X(D)                                                                                                         \
-  case D: {                                                                                                          \
-    constexpr size_t lds = F4<D>::LDS;                                                                               \
-    static_assert(lds <= 160 * 1024 - 64, "LDS budget");                                                             \
-    static DeviceGrant grant;                                                                                        \
-    if (hipError_t e = grant.ensure([] {                                                                             \
-          return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_sweep<D>),                               \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-        }))                                                                                                          \
-      return e;                                                                                                      \
-    if (a.p.ks != F4<D>::KS) return hipErrorInvalidValue;                                                            \
-    hipLaunchKernelGGL((k_prep_sweep<D>), grid, dim3(512), lds, s, a);                                               \
-    break;                                                                                                           \
-  }
+#define X(D) \
+  case D:    \
+    return waves == 4 ? launch_prep_sweep_t<D, 4>(a, nsets, s) : launch_prep_sweep_t<D, 8>(a, nsets, s);
     MLF_FOR_EACH_DP_MID(X)
 #undef X
     default:
       return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
 
 }  // namespace mlf

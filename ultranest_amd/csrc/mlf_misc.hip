@@ -1,6 +1,7 @@
 // mlf_misc.hip -- layout, reduction and likelihood kernels around the two distance kernels.
 // Compiled with -ffp-contract=off; fused multiply-adds appear only where written as fma().
 #include "mlf_misc.hpp"
+#include "mlf_loglike_dev.hpp"
 
 #include <math.h>
 
@@ -873,38 +874,6 @@ void launch_boot_moments(const double *u, int n, int d, const uint8_t *selected,
 // 64*d*8-byte block -- into LDS with fully coalesced loads (row stride d+1 doubles: conflict-free
 // lane = row reads) and evaluates from there.  Tolerance class (1e-12 relative): numpy's pairwise
 // sum / libm cos are not bit-reproduced.
-__device__ __forceinline__ double loglike_row(int kind, const double *x, int d, const double *aux,
-                                              double sigma) {
-  if (kind == 0) {  // docs/gauss.py:25-27
-    double s = 0.0;
-    for (int k = 0; k < d; ++k) {
-      const double z = (x[k] - aux[k]) / sigma;
-      s += z * z;
-    }
-    return -0.5 * s - 0.5 * log(2.0 * M_PI * sigma * sigma) * (double)d;
-  }
-  if (kind == 1) {  // examples/testeggbox.py:9-11
-    double chi = 1.0;
-    for (int k = 0; k < d; ++k) chi *= cos(x[k] / 2.0);
-    const double base = 2.0 + chi;
-    const double b2 = base * base;
-    return b2 * b2 * base;
-  }
-  if (kind == 2) {  // examples/test_PopSliceSampler.py:69-71
-    double chi = 1.0;
-    for (int k = 0; k < d; ++k) chi *= cos(x[k]);
-    return chi * chi;
-  }
-  double s = 0.0;  // examples/testrosenbrock.py:10-13
-  for (int k = 0; k + 1 < d; ++k) {
-    const double av = x[k], bv = x[k + 1];
-    const double t = bv - av * av;
-    const double w = 1.0 - av;
-    s += 100.0 * (t * t) + w * w;
-  }
-  return -2.0 * s;
-}
-
 __global__ __launch_bounds__(128) void k_loglike(int kind, const double *params, int d, long long n,
                                                  const double *aux, double sigma, double *like) {
   extern __shared__ __attribute__((aligned(16))) double rows[];   // [2 waves][64][d + 1]

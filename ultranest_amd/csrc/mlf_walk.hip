@@ -11,6 +11,7 @@
 
 #include <math.h>
 
+#include "mlf_loglike_dev.hpp"
 #include "mlf_philox_dev.hpp"
 
 namespace mlf {
@@ -426,11 +427,8 @@ __device__ __forceinline__ void dw_move_distance(const WalkState &w, const WalkL
 }
 
 // evolve, second half (evolve_update) + PopulationSliceSampler.advance bookkeeping
-// (popstepsampler.py:585-603) + move diagnostics (diagnose_move_distances :64-94)
-__global__ __launch_bounds__(64) void k_walk_update(WalkState w, double Lmin, const StepParams *sp, WalkLayer ly) {
-  const int lane = threadIdx.x;
-  if (sp) Lmin = sp->Lmin;
-  for (int i = blockIdx.x; i < w.P; i += gridDim.x) {
+// (popstepsampler.py:585-603) + move diagnostics (diagnose_move_distances :64-94) for ONE walker, by the wave that owns it
+__device__ void dw_update(const WalkState &w, int i, int lane, double Lmin, const WalkLayer &ly) {
   // every lane reads the walker's scalars and derives the same decision; lane 0 writes them back
   const bool movable = w.movable[i] != 0;
   const bool hit = w.acceptable[i] != 0 && w.Lnew[i] > Lmin;
@@ -455,14 +453,19 @@ __global__ __launch_bounds__(64) void k_walk_update(WalkState w, double Lmin, co
       w.allL[(size_t)i * w.G + g0 + 1] = Lnew;
     }
   }
-  if (!success) continue;
+  if (!success) return;
   const double *un = w.unew + (size_t)i * w.d;
   double *dst = w.allu + ((size_t)i * w.G + g0 + 1) * w.d;
   for (int k = lane; k < w.d; k += 64) dst[k] = un[k];
   for (int k = lane; k < w.nparams; k += 64) w.currentp[(size_t)i * w.nparams + k] = w.pnew[(size_t)i * w.nparams + k];
   // move diagnostics of this step while the wave still owns the walker (a second launch re-read all of this)
   if (ly.kind >= 0) dw_move_distance(w, ly, i, lane, w.allu + ((size_t)i * w.G + g0) * w.d, un);
-  }
+}
+
+__global__ __launch_bounds__(64) void k_walk_update(WalkState w, double Lmin, const StepParams *sp, WalkLayer ly) {
+  const int lane = threadIdx.x;
+  if (sp) Lmin = sp->Lmin;
+  for (int i = blockIdx.x; i < w.P; i += gridDim.x) dw_update(w, i, lane, Lmin, ly);
 }
 
 // step statistics, stage 1: every workgroup reduces 1024 walkers to one row of partial sums
@@ -640,12 +643,8 @@ __global__ __launch_bounds__(64) void k_walk_restart_philox(WalkState w, const d
 // proposal, prior transform.  was_starting feeds the ring-index shift in the harvest kernel.  step_back
 // looks at all G chain slots: slots past a walker's generation hold NaN, so this equals the reference's
 // window of max(generation) + 1 slots.
-__global__ __launch_bounds__(64) void k_walk_prologue(WalkState w, const double *live, const double *Ls, int nlive,
-                                                      int dirkind, WalkDirData dd, int tkind, double ta, double tb,
-                                                      uint8_t *was_starting, StepParams p, const StepParams *sp) {
-  const int lane = threadIdx.x;
-  if (sp) p = *sp;
-  for (int i = blockIdx.x; i < w.P; i += gridDim.x) {
+__device__ void dw_prologue(const WalkState &w, int i, int lane, const double *live, const double *Ls, int nlive, int dirkind,
+                            const WalkDirData &dd, int tkind, double ta, double tb, uint8_t *was_starting, const StepParams &p) {
   long long gen = w.generation[i];
   double t = w.currentt[i];
   // all per-walker scalars are requested up front: one memory round trip instead of one per stage
@@ -675,7 +674,183 @@ __global__ __launch_bounds__(64) void k_walk_prologue(WalkState w, const double 
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   dw_propose(w, i, lane, nullptr, p.seed, p.offset, gen, t, left, right, sl, sr, tkind, ta, tb);
+}
+
+__global__ __launch_bounds__(64) void k_walk_prologue(WalkState w, const double *live, const double *Ls, int nlive,
+                                                      int dirkind, WalkDirData dd, int tkind, double ta, double tb,
+                                                      uint8_t *was_starting, StepParams p, const StepParams *sp) {
+  const int lane = threadIdx.x;
+  if (sp) p = *sp;
+  for (int i = blockIdx.x; i < w.P; i += gridDim.x)
+    dw_prologue(w, i, lane, live, Ls, nlive, dirkind, dd, tkind, ta, tb, was_starting, p);
+}
+
+// ------------------------------------------------------------------ several rounds per launch ----
+// PopulationSliceSampler.__next__ advances every walker by ONE likelihood evaluation and then looks at the walker the ring
+// index points to (popstepsampler.py:610-697); the driver calls it again and again until that walker has finished its
+// nsteps (integrator.py:1839-1950) -- with the threshold, the live points and the scale unchanged in between.  On a GPU each
+// such call is a host round trip (72 us at popsize 1024: 96 % of a d = 10 eggbox run).  Between two harvests the walkers
+// do not interact, so the rounds of one walker can run back to back inside the wave that owns it:
+//   k_walk_round0   every walker: round 0 (step_back, restart, new slice, proposal, prior transform, likelihood, update)
+//   k_walk_ring     one workgroup: the ring index skips restarting walkers exactly as k_walk_harvest does; the ring walker
+//                   then runs rounds 1, 2, ... ALONE until it has finished (or max_rounds): that fixes R, the number of
+//                   rounds the reference's loop would have made; harvest of the record, ring index advanced
+//   k_walk_rest     every other walker: rounds 1 ... R - 1
+//   k_walk_round_stats  per round: the step statistics of that round (one row of the sampler's logstat each)
+// Round r draws from the Philox counters of call r of the call-by-call path (offset + r * per_call), and every stage is
+// the same device function, so the state after the launch sequence is bit for bit the state after R calls of
+// mlf_walkers_step_dev (tests/test_popstepsampler.py::test_rounds_equal_single_steps).
+__device__ void dw_round(const RoundsArgs &a, int i, int lane, int r, const StepParams &p0) {
+  StepParams p = p0;
+  p.offset = p0.offset + (unsigned long long)r * a.per_call;
+  dw_prologue(a.w, i, lane, a.live, a.Ls, a.nlive, a.dirkind, a.dd, a.tkind, a.ta, a.tb, a.was_starting, p);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // (the call-by-call path evaluates every walker's row, acceptable or not; the value of a row that is not acceptable is
+  // never looked at: update_walker's `hit` tests acceptable first)
+  const double L = loglike_wave(a.lkind, a.w.pnew + (size_t)i * a.w.nparams, a.w.d, a.aux, a.sigma, lane);
+  if (lane == 0) a.w.Lnew[i] = L;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  dw_update(a.w, i, lane, p.Lmin, a.ly);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane == 0) {
+    const uint8_t succ = a.w.success[i];
+    a.rflags[(size_t)r * a.w.P + i] = (uint8_t)((a.w.movable[i] ? 1 : 0) | (a.w.acceptable[i] ? 2 : 0) | (succ ? 4 : 0) |
+                                                (a.was_starting[i] ? 8 : 0));
+    a.rdist2[(size_t)r * a.w.P + i] = a.w.dist2[i];
   }
+}
+
+__global__ __launch_bounds__(64) void k_walk_round0(RoundsArgs a) {
+  const StepParams p = *a.sp;
+  for (int i = blockIdx.x; i < a.w.P; i += gridDim.x) dw_round(a, i, threadIdx.x, 0, p);
+}
+
+__global__ __launch_bounds__(256) void k_walk_ring(RoundsArgs a) {
+  __shared__ int s_n[256];
+  __shared__ long long s_ring;
+  const WalkState &w = a.w;
+  const StepParams p = *a.sp;
+  int n = 0;
+  for (int i = threadIdx.x; i < w.P; i += 256) n += a.was_starting[i] ? 1 : 0;
+  s_n[threadIdx.x] = n;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_n[threadIdx.x] += s_n[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {   // setup_start's ring shift (:456-462), as k_walk_harvest makes it
+    long long r = *a.ring;
+    if (s_n[0] > 0 && s_n[0] < w.P)
+      for (int guard = 0; guard < w.P && a.was_starting[r]; ++guard) r = (r + 1) % w.P;
+    s_ring = r;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  const int ring = (int)s_ring;
+  int R = 1;
+  // rounds 1 ...: the ring walker alone.  In those rounds nothing restarts that did not restart in round 0 (same
+  // threshold, same live points), so the ring index stays where round 0 left it
+  while (w.generation[ring] != (long long)(w.G - 1) && R < a.max_rounds) {
+    dw_round(a, ring, lane, R, p);
+    ++R;
+  }
+  const bool found = w.generation[ring] == (long long)(w.G - 1);
+  const size_t row = ((size_t)ring * w.G + (w.G - 1)) * w.d;
+  double *rec = a.rec;
+  if (lane == 0) {
+    a.ctl[0] = R;
+    a.ctl[1] = ring;
+    a.ctl[2] = found ? 1 : 0;
+    rec[0] = found ? 1.0 : 0.0;
+    rec[1] = found ? w.allL[(size_t)ring * w.G + (w.G - 1)] : qnan();
+    rec[2] = w.left[ring];
+    rec[3] = w.right[ring];
+    rec[4] = (double)R;
+  }
+  if (found) {
+    for (int k = lane; k < w.d; k += 64) rec[9 + k] = w.allu[row + k];
+    for (int k = lane; k < w.nparams; k += 64) rec[9 + w.d + k] = w.currentp[(size_t)ring * w.nparams + k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (found) {   // popstepsampler.py:678-681
+    for (int e = lane; e < w.G * w.d; e += 64) w.allu[(size_t)ring * w.G * w.d + e] = qnan();
+    for (int e = lane; e < w.G; e += 64) w.allL[(size_t)ring * w.G + e] = qnan();
+    if (lane == 0) {
+      w.generation[ring] = -1;
+      w.currentt[ring] = qnan();
+    }
+  }
+  if (lane == 0) {   // shift(), :605-609
+    const long long next = found ? ((long long)ring + 1) % w.P : (long long)ring;
+    *a.ring = next;
+    rec[9 + w.d + w.nparams] = (double)next;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_walk_rest(RoundsArgs a) {
+  const StepParams p = *a.sp;
+  const int R = a.ctl[0], ring = a.ctl[1];
+  if (R <= 1) return;
+  for (int i = blockIdx.x; i < a.w.P; i += gridDim.x) {
+    if (i == ring) continue;
+    for (int r = 1; r < R; ++r) dw_round(a, i, threadIdx.x, r, p);
+  }
+}
+
+// rows[r] = (nc, nmovable, nsuccess, nfar, sum log(dist / ref + 1e-10)) of round r, summed in k_walk_stats' order per
+// 1024-walker chunk and k_walk_harvest's order over the chunks (P <= 1024: one chunk; the sums are then the same doubles)
+__global__ __launch_bounds__(256) void k_walk_round_stats(RoundsArgs a) {
+  __shared__ double part[256][5];
+  const int r = blockIdx.x;
+  if (r >= a.ctl[0]) return;
+  const double r2 = a.sp->r2;
+  const double ref = sqrt(r2);
+  const int P = a.w.P;
+  double tot[5] = {0, 0, 0, 0, 0};
+  for (int i0 = 0; i0 < P; i0 += kStatsChunk) {
+    double nc = 0, nmov = 0, nsucc = 0, nfar = 0, slog = 0;
+    for (int j = threadIdx.x; j < kStatsChunk; j += 256) {
+      const int i = i0 + j;
+      if (i >= P) continue;
+      const uint8_t f = a.rflags[(size_t)r * P + i];
+      if (!(f & 1)) continue;
+      nmov += 1;
+      nc += (f & 2) ? 1 : 0;
+      if (f & 4) {
+        nsucc += 1;
+        const double d2 = a.rdist2[(size_t)r * P + i];
+        if (!isnan(d2)) {
+          nfar += (d2 > r2) ? 1 : 0;
+          slog += log(sqrt(d2) / ref + 1e-10);
+        }
+      }
+    }
+    part[threadIdx.x][0] = nc;
+    part[threadIdx.x][1] = nmov;
+    part[threadIdx.x][2] = nsucc;
+    part[threadIdx.x][3] = nfar;
+    part[threadIdx.x][4] = slog;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off)
+        for (int c = 0; c < 5; ++c) part[threadIdx.x][c] += part[threadIdx.x + off][c];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0)
+      for (int c = 0; c < 5; ++c) tot[c] += part[0][c];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int c = 0; c < 5; ++c) a.rows[(size_t)r * 5 + c] = tot[c];
 }
 
 // ------------------------------------------------------------------ stateless forms ------------
@@ -911,6 +1086,13 @@ void launch_walk_expand(const WalkState &w, const unsigned *blk, const double *p
 
 void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStream_t s, const StepParams *sp) {
   hipLaunchKernelGGL(k_walk_update, walker_grid(w.P), dim3(64), 0, s, w, Lmin, sp, layer);
+}
+
+void launch_walk_rounds(const RoundsArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(k_walk_round0, walker_grid(a.w.P), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_walk_ring, dim3(1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_walk_rest, walker_grid(a.w.P), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_walk_round_stats, dim3((unsigned)a.max_rounds), dim3(256), 0, s, a);
 }
 
 void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, double *partials,

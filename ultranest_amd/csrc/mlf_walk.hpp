@@ -66,6 +66,33 @@ struct WalkDirData {
   const double *std;       // region.u.std(axis=0) (kind 1)
 };
 
+// several rounds of the whole-step path in one launch sequence (mlf_walk.hip: k_walk_round0 / k_walk_ring / k_walk_rest /
+// k_walk_round_stats)
+struct RoundsArgs {
+  WalkState w;
+  const double *live, *Ls;   // device copy of the live points and their likelihoods (restarts, differential directions)
+  int nlive;
+  int dirkind;
+  WalkDirData dd;
+  int tkind;
+  double ta, tb;
+  int lkind;
+  const double *aux;
+  double sigma;
+  WalkLayer ly;
+  uint8_t *was_starting;     // [P]
+  const StepParams *sp;      // device: Lmin, scale, dirscale, r2, seed, offset of round 0
+  long long *ring;           // device ring index
+  int *ctl;                  // [0] rounds made R, [1] ring walker of this call, [2] harvested
+  uint8_t *rflags;           // [max_rounds][P] bit0 movable, bit1 acceptable, bit2 success, bit3 was (re)starting
+  double *rdist2;            // [max_rounds][P] move distance^2 of the walkers that succeeded in the round
+  double *rows;              // [max_rounds][5] step statistics per round
+  double *rec;               // [0] harvested, [1] L, [2] left, [3] right, [4] R, [9 ..] u (d), p (nparams), next ring index
+  int max_rounds;
+  unsigned long long per_call;   // Philox counters one call of the call-by-call path consumes
+};
+void launch_walk_rounds(const RoundsArgs &a, hipStream_t s);
+
 void launch_walk_reset(const WalkState &w, hipStream_t s);
 // step_back + snapshot: flags[i] = bit0 !isfinite(currentt) | bit1 searching_left | bit2 searching_right
 void launch_walk_step_back(const WalkState &w, double Lmin, long long *gmax_scratch, uint8_t *flags, hipStream_t s,

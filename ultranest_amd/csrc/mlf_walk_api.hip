@@ -43,6 +43,11 @@ struct mlf_walkers {
   double *h_rec = nullptr;         // pinned
   DevBuf d_sp;
   std::vector<unsigned long long> gkey;
+  // several rounds per call (mlf_walkers_rounds_dev)
+  DevBuf r_ctl, r_flags, r_dist2, r_out, r_sp;
+  StepParams *h_rsp = nullptr;     // pinned
+  double *h_rout = nullptr;        // pinned: record + per-round statistics
+  size_t h_rout_doubles = 0;
 };
 
 namespace {
@@ -182,6 +187,9 @@ int mlf_walkers_destroy(mlf_walkers *w) {
                    &w->lay_wrap, &w->liveL, &w->ring, &w->partials};
   for (DevBuf *b : all) b->release();
   w->d_sp.release();
+  for (DevBuf *b : {&w->r_ctl, &w->r_flags, &w->r_dist2, &w->r_out, &w->r_sp}) b->release();
+  if (w->h_rsp) (void)hipHostFree(w->h_rsp);
+  if (w->h_rout) (void)hipHostFree(w->h_rout);
   if (w->gexec) (void)hipGraphExecDestroy(w->gexec);
   if (w->h_sp) (void)hipHostFree(w->h_sp);
   if (w->h_rec) (void)hipHostFree(w->h_rec);
@@ -529,6 +537,94 @@ int mlf_walkers_step_graph(mlf_walkers *w, double Lmin, double scale, int dirkin
   memcpy(rec, w->h_rec, nrec * sizeof(double));
   const uint64_t per = (uint64_t)((w->d + 1) / 2 + 2);
   *next_offset = offset + (uint64_t)w->P * (per > 64 ? per : 64);
+  return 0;
+}
+
+int mlf_walkers_rounds_dev(mlf_walkers *w, double Lmin, double scale, int dirkind, double dirscale, uint64_t seed,
+                           uint64_t offset, int tkind, double ta, double tb, int lkind, const double *aux, double sigma,
+                           int max_rounds, double *rec, double *round_rows, int *rounds, uint64_t *next_offset) {
+  if (!w || !rec || !round_rows || !rounds || !next_offset) return ctx_fail_arg(MLF_E_BADARG, "null pointer");
+  if (!w->have_liveL) return ctx_fail_arg(MLF_E_STATE, "mlf_walkers_set_live not called");
+  if (dirkind < 0 || dirkind > DIR_MIXTURE) return ctx_fail_arg(MLF_E_BADARG, "unknown direction kind");
+  if (tkind < 0 || tkind > 2 || lkind < 0 || lkind > 3) return ctx_fail_arg(MLF_E_BADARG, "unknown transform / likelihood kind");
+  if (lkind == 0 && !aux) return ctx_fail_arg(MLF_E_BADARG, "the Gaussian likelihood needs its centres");
+  if (max_rounds < 1) return ctx_fail_arg(MLF_E_BADARG, "max_rounds must be positive");
+  const bool need_axes = dirkind == DIR_REGION_ORIENTED || dirkind == DIR_REGION_RANDOM || dirkind == DIR_MIXTURE;
+  if ((need_axes && !w->have_axes) || (dirkind == DIR_CUBE_ORIENTED_SCALED && !w->have_std))
+    return ctx_fail_arg(MLF_E_STATE, "mlf_walkers_set_direction_data has not provided what this direction kind needs");
+  if (int rc = ensure_params(w, (size_t)w->d)) return rc;
+  // the per-round flag / distance arrays are [max_rounds][P]: keep them within 64 MiB
+  const size_t per_round = (size_t)w->P * 9;
+  const size_t cap = ((size_t)64 << 20) / per_round;
+  if ((size_t)max_rounds > cap) max_rounds = cap < 1 ? 1 : (int)cap;
+  if (max_rounds > 4096) max_rounds = 4096;
+  hipStream_t s = ctx_stream();
+  if (!w->ring.p) {
+    CK(w->ring.reserve(8));
+    CK(hipMemsetAsync(w->ring.p, 0, 8, s));
+  }
+  const size_t nrec = 10 + 2 * (size_t)w->d;
+  const size_t nout = nrec + 5 * (size_t)max_rounds;
+  if (!w->h_rsp) CK(hipHostMalloc(reinterpret_cast<void **>(&w->h_rsp), sizeof(StepParams), hipHostMallocDefault));
+  if (w->h_rout_doubles < nout) {
+    if (w->h_rout) CK(hipHostFree(w->h_rout));
+    w->h_rout = nullptr;
+    CK(hipHostMalloc(reinterpret_cast<void **>(&w->h_rout), nout * sizeof(double), hipHostMallocDefault));
+    w->h_rout_doubles = nout;
+  }
+  CK(w->r_sp.reserve(sizeof(StepParams)));
+  CK(w->r_ctl.reserve(4 * sizeof(int)));
+  CK(w->r_flags.reserve((size_t)max_rounds * w->P));
+  CK(w->r_dist2.reserve((size_t)max_rounds * w->P * sizeof(double)));
+  CK(w->r_out.reserve(nout * sizeof(double)));
+  CK(w->aux.reserve((size_t)w->d * 8));
+  if (aux)
+    if (int rc = upload(w->aux, aux, (size_t)w->d * 8, s)) return rc;
+  w->h_rsp->Lmin = Lmin;
+  w->h_rsp->scale = scale;
+  w->h_rsp->dirscale = dirscale;
+  w->h_rsp->r2 = w->r2;
+  w->h_rsp->seed = seed;
+  w->h_rsp->offset = offset;
+  CK(hipMemcpyAsync(w->r_sp.p, w->h_rsp, sizeof(StepParams), hipMemcpyHostToDevice, s));
+  const uint64_t per = (uint64_t)((w->d + 1) / 2 + 2);
+  RoundsArgs a{};
+  a.w = state_of(w);
+  a.live = w->live.as<double>();
+  a.Ls = w->liveL.as<double>();
+  a.nlive = w->nlive;
+  a.dirkind = dirkind;
+  a.dd.axes = w->axes.as<double>();
+  a.dd.live = w->live.as<double>();
+  a.dd.nlive = w->nlive;
+  a.dd.std = w->std.as<double>();
+  a.tkind = tkind;
+  a.ta = ta;
+  a.tb = tb;
+  a.lkind = lkind;
+  a.aux = w->aux.as<double>();
+  a.sigma = sigma;
+  a.ly = layer_of(w);
+  a.was_starting = w->flags.as<uint8_t>();
+  a.sp = w->r_sp.as<StepParams>();
+  a.ring = w->ring.as<long long>();
+  a.ctl = w->r_ctl.as<int>();
+  a.rflags = w->r_flags.as<uint8_t>();
+  a.rdist2 = w->r_dist2.as<double>();
+  a.rec = w->r_out.as<double>();
+  a.rows = w->r_out.as<double>() + nrec;
+  a.max_rounds = max_rounds;
+  a.per_call = (unsigned long long)w->P * (per > 64 ? per : 64);
+  launch_walk_rounds(a, s);
+  CK(hipGetLastError());
+  CK(hipMemcpyAsync(w->h_rout, w->r_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, s));
+  CK(hipStreamSynchronize(s));
+  const int R = (int)w->h_rout[4];
+  if (R < 1 || R > max_rounds) return ctx_fail_arg(MLF_E_STATE, "mlf_walkers_rounds_dev: the device reported an impossible round count");
+  memcpy(rec, w->h_rout, nrec * sizeof(double));
+  memcpy(round_rows, w->h_rout + nrec, (size_t)R * 5 * sizeof(double));
+  *rounds = R;
+  *next_offset = offset + (uint64_t)R * a.per_call;
   return 0;
 }
 

@@ -443,6 +443,14 @@ class DeviceRegion(object):
             stats["stamp7"] = int(st[7])
         return stats
 
+    def fused_stamps(self, block):
+        """Stage stamps (shader cycles, differences to the first) that wave 0 of the k_prep_sweep workgroup selected by the
+        previous call wrote during the last phased batch; selects workgroup `block` for the next batches (None: off)."""
+        out = np.zeros(16, dtype=np.uint64)
+        check(_lib.lib().mlf_region_debug_fused_stamps(self._h, -1 if block is None else int(block), ptr(out), 16))
+        st = out[:13].astype(np.int64)
+        return [int(x - st[0]) if x else None for x in st] if st[0] else None
+
     def time_inside_dev(self, d_pts, npts, d_mask, stream=0, reps=3):
         tot, scan = ctypes.c_float(0), ctypes.c_float(0)
         check(_lib.lib().mlf_region_time_inside_dev(self._h, ctypes.c_void_p(d_pts), npts, ctypes.c_void_p(d_mask),

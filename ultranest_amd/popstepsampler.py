@@ -232,6 +232,30 @@ class _Walkers(object):
         out["ring"] = int(rec[9 + 2 * self.ndim])
         return out
 
+    def rounds_dev(self, Lmin, scale, kind, dirscale, rng, tspec, lspec, max_rounds):
+        """Whole sampler steps on the device until the walker under the ring index has finished (or `max_rounds`):
+        ``mlf_walkers_rounds_dev``.  Returns the record of the LAST round (with "ring" and "rounds") and the per-round
+        statistics rows (rounds, 5): what `rounds` consecutive `step_dev` calls would have returned, one host round trip."""
+        self.nparams = self.ndim
+        tkind, ta, tb = tspec
+        lkind, aux, sigma = lspec
+        rec = np.empty(10 + 2 * self.ndim)
+        if getattr(self, "_round_rows", None) is None or len(self._round_rows) < max_rounds:
+            self._round_rows = np.empty((int(max_rounds), 5))
+        nxt = ctypes.c_uint64(0)
+        nrounds = ctypes.c_int(0)
+        check(_lib.lib().mlf_walkers_rounds_dev(
+            self._h, float(Lmin), float(scale), int(kind), float(dirscale), ctypes.c_uint64(rng.seed), ctypes.c_uint64(rng.offset),
+            int(tkind), float(ta), float(tb), int(lkind), ptr(None if aux is None else f64(aux)), float(sigma), int(max_rounds),
+            ptr(rec), ptr(self._round_rows), ctypes.byref(nrounds), ctypes.byref(nxt)))
+        rng.offset = nxt.value
+        R = nrounds.value
+        rows = self._round_rows[:R]
+        d = self.ndim
+        out = dict(found=rec[0] == 1.0, L=rec[1], left=rec[2], right=rec[3], u=rec[9:9 + d].copy(), p=rec[9 + d:9 + 2 * d].copy(),
+                   ring=int(rec[9 + 2 * d]), rounds=R)
+        return out, rows
+
     def export(self):
         """Host copies of the resident state (tests, debugging)."""
         P, G, d = self.popsize, self.nsteps + 1, self.ndim
@@ -261,6 +285,10 @@ class PopulationSliceSampler(GenericPopulationSampler):
             raise TypeError("device_rng must be an ultranest_amd.regions.DeviceRNG")
         self.device_rng = device_rng
         self.use_graph = True     # whole-step path: replay the kernel sequence as one hipGraph launch
+        # whole-step path: up to this many rounds (= calls of the reference's __next__, which the driver repeats until a
+        # point comes back: integrator.py:1839-1950) per device call, each walker's rounds back to back inside the wave
+        # that owns it; the call returns when the walker under the ring index has finished.  0 / 1: one round per call
+        self.max_rounds = 256
         self._walkers = None
         self._generation = np.zeros(popsize, dtype=int_dtype) - 1
         self._flags = np.ones(popsize, dtype=np.uint8)
@@ -405,7 +433,21 @@ class PopulationSliceSampler(GenericPopulationSampler):
             w.set_live(us, Ls)
             seen["live_age"] = 0
         seen["live_age"] += 1
-        rec = w.step_dev(Lmin, self.scale, device_kind, 1.0, self.device_rng, tspec, lspec, graph=self.use_graph)
+        if self.max_rounds > 1:
+            rec, rows = w.rounds_dev(Lmin, self.scale, device_kind, 1.0, self.device_rng, tspec, lspec, self.max_rounds)
+            have_diag = region.maxradiussq is not None
+            nc = 0
+            for row_nc, nmovable, ns, nfar, sumlog in rows:      # one logstat row per round, as one call each would have made
+                nc += int(row_nc)
+                if ns > 0:
+                    self.logstat.append([ns / max(nmovable, 1), self.scale, self.nsteps,
+                                         nfar / ns if have_diag else 0, np.exp(sumlog / ns) if have_diag else 0])
+                    if self.logfile:
+                        self.logfile.write("rescale\t%.4f\t%.4f\t%g\t%.4f%g\n" % tuple(self.logstat[-1]))
+            rec.update(nc=nc, nsuccess=0)
+            self.rounds_last_call = rec["rounds"]
+        else:
+            rec = w.step_dev(Lmin, self.scale, device_kind, 1.0, self.device_rng, tspec, lspec, graph=self.use_graph)
         out = self._finish_call(rec, region, shift=False)
         self.ringindex = rec["ring"]
         return out
