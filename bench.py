@@ -757,7 +757,7 @@ def main():
                    "parallelism": "proposal rows sharded over " + str(world) + " GPU(s), region replicated",
                    "mfma_prefilter": bool(filter_on),
                    "arithmetic": "inputs, thresholds and every decision that depends on the reference's rounding: binary64 "
-                                 "(non-fused); deciding bounds for the other 99.99 % of the pairs: binary16 operands / "
+                                 "(non-fused); deciding bounds for the other 99.99 %% of the pairs: binary16 operands / "
                                  "binary32 accumulate on the matrix cores, bounded whitening with split binary16 operands; masks bit-identical "
                                  "to the exact FP64 scan (asserted in this run, all %d batches)" % NBATCHES},
         "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],

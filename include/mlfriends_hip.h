@@ -93,6 +93,9 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *   "fused_waves"              8 (default) / 4: waves per workgroup of k_prep_sweep.  8: one workgroup per CU (137 KiB of LDS at d = 50);
  *                              4: 79 KiB per workgroup, two per CU -- workgroups that start and end independently of each other, so
  *                              that one streams proposal rows while the other multiplies
+ *   "fused_variant"            default 1: bit 0 = k_prep_sweep fetches its 28 KiB of matrix fragments by LDS-DMA (every request of a wave
+ *                              under way at once); 0 = by a load / store loop (round 5's form), kept for A/B runs inside ONE process
+ *                              (scripts/fused_ab.py: boxes of the pool differ by 8 % in this kernel)
  *   "mid_max_queries"          default 2048: batches up to this size (and at least "filter_min_queries") run the per-proposal
  *                              stage, the pre-filter sweep, the re-check and the answers in ONE launch (k_inside_mid); 0 = never
  *   "sweep_min"                1 (default): phased batches through the min-only sweep (k_sweep_min: running minima only
@@ -359,6 +362,10 @@ int mlf_walkers_finish_dev(mlf_walkers *w, double Lmin, int tkind, double ta, do
  * device, new slices, proposal, transform + likelihood, update, harvest -- one record back, one
  * synchronisation.  rec has 10 + 2 d doubles: as above, then the ring index after the step. */
 int mlf_walkers_set_live(mlf_walkers *w, const double *us, const double *Ls, size_t nlive);
+/* the rows `rows[0 ... count)` of that device copy replaced (the driver replaces ONE live point per iteration,
+ * integrator.py:2753-2754: uploading the whole set again costs two pageable copies per sampler call); queued on the
+ * library's stream, no synchronisation */
+int mlf_walkers_update_live(mlf_walkers *w, const int64_t *rows, size_t count, const double *us_rows, const double *Ls_rows);
 int mlf_walkers_step_dev(mlf_walkers *w, double Lmin, double scale, int dirkind, double dirscale,
                          uint64_t seed, uint64_t offset, int tkind, double ta, double tb, int lkind,
                          const double *aux, double sigma, double *rec, uint64_t *next_offset);
@@ -380,7 +387,9 @@ int mlf_walkers_step_graph(mlf_walkers *w, double Lmin, double scale, int dirkin
  *   round_rows  max_rounds x 5 doubles, rows 0 ... R - 1 filled: (likelihood evaluations, movable walkers, successes,
  *               far-enough moves, sum log(distance / radius + 1e-10)) of each round -- one row of the sampler's logstat each
  *   *rounds     R.  rec[0] == 0 with R == max_rounds: call again (the driver's loop does exactly that).
- * max_rounds is clamped to 4096 and to 64 MiB of per-round bookkeeping (9 bytes per walker and round). */
+ * max_rounds is clamped to 4096 and to 64 MiB of per-round bookkeeping (9 bytes per walker and round).  Rounds after the first
+ * run with the walker's state in registers where the shapes allow it (even d <= 64, affine layer or none); a NEGATIVE max_rounds
+ * (test hook) forces |max_rounds| rounds through the general form, which passes every stage through global memory. */
 int mlf_walkers_rounds_dev(mlf_walkers *w, double Lmin, double scale, int dirkind, double dirscale,
                            uint64_t seed, uint64_t offset, int tkind, double ta, double tb, int lkind,
                            const double *aux, double sigma, int max_rounds, double *rec, double *round_rows,

@@ -1,5 +1,6 @@
-"""k_prep_sweep with 8 waves per workgroup (one per CU) against 4 (two per CU), C5 batch; stage stamps of single waves.
-    python scripts/fused_ab.py [steps]"""
+"""k_prep_sweep variants against each other INSIDE one process (boxes of the pool differ by 8 % in this kernel), C5 batch;
+stage stamps of single waves.
+    python scripts/fused_ab.py [steps] [name:waves:variant ...]      variant = fused_variant option value"""
 import json
 import os
 import sys
@@ -11,6 +12,7 @@ import bench  # noqa: E402
 from ultranest_amd import _lib  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+configs = [a.split(":") for a in sys.argv[2:]] or [["base", "8", "0"], ["waves4", "4", "0"], ["dma", "8", "1"]]
 dev = torch.device("cuda", 0)
 u, region = bench.build_region(None)
 handle = region._dev.sync(region, True)
@@ -29,11 +31,12 @@ _lib.set_option("filter", 0)
 run(3)
 exact = [m.clone() for m in masks]
 _lib.set_option("filter", 1)
-out = {}
-for rep in range(2):
-    for waves in (8, 4):
-        _lib.set_option("fused_waves", waves)
-        run(150)
+run(300)
+for rep in range(3):
+    for name, waves, variant in configs:
+        _lib.set_option("fused_waves", int(waves))
+        _lib.set_option("fused_variant", int(variant))
+        run(60)
         t0 = time.perf_counter()
         run(steps)
         dt = (time.perf_counter() - t0) / steps
@@ -43,14 +46,15 @@ for rep in range(2):
         run(30)
         lm = handle.timing_filter_launch_ms()
         _lib.set_option("time_filter_launches", 0)
-        per = [float(lm[i::4].mean()) for i in range(4)] if len(lm) % 4 == 0 and len(lm) else []
-        row = dict(fused_waves=waves, ms_per_step=dt * 1e3, masks_equal_exact=ok, launch_ms=per)
-        if rep == 1:
+        per = [round(float(lm[i::4].mean()), 5) for i in range(4)] if len(lm) % 4 == 0 and len(lm) else []
+        row = dict(name=name, fused_waves=int(waves), variant=int(variant), ms_per_step=round(dt * 1e3, 5), masks_equal_exact=ok, launch_ms=per)
+        if rep == 2:
             stamps = {}
-            for blk in (0, 3, 500, 1200, 1900) if waves == 4 else (0, 3, 250, 600, 950):
+            for blk in (3, 600) if int(waves) == 8 else (3, 1200):
                 handle.fused_stamps(blk)
                 run(4)
                 stamps[blk] = handle.fused_stamps(None)
             row["stamps_cycles"] = stamps
         print(json.dumps(row), flush=True)
 _lib.set_option("fused_waves", 8)
+_lib.set_option("fused_variant", 0)

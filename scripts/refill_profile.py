@@ -1,0 +1,36 @@
+"""mlf_region_refill at C5 (N = 4000, d = 50, 2^20 draws inside the wrapping ellipsoid, Gaussian likelihood evaluated in place,
+only the points above the threshold travel back): wall time per batch; under rocprofv3 --kernel-trace --stats its kernels.
+    python scripts/refill_profile.py [reps]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from ultranest_amd import likelihoods  # noqa: E402
+from ultranest_amd.regions import DeviceRNG  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+u, region = bench.build_region(None)
+region.device_rng = DeviceRNG(3)
+loglike = likelihoods.GaussLikelihood(0.5, 0.05, bench.NDIM)
+Ls = loglike(u)
+Lmin = float(np.sort(Ls)[-40])          # only ~1 % of the live-point-like proposals pass: the copy back is small
+n = 1 << 20
+out = {}
+for method, name in ((1, "wrapping_ellipsoid"), (0, "boundingbox")):
+    for _ in range(3):
+        region._dev.refill(region, True, method, n, Lmin, likelihoods.identity_transform.device_spec, loglike.device_spec)
+    t0 = time.perf_counter()
+    kept = nev = 0
+    for _ in range(reps):
+        uu, pp, LL, ne = region._dev.refill(region, True, method, n, Lmin, likelihoods.identity_transform.device_spec, loglike.device_spec)
+        kept += len(LL)
+        nev += ne
+    dt = (time.perf_counter() - t0) / reps
+    out[name] = dict(ms_per_batch=dt * 1e3, draws=n, evaluated_per_batch=nev / reps, kept_per_batch=kept / reps,
+                     draws_per_s=n / dt)
+print(json.dumps(out))

@@ -272,3 +272,31 @@ def recorded_tree_dump(netiter, seed, nroots, nnodes):
         else:
             sys.modules["h5py"] = saved
     return RecordingH5File.written
+
+
+# ---- g16: the two batched population samplers (reference popstepsampler.py:192-358, 746-1001) ----
+BATCHED_SAMPLER_CASES = [
+    # name, class, direction generator, constructor keywords (slice_limit: "scale" = slice_limit_to_scale), popsize, nsteps, d
+    ("walk_random", "PopulationRandomWalkSampler", "generate_random_direction", dict(scale=0.05), 12, 25, 4),
+    ("walk_cube", "PopulationRandomWalkSampler", "generate_cube_oriented_direction", dict(scale=0.05, scale_adapt_factor=0.8), 7, 30, 3),
+    ("slice_random", "PopulationSimpleSliceSampler", "generate_random_direction", dict(), 12, 6, 4),
+    ("slice_mixture_scaled", "PopulationSimpleSliceSampler", "generate_mixture_random_direction",
+     dict(scale=0.5, scale_adapt_factor=0.9, shrink_factor=1.5, slice_limit="scale"), 20, 5, 6),
+    ("slice_region_one", "PopulationSimpleSliceSampler", "generate_region_oriented_direction", dict(max_it=7), 1, 4, 2)]
+
+
+def batched_sampler_problem(mod, d, seed=3, n=200):
+    """live points, region, Gaussian likelihood and threshold of the batched-sampler traces (shared with the tests)"""
+    rs = np.random.RandomState(seed)
+    u = np.clip(0.5 + 0.1 * rs.normal(size=(n, d)), 1e-3, 1 - 1e-3)
+    layer = mod.AffineLayer()
+    layer.optimize(u, u)
+    region = mod.MLFriends(u, layer)
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=10, rng=np.random.RandomState(2))
+    region.create_ellipsoid()
+
+    def loglike(p):
+        return -0.5 * (((p - 0.5) / 0.1) ** 2).sum(axis=1)
+
+    Ls = loglike(u)
+    return u, region, loglike, Ls, float(np.sort(Ls)[20])

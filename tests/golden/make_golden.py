@@ -706,6 +706,30 @@ def g14(ref):
     save("g14_tree_dump", **out)
 
 
+def g16(ref):
+    """PopulationRandomWalkSampler / PopulationSimpleSliceSampler (reference popstepsampler.py:192-358, 746-1001) on a fixed
+    region: 40 calls each from one numpy seed -- points, likelihoods, evaluation counts, final scale, log table, and where
+    the numpy stream stands afterwards."""
+    import ultranest.popstepsampler as pop
+    out = {}
+    for name, cls, direction, kw, popsize, nsteps, d in inputs.BATCHED_SAMPLER_CASES:
+        u, region, loglike, Ls, Lmin = inputs.batched_sampler_problem(ref, d)
+        kw = dict(kw)
+        if kw.get("slice_limit") == "scale":
+            kw["slice_limit"] = pop.slice_limit_to_scale
+        sampler = getattr(pop, cls)(popsize=popsize, nsteps=nsteps, generate_direction=getattr(pop, direction), **kw)
+        np.random.seed(11)
+        res = [sampler.__next__(region, Lmin, u, Ls, lambda x: x * 1.0, loglike) for _ in range(40)]
+        out[name + "_u"] = np.array([r[0] for r in res])
+        out[name + "_p"] = np.array([r[1] for r in res])
+        out[name + "_L"] = np.array([r[2] for r in res])
+        out[name + "_nc"] = np.array([r[3] for r in res], dtype=np.int64)
+        out[name + "_scale"] = np.float64(sampler.scale)
+        out[name + "_logstat"] = np.array(sampler.logstat, dtype=float)
+        out[name + "_next_random"] = np.float64(np.random.uniform())
+    save("g16_batched_samplers", **out)
+
+
 def timing(ref):
     """SURVEY 8(d) / BASELINE.md 3.2: how good a TIMING stand-in is the C restatement (oracle/) for the real Cython path?
     Both on this container's CPU, one core, the 8(d) inputs (N = 4000, d = 50, seed 1), a bounded query sample.  Stored in
@@ -772,7 +796,7 @@ def timing(ref):
     return out
 
 
-GROUPS = dict(g14=g14, g13=g13, g12=g12, g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
+GROUPS = dict(g16=g16, g14=g14, g13=g13, g12=g12, g1=g1, g2=g2, g3=g3, g456=g456, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
 
 if __name__ == "__main__":
     want = sys.argv[1:] or (list(GROUPS) + ["timing"])

@@ -221,10 +221,14 @@ def test_graph_replay_equals_kernel_by_kernel_launches(direction):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("problem,d,direction,max_rounds", [
-    ("gauss", 5, "generate_mixture_random_direction", 64),          # odd d: the likelihood row on one lane
+    ("gauss", 5, "generate_mixture_random_direction", 64),          # odd d: the general form (likelihood row on one lane)
     ("gauss", 8, "generate_cube_oriented_direction", 3),            # the cap is hit: __next__ returns None and is called again
-    ("eggbox", 10, "generate_mixture_random_direction", 256),
+    ("eggbox", 10, "generate_mixture_random_direction", 256),       # even d <= 64: rounds after the first with the state in registers
+    ("eggbox", 10, "generate_mixture_random_direction", -256),      # ... and the same rounds forced through the general form
     ("rosenbrock", 6, "generate_region_random_direction", 17),
+    ("rosenbrock", 50, "generate_differential_direction", 40),
+    ("gauss", 64, "generate_region_oriented_direction", 9),
+    ("gauss", 66, "generate_random_direction", 9),                  # above 64: general form
     ("eggbox", 2, "generate_random_direction", 2)])
 def test_rounds_equal_single_steps(problem, d, direction, max_rounds):
     """mlf_walkers_rounds_dev (every walker's rounds back to back inside its wave, the ring walker deciding how many) against
@@ -273,6 +277,82 @@ def test_rounds_equal_single_steps(problem, d, direction, max_rounds):
     assert log_a.shape == log_b.shape and np.array_equal(log_a, log_b)
     for key in st_a:
         assert np.array_equal(st_a[key], st_b[key], equal_nan=True), key
+
+
+@pytest.mark.gpu
+def test_live_point_copy_follows_row_replacements():
+    """mlf_walkers_update_live (the rows the driver replaced since the last call) leaves the device copy of the live points
+    exactly where a full mlf_walkers_set_live of the new arrays leaves it: two populations, same Philox stream, restarts and
+    differential directions drawn from the copy -- same resident state afterwards; and through the sampler object: live points
+    replaced between calls (as integrator.py:2753-2754 does) against a sampler that re-uploads everything."""
+    import ultranest_amd.popstepsampler as pop
+    from ultranest_amd import likelihoods
+    from ultranest_amd.regions import DeviceRNG
+    d, nlive = 6, 200
+    rs = np.random.RandomState(9)
+    u = np.clip(0.5 + 0.1 * rs.normal(size=(nlive, d)), 1e-3, 1 - 1e-3)
+    loglike = likelihoods.GaussLikelihood(0.5, 0.1, d)
+    region = _gpu_region(u)
+    runs = []
+    for incremental in (True, False):
+        us, Ls = u.copy(), loglike(u)
+        rs2 = np.random.RandomState(10)
+        sampler = pop.PopulationSliceSampler(popsize=48, nsteps=5, generate_direction=pop.generate_differential_direction, scale=0.4,
+                                             device_rng=DeviceRNG(13))
+        out = []
+        for it in range(60):
+            if not incremental:
+                sampler._seen["live_mirror"] = None          # forces the full upload on every call
+            worst = int(np.argmin(Ls))
+            Lmin = Ls[worst]
+            for calls in range(2000):
+                unew, pnew, Lnew, nc = sampler.__next__(region, Lmin, us, Ls, likelihoods.identity_transform, loglike)
+                if unew is not None:
+                    break
+            assert unew is not None, (it, calls)
+            out.append((unew, Lnew))
+            us[worst], Ls[worst] = unew, Lnew                # the driver's replacement of the dead point
+            if it % 7 == 3:                                  # now and then several rows at once
+                k = rs2.randint(nlive, size=3)
+                us[k] = us[k][:, ::-1].copy()
+                Ls[k] = loglike(us[k])
+        runs.append((out, sampler.state(), sampler.device_rng.offset))
+    (a, sa, oa), (b, sb, ob) = runs
+    assert oa == ob
+    for (ua, La), (ub, Lb) in zip(a, b):
+        assert np.array_equal(ua, ub) and La == Lb
+    for key in sa:
+        assert np.array_equal(sa[key], sb[key], equal_nan=True), key
+
+
+@pytest.mark.parametrize("case", ["walk_random", "walk_cube", "slice_random", "slice_mixture_scaled", "slice_region_one"])
+def test_batched_population_samplers_equal_reference(backend, golden, case):
+    """PopulationRandomWalkSampler and PopulationSimpleSliceSampler (reference popstepsampler.py:192-358, 746-1001): the same
+    numpy seed gives the reference's points, likelihoods, evaluation counts, scale, log table and numpy stream position
+    (golden g16, recorded from the reference's classes); the vectorised moves underneath are this package's step functions
+    (HIP kernels on the `hip` backend, the oracle stub here)."""
+    import ultranest_amd.mlfriends as m
+    import ultranest_amd.popstepsampler as pop
+    from golden import inputs as mk
+    g = golden("g16_batched_samplers")
+    name, cls, direction, kw, popsize, nsteps, d = [c for c in mk.BATCHED_SAMPLER_CASES if c[0] == case][0]
+    u, region, loglike, Ls, Lmin = mk.batched_sampler_problem(m, d)
+    kw = dict(kw)
+    if kw.get("slice_limit") == "scale":
+        kw["slice_limit"] = pop.slice_limit_to_scale
+    sampler = getattr(pop, cls)(popsize=popsize, nsteps=nsteps, generate_direction=getattr(pop, direction), **kw)
+    np.random.seed(11)
+    res = [sampler.__next__(region, Lmin, u, Ls, lambda x: x * 1.0, loglike) for _ in range(40)]
+    assert np.array_equal(np.array([r[3] for r in res]), g[name + "_nc"])
+    tol = dict(rtol=0, atol=0) if backend == "oracle-stub" else dict(rtol=1e-12, atol=1e-14)   # device whitening of the diagnostics only
+    np.testing.assert_allclose(np.array([r[0] for r in res]), g[name + "_u"], rtol=0, atol=0)
+    np.testing.assert_allclose(np.array([r[1] for r in res]), g[name + "_p"], rtol=0, atol=0)
+    np.testing.assert_allclose(np.array([r[2] for r in res]), g[name + "_L"], rtol=0, atol=0)
+    assert sampler.scale == float(g[name + "_scale"])
+    np.testing.assert_allclose(np.array(sampler.logstat, dtype=float), g[name + "_logstat"], **(tol if tol["rtol"] else dict(rtol=1e-13, atol=0)))
+    assert np.random.uniform() == float(g[name + "_next_random"])
+    assert len(sampler.prepared_samples) == (popsize - 40 % popsize) % popsize
+    assert str(sampler).startswith(cls)
 
 
 # ---- the reference's own small tests of this module (tests/test_popstepsampling.py), same recipes -------------

@@ -97,6 +97,7 @@ SIGNATURES = {
     "mlf_walkers_finish": [_vp, _dbl, _vp, _vp, _sz, _sz, ctypes.c_int64, _vp],
     "mlf_walkers_finish_dev": [_vp, _dbl, _int, _dbl, _dbl, _int, _vp, _dbl, ctypes.c_int64, _vp],
     "mlf_walkers_set_live": [_vp, _vp, _vp, _sz],
+    "mlf_walkers_update_live": [_vp, _vp, _sz, _vp, _vp],
     "mlf_walkers_step_dev": [_vp, _dbl, _dbl, _int, _dbl, ctypes.c_uint64, ctypes.c_uint64, _int, _dbl, _dbl, _int, _vp, _dbl,
                              _vp, _vp],
     "mlf_walkers_step_graph": [_vp, _dbl, _dbl, _int, _dbl, ctypes.c_uint64, ctypes.c_uint64, _int, _dbl, _dbl, _int, _vp, _dbl,

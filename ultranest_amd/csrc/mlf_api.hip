@@ -74,19 +74,20 @@ enum Opt : int {
   OPT_SECOND_RANGE_PCT,    // "filter_second_range_pct" 0 ... 90: min-only sweep in three ranges, the second ending at this share of the tiles (0: two ranges)
   OPT_THIRD_MIN_WORK,      // "filter_third_range_min_work": three ranges from this many (proposals x 32-row live-point tiles) on
   OPT_FUSED_WAVES,         // "fused_waves" 8 / 4: waves per workgroup of k_prep_sweep (8: one workgroup per CU; 4: two, out of step)
+  OPT_FUSED_VARIANT,       // "fused_variant": bit 0 = k_prep_sweep loads its matrix fragments by LDS-DMA (default 1) or by a load / store loop (0)
   OPT_COUNT
 };
 const char *const kOptNames[OPT_COUNT] = {"filter", "filter_first_range_pct", "filter_split_waves", "filter_narrow_tail",
                                           "small_path", "fused_prep", "filter_phase_min_queries", "filter_phases",
                                           "time_filter_launches", "prep_bounded", "filter_min_queries", "sweep_min", "mid_max_queries", "fused_first_range",
-                                          "boot_symmetric", "filter_order", "filter_second_range_pct", "filter_third_range_min_work", "fused_waves"};
+                                          "boot_symmetric", "filter_order", "filter_second_range_pct", "filter_third_range_min_work", "fused_waves", "fused_variant"};
 }  // namespace
 namespace mlf {
 std::atomic<unsigned> g_grant_epoch{0u};
 std::atomic<unsigned long long> g_grant_calls{0ull};
 }  // namespace mlf
 namespace {
-long long g_opt[OPT_COUNT] = {1, 30, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 1, 1, 1, 50, 100000000ll, 8};
+long long g_opt[OPT_COUNT] = {1, 30, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 1, 1, 1, 50, 100000000ll, 8, 1};
 
 struct OptOverrides {
   long long v[OPT_COUNT] = {};
@@ -622,6 +623,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
         fu.stamps = f.fstamps.as<unsigned long long>();
         fu.stamp_block = (unsigned)f.stamp_block;
       }
+      fu.variant = (unsigned)(opt(f, OPT_FUSED_VARIANT) & 0xff);
       const int fused_waves = (int)opt(f, OPT_FUSED_WAVES);
       if (int rc = timed([&] { return launch_prep_sweep(fu, s, fused_waves); })) return rc;
     } else if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, 0), m, s); })) return rc;

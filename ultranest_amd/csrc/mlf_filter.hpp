@@ -151,8 +151,9 @@ struct FusedArgs {
   int *cmap, *cmin;
   unsigned *ccount;
   unsigned ccap;
-  unsigned long long *stamps;   // optional diagnostics: 13 shader-clock stamps of wave 0 of workgroup `stamp_block`
+  unsigned long long *stamps;   // optional diagnostics: 16 shader-clock stamps of wave 0 of workgroup `stamp_block`
   unsigned stamp_block;
+  unsigned variant;             // "fused_variant" option: bit 0 matrix fragments by LDS-DMA (default) / by a load-store loop
 };
 bool fused_usable(int dp);
 hipError_t launch_prep_sweep(const FusedArgs &a, hipStream_t s, int waves = 8);

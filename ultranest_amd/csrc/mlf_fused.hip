@@ -115,12 +115,28 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
     a.p.counters[0] = 0;
     a.p.counters[1] = 0;
   }
-  {
+  if (!(a.variant & 1u)) {
     uint4 *dst = reinterpret_cast<uint4 *>(ldsf);
     const uint4 *srcT = reinterpret_cast<const uint4 *>(a.p.TtF);
     const uint4 *srcL = reinterpret_cast<const uint4 *>(a.p.LtF);
     for (int e = tid; e < 2 * NT * NS * 64; e += 64 * NW) dst[e] = srcT[e];
     for (int e = tid; e < 2 * C::NLT * 64; e += 64 * NW) dst[2 * NT * NS * 64 + e] = srcL[e];
+  } else {   // variant bit 0 (default): the matrix fragments as 1 KiB pieces straight into LDS (global_load_lds): every request of
+             // the wave under way at once, no register round trip -- k_prep_sweep 0.203 -> 0.1997 ms in one process
+             // (profiles/r06_fused_ab.jsonl); the load / store loop stays for A/B runs
+    typedef __attribute__((address_space(1))) const void gp_t;
+    typedef __attribute__((address_space(3))) void lp_t;
+    constexpr int NPT = 2 * NT * NS, NPL = 2 * C::NLT;   // pieces of the two tables
+    const unsigned char *srcT = reinterpret_cast<const unsigned char *>(a.p.TtF);
+    const unsigned char *srcL = reinterpret_cast<const unsigned char *>(a.p.LtF);
+#pragma unroll
+    for (int i = 0; i < (NPT + NPL + NW - 1) / NW; ++i) {
+      const int pc = wv + NW * i;   // wave-uniform
+      if (pc < NPT)
+        __builtin_amdgcn_global_load_lds((gp_t *)(srcT + (size_t)pc * 1024 + lane * 16), (lp_t *)(ldsf + (size_t)pc * 1024), 16, 0, 0);
+      else if (pc < NPT + NPL)
+        __builtin_amdgcn_global_load_lds((gp_t *)(srcL + (size_t)(pc - NPT) * 1024 + lane * 16), (lp_t *)(ldsf + (size_t)pc * 1024), 16, 0, 0);
+    }
   }
   static_assert(32 * NE <= 64 * NW && 32 * NT <= 64 * NW && 16 * NS <= 64 * NW, "one thread per constant");
   if (tid < 32 * NE) y0l[tid] = a.p.y0[tid];
@@ -166,6 +182,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
     }
   };
   fetch_group(g0);
+  if (a.variant & 1u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the tables (and its first rows) have landed
   __syncthreads();   // fragments and constants are in LDS
   stamp(1);
 
@@ -273,6 +290,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
           tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, hia[s], tt[t], 0, 0, 0);
         }
       }
+      if (g == 1) stamp(15);
       qs = half_sum(qs) * inv_slsx2;
       const float dn2 = half_sum(dn2a) * inv_sx2;
       bool sure_in = false, sure_out = false;
@@ -363,7 +381,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
         dn2a = operands();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        if (g == 0) stamp(13);
         if (g + 2 < QW) fetch_group(grp + 2);
+        if (g == 0) stamp(14);
       }
     }
 #pragma unroll
@@ -464,6 +484,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
     qmn[g] = m;
     total_keep += (unsigned)__popc(keepm[g]);
   }
+  // (measured and dropped in round 6: every wave reserving its own slots -- no workgroup barrier, 7 800 atomics per launch on
+  // one word -- 0.2015 against 0.2002 ms for the launch, profiles/r06_fused_ab.jsonl)
   if (lane == 0) wg_keep[wv] = total_keep;
   __syncthreads();
   if (tid == 0) {

@@ -47,21 +47,11 @@ __device__ __forceinline__ double loglike_row(int kind, const double *x, int d, 
 // even d <= 128 follows k_loglike_rows (lane l < HW holds coordinates 2 l, 2 l + 1; HW = the smallest power of two with
 // 2 HW >= d; terms combined by the same xor tree), otherwise lane 0 runs loglike_row.  tests/test_popstepsampler.py compares
 // the multi-round walker kernel, which uses this, with the call-by-call path, which uses launch_loglike.
-__device__ inline double loglike_wave(int kind, const double *x, int d, const double *aux, double sigma, int lane) {
-  if ((d & 1) || d > 128) {
-    double out = 0.0;
-    if (lane == 0) out = loglike_row(kind, x, d, aux, sigma);
-    return __shfl(out, 0, 64);
-  }
-  int hw = 2;
-  while (2 * hw < d) hw *= 2;
+// the even-d form on values already in the pair layout: lane l < hw holds x0 = x[2 l], x1 = x[2 l + 1]
+__device__ inline double loglike_pairs(int kind, double x0, double x1, int d, int hw, const double *aux, double sigma, int lane) {
   const int k0 = 2 * lane;
   const bool active = lane < hw && k0 < d;
-  double x0 = 0.0, x1 = 0.0;
-  if (active) {
-    x0 = x[k0];
-    x1 = x[k0 + 1];
-  }
+  if (!active) x0 = x1 = 0.0;
   double acc;
   if (kind == 0) {
     double c0 = 0.0, c1 = 0.0;
@@ -98,6 +88,24 @@ __device__ inline double loglike_wave(int kind, const double *x, int d, const do
     out = -2.0 * acc;
   }
   return __shfl(out, 0, 64);
+}
+
+__device__ inline double loglike_wave(int kind, const double *x, int d, const double *aux, double sigma, int lane) {
+  if ((d & 1) || d > 128) {
+    double out = 0.0;
+    if (lane == 0) out = loglike_row(kind, x, d, aux, sigma);
+    return __shfl(out, 0, 64);
+  }
+  int hw = 2;
+  while (2 * hw < d) hw *= 2;
+  const int k0 = 2 * lane;
+  const bool active = lane < hw && k0 < d;
+  double x0 = 0.0, x1 = 0.0;
+  if (active) {
+    x0 = x[k0];
+    x1 = x[k0 + 1];
+  }
+  return loglike_pairs(kind, x0, x1, d, hw, aux, sigma, lane);
 }
 
 }  // namespace mlf

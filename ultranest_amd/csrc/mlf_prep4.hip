@@ -127,13 +127,24 @@ __global__ __launch_bounds__(64 * P4<DP>::NW, 1) void k_prep4(Prep4Args a) {
     a.counters[0] = 0;
     a.counters[1] = 0;
   }
-  {
-    uint4 *dst = reinterpret_cast<uint4 *>(lds4);
-    const uint4 *srcT = reinterpret_cast<const uint4 *>(a.TtF);
-    const uint4 *srcL = reinterpret_cast<const uint4 *>(a.LtF);
-    if (quant)
-      for (int e = tid; e < 2 * NT * NS * 64; e += 64 * C::NW) dst[e] = srcT[e];
-    for (int e = tid; e < 2 * C::NLT * 64; e += 64 * C::NW) dst[2 * NT * NS * 64 + e] = srcL[e];
+  {   // the matrix fragments as 1 KiB pieces straight into LDS (global_load_lds; wave wv takes pieces wv, wv + NW, ...): every
+      // request of the wave under way at once.  A load / store loop made two to four dependent memory round trips here --
+      // 5-8 us in front of the first matrix instruction of a workgroup (stage stamps of k_prep_sweep, profiles/r06_fused_ab.jsonl)
+    typedef __attribute__((address_space(1))) const void gp_t;
+    typedef __attribute__((address_space(3))) void lp_t;
+    constexpr int NPT = 2 * NT * NS, NPL = 2 * C::NLT;
+    const unsigned char *srcT = reinterpret_cast<const unsigned char *>(a.TtF);
+    const unsigned char *srcL = reinterpret_cast<const unsigned char *>(a.LtF);
+#pragma unroll
+    for (int i = 0; i < (NPT + NPL + C::NW - 1) / C::NW; ++i) {
+      const int pc = wv + C::NW * i;   // wave-uniform
+      if (pc < NPT) {
+        if (quant)
+          __builtin_amdgcn_global_load_lds((gp_t *)(srcT + (size_t)pc * 1024 + lane * 16), (lp_t *)(lds4 + (size_t)pc * 1024), 16, 0, 0);
+      } else if (pc < NPT + NPL) {
+        __builtin_amdgcn_global_load_lds((gp_t *)(srcL + (size_t)(pc - NPT) * 1024 + lane * 16), (lp_t *)(lds4 + (size_t)pc * 1024), 16, 0, 0);
+      }
+    }
   }
   if (tid < 32 * NE) y0l[tid] = a.y0[tid];   // already scaled by s_L s_x
   if (tid < 32 * NT) {
@@ -141,6 +152,7 @@ __global__ __launch_bounds__(64 * P4<DP>::NW, 1) void k_prep4(Prep4Args a) {
     csl[tid] = (quant && col < DP) ? 2.0f * (float)(sigma * a.stats[8 + col]) : 0.0f;   // + 2 sigma c_s: the operand is -2 (sigma t - sigma c_s)
   }
   if (tid < 16 * NS) ctrl[tid] = tid < d ? (double)a.c.s_x * a.lay_ctr[tid] : 0.0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces have landed
   __syncthreads();
 
   // uniform per-kernel quantities (binary32, rounded outward)

@@ -69,16 +69,29 @@ __global__ void k_generate_ball(double *z, long long n, int d, double enlarge, u
 
 // w = center + (z @ axes_T) was produced without the centre by the whitening kernel; add it and
 // record whether the point lies strictly inside the unit cube (reference :1154)
-__global__ void k_center_and_cube(double *w, long long n, int d, const double *center, uint8_t *in_cube) {
-  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  bool ok = true;
-  for (int k = 0; k < d; ++k) {
-    const double v = w[p * d + k] + center[k];
-    w[p * d + k] = v;
-    ok = ok && (v > 0.0) && (v < 1.0);
+// One WAVE per 64 rows, lanes striding the rows' elements (coalesced 512-byte accesses); a row's verdict is the AND over
+// its d elements, kept per lane for the rows a lane touches and combined through LDS.  (One thread per row read with a
+// stride of 8 d bytes between lanes: 1.46 ms per 2^20 x 50, ten times the streaming time -- profiles/r06_refill_kernel_stats.csv.)
+__global__ __launch_bounds__(256) void k_center_and_cube(double *w, long long n, int d, const double *center, uint8_t *in_cube) {
+  __shared__ unsigned bad[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long row0 = ((long long)blockIdx.x * 4 + wv) * 64;
+  if (row0 >= n) return;
+  const int nrows = n - row0 >= 64 ? 64 : (int)(n - row0);
+  bad[wv][lane] = 0u;
+  __builtin_amdgcn_wave_barrier();
+  double *base = w + row0 * d;
+  const int total = nrows * d;
+  for (int e = lane; e < total; e += 64) {
+    const int r = e / d, k = e - r * d;
+    const double v = base[e] + center[k];
+    base[e] = v;
+    if (!((v > 0.0) && (v < 1.0))) bad[wv][r] = 1u;   // benign race: every writer stores 1
   }
-  in_cube[p] = ok ? 1 : 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < nrows) in_cube[row0 + lane] = bad[wv][lane] ? 0 : 1;
 }
 
 // method 2 (reference mlfriends.pyx:1114-1133): uniform in the padded t-space bounding box,
@@ -281,7 +294,7 @@ void launch_generate_ball(double *z, long long n, int d, double enlarge, unsigne
 }
 
 void launch_center_and_cube(double *w, long long n, int d, const double *center, uint8_t *in_cube, hipStream_t s) {
-  hipLaunchKernelGGL(k_center_and_cube, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n, d, center, in_cube);
+  hipLaunchKernelGGL(k_center_and_cube, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n, d, center, in_cube);   // 4 waves x 64 rows
 }
 
 void launch_generate_tbox(double *t, long long n, int d, const double *lo, const double *hi, double pad,

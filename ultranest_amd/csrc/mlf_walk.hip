@@ -187,33 +187,42 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// setup_brackets with a device-side direction draw for a walker whose bracket is undefined.
-// Philox stream 2, (npairs + 2) blocks per walker: block 0 = integer picks + mixture coin,
-// blocks 1.. = Box-Muller pairs (coordinate k takes the cosine / sine branch of pair k / 2).
-// `t`, `left`, `right`, `sl`, `sr` are the wave's copies of the walker state (updated here).
-__device__ void dw_brackets_philox(const WalkState &w, int i, int lane, double scale, int kind, double dirscale,
-                                   const WalkDirData &dd, unsigned long long seed, unsigned long long offset, double &t,
-                                   double &left, double &right, bool &sl, bool &sr) {
-  if (isfinite(t)) return;   // wave-uniform
+// Direction of a new slice for walker i (stepfuncs.pyx:348-535), drawn on the device: every lane gets ITS coordinates
+// vr[h] = v[lane + 64 h] (0 beyond d).  Philox stream 2, (npairs + 2) blocks per walker: block 0 = integer picks + mixture
+// coin, blocks 1.. = Box-Muller pairs (coordinate k takes the cosine / sine branch of pair k / 2).
+__device__ void dw_direction(const WalkState &w, int i, int lane, int kind, double dirscale, const WalkDirData &dd,
+                             unsigned long long seed, unsigned long long offset, double (&vr)[2]) {
   const int d = w.d;
-  double *v = w.currentv + (size_t)i * d;
   const int npairs = (d + 1) / 2;
   const unsigned long long base = offset + (unsigned long long)i * (unsigned long long)(npairs + 2);
   unsigned pick[4];
   philox_block(seed, 2u, base, pick);
   int k = kind;
   if (k == DIR_MIXTURE) k = (u01(pick[2], pick[3]) < 0.5) ? DIR_DIFFERENTIAL : DIR_REGION_ORIENTED;
+  vr[0] = vr[1] = 0.0;
   if (k == DIR_CUBE_ORIENTED || k == DIR_CUBE_ORIENTED_SCALED) {
     const int j = (int)below(pick[0], (unsigned)d);
-    for (int c = lane; c < d; c += 64) v[c] = c == j ? ((k == DIR_CUBE_ORIENTED) ? dirscale : dirscale * dd.std[j]) : 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = lane + 64 * h;
+      if (c < d) vr[h] = c == j ? ((k == DIR_CUBE_ORIENTED) ? dirscale : dirscale * dd.std[j]) : 0.0;
+    }
   } else if (k == DIR_REGION_ORIENTED) {
     const int j = (int)below(pick[0], (unsigned)d);
-    for (int c = lane; c < d; c += 64) v[c] = dd.axes[(size_t)j * d + c] * dirscale;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = lane + 64 * h;
+      if (c < d) vr[h] = dd.axes[(size_t)j * d + c] * dirscale;
+    }
   } else if (k == DIR_DIFFERENTIAL) {
     const unsigned a = below(pick[0], (unsigned)dd.nlive);
     unsigned b = below(pick[1], (unsigned)(dd.nlive - 1));
     if (b >= a) ++b;
-    for (int c = lane; c < d; c += 64) v[c] = (dd.live[(size_t)a * d + c] - dd.live[(size_t)b * d + c]) * dirscale;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = lane + 64 * h;
+      if (c < d) vr[h] = (dd.live[(size_t)a * d + c] - dd.live[(size_t)b * d + c]) * dirscale;
+    }
   } else {   // DIR_RANDOM, DIR_REGION_RANDOM: isotropic unit vector of length dirscale
     double g[2] = {0.0, 0.0};
     double part = 0.0;
@@ -235,7 +244,7 @@ __device__ void dw_brackets_philox(const WalkState &w, int i, int lane, double s
     if (k == DIR_RANDOM) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
-        if (lane + 64 * h < d) v[lane + 64 * h] = g[h];
+        if (lane + 64 * h < d) vr[h] = g[h];
     } else {   // v[r] = sum_c axes[r][c] * v1[c]   (einsum 'ij,kj->ki', stepfuncs.pyx:476)
       double acc[2] = {0.0, 0.0};
       for (int c = 0; c < d; ++c) {
@@ -248,8 +257,28 @@ __device__ void dw_brackets_philox(const WalkState &w, int i, int lane, double s
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h)
-        if (lane + 64 * h < d) v[lane + 64 * h] = acc[h];
+        if (lane + 64 * h < d) vr[h] = acc[h];
     }
+  }
+}
+
+// setup_brackets with a device-side direction draw for a walker whose bracket is undefined (popstepsampler.py:483-505).
+// `t`, `left`, `right`, `sl`, `sr` are the wave's copies of the walker state (updated here); vr (optional) receives the
+// lane's coordinates of the new direction.
+__device__ void dw_brackets_philox(const WalkState &w, int i, int lane, double scale, int kind, double dirscale,
+                                   const WalkDirData &dd, unsigned long long seed, unsigned long long offset, double &t,
+                                   double &left, double &right, bool &sl, bool &sr, double *vr_out = nullptr) {
+  if (isfinite(t)) return;   // wave-uniform
+  const int d = w.d;
+  double *v = w.currentv + (size_t)i * d;
+  double vr[2];
+  dw_direction(w, i, lane, kind, dirscale, dd, seed, offset, vr);
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (lane + 64 * h < d) v[lane + 64 * h] = vr[h];
+  if (vr_out) {
+    vr_out[0] = vr[0];
+    vr_out[1] = vr[1];
   }
   left = -scale;
   right = scale;
@@ -385,34 +414,46 @@ __global__ __launch_bounds__(256) void k_walk_expand(WalkState w, const unsigned
 // diagnose_move_distances for one walker that moved (wave-wide, lane = whitened coordinate; T rows are read
 // coalesced, squared differences summed by a fixed shuffle tree): uo = the point the step started from, un = the
 // accepted point
+// d <= 64, affine layer: lane k holds coordinate k of the two points (vo: where the step started, vn: the accepted point; 0
+// beyond d); returns the squared whitened distance on lane 0.  Both points share every matrix element; the chains read the
+// centred coordinates by lane broadcast (same values and order as whiten_point: results are identical)
+__device__ __forceinline__ double move_distance_regs(const WalkLayer &ly, int d, int lane, double vo, double vn) {
+  if (lane < d) {
+    if (ly.wrap && !isnan(ly.wrap[lane])) {
+      vo = fmod(vo + ly.wrap[lane], 1.0);
+      vn = fmod(vn + ly.wrap[lane], 1.0);
+    }
+    vo -= ly.ctr[lane];
+    vn -= ly.ctr[lane];
+  } else {
+    vo = vn = 0.0;
+  }
+  double ta = 0.0, tb = 0.0;
+  const int c = lane < d ? lane : 0;
+  for (int k = 0; k < d; ++k) {
+    const double m = ly.mat[(size_t)k * d + c];
+    ta = __builtin_fma(__shfl(vo, k, 64), m, ta);
+    tb = __builtin_fma(__shfl(vn, k, 64), m, tb);
+  }
+  double acc = 0.0;
+  if (lane < d) {
+    const double diff = ta - tb;
+    acc = diff * diff;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  return acc;
+}
+
 __device__ __forceinline__ void dw_move_distance(const WalkState &w, const WalkLayer &ly, int i, int lane, const double *uo,
                                                  const double *un) {
   double acc = 0.0;
   if (ly.kind == 0 && w.d <= 64) {
-    // both points share every matrix element: lane k keeps the centred coordinate k of the two points, the
-    // chains read them by lane broadcast (same values and order as whiten_point: results are identical)
     double vo = 0.0, vn = 0.0;
     if (lane < w.d) {
       vo = uo[lane];
       vn = un[lane];
-      if (ly.wrap && !isnan(ly.wrap[lane])) {
-        vo = fmod(vo + ly.wrap[lane], 1.0);
-        vn = fmod(vn + ly.wrap[lane], 1.0);
-      }
-      vo -= ly.ctr[lane];
-      vn -= ly.ctr[lane];
     }
-    double ta = 0.0, tb = 0.0;
-    const int c = lane < w.d ? lane : 0;
-    for (int k = 0; k < w.d; ++k) {
-      const double m = ly.mat[(size_t)k * w.d + c];
-      ta = __builtin_fma(__shfl(vo, k, 64), m, ta);
-      tb = __builtin_fma(__shfl(vn, k, 64), m, tb);
-    }
-    if (lane < w.d) {
-      const double diff = ta - tb;
-      acc = diff * diff;
-    }
+    acc = move_distance_regs(ly, w.d, lane, vo, vn);
   } else {
     for (int c = lane; c < w.d; c += 64) {
       double ta, tb;
@@ -421,8 +462,8 @@ __device__ __forceinline__ void dw_move_distance(const WalkState &w, const WalkL
       const double diff = ta - tb;
       acc += diff * diff;
     }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   }
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (lane == 0) w.dist2[i] = acc;
 }
 
@@ -723,7 +764,144 @@ __device__ void dw_round(const RoundsArgs &a, int i, int lane, int r, const Step
     a.rflags[(size_t)r * a.w.P + i] = (uint8_t)((a.w.movable[i] ? 1 : 0) | (a.w.acceptable[i] ? 2 : 0) | (succ ? 4 : 0) |
                                                 (a.was_starting[i] ? 8 : 0));
     a.rdist2[(size_t)r * a.w.P + i] = a.w.dist2[i];
+    a.rlast[i] = r + 1;
   }
+}
+
+// Rounds r0, r0 + 1, ... of ONE walker with its state in REGISTERS (the form above passes every intermediate through global
+// memory between the lanes of the wave: ~6 us per round, four fences and half a dozen dependent L2 round trips; here a round
+// is a few hundred instructions).  Same arithmetic, stage by stage, as dw_prologue / loglike_wave / dw_update -- the shared
+// cores (dw_direction, loglike_wave's pair layout, update_walker, move_distance_regs) are the SAME functions -- so the
+// resident state afterwards is bit for bit that of the memory form.  What rounds after the first of a call never do is
+// dropped: step_back (every chain entry appended under this threshold lies above it; round 0 removed the others) and
+// restarts (a walker that could not restart in round 0 -- no live point above the threshold -- cannot later).
+// Preconditions (rounds_in_registers): even d <= 64 (loglike_wave's pair layout, move_distance_regs), affine layer or none.
+// `until_finished`: stop when the walker has its nsteps (the ring walker); returns the round index after the last one made.
+__device__ int dw_rounds_regs(const RoundsArgs &a, int i, int lane, int r0, int r1, bool until_finished, const StepParams &p0) {
+  const WalkState &w = a.w;
+  const int d = w.d;
+  long long gen = w.generation[i];
+  double tcur = w.currentt[i], left = w.left[i], right = w.right[i];
+  uint8_t sl = w.sl[i], sr = w.sr[i];
+  const bool have = lane < d;
+  double u0 = 0.0, v = 0.0;   // the lane's coordinate of the chain's current point and of the slice direction
+  if (gen >= 0 && have) u0 = w.allu[((size_t)i * w.G + gen) * d + lane];
+  if (have) v = w.currentv[(size_t)i * d + lane];
+  int hw = 2;
+  while (2 * hw < d) hw *= 2;
+  int r = r0;
+  for (; r < r1; ++r) {
+    if (until_finished && gen == (long long)(w.G - 1)) break;
+    const unsigned long long offset = p0.offset + (unsigned long long)r * a.per_call;
+    const bool movable = gen >= 0 && gen < w.G - 1;
+    uint8_t flags = gen < 0 ? 8 : 0;
+    double dist2 = qnan();
+    if (gen >= 0 && !isfinite(tcur)) {   // new slice (dw_brackets_philox; a walker that never started has no point to slice from
+                                         // -- the memory form draws a direction for it all the same, which nothing ever reads)
+      bool bsl = sl != 0, bsr = sr != 0;
+      double vr[2];
+      dw_brackets_philox(w, i, lane, p0.scale, a.dirkind, p0.dirscale, a.dd, p0.seed, offset, tcur, left, right, bsl, bsr, vr);
+      sl = bsl ? 1 : 0;
+      sr = bsr ? 1 : 0;
+      v = vr[0];
+    } else if (gen < 0 && !isfinite(tcur)) {
+      bool bsl = sl != 0, bsr = sr != 0;
+      dw_brackets_philox(w, i, lane, p0.scale, a.dirkind, p0.dirscale, a.dd, p0.seed, offset, tcur, left, right, bsl, bsr, nullptr);
+      sl = bsl ? 1 : 0;
+      sr = bsr ? 1 : 0;
+    }
+    if (movable) {
+      flags |= 1;
+      // evolve, first half (dw_propose)
+      double tu;
+      if (sl) {
+        tu = left;
+      } else if (sr) {
+        tu = right;
+      } else {
+        unsigned r4[4];
+        philox_block(p0.seed, 3u, offset + (unsigned long long)i, r4);
+        const double un = u01(r4[0], r4[1]);
+        const double range = right - left;
+        const double scaled = range * un;
+        tcur = left + scaled;
+        tu = tcur;
+      }
+      const double step = v * tu;
+      const double x = u0 + step;
+      const bool acceptable = __all(!have || inside_open_unit(x));
+      double pcoord = x;
+      if (a.tkind == 1) {
+        const double m = x * a.ta;
+        pcoord = m + a.tb;
+      } else if (a.tkind == 2) {
+        const double m = x * a.ta;
+        pcoord = m * a.tb;
+      }
+      bool hit = false;
+      double L = 0.0;
+      if (acceptable) {   // wave-uniform
+        flags |= 2;
+        // loglike_wave's pair layout: lane l < hw holds parameters 2 l, 2 l + 1
+        const double x0 = __shfl(pcoord, (2 * lane) & 63, 64), x1 = __shfl(pcoord, (2 * lane + 1) & 63, 64);
+        L = loglike_pairs(a.lkind, x0, x1, d, hw, a.aux, a.sigma, lane);
+        hit = L > p0.Lmin;
+      }
+      // evolve_update + advance (dw_update)
+      const bool success = update_walker(hit, tcur, left, right, sl, sr);
+      if (success) {
+        flags |= 4;
+        const long long g1 = gen + 1;
+        if (have) {
+          w.allu[((size_t)i * w.G + g1) * d + lane] = x;
+          w.currentp[(size_t)i * w.nparams + lane] = pcoord;
+        }
+        if (lane == 0) w.allL[(size_t)i * w.G + g1] = L;
+        if (a.ly.kind >= 0) dist2 = move_distance_regs(a.ly, d, lane, u0, x);
+        gen = g1;
+        u0 = x;
+      }
+    }
+    if (lane == 0) {
+      a.rflags[(size_t)r * w.P + i] = flags;
+      a.rdist2[(size_t)r * w.P + i] = dist2;
+    }
+  }
+  if (lane == 0) {
+    w.generation[i] = gen;
+    w.currentt[i] = tcur;
+    w.left[i] = left;
+    w.right[i] = right;
+    w.sl[i] = sl;
+    w.sr[i] = sr;
+    a.rlast[i] = r;   // rounds [r, ...) of this call carry no flags of this walker (k_walk_round_stats)
+  }
+  return r;
+}
+
+// the layer of the move diagnostics staged in LDS for the register form (d <= 64: 32 KiB + centre + wrap shifts): the chain
+// of move_distance_regs reads one matrix element per step, and from global memory every step waited for its own L2 round trip
+struct LayerLds {
+  double mat[64 * 64];
+  double ctr[64];
+  double wrap[64];
+};
+__device__ WalkLayer stage_layer(const WalkLayer &ly, int d, LayerLds &lds, int tid, int nthreads) {
+  WalkLayer out = ly;
+  if (ly.kind != 0) return out;
+  for (int e = tid; e < d * d; e += nthreads) lds.mat[e] = ly.mat[e];
+  for (int e = tid; e < d; e += nthreads) {
+    lds.ctr[e] = ly.ctr[e];
+    if (ly.wrap) lds.wrap[e] = ly.wrap[e];
+  }
+  out.mat = lds.mat;
+  out.ctr = lds.ctr;
+  if (ly.wrap) out.wrap = lds.wrap;
+  return out;
+}
+
+__device__ __forceinline__ bool rounds_in_registers(const RoundsArgs &a) {
+  return !(a.w.d & 1) && a.w.d <= 64 && a.w.nparams == a.w.d && (a.ly.kind == 0 || a.ly.kind < 0) && !a.force_memory_form;
 }
 
 __global__ __launch_bounds__(64) void k_walk_round0(RoundsArgs a) {
@@ -757,9 +935,24 @@ __global__ __launch_bounds__(256) void k_walk_ring(RoundsArgs a) {
   int R = 1;
   // rounds 1 ...: the ring walker alone.  In those rounds nothing restarts that did not restart in round 0 (same
   // threshold, same live points), so the ring index stays where round 0 left it
-  while (w.generation[ring] != (long long)(w.G - 1) && R < a.max_rounds) {
-    dw_round(a, ring, lane, R, p);
-    ++R;
+  if (rounds_in_registers(a)) {
+    __shared__ LayerLds lds;
+    RoundsArgs al = a;
+    if (w.generation[ring] != (long long)(w.G - 1)) {   // (wave-uniform) there will be rounds
+      al.ly = stage_layer(a.ly, w.d, lds, lane, 64);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    R = dw_rounds_regs(al, ring, lane, 1, a.max_rounds, true, p);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    while (w.generation[ring] != (long long)(w.G - 1) && R < a.max_rounds) {
+      dw_round(a, ring, lane, R, p);
+      ++R;
+    }
   }
   const bool found = w.generation[ring] == (long long)(w.G - 1);
   const size_t row = ((size_t)ring * w.G + (w.G - 1)) * w.d;
@@ -800,9 +993,22 @@ __global__ __launch_bounds__(64) void k_walk_rest(RoundsArgs a) {
   const StepParams p = *a.sp;
   const int R = a.ctl[0], ring = a.ctl[1];
   if (R <= 1) return;
+  const bool regs = rounds_in_registers(a);
+  __shared__ LayerLds lds;
+  RoundsArgs al = a;
+  if (regs) {
+    al.ly = stage_layer(a.ly, a.w.d, lds, threadIdx.x, 64);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   for (int i = blockIdx.x; i < a.w.P; i += gridDim.x) {
     if (i == ring) continue;
-    for (int r = 1; r < R; ++r) dw_round(a, i, threadIdx.x, r, p);
+    if (regs) {
+      dw_rounds_regs(al, i, threadIdx.x, 1, R, false, p);
+    } else {
+      for (int r = 1; r < R; ++r) dw_round(a, i, threadIdx.x, r, p);
+    }
   }
 }
 
@@ -821,6 +1027,7 @@ __global__ __launch_bounds__(256) void k_walk_round_stats(RoundsArgs a) {
     for (int j = threadIdx.x; j < kStatsChunk; j += 256) {
       const int i = i0 + j;
       if (i >= P) continue;
+      if (r >= a.rlast[i]) continue;      // the walker made no such round (the ring walker's R is everybody's bound, see rlast)
       const uint8_t f = a.rflags[(size_t)r * P + i];
       if (!(f & 1)) continue;
       nmov += 1;
@@ -1086,6 +1293,21 @@ void launch_walk_expand(const WalkState &w, const unsigned *blk, const double *p
 
 void launch_walk_update(const WalkState &w, double Lmin, WalkLayer layer, hipStream_t s, const StepParams *sp) {
   hipLaunchKernelGGL(k_walk_update, walker_grid(w.P), dim3(64), 0, s, w, Lmin, sp, layer);
+}
+
+__global__ void k_walk_scatter_live(const double *rows, const double *Ls, const long long *idx, int n, int d, double *live, double *liveL) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * d) return;
+  const int j = e / d, k = e - j * d;
+  const long long i = idx[j];
+  live[(size_t)i * d + k] = rows[(size_t)j * d + k];
+  if (k == 0) liveL[i] = Ls[j];
+}
+
+void launch_walk_scatter_live(const double *rows, const double *Ls, const long long *idx, int n, int d, double *live, double *liveL,
+                              hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_walk_scatter_live, grid_for((long long)n * d), dim3(256), 0, s, rows, Ls, idx, n, d, live, liveL);
 }
 
 void launch_walk_rounds(const RoundsArgs &a, hipStream_t s) {

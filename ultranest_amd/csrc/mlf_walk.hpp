@@ -86,12 +86,17 @@ struct RoundsArgs {
   int *ctl;                  // [0] rounds made R, [1] ring walker of this call, [2] harvested
   uint8_t *rflags;           // [max_rounds][P] bit0 movable, bit1 acceptable, bit2 success, bit3 was (re)starting
   double *rdist2;            // [max_rounds][P] move distance^2 of the walkers that succeeded in the round
+  int *rlast;                // [P] rounds [0, rlast) of this call wrote the walker's flags
+  int force_memory_form;     // tests: every round through global memory (dw_round), as the first form of this path did
   double *rows;              // [max_rounds][5] step statistics per round
   double *rec;               // [0] harvested, [1] L, [2] left, [3] right, [4] R, [9 ..] u (d), p (nparams), next ring index
   int max_rounds;
   unsigned long long per_call;   // Philox counters one call of the call-by-call path consumes
 };
 void launch_walk_rounds(const RoundsArgs &a, hipStream_t s);
+// rows idx[j] of the device copy of the live points (and their likelihoods) replaced
+void launch_walk_scatter_live(const double *rows, const double *Ls, const long long *idx, int n, int d, double *live, double *liveL,
+                              hipStream_t s);
 
 void launch_walk_reset(const WalkState &w, hipStream_t s);
 // step_back + snapshot: flags[i] = bit0 !isfinite(currentt) | bit1 searching_left | bit2 searching_right

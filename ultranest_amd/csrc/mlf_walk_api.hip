@@ -44,7 +44,11 @@ struct mlf_walkers {
   DevBuf d_sp;
   std::vector<unsigned long long> gkey;
   // several rounds per call (mlf_walkers_rounds_dev)
-  DevBuf r_ctl, r_flags, r_dist2, r_out, r_sp;
+  DevBuf r_ctl, r_flags, r_dist2, r_out, r_sp, r_last, live_stage;
+  hipGraphExec_t rgexec = nullptr; // the launch sequence of mlf_walkers_rounds_dev (parameter copy, four kernels, record copy) as ONE graph launch
+  std::vector<unsigned long long> rgkey;
+  double *h_live = nullptr;        // pinned staging of mlf_walkers_update_live
+  size_t h_live_bytes = 0;
   StepParams *h_rsp = nullptr;     // pinned
   double *h_rout = nullptr;        // pinned: record + per-round statistics
   size_t h_rout_doubles = 0;
@@ -187,7 +191,9 @@ int mlf_walkers_destroy(mlf_walkers *w) {
                    &w->lay_wrap, &w->liveL, &w->ring, &w->partials};
   for (DevBuf *b : all) b->release();
   w->d_sp.release();
-  for (DevBuf *b : {&w->r_ctl, &w->r_flags, &w->r_dist2, &w->r_out, &w->r_sp}) b->release();
+  for (DevBuf *b : {&w->r_ctl, &w->r_flags, &w->r_dist2, &w->r_out, &w->r_sp, &w->r_last, &w->live_stage}) b->release();
+  if (w->h_live) (void)hipHostFree(w->h_live);
+  if (w->rgexec) (void)hipGraphExecDestroy(w->rgexec);
   if (w->h_rsp) (void)hipHostFree(w->h_rsp);
   if (w->h_rout) (void)hipHostFree(w->h_rout);
   if (w->gexec) (void)hipGraphExecDestroy(w->gexec);
@@ -409,6 +415,38 @@ int mlf_walkers_set_live(mlf_walkers *w, const double *us, const double *Ls, siz
   return 0;
 }
 
+int mlf_walkers_update_live(mlf_walkers *w, const int64_t *rows, size_t count, const double *us_rows, const double *Ls_rows) {
+  if (!w || (count && (!rows || !us_rows || !Ls_rows))) return ctx_fail_arg(MLF_E_BADARG, "null pointer");
+  if (!w->have_liveL) return ctx_fail_arg(MLF_E_STATE, "mlf_walkers_set_live not called");
+  if (count == 0) return 0;
+  const size_t d = (size_t)w->d;
+  for (size_t j = 0; j < count; ++j)
+    if (rows[j] < 0 || rows[j] >= w->nlive) return ctx_fail_arg(MLF_E_BADARG, "live point index out of range");
+  hipStream_t s = ctx_stream();
+  // pinned staging, reused from call to call: every path that reads the device copy ends with a synchronisation of the
+  // library's stream, so the copy queued by the previous update has long been made
+  const size_t need = count * (d + 2) * sizeof(double);
+  if (w->h_live_bytes < need) {
+    if (w->h_live) CK(hipHostFree(w->h_live));
+    w->h_live = nullptr;
+    w->h_live_bytes = 0;
+    const size_t cap = need < 4096 ? 4096 : need;
+    CK(hipHostMalloc(reinterpret_cast<void **>(&w->h_live), cap, hipHostMallocDefault));
+    w->h_live_bytes = cap;
+  }
+  CK(w->live_stage.reserve(w->h_live_bytes));
+  double *hs = w->h_live;
+  memcpy(hs, us_rows, count * d * sizeof(double));
+  memcpy(hs + count * d, Ls_rows, count * sizeof(double));
+  memcpy(hs + count * (d + 1), rows, count * sizeof(int64_t));
+  CK(hipMemcpyAsync(w->live_stage.p, hs, need, hipMemcpyHostToDevice, s));
+  const double *ds = w->live_stage.as<double>();
+  launch_walk_scatter_live(ds, ds + count * d, reinterpret_cast<const long long *>(ds + count * (d + 1)), (int)count, (int)d,
+                           w->live.as<double>(), w->liveL.as<double>(), s);
+  CK(hipGetLastError());
+  return 0;
+}
+
 int mlf_walkers_step_dev(mlf_walkers *w, double Lmin, double scale, int dirkind, double dirscale, uint64_t seed,
                          uint64_t offset, int tkind, double ta, double tb, int lkind, const double *aux, double sigma,
                          double *rec, uint64_t *next_offset) {
@@ -548,7 +586,9 @@ int mlf_walkers_rounds_dev(mlf_walkers *w, double Lmin, double scale, int dirkin
   if (dirkind < 0 || dirkind > DIR_MIXTURE) return ctx_fail_arg(MLF_E_BADARG, "unknown direction kind");
   if (tkind < 0 || tkind > 2 || lkind < 0 || lkind > 3) return ctx_fail_arg(MLF_E_BADARG, "unknown transform / likelihood kind");
   if (lkind == 0 && !aux) return ctx_fail_arg(MLF_E_BADARG, "the Gaussian likelihood needs its centres");
-  if (max_rounds < 1) return ctx_fail_arg(MLF_E_BADARG, "max_rounds must be positive");
+  const int force_memory_form = max_rounds < 0;   // test hook: every round through global memory (the first form of this path)
+  if (force_memory_form) max_rounds = -max_rounds;
+  if (max_rounds < 1) return ctx_fail_arg(MLF_E_BADARG, "max_rounds must not be 0");
   const bool need_axes = dirkind == DIR_REGION_ORIENTED || dirkind == DIR_REGION_RANDOM || dirkind == DIR_MIXTURE;
   if ((need_axes && !w->have_axes) || (dirkind == DIR_CUBE_ORIENTED_SCALED && !w->have_std))
     return ctx_fail_arg(MLF_E_STATE, "mlf_walkers_set_direction_data has not provided what this direction kind needs");
@@ -577,6 +617,7 @@ int mlf_walkers_rounds_dev(mlf_walkers *w, double Lmin, double scale, int dirkin
   CK(w->r_flags.reserve((size_t)max_rounds * w->P));
   CK(w->r_dist2.reserve((size_t)max_rounds * w->P * sizeof(double)));
   CK(w->r_out.reserve(nout * sizeof(double)));
+  CK(w->r_last.reserve((size_t)w->P * sizeof(int)));
   CK(w->aux.reserve((size_t)w->d * 8));
   if (aux)
     if (int rc = upload(w->aux, aux, (size_t)w->d * 8, s)) return rc;
@@ -586,7 +627,6 @@ int mlf_walkers_rounds_dev(mlf_walkers *w, double Lmin, double scale, int dirkin
   w->h_rsp->r2 = w->r2;
   w->h_rsp->seed = seed;
   w->h_rsp->offset = offset;
-  CK(hipMemcpyAsync(w->r_sp.p, w->h_rsp, sizeof(StepParams), hipMemcpyHostToDevice, s));
   const uint64_t per = (uint64_t)((w->d + 1) / 2 + 2);
   RoundsArgs a{};
   a.w = state_of(w);
@@ -611,13 +651,46 @@ int mlf_walkers_rounds_dev(mlf_walkers *w, double Lmin, double scale, int dirkin
   a.ctl = w->r_ctl.as<int>();
   a.rflags = w->r_flags.as<uint8_t>();
   a.rdist2 = w->r_dist2.as<double>();
+  a.rlast = w->r_last.as<int>();
+  a.force_memory_form = force_memory_form;
   a.rec = w->r_out.as<double>();
   a.rows = w->r_out.as<double>() + nrec;
   a.max_rounds = max_rounds;
   a.per_call = (unsigned long long)w->P * (per > 64 ? per : 64);
-  launch_walk_rounds(a, s);
-  CK(hipGetLastError());
-  CK(hipMemcpyAsync(w->h_rout, w->r_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, s));
+  // Everything a captured argument depends on; the values that change from call to call (threshold, scale, radius, seed,
+  // offset) travel through the pinned parameter block.  A change (new region: layer buffers, radius-independent) means a new capture
+  auto bits = [](double v) {
+    unsigned long long u;
+    memcpy(&u, &v, sizeof u);
+    return u;
+  };
+  auto addr = [](const void *p) { return (unsigned long long)(uintptr_t)p; };
+  std::vector<unsigned long long> key = {
+      (unsigned long long)dirkind, (unsigned long long)tkind, bits(ta), bits(tb), (unsigned long long)lkind, bits(sigma),
+      (unsigned long long)(w->layer_kind + 1), (unsigned long long)w->layer_wrap, (unsigned long long)w->nlive,
+      (unsigned long long)max_rounds, (unsigned long long)force_memory_form, (unsigned long long)nout, bits(w->r2),
+      addr(w->live.p), addr(w->liveL.p), addr(w->axes.p), addr(w->std.p), addr(w->lay_ctr.p), addr(w->lay_mat.p),
+      addr(w->lay_wrap.p), addr(w->aux.p), addr(w->r_out.p), addr(w->pnew.p), addr(w->currentp.p), addr(w->r_flags.p),
+      addr(w->r_dist2.p), addr(w->r_last.p), addr(w->r_ctl.p), addr(w->r_sp.p), addr(w->h_rout), addr(w->h_rsp), addr(w->flags.p),
+      addr(w->ring.p)};
+  if (!w->rgexec || key != w->rgkey) {
+    if (w->rgexec) {
+      CK(hipGraphExecDestroy(w->rgexec));
+      w->rgexec = nullptr;
+    }
+    CK(hipStreamSynchronize(s));
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    (void)hipMemcpyAsync(w->r_sp.p, w->h_rsp, sizeof(StepParams), hipMemcpyHostToDevice, s);
+    launch_walk_rounds(a, s);
+    (void)hipMemcpyAsync(w->h_rout, w->r_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, s);
+    hipGraph_t graph = nullptr;
+    CK(hipStreamEndCapture(s, &graph));
+    hipError_t e = hipGraphInstantiate(&w->rgexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return ctx_fail_hip(e, "hipGraphInstantiate", "mlf_walk_api.hip", __LINE__);
+    w->rgkey = key;
+  }
+  CK(hipGraphLaunch(w->rgexec, s));
   CK(hipStreamSynchronize(s));
   const int R = (int)w->h_rout[4];
   if (R < 1 || R > max_rounds) return ctx_fail_arg(MLF_E_STATE, "mlf_walkers_rounds_dev: the device reported an impossible round count");

@@ -448,7 +448,7 @@ class DeviceRegion(object):
         previous call wrote during the last phased batch; selects workgroup `block` for the next batches (None: off)."""
         out = np.zeros(16, dtype=np.uint64)
         check(_lib.lib().mlf_region_debug_fused_stamps(self._h, -1 if block is None else int(block), ptr(out), 16))
-        st = out[:13].astype(np.int64)
+        st = out[:16].astype(np.int64)
         return [int(x - st[0]) if x else None for x in st] if st[0] else None
 
     def time_inside_dev(self, d_pts, npts, d_mask, stream=0, reps=3):

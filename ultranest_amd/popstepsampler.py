@@ -105,6 +105,159 @@ class GenericPopulationSampler(object):
         pass
 
 
+class _BatchedPopulationSampler(GenericPopulationSampler):
+    """The two samplers of the reference that advance the WHOLE population by `nsteps` moves in one call and then hand the
+    walkers out one per call (reference popstepsampler.py:192-358 and :746-1001).  The moves themselves are the vectorised
+    step functions of this package (direction generators, line / cube intersection, slice bookkeeping, move diagnostics: HIP
+    kernels behind ``ultranest_amd.stepfuncs``); what is restated here is their order and the ``np.random`` / scipy draws,
+    so that a seeded run returns the reference's points (tests/test_popstepsampler.py, golden g16)."""
+
+    def region_changed(self, Ls, region):
+        """Nothing of the region is cached between calls."""
+
+    def _refill(self, region, Lmin, us, Ls, transform, loglike, **kwargs):
+        raise NotImplementedError
+
+    def __next__(self, region, Lmin, us, Ls, transform, loglike, ndraw=10, plot=False, tregion=None, log=False, **kwargs):
+        """``(u, p, L, nc)`` of the next prepared walker; the call that finds none left first moves the whole population
+        (nc = its likelihood evaluations, 0 otherwise)."""
+        nc = 0
+        if not self.prepared_samples:
+            nc = self._refill(region, Lmin, us, Ls, transform, loglike, **kwargs)
+        u, p, L = self.prepared_samples.pop(0)
+        return u, p, L, nc
+
+
+class PopulationRandomWalkSampler(_BatchedPopulationSampler):
+    """Vectorized Gaussian random walk (reference popstepsampler.py:192-358; same constructor and ``__next__`` contract)."""
+
+    def __init__(self, popsize, nsteps, generate_direction, scale, scale_adapt_factor=0.9, scale_min=1e-20, scale_max=20,
+                 log=False, logfile=None):
+        assert scale_adapt_factor <= 1
+        self.popsize, self.nsteps, self.generate_direction = popsize, nsteps, generate_direction
+        self.scale, self.scale_adapt_factor, self.scale_min, self.scale_max = scale, scale_adapt_factor, scale_min, scale_max
+        self.nrejects = self.ncalls = 0
+        self.log, self.logfile, self.logstat = log, logfile, []
+        self.logstat_labels = ['accept_rate', 'efficiency', 'scale', 'far_enough', 'mean_rel_jump']
+        self.prepared_samples = []
+
+    def __str__(self):
+        return 'PopulationRandomWalkSampler(popsize=%d, nsteps=%d, generate_direction=%s, scale=%.g)' % (
+            self.popsize, self.nsteps, self.generate_direction, self.scale)
+
+    def _refill(self, region, Lmin, us, Ls, transform, loglike):
+        import scipy.stats
+        nlive = len(us)
+        nmoves = self.nsteps * self.popsize
+        target_rejects = nmoves * (1 - 0.234)              # the acceptance rate the scale is steered to
+        rejects_before = self.nrejects
+        start = np.random.randint(0, nlive, size=self.popsize)
+        allu, allL, allp = us[start, :], Ls[start], None
+        accepted = np.zeros(self.popsize, dtype=bool)
+        for _ in range(self.nsteps):
+            v = self.generate_direction(allu, region, self.scale)
+            tleft, tright = unitcube_line_intersection(allu, v)
+            # a unit normal step along v, truncated to the part of the line inside the cube (scipy draws from np.random)
+            t = scipy.stats.truncnorm.rvs(tleft, tright, loc=0, scale=1).reshape((-1, 1))
+            unew = allu + v * t
+            outside = ~np.logical_and(unew > 0, unew < 1).all(axis=1)
+            assert not outside.any(), unew[outside, :]
+            pnew = transform(unew)
+            Lnew = loglike(pnew)
+            accepted = Lnew > Lmin
+            self.nrejects += (~accepted).sum()
+            if allp is None:
+                allp = pnew * np.nan
+            allu[accepted, :], allp[accepted, :], allL[accepted] = unew[accepted, :], pnew[accepted, :], Lnew[accepted]
+        assert np.isfinite(allp).all(), 'some walkers never moved! Double nsteps of PopulationRandomWalkSampler.'
+        # (the reference diagnoses the walkers that accepted their LAST move: reference :334)
+        far_enough, (moved, radius) = diagnose_move_distances(region, us[start[accepted], :], allu[accepted, :])
+        self.prepared_samples = list(zip(allu, allp, allL))
+        expected = rejects_before + target_rejects
+        # (efficiency in the reference's own arithmetic, :339: the count before this call is recovered from `expected`)
+        self.logstat.append([accepted.mean(), 1 - (self.nrejects - (expected - target_rejects)) / nmoves,
+                             self.scale, self.nsteps, np.mean(far_enough), np.exp(np.mean(np.log(moved / radius + 1e-10)))])
+        if self.logfile:    # (the reference's own format string takes five of the six columns)
+            row = self.logstat[-1]
+            self.logfile.write("rescale\t%.4f\t%.4f\t%g\t%.4f%g\n" % (row[0], row[1], row[2], row[4], row[5]))
+        if self.nrejects > expected and self.scale > self.scale_min:
+            self.scale *= self.scale_adapt_factor            # too many rejections: shorter steps
+        elif self.nrejects < expected and self.scale < self.scale_max:
+            self.scale /= self.scale_adapt_factor
+        return nmoves
+
+
+class PopulationSimpleSliceSampler(_BatchedPopulationSampler):
+    """Vectorized slice sampler without stepping out: the slice starts as the line's intersection with the unit cube
+    (or ``[-1, 1]`` of the scaled direction, ``slice_limit_to_scale``) and shrinks towards the current point
+    (reference popstepsampler.py:746-1001; same constructor and ``__next__`` contract).  The likelihood is always called
+    with ``popsize`` points: workers whose point has found its successor are dealt to the points still searching
+    (``update_vectorised_slice_sampler``, reference stepfuncs.pyx:537-630 -- one workgroup on the device here)."""
+
+    def __init__(self, popsize, nsteps, generate_direction, scale_adapt_factor=1.0, adapt_slice_scale_target=2.0, scale=1.0,
+                 scale_jitter_func=None, slice_limit=slice_limit_to_unitcube, max_it=100, shrink_factor=1.0):
+        assert shrink_factor >= 1.0, "The shrink factor should be greater than 1.0 to be efficient"
+        self.popsize, self.nsteps, self.generate_direction = popsize, nsteps, generate_direction
+        self.max_it, self.shrink_factor = max_it, shrink_factor
+        self.scale, self.scale_adapt_factor, self.adapt_slice_scale_target = float(scale), scale_adapt_factor, adapt_slice_scale_target
+        self.scale_jitter_func = (lambda: 1.) if scale_jitter_func is None else scale_jitter_func
+        self.slice_limit = slice_limit
+        self.nrejects = self.ncalls = self.discarded = 0
+        self.logstat = []
+        self.logstat_labels = ['accept_rate', 'efficiency', 'scale', 'far_enough', 'mean_rel_jump']
+        self.prepared_samples = []
+
+    def __str__(self):
+        return 'PopulationSimpleSliceSampler(popsize=%d, nsteps=%d, generate_direction=%s, scale=%.g)' % (
+            self.popsize, self.nsteps, self.generate_direction, self.scale)
+
+    def _refill(self, region, Lmin, us, Ls, transform, loglike, test=False):
+        nlive, ndim = us.shape
+        P = self.popsize
+        start = np.random.randint(0, nlive, size=P)
+        allu = np.array(us if test else us[start, :], dtype=float)        # test: the live points themselves (reversibility checks)
+        allp = np.full((P, ndim), np.nan)
+        allL = np.array(Ls[start], dtype=float)
+        nc = ndiscarded = 0
+        width_sum = 0.
+        for _ in range(self.nsteps):
+            jitter = self.scale_jitter_func()
+            v = self.generate_direction(allu, region, scale=1.0) * self.scale * jitter
+            cube_left, cube_right = unitcube_line_intersection(allu, v)
+            wleft, wright = self.slice_limit(cube_left, cube_right)           # bounds seen by each WORKER (likelihood slot)
+            tleft, tright = self.slice_limit(cube_left, cube_right)           # bounds of each POINT's slice
+            worker_running = np.arange(P, dtype=int_dtype)                    # which point a worker serves
+            status = np.zeros(P, dtype=int_dtype)                            # 1 = the point has its successor
+            for _it in range(self.max_it):
+                t = wleft + (wright - wleft) * np.random.uniform(size=(P,))
+                unew = allu[worker_running, :] + t.reshape((-1, 1)) * v[worker_running, :]
+                pnew = transform(unew)
+                Lnew = loglike(pnew)
+                nc += P
+                tleft, tright, worker_running, status, allu, allL, allp, nd = update_vectorised_slice_sampler(
+                    t, tleft, tright, Lnew, unew, pnew, worker_running, status, Lmin, self.shrink_factor, allu, allL, allp, P)
+                ndiscarded += nd
+                wleft, wright = tleft[worker_running], tright[worker_running]
+                if not np.any(status == 0):
+                    break
+            width_sum += np.median(tright - tleft)
+        mean_width = width_sum / self.nsteps
+        self.discarded += ndiscarded
+        self.ncalls += nc
+        assert np.isfinite(allp).all(), 'some walkers never moved! Double nsteps of PopulationSimpleSliceSampler.'
+        far_enough, (moved, radius) = diagnose_move_distances(region, us[start, :], allu)
+        self.prepared_samples = list(zip(allu, allp, allL))
+        have = len(far_enough) > 0
+        self.logstat.append([P / nc, self.scale, self.nsteps, np.mean(far_enough) if have else 0,
+                             np.exp(np.mean(np.log(moved / radius + 1e-10))) if have else 0])
+        # steer the scale so that the final slices are 1 / adapt_slice_scale_target wide (reference :990-995)
+        if mean_width >= 1. / self.adapt_slice_scale_target:
+            self.scale *= 1. / self.scale_adapt_factor
+        else:
+            self.scale *= self.scale_adapt_factor
+        return nc
+
+
 class _Walkers(object):
     """Owner of one ``mlf_walkers`` handle (include/mlfriends_hip.h)."""
 
@@ -215,6 +368,10 @@ class _Walkers(object):
         us, Ls = f64(us), f64(Ls)
         check(_lib.lib().mlf_walkers_set_live(self._h, ptr(us), ptr(Ls), len(Ls)))
 
+    def update_live(self, rows, us_rows, Ls_rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        check(_lib.lib().mlf_walkers_update_live(self._h, ptr(rows), len(rows), ptr(f64(us_rows)), ptr(f64(Ls_rows))))
+
     def step_dev(self, Lmin, scale, kind, dirscale, rng, tspec, lspec, graph=True):
         """Whole sampler step on the device (graph: replayed as one hipGraph launch); returns the record
         (with the ring index after the step)."""
@@ -240,8 +397,8 @@ class _Walkers(object):
         tkind, ta, tb = tspec
         lkind, aux, sigma = lspec
         rec = np.empty(10 + 2 * self.ndim)
-        if getattr(self, "_round_rows", None) is None or len(self._round_rows) < max_rounds:
-            self._round_rows = np.empty((int(max_rounds), 5))
+        if getattr(self, "_round_rows", None) is None or len(self._round_rows) < abs(max_rounds):
+            self._round_rows = np.empty((abs(int(max_rounds)), 5))
         nxt = ctypes.c_uint64(0)
         nrounds = ctypes.c_int(0)
         check(_lib.lib().mlf_walkers_rounds_dev(
@@ -426,24 +583,45 @@ class PopulationSliceSampler(GenericPopulationSampler):
         (``mlf_walkers_step_dev``): restarts draw from a device copy of the live points and the ring
         index lives on the device; one record comes back."""
         w, seen = self._walkers, self._seen
-        # the device copy of (us, Ls) is refreshed when it is cheap or has become old; live points that
-        # were replaced meanwhile fail the L > Lmin test of the restart kernel, so a stale copy only
-        # misses the newest points
-        if seen.get("live_age", None) is None or us.size <= 32768 or seen["live_age"] >= 32:
+        # the device copy of (us, Ls) follows the host arrays ROW BY ROW: the driver replaces one live point per iteration
+        # (integrator.py:2753-2754), so the rows whose likelihood or first coordinate changed since the last call are
+        # uploaded (typically one: 8 (d + 2) bytes through pinned staging, no synchronisation) instead of the whole set
+        # (two pageable copies per call: ~40 us of an 80 us call at 1000 x 10)
+        mirror = seen.get("live_mirror")
+        if seen.get("live_age", None) is None or mirror is None or mirror[0].shape != Ls.shape or mirror[2] != us.shape[1]:
             w.set_live(us, Ls)
+            seen["live_mirror"] = [np.array(Ls, dtype=float), np.array(us[:, 0], dtype=float), us.shape[1]]
             seen["live_age"] = 0
+        else:
+            changed = np.flatnonzero(np.logical_or(Ls != mirror[0], us[:, 0] != mirror[1]))
+            if len(changed) > max(8, len(Ls) // 8):
+                w.set_live(us, Ls)
+                mirror[0][:] = Ls
+                mirror[1][:] = us[:, 0]
+            elif len(changed):
+                w.update_live(changed, us[changed], Ls[changed])
+                mirror[0][changed] = Ls[changed]
+                mirror[1][changed] = us[changed, 0]
         seen["live_age"] += 1
-        if self.max_rounds > 1:
+        if abs(self.max_rounds) > 1:      # (negative: the same rounds through the general, memory-resident form -- tests)
             rec, rows = w.rounds_dev(Lmin, self.scale, device_kind, 1.0, self.device_rng, tspec, lspec, self.max_rounds)
             have_diag = region.maxradiussq is not None
-            nc = 0
-            for row_nc, nmovable, ns, nfar, sumlog in rows:      # one logstat row per round, as one call each would have made
-                nc += int(row_nc)
-                if ns > 0:
-                    self.logstat.append([ns / max(nmovable, 1), self.scale, self.nsteps,
-                                         nfar / ns if have_diag else 0, np.exp(sumlog / ns) if have_diag else 0])
-                    if self.logfile:
-                        self.logfile.write("rescale\t%.4f\t%.4f\t%g\t%.4f%g\n" % tuple(self.logstat[-1]))
+            nc = int(rows[:, 0].sum())
+            ok = rows[:, 2] > 0            # one logstat row per round with a success, as one call each would have made
+            if ok.any():
+                r = rows[ok]
+                ns = r[:, 2]
+                table = np.empty((len(r), 5))
+                table[:, 0] = ns / np.maximum(r[:, 1], 1)
+                table[:, 1] = self.scale
+                table[:, 2] = self.nsteps
+                table[:, 3] = r[:, 3] / ns if have_diag else 0
+                table[:, 4] = np.exp(r[:, 4] / ns) if have_diag else 0
+                new_rows = table.tolist()
+                self.logstat.extend(new_rows)
+                if self.logfile:
+                    for row in new_rows:
+                        self.logfile.write("rescale\t%.4f\t%.4f\t%g\t%.4f%g\n" % tuple(row))
             rec.update(nc=nc, nsuccess=0)
             self.rounds_last_call = rec["rounds"]
         else:
@@ -476,6 +654,7 @@ class PopulationSliceSampler(GenericPopulationSampler):
 __all__ = [
     "generate_cube_oriented_direction", "generate_cube_oriented_direction_scaled", "generate_random_direction",
     "generate_region_oriented_direction", "generate_region_random_direction", "generate_differential_direction",
-    "generate_mixture_random_direction", "PopulationSliceSampler", "unitcube_line_intersection",
+    "generate_mixture_random_direction", "PopulationSliceSampler", "PopulationRandomWalkSampler",
+    "PopulationSimpleSliceSampler", "unitcube_line_intersection",
     "diagnose_move_distances",
     "slice_limit_to_unitcube", "slice_limit_to_scale", "int_dtype"]
