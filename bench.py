@@ -263,6 +263,8 @@ def step_roofline(handle, stats, kdim, ntiles32, filter_launches, launch_ms_list
         return None
 
     launches = []
+    # k_prep_sweep<DP, waves per workgroup>: 4 (two workgroups per CU) up to d = 50 by default, else 8 ("fused_waves")
+    fused_name = "k_prep_sweep<%d, %d>" % (NDIM, 4 if (handle.get_option("fused_waves") == 4 and NDIM <= 50) else 8)
     if per_step in (3, 4) and cut and len(by_phase) == per_step:
         # min-only sweep (mlf_sweepmin.hip): first range over every group, the later ones over the groups left after the
         # compaction in front of them, then the uncertain proposals (sets of 4 groups) once more over all tiles
@@ -274,7 +276,7 @@ def step_roofline(handle, stats, kdim, ntiles32, filter_launches, launch_ms_list
         usets = -(-(-(-nunc // 32)) // 4)
         for i in range(nranges):
             first = i == 0
-            name = "k_prep_sweep<50>" if (first and fused_first) else "k_sweep_min<4, 4, 2>"
+            name = fused_name if (first and fused_first) else "k_sweep_min<4, 4, 2>"
             sweep_mfma = groups[i] * tiles[i] * ks
             prep_mfma = ngroups1 * PREP_MFMA_PER_GROUP if (first and fused_first) else 0
             set_in = 0 if (first and fused_first) else groups[i] * 32 * slot

@@ -90,9 +90,9 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *                              the binary16 operand never leaves the registers, 256 MB less HBM traffic per 10^6 x 50 batch);
  *                              0: k_prep4, then k_sweep_min (the default until the first range became short: with a first range
  *                              of 30 % and more of the tiles the separate launches were 3 % faster)
- *   "fused_waves"              8 (default) / 4: waves per workgroup of k_prep_sweep.  8: one workgroup per CU (137 KiB of LDS at d = 50);
- *                              4: 79 KiB per workgroup, two per CU -- workgroups that start and end independently of each other, so
- *                              that one streams proposal rows while the other multiplies
+ *   "fused_waves"              4 (default) / 8: waves per workgroup of k_prep_sweep.  4: 79 KiB of LDS per workgroup at d = 50, two per CU --
+ *                              the CU's eight waves start and end in two independent halves (0.177 against 0.181 ms at C5); used up
+ *                              to d = 50 (above, two such workgroups do not fit a CU).  8: one workgroup of 8 waves per CU
  *   "fused_variant"            default 1: bit 0 = k_prep_sweep fetches its 28 KiB of matrix fragments by LDS-DMA (every request of a wave
  *                              under way at once); 0 = by a load / store loop (round 5's form), kept for A/B runs inside ONE process
  *                              (scripts/fused_ab.py: boxes of the pool differ by 8 % in this kernel)

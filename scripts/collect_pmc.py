@@ -33,7 +33,7 @@ stats = {}
 import glob
 for f in glob.glob(src + "_stats/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
-        stats[r["Name"][:44]] = float(r["AverageNs"]) * 1e-6
+        stats[r["Name"]] = float(r["AverageNs"]) * 1e-6
 summary = {}
 for k in sq:
     if not k.startswith(("void mlf::k_sweep_min", "void mlf::k_uncertain", "void mlf::k_prep4", "void mlf::k_prep_sweep", "void mlf::k_scan",
@@ -42,6 +42,8 @@ for k in sq:
     a, w = sq[k], wait.get(k, {})
     cycles = a["GRBM_GUI_ACTIVE"] / 8.0                      # per XCD = launch duration in shader cycles
     ms = stats.get(k)
+    if ms is None:      # the counter tables may carry a shortened kernel name
+        ms = next((v for name, v in stats.items() if name.startswith(k) or k.startswith(name[:44])), None)
     fills_the_chip = k.startswith(("void mlf::k_sweep_min", "void mlf::k_prep_sweep"))   # see the module docstring
     e = dict(avg_ms_kernel_stats=ms, launch_cycles=cycles if fills_the_chip else None,
              clock_GHz=(cycles / (ms * 1e6)) if (ms and fills_the_chip) else None,
@@ -72,7 +74,7 @@ sweeps = {k: v["hbm_bytes_gfx950_corrected"] for k, v in summary.items() if k.st
 stats_calls = {}
 for f in glob.glob(src + "_stats/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
-        stats_calls[r["Name"][:44]] = int(r["Calls"])
+        stats_calls[r["Name"]] = int(r["Calls"])
 if sweeps:
     # the ranges run the same instance: its counters are the mean over its launches already
     per_launch = sum(sweeps.values()) / len(sweeps)

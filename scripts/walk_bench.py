@@ -44,7 +44,8 @@ else:
     from ultranest_amd.regions import DeviceRNG
     configs = [("numpy stream, numpy likelihood", host_transform, host_loglike, None),
                ("numpy stream, resident likelihood", likelihoods.rosenbrock_transform, likelihoods.rosenbrock_loglike, None),
-               ("philox, resident likelihood", likelihoods.rosenbrock_transform, likelihoods.rosenbrock_loglike, 7)]
+               ("philox, resident likelihood, one round per call", likelihoods.rosenbrock_transform, likelihoods.rosenbrock_loglike, 7),
+               ("philox, resident likelihood, rounds until a walker is harvested", likelihoods.rosenbrock_transform, likelihoods.rosenbrock_loglike, 7)]
 
 layer = m.AffineLayer()
 layer.optimize(u, u)
@@ -59,6 +60,8 @@ for popsize in (100, 1000, 10000, 100000):
         kw = {} if impl == "reference" or seed is None else dict(device_rng=DeviceRNG(seed))
         sampler = pop.PopulationSliceSampler(popsize=popsize, nsteps=nsteps,
                                              generate_direction=pop.generate_mixture_random_direction, scale=0.1, **kw)
+        if hasattr(sampler, "max_rounds"):
+            sampler.max_rounds = 256 if label.endswith("harvested") else 1
         ncalls = 60 if popsize <= 10000 else 25
         for _ in range(5):
             sampler.__next__(region, Lmin, u, Ls, transform, loglike)
@@ -70,7 +73,8 @@ for popsize in (100, 1000, 10000, 100000):
             nfound += r[0] is not None
         dt = (time.perf_counter() - t0) / ncalls
         row = dict(impl=impl, mode=label, popsize=popsize, d=d, ms_per_call=dt * 1e3,
-                   walker_steps_per_s=popsize / dt, likelihood_evals_per_call=nc / ncalls, found=nfound)
+                   walker_steps_per_s=(popsize / dt) if not label.endswith("harvested") else None,
+                   likelihood_evals_per_call=nc / ncalls, likelihood_evals_per_s=nc / ncalls / dt, found=nfound)
         out.append(row)
         print(json.dumps(row), flush=True)
 json.dump(out, open(os.path.join("gpurun_out" if os.path.isdir("gpurun_out") else ".", "walk_bench_%s.json" % impl), "w"), indent=1)

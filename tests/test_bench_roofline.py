@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 class _Handle(object):
     def get_option(self, name):
-        return {"filter_first_range_pct": 30, "filter_second_range_pct": 50, "filter_order": 1}[name]
+        return {"filter_first_range_pct": 30, "filter_second_range_pct": 50, "filter_order": 1, "fused_waves": 8}[name]
 
 
 def test_step_roofline_reproduces_the_hand_computation():
@@ -27,11 +27,11 @@ def test_step_roofline_reproduces_the_hand_computation():
     step_ms = 0.3844
     alg = bench.NPROPOSALS * (8 * bench.NDIM + 1) + 8 * bench.N_LIVE * bench.NDIM + 2 * 8 * bench.NDIM**2
     hbm = {"achieved_GBps": alg / (step_ms * 1e-3) / 1e9, "frac": alg / (step_ms * 1e-3) / 1e9 / 8000.0}
-    pmc = {"per_kernel_all": {"k_prep_sweep<50>": 493616128.0, "k_sweep_min<4, 4, 2>": 81673216.0, "k_uncertain<4, 4>": 68191232.0},
+    pmc = {"per_kernel_all": {"k_prep_sweep<50, 8>": 493616128.0, "k_sweep_min<4, 4, 2>": 81673216.0, "k_uncertain<4, 4>": 68191232.0},
            "hbm_bytes_per_step_all_kernels": 731218944.0, "fresh": False, "status": "STALE: test"}
     r = bench.step_roofline(_Handle(), stats, 64, 125, (80, sum(per_launch) * 20), launch_ms, 20, True, step_ms, 0.41, alg, pmc, hbm,
                             2.63e11)
-    assert r["kernel"] == "k_prep_sweep<50>" and r["bound"] == "hbm" and r["unit"] == "GB/s"
+    assert r["kernel"] == "k_prep_sweep<50, 8>" and r["bound"] == "hbm" and r["unit"] == "GB/s"
     assert abs(r["frac"] - 0.32) < 0.005, r["frac"]                       # 476 MB / 185.98 us = 2.56 TB/s
     assert abs(r["other_roof"]["frac"] - 0.25) < 0.005                    # 3.56e6 MFMA x 32768 / 185.98 us = 628 TF
     assert r["launches"][0]["executed_mfma"] == 31250 * 42 + 31250 * 18 * 4

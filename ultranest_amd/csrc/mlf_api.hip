@@ -73,7 +73,7 @@ enum Opt : int {
   OPT_ORDER,               // "filter_order" 0/1: mask-mode operand in storage order / nearest to the centre first (k_ref_rank)
   OPT_SECOND_RANGE_PCT,    // "filter_second_range_pct" 0 ... 90: min-only sweep in three ranges, the second ending at this share of the tiles (0: two ranges)
   OPT_THIRD_MIN_WORK,      // "filter_third_range_min_work": three ranges from this many (proposals x 32-row live-point tiles) on
-  OPT_FUSED_WAVES,         // "fused_waves" 8 / 4: waves per workgroup of k_prep_sweep (8: one workgroup per CU; 4: two, out of step)
+  OPT_FUSED_WAVES,         // "fused_waves" 4 / 8: waves per workgroup of k_prep_sweep (4, default: two workgroups per CU up to d = 50; 8: one)
   OPT_FUSED_VARIANT,       // "fused_variant": bit 0 = k_prep_sweep loads its matrix fragments by LDS-DMA (default 1) or by a load / store loop (0)
   OPT_COUNT
 };
@@ -87,7 +87,7 @@ std::atomic<unsigned> g_grant_epoch{0u};
 std::atomic<unsigned long long> g_grant_calls{0ull};
 }  // namespace mlf
 namespace {
-long long g_opt[OPT_COUNT] = {1, 30, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 1, 1, 1, 50, 100000000ll, 8, 1};
+long long g_opt[OPT_COUNT] = {1, 30, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 1, 1, 1, 50, 100000000ll, 4, 1};
 
 struct OptOverrides {
   long long v[OPT_COUNT] = {};

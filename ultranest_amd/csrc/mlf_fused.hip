@@ -257,6 +257,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
       const long long p = grp * 32 + p32;
       const bool live = p < np;
       float qs = 0.0f;
+      float16v tt[NT];
+      // (round 6, measured and dropped: the chains of a group interleaved by k-step -- tt[0], tt[1], ye[0] in turn, every chain
+      // in its own order, same bits -- 0.1803-0.1809 against 0.1805 ms for the launch: the chains are not what the stage waits for)
       {
         float16v ye[NE];
 #pragma unroll
@@ -278,7 +281,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
 #pragma unroll
           for (int r = 0; r < 16; ++r) qs = __builtin_fmaf(ye[t][r], ye[t][r], qs);
       }
-      float16v tt[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         tt[t] = (float16v){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -290,7 +292,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
           tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, hia[s], tt[t], 0, 0, 0);
         }
       }
-      if (g == 1) stamp(15);
       qs = half_sum(qs) * inv_slsx2;
       const float dn2 = half_sum(dn2a) * inv_sx2;
       bool sure_in = false, sure_out = false;
@@ -381,9 +382,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
         dn2a = operands();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (g == 0) stamp(13);
         if (g + 2 < QW) fetch_group(grp + 2);
-        if (g == 0) stamp(14);
       }
     }
 #pragma unroll
@@ -532,7 +531,7 @@ bool fused_usable(int dp) { return dp >= 2 && dp <= 56 && (dp & 1) == 0; }
 template <int D, int NW>
 static hipError_t launch_prep_sweep_t(const FusedArgs &a, long long nsets, hipStream_t s) {
   constexpr size_t lds = F4<D, NW>::LDS;
-  static_assert(lds <= 160 * 1024 - 64, "LDS budget");   // NW = 4: two workgroups per CU up to d = 50 (2 x 81 088 B); 52, 56: one
+  static_assert(lds <= 160 * 1024 - 64, "LDS budget");
   static DeviceGrant grant;
   if (hipError_t e = grant.ensure([] {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_sweep<D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -544,16 +543,20 @@ static hipError_t launch_prep_sweep_t(const FusedArgs &a, long long nsets, hipSt
   return hipGetLastError();
 }
 
-// waves: 8 = one workgroup of 8 waves per CU; 4 = workgroups of 4 waves, two per CU (which fall out of step: one streams rows
-// while the other multiplies)
+// waves = 4 (default): workgroups of 4 waves, TWO per CU where the rows of four groups + the tables fit half the LDS (d <= 50:
+// 2 x 81 088 B) -- the CU's eight waves then start and end in two independent halves (0.1768 against 0.1805 ms at C5, one
+// process, profiles/r06_fused_ab.jsonl); waves = 8, and every d above 50: one workgroup of 8 waves per CU
 hipError_t launch_prep_sweep(const FusedArgs &a, hipStream_t s, int waves) {
   if (a.p.np <= 0) return hipSuccess;
   const long long ngroups = (a.p.np + 31) / 32;
   const long long nsets = (ngroups + 3) / 4;
   switch (a.p.dp) {
-#define X(D) \
-  case D:    \
-    return waves == 4 ? launch_prep_sweep_t<D, 4>(a, nsets, s) : launch_prep_sweep_t<D, 8>(a, nsets, s);
+#define X(D)                                                                                  \
+  case D:                                                                                     \
+    if constexpr (2 * F4<D, 4>::LDS <= 160 * 1024) {                                          \
+      if (waves == 4) return launch_prep_sweep_t<D, 4>(a, nsets, s);                          \
+    }                                                                                         \
+    return launch_prep_sweep_t<D, 8>(a, nsets, s);
     MLF_FOR_EACH_DP_MID(X)
 #undef X
     default:
