@@ -400,7 +400,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
   int run[QW];
 #pragma unroll
   for (int g = 0; g < QW; ++g) run[g] = kPosInf;
-  if (g0 < ngroups) {
+  // a wave none of whose proposals is left for the filter (all gated out by the ellipsoid, or routed to the exact scan) has
+  // nothing to sweep: thi <= 0 marks such a proposal, and stage C looks at no minimum of an invalid one (set U: the launch
+  // 0.151 ms -> see profiles/r06_fused_ab.jsonl)
+  bool any_valid = false;
+#pragma unroll
+  for (int g = 0; g < QW; ++g) any_valid = any_valid || thi[g] > 0.0f;
+  if (g0 < ngroups && __any(any_valid)) {
     const int ntl = a.tile1 - a.tile0;
     const int tstart = a.tile0 + (int)((set * 37) % ntl);
     constexpr int kTileBytes = KS * 1024;
