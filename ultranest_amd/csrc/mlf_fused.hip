@@ -50,8 +50,16 @@ struct F4 {
   static constexpr size_t LDS = r16(FRAG) + NW * WAVE + 64 + (NW == 8 ? 0 : 128);
 };
 
-__host__ __device__ inline int f4_column(int t, int i) {
+__host__ __device__ constexpr int f4_column(int t, int i) {
   return 32 * t + 16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3);
+}
+// accumulator registers 2 m, 2 m + 1 of tile t hold, in BOTH halves of the wave, rows of T^T that belong to padded columns
+// (>= dp): their values are exact zeros (zero matrix rows, zero centre term)
+__host__ __device__ constexpr bool f4_pair_is_padding(int t, int m, int dp) {
+  for (int r = 2 * m; r < 2 * m + 2; ++r)
+    for (int h = 0; h < 2; ++h)
+      if (f4_column(t, (r & 3) + 8 * (r >> 2) + 4 * h) < dp) return false;
+  return true;
 }
 __device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 __device__ __forceinline__ int min3i(int a, int b, int c) {
@@ -211,6 +219,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
       for (int j2 = 0; j2 < 4; ++j2) {
+        if (16 * s + 2 * j2 >= DP) {   // (compile time) both halves of the wave hold padding here: k >= DP >= d -- exact zeros,
+          const _Float16 z = (_Float16)0.0f;   // nothing to read or convert (d = 50: 6 of the 32 pairs of a lane)
+          hia[s][2 * j2] = z;
+          hia[s][2 * j2 + 1] = z;
+          loa[s][2 * j2] = z;
+          loa[s][2 * j2 + 1] = z;
+          continue;
+        }
         float x32[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -330,6 +346,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
+          if (f4_pair_is_padding(t, m, DP)) continue;   // (compile time; pk was zeroed above; d = 50: 3 of the 16 pairs)
           const float v0 = __builtin_fmaf(tt[t][2 * m], kappa, csl[32 * t + ((2 * m) & 3) + 8 * ((2 * m) >> 2) + 4 * h]);
           const float v1 = __builtin_fmaf(tt[t][2 * m + 1], kappa, csl[32 * t + ((2 * m + 1) & 3) + 8 * ((2 * m + 1) >> 2) + 4 * h]);
           union { half2v v; unsigned u; } cv;

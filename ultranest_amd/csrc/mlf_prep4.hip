@@ -92,8 +92,15 @@ struct P4 {
 };
 
 // filter column of row i of tile t of the whitening product
-__host__ __device__ inline int p4_column(int t, int i) {
+__host__ __device__ constexpr int p4_column(int t, int i) {
   return 32 * t + 16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3);
+}
+// accumulator registers 2 m, 2 m + 1 of tile t hold, in BOTH halves of the wave, rows of T^T of padded columns (>= dp): zeros
+__host__ __device__ constexpr bool p4_pair_is_padding(int t, int m, int dp) {
+  for (int r = 2 * m; r < 2 * m + 2; ++r)
+    for (int h = 0; h < 2; ++h)
+      if (p4_column(t, (r & 3) + 8 * (r >> 2) + 4 * h) < dp) return false;
+  return true;
 }
 
 __device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
@@ -210,6 +217,14 @@ __global__ __launch_bounds__(64 * P4<DP>::NW, 1) void k_prep4(Prep4Args a) {
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
       for (int j2 = 0; j2 < 4; ++j2) {
+        if (16 * s + 2 * j2 >= DP) {   // (compile time) both halves of the wave hold padding here: k >= DP >= d -- exact zeros
+          const _Float16 z = (_Float16)0.0f;
+          hi[s][2 * j2] = z;
+          hi[s][2 * j2 + 1] = z;
+          lo[s][2 * j2] = z;
+          lo[s][2 * j2 + 1] = z;
+          continue;
+        }
         float x32[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -339,6 +354,10 @@ __global__ __launch_bounds__(64 * P4<DP>::NW, 1) void k_prep4(Prep4Args a) {
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
+          if (p4_pair_is_padding(t, m, DP)) {   // (compile time) exact zeros in both halves of the wave
+            pk[t * 8 + m] = 0u;
+            continue;
+          }
           const float v0 = __builtin_fmaf(tt[t][2 * m], kappa, csl[32 * t + ((2 * m) & 3) + 8 * ((2 * m) >> 2) + 4 * h]);
           const float v1 = __builtin_fmaf(tt[t][2 * m + 1], kappa, csl[32 * t + ((2 * m + 1) & 3) + 8 * ((2 * m + 1) >> 2) + 4 * h]);
           union { half2v v; unsigned u; } cv;
