@@ -161,31 +161,37 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
   const long long total = np * (long long)d;
   typedef __attribute__((address_space(1))) const void gptr_t;
   typedef __attribute__((address_space(3))) void lptr_t;
+  // The 32 rows of a group are 16 d contiguous 16-byte units; they travel as 1 KiB pieces (64 lanes x 16 bytes).  Four pieces
+  // share ONE address register and ONE LDS base (M0): the instruction's immediate offset (0, 1024, 2048, 3072) moves both
+  // sides -- 13 separate 64-bit address computations and M0 writes per group were 10 % of the stage's vector instructions.
+  // Only the group's own units are requested (whole pieces by a scalar condition, the last one by a lane mask): nothing is read
+  // behind the batch.  The one group that ends behind the batch takes the plain loop at the bottom.
+  const int units = 16 * d, nfull = units >> 6, rem = units & 63;
   auto fetch_group = [&](long long grp) __attribute__((always_inline)) {
     if (grp >= ngroups) return;
     const long long base = grp * 32 * (long long)d;
-    if (NW == 8 && base + 128 * C::NPC <= total) {
+    if (base + 32 * (long long)d <= total) {
+      const unsigned char *src = reinterpret_cast<const unsigned char *>(a.p.pts + base) + lane * 16;
 #pragma unroll
-      for (int i = 0; i < C::NPC; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t *)(a.p.pts + base + 2 * (lane + 64 * i)), (lptr_t *)(area + i * 1024), 16, 0, 0);
-    } else if (NW != 8 && base + 32 * (long long)d <= total) {   // the group's 32 rows lie inside the batch: only they are requested
-      const int nfull = (16 * d) >> 6, rem = (16 * d) & 63;   // whole 1 KiB pieces of the 32 rows, 16-byte units of the last one
-#pragma unroll
-      for (int i = 0; i < C::NPC; ++i) {
-        if (i < nfull)        // (scalar conditions: no per-lane compare per piece)
-          __builtin_amdgcn_global_load_lds((gptr_t *)(a.p.pts + base + 2 * (lane + 64 * i)), (lptr_t *)(area + i * 1024), 16, 0, 0);
-        else if (i == nfull && lane < rem)
-          __builtin_amdgcn_global_load_lds((gptr_t *)(a.p.pts + base + 2 * (lane + 64 * i)), (lptr_t *)(area + i * 1024), 16, 0, 0);
+      for (int ib = 0; ib < C::NPC; ib += 4) {   // whole pieces: scalar conditions only (the immediate offset has to be a literal)
+        gptr_t *gp = (gptr_t *)(src + ib * 1024);
+        lptr_t *lp = (lptr_t *)(area + ib * 1024);
+        if (ib < nfull) __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+        if (ib + 1 < C::NPC && ib + 1 < nfull) __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+        if (ib + 2 < C::NPC && ib + 2 < nfull) __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+        if (ib + 3 < C::NPC && ib + 3 < nfull) __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
       }
+      if (lane < rem)   // the last, partial piece (one lane mask per group)
+        __builtin_amdgcn_global_load_lds((gptr_t *)(src + nfull * 1024), (lptr_t *)(area + nfull * 1024), 16, 0, 0);
     } else {
-#pragma unroll
-      for (int i = 0; i < C::NPC; ++i) {
-        const int e = lane + 64 * i;
+#pragma nounroll
+      for (int e = lane; e < units; e += 64) {   // (at most one group per batch) plain loads, zero behind the batch
         const long long g = base + 2 * e;
-        if (e < 16 * d && g + 1 < total)
-          __builtin_amdgcn_global_load_lds((gptr_t *)(a.p.pts + g), (lptr_t *)(area + i * 1024), 16, 0, 0);
-        else if (e < 16 * d && g + 1 == total)
-          xs[2 * e] = a.p.pts[g];
+        double v0 = 0.0, v1 = 0.0;
+        if (g < total) v0 = a.p.pts[g];
+        if (g + 1 < total) v1 = a.p.pts[g + 1];
+        xs[2 * e] = v0;
+        xs[2 * e + 1] = v1;
       }
     }
   };

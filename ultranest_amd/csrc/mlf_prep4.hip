@@ -192,19 +192,26 @@ __global__ __launch_bounds__(64 * P4<DP>::NW, 1) void k_prep4(Prep4Args a) {
   auto fetch_group = [&](long long grp) {
     const long long base = grp * 32 * (long long)d;
     if (base + 128 * C::NPC <= total) {   // wave-uniform: the whole 1 KiB-granular window lies inside the batch
+      // four pieces share one address register and one LDS base (M0): the instruction's immediate offset moves both sides
+      const unsigned char *src = reinterpret_cast<const unsigned char *>(a.pts + base) + lane * 16;
 #pragma unroll
-      for (int i = 0; i < C::NPC; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t *)(a.pts + base + 2 * (lane + 64 * i)),
-                                         (lptr_t *)(reinterpret_cast<char *>(xs) + i * 1024), 16, 0, 0);
+      for (int ib = 0; ib < C::NPC; ib += 4) {
+        gptr_t *gp = (gptr_t *)(src + ib * 1024);
+        lptr_t *lp = (lptr_t *)(reinterpret_cast<char *>(xs) + ib * 1024);
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+        if (ib + 1 < C::NPC) __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+        if (ib + 2 < C::NPC) __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+        if (ib + 3 < C::NPC) __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+      }
     } else {
-#pragma unroll
-      for (int i = 0; i < C::NPC; ++i) {
-        const int e = lane + 64 * i;
+#pragma nounroll
+      for (int e = lane; e < 16 * d; e += 64) {   // (the last groups of a batch) plain loads, zero behind the batch
         const long long g = base + 2 * e;
-        if (e < 16 * d && g + 1 < total)
-          __builtin_amdgcn_global_load_lds((gptr_t *)(a.pts + g), (lptr_t *)(reinterpret_cast<char *>(xs) + i * 1024), 16, 0, 0);
-        else if (e < 16 * d && g + 1 == total)   // np * d odd: the batch ends in the middle of this 16-byte piece
-          xs[2 * e] = a.pts[g];
+        double v0 = 0.0, v1 = 0.0;
+        if (g < total) v0 = a.pts[g];
+        if (g + 1 < total) v1 = a.pts[g + 1];
+        xs[2 * e] = v0;
+        xs[2 * e + 1] = v1;
       }
     }
   };
