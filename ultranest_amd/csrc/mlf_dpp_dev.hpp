@@ -35,6 +35,34 @@ __device__ __forceinline__ void fmac_row_bcast(double &acc, double entries16, do
   asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(entries16), "v"(y), "n"(K));
 }
 
+// The two halves of a wave (lanes l and l + 32) exchanged by ONE vector instruction (gfx950: v_permlane32_swap_b32 with both
+// operands copies of x: the first result holds x of the LOW half in all 64 lanes, the second x of the HIGH half) -- instead
+// of ds_bpermute, an LDS-crossbar round trip of 100+ cycles with dependent code behind it.
+__device__ __forceinline__ void halves_of(unsigned x, unsigned &low, unsigned &high) {
+  typedef unsigned uint2s __attribute__((ext_vector_type(2)));
+  const uint2s r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  low = r[0];
+  high = r[1];
+}
+// x(l) + x(l ^ 32): the bits of `x + __shfl_xor(x, 32)` in every lane (binary32 addition commutes)
+__device__ __forceinline__ float half_sum32(float x) {
+  unsigned lo, hi;
+  halves_of(__float_as_uint(x), lo, hi);
+  return __uint_as_float(lo) + __uint_as_float(hi);
+}
+// x of lane (l & 31) in every lane: `__shfl(x, l & 31)`
+__device__ __forceinline__ float low_half32(float x) {
+  unsigned lo, hi;
+  halves_of(__float_as_uint(x), lo, hi);
+  return __uint_as_float(lo);
+}
+// min over the two halves (signed compare): `min(x, __shfl_xor(x, 32))`
+__device__ __forceinline__ int half_min32(int x) {
+  unsigned lo, hi;
+  halves_of((unsigned)x, lo, hi);
+  return (int)lo < (int)hi ? (int)lo : (int)hi;
+}
+
 __device__ __forceinline__ void dpp_settle(double &x) { asm volatile("s_nop 1" : "+v"(x)); }
 
 template <int K, int N, class F>

@@ -15,6 +15,7 @@
 // Everything k_prep4 wrote for the later stages is written here too: gate, route, best = none, the ellipsoid band list.
 // (Round 2 measured this fusion with k_filter's loop: 395 against 112 + 273 us; with the min-only loop see DESIGN 4f.)
 #include "mlf_filter.hpp"
+#include "mlf_dpp_dev.hpp"
 #include "mlf_filter_dev.hpp"
 #include "mlf_prep4.hpp"
 
@@ -61,7 +62,7 @@ __host__ __device__ constexpr bool f4_pair_is_padding(int t, int m, int dp) {
       if (f4_column(t, (r & 3) + 8 * (r >> 2) + 4 * h) < dp) return false;
   return true;
 }
-__device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float half_sum(float v) { return half_sum32(v); }
 __device__ __forceinline__ int min3i(int a, int b, int c) {
   const int m = a < b ? a : b;
   return m < c ? m : c;
@@ -98,7 +99,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
   float *y0l = reinterpret_cast<float *>(const_cast<uint4 *>(Ll + C::NLT * 64));
   float *csl = y0l + 32 * NE;
   double *ctrl = reinterpret_cast<double *>(csl + 32 * NT);
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave's number in a SCALAR register: what hangs on it (its LDS area, its groups, the conditions on them) is then computed and
+  // branched on by the scalar unit -- the compiler does not see that tid >> 6 is the same in all lanes
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p32 = lane & 31, h = lane >> 5;
   unsigned char *area = ldsf + C::r16(C::FRAG) + (size_t)wv * C::WAVE;
   double *xs = reinterpret_cast<double *>(area);
@@ -415,8 +419,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
       bq[g][s] = cv.h8;
     }
     // every lane of a query needs its thresholds (the per-proposal stage leaves them in the low half)
-    tlo[g] = __shfl(lo_f, p32, 64);
-    thi[g] = __shfl(hi_f, p32, 64);
+    tlo[g] = low_half32(lo_f);
+    thi[g] = low_half32(hi_f);
   }
 
   // ---- B. the first live-point range, running minima only (k_sweep_min's loop)
@@ -502,8 +506,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
     qmn[g] = kPosInf;
     if (g0 + g >= ngroups) continue;
     const long long qi = (g0 + g) * 32 + p32;
-    const int other = __shfl_xor(run[g], 32);
-    const int m = run[g] < other ? run[g] : other;
+    const int m = half_min32(run[g]);
     const float mf = __int_as_float(m);
     const bool valid = qi < np && thi[g] > 0.0f;
     const bool hit = valid && mf <= tlo[g];

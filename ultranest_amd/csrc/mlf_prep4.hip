@@ -56,6 +56,7 @@
 
 #include <vector>
 
+#include "mlf_dpp_dev.hpp"
 #include "mlf_filter_dev.hpp"
 #include "mlf_prep3.hpp"
 #include "mlf_ell_exact.hpp"
@@ -103,7 +104,7 @@ __host__ __device__ constexpr bool p4_pair_is_padding(int t, int m, int dp) {
   return true;
 }
 
-__device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float half_sum(float v) { return half_sum32(v); }
 
 }  // namespace
 

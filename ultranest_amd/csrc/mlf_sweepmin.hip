@@ -31,6 +31,7 @@
 // (filter_thresholds: a negative lower threshold becomes -inf), so "minimum <= T_lo" and "minimum <= T_hi" are decided
 // correctly whichever negative value the integer minimum happens to keep.
 #include "mlf_filter.hpp"
+#include "mlf_dpp_dev.hpp"
 #include "mlf_filter_dev.hpp"
 #include "mlf_recheck_dev.hpp"
 
@@ -248,8 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(min_waves(K
     qmn[g] = kPosInf;
     if (g0 + g >= ngroups) continue;
     const long long qi = qnum[g];
-    const int other = __shfl_xor(run[g], 32);
-    const int m = run[g] < other ? run[g] : other;                 // both halves hold the query's minimum now
+    const int m = half_min32(run[g]);                              // both halves hold the query's minimum now
     const float mf = __int_as_float(m);
     const bool valid = qi >= 0 && qi < a.nq && thi[g] > 0.0f;      // T_hi > 0 <=> the query has thresholds (route 1)
     const bool hit = valid && mf <= tlo[g];
