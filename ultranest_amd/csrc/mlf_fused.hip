@@ -29,6 +29,9 @@ typedef _Float16 half8v __attribute__((ext_vector_type(8)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
+#ifndef MLF_OPERAND_STEPS
+#define MLF_OPERAND_STEPS 4
+#endif
 namespace {
 
 template <int DP, int NW = 8>
@@ -49,6 +52,30 @@ struct F4 {
   // + the workgroup's compaction counts (all LDS in the dynamic region); the operand reads of the padded coordinates
   // (k >= d, values discarded) reach up to 16 NS - d doubles behind the last wave's rows: they stay inside the allocation
   static constexpr size_t LDS = r16(FRAG) + NW * WAVE + 64 + (NW == 8 ? 0 : 128);
+};
+
+// The matrix chains of a group as ONE list of steps (a step = one k-step of one output tile: two fragment reads, three matrix
+// instructions): first the L^T tiles (ellipsoid form), then the T^T tiles, tiles taking turns within each part so that
+// neighbouring steps are independent chains.  i -> (part, tile, k-step, fragment index in its table)
+template <int NS, int NE, int NT>
+struct F4Steps {
+  static constexpr int NYE = NS + (NE > 1 ? NS - 2 : 0);
+  static constexpr int N = NYE + NT * NS;
+  static constexpr int ye_find(int i, bool want_t) {
+    int c = 0;
+    for (int s = 0; s < NS; ++s)
+      for (int t = 0; t < NE; ++t)
+        if (s >= 2 * t) {
+          if (c == i) return want_t ? t : s;
+          ++c;
+        }
+    return 0;
+  }
+  static constexpr bool is_t(int i) { return i >= NYE; }
+  static constexpr int tile(int i) { return i < NYE ? ye_find(i, true) : (i - NYE) % NT; }
+  static constexpr int kstep(int i) { return i < NYE ? ye_find(i, false) : (i - NYE) / NT; }
+  static constexpr int fragment(int i) { return i < NYE ? (tile(i) ? NS : 0) + kstep(i) - 2 * tile(i) : tile(i) * NS + kstep(i); }
+  static constexpr bool first_of_chain(int i) { return i >= NYE && kstep(i) == 0; }
 };
 
 __host__ __device__ constexpr int f4_column(int t, int i) {
@@ -223,37 +250,73 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
   float tlo[QW], thi[QW];
   half8v hia[NS], loa[NS];
   float dn2a = 0.0f;
+  // this lane's piece of its proposal's row and of the centre: ONE address register each, the coordinate in the instruction's
+  // offset field (left to itself the compiler keeps 52 precomputed addresses in registers across the groups and reads four
+  // values per LDS round trip for want of room)
+  typedef __attribute__((address_space(3))) const double lds_cdouble;
+  lds_cdouble *xrow = (lds_cdouble *)(xs + p32 * d + 8 * h);
+  lds_cdouble *crow = (lds_cdouble *)(ctrl + 8 * h);
+  asm volatile("" : "+v"(xrow), "+v"(crow));
   auto operands = [&]() __attribute__((always_inline)) {
     float dn2 = 0.0f;
+    // SB k-steps per LDS round trip: all their reads first, pinned there by an empty asm that takes the values (left alone the
+    // compiler asks for four values, waits, converts, asks for the next four: 7 dependent round trips per group)
+    constexpr int SB = MLF_OPERAND_STEPS;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int sb = 0; sb < NS; sb += SB) {
+      double xv[SB][8], cv[SB][8];
 #pragma unroll
-      for (int j2 = 0; j2 < 4; ++j2) {
-        if (16 * s + 2 * j2 >= DP) {   // (compile time) both halves of the wave hold padding here: k >= DP >= d -- exact zeros,
-          const _Float16 z = (_Float16)0.0f;   // nothing to read or convert (d = 50: 6 of the 32 pairs of a lane)
-          hia[s][2 * j2] = z;
-          hia[s][2 * j2 + 1] = z;
-          loa[s][2 * j2] = z;
-          loa[s][2 * j2 + 1] = z;
-          continue;
+      for (int s = sb; s < sb + SB && s < NS; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          if (16 * s + (jj & ~1) >= DP) continue;   // (compile time) padding in both halves of the wave, see below
+          xv[s - sb][jj] = xrow[16 * s + jj];
+          cv[s - sb][jj] = crow[16 * s + jj];
         }
-        float x32[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int jj = 2 * j2 + e;
-          const int k = 16 * s + 8 * h + jj;
-          const bool ok = 16 * s + 8 + jj < C::KMIN || k < d;
-          const double xv = __builtin_fma(xs[p32 * d + k], sxd, -ctrl[k < 16 * NS ? k : 0]);
-          x32[e] = ok ? (float)xv : 0.0f;
-          dn2 = __builtin_fmaf(x32[e], x32[e], dn2);
+      for (int s = sb; s < sb + SB && s < NS; ++s)
+#pragma unroll
+        for (int j4 = 0; j4 < 8; j4 += 4) {
+          if (16 * s + j4 >= DP) continue;
+          if (16 * s + j4 + 2 >= DP)
+            asm volatile("" : "+v"(xv[s - sb][j4]), "+v"(xv[s - sb][j4 + 1]), "+v"(cv[s - sb][j4]), "+v"(cv[s - sb][j4 + 1]) : : "memory");
+          else
+            asm volatile(""
+                         : "+v"(xv[s - sb][j4]), "+v"(xv[s - sb][j4 + 1]), "+v"(xv[s - sb][j4 + 2]), "+v"(xv[s - sb][j4 + 3]),
+                           "+v"(cv[s - sb][j4]), "+v"(cv[s - sb][j4 + 1]), "+v"(cv[s - sb][j4 + 2]), "+v"(cv[s - sb][j4 + 3])
+                         :
+                         : "memory");
         }
-        const half2v hp = __builtin_convertvector((float2v){x32[0], x32[1]}, half2v);
-        const float2v res = {x32[0] - (float)hp[0], x32[1] - (float)hp[1]};
-        const half2v lp = __builtin_convertvector(res, half2v);
-        hia[s][2 * j2] = hp[0];
-        hia[s][2 * j2 + 1] = hp[1];
-        loa[s][2 * j2] = lp[0];
-        loa[s][2 * j2 + 1] = lp[1];
+#pragma unroll
+      for (int s = sb; s < sb + SB && s < NS; ++s) {
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+          if (16 * s + 2 * j2 >= DP) {   // (compile time) both halves of the wave hold padding here: k >= DP >= d -- exact zeros,
+            const _Float16 z = (_Float16)0.0f;   // nothing to read or convert (d = 50: 6 of the 32 pairs of a lane)
+            hia[s][2 * j2] = z;
+            hia[s][2 * j2 + 1] = z;
+            loa[s][2 * j2] = z;
+            loa[s][2 * j2 + 1] = z;
+            continue;
+          }
+          float x32[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int jj = 2 * j2 + e;
+            const int k = 16 * s + 8 * h + jj;
+            const bool ok = 16 * s + 8 + jj < C::KMIN || k < d;
+            const double x = __builtin_fma(xv[s - sb][jj], sxd, -cv[s - sb][jj]);
+            x32[e] = ok ? (float)x : 0.0f;
+            dn2 = __builtin_fmaf(x32[e], x32[e], dn2);
+          }
+          const half2v hp = __builtin_convertvector((float2v){x32[0], x32[1]}, half2v);
+          const float2v res = {x32[0] - (float)hp[0], x32[1] - (float)hp[1]};
+          const half2v lp = __builtin_convertvector(res, half2v);
+          hia[s][2 * j2] = hp[0];
+          hia[s][2 * j2 + 1] = hp[1];
+          loa[s][2 * j2] = lp[0];
+          loa[s][2 * j2 + 1] = lp[1];
+        }
       }
     }
     return dn2;
@@ -284,39 +347,57 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
       const bool live = p < np;
       float qs = 0.0f;
       float16v tt[NT];
-      // (round 6, measured and dropped: the chains of a group interleaved by k-step -- tt[0], tt[1], ye[0] in turn, every chain
-      // in its own order, same bits -- 0.1803-0.1809 against 0.1805 ms for the launch: the chains are not what the stage waits for)
+      float cs[NT][16];
       {
+        // fragments TWO steps ahead of the matrix instructions that take them (a ring of three register pairs; the empty asm
+        // keeps every read where it is written: left alone the compiler reads a step's pair, waits for it, and issues its three
+        // instructions -- an LDS round trip per step in a chain that is serial anyway)
+        using ST = F4Steps<NS, NE, NT>;
         float16v ye[NE];
 #pragma unroll
         for (int t = 0; t < NE; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) ye[t][r] = y0l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+        // the packing's column constants: asked for here, in front of the chains (their fences keep the reads here); the
+        // packing loop used to wait for them piece by piece, six LDS round trips behind each other
 #pragma unroll
-        for (int t = 0; t < NE; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int s = 2 * t; s < NS; ++s) {
-            const int f = (t ? NS : 0) + s - 2 * t;
-            const half8v lh = frag(Lh, f), ll = frag(Ll, f);
-            ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh, hia[s], ye[t], 0, 0, 0);
-            ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh, loa[s], ye[t], 0, 0, 0);
-            ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ll, hia[s], ye[t], 0, 0, 0);
+          for (int r = 0; r < 16; ++r)
+            if (!f4_pair_is_padding(t, r >> 1, DP)) cs[t][r] = csl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+        half8v fh[3], fl[3];
+        auto read_step = [&](auto I) __attribute__((always_inline)) {
+          constexpr int i = decltype(I)::value;
+          if constexpr (i < ST::N) {
+            constexpr int f = ST::fragment(i);
+            fh[i % 3] = frag(ST::is_t(i) ? Th : Lh, f);
+            fl[i % 3] = frag(ST::is_t(i) ? Tl : Ll, f);
           }
+        };
+        read_step(std::integral_constant<int, 0>{});
+        read_step(std::integral_constant<int, 1>{});
+        static_for<0, ST::N>([&](auto I) __attribute__((always_inline)) {
+          constexpr int i = decltype(I)::value;
+          read_step(std::integral_constant<int, i + 2>{});
+          asm volatile("" ::: "memory");
+          constexpr int t = ST::tile(i), ks = ST::kstep(i);
+          const float16v z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if constexpr (ST::is_t(i)) {
+            tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[i % 3], hia[ks], ST::first_of_chain(i) ? z : tt[t], 0, 0, 0);
+            tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[i % 3], loa[ks], tt[t], 0, 0, 0);
+            tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[i % 3], hia[ks], tt[t], 0, 0, 0);
+          } else {
+            ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[i % 3], hia[ks], ye[t], 0, 0, 0);
+            ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[i % 3], loa[ks], ye[t], 0, 0, 0);
+            ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[i % 3], hia[ks], ye[t], 0, 0, 0);
+          }
+          if constexpr (i == ST::NYE - 1) {
 #pragma unroll
-        for (int t = 0; t < NE; ++t)
+            for (int t2 = 0; t2 < NE; ++t2)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) qs = __builtin_fmaf(ye[t][r], ye[t][r], qs);
-      }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        tt[t] = (float16v){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          const half8v th = frag(Th, t * NS + s), tl = frag(Tl, t * NS + s);
-          tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, hia[s], tt[t], 0, 0, 0);
-          tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, loa[s], tt[t], 0, 0, 0);
-          tt[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, hia[s], tt[t], 0, 0, 0);
-        }
+              for (int r = 0; r < 16; ++r) qs = __builtin_fmaf(ye[t2][r], ye[t2][r], qs);
+          }
+        });
       }
       qs = half_sum(qs) * inv_slsx2;
       const float dn2 = half_sum(dn2a) * inv_sx2;
@@ -357,8 +438,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
           if (f4_pair_is_padding(t, m, DP)) continue;   // (compile time; pk was zeroed above; d = 50: 3 of the 16 pairs)
-          const float v0 = __builtin_fmaf(tt[t][2 * m], kappa, csl[32 * t + ((2 * m) & 3) + 8 * ((2 * m) >> 2) + 4 * h]);
-          const float v1 = __builtin_fmaf(tt[t][2 * m + 1], kappa, csl[32 * t + ((2 * m + 1) & 3) + 8 * ((2 * m + 1) >> 2) + 4 * h]);
+          const float v0 = __builtin_fmaf(tt[t][2 * m], kappa, cs[t][2 * m]);
+          const float v1 = __builtin_fmaf(tt[t][2 * m + 1], kappa, cs[t][2 * m + 1]);
           union { half2v v; unsigned u; } cv;
           cv.v = __builtin_convertvector((float2v){v0, v1}, half2v);
           const float f0 = (float)cv.v[0], f1 = (float)cv.v[1];
