@@ -121,7 +121,8 @@ __global__ __launch_bounds__(64 * P4<DP>::NW, 1) void k_prep4(Prep4Args a) {
   float *y0l = reinterpret_cast<float *>(const_cast<uint4 *>(Ll + C::NLT * 64));
   float *csl = y0l + 32 * NE;
   double *ctrl = reinterpret_cast<double *>(csl + 32 * NT);   // [16 NS] s_x c_k, zero past d
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // in a scalar register: what hangs on it is scalar work (mlf_fused.hip)
   const int p32 = lane & 31, h = lane >> 5;
   double *xs = ctrl + 16 * NS + wv * C::WAVE_DOUBLES;
   const int d = a.d;
@@ -219,8 +220,37 @@ __global__ __launch_bounds__(64 * P4<DP>::NW, 1) void k_prep4(Prep4Args a) {
   // operands of the staged group: lane (p, h) takes coordinates 16 s + 8 h + j of row p, centred and scaled in binary64
   // (one FMA), rounded to binary32 and split into two binary16 pieces; returns the lane's part of |x32|^2
   const double sxd = (double)a.c.s_x;
+  // this lane's piece of its proposal's row and of the centre: one address register each, the coordinate in the instruction's
+  // offset field, and ALL reads of a group in one LDS round trip (pinned by an empty asm that takes the values; mlf_fused.hip)
+  typedef __attribute__((address_space(3))) const double lds_cdouble;
+  lds_cdouble *xrow = (lds_cdouble *)(xs + p32 * d + 8 * h);
+  lds_cdouble *crow = (lds_cdouble *)(ctrl + 8 * h);
+  asm volatile("" : "+v"(xrow), "+v"(crow));
   auto operands = [&](half8v *hi, half8v *lo) {
     float dn2 = 0.0f;
+    double xv[NS][8], cv[NS][8];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        if (16 * s + (jj & ~1) >= DP) continue;   // (compile time) padding in both halves of the wave, see below
+        xv[s][jj] = xrow[16 * s + jj];            // unconditional reads (k >= d: discarded)
+        cv[s][jj] = crow[16 * s + jj];
+      }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int j4 = 0; j4 < 8; j4 += 4) {
+        if (16 * s + j4 >= DP) continue;
+        if (16 * s + j4 + 2 >= DP)
+          asm volatile("" : "+v"(xv[s][j4]), "+v"(xv[s][j4 + 1]), "+v"(cv[s][j4]), "+v"(cv[s][j4 + 1]) : : "memory");
+        else
+          asm volatile(""
+                       : "+v"(xv[s][j4]), "+v"(xv[s][j4 + 1]), "+v"(xv[s][j4 + 2]), "+v"(xv[s][j4 + 3]), "+v"(cv[s][j4]),
+                         "+v"(cv[s][j4 + 1]), "+v"(cv[s][j4 + 2]), "+v"(cv[s][j4 + 3])
+                       :
+                       : "memory");
+      }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
@@ -239,8 +269,8 @@ __global__ __launch_bounds__(64 * P4<DP>::NW, 1) void k_prep4(Prep4Args a) {
           const int jj = 2 * j2 + e;
           const int k = 16 * s + 8 * h + jj;
           const bool ok = 16 * s + 8 + jj < C::KMIN || k < d;   // columns below KMIN exist for every d of this instance
-          const double xv = __builtin_fma(xs[p32 * d + k], sxd, -ctrl[k < 16 * NS ? k : 0]);   // unconditional read
-          x32[e] = ok ? (float)xv : 0.0f;
+          const double x = __builtin_fma(xv[s][jj], sxd, -cv[s][jj]);
+          x32[e] = ok ? (float)x : 0.0f;
           dn2 = __builtin_fmaf(x32[e], x32[e], dn2);
         }
         const half2v hp = __builtin_convertvector((float2v){x32[0], x32[1]}, half2v);
