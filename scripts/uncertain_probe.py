@@ -17,6 +17,8 @@ handle = region._dev.sync(region, True)
 stream = torch.cuda.current_stream().cuda_stream
 batch = bench.proposals_in_ellipsoid(region, bench.NPROPOSALS, 1000, dev)
 mask = torch.empty(bench.NPROPOSALS, dtype=torch.uint8, device=dev)
+if os.environ.get("MLF_VARIANT"):
+    _lib.set_option("fused_variant", int(os.environ["MLF_VARIANT"]))
 for rep in range(4):
     for i in range(20):
         handle.inside_dev(batch.data_ptr(), bench.NPROPOSALS, mask.data_ptr(), stream)
