@@ -203,17 +203,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
     const long long base = grp * 32 * (long long)d;
     if (base + 32 * (long long)d <= total) {
       const unsigned char *src = reinterpret_cast<const unsigned char *>(a.p.pts + base) + lane * 16;
+      // the piece count through an opaque copy: compared again at every use (one s_cmp) -- seen as a loop invariant of the
+      // unrolled groups, the 13 comparison results were kept as 64-bit masks, spilled, and read back lane by lane
+      int nf = nfull;
+      asm volatile("" : "+s"(nf));
 #pragma unroll
       for (int ib = 0; ib < C::NPC; ib += 4) {   // whole pieces: scalar conditions only (the immediate offset has to be a literal)
         gptr_t *gp = (gptr_t *)(src + ib * 1024);
         lptr_t *lp = (lptr_t *)(area + ib * 1024);
-        if (ib < nfull) __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
-        if (ib + 1 < C::NPC && ib + 1 < nfull) __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
-        if (ib + 2 < C::NPC && ib + 2 < nfull) __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
-        if (ib + 3 < C::NPC && ib + 3 < nfull) __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+        if (ib < nf) __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+        if (ib + 1 < C::NPC && ib + 1 < nf) __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+        if (ib + 2 < C::NPC && ib + 2 < nf) __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+        if (ib + 3 < C::NPC && ib + 3 < nf) __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
       }
       if (lane < rem)   // the last, partial piece (one lane mask per group)
-        __builtin_amdgcn_global_load_lds((gptr_t *)(src + nfull * 1024), (lptr_t *)(area + nfull * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t *)(src + nf * 1024), (lptr_t *)(area + nf * 1024), 16, 0, 0);
     } else {
 #pragma nounroll
       for (int e = lane; e < units; e += 64) {   // (at most one group per batch) plain loads, zero behind the batch
