@@ -618,7 +618,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       fu.cmin = m.cmin;
       fu.ccount = m.ccount;
       fu.ccap = m.ccap;
-      if (f.stamp_block >= 0) {   // diagnostics (mlf_region_debug_fused_stamps)
+      if (f.stamp_block >= 0 && f.stamp_block < 1000000) {   // diagnostics (mlf_region_debug_fused_stamps)
         CK(f.fstamps.reserve(16 * sizeof(unsigned long long)));
         fu.stamps = f.fstamps.as<unsigned long long>();
         fu.stamp_block = (unsigned)f.stamp_block;
@@ -645,8 +645,21 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
     m.cmin = min3 ? f.pmin2.as<int>() : nullptr;
     m.ccount = f.png.as<unsigned>() + 3;
     m.last = min3 ? 0 : 1;
+    // diagnostics: stage stamps of one k_sweep_min workgroup -- block 1 000 000 + b: the launch that follows the first range,
+    // 2 000 000 + b: the one after it
+    auto sweep_stamps = [&](int which) -> int {
+      m.stamps = nullptr;
+      if (f.stamp_block >= which * 1000000 && f.stamp_block < (which + 1) * 1000000) {
+        CK(f.fstamps.reserve(16 * sizeof(unsigned long long)));
+        m.stamps = f.fstamps.as<unsigned long long>();
+        m.stamp_block = (unsigned)(f.stamp_block - which * 1000000);
+      }
+      return 0;
+    };
+    if (int rc = sweep_stamps(1)) return rc;
     if (min3) {
       if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, 0), m, s); })) return rc;
+      if (int rc = sweep_stamps(2)) return rc;
       m.tile0 = c2;
       m.tile1 = f.ntiles32;
       m.qF = f.pqF[1].p;

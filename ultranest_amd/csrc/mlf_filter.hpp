@@ -70,6 +70,8 @@ struct MinArgs {
   unsigned *ccount;
   unsigned ccap;
   int last;              // 0: keeps the queries without a certain hit; 1: keeps the uncertain ones (minimum in the band)
+  unsigned long long *stamps;   // diagnostics (mlf_region_debug_fused_stamps, blocks >= 1 000 000): stage stamps of wave 0 of ...
+  unsigned stamp_block;         // ... this workgroup's first pass
 };
 constexpr unsigned kUncertainListCap = 4096;   // band pairs of one set of 128 uncertain queries (expected: ~140)
 struct UncertainArgs {

@@ -117,6 +117,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(min_waves(K
   // atomic per wave on the same word -- 15 600 of them in 0.1 ms in the second range, where nearly every wave keeps a
   // query or two -- queues up at the L2: measured 0.111 against 0.092 ms for the launch)
   __shared__ unsigned wg_keep[4], wg_base;
+  // diagnostics: shader-clock stamps of wave 0 of ONE workgroup (its first pass): 0 start, 1 operands and the first two tiles
+  // asked for, 2 first tile done, 3 tile loop done, 4 fates known, 5 / 6 past the two barriers, 7 compaction stores issued
+  bool stamp_on = a.stamps != nullptr && blockIdx.x == a.stamp_block && threadIdx.x < 64;
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (stamp_on) {   // wave-uniform
+      const unsigned long long t = __builtin_readcyclecounter();
+      if (lane == 0) a.stamps[k] = t;
+    }
+  };
+  stamp(0);
+  // ... and the 100 MHz clock all workgroups share: [8] / [9] start / end of workgroup 0's first pass, [10] / [11] of the selected one
+  auto stamp_rt = [&](int k) __attribute__((always_inline)) {
+    if (a.stamps != nullptr && threadIdx.x == 0) {
+      if (blockIdx.x == 0) a.stamps[8 + k] = __builtin_amdgcn_s_memrealtime();
+      if (blockIdx.x == a.stamp_block) a.stamps[10 + k] = __builtin_amdgcn_s_memrealtime();
+    }
+  };
+  stamp_rt(0);
   // A compacted set's size is known on the device only, so its launch used to carry a workgroup for every 16 groups of the
   // BATCH: 1 953 at 10^6 proposals, of which a third range fills 510 -- the other 1 443 start, read the count and leave, two
   // or three rounds of them through the 512 resident slots behind the working ones.  For batches of that size the launcher
@@ -212,9 +230,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(min_waves(K
     __builtin_amdgcn_sched_barrier(0);
     load_tile<KS>(A1, rsrc, voff, o1);
     __builtin_amdgcn_sched_barrier(0);
+    stamp(1);
     for (int it = 0; it < ntl; it += 3) {
       load_tile<KS>(A2, rsrc, voff, o2);
       tile(A0);
+      if (it == 0) stamp(2);
       if (it + 1 >= ntl) break;
       o0 = next_off(o2);
       load_tile<KS>(A0, rsrc, voff, o0);
@@ -239,6 +259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(min_waves(K
     }
   }
 
+  stamp(3);
   // ---- the queries' fates, and the compaction of those that go on
   unsigned keepm[QW];
   int qid[QW], qmn[QW];
@@ -263,12 +284,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(min_waves(K
 #pragma unroll
   for (int g = 0; g < QW; ++g) total += (unsigned)__popc(keepm[g]);
   if (lane == 0) wg_keep[threadIdx.x >> 6] = total;
+  stamp(4);
   __syncthreads();
+  stamp(5);
   if (threadIdx.x == 0) {
     const unsigned all = wg_keep[0] + wg_keep[1] + wg_keep[2] + wg_keep[3];
     wg_base = all ? atomicAdd(a.ccount, all) : 0u;
   }
   __syncthreads();
+  stamp(6);
   if (total != 0u) {   // wave-uniform
     unsigned base = wg_base;
     for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wg_keep[w];
@@ -299,6 +323,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(min_waves(K
       base += (unsigned)__popc(keepm[g]);
     }
   }
+  stamp(7);
+  if (stamp_on || (pass == 0 && blockIdx.x == 0)) stamp_rt(1);
+  stamp_on = false;
   }   // walk over the set
 }
 
