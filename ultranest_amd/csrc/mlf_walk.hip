@@ -777,7 +777,41 @@ __device__ void dw_round(const RoundsArgs &a, int i, int lane, int r, const Step
 // restarts (a walker that could not restart in round 0 -- no live point above the threshold -- cannot later).
 // Preconditions (rounds_in_registers): even d <= 64 (loglike_wave's pair layout, move_distance_regs), affine layer or none.
 // `until_finished`: stop when the walker has its nsteps (the ring walker); returns the round index after the last one made.
-__device__ int dw_rounds_regs(const RoundsArgs &a, int i, int lane, int r0, int r1, bool until_finished, const StepParams &p0) {
+// Hand-shake between the ring walker's wave and all the others inside ONE launch (k_walk_rounds): ONE word, ctl[3] = the last
+// round the ring walker has committed to make (it writes r BEFORE making round r) + kRingThrough once it has made its last;
+// ctl[5] = a follower gave up waiting.  A follower makes round r when the word says >= r: it trails the ring walker by less than a
+// round instead of repeating its rounds after it (k_walk_ring, then k_walk_rest: the same chain of round latencies twice).
+// Relaxed atomics at agent scope (the word lives in L2; nobody reads DATA the other side wrote, so no cache is flushed or
+// invalidated: with release / acquire every poll of 1 000 waves invalidated its CU's caches -- 22 us per round instead of 5).
+constexpr int kRingThrough = 1 << 30;
+__device__ __forceinline__ void ring_commits(int *ctl, int r, int lane) {
+  if (lane == 0) __hip_atomic_store(ctl + 3, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ring_is_through(int *ctl, int last_round, int lane) {
+  if (lane == 0) __hip_atomic_store(ctl + 3, last_round | kRingThrough, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool follower_may_make(int *ctl, int r, int lane) {
+  int ok = 0;
+  if (lane == 0) {
+    for (int spins = 0;; ++spins) {
+      const int word = __hip_atomic_load(ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((word & (kRingThrough - 1)) >= r) {
+        ok = 1;
+        break;
+      }
+      if (word & kRingThrough) break;   // the ring walker is through and never made round r
+      if (spins > (1 << 21)) {   // ~1 s: never seen; the call then fails (mlf_walkers_rounds_dev) instead of hanging the device
+        __hip_atomic_store(ctl + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(ok) != 0;
+}
+
+// role: 0 = no hand-shake, 1 = the ring walker (commits to every round before it makes it), 2 = a follower (waits for the commit)
+__device__ int dw_rounds_regs(const RoundsArgs &a, int i, int lane, int r0, int r1, bool until_finished, const StepParams &p0, int role = 0) {
   const WalkState &w = a.w;
   const int d = w.d;
   long long gen = w.generation[i];
@@ -792,6 +826,8 @@ __device__ int dw_rounds_regs(const RoundsArgs &a, int i, int lane, int r0, int 
   int r = r0;
   for (; r < r1; ++r) {
     if (until_finished && gen == (long long)(w.G - 1)) break;
+    if (role == 1) ring_commits(a.ctl, r, lane);
+    if (role == 2 && !follower_may_make(a.ctl, r, lane)) break;
     const unsigned long long offset = p0.offset + (unsigned long long)r * a.per_call;
     const bool movable = gen >= 0 && gen < w.G - 1;
     uint8_t flags = gen < 0 ? 8 : 0;
@@ -909,11 +945,10 @@ __global__ __launch_bounds__(64) void k_walk_round0(RoundsArgs a) {
   for (int i = blockIdx.x; i < a.w.P; i += gridDim.x) dw_round(a, i, threadIdx.x, 0, p);
 }
 
-__global__ __launch_bounds__(256) void k_walk_ring(RoundsArgs a) {
+// setup_start's ring shift (:456-462), as k_walk_harvest makes it, and the hand-shake words of the launch that follows
+__global__ __launch_bounds__(256) void k_walk_pick(RoundsArgs a) {
   __shared__ int s_n[256];
-  __shared__ long long s_ring;
   const WalkState &w = a.w;
-  const StepParams p = *a.sp;
   int n = 0;
   for (int i = threadIdx.x; i < w.P; i += 256) n += a.was_starting[i] ? 1 : 0;
   s_n[threadIdx.x] = n;
@@ -922,44 +957,77 @@ __global__ __launch_bounds__(256) void k_walk_ring(RoundsArgs a) {
     if ((int)threadIdx.x < off) s_n[threadIdx.x] += s_n[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) {   // setup_start's ring shift (:456-462), as k_walk_harvest makes it
+  if (threadIdx.x == 0) {
     long long r = *a.ring;
     if (s_n[0] > 0 && s_n[0] < w.P)
       for (int guard = 0; guard < w.P && a.was_starting[r]; ++guard) r = (r + 1) % w.P;
-    s_ring = r;
+    a.ctl[0] = 0;
+    a.ctl[1] = (int)r;
+    a.ctl[2] = 0;
+    a.ctl[3] = 0;
+    a.ctl[4] = 0;
+    a.ctl[5] = 0;
   }
-  __syncthreads();
-  if (threadIdx.x >= 64) return;
+}
+
+// Rounds 1 ... of everybody in one launch.  Workgroup 0 (dispatched first, so always resident): the ring walker, until it has
+// finished -- in those rounds nothing restarts that did not restart in round 0 (same threshold, same live points), so the ring
+// index stays where round 0 left it.  Workgroups 1 ...: the other walkers, each making round r as soon as the ring walker has
+// committed to it (dw_rounds_regs, role 2).  Before: k_walk_ring (the ring walker alone, R rounds), THEN k_walk_rest (everybody else,
+// the same R rounds): 84 us median / 148 mean per call at C3's shape.
+__global__ __launch_bounds__(64) void k_walk_rounds(RoundsArgs a) {
+  const WalkState &w = a.w;
+  const StepParams p = *a.sp;
   const int lane = threadIdx.x;
-  const int ring = (int)s_ring;
+  const int ring = a.ctl[1];
+  const bool regs = rounds_in_registers(a);
+  __shared__ LayerLds lds;
+  RoundsArgs al = a;
+  if (blockIdx.x != 0) {
+    if (regs) {
+      al.ly = stage_layer(a.ly, w.d, lds, lane, 64);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    for (int i = (int)blockIdx.x - 1; i < w.P; i += (int)gridDim.x - 1) {
+      if (i == ring) continue;
+      if (regs) {
+        dw_rounds_regs(al, i, lane, 1, a.max_rounds, false, p, 2);
+      } else {
+        for (int r = 1; r < a.max_rounds; ++r) {
+          if (!follower_may_make(a.ctl, r, lane)) break;
+          dw_round(a, i, lane, r, p);
+        }
+      }
+    }
+    return;
+  }
   int R = 1;
-  // rounds 1 ...: the ring walker alone.  In those rounds nothing restarts that did not restart in round 0 (same
-  // threshold, same live points), so the ring index stays where round 0 left it
-  if (rounds_in_registers(a)) {
-    __shared__ LayerLds lds;
-    RoundsArgs al = a;
+  if (regs) {
     if (w.generation[ring] != (long long)(w.G - 1)) {   // (wave-uniform) there will be rounds
       al.ly = stage_layer(a.ly, w.d, lds, lane, 64);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    R = dw_rounds_regs(al, ring, lane, 1, a.max_rounds, true, p);
+    R = dw_rounds_regs(al, ring, lane, 1, a.max_rounds, true, p, 1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   } else {
     while (w.generation[ring] != (long long)(w.G - 1) && R < a.max_rounds) {
+      ring_commits(a.ctl, R, lane);
       dw_round(a, ring, lane, R, p);
       ++R;
     }
   }
+  ring_is_through(a.ctl, R - 1, lane);   // no further commits
   const bool found = w.generation[ring] == (long long)(w.G - 1);
   const size_t row = ((size_t)ring * w.G + (w.G - 1)) * w.d;
   double *rec = a.rec;
   if (lane == 0) {
     a.ctl[0] = R;
-    a.ctl[1] = ring;
     a.ctl[2] = found ? 1 : 0;
     rec[0] = found ? 1.0 : 0.0;
     rec[1] = found ? w.allL[(size_t)ring * w.G + (w.G - 1)] : qnan();
@@ -986,29 +1054,6 @@ __global__ __launch_bounds__(256) void k_walk_ring(RoundsArgs a) {
     const long long next = found ? ((long long)ring + 1) % w.P : (long long)ring;
     *a.ring = next;
     rec[9 + w.d + w.nparams] = (double)next;
-  }
-}
-
-__global__ __launch_bounds__(64) void k_walk_rest(RoundsArgs a) {
-  const StepParams p = *a.sp;
-  const int R = a.ctl[0], ring = a.ctl[1];
-  if (R <= 1) return;
-  const bool regs = rounds_in_registers(a);
-  __shared__ LayerLds lds;
-  RoundsArgs al = a;
-  if (regs) {
-    al.ly = stage_layer(a.ly, a.w.d, lds, threadIdx.x, 64);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-  for (int i = blockIdx.x; i < a.w.P; i += gridDim.x) {
-    if (i == ring) continue;
-    if (regs) {
-      dw_rounds_regs(al, i, threadIdx.x, 1, R, false, p);
-    } else {
-      for (int r = 1; r < R; ++r) dw_round(a, i, threadIdx.x, r, p);
-    }
   }
 }
 
@@ -1056,8 +1101,10 @@ __global__ __launch_bounds__(256) void k_walk_round_stats(RoundsArgs a) {
       for (int c = 0; c < 5; ++c) tot[c] += part[0][c];
     __syncthreads();
   }
-  if (threadIdx.x == 0)
+  if (threadIdx.x == 0) {
     for (int c = 0; c < 5; ++c) a.rows[(size_t)r * 5 + c] = tot[c];
+    if (r == 0) a.rec[5] = (double)a.ctl[5];   // a follower gave up waiting (k_walk_rounds): the call fails
+  }
 }
 
 // ------------------------------------------------------------------ stateless forms ------------
@@ -1312,8 +1359,8 @@ void launch_walk_scatter_live(const double *rows, const double *Ls, const long l
 
 void launch_walk_rounds(const RoundsArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(k_walk_round0, walker_grid(a.w.P), dim3(64), 0, s, a);
-  hipLaunchKernelGGL(k_walk_ring, dim3(1), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_walk_rest, walker_grid(a.w.P), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_walk_pick, dim3(1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_walk_rounds, dim3(walker_grid(a.w.P).x + 1), dim3(64), 0, s, a);
   hipLaunchKernelGGL(k_walk_round_stats, dim3((unsigned)a.max_rounds), dim3(256), 0, s, a);
 }
 

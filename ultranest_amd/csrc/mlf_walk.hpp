@@ -66,7 +66,7 @@ struct WalkDirData {
   const double *std;       // region.u.std(axis=0) (kind 1)
 };
 
-// several rounds of the whole-step path in one launch sequence (mlf_walk.hip: k_walk_round0 / k_walk_ring / k_walk_rest /
+// several rounds of the whole-step path in one launch sequence (mlf_walk.hip: k_walk_round0 / k_walk_pick / k_walk_rounds /
 // k_walk_round_stats)
 struct RoundsArgs {
   WalkState w;
@@ -83,7 +83,8 @@ struct RoundsArgs {
   uint8_t *was_starting;     // [P]
   const StepParams *sp;      // device: Lmin, scale, dirscale, r2, seed, offset of round 0
   long long *ring;           // device ring index
-  int *ctl;                  // [0] rounds made R, [1] ring walker of this call, [2] harvested
+  int *ctl;                  // [0] rounds made R, [1] ring walker of this call, [2] harvested, [3] last round the ring walker has
+                             // committed to (+ 2^30 once it is through), [5] a follower gave up waiting (8 words)
   uint8_t *rflags;           // [max_rounds][P] bit0 movable, bit1 acceptable, bit2 success, bit3 was (re)starting
   double *rdist2;            // [max_rounds][P] move distance^2 of the walkers that succeeded in the round
   int *rlast;                // [P] rounds [0, rlast) of this call wrote the walker's flags

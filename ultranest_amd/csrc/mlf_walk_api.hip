@@ -613,7 +613,7 @@ int mlf_walkers_rounds_dev(mlf_walkers *w, double Lmin, double scale, int dirkin
     w->h_rout_doubles = nout;
   }
   CK(w->r_sp.reserve(sizeof(StepParams)));
-  CK(w->r_ctl.reserve(4 * sizeof(int)));
+  CK(w->r_ctl.reserve(8 * sizeof(int)));
   CK(w->r_flags.reserve((size_t)max_rounds * w->P));
   CK(w->r_dist2.reserve((size_t)max_rounds * w->P * sizeof(double)));
   CK(w->r_out.reserve(nout * sizeof(double)));
@@ -693,6 +693,7 @@ int mlf_walkers_rounds_dev(mlf_walkers *w, double Lmin, double scale, int dirkin
   CK(hipGraphLaunch(w->rgexec, s));
   CK(hipStreamSynchronize(s));
   const int R = (int)w->h_rout[4];
+  if (w->h_rout[5] != 0.0) return ctx_fail_arg(MLF_E_STATE, "mlf_walkers_rounds_dev: a walker gave up waiting for the ring walker's rounds");
   if (R < 1 || R > max_rounds) return ctx_fail_arg(MLF_E_STATE, "mlf_walkers_rounds_dev: the device reported an impossible round count");
   memcpy(rec, w->h_rout, nrec * sizeof(double));
   memcpy(round_rows, w->h_rout + nrec, (size_t)R * 5 * sizeof(double));
