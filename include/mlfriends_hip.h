@@ -488,7 +488,11 @@ int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap);
 /* diagnostics of the fused first launch (k_prep_sweep): returns in out[0 ... 12] the shader-clock stamps wave 0 of the workgroup
  * chosen by the PREVIOUS call wrote during the last phased batch -- [0] entry, [1] matrix fragments in LDS, [2 + 2 g] rows of
  * query group g landed, [3 + 2 g] group g's per-proposal stage done (g = 0 ... 3), [10] first-range sweep starts, [11] sweep
- * done, [12] compaction done -- and selects workgroup `block` for the following batches (block < 0: off). */
+ * done, [12] compaction done -- and selects workgroup `block` for the following batches (block < 0: off).
+ * block = 1 000 000 + b / 2 000 000 + b: workgroup b of the k_sweep_min launch that follows the first range / of the one after
+ * it instead -- [0] entry, [1] operands and the first two tiles asked for, [2] first tile done, [3] tile loop done, [4] fates
+ * known, [5] / [6] past the two barriers, [7] compaction stores issued; [8] / [9] the 100 MHz clock all workgroups share at the
+ * start / end of workgroup 0, [10] / [11] of workgroup b (scripts/sweep_stamps.py). */
 int mlf_region_debug_fused_stamps(mlf_region *r, int block, unsigned long long *out, int cap);
 /* Measured issue rate of independent v_add_f64/v_mul_f64 (the non-fused FP64 vector rate that
  * bounds the distance kernels), in Tera-instructions*lanes per second (= TFLOP/s, 1 flop each). */

@@ -445,7 +445,9 @@ class DeviceRegion(object):
 
     def fused_stamps(self, block):
         """Stage stamps (shader cycles, differences to the first) that wave 0 of the k_prep_sweep workgroup selected by the
-        previous call wrote during the last phased batch; selects workgroup `block` for the next batches (None: off)."""
+        previous call wrote during the last phased batch; selects workgroup `block` for the next batches (None: off).
+        block = 1 000 000 + b / 2 000 000 + b: workgroup b of the second / third range's k_sweep_min launch (entries 8 ... 11 then
+        hold the shared 100 MHz clock, see include/mlfriends_hip.h)."""
         out = np.zeros(16, dtype=np.uint64)
         check(_lib.lib().mlf_region_debug_fused_stamps(self._h, -1 if block is None else int(block), ptr(out), 16))
         st = out[:16].astype(np.int64)
