@@ -220,17 +220,20 @@ def test_graph_replay_equals_kernel_by_kernel_launches(direction):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("problem,d,direction,max_rounds", [
-    ("gauss", 5, "generate_mixture_random_direction", 64),          # odd d: the general form (likelihood row on one lane)
-    ("gauss", 8, "generate_cube_oriented_direction", 3),            # the cap is hit: __next__ returns None and is called again
-    ("eggbox", 10, "generate_mixture_random_direction", 256),       # even d <= 64: rounds after the first with the state in registers
-    ("eggbox", 10, "generate_mixture_random_direction", -256),      # ... and the same rounds forced through the general form
-    ("rosenbrock", 6, "generate_region_random_direction", 17),
-    ("rosenbrock", 50, "generate_differential_direction", 40),
-    ("gauss", 64, "generate_region_oriented_direction", 9),
-    ("gauss", 66, "generate_random_direction", 9),                  # above 64: general form
-    ("eggbox", 2, "generate_random_direction", 2)])
-def test_rounds_equal_single_steps(problem, d, direction, max_rounds):
+@pytest.mark.parametrize("problem,d,direction,max_rounds,popsize", [
+    ("gauss", 5, "generate_mixture_random_direction", 64, 64),      # odd d: the general form (likelihood row on one lane)
+    ("gauss", 8, "generate_cube_oriented_direction", 3, 64),        # the cap is hit: __next__ returns None and is called again
+    ("eggbox", 10, "generate_mixture_random_direction", 256, 64),   # even d <= 64: rounds after the first with the state in registers
+    ("eggbox", 10, "generate_mixture_random_direction", -256, 64),  # ... and the same rounds forced through the general form
+    ("rosenbrock", 6, "generate_region_random_direction", 17, 64),
+    ("rosenbrock", 50, "generate_differential_direction", 40, 64),
+    ("gauss", 64, "generate_region_oriented_direction", 9, 64),
+    ("gauss", 66, "generate_random_direction", 9, 64),              # above 64: general form
+    ("eggbox", 2, "generate_random_direction", 2, 64),
+    ("eggbox", 4, "generate_mixture_random_direction", 64, 1500),   # two chunks of 1024 walkers: statistics per chunk, then added up
+    ("gauss", 6, "generate_region_random_direction", 32, 4500),     # above 4096 walkers: the ring walker's launch, then everybody else's
+    ("gauss", 5, "generate_random_direction", 16, 4500)])           # ... in the general form
+def test_rounds_equal_single_steps(problem, d, direction, max_rounds, popsize):
     """mlf_walkers_rounds_dev (every walker's rounds back to back inside its wave, the ring walker deciding how many) against
     one mlf_walkers_step_dev call per round, driven as the reference's driver drives __next__ (integrator.py:1839-1950: call
     until a point comes back, then raise the threshold): same points, likelihoods, evaluation counts, scale, ring index,
@@ -254,11 +257,11 @@ def test_rounds_equal_single_steps(problem, d, direction, max_rounds):
     thresholds = np.sort(Ls)
     runs = []
     for mr in (1, max_rounds):
-        sampler = pop.PopulationSliceSampler(popsize=64, nsteps=7, generate_direction=getattr(pop, direction), scale=0.4,
+        sampler = pop.PopulationSliceSampler(popsize=popsize, nsteps=7, generate_direction=getattr(pop, direction), scale=0.4,
                                              device_rng=DeviceRNG(31))
         sampler.max_rounds = mr
         out = []
-        for it in range(120):
+        for it in range(120 if popsize <= 64 else 40):
             Lcut = thresholds[min(it // 3, len(Ls) // 2)]          # rising threshold: step_back and restarts happen
             nc_total, calls = 0, 0
             while True:

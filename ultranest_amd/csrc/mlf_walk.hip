@@ -983,16 +983,27 @@ __global__ __launch_bounds__(64) void k_walk_rounds(RoundsArgs a) {
   const bool regs = rounds_in_registers(a);
   __shared__ LayerLds lds;
   RoundsArgs al = a;
-  if (blockIdx.x != 0) {
+  if (blockIdx.x != 0 || a.phase == 2) {
+    if (a.phase == 1) return;
+    // no round 1 (the ring walker finished in round 0): nothing to do -- in particular no 20 KB layer matrix into LDS per walker
+    if (a.phase == 2 ? a.ctl[0] <= 1 : !follower_may_make(a.ctl, 1, lane)) return;
     if (regs) {
       al.ly = stage_layer(a.ly, w.d, lds, lane, 64);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    for (int i = (int)blockIdx.x - 1; i < w.P; i += (int)gridDim.x - 1) {
+    const int first = a.phase == 2 ? (int)blockIdx.x : (int)blockIdx.x - 1, stride = a.phase == 2 ? (int)gridDim.x : (int)gridDim.x - 1;
+    for (int i = first; i < w.P; i += stride) {
       if (i == ring) continue;
-      if (regs) {
+      if (a.phase == 2) {   // the ring walker is through (the launch before): R is known, nobody polls
+        const int R = a.ctl[0];
+        if (regs) {
+          dw_rounds_regs(al, i, lane, 1, R, false, p, 0);
+        } else {
+          for (int r = 1; r < R; ++r) dw_round(a, i, lane, r, p);
+        }
+      } else if (regs) {
         dw_rounds_regs(al, i, lane, 1, a.max_rounds, false, p, 2);
       } else {
         for (int r = 1; r < a.max_rounds; ++r) {
@@ -1003,6 +1014,8 @@ __global__ __launch_bounds__(64) void k_walk_rounds(RoundsArgs a) {
     }
     return;
   }
+  // everybody else's pace hangs on this wave: it goes first on its SIMD
+  __builtin_amdgcn_s_setprio(3);
   int R = 1;
   if (regs) {
     if (w.generation[ring] != (long long)(w.G - 1)) {   // (wave-uniform) there will be rounds
@@ -1059,55 +1072,93 @@ __global__ __launch_bounds__(64) void k_walk_rounds(RoundsArgs a) {
 
 // rows[r] = (nc, nmovable, nsuccess, nfar, sum log(dist / ref + 1e-10)) of round r, summed in k_walk_stats' order per
 // 1024-walker chunk and k_walk_harvest's order over the chunks (P <= 1024: one chunk; the sums are then the same doubles)
+// one 1024-walker chunk of round r: (nc, nmovable, nsuccess, nfar, sum log(dist / ref + 1e-10)) in k_walk_stats' order; thread 0 returns it
+__device__ __forceinline__ void round_stats_chunk(const RoundsArgs &a, int r, int i0, double (*part)[5], double (&out)[5]) {
+  const double r2 = a.sp->r2;
+  const double ref = sqrt(r2);
+  const int P = a.w.P;
+  double nc = 0, nmov = 0, nsucc = 0, nfar = 0, slog = 0;
+  for (int j = threadIdx.x; j < kStatsChunk; j += 256) {
+    const int i = i0 + j;
+    if (i >= P) continue;
+    if (r >= a.rlast[i]) continue;      // the walker made no such round (the ring walker's R is everybody's bound, see rlast)
+    const uint8_t f = a.rflags[(size_t)r * P + i];
+    if (!(f & 1)) continue;
+    nmov += 1;
+    nc += (f & 2) ? 1 : 0;
+    if (f & 4) {
+      nsucc += 1;
+      const double d2 = a.rdist2[(size_t)r * P + i];
+      if (!isnan(d2)) {
+        nfar += (d2 > r2) ? 1 : 0;
+        slog += log(sqrt(d2) / ref + 1e-10);
+      }
+    }
+  }
+  part[threadIdx.x][0] = nc;
+  part[threadIdx.x][1] = nmov;
+  part[threadIdx.x][2] = nsucc;
+  part[threadIdx.x][3] = nfar;
+  part[threadIdx.x][4] = slog;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+      for (int c = 0; c < 5; ++c) part[threadIdx.x][c] += part[threadIdx.x + off][c];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int c = 0; c < 5; ++c) out[c] = part[0][c];
+  __syncthreads();
+}
+
+// rows[r] of round r, summed in k_walk_stats' order per 1024-walker chunk and k_walk_harvest's order over the chunks.  One chunk
+// (populations up to 1024 walkers): one workgroup per round ...
 __global__ __launch_bounds__(256) void k_walk_round_stats(RoundsArgs a) {
   __shared__ double part[256][5];
   const int r = blockIdx.x;
   if (r >= a.ctl[0]) return;
-  const double r2 = a.sp->r2;
-  const double ref = sqrt(r2);
-  const int P = a.w.P;
   double tot[5] = {0, 0, 0, 0, 0};
-  for (int i0 = 0; i0 < P; i0 += kStatsChunk) {
-    double nc = 0, nmov = 0, nsucc = 0, nfar = 0, slog = 0;
-    for (int j = threadIdx.x; j < kStatsChunk; j += 256) {
-      const int i = i0 + j;
-      if (i >= P) continue;
-      if (r >= a.rlast[i]) continue;      // the walker made no such round (the ring walker's R is everybody's bound, see rlast)
-      const uint8_t f = a.rflags[(size_t)r * P + i];
-      if (!(f & 1)) continue;
-      nmov += 1;
-      nc += (f & 2) ? 1 : 0;
-      if (f & 4) {
-        nsucc += 1;
-        const double d2 = a.rdist2[(size_t)r * P + i];
-        if (!isnan(d2)) {
-          nfar += (d2 > r2) ? 1 : 0;
-          slog += log(sqrt(d2) / ref + 1e-10);
-        }
-      }
-    }
-    part[threadIdx.x][0] = nc;
-    part[threadIdx.x][1] = nmov;
-    part[threadIdx.x][2] = nsucc;
-    part[threadIdx.x][3] = nfar;
-    part[threadIdx.x][4] = slog;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if ((int)threadIdx.x < off)
-        for (int c = 0; c < 5; ++c) part[threadIdx.x][c] += part[threadIdx.x + off][c];
-      __syncthreads();
-    }
+  for (int i0 = 0; i0 < a.w.P; i0 += kStatsChunk) {
+    double c5[5];
+    round_stats_chunk(a, r, i0, part, c5);
     if (threadIdx.x == 0)
-      for (int c = 0; c < 5; ++c) tot[c] += part[0][c];
-    __syncthreads();
+      for (int c = 0; c < 5; ++c) tot[c] += c5[c];
   }
   if (threadIdx.x == 0) {
     for (int c = 0; c < 5; ++c) a.rows[(size_t)r * 5 + c] = tot[c];
     if (r == 0) a.rec[5] = (double)a.ctl[5];   // a follower gave up waiting (k_walk_rounds): the call fails
   }
 }
+// ... more: one workgroup per (round, chunk) and a second launch that adds the chunks up as k_walk_harvest does (one workgroup
+// walking the 98 chunks of a 10^5-walker population took 0.44 ms of a 0.75 ms call -- and added them up one after the other, which
+// is not the harvest's tree: the sum of logarithms differed in its last bits from three chunks on; tests now cover 4 500 walkers)
+__global__ __launch_bounds__(256) void k_walk_round_stats_chunks(RoundsArgs a, int nchunks) {
+  __shared__ double part[256][5];
+  const int r = blockIdx.x, c0 = blockIdx.y;
+  if (r >= a.ctl[0]) return;
+  double c5[5];
+  round_stats_chunk(a, r, c0 * kStatsChunk, part, c5);
+  if (threadIdx.x == 0)
+    for (int c = 0; c < 5; ++c) a.rparts[((size_t)r * nchunks + c0) * 5 + c] = c5[c];
+}
+__global__ __launch_bounds__(256) void k_walk_round_stats_sum(RoundsArgs a, int nchunks) {
+  __shared__ double part[256][5];
+  const int r = blockIdx.x;
+  if (r >= a.ctl[0]) return;
+  double v[5] = {0, 0, 0, 0, 0};   // k_walk_harvest's order over the chunks: thread t takes chunks t, t + 256, ..., then the tree
+  for (int b = threadIdx.x; b < nchunks; b += 256)
+    for (int c = 0; c < 5; ++c) v[c] += a.rparts[((size_t)r * nchunks + b) * 5 + c];
+  for (int c = 0; c < 5; ++c) part[threadIdx.x][c] = v[c];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+      for (int c = 0; c < 5; ++c) part[threadIdx.x][c] += part[threadIdx.x + off][c];
+    __syncthreads();
+  }
+  if (threadIdx.x < 5) a.rows[(size_t)r * 5 + threadIdx.x] = part[0][threadIdx.x];
+  if (r == 0 && threadIdx.x == 0) a.rec[5] = (double)a.ctl[5];
+}
 
-// ------------------------------------------------------------------ stateless forms ------------
 __global__ void k_within_unit_cube(const double *u, int n, int d, uint8_t *out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1360,8 +1411,27 @@ void launch_walk_scatter_live(const double *rows, const double *Ls, const long l
 void launch_walk_rounds(const RoundsArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(k_walk_round0, walker_grid(a.w.P), dim3(64), 0, s, a);
   hipLaunchKernelGGL(k_walk_pick, dim3(1), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_walk_rounds, dim3(walker_grid(a.w.P).x + 1), dim3(64), 0, s, a);
-  hipLaunchKernelGGL(k_walk_round_stats, dim3((unsigned)a.max_rounds), dim3(256), 0, s, a);
+  // populations the chip holds at once: one launch, the followers trail the ring walker.  Larger ones are throughput-bound: the
+  // ring walker first, alone (its rounds are quick with nobody next to it), then everybody else (popsize 100 000, d = 50:
+  // 0.77 against 1.39 ms per call)
+  RoundsArgs b = a;
+  if (a.w.P <= 4096) {
+    b.phase = 0;
+    hipLaunchKernelGGL(k_walk_rounds, dim3(walker_grid(a.w.P).x + 1), dim3(64), 0, s, b);
+  } else {
+    b.phase = 1;
+    hipLaunchKernelGGL(k_walk_rounds, dim3(1), dim3(64), 0, s, b);
+    b.phase = 2;   // 2048 workgroups walk the population: the layer matrix is staged 2048 times, not once per walker, and a call
+                   // without further rounds does not pay for 10^5 workgroups that start (33 KB of LDS each) only to leave
+    hipLaunchKernelGGL(k_walk_rounds, dim3(2048), dim3(64), 0, s, b);
+  }
+  const int nchunks = (a.w.P + kStatsChunk - 1) / kStatsChunk;
+  if (nchunks <= 1 || !a.rparts) {
+    hipLaunchKernelGGL(k_walk_round_stats, dim3((unsigned)a.max_rounds), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(k_walk_round_stats_chunks, dim3((unsigned)a.max_rounds, (unsigned)nchunks), dim3(256), 0, s, a, nchunks);
+    hipLaunchKernelGGL(k_walk_round_stats_sum, dim3((unsigned)a.max_rounds), dim3(256), 0, s, a, nchunks);
+  }
 }
 
 void launch_walk_harvest(const WalkState &w, long long ring, long long *ring_dev, double r2, double *rec, double *partials,

@@ -93,6 +93,8 @@ struct RoundsArgs {
   double *rec;               // [0] harvested, [1] L, [2] left, [3] right, [4] R, [9 ..] u (d), p (nparams), next ring index
   int max_rounds;
   unsigned long long per_call;   // Philox counters one call of the call-by-call path consumes
+  double *rparts;            // [max_rounds][chunks of 1024 walkers][5]: per-chunk statistics (populations above 1024 walkers)
+  int phase;                 // k_walk_rounds: 0 = ring walker and followers in one launch, 1 = the ring walker only, 2 = the followers only
 };
 void launch_walk_rounds(const RoundsArgs &a, hipStream_t s);
 // rows idx[j] of the device copy of the live points (and their likelihoods) replaced

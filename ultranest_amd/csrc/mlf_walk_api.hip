@@ -44,7 +44,7 @@ struct mlf_walkers {
   DevBuf d_sp;
   std::vector<unsigned long long> gkey;
   // several rounds per call (mlf_walkers_rounds_dev)
-  DevBuf r_ctl, r_flags, r_dist2, r_out, r_sp, r_last, live_stage;
+  DevBuf r_ctl, r_flags, r_dist2, r_out, r_sp, r_last, r_parts, live_stage;
   hipGraphExec_t rgexec = nullptr; // the launch sequence of mlf_walkers_rounds_dev (parameter copy, four kernels, record copy) as ONE graph launch
   std::vector<unsigned long long> rgkey;
   double *h_live = nullptr;        // pinned staging of mlf_walkers_update_live
@@ -191,7 +191,7 @@ int mlf_walkers_destroy(mlf_walkers *w) {
                    &w->lay_wrap, &w->liveL, &w->ring, &w->partials};
   for (DevBuf *b : all) b->release();
   w->d_sp.release();
-  for (DevBuf *b : {&w->r_ctl, &w->r_flags, &w->r_dist2, &w->r_out, &w->r_sp, &w->r_last, &w->live_stage}) b->release();
+  for (DevBuf *b : {&w->r_ctl, &w->r_flags, &w->r_dist2, &w->r_out, &w->r_sp, &w->r_last, &w->r_parts, &w->live_stage}) b->release();
   if (w->h_live) (void)hipHostFree(w->h_live);
   if (w->rgexec) (void)hipGraphExecDestroy(w->rgexec);
   if (w->h_rsp) (void)hipHostFree(w->h_rsp);
@@ -618,6 +618,8 @@ int mlf_walkers_rounds_dev(mlf_walkers *w, double Lmin, double scale, int dirkin
   CK(w->r_dist2.reserve((size_t)max_rounds * w->P * sizeof(double)));
   CK(w->r_out.reserve(nout * sizeof(double)));
   CK(w->r_last.reserve((size_t)w->P * sizeof(int)));
+  const size_t nchunks = ((size_t)w->P + 1023) / 1024;
+  if (nchunks > 1) CK(w->r_parts.reserve((size_t)max_rounds * nchunks * 5 * sizeof(double)));
   CK(w->aux.reserve((size_t)w->d * 8));
   if (aux)
     if (int rc = upload(w->aux, aux, (size_t)w->d * 8, s)) return rc;
@@ -652,6 +654,7 @@ int mlf_walkers_rounds_dev(mlf_walkers *w, double Lmin, double scale, int dirkin
   a.rflags = w->r_flags.as<uint8_t>();
   a.rdist2 = w->r_dist2.as<double>();
   a.rlast = w->r_last.as<int>();
+  a.rparts = nchunks > 1 ? w->r_parts.as<double>() : nullptr;
   a.force_memory_form = force_memory_form;
   a.rec = w->r_out.as<double>();
   a.rows = w->r_out.as<double>() + nrec;
@@ -671,7 +674,7 @@ int mlf_walkers_rounds_dev(mlf_walkers *w, double Lmin, double scale, int dirkin
       (unsigned long long)max_rounds, (unsigned long long)force_memory_form, (unsigned long long)nout, bits(w->r2),
       addr(w->live.p), addr(w->liveL.p), addr(w->axes.p), addr(w->std.p), addr(w->lay_ctr.p), addr(w->lay_mat.p),
       addr(w->lay_wrap.p), addr(w->aux.p), addr(w->r_out.p), addr(w->pnew.p), addr(w->currentp.p), addr(w->r_flags.p),
-      addr(w->r_dist2.p), addr(w->r_last.p), addr(w->r_ctl.p), addr(w->r_sp.p), addr(w->h_rout), addr(w->h_rsp), addr(w->flags.p),
+      addr(w->r_dist2.p), addr(w->r_last.p), addr(w->r_parts.p), addr(w->r_ctl.p), addr(w->r_sp.p), addr(w->h_rout), addr(w->h_rsp), addr(w->flags.p),
       addr(w->ring.p)};
   if (!w->rgexec || key != w->rgkey) {
     if (w->rgexec) {
