@@ -1014,8 +1014,6 @@ __global__ __launch_bounds__(64) void k_walk_rounds(RoundsArgs a) {
     }
     return;
   }
-  // everybody else's pace hangs on this wave: it goes first on its SIMD
-  __builtin_amdgcn_s_setprio(3);
   int R = 1;
   if (regs) {
     if (w.generation[ring] != (long long)(w.G - 1)) {   // (wave-uniform) there will be rounds
