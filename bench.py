@@ -47,6 +47,8 @@ CLOCK_SETTLE_STEPS = 100         # untimed steps in front of the W warm-up steps
 NBATCHES = 3                     # distinct 400 MB proposal batches a timed loop visits in turn (1.2 GB > the 256 MB Infinity Cache)
 PREP_MFMA_PER_GROUP = 42         # v_mfma_f32_32x32x16_f16 of the per-proposal stage per 32 proposals at d = 50: 3 partial products
 # (hi hi, hi lo, lo hi) x [6 k-steps of the triangular L^T (ellipsoid form) + 8 of T^T (whitening)]
+PREP_MFMA_PER_GROUP_SAME_FORM = 24   # ... where the ellipsoid's matrix is T T^T of the layer (AffineLayer, one cluster -- this workload):
+# k_prep_sweep<.., SQ> reads the ellipsoid form off the whitening chain, the L^T chain is not executed (debug_stats: same_quadratic_form)
 SET_BYTES_PER_SLOT = lambda ks: ks * 32 + 16   # noqa: E731 -- a compacted proposal: K = 16 ks binary16 columns + T_lo, T_hi, index, minimum
 
 
@@ -254,6 +256,7 @@ def step_roofline(handle, stats, kdim, ntiles32, filter_launches, launch_ms_list
     by_phase = [float(np.mean(launch_ms_list[i::per_step])) for i in range(per_step)] if len(launch_ms_list) else []
     cut, cut2 = stats["range_cuts"]       # the tile ranges as the library cut them for this batch
     slot = SET_BYTES_PER_SLOT(ks)
+    prep_per_group = PREP_MFMA_PER_GROUP_SAME_FORM if stats.get("same_quadratic_form") else PREP_MFMA_PER_GROUP
     per_kernel_pmc = (pmc or {}).get("per_kernel_all") or {}
 
     def counter_bytes(prefix):
@@ -278,7 +281,7 @@ def step_roofline(handle, stats, kdim, ntiles32, filter_launches, launch_ms_list
             first = i == 0
             name = fused_name if (first and fused_first) else "k_sweep_min<4, 4, 2>"
             sweep_mfma = groups[i] * tiles[i] * ks
-            prep_mfma = ngroups1 * PREP_MFMA_PER_GROUP if (first and fused_first) else 0
+            prep_mfma = ngroups1 * prep_per_group if (first and fused_first) else 0
             set_in = 0 if (first and fused_first) else groups[i] * 32 * slot
             set_out = (groups[i + 1] * 32 * slot) if i + 1 < nranges else nunc * slot
             alg_in = NPROPOSALS * (8 * NDIM + 1) if (first and fused_first) else 0
@@ -743,7 +746,7 @@ def main():
     # per-proposal stage: row in (8 d), binary16 operand + thresholds + route / slot / best words out
     prep4_ms = (unfused["prep"] if unfused else None) if fused_first else prep_ms      # k_prep4 in its own launch
     prep_bytes = NPROPOSALS * (8 * NDIM + 2 * kdim + 8 + 1 + 4 + 4 + 1)
-    prep_mfma_flops = NPROPOSALS / 32 * PREP_MFMA_PER_GROUP * MFMA_F16_FLOPS
+    prep_mfma_flops = NPROPOSALS / 32 * PREP_MFMA_PER_GROUP * MFMA_F16_FLOPS   # k_prep4 in its own launch runs both chains
     out = {
         "metric": "proposal-points filtered/sec (MLFriends.inside) + region-rebuild ms, N=4000 d=50",
         "value": headline["value"], "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -93,9 +93,13 @@ int mlf_col_extent(const double *pts, size_t n, size_t d, double *lo, double *hi
  *   "fused_waves"              4 (default) / 8: waves per workgroup of k_prep_sweep.  4: 79 KiB of LDS per workgroup at d = 50, two per CU --
  *                              the CU's eight waves start and end in two independent halves (0.177 against 0.181 ms at C5); used up
  *                              to d = 50 (above, two such workgroups do not fit a CU).  8: one workgroup of 8 waves per CU
- *   "fused_variant"            default 1: bit 0 = k_prep_sweep fetches its 28 KiB of matrix fragments by LDS-DMA (every request of a wave
+ *   "fused_variant"            default 3: bit 0 = k_prep_sweep fetches its matrix fragments by LDS-DMA (every request of a wave
  *                              under way at once); 0 = by a load / store loop (round 5's form), kept for A/B runs inside ONE process
- *                              (scripts/fused_ab.py: boxes of the pool differ by 8 % in this kernel)
+ *                              (scripts/fused_ab.py: boxes of the pool differ by 8 % in this kernel).  bit 1 = where the wrapping
+ *                              ellipsoid's matrix equals T T^T of the layer up to a residue measured at mlf_region_set (|E|_F <= 2^-34 |A|_F)
+ *                              and both share their centre bit for bit (AffineLayer with one cluster), the ellipsoid test reads
+ *                              delta^T A delta = |T^T delta|^2 + delta^T E delta off the whitening chain: 24 instead of 42 matrix
+ *                              instructions per 32 proposals at d = 50, no L^T fragments; band proposals take the exact path as before
  *   "mid_max_queries"          default 2048: batches up to this size (and at least "filter_min_queries") run the per-proposal
  *                              stage, the pre-filter sweep, the re-check and the answers in ONE launch (k_inside_mid); 0 = never
  *   "sweep_min"                1 (default): phased batches through the min-only sweep (k_sweep_min: running minima only
@@ -483,7 +487,8 @@ int mlf_comm_destroy(void);
  * over all live points ended in the band (the set the min-only sweep hands to its listing pass), out[7] (cap > 7)
  * 32-query groups left for the third range ("filter_second_range_pct"), out[8 ... 15] (cap >= 16) shader-clock stamps of the
  * stage boundaries of one workgroup of the last launch that records them, out[16], out[17] (cap >= 18) the tile cuts of the last
- * min-only batch (the second is 0 with two ranges).  cap >= 6. */
+ * min-only batch (the second is 0 with two ranges), out[18] (cap >= 19) 1 if the last fused first launch read the ellipsoid's
+ * quadratic form off the whitening chain ("fused_variant" bit 1).  cap >= 6. */
 int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap);
 /* diagnostics of the fused first launch (k_prep_sweep): returns in out[0 ... 12] the shader-clock stamps wave 0 of the workgroup
  * chosen by the PREVIOUS call wrote during the last phased batch -- [0] entry, [1] matrix fragments in LDS, [2 + 2 g] rows of

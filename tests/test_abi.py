@@ -114,7 +114,7 @@ def test_every_documented_option_is_accepted_without_a_device():
     assert sorted(names) == sorted(listed) and len(listed) == 20
     defaults = {"filter_min_queries": 257, "filter_phase_min_queries": 32768, "filter_first_range_pct": 30,
                 "filter_split_waves": 2048, "time_filter_launches": 0, "mid_max_queries": 2048, "filter_second_range_pct": 50,
-                "filter_third_range_min_work": 100000000, "fused_waves": 4, "fused_variant": 1}
+                "filter_third_range_min_work": 100000000, "fused_waves": 4, "fused_variant": 3}
     for name in names:
         _lib.set_option(name, defaults.get(name, 1))
     with pytest.raises(ValueError, match="unknown option"):

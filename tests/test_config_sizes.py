@@ -100,6 +100,19 @@ def test_c5_rosenbrock_d50_population_slice_sampler_vs_oracle(monkeypatch):
     assert np.array_equal(state_g["allu"], state_w["allu"], equal_nan=True)
 
 
+def _inside_resident(region, pts):
+    """MLFriends.inside on a batch that is resident in HBM, as bench.py times it (a host batch of this size is sent in chunks of
+    131 072 rows, each of which takes the single-sweep routing): mask + the batch counters"""
+    import torch
+    handle = region._dev.sync(region, True)
+    dev = torch.device("cuda", 0)
+    d_pts = torch.as_tensor(np.ascontiguousarray(pts), device=dev)
+    d_mask = torch.zeros(len(pts), dtype=torch.uint8, device=dev)
+    handle.inside_dev(d_pts.data_ptr(), len(pts), d_mask.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return d_mask.cpu().numpy().astype(bool), handle.debug_stats()
+
+
 def _ellipsoid_draws(region, z, rad):
     """set E of SURVEY.md 8d from pre-drawn normals `z` and radial uniforms `rad`"""
     zz = z / np.linalg.norm(z, axis=1, keepdims=True)
@@ -156,7 +169,10 @@ def test_c5_full_size_filter_equals_exact_scan(case, fuzz_draws):
         finally:
             _lib.set_option("filter", 1)
         assert np.array_equal(got, want), (case, r2, int((got != want).sum()))
+        got_res, stats = _inside_resident(region, pts)          # the same batch resident in HBM: the phased min-only routing
+        assert np.array_equal(got_res, want), (case, r2, int((got_res != want).sum()), stats)
         if case == "baseline":
+            assert stats["range_cuts"][1] > 0 and stats["same_quadratic_form"] == 1, stats
             # ... and the CPU oracle itself on a 200 000-row slice of the SAME full-size batch (strided, so that the slice
             # crosses every workgroup / compaction set of the batch): the filtered mask of a 10^6 batch is then pinned to
             # the oracle inside pytest, not only to the HIP exact scan (~4 s of one host core)
@@ -216,3 +232,55 @@ def test_c5_full_size_optional_routings(name, opts, fuzz_draws):
     assert np.array_equal(default, want), (name, int((default != want).sum()))
     assert np.array_equal(got, want), (name, int((got != want).sum()))
     assert 0.0 < got.mean() < 1.0
+
+
+@pytest.mark.parametrize("case", ["one-cluster", "shifted-centre", "other-matrix"])
+def test_c5_full_size_same_quadratic_form(case, fuzz_draws):
+    """k_prep_sweep<.., SQ>: with an AffineLayer fitted to ONE cluster the wrapping ellipsoid's matrix is T T^T of the layer up to
+    LAPACK rounding (mlfriends.pyx:684-706 against :447-452, :1040-1048) and both share the mean as their centre, so the first
+    launch reads the ellipsoid form off the whitening chain ("fused_variant" bit 1).  Proposals hug the ellipsoid's boundary
+    (|q / enlarge - 1| up to 4e-4, a few widths of the band the bounded form leaves to the exact test: the only place where that
+    decision is delicate) from both sides; the masks of both forms equal
+    the exact scan's and the oracle's.  A region whose centres differ by one ulp, or whose ellipsoid is not the layer's, must
+    not take that form."""
+    from ultranest_amd import _lib
+    from oracle import oracle as orc
+    z, rad = fuzz_draws
+    P, d = z.shape
+    N = 4000
+    rs = np.random.RandomState(91 + FUZZ_OFFSET)
+    u = 0.5 + 0.05 * rs.normal(size=(N, d)) * np.linspace(0.5, 1.5, d)
+    region = _c5_region(u)
+    if case == "shifted-centre":
+        region.ellipsoid_center = region.ellipsoid_center.copy()
+        region.ellipsoid_center[7] = np.nextafter(region.ellipsoid_center[7], 1.0)
+    if case == "other-matrix":
+        region.ellipsoid_invcov = region.ellipsoid_invcov * (1 + 1e-6)
+    zz = z / np.linalg.norm(z, axis=1, keepdims=True)
+    radius = np.where(np.arange(P)[:, None] % 4 == 0, rad ** (1.0 / d), 1.0 + 4e-4 * (rad - 0.5))
+    pts = region.ellipsoid_center + (zz * (region.enlarge ** 0.5 * radius)) @ region.ellipsoid_axes_T
+    pts[5::1000] = u[rs.randint(N, size=len(pts[5::1000]))]
+    got = {}
+    try:
+        for variant in (3, 1):
+            _lib.set_option("fused_variant", variant)
+            got[variant], stats = _inside_resident(region, pts)
+            assert stats["range_cuts"][1] > 0, stats               # the headline routing: k_prep_sweep + two more ranges
+            assert stats["same_quadratic_form"] == (1 if variant == 3 and case == "one-cluster" else 0), (variant, stats)
+            # three quarters of the batch lie within 2e-4 (relative, in the radius) of the boundary: part of them inside the band
+            # that goes to the exact test, the rest decided by the bounded form right next to it
+            assert 0.02 * P < stats["ellipsoid_band"] < 0.6 * P, stats
+        _lib.set_option("filter", 0)
+        want = region.inside(pts)
+    finally:
+        _lib.set_option("filter", 1)
+        _lib.set_option("fused_variant", 3)
+    assert np.array_equal(got[3], want), int((got[3] != want).sum())
+    assert np.array_equal(got[1], want), int((got[1] != want).sum())
+    layer = region.transformLayer
+    sl = slice(1, None, 10)
+    gate_o = orc.inside_ellipsoid(np.ascontiguousarray(pts[sl]), region.ellipsoid_center, region.ellipsoid_invcov, region.enlarge).astype(bool)
+    assert 0.3 < gate_o.mean() < 0.9, gate_o.mean()                # both sides of the boundary are populated
+    want_o = orc.region_inside(np.ascontiguousarray(pts[sl]), region.unormed, layer.ctr, layer.T, region.ellipsoid_center,
+                               region.ellipsoid_invcov, region.enlarge, region.maxradiussq).astype(bool)
+    assert np.array_equal(got[3][sl], want_o), int((got[3][sl] != want_o).sum())

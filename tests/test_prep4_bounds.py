@@ -332,3 +332,79 @@ def test_whitening_chain_error_model():
             dnorm = np.linalg.norm(x32.astype(np.float64)) / sx * (1 + 2.0**-18)
             zeta = sigma * (zt * dnorm + g * np.linalg.norm(cs) + zt_abs)
             assert np.linalg.norm(out - exact) <= zeta * (1 + 2.0**-20), (d, cond, it)
+
+
+class SameFormSetup:
+    """host constants of the "same quadratic form" variant (region_prep4_setup, csrc/mlf_api.hip: p4c_same): the ellipsoid
+    test reads delta^T A delta = |T^T delta|^2 + delta^T E delta off the whitening chain; None when the residue is refused"""
+
+    def __init__(self, T, A, c, amax):
+        d = T.shape[0]
+        dp = d + (d & 1)
+        self.K = K = 16 * ((dp + 15) // 16)
+        self.sx = pow2_scale(amax, 5)
+        self.st = pow2_scale(np.abs(T).max(), 8)
+        th, tl, err = split16_matrix(T.T, self.st)         # rows = outputs
+        self.th, self.tl = pad16(th, K), pad16(tl, K)
+        tf = np.linalg.norm(T)
+        afro = np.linalg.norm(A)
+        E = 0.5 * (A + A.T) - T @ T.T
+        e_bound = (np.linalg.norm(E) + (d + 4.0) * 2.0**-52 * (tf * tf + afro)) * (1 + 1e-12)
+        self.accepted = bool(e_bound <= 2.0**-34 * afro)
+        self.g = g_chain(dp)
+        self.consts = dict(g=self.g, y0n=f32(0), lf=up32(tf * (1 + 1e-12)), el=up32(np.linalg.norm(err) / self.st * (1 + 1e-12)),
+                           l_abs=up32(tf * np.sqrt(K) * 2.0**-25 / self.sx * (1 + 1e-12)), s0n=f32(0),
+                           eps_scale=up32((2.0**-34 * afro + e_bound) * (1 + 1e-12)))
+        self.c_lay = c
+        self.sl = self.st                                    # (inv_sl_sx = inv_st_sx)
+        self.lh, self.ll = self.th, self.tl
+        self.y0f = np.zeros(d, dtype=np.float32)
+
+    operands = EllSetup.operands
+
+
+@pytest.mark.parametrize("d,cond,perturb", [(2, 1.0, 0.0), (5, 30.0, 0.0), (20, 3.0, 2.0**-37), (50, 1.5, 0.0), (50, 40.0, 2.0**-36),
+                                            (50, 1.5, 2.0**-33), (56, 5.0, 0.0)])
+def test_same_form_ellipsoid_decisions_are_sound(d, cond, perturb):
+    """AffineLayer with one cluster: the layer's T = eigvec * eigval^-0.5 and the ellipsoid's A = inv(cov) come from the same
+    covariance (mlfriends.pyx:684-706, 447-452 + :1040-1048), so A = T T^T up to LAPACK rounding -- optionally with a residue
+    of the size the acceptance rule still admits.  ellipsoid_decision() restates the kernel's decision with the whitening
+    chain in the ellipsoid chain's place (k_prep_sweep<.., SQ = true>)."""
+    rs = np.random.RandomState(d * 11 + int(cond))
+    Q, _ = np.linalg.qr(rs.normal(size=(d, d)))
+    ev = np.geomspace(1.0, cond**2, d) * 1e-3
+    cov = (Q * ev) @ Q.T
+    cov = 0.5 * (cov + cov.T)
+    eigval, eigvec = np.linalg.eigh(cov)
+    T = eigvec * eigval**-0.5
+    A = np.linalg.inv(cov)
+    if perturb:
+        P = rs.normal(size=(d, d))
+        A = A + perturb * np.linalg.norm(A) * (P + P.T) / np.linalg.norm(P + P.T)
+    c = 0.5 + 0.01 * rs.normal(size=d)
+    enlarge = float(d) * 1.3
+    z = rs.normal(size=(300, d))
+    z /= np.linalg.norm(z, axis=1, keepdims=True)
+    radii = np.sqrt(enlarge) * np.concatenate((1 + 3e-5 * rs.normal(size=150), rs.uniform(0.3, 1.7, size=150)))
+    x = c + (z * radii[:, None]) @ np.linalg.inv(T)                 # |T^T (x - c)| = radius
+    es = SameFormSetup(T, A, c, np.abs(x - c).max() * 0.7)
+    assert es.accepted == (perturb < 2.0**-34)
+    if not es.accepted:
+        return
+    nin = nout = nband = 0
+    for i, row in enumerate(x):
+        delta = row - c
+        q_ref = einsum_order_q(delta, A)
+        sure_in, sure_out, t_hat, eta = ellipsoid_decision(row, es, enlarge, tree=bool(i & 1))
+        assert not (sure_in and sure_out)
+        if sure_in:
+            assert q_ref <= enlarge
+            nin += 1
+        elif sure_out:
+            assert q_ref > enlarge
+            nout += 1
+        else:
+            nband += 1
+        assert np.linalg.norm(t_hat - T.T @ delta) <= eta
+    assert nin > 40 and nout > 40
+    assert nband < 200, (nin, nout, nband)

@@ -74,7 +74,8 @@ enum Opt : int {
   OPT_SECOND_RANGE_PCT,    // "filter_second_range_pct" 0 ... 90: min-only sweep in three ranges, the second ending at this share of the tiles (0: two ranges)
   OPT_THIRD_MIN_WORK,      // "filter_third_range_min_work": three ranges from this many (proposals x 32-row live-point tiles) on
   OPT_FUSED_WAVES,         // "fused_waves" 4 / 8: waves per workgroup of k_prep_sweep (4, default: two workgroups per CU up to d = 50; 8: one)
-  OPT_FUSED_VARIANT,       // "fused_variant": bit 0 = k_prep_sweep loads its matrix fragments by LDS-DMA (default 1) or by a load / store loop (0)
+  OPT_FUSED_VARIANT,       // "fused_variant": bit 0 = k_prep_sweep loads its matrix fragments by LDS-DMA (default) or by a load / store loop;
+                           // bit 1 = the ellipsoid form read off the whitening chain where the region allows it (default; region_prep4_setup)
   OPT_COUNT
 };
 const char *const kOptNames[OPT_COUNT] = {"filter", "filter_first_range_pct", "filter_split_waves", "filter_narrow_tail",
@@ -87,7 +88,7 @@ std::atomic<unsigned> g_grant_epoch{0u};
 std::atomic<unsigned long long> g_grant_calls{0ull};
 }  // namespace mlf
 namespace {
-long long g_opt[OPT_COUNT] = {1, 30, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 1, 1, 1, 50, 100000000ll, 4, 1};
+long long g_opt[OPT_COUNT] = {1, 30, 2048, 1, 1, 1, 32768, 1, 0, 1, kFilterMinQueriesDefault, 1, 2048, 1, 1, 1, 50, 100000000ll, 4, 3};
 
 struct OptOverrides {
   long long v[OPT_COUNT] = {};
@@ -107,6 +108,7 @@ long long opt_clamp(int id, long long value) {
     case OPT_PHASES: return value < 0 ? 0 : (value > 64 ? 64 : value);
     case OPT_SECOND_RANGE_PCT: return value < 0 ? 0 : (value > 90 ? 90 : value);
     case OPT_FUSED_WAVES: return value == 4 ? 4 : 8;
+    case OPT_FUSED_VARIANT: return value & 3;
     case OPT_BOOT_SYM: return value < 0 ? 0 : (value > 2 ? 2 : value);
     case OPT_THIRD_MIN_WORK: return value < 0 ? 0 : value;
     case OPT_PHASE_MIN_QUERIES:
@@ -145,6 +147,7 @@ struct FilterCtx {
   unsigned batch_parity = 0;
   size_t last_nsegs = 0;      // list segments of the last filtered batch
   int last_cut[2] = {0, 0};   // tile cuts of the last min-only batch (second: 0 with two ranges)
+  bool last_same_form = false;   // the last fused launch read the ellipsoid form off the whitening chain (debug_stats)
   bool ell_pending = false;   // band list of the running call not decided yet (the tail of the re-check launch decides it)
   EllExactArgs ell_args{};
   // (start, stop) event pairs around every k_filter launch of the timed calls
@@ -435,6 +438,7 @@ struct ExactSrc {
   int ldt;
   const double *T64;  // the same as 64 x 64, zero padded (d <= 64)
   const Prep4Args *prep;   // not null: the per-proposal stage has NOT run yet -- the min-only path runs it inside its first launch
+  const Prep4Consts *same; // not null: constants of the "same quadratic form" variant of that launch (region_prep4_setup)
 };
 
 // does a batch of nq queries take the min-only path?  (the phase rule of filter_run)
@@ -624,6 +628,11 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
         fu.stamp_block = (unsigned)f.stamp_block;
       }
       fu.variant = (unsigned)(opt(f, OPT_FUSED_VARIANT) & 0xff);
+      if ((fu.variant & 2u) && xs->same)
+        fu.p.c = *xs->same;
+      else
+        fu.variant &= ~2u;
+      f.last_same_form = (fu.variant & 2u) != 0u;
       const int fused_waves = (int)opt(f, OPT_FUSED_WAVES);
       if (int rc = timed([&] { return launch_prep_sweep(fu, s, fused_waves); })) return rc;
     } else if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, 0), m, s); })) return rc;
@@ -953,6 +962,10 @@ struct mlf_region {
   DevBuf p4_LtF, p4_TtF, p4_y0, lay_T64, ell_L;
   Prep4Consts p4c{};
   bool p4_ready = false;
+  // "same quadratic form": A = T T^T + E with |E|_F measured (same_matrix) and c_lay == c_ell bit for bit (same_centres):
+  // k_prep_sweep<.., true> reads delta^T A delta off the whitening chain; p4c_same = the constants of that form
+  Prep4Consts p4c_same{};
+  bool same_matrix = false, same_centres = false;
   std::vector<double> h_L, h_lay_ctr, h_ell_ctr;   // host copies: y0 = L^T (c_lay - c_ell) follows the ellipsoid centre
   FilterCtx filter;
   DevBuf gen, gen2, cube, smask, blk, sout, ax_zero, ax_mat;   // device-side sampling
@@ -1006,6 +1019,7 @@ int region_prep4_centres(mlf_region *r, hipStream_t s) {
     r->p4_ready = false;
     return 0;
   }
+  r->same_centres = s0n2 == 0.0;   // every difference an exact zero
   r->p4c.s0n = f32_up(std::sqrt(s0n2) * (1.0 + 1e-12));
   r->p4c.y0n = f32_up(std::sqrt(y0n2) * (1.0 + 1e-12));
   if (int rc = upload(r->p4_y0, y0f.data(), y0f.size() * sizeof(float), s)) return rc;
@@ -1017,8 +1031,10 @@ int region_prep4_centres(mlf_region *r, hipStream_t s) {
 // fro2 = |A|_F^2; layer_T / layer_ctr may be null for regions without a neighbour scan; `live` = the cube-space live
 // points (n x d) or null: their spread around the layer centre fixes the scale of the binary16 proposal operand.
 int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2, const double *ell_center,
-                       const double *layer_ctr, const double *layer_T, const double *live, size_t nlive, hipStream_t s) {
+                       const double *layer_ctr, const double *layer_T, const double *live, size_t nlive, hipStream_t s,
+                       const double *ell_invcov) {
   r->p4_ready = false;
+  r->same_matrix = r->same_centres = false;
   const int d = r->d, dp = r->dp;
   if (!prep4_usable(d) || (dp & 1) || dp > 64 || !r->chol_ok || r->has_wrap) return 0;
   if (r->use_scan && (r->layer_kind != 0 || !layer_T || !layer_ctr)) return 0;
@@ -1118,6 +1134,34 @@ int region_prep4_setup(mlf_region *r, const std::vector<double> &L, double fro2,
     for (int k = 0; k < d; ++k)
       for (int c2 = 0; c2 < d; ++c2) t64[(size_t)k * 64 + c2] = layer_T[(size_t)k * d + c2];
     if (int rc = upload(r->lay_T64, t64.data(), t64.size() * sizeof(double), s)) return rc;
+    // Same quadratic form?  E = sym(A) - T T^T in binary64 (the reference's einsum sees delta^T A delta = delta^T sym(A) delta);
+    // |delta^T E delta| <= |E|_F |delta|^2 joins eps.  The residue is computed with rounding errors of its own: every entry of
+    // T T^T is a d-term dot product (error <= d 2^-53 (|T| |T|^T)_ij, in the Frobenius norm <= d 2^-53 |T|_F^2), the
+    // symmetrisation and the difference add 2^-52 |A|_F.  Accepted while the enlarged eps stays below twice the old one.
+    if (ell_invcov) {
+      double e2 = 0.0;
+      for (int i = 0; i < d; ++i)
+        for (int j = 0; j <= i; ++j) {
+          double pij = 0.0;
+          for (int cc = 0; cc < d; ++cc) pij += layer_T[(size_t)i * d + cc] * layer_T[(size_t)j * d + cc];
+          const double e = 0.5 * (ell_invcov[(size_t)i * d + j] + ell_invcov[(size_t)j * d + i]) - pij;
+          e2 += (i == j ? 1.0 : 2.0) * e * e;
+        }
+      const double afro = std::sqrt(fro2);
+      const double e_bound = (std::sqrt(e2) + (d + 4.0) * std::ldexp(1.0, -52) * (tf2 + afro)) * (1.0 + 1e-12);
+      if (std::isfinite(e_bound) && e_bound <= std::ldexp(1.0, -34) * afro) {
+        Prep4Consts &q = r->p4c_same;
+        q = c;
+        q.y0n = 0.0f;                                   // the whitening chain starts at zero
+        q.lf = f32_up(tf * (1.0 + 1e-12));              // eta = g |T|_F |delta| + |E_T|_F |delta| / s_T + |T|_F sqrt(K) 2^-25 / s_x
+        q.el = f32_up(et / st * (1.0 + 1e-12));
+        q.l_abs = c.zt_abs;
+        q.s0n = 0.0f;                                   // (same_centres)
+        q.eps_scale = f32_up((std::ldexp(1.0, -34) * afro + e_bound) * (1.0 + 1e-12));
+        q.inv_sl_sx = c.inv_st_sx;                      // accumulator of the whitening chain -> T^T delta
+        r->same_matrix = true;
+      }
+    }
   }
   if (!arena_active()) CK(hipStreamSynchronize(s));
   r->p4_ready = true;
@@ -1312,9 +1356,16 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
     const bool defer_prep = r->use_scan && use_filter && !pregate && !d_idx && opt(f, OPT_FUSED_FIRST) && fused_usable(r->dp) &&
                             filter_takes_min_path(f, (long long)np);
     static thread_local Prep4Args deferred;
+    static thread_local Prep4Consts deferred_same;
     if (defer_prep) {
       deferred = pa;
       xsrc.prep = &deferred;
+      if (r->same_matrix && r->same_centres) {
+        deferred_same = r->p4c_same;
+        deferred_same.enl_lo = pa.c.enl_lo;
+        deferred_same.enl_hi = pa.c.enl_hi;
+        xsrc.same = &deferred_same;
+      }
     } else {
       CK(launch_prep4(pa, s));
     }
@@ -2238,7 +2289,9 @@ int mlf_region_set(mlf_region *r, const double *unormed, size_t n, size_t d, int
       CK(hipStreamSynchronize(c.stream));
       live_host = back.data();
     }
-    if (int rc = region_prep4_setup(r, L, fro_sq, ell_center, layer_ctr, layer_T, live_host, n_for_scale, c.stream)) return rc;
+    if (int rc = region_prep4_setup(r, L, fro_sq, ell_center, layer_ctr, layer_T, live_host, n_for_scale, c.stream,
+                                    ell_invcov))
+      return rc;
   }
   if (int rc = arena_flush(c.stream)) return rc;
   CK(hipStreamSynchronize(c.stream));
@@ -2898,6 +2951,7 @@ int mlf_region_debug_stats(mlf_region *r, unsigned long long *out, int cap) {
     out[16] = (unsigned long long)f.last_cut[0];
     out[17] = (unsigned long long)f.last_cut[1];
   }
+  if (cap > 18) out[18] = f.last_same_form ? 1ull : 0ull;   // the last fused launch took the ellipsoid form from the whitening chain
   {
     if (cap >= 16 && f.mid_last && f.segcnt.p) {   // k_inside_mid, workgroup (0, 0): stage boundaries
       unsigned st[8];

@@ -114,7 +114,13 @@ __device__ __forceinline__ void pin_step() {
 
 }  // namespace
 
-template <int DP, int NW>
+// SQ ("same quadratic form"): the wrapping ellipsoid's matrix A equals T T^T of the layer up to a measured residue E and both
+// share their centre (AffineLayer with one cluster: mlfriends.pyx:447-452 against :684-706 -- the same sample covariance times
+// d + 2, inverted once by LAPACK and once through its eigen-decomposition).  Then delta^T A delta = |T^T delta|^2 + delta^T E delta:
+// the ellipsoid form is read off the whitening chain's accumulators, the L^T chain (18 of 42 matrix instructions per group at
+// d = 50), its fragments and its start values are gone.  The host hands over the constants of THAT form (region_prep4_setup:
+// eta from the T chain's error model, eps enlarged by |E|_F); band proposals are decided by the exact einsum path as before.
+template <int DP, int NW, bool SQ>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedArgs a) {
   using C = F4<DP, NW>;
   constexpr int NS = C::NS, NT = C::NT, NE = C::NE, KS = C::KS, QW = 4;
@@ -159,13 +165,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
     const uint4 *srcT = reinterpret_cast<const uint4 *>(a.p.TtF);
     const uint4 *srcL = reinterpret_cast<const uint4 *>(a.p.LtF);
     for (int e = tid; e < 2 * NT * NS * 64; e += 64 * NW) dst[e] = srcT[e];
-    for (int e = tid; e < 2 * C::NLT * 64; e += 64 * NW) dst[2 * NT * NS * 64 + e] = srcL[e];
+    if constexpr (!SQ)
+      for (int e = tid; e < 2 * C::NLT * 64; e += 64 * NW) dst[2 * NT * NS * 64 + e] = srcL[e];
   } else {   // variant bit 0 (default): the matrix fragments as 1 KiB pieces straight into LDS (global_load_lds): every request of
              // the wave under way at once, no register round trip -- k_prep_sweep 0.203 -> 0.1997 ms in one process
              // (profiles/r06_fused_ab.jsonl); the load / store loop stays for A/B runs
     typedef __attribute__((address_space(1))) const void gp_t;
     typedef __attribute__((address_space(3))) void lp_t;
-    constexpr int NPT = 2 * NT * NS, NPL = 2 * C::NLT;   // pieces of the two tables
+    constexpr int NPT = 2 * NT * NS, NPL = SQ ? 0 : 2 * C::NLT;   // pieces of the two tables
     const unsigned char *srcT = reinterpret_cast<const unsigned char *>(a.p.TtF);
     const unsigned char *srcL = reinterpret_cast<const unsigned char *>(a.p.LtF);
 #pragma unroll
@@ -178,7 +185,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
     }
   }
   static_assert(32 * NE <= 64 * NW && 32 * NT <= 64 * NW && 16 * NS <= 64 * NW, "one thread per constant");
-  if (tid < 32 * NE) y0l[tid] = a.p.y0[tid];
+  if constexpr (!SQ)
+    if (tid < 32 * NE) y0l[tid] = a.p.y0[tid];
   if (tid < 32 * NT) {
     const int col = f4_column(tid >> 5, tid & 31);
     csl[tid] = col < DP ? 2.0f * (float)(sigma * a.p.stats[8 + col]) : 0.0f;
@@ -357,11 +365,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
         // keeps every read where it is written: left alone the compiler reads a step's pair, waits for it, and issues its three
         // instructions -- an LDS round trip per step in a chain that is serial anyway)
         using ST = F4Steps<NS, NE, NT>;
+        constexpr int I0 = SQ ? ST::NYE : 0;   // SQ: the list starts at the whitening chain
         float16v ye[NE];
+        if constexpr (!SQ) {
 #pragma unroll
-        for (int t = 0; t < NE; ++t)
+          for (int t = 0; t < NE; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) ye[t][r] = y0l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+            for (int r = 0; r < 16; ++r) ye[t][r] = y0l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+        }
         // the packing's column constants: asked for here, in front of the chains (their fences keep the reads here); the
         // packing loop used to wait for them piece by piece, six LDS round trips behind each other
 #pragma unroll
@@ -378,9 +389,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
             fl[i % 3] = frag(ST::is_t(i) ? Tl : Ll, f);
           }
         };
-        read_step(std::integral_constant<int, 0>{});
-        read_step(std::integral_constant<int, 1>{});
-        static_for<0, ST::N>([&](auto I) __attribute__((always_inline)) {
+        read_step(std::integral_constant<int, I0>{});
+        read_step(std::integral_constant<int, I0 + 1>{});
+        static_for<I0, ST::N>([&](auto I) __attribute__((always_inline)) {
           constexpr int i = decltype(I)::value;
           read_step(std::integral_constant<int, i + 2>{});
           asm volatile("" ::: "memory");
@@ -395,13 +406,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
             ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[i % 3], loa[ks], ye[t], 0, 0, 0);
             ye[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[i % 3], hia[ks], ye[t], 0, 0, 0);
           }
-          if constexpr (i == ST::NYE - 1) {
+          if constexpr (!SQ && i == ST::NYE - 1) {
 #pragma unroll
             for (int t2 = 0; t2 < NE; ++t2)
 #pragma unroll
               for (int r = 0; r < 16; ++r) qs = __builtin_fmaf(ye[t2][r], ye[t2][r], qs);
           }
         });
+        if constexpr (SQ) {   // |s_T s_x T^T delta|^2: the rows of padded columns are exact zeros
+#pragma unroll
+          for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (!f4_pair_is_padding(t2, r >> 1, DP)) qs = __builtin_fmaf(tt[t2][r], tt[t2][r], qs);
+        }
       }
       qs = half_sum(qs) * inv_slsx2;
       const float dn2 = half_sum(dn2a) * inv_sx2;
@@ -645,18 +663,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
 
 bool fused_usable(int dp) { return dp >= 2 && dp <= 56 && (dp & 1) == 0; }
 
-template <int D, int NW>
+template <int D, int NW, bool SQ>
 static hipError_t launch_prep_sweep_t(const FusedArgs &a, long long nsets, hipStream_t s) {
   constexpr size_t lds = F4<D, NW>::LDS;
   static_assert(lds <= 160 * 1024 - 64, "LDS budget");
   static DeviceGrant grant;
   if (hipError_t e = grant.ensure([] {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_sweep<D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prep_sweep<D, NW, SQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       }))
     return e;
   if (a.p.ks != F4<D, NW>::KS) return hipErrorInvalidValue;
   const dim3 grid((unsigned)((nsets + NW - 1) / NW));
-  hipLaunchKernelGGL((k_prep_sweep<D, NW>), grid, dim3(64 * NW), lds, s, a);
+  hipLaunchKernelGGL((k_prep_sweep<D, NW, SQ>), grid, dim3(64 * NW), lds, s, a);
   return hipGetLastError();
 }
 
@@ -667,13 +685,14 @@ hipError_t launch_prep_sweep(const FusedArgs &a, hipStream_t s, int waves) {
   if (a.p.np <= 0) return hipSuccess;
   const long long ngroups = (a.p.np + 31) / 32;
   const long long nsets = (ngroups + 3) / 4;
+  const bool sq = (a.variant & 2u) != 0u;   // the caller has put the constants of that form into a.p.c
   switch (a.p.dp) {
 #define X(D)                                                                                  \
   case D:                                                                                     \
     if constexpr (2 * F4<D, 4>::LDS <= 160 * 1024) {                                          \
-      if (waves == 4) return launch_prep_sweep_t<D, 4>(a, nsets, s);                          \
+      if (waves == 4) return sq ? launch_prep_sweep_t<D, 4, true>(a, nsets, s) : launch_prep_sweep_t<D, 4, false>(a, nsets, s); \
     }                                                                                         \
-    return launch_prep_sweep_t<D, 8>(a, nsets, s);
+    return sq ? launch_prep_sweep_t<D, 8, true>(a, nsets, s) : launch_prep_sweep_t<D, 8, false>(a, nsets, s);
     MLF_FOR_EACH_DP_MID(X)
 #undef X
     default:

@@ -431,12 +431,13 @@ class DeviceRegion(object):
 
     def debug_stats(self):
         """Counters of the last filtered batch (see mlf_region_debug_stats in include/mlfriends_hip.h)."""
-        out = np.zeros(18, dtype=np.uint64)
-        check(_lib.lib().mlf_region_debug_stats(self._h, ptr(out), 18))
+        out = np.zeros(19, dtype=np.uint64)
+        check(_lib.lib().mlf_region_debug_stats(self._h, ptr(out), 19))
         keys = ("ellipsoid_band", None, "uncertain_pairs", "largest_segment", "segments", "second_range_groups",
                 "uncertain_queries", "third_range_groups")
         stats = {k: int(v) for k, v in zip(keys, out[:8]) if k}
         stats["range_cuts"] = [int(out[16]), int(out[17])]      # tile cuts of the last min-only batch (second: 0 = two ranges)
+        stats["same_quadratic_form"] = int(out[18])             # k_prep_sweep read the ellipsoid form off the whitening chain
         if out[8]:     # k_uncertain, workgroup 0: shader cycles between the stage boundaries of its first set
             st = out[8:16].astype(np.int64)
             stats["uncertain_stage_cycles"] = [int((st[i + 1] - st[i]) & 0xffffffff) for i in range(6) if st[i + 1]]
