@@ -13,6 +13,8 @@ import bench  # noqa: E402
 from ultranest_amd import likelihoods  # noqa: E402
 from ultranest_amd.regions import DeviceRNG  # noqa: E402
 
+import gc  # noqa: E402
+
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 u, region = bench.build_region(None)
 region.device_rng = DeviceRNG(3)
@@ -21,6 +23,9 @@ Ls = loglike(u)
 Lmin = float(np.sort(Ls)[-40])          # only ~1 % of the live-point-like proposals pass: the copy back is small
 n = 1 << 20
 out = {}
+gc.collect()
+gc.freeze()      # a full pass of the cyclic collector over torch's objects (35 ms) landed inside the 10 timed calls of the second
+gc.disable()     # method in every earlier run of this script (3.7-4.4 ms "per batch" for 0.3 ms of work)
 for method, name in ((1, "wrapping_ellipsoid"), (0, "boundingbox")):
     for _ in range(3):
         region._dev.refill(region, True, method, n, Lmin, likelihoods.identity_transform.device_spec, loglike.device_spec)

@@ -92,7 +92,7 @@ def test_cube_sampling_is_the_host_pipeline_on_the_philox_batch(kind, d):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["MLFriends", "RobustEllipsoidRegion"])
-@pytest.mark.parametrize("d", [3, 8, 50])
+@pytest.mark.parametrize("d", [2, 3, 8, 50])
 def test_ellipsoid_sampling_matches_restatement_and_region(kind, d):
     region, DeviceRNG = _region(kind, 400, d, 100 + d)
     nsamples = 30000

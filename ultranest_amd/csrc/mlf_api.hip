@@ -968,8 +968,8 @@ struct mlf_region {
   bool same_matrix = false, same_centres = false;
   std::vector<double> h_L, h_lay_ctr, h_ell_ctr;   // host copies: y0 = L^T (c_lay - c_ell) follows the ellipsoid centre
   FilterCtx filter;
-  DevBuf gen, gen2, cube, smask, blk, sout, ax_zero, ax_mat;   // device-side sampling
-  DevBuf s_invT, s_lo, s_hi, s_thin, s_count, rf_p, rf_L, rf_out, rf_aux;
+  DevBuf gen, gen2, cube, smask, blk, sout, ax_zero, ax_mat, ax_pad;   // device-side sampling
+  DevBuf s_invT, s_lo, s_hi, s_thin, s_count, rf_p, rf_L, rf_out, rf_aux, rf_keep;
   bool axes_ready = false, sampling_ready = false;
   std::vector<hipEvent_t> events;  // 4 per timed call
   size_t events_used = 0;
@@ -2133,7 +2133,8 @@ int mlf_region_destroy(mlf_region *r) {
   DevBuf *bufs[] = {&r->refT, &r->refR, &r->lay_ctr, &r->lay_mat, &r->lay_T8, &r->ell_Lt, &r->ell_LtF, &r->lay_TtF, &r->wrap, &r->ell_ctr,
                     &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row, &r->p4_LtF, &r->p4_TtF, &r->p4_y0, &r->lay_T64, &r->ell_L,
                     &r->gen, &r->gen2, &r->cube, &r->smask, &r->blk, &r->sout, &r->ax_zero, &r->ax_mat,
-                    &r->s_invT, &r->s_lo, &r->s_hi, &r->s_thin, &r->s_count, &r->rf_p, &r->rf_L, &r->rf_out, &r->rf_aux};
+                    &r->s_invT, &r->s_lo, &r->s_hi, &r->s_thin, &r->s_count, &r->rf_p, &r->rf_L, &r->rf_out, &r->rf_aux,
+                    &r->rf_keep, &r->ax_pad};
   for (DevBuf *b : bufs) b->release();
   for (hipEvent_t e : r->events) (void)hipEventDestroy(e);
   r->filter.release();
@@ -2549,6 +2550,14 @@ int mlf_region_set_axes(mlf_region *r, const double *axes_T) {
   std::vector<double> m = pad_matrix(axes_T, d, dp, true);
   if (int rc = upload(r->ax_zero, zero.data(), zero.size() * sizeof(double), c.stream)) return rc;
   if (int rc = upload(r->ax_mat, m.data(), m.size() * sizeof(double), c.stream)) return rc;
+  std::vector<double> ap;   // k_generate_ellipsoid's copy: element (j, k) = axes_T[j][k], rows padded to 4 x chunk outputs
+  if (d <= 128) {
+    const int ldk = 4 * generate_ellipsoid_chunk(d);
+    ap.assign((size_t)d * ldk, 0.0);
+    for (int j = 0; j < d; ++j)
+      for (int k = 0; k < d; ++k) ap[(size_t)j * ldk + k] = axes_T[(size_t)j * d + k];
+    if (int rc = upload(r->ax_pad, ap.data(), ap.size() * sizeof(double), c.stream)) return rc;
+  }
   CK(hipStreamSynchronize(c.stream));
   r->axes_ready = true;
   return 0;
@@ -2676,8 +2685,11 @@ int region_sample_tspace(mlf_region *r, int method, long long n, uint64_t seed, 
 }  // namespace
 
 // fetch = false leaves the accepted rows in r->sout (device) for mlf_region_refill
+// masked_ok (with fetch = false): methods 0 and 1 may leave the batch where it was drawn (r->gen, all `nsamples` rows) with the
+// membership mask in r->smask instead of compacting the accepted rows into r->sout; *masked tells which of the two happened
 static int region_sample_impl(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset, double *out,
-                              size_t capacity, size_t *naccepted, uint64_t *next_offset, bool fetch);
+                              size_t capacity, size_t *naccepted, uint64_t *next_offset, bool fetch, bool masked_ok = false,
+                              bool *masked = nullptr);
 
 int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset, double *out,
                       size_t capacity, size_t *naccepted, uint64_t *next_offset) {
@@ -2686,7 +2698,9 @@ int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed,
 }
 
 static int region_sample_impl(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset,
-                      double *out, size_t capacity, size_t *naccepted, uint64_t *next_offset, bool fetch) {
+                      double *out, size_t capacity, size_t *naccepted, uint64_t *next_offset, bool fetch, bool masked_ok,
+                      bool *masked) {
+  if (masked) *masked = false;
   if (!r || !naccepted || !next_offset) return fail_arg(MLF_E_BADARG, "null pointer");
   if (!r->ready) return fail_arg(MLF_E_STATE, "region used before mlf_region_set");
   if (method < 0 || method > 3)
@@ -2713,21 +2727,26 @@ static int region_sample_impl(mlf_region *r, int method, size_t nsamples, uint64
     launch_generate_cube(r->gen.as<double>(), n * d, seed, offset, s);
     *next_offset = offset + (uint64_t)((n * d + 1) / 2);
   } else {
-    CK(r->gen2.reserve((size_t)n * d * sizeof(double)));
     CK(r->cube.reserve((size_t)n));
-    launch_generate_ball(r->gen2.as<double>(), n, d, r->enlarge, seed, offset, s);
     *next_offset = offset + (uint64_t)n * (uint64_t)((d + 1) / 2 + 1);
-    PrepArgs pa{};
-    pa.pts = r->gen2.as<double>();
-    pa.np = n;
-    pa.d = d;
-    pa.do_tr = 1;
-    pa.lay_ctr = r->ax_zero.as<double>();
-    pa.lay_Tt = r->ax_mat.as<double>();
-    pa.t_out = r->gen.as<double>();
-    pa.ldt = d;
-    CK(launch_prep(r->dp, pa, s));
-    launch_center_and_cube(r->gen.as<double>(), n, d, r->ell_ctr.as<double>(), r->cube.as<uint8_t>(), s);
+    if (d <= 128 && r->ax_pad.p) {   // draws, axes product, centre and cube test in one launch: the batch is written once
+      CK(launch_generate_ellipsoid(r->gen.as<double>(), n, d, r->enlarge, r->ax_pad.as<double>(), r->ell_ctr.as<double>(),
+                                   r->cube.as<uint8_t>(), seed, offset, s));
+    } else {
+      CK(r->gen2.reserve((size_t)n * d * sizeof(double)));
+      launch_generate_ball(r->gen2.as<double>(), n, d, r->enlarge, seed, offset, s);
+      PrepArgs pa{};
+      pa.pts = r->gen2.as<double>();
+      pa.np = n;
+      pa.d = d;
+      pa.do_tr = 1;
+      pa.lay_ctr = r->ax_zero.as<double>();
+      pa.lay_Tt = r->ax_mat.as<double>();
+      pa.t_out = r->gen.as<double>();
+      pa.ldt = d;
+      CK(launch_prep(r->dp, pa, s));
+      launch_center_and_cube(r->gen.as<double>(), n, d, r->ell_ctr.as<double>(), r->cube.as<uint8_t>(), s);
+    }
     pregate = r->cube.as<uint8_t>();
   }
   CK(hipGetLastError());
@@ -2735,10 +2754,24 @@ static int region_sample_impl(mlf_region *r, int method, size_t nsamples, uint64
                                      nullptr, pregate))
     return rc;
   const unsigned cap = capacity > 0xffffffffu ? 0xffffffffu : (unsigned)capacity;
+  unsigned count = 0;
+  if (masked_ok && !fetch && capacity >= nsamples) {
+    // the refill works on the batch where it is: count the accepted rows; only a thin batch (under a quarter accepted) is
+    // worth compacting before the prior transform and the likelihood run over it
+    launch_mask_offsets(r->smask.as<uint8_t>(), n, r->blk.as<unsigned>(), s);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(&count, r->blk.as<unsigned>() + nblk, sizeof count, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    if ((size_t)count * 4 >= nsamples) {
+      *naccepted = count;
+      *masked = true;
+      return 0;
+    }
+    if (count == 0) return 0;
+  }
   launch_compact(r->gen.as<double>(), r->smask.as<uint8_t>(), n, d, r->blk.as<unsigned>(), r->sout.as<double>(),
                  cap, s);
   CK(hipGetLastError());
-  unsigned count = 0;
   CK(hipMemcpyAsync(&count, r->blk.as<unsigned>() + nblk, sizeof count, hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));
   const size_t take = count < cap ? count : cap;
@@ -2760,31 +2793,43 @@ int mlf_region_refill(mlf_region *r, int method, size_t nsamples, uint64_t seed,
   *nevaluated = 0;
   *nkept = 0;
   size_t nacc = 0;
-  if (int rc = region_sample_impl(r, method, nsamples, seed, offset, nullptr, nsamples, &nacc, next_offset, false)) return rc;
+  bool masked = false;
+  if (int rc = region_sample_impl(r, method, nsamples, seed, offset, nullptr, nsamples, &nacc, next_offset, false, true, &masked))
+    return rc;
   *nevaluated = nacc;
   if (nacc == 0 || capacity == 0) return 0;
   Ctx &c = g_ctx;
   hipStream_t s = c.stream;
   const int d = r->d;
-  const long long n = (long long)nacc;
+  // masked: the whole batch as drawn (r->gen) with its membership mask (r->smask) -- the prior transform and the likelihood run
+  // over all rows (a rejected row costs a wasted evaluation, no copy), the threshold cut keeps accepted rows only, and the
+  // rows that pass it are compacted once; rows, order and values are those of the compacted route (r->sout, dense)
+  const double *rows = masked ? r->gen.as<double>() : r->sout.as<double>();
+  const uint8_t *member = masked ? r->smask.as<uint8_t>() : nullptr;
+  const long long n = masked ? (long long)nsamples : (long long)nacc;
   const int nblk = (int)((n + 255) / 256);
   CK(r->rf_p.reserve((size_t)n * d * sizeof(double)));
   CK(r->rf_L.reserve((size_t)n * sizeof(double)));
   CK(r->rf_out.reserve(capacity * (2 * (size_t)d + 1) * sizeof(double)));
-  CK(r->smask.reserve((size_t)n));
+  CK(r->rf_keep.reserve((size_t)n));
   CK(r->blk.reserve(((size_t)nblk + 1) * sizeof(unsigned)));
   if (aux)
     if (int rc = upload(r->rf_aux, aux, (size_t)d * sizeof(double), s)) return rc;
   // prior transform + likelihood on the accepted proposals, where they are (reference _refill_samples,
   // integrator.py:1789-1804); only the points above the threshold travel to the host
-  launch_elementwise_affine(r->sout.as<double>(), n * d, tkind, ta, tb, r->rf_p.as<double>(), s);
-  launch_loglike(lkind, r->rf_p.as<double>(), d, n, r->rf_aux.as<double>(), sigma, r->rf_L.as<double>(), s);
-  launch_mask_greater(r->rf_L.as<double>(), n, Lmin, r->smask.as<uint8_t>(), s);
+  const double *prow = rows;   // identity transform: the parameters ARE the cube coordinates, no copy
+  if (tkind != 0) {
+    launch_elementwise_affine(rows, n * d, tkind, ta, tb, r->rf_p.as<double>(), s);
+    prow = r->rf_p.as<double>();
+  }
+  launch_loglike(lkind, prow, d, n, r->rf_aux.as<double>(), sigma, r->rf_L.as<double>(), s);
+  uint8_t *keep = r->rf_keep.as<uint8_t>();
+  launch_mask_greater(r->rf_L.as<double>(), n, Lmin, keep, s, member);
   const unsigned cap = capacity > 0xffffffffu ? 0xffffffffu : (unsigned)capacity;
   double *ou = r->rf_out.as<double>(), *op = ou + capacity * (size_t)d, *oL = op + capacity * (size_t)d;
-  launch_compact(r->sout.as<double>(), r->smask.as<uint8_t>(), n, d, r->blk.as<unsigned>(), ou, cap, s);
-  launch_compact(r->rf_p.as<double>(), r->smask.as<uint8_t>(), n, d, r->blk.as<unsigned>(), op, cap, s);
-  launch_compact(r->rf_L.as<double>(), r->smask.as<uint8_t>(), n, 1, r->blk.as<unsigned>(), oL, cap, s);
+  launch_compact(rows, keep, n, d, r->blk.as<unsigned>(), ou, cap, s);
+  launch_compact(prow, keep, n, d, r->blk.as<unsigned>(), op, cap, s);
+  launch_compact(r->rf_L.as<double>(), keep, n, 1, r->blk.as<unsigned>(), oL, cap, s);
   CK(hipGetLastError());
   unsigned count = 0;
   CK(hipMemcpyAsync(&count, r->blk.as<unsigned>() + nblk, sizeof count, hipMemcpyDeviceToHost, s));

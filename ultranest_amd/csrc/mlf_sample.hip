@@ -67,6 +67,101 @@ __global__ void k_generate_ball(double *z, long long n, int d, double enlarge, u
   for (int k = 0; k < d; ++k) row[k] *= scale;
 }
 
+// sample_from_wrapping_ellipsoid in ONE launch (reference :1135-1160): the draws of k_generate_ball (same counters, same
+// Box-Muller, same scaling), the product with the ellipsoid's axes, the centre and the unit-cube test -- the batch is written
+// once, in whole contiguous pieces.  Before: k_generate_ball (one thread per row: stores with a stride of 8 d bytes between
+// lanes, every value written twice, 1.17 ms per 2^20 x 50), k_prep's matrix product (0.67 ms) and k_center_and_cube (0.15 ms),
+// 1.26 GB of traffic for a 0.42 GB batch.
+//   workgroup = 256 threads = 64 rows.  1: thread per Box-Muller pair (flat over the rows' pairs), values to LDS.  2: 4 threads per
+//   row add up |z|^2 (k = part, part + 4, ...; combined by xor-shuffles: a fixed order, not the sequential one of k_generate_ball --
+//   the draws agree to the last bits only, 1e-16 relative) and one of them draws the radius.  3: lane = row, WAVE = output chunk
+//   of CH columns: w_k = sum_j (z_j scale) A[j][k], FMA chain in ascending j as k_prep does -- the matrix elements are the same
+//   for all lanes of a wave and come through the SCALAR cache (wave number by readfirstlane), one SGPR pair per FMA; the first
+//   version read them per lane (64 lanes x 8 bytes per FMA through the vector memory pipe: 0.6 of its 0.88 ms).  A = the padded
+//   copy [d][4 CH].  + centre; cube test.  4: the finished rows (staged over the z values, which nobody reads any more) leave as
+//   one contiguous piece.
+template <int CH>
+__global__ __launch_bounds__(256) void k_generate_ellipsoid(double *w, long long n, int d, double enlarge, const double *A,
+                                                            const double *center, uint8_t *in_cube, unsigned long long seed,
+                                                            unsigned long long offset, unsigned pmagic) {
+  extern __shared__ __attribute__((aligned(16))) double lds_ge[];
+  constexpr int RB = 64;
+  const int zs_stride = d + 1;
+  double *zs = lds_ge;                       // [64][d + 1]; from stage 3's end on: the outputs, [64 d]
+  double *scale = zs + RB * zs_stride;       // [64]
+  unsigned *bad = reinterpret_cast<unsigned *>(scale + RB);   // [64]
+  const int tid = threadIdx.x;
+  const long long row0 = (long long)blockIdx.x * RB;
+  const int nrows = n - row0 >= RB ? RB : (int)(n - row0);
+  const int npairs = (d + 1) / 2;
+  if (tid < RB) bad[tid] = 0u;
+  for (unsigned e = tid; e < (unsigned)(nrows * npairs); e += 256) {
+    const unsigned r = npairs == 1 ? e : __umulhi(e, pmagic), j = e - r * (unsigned)npairs;   // (2^32 / 1 does not fit the magic word)
+    const unsigned long long ctr = offset + (unsigned long long)(row0 + r) * (unsigned long long)(npairs + 1) + j;
+    unsigned wd[4];
+    philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 1u, 0u, (unsigned)seed, (unsigned)(seed >> 32), wd);
+    const double rad = sqrt(-2.0 * log(u01(wd[0], wd[1])));
+    // cos / sin of 2 pi u as cospi / sinpi of 2 u: one exact argument reduction for both instead of two reductions by a
+    // rounded 2 pi u (k_generate_ball's form; the values differ by the rounding of that product, ~1e-16)
+    double sn, cs;
+    sincospi(2.0 * u01(wd[2], wd[3]), &sn, &cs);
+    zs[r * zs_stride + 2 * j] = rad * cs;
+    if ((int)(2 * j + 1) < d) zs[r * zs_stride + 2 * j + 1] = rad * sn;
+  }
+  __syncthreads();
+  {
+    const int r = tid >> 2, part = tid & 3;
+    double acc = 0.0;
+    if (r < nrows)
+      for (int k = part; k < d; k += 4) {
+        const double v = zs[r * zs_stride + k];
+        acc += v * v;
+      }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0 && r < nrows) {
+      const unsigned long long ctr = offset + (unsigned long long)(row0 + r) * (unsigned long long)(npairs + 1) + npairs;
+      unsigned wd[4];
+      philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 1u, 0u, (unsigned)seed, (unsigned)(seed >> 32), wd);
+      scale[r] = sqrt(enlarge) * pow(u01(wd[0], wd[1]), 1.0 / (double)d) / sqrt(acc);
+    }
+  }
+  __syncthreads();
+  const int r = tid & 63;
+  const int c = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave's output chunk: a scalar, and with it every matrix address
+  double acc[CH];
+#pragma unroll
+  for (int kk = 0; kk < CH; ++kk) acc[kk] = 0.0;
+  if (c * CH < d) {   // wave-uniform
+    const double sc = r < nrows ? scale[r] : 0.0;
+    const double *Ac = A + c * CH;
+    const double *zr = zs + (r < nrows ? r : 0) * zs_stride;
+    for (int j = 0; j < d; ++j) {
+      const double zj = zr[j] * sc;
+#pragma unroll
+      for (int kk = 0; kk < CH; ++kk) acc[kk] = __builtin_fma(zj, Ac[(size_t)j * (4 * CH) + kk], acc[kk]);
+    }
+  }
+  __syncthreads();   // every wave has read its z values: the buffer takes the outputs
+  if (c * CH < d && r < nrows) {
+    bool out_of_cube = false;
+#pragma unroll
+    for (int kk = 0; kk < CH; ++kk) {
+      const int k = c * CH + kk;
+      if (k < d) {
+        const double v = acc[kk] + center[k];
+        zs[r * d + k] = v;
+        out_of_cube = out_of_cube || !((v > 0.0) && (v < 1.0));
+      }
+    }
+    if (out_of_cube) bad[r] = 1u;   // benign race: every writer stores 1
+  }
+  __syncthreads();
+  double *dst = w + row0 * d;
+  for (int e = tid; e < nrows * d; e += 256) dst[e] = zs[e];
+  if (tid < nrows) in_cube[row0 + tid] = bad[tid] ? 0 : 1;
+}
+
 // w = center + (z @ axes_T) was produced without the centre by the whitening kernel; add it and
 // record whether the point lies strictly inside the unit cube (reference :1154)
 // One WAVE per 64 rows, lanes striding the rows' elements (coalesced 512-byte accesses); a row's verdict is the AND over
@@ -198,9 +293,10 @@ __global__ void k_elementwise_affine(const double *x, long long n, int tkind, do
   out[e] = p;
 }
 
-__global__ void k_mask_greater(const double *v, long long n, double threshold, uint8_t *mask) {
+// mask[e] = v[e] > threshold (and also[e], where a mask of the rows that count is given: the others hold no likelihood)
+__global__ void k_mask_greater(const double *v, long long n, double threshold, const uint8_t *also, uint8_t *mask) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n) mask[e] = v[e] > threshold ? 1 : 0;
+  if (e < n) mask[e] = (v[e] > threshold && (!also || also[e] != 0)) ? 1 : 0;
 }
 
 __global__ void k_mask_and(uint8_t *mask, const uint8_t *other, long long n) {
@@ -259,9 +355,41 @@ __global__ __launch_bounds__(1024) void k_scan_counts(unsigned *blk, int nblk) {
   if (tid == 1023) blk[nblk] = part[1023];
 }
 
+// The 256 rows of a workgroup are one contiguous piece of the batch: its threads walk the piece element by element (coalesced
+// reads; a row's d elements land next to each other at its rank: coalesced writes) and skip the elements of rejected rows.
+// (One thread per row copied with a stride of 8 d bytes between lanes: 1.19 ms per 2^20 x 50 batch, 0.66 TB/s --
+// profiles/r06_refill_kernel_stats_after.csv.)  dmagic = ceil(2^32 / d): e / d = umulhi(e, dmagic) for e < 2^32 / d.
 __global__ __launch_bounds__(256) void k_scatter_accepted(const double *pts, const uint8_t *mask,
-                                                          long long n, int d, const unsigned *blk,
+                                                          long long n, int d, unsigned dmagic, const unsigned *blk,
                                                           double *out, unsigned capacity) {
+  __shared__ unsigned wsum[4];
+  __shared__ unsigned rk[256];
+  const long long row0 = (long long)blockIdx.x * 256;
+  const long long p = row0 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool acc = p < n && mask[p] != 0;
+  const unsigned long long b = __ballot(acc);
+  if (lane == 0) wsum[wave] = (unsigned)__popcll(b);
+  __syncthreads();
+  unsigned base = blk[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const unsigned rank = base + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+  rk[threadIdx.x] = (acc && rank < capacity) ? rank : 0xffffffffu;
+  __syncthreads();
+  if (wsum[0] + wsum[1] + wsum[2] + wsum[3] == 0u) return;
+  const long long left = n - row0;
+  const unsigned total = (unsigned)(left < 256 ? left : 256) * (unsigned)d;
+  const double *src = pts + row0 * d;
+  for (unsigned e = threadIdx.x; e < total; e += 256) {
+    const unsigned r = __umulhi(e, dmagic);
+    const unsigned rr = rk[r];
+    if (rr != 0xffffffffu) out[(size_t)rr * d + (e - r * (unsigned)d)] = src[e];
+  }
+}
+
+// d = 1 (a vector of likelihood values): one element per thread
+__global__ __launch_bounds__(256) void k_scatter_scalars(const double *v, const uint8_t *mask, long long n, const unsigned *blk,
+                                                         double *out, unsigned capacity) {
   __shared__ unsigned wsum[4];
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -272,8 +400,7 @@ __global__ __launch_bounds__(256) void k_scatter_accepted(const double *pts, con
   unsigned base = blk[blockIdx.x];
   for (int w = 0; w < wave; ++w) base += wsum[w];
   const unsigned rank = base + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
-  if (acc && rank < capacity)
-    for (int k = 0; k < d; ++k) out[(size_t)rank * d + k] = pts[p * d + k];
+  if (acc && rank < capacity) out[rank] = v[p];
 }
 
 // ---------------------------------------------------------------- launchers -------------------
@@ -291,6 +418,43 @@ void launch_generate_ball(double *z, long long n, int d, double enlarge, unsigne
                           unsigned long long offset, hipStream_t s) {
   hipLaunchKernelGGL(k_generate_ball, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, n, d, enlarge, seed,
                      offset);
+}
+
+int generate_ellipsoid_chunk(int d) {   // outputs per wave: the instantiated size that covers ceil(d / 4)
+  const int need = (d + 3) / 4;
+  return need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 13 ? 13 : need <= 16 ? 16 : 32;
+}
+
+hipError_t launch_generate_ellipsoid(double *w, long long n, int d, double enlarge, const double *A_padded, const double *center,
+                                     uint8_t *in_cube, unsigned long long seed, unsigned long long offset, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (d < 1 || d > 128) return hipErrorInvalidValue;
+  const int npairs = (d + 1) / 2;
+  const unsigned pmagic = npairs > 1 ? (unsigned)((0x100000000ull + (unsigned)npairs - 1) / (unsigned)npairs) : 0u;
+  const size_t lds = ((size_t)64 * (d + 1) + 64) * sizeof(double) + 64 * sizeof(unsigned);
+  const dim3 grid((unsigned)((n + 63) / 64));
+  static DeviceGrant grant;   // d = 128: 66 KiB
+  if (hipError_t e = grant.ensure([] {
+        hipError_t rc = hipSuccess;
+#define MLF_GE(C)                                                                                                              \
+  if (rc == hipSuccess)                                                                                                        \
+    rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_generate_ellipsoid<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+        MLF_GE(1) MLF_GE(2) MLF_GE(4) MLF_GE(8) MLF_GE(13) MLF_GE(16) MLF_GE(32)
+#undef MLF_GE
+        return rc;
+      }))
+    return e;
+  switch (generate_ellipsoid_chunk(d)) {
+#define MLF_GE(C)                                                                                                              \
+  case C:                                                                                                                      \
+    hipLaunchKernelGGL((k_generate_ellipsoid<C>), grid, dim3(256), lds, s, w, n, d, enlarge, A_padded, center, in_cube, seed,  \
+                       offset, pmagic);                                                                                        \
+    break;
+    MLF_GE(1) MLF_GE(2) MLF_GE(4) MLF_GE(8) MLF_GE(13) MLF_GE(16) MLF_GE(32)
+#undef MLF_GE
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 void launch_center_and_cube(double *w, long long n, int d, const double *center, uint8_t *in_cube, hipStream_t s) {
@@ -326,9 +490,9 @@ void launch_elementwise_affine(const double *x, long long n, int tkind, double a
   hipLaunchKernelGGL(k_elementwise_affine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, tkind, a, b, out);
 }
 
-void launch_mask_greater(const double *v, long long n, double threshold, uint8_t *mask, hipStream_t s) {
+void launch_mask_greater(const double *v, long long n, double threshold, uint8_t *mask, hipStream_t s, const uint8_t *also) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_mask_greater, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, n, threshold, mask);
+  hipLaunchKernelGGL(k_mask_greater, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, n, threshold, also, mask);
 }
 
 void launch_mask_and(uint8_t *mask, const uint8_t *other, long long n, hipStream_t s) {
@@ -359,7 +523,11 @@ void launch_compact(const double *pts, const uint8_t *mask, long long n, int d, 
   const int nblk = (int)((n + 255) / 256);
   hipLaunchKernelGGL(k_count_accepted, dim3(nblk), dim3(256), 0, s, mask, n, blk);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, blk, nblk);
-  hipLaunchKernelGGL(k_scatter_accepted, dim3(nblk), dim3(256), 0, s, pts, mask, n, d, blk, out, capacity);
+  const unsigned dmagic = d > 1 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u;
+  if (d == 1)
+    hipLaunchKernelGGL(k_scatter_scalars, dim3(nblk), dim3(256), 0, s, pts, mask, n, blk, out, capacity);
+  else
+    hipLaunchKernelGGL(k_scatter_accepted, dim3(nblk), dim3(256), 0, s, pts, mask, n, d, dmagic, blk, out, capacity);
 }
 
 }  // namespace mlf
