@@ -15,7 +15,7 @@ from ultranest_amd.regions import DeviceRNG  # noqa: E402
 
 import gc  # noqa: E402
 
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 10
 u, region = bench.build_region(None)
 region.device_rng = DeviceRNG(3)
 loglike = likelihoods.GaussLikelihood(0.5, 0.05, bench.NDIM)
@@ -26,7 +26,12 @@ out = {}
 gc.collect()
 gc.freeze()      # a full pass of the cyclic collector over torch's objects (35 ms) landed inside the 10 timed calls of the second
 gc.disable()     # method in every earlier run of this script (3.7-4.4 ms "per batch" for 0.3 ms of work)
-for method, name in ((1, "wrapping_ellipsoid"), (0, "boundingbox")):
+methods = [(1, "wrapping_ellipsoid"), (0, "boundingbox")]
+if "--all" in sys.argv:      # the two methods whose proposals are born in the whitened space
+    methods += [(2, "transformed_boundingbox"), (3, "points")]
+    region.bbox_lo = region.unormed.min(axis=0)     # what MLFriends.sample_from_transformed_boundingbox computes on first use
+    region.bbox_hi = region.unormed.max(axis=0)
+for method, name in methods:
     for _ in range(3):
         region._dev.refill(region, True, method, n, Lmin, likelihoods.identity_transform.device_spec, loglike.device_spec)
     t0 = time.perf_counter()

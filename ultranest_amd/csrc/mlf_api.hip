@@ -970,6 +970,7 @@ struct mlf_region {
   FilterCtx filter;
   DevBuf gen, gen2, cube, smask, blk, sout, ax_zero, ax_mat, ax_pad;   // device-side sampling
   DevBuf s_invT, s_lo, s_hi, s_thin, s_count, rf_p, rf_L, rf_out, rf_aux, rf_keep;
+  DevBuf s_invT_pad, s_tc, s_wc, s_thc, s_gate;   // t-space sampling: padded invT, survivors of the cheap tests (rows, cube rows, thinning draws)
   bool axes_ready = false, sampling_ready = false;
   std::vector<hipEvent_t> events;  // 4 per timed call
   size_t events_used = 0;
@@ -2134,7 +2135,7 @@ int mlf_region_destroy(mlf_region *r) {
                     &r->ell_A, &r->tq,  &r->gate,    &r->pts,     &r->mask, &r->row, &r->p4_LtF, &r->p4_TtF, &r->p4_y0, &r->lay_T64, &r->ell_L,
                     &r->gen, &r->gen2, &r->cube, &r->smask, &r->blk, &r->sout, &r->ax_zero, &r->ax_mat,
                     &r->s_invT, &r->s_lo, &r->s_hi, &r->s_thin, &r->s_count, &r->rf_p, &r->rf_L, &r->rf_out, &r->rf_aux,
-                    &r->rf_keep, &r->ax_pad};
+                    &r->rf_keep, &r->ax_pad, &r->s_invT_pad, &r->s_tc, &r->s_wc, &r->s_thc, &r->s_gate};
   for (DevBuf *b : bufs) b->release();
   for (hipEvent_t e : r->events) (void)hipEventDestroy(e);
   r->filter.release();
@@ -2570,6 +2571,14 @@ int mlf_region_set_sampling_data(mlf_region *r, const double *invT, const double
   Ctx &c = g_ctx;
   const size_t d = (size_t)r->d;
   if (int rc = upload(r->s_invT, invT, d * d * sizeof(double), c.stream)) return rc;
+  std::vector<double> ip;   // k_rows_affine's copy: rows padded to 4 x chunk outputs
+  if (d <= 128) {
+    const size_t ldk = 4 * (size_t)generate_ellipsoid_chunk((int)d);
+    ip.assign(d * ldk, 0.0);
+    for (size_t j = 0; j < d; ++j)
+      for (size_t k = 0; k < d; ++k) ip[j * ldk + k] = invT[j * d + k];
+    if (int rc = upload(r->s_invT_pad, ip.data(), ip.size() * sizeof(double), c.stream)) return rc;
+  }
   if (int rc = upload(r->s_lo, bbox_lo, d * sizeof(double), c.stream)) return rc;
   if (int rc = upload(r->s_hi, bbox_hi, d * sizeof(double), c.stream)) return rc;
   CK(hipStreamSynchronize(c.stream));
@@ -2601,6 +2610,80 @@ int region_scan_mask(mlf_region *r, const double *d_t, long long np, uint8_t *d_
   return 0;
 }
 
+// w = t . invT + ctr (+ unwrap) and the cube flags of `n` rows
+int region_untransform(mlf_region *r, const double *t, long long n, double *w, uint8_t *in_cube, hipStream_t s) {
+  const double *wrap = r->has_wrap ? r->wrap.as<double>() : nullptr;
+  if (r->d <= 128 && r->s_invT_pad.p)
+    CK(launch_rows_affine(t, n, r->d, r->s_invT_pad.as<double>(), r->lay_ctr.as<double>(), wrap, w, in_cube, s));
+  else
+    launch_untransform_rows(t, n, r->d, r->s_invT.as<double>(), r->lay_ctr.as<double>(), wrap, w, in_cube, s);
+  CK(hipGetLastError());
+  return 0;
+}
+
+// wrapping-ellipsoid test alone (H3, mlfriends.pyx:882-912) of `np` cube-space rows: the bounded matrix-core form with the exact
+// test behind its band where the region has it (what a region without a neighbour scan runs), else the binary64 kernel
+int region_ellipsoid_gate(mlf_region *r, const double *d_pts, size_t np, uint8_t *gate, hipStream_t s) {
+  if (np == 0) return 0;
+  FilterCtx &f = r->filter;
+  const bool bounded = r->layer_kind == 0 && opt(f, OPT_FUSED_PREP) && opt(f, OPT_PREP_BOUNDED) && prep3_usable(r->d) && r->chol_ready &&
+                       r->p4_ready && !r->has_wrap && np < (size_t)0x7fffffff && (reinterpret_cast<uintptr_t>(d_pts) & 15) == 0;
+  if (!bounded) {
+    PrepArgs pa{};
+    pa.pts = d_pts;
+    pa.np = (long long)np;
+    pa.d = r->d;
+    pa.do_ell = 1;
+    pa.ell_ctr = r->ell_ctr.as<double>();
+    pa.ell_A = r->ell_A.as<double>();
+    pa.enlarge = r->enlarge;
+    pa.mask = gate;
+    CK(launch_prep(r->dp, pa, s));
+    return 0;
+  }
+  if (int rc = misc_reserve(f)) return rc;
+  CK(f.ell_list.reserve(np * sizeof(int)));
+  Prep4Args pa{};
+  pa.pts = d_pts;
+  pa.np = (long long)np;
+  pa.d = r->d;
+  pa.dp = r->dp;
+  pa.LtF = r->p4_LtF.p;
+  pa.y0 = r->p4_y0.as<float>();
+  pa.TtF = r->p4_TtF.p;
+  pa.lay_ctr = r->use_scan ? r->lay_ctr.as<double>() : r->ell_ctr.as<double>();   // the centre the chain's start values belong to
+  pa.c = r->p4c;
+  pa.c.enl_lo = f32_dn(r->enlarge);
+  pa.c.enl_hi = f32_up(r->enlarge);
+  pa.gate = gate;
+  pa.do_tr = 0;
+  pa.ell_count = f.misc.as<unsigned>();
+  pa.ell_list = f.ell_list.as<int>();
+  pa.ell_cap = (unsigned)np;
+  CK(launch_prep4(pa, s));
+  EllExactArgs ea{};
+  ea.count = f.misc.as<unsigned>();
+  ea.done = f.misc.as<unsigned>() + 1;
+  ea.last = f.misc.as<unsigned>() + 4;
+  ea.list = f.ell_list.as<int>();
+  ea.cap = (unsigned)np;
+  ea.pts = d_pts;
+  ea.d = r->d;
+  ea.dp = r->dp;
+  ea.ell_ctr = r->ell_ctr.as<double>();
+  ea.ell_Lt = r->ell_Lt.as<double>();
+  ea.ell_L = r->ell_L.as<double>();
+  ea.ell_A = r->ell_A.as<double>();
+  ea.eps_scale = r->ell_eps_scale;
+  ea.enlarge = r->enlarge;
+  ea.chol_ok = r->chol_ok ? 1 : 0;
+  ea.gate = gate;
+  ea.route = nullptr;
+  launch_ell_exact(ea, s);
+  CK(hipGetLastError());
+  return 0;
+}
+
 // methods 2 and 3 of MLFriends.sample: proposals are born in t-space
 int region_sample_tspace(mlf_region *r, int method, long long n, uint64_t seed, uint64_t offset, double *out,
                          size_t capacity, size_t *naccepted, uint64_t *next_offset, bool fetch) {
@@ -2620,28 +2703,66 @@ int region_sample_tspace(mlf_region *r, int method, long long n, uint64_t seed, 
     CK(hipGetLastError());
     *next_offset = offset + (uint64_t)((n * d + 1) / 2);
     if (int rc = region_scan_mask(r, t, n, mask, s)) return rc;
-  } else {
+  } else {   // method 3
+    // Reference order (:1072-1094, :1154-1160): multiplicity of every proposal -> thinning -> untransform -> cube and ellipsoid
+    // tests.  Every one of these is a function of the proposal alone (the thinning uniform is drawn with it), so the accepted set
+    // does not depend on their order: the cheap tests run FIRST, on the whole batch (untransform + cube 0.2 ms, ellipsoid 0.15 ms
+    // per 2^20 x 50), and the multiplicity -- the exact count over all live points, 22 ms for the whole batch, the one stage that
+    // cannot stop at the first hit -- is taken of their survivors only (a few per cent at C5).
     CK(r->s_thin.reserve((size_t)n * sizeof(double)));
-    CK(r->s_count.reserve((size_t)n * sizeof(long long)));
+    CK(r->s_gate.reserve((size_t)n));
     launch_generate_around_points(t, r->s_thin.as<double>(), n, d, r->refR.as<double>(), r->n, r->dp, r->r2, seed,
                                   offset, s);
     CK(hipGetLastError());
     *next_offset = offset + (uint64_t)n * (uint64_t)((d + 1) / 2 + 2);
+    double *wall = r->gen2.as<double>();
+    if (int rc = region_untransform(r, t, n, wall, r->cube.as<uint8_t>(), s)) return rc;
+    if (int rc = region_ellipsoid_gate(r, wall, (size_t)n, r->s_gate.as<uint8_t>(), s)) return rc;
+    launch_mask_and(r->s_gate.as<uint8_t>(), r->cube.as<uint8_t>(), n, s);
+    launch_mask_offsets(r->s_gate.as<uint8_t>(), n, r->blk.as<unsigned>(), s);
+    CK(hipGetLastError());
+    unsigned k0 = 0;
+    CK(hipMemcpyAsync(&k0, r->blk.as<unsigned>() + nblk, sizeof k0, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    *naccepted = 0;
+    if (k0 == 0) return 0;
+    CK(r->s_tc.reserve((size_t)k0 * d * sizeof(double)));
+    CK(r->s_wc.reserve((size_t)k0 * d * sizeof(double)));
+    CK(r->s_thc.reserve((size_t)k0 * sizeof(double)));
+    CK(r->s_count.reserve((size_t)k0 * sizeof(long long)));
+    launch_compact(t, r->s_gate.as<uint8_t>(), n, d, r->blk.as<unsigned>(), r->s_tc.as<double>(), k0, s);
+    launch_compact(wall, r->s_gate.as<uint8_t>(), n, d, r->blk.as<unsigned>(), r->s_wc.as<double>(), k0, s);
+    launch_compact(r->s_thin.as<double>(), r->s_gate.as<uint8_t>(), n, 1, r->blk.as<unsigned>(), r->s_thc.as<double>(), k0, s);
     ScanArgs a{};   // multiplicity: how many balls contain the proposal (no early exit, reference :1087-1088)
     a.refT = r->refT.as<double>();
     a.n = r->n;
     a.npad = r->npad;
     a.ntiles = r->npad / kWave;
-    a.q = t;
+    a.q = r->s_tc.as<double>();
     a.ldq = d;
-    a.nq = n;
+    a.nq = k0;
     a.d = d;
     a.r2 = r->r2;
     a.mode = SCAN_COUNT;
     a.out_idx = r->s_count.as<long long>();
     CK(launch_scan(r->dp, a, s));
-    launch_thin_by_multiplicity(r->s_count.as<long long>(), r->s_thin.as<double>(), n, mask, s);
+    launch_thin_by_multiplicity(r->s_count.as<long long>(), r->s_thc.as<double>(), k0, mask, s);
     CK(hipGetLastError());
+    CK(r->sout.reserve(capacity * (size_t)d * sizeof(double)));
+    const unsigned cap3 = capacity > 0xffffffffu ? 0xffffffffu : (unsigned)capacity;
+    launch_compact(r->s_wc.as<double>(), mask, k0, d, r->blk.as<unsigned>(), r->sout.as<double>(), cap3, s);
+    CK(hipGetLastError());
+    unsigned count3 = 0;
+    const int nblk0 = (int)((k0 + 255) / 256);
+    CK(hipMemcpyAsync(&count3, r->blk.as<unsigned>() + nblk0, sizeof count3, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    const size_t take3 = count3 < cap3 ? count3 : cap3;
+    if (take3 && fetch) {
+      CK(hipMemcpyAsync(out, r->sout.p, take3 * (size_t)d * sizeof(double), hipMemcpyDeviceToHost, s));
+      CK(hipStreamSynchronize(s));
+    }
+    *naccepted = take3;
+    return 0;
   }
   // survivors of the neighbour test, compacted; everything after works on those rows only
   launch_compact(t, mask, n, d, r->blk.as<unsigned>(), r->gen2.as<double>(), (unsigned)n, s);
@@ -2652,18 +2773,8 @@ int region_sample_tspace(mlf_region *r, int method, long long n, uint64_t seed, 
   *naccepted = 0;
   if (k1 == 0) return 0;
   double *w = r->gen.as<double>();   // the t-space batch is not needed any more
-  launch_untransform_rows(r->gen2.as<double>(), k1, d, r->s_invT.as<double>(), r->lay_ctr.as<double>(),
-                          r->has_wrap ? r->wrap.as<double>() : nullptr, w, r->cube.as<uint8_t>(), s);
-  PrepArgs pa{};
-  pa.pts = w;
-  pa.np = k1;
-  pa.d = d;
-  pa.do_ell = 1;
-  pa.ell_ctr = r->ell_ctr.as<double>();
-  pa.ell_A = r->ell_A.as<double>();
-  pa.enlarge = r->enlarge;
-  pa.mask = mask;
-  CK(launch_prep(r->dp, pa, s));
+  if (int rc = region_untransform(r, r->gen2.as<double>(), k1, w, r->cube.as<uint8_t>(), s)) return rc;
+  if (int rc = region_ellipsoid_gate(r, w, k1, mask, s)) return rc;
   launch_mask_and(mask, r->cube.as<uint8_t>(), k1, s);
   CK(r->sout.reserve(capacity * (size_t)d * sizeof(double)));
   const unsigned cap = capacity > 0xffffffffu ? 0xffffffffu : (unsigned)capacity;

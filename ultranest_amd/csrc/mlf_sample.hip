@@ -67,6 +67,77 @@ __global__ void k_generate_ball(double *z, long long n, int d, double enlarge, u
   for (int k = 0; k < d; ++k) row[k] *= scale;
 }
 
+// Shared last stages of k_generate_ellipsoid / k_rows_affine: the workgroup's 64 rows lie in LDS (zs[r * zs_stride + j]);
+// lane = row, WAVE = output chunk of CH columns: out_k = sum_j (z_j scale_r) A[j][k] + shift_k, FMA chain in ascending j.  The
+// matrix elements are the same for all lanes of a wave and come through the SCALAR cache (wave number by readfirstlane), one SGPR
+// pair per FMA -- read per lane (64 lanes x 8 bytes per FMA through the vector memory pipe) they were 0.6 of 0.88 ms.  A = the
+// padded copy [d][4 CH].  Circular axes rotated back (AffineLayer.unwrap, mlfriends.pyx:538-545) where wrap_shift is given;
+// unit-cube test; the finished rows (staged over the inputs, which nobody reads any more) leave as one contiguous piece.
+template <int CH>
+__device__ __forceinline__ void rows_times_matrix(double *zs, int zs_stride, const double *scale, int nrows, int d, const double *A,
+                                                  const double *shift, const double *wrap_shift, unsigned *bad, double *dst,
+                                                  uint8_t *in_cube, int tid) {
+  const int r = tid & 63;
+  const int c = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave's output chunk: a scalar, and with it every matrix address
+  double acc[CH];
+#pragma unroll
+  for (int kk = 0; kk < CH; ++kk) acc[kk] = 0.0;
+  if (c * CH < d) {   // wave-uniform
+    const double sc = scale ? (r < nrows ? scale[r] : 0.0) : 1.0;
+    const double *Ac = A + c * CH;
+    const double *zr = zs + (r < nrows ? r : 0) * zs_stride;
+    for (int j = 0; j < d; ++j) {
+      const double zj = scale ? zr[j] * sc : zr[j];
+#pragma unroll
+      for (int kk = 0; kk < CH; ++kk) acc[kk] = __builtin_fma(zj, Ac[(size_t)j * (4 * CH) + kk], acc[kk]);
+    }
+  }
+  __syncthreads();   // every wave has read its inputs: the buffer takes the outputs
+  if (c * CH < d && r < nrows) {
+    bool out_of_cube = false;
+#pragma unroll
+    for (int kk = 0; kk < CH; ++kk) {
+      const int k = c * CH + kk;
+      if (k < d) {
+        double v = acc[kk] + shift[k];
+        if (wrap_shift) {
+          const double sh = wrap_shift[k];
+          if (sh == sh) v = fmod(v + (1.0 - sh), 1.0);   // cut = 1 - shift
+        }
+        zs[r * d + k] = v;
+        out_of_cube = out_of_cube || !((v > 0.0) && (v < 1.0));
+      }
+    }
+    if (out_of_cube) bad[r] = 1u;   // benign race: every writer stores 1
+  }
+  __syncthreads();
+  for (int e = tid; e < nrows * d; e += 256) dst[e] = zs[e];
+  if (tid < nrows) in_cube[tid] = bad[tid] ? 0 : 1;
+}
+
+// AffineLayer.untransform for whole batches (reference mlfriends.pyx:745-752): w = t . invT + ctr, circular axes rotated back,
+// unit-cube test.  64 rows per workgroup arrive in LDS as one contiguous piece.  (k_untransform_rows, one thread per row and
+// matrix elements per lane: 17.4 ms per 10^6 x 50 rows, profiles/r06_refill_tspace_before.csv.)
+template <int CH>
+__global__ __launch_bounds__(256) void k_rows_affine(const double *t, long long n, int d, const double *A, const double *ctr,
+                                                     const double *wrap_shift, double *w, uint8_t *in_cube, unsigned dmagic) {
+  extern __shared__ __attribute__((aligned(16))) double lds_ra[];
+  const int zs_stride = d + 1;
+  double *zs = lds_ra;
+  unsigned *bad = reinterpret_cast<unsigned *>(zs + 64 * zs_stride);
+  const int tid = threadIdx.x;
+  const long long row0 = (long long)blockIdx.x * 64;
+  const int nrows = n - row0 >= 64 ? 64 : (int)(n - row0);
+  if (tid < 64) bad[tid] = 0u;
+  const double *src = t + row0 * d;
+  for (unsigned e = tid; e < (unsigned)(nrows * d); e += 256) {
+    const unsigned r = d == 1 ? e : __umulhi(e, dmagic);
+    zs[r * zs_stride + (e - r * (unsigned)d)] = src[e];
+  }
+  __syncthreads();
+  rows_times_matrix<CH>(zs, zs_stride, nullptr, nrows, d, A, ctr, wrap_shift, bad, w + row0 * d, in_cube + row0, tid);
+}
+
 // sample_from_wrapping_ellipsoid in ONE launch (reference :1135-1160): the draws of k_generate_ball (same counters, same
 // Box-Muller, same scaling), the product with the ellipsoid's axes, the centre and the unit-cube test -- the batch is written
 // once, in whole contiguous pieces.  Before: k_generate_ball (one thread per row: stores with a stride of 8 d bytes between
@@ -127,39 +198,7 @@ __global__ __launch_bounds__(256) void k_generate_ellipsoid(double *w, long long
     }
   }
   __syncthreads();
-  const int r = tid & 63;
-  const int c = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave's output chunk: a scalar, and with it every matrix address
-  double acc[CH];
-#pragma unroll
-  for (int kk = 0; kk < CH; ++kk) acc[kk] = 0.0;
-  if (c * CH < d) {   // wave-uniform
-    const double sc = r < nrows ? scale[r] : 0.0;
-    const double *Ac = A + c * CH;
-    const double *zr = zs + (r < nrows ? r : 0) * zs_stride;
-    for (int j = 0; j < d; ++j) {
-      const double zj = zr[j] * sc;
-#pragma unroll
-      for (int kk = 0; kk < CH; ++kk) acc[kk] = __builtin_fma(zj, Ac[(size_t)j * (4 * CH) + kk], acc[kk]);
-    }
-  }
-  __syncthreads();   // every wave has read its z values: the buffer takes the outputs
-  if (c * CH < d && r < nrows) {
-    bool out_of_cube = false;
-#pragma unroll
-    for (int kk = 0; kk < CH; ++kk) {
-      const int k = c * CH + kk;
-      if (k < d) {
-        const double v = acc[kk] + center[k];
-        zs[r * d + k] = v;
-        out_of_cube = out_of_cube || !((v > 0.0) && (v < 1.0));
-      }
-    }
-    if (out_of_cube) bad[r] = 1u;   // benign race: every writer stores 1
-  }
-  __syncthreads();
-  double *dst = w + row0 * d;
-  for (int e = tid; e < nrows * d; e += 256) dst[e] = zs[e];
-  if (tid < nrows) in_cube[row0 + tid] = bad[tid] ? 0 : 1;
+  rows_times_matrix<CH>(zs, zs_stride, scale, nrows, d, A, center, nullptr, bad, w + row0 * d, in_cube + row0, tid);
 }
 
 // w = center + (z @ axes_T) was produced without the centre by the whitening kernel; add it and
@@ -213,37 +252,60 @@ __global__ void k_generate_tbox(double *t, long long nelem, int d, const double 
 // method 3 (reference :1072-1094): a random live point plus a uniform draw in its ball of radius sqrt(r2).
 // Philox stream 6, (npairs + 2) blocks per proposal: block 0 = live index + radial uniform + thinning uniform
 // (kept in thin_u), blocks 1.. = Box-Muller pairs.
-__global__ void k_generate_around_points(double *t, double *thin_u, long long n, int d, const double *refR, int nlive,
-                                         int dp, double r2, unsigned long long seed, unsigned long long offset) {
-  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
+// 64 rows per workgroup, one thread per Box-Muller pair (flat over the rows' pairs) into LDS, 4 threads per row for |z|^2, the
+// finished rows written as one contiguous piece.  (One thread per row with stores 8 d bytes apart between lanes: 1.53 ms per
+// 2^20 x 50.)  Same counters as that version; |z|^2 added up in a fixed order of its own (draws agree to ~1e-16).
+__global__ __launch_bounds__(256) void k_generate_around_points(double *t, double *thin_u, long long n, int d, const double *refR,
+                                                                int nlive, int dp, double r2, unsigned long long seed,
+                                                                unsigned long long offset, unsigned pmagic, unsigned dmagic) {
+  extern __shared__ __attribute__((aligned(16))) double lds_ap[];
+  const int zs_stride = d + 1;
+  double *zs = lds_ap;                     // [64][d + 1]
+  double *fac = zs + 64 * zs_stride;       // [64]
+  unsigned *which = reinterpret_cast<unsigned *>(fac + 64);   // [64]
+  const int tid = threadIdx.x;
+  const long long row0 = (long long)blockIdx.x * 64;
+  const int nrows = n - row0 >= 64 ? 64 : (int)(n - row0);
   const int npairs = (d + 1) / 2;
-  const unsigned long long base = offset + (unsigned long long)p * (unsigned long long)(npairs + 2);
-  unsigned w0[4];
-  philox_block(seed, 6u, base, w0);
-  const unsigned which = below(w0[0], (unsigned)nlive);
-  unsigned w1[4];
-  philox_block(seed, 6u, base + 1, w1);
-  const double radial = u01(w0[2], w0[3]);
-  thin_u[p] = u01(w1[0], w1[1]);
-  double *row = t + p * d;
-  double norm2 = 0.0;
-  for (int j = 0; j < npairs; ++j) {
+  for (unsigned e = tid; e < (unsigned)(nrows * npairs); e += 256) {
+    const unsigned r = npairs == 1 ? e : __umulhi(e, pmagic), j = e - r * (unsigned)npairs;
+    const unsigned long long base = offset + (unsigned long long)(row0 + r) * (unsigned long long)(npairs + 2);
     unsigned r4[4];
     philox_block(seed, 6u, base + 2 + j, r4);
     const double rad = sqrt(-2.0 * log(u01(r4[0], r4[1])));
-    const double ang = 2.0 * M_PI * u01(r4[2], r4[3]);
-    const double g0 = rad * cos(ang), g1 = rad * sin(ang);
-    row[2 * j] = g0;
-    norm2 += g0 * g0;
-    if (2 * j + 1 < d) {
-      row[2 * j + 1] = g1;
-      norm2 += g1 * g1;
+    double sn, cs;
+    sincospi(2.0 * u01(r4[2], r4[3]), &sn, &cs);
+    zs[r * zs_stride + 2 * j] = rad * cs;
+    if ((int)(2 * j + 1) < d) zs[r * zs_stride + 2 * j + 1] = rad * sn;
+  }
+  __syncthreads();
+  {
+    const int r = tid >> 2, part = tid & 3;
+    double acc = 0.0;
+    if (r < nrows)
+      for (int k = part; k < d; k += 4) {
+        const double v = zs[r * zs_stride + k];
+        acc += v * v;
+      }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0 && r < nrows) {
+      const unsigned long long base = offset + (unsigned long long)(row0 + r) * (unsigned long long)(npairs + 2);
+      unsigned w0[4], w1[4];
+      philox_block(seed, 6u, base, w0);
+      philox_block(seed, 6u, base + 1, w1);
+      which[r] = below(w0[0], (unsigned)nlive);
+      const double radial = u01(w0[2], w0[3]);
+      thin_u[row0 + r] = u01(w1[0], w1[1]);
+      fac[r] = pow(radial, 1.0 / (double)d) / sqrt(acc) * sqrt(r2);
     }
   }
-  const double f = pow(radial, 1.0 / (double)d) / sqrt(norm2) * sqrt(r2);
-  const double *a = refR + (size_t)which * dp;
-  for (int k = 0; k < d; ++k) row[k] = a[k] + row[k] * f;
+  __syncthreads();
+  double *dst = t + row0 * d;
+  for (unsigned e = tid; e < (unsigned)(nrows * d); e += 256) {
+    const unsigned r = d == 1 ? e : __umulhi(e, dmagic), k = e - r * (unsigned)d;
+    dst[e] = refR[(size_t)which[r] * dp + k] + zs[r * zs_stride + k] * fac[r];
+  }
 }
 
 // keep a proposal with probability 1 / multiplicity (reference :1089: uniform(high=multiplicity) < 1)
@@ -457,6 +519,36 @@ hipError_t launch_generate_ellipsoid(double *w, long long n, int d, double enlar
   return hipGetLastError();
 }
 
+hipError_t launch_rows_affine(const double *t, long long n, int d, const double *A_padded, const double *ctr, const double *wrap_shift,
+                              double *w, uint8_t *in_cube, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (d < 1 || d > 128) return hipErrorInvalidValue;
+  const unsigned dmagic = d > 1 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u;
+  const size_t lds = (size_t)64 * (d + 1) * sizeof(double) + 64 * sizeof(unsigned);
+  const dim3 grid((unsigned)((n + 63) / 64));
+  static DeviceGrant grant;
+  if (hipError_t e = grant.ensure([] {
+        hipError_t rc = hipSuccess;
+#define MLF_RA(C)                                                                                                              \
+  if (rc == hipSuccess)                                                                                                        \
+    rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rows_affine<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+        MLF_RA(1) MLF_RA(2) MLF_RA(4) MLF_RA(8) MLF_RA(13) MLF_RA(16) MLF_RA(32)
+#undef MLF_RA
+        return rc;
+      }))
+    return e;
+  switch (generate_ellipsoid_chunk(d)) {
+#define MLF_RA(C)                                                                                                              \
+  case C:                                                                                                                      \
+    hipLaunchKernelGGL((k_rows_affine<C>), grid, dim3(256), lds, s, t, n, d, A_padded, ctr, wrap_shift, w, in_cube, dmagic);   \
+    break;
+    MLF_RA(1) MLF_RA(2) MLF_RA(4) MLF_RA(8) MLF_RA(13) MLF_RA(16) MLF_RA(32)
+#undef MLF_RA
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 void launch_center_and_cube(double *w, long long n, int d, const double *center, uint8_t *in_cube, hipStream_t s) {
   hipLaunchKernelGGL(k_center_and_cube, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n, d, center, in_cube);   // 4 waves x 64 rows
 }
@@ -470,8 +562,17 @@ void launch_generate_tbox(double *t, long long n, int d, const double *lo, const
 
 void launch_generate_around_points(double *t, double *thin_u, long long n, int d, const double *refR, int nlive, int dp,
                                    double r2, unsigned long long seed, unsigned long long offset, hipStream_t s) {
-  hipLaunchKernelGGL(k_generate_around_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t, thin_u, n, d, refR,
-                     nlive, dp, r2, seed, offset);
+  if (n <= 0) return;
+  const int npairs = (d + 1) / 2;
+  const unsigned pmagic = npairs > 1 ? (unsigned)((0x100000000ull + (unsigned)npairs - 1) / (unsigned)npairs) : 0u;
+  const unsigned dmagic = d > 1 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u;
+  const size_t lds = ((size_t)64 * (d + 1) + 64) * sizeof(double) + 64 * sizeof(unsigned);
+  static DeviceGrant grant;
+  (void)grant.ensure([] {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_generate_around_points), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+  });
+  hipLaunchKernelGGL(k_generate_around_points, dim3((unsigned)((n + 63) / 64)), dim3(256), lds, s, t, thin_u, n, d, refR,
+                     nlive, dp, r2, seed, offset, pmagic, dmagic);
 }
 
 void launch_thin_by_multiplicity(const long long *count, const double *thin_u, long long n, uint8_t *mask, hipStream_t s) {

@@ -14,6 +14,10 @@ void launch_generate_ball(double *z, long long n, int d, double enlarge, unsigne
 int generate_ellipsoid_chunk(int d);
 hipError_t launch_generate_ellipsoid(double *w, long long n, int d, double enlarge, const double *A_padded, const double *center,
                                      uint8_t *in_cube, unsigned long long seed, unsigned long long offset, hipStream_t s);
+// AffineLayer.untransform of whole batches: w = t . M + ctr (M padded like A_padded above), circular axes rotated back where
+// wrap_shift (NaN = not circular) is given, in_cube[p] = all coordinates strictly inside (0, 1).  d <= 128.
+hipError_t launch_rows_affine(const double *t, long long n, int d, const double *M_padded, const double *ctr, const double *wrap_shift,
+                              double *w, uint8_t *in_cube, hipStream_t s);
 void launch_center_and_cube(double *w, long long n, int d, const double *center, uint8_t *in_cube, hipStream_t s);
 void launch_generate_tbox(double *t, long long n, int d, const double *lo, const double *hi, double pad,
                           unsigned long long seed, unsigned long long offset, hipStream_t s);
