@@ -262,3 +262,51 @@ def test_fully_resident_nested_sampling_run():
     res = s.run(dlogz=0.1)
     assert abs(res["logz"]) < 4 * res["logzerr"] + 0.15, res
     assert res["ncall"] > 5000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [2, 3])
+def test_tspace_sampling_with_a_circular_axis(method):
+    """Methods 2 and 3 on a layer with a circular parameter (AffineLayer.unwrap, mlfriends.pyx:538-545, inside untransform :745-752):
+    the live points straddle the 0 / 1 border of axis 0; the device's accepted points are the host pipeline's on the restated draws."""
+    import ultranest_amd.mlfriends as m
+    from ultranest_amd import kernels
+    from ultranest_amd.regions import DeviceRNG
+    rng = np.random.RandomState(58)
+    n, d = 500, 5
+    u = 0.5 + 0.08 * rng.normal(size=(n, d))
+    u[:, 0] = (0.98 + 0.05 * rng.normal(size=n)) % 1.0
+    u = u[np.logical_and(u > 0, u < 1).all(axis=1)]
+    layer = m.AffineLayer(wrapped_dims=[0])
+    layer.optimize(u, u)
+    region = m.MLFriends(u, layer)
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=10, rng=rng)
+    region.create_ellipsoid()
+    assert (u[:, 0] < 0.2).any() and (u[:, 0] > 0.8).any()
+    nsamples = 60000
+    region.device_rng = DeviceRNG(9)
+    if method == 2:
+        got = region.sample_from_transformed_boundingbox(nsamples)
+        tpts, nxt = philox.tbox_points(9, 0, nsamples, d, region.bbox_lo, region.bbox_hi, region.maxradiussq**0.5)
+        assert region.device_rng.offset == nxt
+        region.device_rng = None
+        cand = tpts[region._near_live_points(tpts)]
+    else:
+        got = region.sample_from_points(nsamples)
+        tpts, thin, which, nxt = philox.around_points(9, 0, nsamples, d, region.unormed, region.maxradiussq)
+        assert region.device_rng.offset == nxt
+        region.device_rng = None
+        mult = np.empty(nsamples, dtype=np.int64)
+        kernels.count_nearby(region.unormed, tpts, region.maxradiussq, mult)
+        cand = tpts[thin * mult < 1]
+    w = region.transformLayer.untransform(cand)
+    ok = np.logical_and(w > 0, w < 1).all(axis=1)
+    ok[ok] = region.inside_ellipsoid(w[ok])
+    want = w[ok]
+    assert len(want) > 200 and (want[:, 0] < 0.2).any() and (want[:, 0] > 0.8).any()       # both sides of the cut are populated
+    assert abs(len(got) - len(want)) <= max(3, len(want) // 500)
+    if len(got) == len(want):
+        assert np.allclose(got, want, rtol=0, atol=1e-12)
+    # a proposal whose wrapped coordinate lies outside [0, 1) comes back from unwrap -> wrap on the other side of the cut: the
+    # reference's pipeline accepts it here and `inside` places it elsewhere (0.15 % of the points of this region; host and device alike)
+    assert region.inside(got).mean() > 0.99
