@@ -23,7 +23,7 @@ cd $R
 python scripts/collect_pmc.py $O/$P profiles/r06 > $O/${P}_collect.log 2>&1; tail -3 $O/${P}_collect.log | cut -c1-200
 cp profiles/pmc_scan_traffic.json profiles/r06_pmc_summary.json $O/ 2>/dev/null
 for f in sq wait FETCH_SIZE WRITE_SIZE; do cp $O/${P}_pmc_$f.txt $O/r06_pmc_$f.txt; done
-echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -x -q > $O/r06_pytest_gpu.log 2>&1; grep -n "passed\|failed\|Error" $O/r06_pytest_gpu.log | tail -5; grep -B5 -A25 "^E " $O/r06_pytest_gpu.log | head -50
+echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q > $O/r06_pytest_gpu.log 2>&1; grep -n "passed\|failed\|Error" $O/r06_pytest_gpu.log | tail -5; grep -B5 -A25 "^E " $O/r06_pytest_gpu.log | head -50
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/r06_smoke.log 2>&1; tail -2 $O/r06_smoke.log
 echo "== bench"; timeout 600 python bench.py --steps 20 --warmup 5 > $O/r06_bench.json 2> $O/r06_bench.err; python - <<'PY'
 import json
@@ -51,7 +51,7 @@ echo "== f1 / f2 benches"
 timeout 200 python scripts/walk_rounds_profile.py 1500 > $O/r06_walk_rounds.json 2> $O/r06_walk_rounds.err; cat $O/r06_walk_rounds.json
 timeout 300 python scripts/walk_bench.py > $O/r06_walk_bench.json 2> $O/r06_walk_bench.err; tail -c 600 $O/r06_walk_bench.json
 timeout 300 python scripts/sample_bench.py > $O/r06_sample_bench.json 2> $O/r06_sample_bench.err; tail -c 700 $O/r06_sample_bench.json
-timeout 200 python scripts/refill_profile.py 10 > $O/r06_refill.json 2> $O/r06_refill.err; cat $O/r06_refill.json
+timeout 200 python scripts/refill_profile.py 10 --all > $O/r06_refill.json 2> $O/r06_refill.err; cat $O/r06_refill.json
 echo "== 8 ranks on this box's single device over gloo (rehearsal of the driver's multi-GPU pass)"
 timeout 600 python bench.py --gpus 8 --scaling strong --steps 5 --warmup 2 --no-cpu > $O/r06_bench_8rank_selfspawn_gloo.json 2> $O/r06_bench_8rank.err; python - <<'PY'
 import json
