@@ -267,7 +267,9 @@ def step_roofline(handle, stats, kdim, ntiles32, filter_launches, launch_ms_list
 
     launches = []
     # k_prep_sweep<DP, waves per workgroup>: 4 (two workgroups per CU) up to d = 50 by default, else 8 ("fused_waves")
-    fused_name = "k_prep_sweep<%d, %d>" % (NDIM, 4 if (handle.get_option("fused_waves") == 4 and NDIM <= 50) else 8)
+    # ..., same quadratic form>: the ellipsoid form read off the whitening chain (this workload: AffineLayer, one cluster)
+    fused_name = "k_prep_sweep<%d, %d%s>" % (NDIM, 4 if (handle.get_option("fused_waves") == 4 and NDIM <= 50) else 8,
+                                            ", true" if stats.get("same_quadratic_form") else "")
     if per_step in (3, 4) and cut and len(by_phase) == per_step:
         # min-only sweep (mlf_sweepmin.hip): first range over every group, the later ones over the groups left after the
         # compaction in front of them, then the uncertain proposals (sets of 4 groups) once more over all tiles

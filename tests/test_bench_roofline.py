@@ -40,6 +40,10 @@ def test_step_roofline_reproduces_the_hand_computation():
     assert abs(r["step"]["mfma_frac_of_2500"] - 0.30) < 0.005 and abs(r["step"]["counter_bytes_over_algorithmic"] - 1.82) < 0.01
     assert 17.0 < r["fp64_valu_roofline_of_survey_8d"]["ratio_to_that_peak"] < 17.8
     assert len(r["launches"]) == 4 and abs(sum(e["share_of_step_time"] for e in r["launches"]) - sum(per_launch) / step_ms) < 1e-12
+    # the first launch with the ellipsoid form read off the whitening chain: 24 instead of 42 matrix instructions per group
+    r3 = bench.step_roofline(_Handle(), dict(stats, same_quadratic_form=1), 64, 125, (80, sum(per_launch) * 20), launch_ms, 20, True,
+                             step_ms, 0.41, alg, pmc, hbm, 2.63e11)
+    assert r3["kernel"] == "k_prep_sweep<50, 8, true>" and r3["launches"][0]["executed_mfma"] == 31250 * 24 + 31250 * 18 * 4
     pmc["fresh"] = True
     r2 = bench.step_roofline(_Handle(), stats, 64, 125, (80, 1.0), launch_ms, 20, True, step_ms, 0.41, alg, pmc, hbm, None)
     assert r2["traffic"] == 493616128.0 and r2["fp64_valu_roofline_of_survey_8d"] is None
