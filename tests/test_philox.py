@@ -310,3 +310,39 @@ def test_tspace_sampling_with_a_circular_axis(method):
     # a proposal whose wrapped coordinate lies outside [0, 1) comes back from unwrap -> wrap on the other side of the cut: the
     # reference's pipeline accepts it here and `inside` places it elsewhere (0.15 % of the points of this region; host and device alike)
     assert region.inside(got).mean() > 0.99
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [4, 50])
+def test_ellipsoid_sampling_with_the_cube_test_inside_the_fused_first_launch(d):
+    """Large batches of method 1 take the phased routing, whose first launch (k_prep_sweep) honours the cube test itself (the
+    pre-gate arrives in the gate array); forced here at a small size.  The live points sit near a corner, so that a good part of
+    the ellipsoid lies outside the cube.  Same accepted points as the routing with a separate per-proposal stage."""
+    import ultranest_amd.mlfriends as m
+    from ultranest_amd import _lib
+    from ultranest_amd.regions import DeviceRNG
+    rng = np.random.RandomState(400 + d)
+    u = 0.93 + 0.03 * rng.normal(size=(600, d))
+    u = u[np.logical_and(u > 0, u < 1).all(axis=1)]
+    layer = m.AffineLayer()
+    layer.optimize(u, u)
+    region = m.MLFriends(u, layer)
+    region.maxradiussq, region.enlarge = region.compute_enlargement(nbootstraps=10, rng=rng)
+    region.create_ellipsoid()
+    nsamples = 50000
+    got = {}
+    try:
+        for phase_min in (32768, 64):
+            _lib.set_option("filter_phase_min_queries", phase_min)
+            region.device_rng = DeviceRNG(77)
+            got[phase_min] = region.sample_from_wrapping_ellipsoid(nsamples)
+            if phase_min == 64:
+                assert region._dev.handle.debug_stats()["range_cuts"][0] > 0       # the phased routing ran
+    finally:
+        _lib.set_option("filter_phase_min_queries", 32768)
+    z, _ = philox.ball_points(77, 0, nsamples, d, region.enlarge)
+    w = region.ellipsoid_center + np.dot(z, region.ellipsoid_axes_T)
+    in_cube = np.logical_and(w > 0, w < 1).all(axis=1)
+    assert 0.02 < in_cube.mean() < 0.98, in_cube.mean()                            # the cube test decides a good share
+    assert len(got[64]) > 20 and np.array_equal(got[64], got[32768])
+    assert np.logical_and(got[64] > 0, got[64] < 1).all()

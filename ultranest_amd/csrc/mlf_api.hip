@@ -439,6 +439,7 @@ struct ExactSrc {
   const double *T64;  // the same as 64 x 64, zero padded (d <= 64)
   const Prep4Args *prep;   // not null: the per-proposal stage has NOT run yet -- the min-only path runs it inside its first launch
   const Prep4Consts *same; // not null: constants of the "same quadratic form" variant of that launch (region_prep4_setup)
+  bool pregated;           // the gate array holds a pre-gate on entry (device-side sampling: the cube test) for that launch to honour
 };
 
 // does a batch of nq queries take the min-only path?  (the phase rule of filter_run)
@@ -633,6 +634,7 @@ int filter_run(FilterCtx &f, const double *refT, const double *refR, int n, int 
       else
         fu.variant &= ~2u;
       f.last_same_form = (fu.variant & 2u) != 0u;
+      if (xs->pregated) fu.variant |= 4u;
       const int fused_waves = (int)opt(f, OPT_FUSED_WAVES);
       if (int rc = timed([&] { return launch_prep_sweep(fu, s, fused_waves); })) return rc;
     } else if (int rc = timed([&] { return launch_sweep_min(f.ks, filter_groups_per_wave(f.ks, 0), m, s); })) return rc;
@@ -1354,13 +1356,18 @@ int region_inside_enqueue(mlf_region *r, const double *d_pts, size_t np, uint8_t
       xsrc.T64 = r->lay_T64.as<double>();
     }
     // large batches on the min-only path: the per-proposal stage runs inside the first sweep launch (mlf_fused.hip)
-    const bool defer_prep = r->use_scan && use_filter && !pregate && !d_idx && opt(f, OPT_FUSED_FIRST) && fused_usable(r->dp) &&
+    const bool defer_prep = r->use_scan && use_filter && !d_idx && opt(f, OPT_FUSED_FIRST) && fused_usable(r->dp) &&
                             filter_takes_min_path(f, (long long)np);
     static thread_local Prep4Args deferred;
     static thread_local Prep4Consts deferred_same;
     if (defer_prep) {
       deferred = pa;
       xsrc.prep = &deferred;
+      if (pregate) {   // the fused first launch reads the pre-gate out of the gate array and writes its own verdict over it
+        CK(hipMemcpyAsync(gate, pregate, np, hipMemcpyDeviceToDevice, s));
+        xsrc.pregated = true;
+        pregate = nullptr;   // honoured there: no k_apply_pregate, and the ellipsoid band rides in the re-check launch as usual
+      }
       if (r->same_matrix && r->same_centres) {
         deferred_same = r->p4c_same;
         deferred_same.enl_lo = pa.c.enl_lo;
@@ -2730,9 +2737,10 @@ int region_sample_tspace(mlf_region *r, int method, long long n, uint64_t seed, 
     CK(r->s_wc.reserve((size_t)k0 * d * sizeof(double)));
     CK(r->s_thc.reserve((size_t)k0 * sizeof(double)));
     CK(r->s_count.reserve((size_t)k0 * sizeof(long long)));
-    launch_compact(t, r->s_gate.as<uint8_t>(), n, d, r->blk.as<unsigned>(), r->s_tc.as<double>(), k0, s);
-    launch_compact(wall, r->s_gate.as<uint8_t>(), n, d, r->blk.as<unsigned>(), r->s_wc.as<double>(), k0, s);
-    launch_compact(r->s_thin.as<double>(), r->s_gate.as<uint8_t>(), n, 1, r->blk.as<unsigned>(), r->s_thc.as<double>(), k0, s);
+    // (the offsets of this mask are in blk already: launch_mask_offsets above)
+    launch_scatter(t, r->s_gate.as<uint8_t>(), n, d, r->blk.as<unsigned>(), r->s_tc.as<double>(), k0, s);
+    launch_scatter(wall, r->s_gate.as<uint8_t>(), n, d, r->blk.as<unsigned>(), r->s_wc.as<double>(), k0, s);
+    launch_scatter(r->s_thin.as<double>(), r->s_gate.as<uint8_t>(), n, 1, r->blk.as<unsigned>(), r->s_thc.as<double>(), k0, s);
     ScanArgs a{};   // multiplicity: how many balls contain the proposal (no early exit, reference :1087-1088)
     a.refT = r->refT.as<double>();
     a.n = r->n;
@@ -2938,9 +2946,10 @@ int mlf_region_refill(mlf_region *r, int method, size_t nsamples, uint64_t seed,
   launch_mask_greater(r->rf_L.as<double>(), n, Lmin, keep, s, member);
   const unsigned cap = capacity > 0xffffffffu ? 0xffffffffu : (unsigned)capacity;
   double *ou = r->rf_out.as<double>(), *op = ou + capacity * (size_t)d, *oL = op + capacity * (size_t)d;
-  launch_compact(rows, keep, n, d, r->blk.as<unsigned>(), ou, cap, s);
-  launch_compact(prow, keep, n, d, r->blk.as<unsigned>(), op, cap, s);
-  launch_compact(r->rf_L.as<double>(), keep, n, 1, r->blk.as<unsigned>(), oL, cap, s);
+  launch_mask_offsets(keep, n, r->blk.as<unsigned>(), s);   // one count + scan for the three arrays
+  launch_scatter(rows, keep, n, d, r->blk.as<unsigned>(), ou, cap, s);
+  launch_scatter(prow, keep, n, d, r->blk.as<unsigned>(), op, cap, s);
+  launch_scatter(r->rf_L.as<double>(), keep, n, 1, r->blk.as<unsigned>(), oL, cap, s);
   CK(hipGetLastError());
   unsigned count = 0;
   CK(hipMemcpyAsync(&count, r->blk.as<unsigned>() + nblk, sizeof count, hipMemcpyDeviceToHost, s));

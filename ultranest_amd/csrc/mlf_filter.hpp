@@ -155,7 +155,9 @@ struct FusedArgs {
   unsigned ccap;
   unsigned long long *stamps;   // optional diagnostics: 16 shader-clock stamps of wave 0 of workgroup `stamp_block`
   unsigned stamp_block;
-  unsigned variant;             // "fused_variant" option: bit 0 matrix fragments by LDS-DMA (default) / by a load-store loop
+  unsigned variant;             // "fused_variant" option: bit 0 matrix fragments by LDS-DMA (default) / by a load-store loop; bit 1 same
+                                // quadratic form (the caller put that form's constants into p.c); bit 2 (set by the caller, not an
+                                // option): p.gate[] holds a pre-gate on entry, 0 = outside whatever the ellipsoid test says
 };
 bool fused_usable(int dp);
 hipError_t launch_prep_sweep(const FusedArgs &a, hipStream_t s, int waves = 8);

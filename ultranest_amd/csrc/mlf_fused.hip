@@ -357,6 +357,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
     if (grp < ngroups) {   // wave-uniform
       const long long p = grp * 32 + p32;
       const bool live = p < np;
+      // variant bit 2: gate[] arrives holding a pre-gate (device-side sampling: "inside the unit cube") -- a proposal that failed
+      // it is outside for certain, whatever the ellipsoid says; asked for here, needed after the chains
+      unsigned char pre = 1;
+      if ((a.variant & 4u) && live) pre = a.p.gate[p];
       float qs = 0.0f;
       float16v tt[NT];
       float cs[NT][16];
@@ -436,8 +440,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_prep_sweep(FusedAr
         const float qhi = ((hi * hi) * up + eps) * up;
         const float lo = (sq * dn - eta) * dn;
         const float qlo = ((lo * lo) * dn - eps * up) * dn;
-        sure_in = finite && qhi < a.p.c.enl_lo;
-        sure_out = finite && lo > 0.0f && qlo > a.p.c.enl_hi;
+        sure_in = finite && qhi < a.p.c.enl_lo && pre != 0;
+        sure_out = (finite && lo > 0.0f && qlo > a.p.c.enl_hi) || pre == 0;
       }
       const bool band = live && !sure_in && !sure_out;
       const bool ins_any = live && !sure_out;

@@ -621,9 +621,14 @@ void launch_mask_offsets(const uint8_t *mask, long long n, unsigned *blk, hipStr
 
 void launch_compact(const double *pts, const uint8_t *mask, long long n, int d, unsigned *blk, double *out,
                     unsigned capacity, hipStream_t s) {
+  launch_mask_offsets(mask, n, blk, s);
+  launch_scatter(pts, mask, n, d, blk, out, capacity, s);
+}
+
+// the scatter alone: blk holds the offsets of THIS mask (launch_mask_offsets); several arrays compacted by one mask share them
+void launch_scatter(const double *pts, const uint8_t *mask, long long n, int d, const unsigned *blk, double *out,
+                    unsigned capacity, hipStream_t s) {
   const int nblk = (int)((n + 255) / 256);
-  hipLaunchKernelGGL(k_count_accepted, dim3(nblk), dim3(256), 0, s, mask, n, blk);
-  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, blk, nblk);
   const unsigned dmagic = d > 1 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u;
   if (d == 1)
     hipLaunchKernelGGL(k_scatter_scalars, dim3(nblk), dim3(256), 0, s, pts, mask, n, blk, out, capacity);

@@ -37,5 +37,8 @@ void launch_mask_offsets(const uint8_t *mask, long long n, unsigned *blk, hipStr
 // blk: (ceil(n/256) + 1) counters; after the call blk[ceil(n/256)] holds the number of accepted rows
 void launch_compact(const double *pts, const uint8_t *mask, long long n, int d, unsigned *blk, double *out,
                     unsigned capacity, hipStream_t s);
+// the scatter of launch_compact alone, on offsets that launch_mask_offsets computed for the same mask
+void launch_scatter(const double *pts, const uint8_t *mask, long long n, int d, const unsigned *blk, double *out,
+                    unsigned capacity, hipStream_t s);
 
 }  // namespace mlf
