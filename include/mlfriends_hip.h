@@ -277,7 +277,9 @@ int mlf_loglike_dev(int kind, const double *d_params, size_t d, size_t n, const 
  * (sample_from_transformed_boundingbox :1114-1133), 3 = around random live points, thinned by the
  * number of balls containing the draw (sample_from_points :1072-1094); both are untransformed with
  * invT (AffineLayer.untransform :745-752), cube- and ellipsoid-tested.  mlf_region_set_sampling_data
- * provides invT (d x d) and bbox_lo / bbox_hi (reference :983-984). */
+ * provides invT (d x d) and bbox_lo / bbox_hi (reference :983-984).  Method 3 applies the cube and ellipsoid tests BEFORE it
+ * counts the balls (each test is a function of the draw alone, the thinning uniform included: the accepted set is the
+ * reference order's), so that the exact count runs on the survivors only. */
 int mlf_region_set_axes(mlf_region *r, const double *axes_T);
 int mlf_region_set_sampling_data(mlf_region *r, const double *invT, const double *bbox_lo, const double *bbox_hi);
 int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset,
@@ -285,7 +287,9 @@ int mlf_region_sample(mlf_region *r, int method, size_t nsamples, uint64_t seed,
 /* One proposal batch of the driver's _refill_samples (integrator.py:1773-1837) without leaving the
  * device: mlf_region_sample's accepted points -> prior transform (tkind 0 identity, 1 x*a+b,
  * 2 (x*a)*b) -> likelihood (kind as in mlf_loglike_dev) -> only the points with L > Lmin are copied
- * back (u, p, L; at most `capacity`).  nevaluated = region-accepted proposals = likelihood evaluations. */
+ * back (u, p, L; at most `capacity`).  nevaluated = region-accepted proposals = the likelihood evaluations the reference would
+ * make (methods 0 and 1 evaluate the batch where it was drawn, under the membership mask, when at least a quarter of it was
+ * accepted: a rejected row then costs a discarded evaluation instead of a copy of the accepted ones). */
 int mlf_region_refill(mlf_region *r, int method, size_t nsamples, uint64_t seed, uint64_t offset,
                       double Lmin, int tkind, double ta, double tb, int lkind, const double *aux,
                       double sigma, double *out_u, double *out_p, double *out_L, size_t capacity,
