@@ -62,5 +62,5 @@ except Exception as e:
     print("8-rank:", e)
 PY
 tail -3 $O/r06_bench_8rank.err | cut -c1-300
-echo "== soak"; SOAK_A="601 602 603 604" SOAK_B="61" bash scripts/gpu_soak.sh 2>&1 | tail -6; cp $O/soak.log $O/r06_soak.log
+echo "== soak"; SOAK_A="701 702 703 704" SOAK_B="71" bash scripts/gpu_soak.sh 2>&1 | tail -6; cp $O/soak.log $O/r06_soak.log
 find $O -name "*.csv" -size +4M -delete
