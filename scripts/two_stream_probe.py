@@ -65,5 +65,28 @@ for n in (2, 4, 8):
     out["two_streams_%d_chunks_ms" % n] = timed(split(n))
     out["equal_%d" % n] = bool((mask == ref).all().item())
     out["one_stream_%d_chunks_ms" % n] = timed(serial(n))
+# WHOLE batches alternating between two handles on two streams: the tail of one batch (k_uncertain: a latency chain on 181 of 256
+# CUs, k_scan tail) under the first launch of the next.  ms per BATCH.
+pts_b = bench.proposals_in_ellipsoid(region, P, 2000, dev)
+mask_b = torch.empty(P, dtype=torch.uint8, device=dev)
+ref_b = torch.empty(P, dtype=torch.uint8, device=dev)
+h0.inside_dev(pts_b.data_ptr(), P, ref_b.data_ptr(), cur)
+torch.cuda.synchronize()
+
+
+def alternate():
+    h0.inside_dev(pts.data_ptr(), P, mask.data_ptr(), s0.cuda_stream)
+    h1.inside_dev(pts_b.data_ptr(), P, mask_b.data_ptr(), s1.cuda_stream)
+
+
+def back_to_back():
+    h0.inside_dev(pts.data_ptr(), P, mask.data_ptr(), cur)
+    h0.inside_dev(pts_b.data_ptr(), P, mask_b.data_ptr(), cur)
+
+
+out["two_batches_one_stream_ms_per_batch"] = timed(back_to_back) / 2
+out["two_batches_two_streams_ms_per_batch"] = timed(alternate) / 2
+out["alternate_equal"] = bool((mask == ref).all().item() and (mask_b == ref_b).all().item())
+out["two_batches_one_stream_again_ms_per_batch"] = timed(back_to_back) / 2
 out["one_stream_again_ms"] = timed(one)
 print(json.dumps(out))
