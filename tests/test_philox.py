@@ -92,9 +92,9 @@ def test_cube_sampling_is_the_host_pipeline_on_the_philox_batch(kind, d):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["MLFriends", "RobustEllipsoidRegion"])
-@pytest.mark.parametrize("d", [2, 3, 8, 50])
+@pytest.mark.parametrize("d", [2, 3, 8, 50, 100])
 def test_ellipsoid_sampling_matches_restatement_and_region(kind, d):
-    region, DeviceRNG = _region(kind, 400, d, 100 + d)
+    region, DeviceRNG = _region(kind, 400 if d <= 50 else 1200, d, 100 + d)   # (d = 100: 32 outputs per wave, 52 KiB of LDS per workgroup)
     nsamples = 30000
     region.device_rng = DeviceRNG(17)
     got = region.sample_from_wrapping_ellipsoid(nsamples)
@@ -159,7 +159,7 @@ def test_sampler_with_device_rng_recovers_gaussian_evidence():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("d", [2, 7, 30])
+@pytest.mark.parametrize("d", [2, 7, 30, 70])
 def test_transformed_boundingbox_sampling_matches_restatement(d):
     """method 2: the restated Philox batch in whitened space pushed through the host pipeline of the
     reference (neighbour test, untransform, cube, ellipsoid) gives the device's accepted points."""
